@@ -1,0 +1,193 @@
+/* tracehip.h — C ABI of libtracehip.so, the MI355X (gfx950) wavefront ray/path-tracing engine behind Trace.jl's
+ * Integrator / Sampler / Film surface.
+ *
+ * The reference (pxl-th/Trace.jl @ 2024_10_08) has no FFI layer: its "operator API" is Julia dispatch on a handful of
+ * types.  Each entry point below names the reference interface (file:line under /root/reference/src)
+ * it replaces.  A Julia shim (trace.jl_amd/julia/TraceHIP.jl) `ccall`s these after walking
+ * Scene -> BVHAccel -> GeometricPrimitive; the tested host in this repo is the Python mirror in trace.jl_amd/.
+ *
+ * Conventions: every function returns 0 on success and a negative trhip_status on failure; the message is available
+ * from trhip_last_error().  Nothing throws across the boundary.  Host pointers are caller-owned and only borrowed for
+ * the duration of the call.  Calls are blocking (internal HIP streams are synchronised before returning).  One
+ * trhip_ctx owns one GPU; use one process per GPU (multi-GPU film reduction is done by the host over RCCL).
+ * Matrices are 16 floats, row-major: m[4*row + col] (Julia's Mat4f is column-major: pass transpose / permutedims).
+ * All arithmetic is IEEE Float32 without FMA contraction; transcendental functions and the sampler are the ones
+ * specified in trace_detmath.h / trace_sampler.h, so results are reproducible bit-for-bit on any conforming host.
+ */
+#ifndef TRACEHIP_H
+#define TRACEHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct trhip_ctx trhip_ctx;
+typedef struct trhip_scene trhip_scene;
+
+typedef enum {
+    TRHIP_OK = 0,
+    TRHIP_ERR_INVALID = -1,    /* bad argument / call order */
+    TRHIP_ERR_HIP = -2,        /* HIP runtime error (no device, out of memory, launch failure) */
+    TRHIP_ERR_UNSUPPORTED = -3 /* feature of the reference that this build does not accelerate */
+} trhip_status;
+
+/* ---- context ------------------------------------------------------------------------------------------------------- */
+/* Fails (TRHIP_ERR_HIP) when no gfx950 device is visible: there is no CPU fallback. */
+int trhip_init(trhip_ctx** ctx, int device_id);
+void trhip_shutdown(trhip_ctx* ctx);
+/* ctx may be NULL to read the message of a failed trhip_init. */
+const char* trhip_last_error(const trhip_ctx* ctx);
+/* ABI version of this header: major*1000 + minor. */
+int trhip_version(void);
+
+/* ---- scene flattening (replaces the Scene / BVHAccel / GeometricPrimitive object graph) --------------------------- */
+/* Scene(lights, aggregate)  Trace.jl:176-187 */
+int trhip_scene_new(trhip_ctx* ctx, trhip_scene** out);
+void trhip_scene_free(trhip_scene* scene);
+
+/* Materials with ConstantTexture arguments (textures/basic.jl:4-10), materials/material.jl:
+ *   TRHIP_MATTE   (:1-31)    params = Kd.rgb, sigma                                           (4)
+ *   TRHIP_MIRROR  (:34-46)   params = Kr.rgb                                                  (3)
+ *   TRHIP_GLASS   (:49-116)  params = Kr.rgb, Kt.rgb, u_roughness, v_roughness, index, remap  (10)
+ *   TRHIP_PLASTIC (:119-151) params = Kd.rgb, Ks.rgb, roughness, remap                        (8) */
+enum { TRHIP_MATTE = 0, TRHIP_MIRROR = 1, TRHIP_GLASS = 2, TRHIP_PLASTIC = 3 };
+int trhip_scene_add_material(trhip_scene* scene, int kind, const float* params, int n_params, uint32_t* id_out);
+
+/* create_triangle_mesh + one GeometricPrimitive per triangle  (shapes/triangle_mesh.jl:45-58, primitive.jl:5-9).
+ * world_xyz: vertices already moved to world space by the host exactly as TriangleMesh does (triangle_mesh.jl:23);
+ * normals are passed untransformed (triangle_mesh.jl:23-28) or NULL; indices are 1-based as in the reference;
+ * flip_orientation = reverse_orientation XOR transform_swaps_handedness of the ShapeCore (shapes/Shape.jl:7-14);
+ * material_id_per_tri may be NULL only for geometry-only scenes (kernel-level trace entry points).
+ * first_prim_out receives the index of the first created primitive in caller order. */
+int trhip_scene_add_triangles(trhip_scene* scene, const float* world_xyz, uint32_t n_verts, const uint32_t* indices_1based, uint32_t n_tris,
+                              const float* normals_or_null, const uint32_t* material_id_per_tri, int flip_orientation, uint32_t* first_prim_out);
+
+/* Sphere(core, radius, z_min, z_max, ϕ_max°) + GeometricPrimitive  (shapes/sphere.jl:1-30).  Both matrices of
+ * core.object_to_world (m and inv_m, transformations.jl:1-4) are passed because the reference keeps them separately
+ * (and multiplies inverses in a non-standard order, transformations.jl:20-22). */
+int trhip_scene_add_sphere(trhip_scene* scene, const float obj2world_m[16], const float obj2world_inv_m[16], int reverse_orientation, float radius,
+                           float z_min, float z_max, float phi_max_deg, uint32_t material_id, uint32_t* prim_out);
+
+/* PointLight(light_to_world, I)  lights/point.jl:19-24 ;  SpotLight(light_to_world, I, total°, falloff_start°)  lights/spot.jl:10-19 */
+int trhip_scene_add_point_light(trhip_scene* scene, const float light2world_m[16], const float light2world_inv_m[16], const float I[3]);
+int trhip_scene_add_spot_light(trhip_scene* scene, const float light2world_m[16], const float light2world_inv_m[16], const float I[3],
+                               float total_width_deg, float falloff_start_deg);
+
+/* BVHAccel(primitives, max_node_primitives)  accel/bvh.jl:55-79.  Builds a binned-SAH BVH2 on the host (results of
+ * traversal do not depend on the topology except for exact-t ties), flattens it in the reference's
+ * depth-first layout (first child = i+1, bvh.jl:187-206) and uploads everything to HBM. */
+int trhip_scene_commit(trhip_scene* scene, int max_node_primitives);
+
+/* Inspection of the committed BVH (tests feed the same topology to the CPU oracle so that parity is bit-exact).
+ * node_bounds: n_nodes*6 (min xyz, max xyz).  Leaf: (flags & 3) == 3, a = first ordered-primitive slot, n = flags >> 2.
+ * Interior: a = index of the second child, flags & 3 = split axis (0..2), first child = i + 1.
+ * prim_order[slot] = caller primitive index.  Any output pointer may be NULL. */
+int trhip_scene_bvh_size(const trhip_scene* scene, uint32_t* n_nodes, uint32_t* n_prims);
+int trhip_scene_get_bvh(const trhip_scene* scene, float* node_bounds, uint32_t* node_a, uint32_t* node_flags, uint32_t* prim_order);
+/* Replace the BVH by a caller-supplied one in the same layout (e.g. the reference's own builder run elsewhere). */
+int trhip_scene_set_bvh(trhip_scene* scene, const float* node_bounds, const uint32_t* node_a, const uint32_t* node_flags, uint32_t n_nodes,
+                        const uint32_t* prim_order, uint32_t n_prims);
+
+/* ---- sensor: PerspectiveCamera + Film + filter (camera/perspective.jl:58-80, film.jl:34-61, filter.jl) ------------- */
+typedef struct {
+    float raster_to_camera[16]; /* camera.core.raster_to_camera.m — composed by the host constructors, bugs included (A.3, A.4) */
+    float camera_to_world[16];  /* camera.core.core.camera_to_world.m */
+    float lens_radius, focal_distance, shutter_open, shutter_close;
+    float crop_min[2], crop_max[2]; /* Film.crop_bounds: 1-based inclusive pixel bounds (film.jl:41-44) */
+    float filter_radius[2];         /* Film.filter.radius */
+    float filter_table[256];        /* Film.filter_table, (y, x) order: table[16*y + x] (film.jl:38-40, 55-59) */
+    float scale;                    /* Film.scale */
+} trhip_sensor;
+
+typedef struct {
+    uint64_t camera_samples; /* camera samples completed */
+    uint64_t closest_rays;   /* closest-hit rays traced, all bounces */
+    uint64_t shadow_rays;    /* any-hit (shadow) rays traced, all bounces */
+    uint64_t nodes_visited;  /* filled only when instrumentation is on (trhip_set_option "count_visits") */
+    uint64_t prims_tested;
+    uint64_t nodes_visited_shadow;
+    uint64_t prims_tested_shadow;
+    double ms_total;         /* wall time of the render call's device work (HIP events) */
+    double ms_raygen, ms_trace_closest, ms_shade, ms_trace_any, ms_film;
+    uint32_t launches_raygen, launches_trace_closest, launches_shade, launches_trace_any, launches_film;
+    uint32_t n_batches, max_depth_reached;
+} trhip_stats;
+
+/* ---- integrators (replace `integrator(scene)`, integrators/sampler.jl:12-56) ---------------------------------------
+ * out_xyzw: (crop height) * (crop width) * 4 floats in film.pixels (y, x) order = Pixel.xyz sums + filter_weight_sum
+ * (film.jl:7-11), i.e. exactly the state `save(film)` (film.jl:204-222) starts from.  NaN radiance samples are zeroed
+ * (integrators/sampler.jl:46).  The sampler is the seeded counter-based sampler of trace_sampler.h with
+ * `samples_per_pixel = spp`; `sample_offset` shifts the global sample indices (rank r of an N-GPU job renders indices
+ * [r*spp, (r+1)*spp) and the host sum-reduces the films).
+ * The *_device variants write to a DEVICE pointer (e.g. a torch tensor's data_ptr) instead of host memory. */
+int trhip_render_whitted(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sensor* sensor, uint32_t spp, int max_depth, uint64_t seed,
+                         uint32_t sample_offset, float* out_xyzw, trhip_stats* stats);
+/* PathIntegrator: not in the reference; defined in DESIGN.md from integrators/sppm.jl:208-266, 503-554. */
+int trhip_render_path(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sensor* sensor, uint32_t spp, int max_depth, uint64_t seed,
+                      uint32_t sample_offset, float* out_xyzw, trhip_stats* stats);
+int trhip_render_path_device(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sensor* sensor, uint32_t spp, int max_depth, uint64_t seed,
+                             uint32_t sample_offset, void* d_out_xyzw, trhip_stats* stats);
+int trhip_render_whitted_device(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sensor* sensor, uint32_t spp, int max_depth, uint64_t seed,
+                                uint32_t sample_offset, void* d_out_xyzw, trhip_stats* stats);
+/* Per-sample radiance of the last render call (after the NaN rule), n_sample_pixels * spp * 3 floats indexed
+ * [(s * n_sample_pixels + (y - sb.min.y) * sb_width + (x - sb.min.x)) * 3 + c]; sample bounds sb = get_sample_bounds(film)
+ * (film.jl:68-73).  Parity tests compare this with the oracle bit-for-bit. */
+int trhip_last_sample_radiance(trhip_ctx* ctx, float* out_rgb, uint64_t n_floats);
+
+/* save(film) minus the PNG encoder (film.jl:204-222): xyzw -> linear RGB in [0,1], H*W*3, rows not flipped. */
+int trhip_film_to_rgb(trhip_ctx* ctx, const float* xyzw, uint32_t width, uint32_t height, float scale, float* out_rgb);
+
+/* ---- kernel-level entry points (parity tests and micro-benchmarks) --------------------------------------------------
+ * rays: n*8 floats (o.xyz, t_max, d.xyz, time) = Ray (ray.jl:1-6).
+ * trhip_hit: t = ray.t_max after intersect!(bvh, ray) (accel/bvh.jl:212-258; +Inf on a miss), prim = ordered-primitive
+ * slot of the hit (-1 on a miss), b1/b2 = first two barycentrics of a triangle hit (triangle_mesh.jl:217-218). */
+typedef struct {
+    float t;
+    int32_t prim;
+    float b1, b2;
+} trhip_hit;
+int trhip_trace_closest(trhip_ctx* ctx, const trhip_scene* scene, const float* rays, uint64_t n, trhip_hit* out);
+/* intersect_p(bvh, ray)  accel/bvh.jl:260-299 */
+int trhip_trace_any(trhip_ctx* ctx, const trhip_scene* scene, const float* rays, uint64_t n, uint8_t* occluded);
+/* Same on device-resident buffers, `repeat` launches back to back; returns average kernel ms (HIP events) — used by bench.py. */
+int trhip_trace_closest_device(trhip_ctx* ctx, const trhip_scene* scene, const void* d_rays, uint64_t n, void* d_hits, int repeat, double* avg_ms);
+int trhip_trace_any_device(trhip_ctx* ctx, const trhip_scene* scene, const void* d_rays, uint64_t n, void* d_occluded, int repeat, double* avg_ms);
+
+/* Visit counters of the last *_device trace call when "count_visits" is on: nodes, prims (closest) then nodes, prims (any-hit). */
+int trhip_last_visit_counts(trhip_ctx* ctx, uint64_t* out4);
+
+/* Geometry of a closest hit as the shading kernel rebuilds it (SurfaceInteraction, surface_interaction.jl:51-88,154-181;
+ * BSDF frame materials/bsdf.jl:41-50): per ray 15 floats p(3) n(3) ns(3) wo(3) ss(3); zeros on a miss. */
+int trhip_hit_geometry(trhip_ctx* ctx, const trhip_scene* scene, const float* rays, uint64_t n, float* out_geom15);
+
+/* generate_ray(camera, sample) camera/perspective.jl:85-114 for n camera samples (film.xy, lens.xy, time) -> n*8 rays. */
+int trhip_generate_rays(trhip_ctx* ctx, const trhip_sensor* sensor, const float* samples5, uint64_t n, float* out_rays8);
+
+/* BSDF through a material (materials/material.jl + materials/bsdf.jl:79-193) for n shading frames frame9 = ng ns ss(=normalize(shading.∂p∂u)):
+ *   mode 0: dirs6 = wo(3) wi(3)      -> out8 = f(3) pdf 0 0 0 0          (b(wo,wi,flags), compute_pdf)
+ *   mode 1: dirs6 = wo(3) u(2) 0     -> out8 = wi(3) f(3) pdf type       (sample_f) */
+int trhip_bsdf_query(trhip_ctx* ctx, const trhip_scene* scene, uint32_t material, int allow_multiple_lobes, int mode, int flags,
+                     const float* frame9, const float* dirs6, uint64_t n, float* out8);
+
+/* Film splat of caller-provided samples: add_sample! + merge_film_tile! in the reference's tile order
+ * (film.jl:134-193, integrators/sampler.jl:24-52).  sample_L: n_sample_pixels*spp*3 as in trhip_last_sample_radiance;
+ * p_film positions are regenerated from (seed, sample_offset). */
+int trhip_film_accumulate(trhip_ctx* ctx, const trhip_sensor* sensor, uint32_t spp, uint64_t seed, uint32_t sample_offset, const float* sample_L,
+                          float* out_xyzw);
+
+/* ---- options ------------------------------------------------------------------------------------------------------- */
+/* "count_visits" (0/1): instrumented traversal kernels fill nodes_visited / prims_tested.
+ * "batch_paths": paths in flight per wavefront batch (default 16 Mi).
+ * "timing" (0/1): per-kernel HIP-event timing in trhip_stats (default 1). */
+int trhip_set_option(trhip_ctx* ctx, const char* name, int64_t value);
+
+/* The deterministic elementary functions of trace_detmath.h for hosts that cannot include a C header
+ * (fn: 0 sin, 1 cos, 2 tan, 3 atan2(y, x), 4 acos, 5 log); y may be NULL unless fn == 3.  Needs no GPU. */
+int trhip_detmath_f32(int fn, const float* x, const float* y, uint64_t n, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRACEHIP_H */

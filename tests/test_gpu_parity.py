@@ -1,0 +1,231 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every stage of the hot path, through the C ABI, against the CPU
+oracle on the same seeded inputs.  Bar: BIT-EXACT (Float32 bit patterns) — the kernels share the oracle's operation
+order, the deterministic elementary functions and the counter-based sampler, and are built without FMA contraction.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def assert_bits_equal(a, b, what):
+    a, b = np.ascontiguousarray(a, np.float32), np.ascontiguousarray(b, np.float32)
+    assert a.shape == b.shape, f"{what}: shape {a.shape} vs {b.shape}"
+    # NaN payloads may differ between producers; compare NaN-ness there and bits elsewhere
+    na, nb = np.isnan(a), np.isnan(b)
+    assert np.array_equal(na, nb), f"{what}: NaN pattern differs"
+    bad = (bits(a) != bits(b)) & ~na
+    assert not bad.any(), f"{what}: {int(bad.sum())} of {a.size} values differ, first at {np.argwhere(bad)[0]}: {a[tuple(np.argwhere(bad)[0])]!r} vs {b[tuple(np.argwhere(bad)[0])]!r}"
+
+
+def scene_pair(T, ob, scene):
+    flat = scene.flatten()
+    osc = ob.OracleScene.from_scene(scene, bvh=flat.bvh())
+    return flat, osc
+
+
+def camera_rays(T, ob, cam, spp=1, seed=3):
+    samples = T.scenes.camera_sample_grid(cam, spp, seed)
+    return ob.generate_rays(cam, samples)
+
+
+@pytest.fixture(scope="module")
+def shadows(T, ob, ctx):
+    scene = T.scenes.shadows_scene()
+    flat, osc = scene_pair(T, ob, scene)
+    return scene, flat, osc
+
+
+@pytest.fixture(scope="module")
+def mesh(T, ob, ctx):
+    scene = T.scenes.mesh_scene(64)  # 8 192 triangles + Cornell box + 2 spheres
+    flat, osc = scene_pair(T, ob, scene)
+    return scene, flat, osc
+
+
+def test_generate_rays_matches_oracle(T, ob, ctx):
+    """a3: generate_ray (camera/perspective.jl:85-114) incl. the thin-lens branch."""
+    import ctypes as C
+    for lens_radius in (0.0, 0.05):
+        cam = T.scenes.shadows_camera(48)
+        cam.lens_radius = np.float32(lens_radius)
+        cam.focal_distance = np.float32(52.0)
+        samples = T.scenes.camera_sample_grid(cam, 2, seed=11)
+        ref = ob.generate_rays(cam, samples)
+        out = np.empty_like(ref)
+        sn = cam.sensor()
+        ctx.check(T.lib().trhip_generate_rays(ctx._h, C.byref(sn), T._ffi.fptr(samples), samples.shape[0], T._ffi.fptr(out)))
+        assert_bits_equal(out, ref, f"generate_ray lens_radius={lens_radius}")
+
+
+@pytest.mark.parametrize("which", ["shadows", "mesh"])
+def test_trace_closest_camera_and_incoherent(T, ob, which, shadows, mesh):
+    """a6-a9: closest-hit traversal + Triangle/Sphere intersection: t and primitive bit-exact on the same BVH."""
+    scene, flat, osc = shadows if which == "shadows" else mesh
+    cam = T.scenes.shadows_camera(96)
+    wb = osc.world_bound()
+    rays = np.concatenate([camera_rays(T, ob, cam), T.scenes.incoherent_rays(60000, wb[:3] - 0.2, wb[3:] + 0.2)])
+    hits = flat.trace_closest(rays)
+    t_ref, prim_ref, _, _ = osc.trace_closest(rays)
+    assert (prim_ref >= 0).sum() > 1000
+    assert np.array_equal(hits["prim"], prim_ref), f"{int((hits['prim'] != prim_ref).sum())} primitive ids differ"
+    assert_bits_equal(hits["t"], t_ref, "t_hit")
+
+
+@pytest.mark.parametrize("which", ["shadows", "mesh"])
+def test_trace_any(T, ob, which, shadows, mesh):
+    """a6: intersect_p (accel/bvh.jl:260-299), including finite t_max and unnormalised directions (shadow rays, A.8)."""
+    scene, flat, osc = shadows if which == "shadows" else mesh
+    wb = osc.world_bound()
+    rays = T.scenes.incoherent_rays(50000, wb[:3] - 0.2, wb[3:] + 0.2, seed=99)
+    rays[::3, 4:7] *= 3.7     # unnormalised
+    rays[::5, 3] = 0.4        # finite t_max
+    occ = flat.trace_any(rays)
+    occ_ref, _ = osc.trace_any(rays)
+    assert 0.05 < occ_ref.mean() < 0.999
+    assert np.array_equal(occ, occ_ref)
+
+
+@pytest.mark.parametrize("which", ["shadows", "mesh"])
+def test_hit_geometry(T, ob, which, shadows, mesh):
+    """a8-a11: the SurfaceInteraction / BSDF frame the shading kernel rebuilds: p, n, ns, wo, ss bit-exact."""
+    scene, flat, osc = shadows if which == "shadows" else mesh
+    cam = T.scenes.shadows_camera(64)
+    wb = osc.world_bound()
+    rays = np.concatenate([camera_rays(T, ob, cam, seed=5), T.scenes.incoherent_rays(20000, wb[:3], wb[3:], seed=6)])
+    geom = flat.hit_geometry(rays)
+    _, prim_ref, geom_ref, _ = osc.trace_closest(rays, want_geom=True)
+    assert (prim_ref >= 0).sum() > 500
+    assert_bits_equal(geom, geom_ref, "hit geometry (p n ns wo ss)")
+
+
+def _frames(n, seed):
+    rng = np.random.default_rng(seed)
+    ns = rng.normal(size=(n, 3)).astype(np.float32)
+    ns /= np.linalg.norm(ns, axis=1, keepdims=True)
+    ng = ns + 0.05 * rng.normal(size=(n, 3)).astype(np.float32)
+    ng /= np.linalg.norm(ng, axis=1, keepdims=True)
+    t = np.cross(ns, rng.normal(size=(n, 3))).astype(np.float32)
+    return np.concatenate([ng, ns, t], axis=1).astype(np.float32)
+
+
+def _dirs(n, seed):
+    rng = np.random.default_rng(seed)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    return (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+
+
+MATERIALS = {
+    "matte": lambda T: T.MatteMaterial(T.ConstantTexture(T.RGBSpectrum(0.8, 0.5, 0.3)), T.ConstantTexture(0.0)),
+    "oren_nayar": lambda T: T.MatteMaterial(T.ConstantTexture(T.RGBSpectrum(0.8, 0.5, 0.3)), T.ConstantTexture(25.0)),
+    "mirror": lambda T: T.MirrorMaterial(T.ConstantTexture(T.RGBSpectrum(0.9))),
+    "glass": lambda T: T.GlassMaterial(T.ConstantTexture(T.RGBSpectrum(1.0)), T.ConstantTexture(T.RGBSpectrum(0.9, 1.0, 0.8)), T.ConstantTexture(0.0), T.ConstantTexture(0.0),
+                                       T.ConstantTexture(1.5), True),
+    "rough_glass": lambda T: T.GlassMaterial(T.ConstantTexture(T.RGBSpectrum(1.0)), T.ConstantTexture(T.RGBSpectrum(1.0)), T.ConstantTexture(0.3), T.ConstantTexture(0.2),
+                                             T.ConstantTexture(1.33), True),
+    "plastic": lambda T: T.PlasticMaterial(T.ConstantTexture(T.RGBSpectrum(0.64)), T.ConstantTexture(T.RGBSpectrum(0.1)), T.ConstantTexture(0.010408001), True),
+    "plastic_noremap": lambda T: T.PlasticMaterial(T.ConstantTexture(T.RGBSpectrum(0.3, 0.6, 0.2)), T.ConstantTexture(T.RGBSpectrum(0.5)), T.ConstantTexture(0.15), False),
+}
+
+
+@pytest.mark.parametrize("name", list(MATERIALS))
+@pytest.mark.parametrize("multi", [False, True])
+def test_bsdf_eval_and_sample(T, ob, ctx, name, multi):
+    """a10, a12, a13: materials -> lobes, BSDF f / pdf / sample_f for every BxDF the materials can add."""
+    mat = MATERIALS[name](T)
+    tri = T.create_triangle_mesh(T.ShapeCore(T.translate([0, 0, 0]), False), 1, np.array([1, 2, 3], np.uint32), 3, [[0, 0, 0], [1, 0, 0], [0, 1, 0]])
+    scene = T.Scene([], T.BVHAccel([T.GeometricPrimitive(tri[0], mat)], 1))
+    flat, osc = scene_pair(T, ob, scene)
+    n = 20000
+    frames = _frames(n, 1)
+    wo, wi = _dirs(n, 2), _dirs(n, 3)
+    rng = np.random.default_rng(4)
+    u = rng.random((n, 2), dtype=np.float32)
+    ALL = 31
+    for flags in (ALL, ALL & ~16, 1 | 16, 2 | 16):
+        d0 = np.concatenate([wo, wi], axis=1)
+        assert_bits_equal(flat.bsdf_query(0, multi, 0, flags, frames, d0), osc.bsdf_query(0, multi, 0, flags, frames, d0), f"{name} f/pdf flags={flags}")
+        d1 = np.concatenate([wo, u, np.zeros((n, 1), np.float32)], axis=1)
+        assert_bits_equal(flat.bsdf_query(0, multi, 1, flags, frames, d1), osc.bsdf_query(0, multi, 1, flags, frames, d1), f"{name} sample_f flags={flags}")
+
+
+@pytest.mark.parametrize("res,spp,depth", [(40, 3, 5), (64, 2, 8)])
+def test_render_path_shadows_bit_exact(T, ob, shadows, res, spp, depth):
+    """a1-a16 end to end on config C1's scene: per-sample radiance AND film accumulators bit-exact."""
+    scene, flat, osc = shadows
+    cam = T.scenes.shadows_camera(res)
+    integ = T.PathIntegrator(cam, T.SeededSampler(spp, seed=0x5EED0001), depth)
+    xyzw = integ.render(scene)
+    L = integ.sample_radiance(scene)
+    ref_xyzw, ref_L, st = osc.render(cam, "path", spp, depth, seed=0x5EED0001, want_samples=True)
+    assert ref_L.max() > 0
+    assert_bits_equal(L, ref_L, "per-sample radiance")
+    assert_bits_equal(xyzw, ref_xyzw, "film xyz + weight sums")
+    assert integ.stats.camera_samples == st.camera_samples
+    assert integ.stats.closest_rays == st.closest_rays
+    assert integ.stats.shadow_rays == st.shadow_rays
+
+
+def test_render_path_mesh_bit_exact(T, ob, mesh):
+    scene, flat, osc = mesh
+    cam = T.scenes.cornell_camera(48)
+    integ = T.PathIntegrator(cam, T.SeededSampler(2, seed=42), 6)
+    xyzw = integ.render(scene)
+    L = integ.sample_radiance(scene)
+    ref_xyzw, ref_L, st = osc.render(cam, "path", 2, 6, seed=42, want_samples=True)
+    assert_bits_equal(L, ref_L, "per-sample radiance")
+    assert_bits_equal(xyzw, ref_xyzw, "film")
+    assert integ.stats.closest_rays == st.closest_rays and integ.stats.shadow_rays == st.shadow_rays
+
+
+def test_render_batches_and_sample_offset(T, ob, ctx, shadows):
+    """Batching must not change results; sample_offset shifts the sampler streams (multi-GPU sharding, §8e)."""
+    scene, flat, osc = shadows
+    cam = T.scenes.shadows_camera(32)
+    a = T.PathIntegrator(cam, T.SeededSampler(4, seed=9), 4).render(scene).copy()
+    ctx.set_option("batch_paths", 34 * 34 + 5)  # one sample pass per batch
+    try:
+        b = T.PathIntegrator(cam, T.SeededSampler(4, seed=9), 4).render(scene).copy()
+    finally:
+        ctx.set_option("batch_paths", 16 << 20)
+    assert_bits_equal(a, b, "batched film")
+    # two half renders with offsets sum (in fp32, tolerance) to the full one
+    h0 = T.PathIntegrator(cam, T.SeededSampler(2, seed=9, sample_offset=0), 4).render(scene).copy()
+    h1 = T.PathIntegrator(cam, T.SeededSampler(2, seed=9, sample_offset=2), 4).render(scene).copy()
+    np.testing.assert_allclose(h0 + h1, a, rtol=2e-5, atol=1e-6)
+    ref, _, _ = osc.render(cam, "path", 2, 4, seed=9, sample_offset=2)
+    assert_bits_equal(h1, ref, "offset film")
+
+
+def test_film_accumulate_matches_oracle_tile_order(T, ob, ctx):
+    """a16: add_sample! + merge_film_tile! for arbitrary radiance incl. NaN samples (integrators/sampler.jl:46) and a wide filter."""
+    import ctypes as C
+    flt = T.LanczosSincFilter([2.5, 1.5], 3.0)
+    film = T.Film([37, 29], T.Bounds2([0.0, 0.0], [1.0, 1.0]), flt, 1.0, 1.0, "")
+    cam = T.PerspectiveCamera(T.look_at([0, 15, 50], [0, 0, -2], [0, 1, 0]), T.Bounds2([-1.0, -1.0], [1.0, 1.0]), 0.0, 1.0, 0.0, 1e6, 90.0, film)
+    # a scene with nothing in it: the oracle render then only exercises the film; feed radiance through a constant trick:
+    # use the real path instead — render the shadows scene and compare the film of GPU accumulate fed with the ORACLE's samples
+    scene = T.scenes.shadows_scene()
+    osc = ob.OracleScene.from_scene(scene)
+    spp = 3
+    ref_xyzw, ref_L, _ = osc.render(cam, "path", spp, 3, seed=5, want_samples=True)
+    sn = cam.sensor()
+    out = np.empty_like(ref_xyzw)
+    ctx.check(T.lib().trhip_film_accumulate(ctx._h, C.byref(sn), spp, 5, 0, T._ffi.fptr(ref_L), T._ffi.fptr(out)))
+    assert_bits_equal(out, ref_xyzw, "film accumulate (wide anisotropic filter)")
+
+
+def test_film_to_rgb(T, ob, ctx, shadows):
+    scene, flat, osc = shadows
+    cam = T.scenes.shadows_camera(32)
+    T.PathIntegrator(cam, T.SeededSampler(2, seed=1), 3).render(scene)
+    rgb = cam.film.to_rgb()
+    h, w = cam.film.size
+    xyzw = np.concatenate([cam.film.xyz, cam.film.filter_weight_sum[..., None]], axis=-1).astype(np.float32)
+    ref = np.empty((h, w, 3), np.float32)
+    ob.lib().orc_film_to_rgb(ob.fp(np.ascontiguousarray(xyzw)), w, h, 1.0, ob.fp(ref))
+    assert_bits_equal(rgb, ref, "film_to_rgb")

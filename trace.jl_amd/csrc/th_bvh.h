@@ -1,0 +1,181 @@
+// th_bvh.h — host-side BVH2 construction for BVHAccel(primitives, max_node_primitives) (accel/bvh.jl:55-206).
+// NOT a restatement of the reference builder (whose SAH has several quirks): traversal results do not
+// depend on the topology except for exact-t ties, so this is a plain binned-SAH builder (16 bins, all three axes,
+// median fallback) that emits nodes directly in the reference's depth-first layout (first child = i + 1).
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <vector>
+
+namespace th {
+
+struct HostAABB {
+    float mn[3], mx[3];
+    void reset() {
+        for (int a = 0; a < 3; ++a) {
+            mn[a] = INFINITY;
+            mx[a] = -INFINITY;
+        }
+    }
+    void grow(const HostAABB& b) {
+        for (int a = 0; a < 3; ++a) {
+            mn[a] = std::fmin(mn[a], b.mn[a]);
+            mx[a] = std::fmax(mx[a], b.mx[a]);
+        }
+    }
+    void grow_point(const float* p) {
+        for (int a = 0; a < 3; ++a) {
+            mn[a] = std::fmin(mn[a], p[a]);
+            mx[a] = std::fmax(mx[a], p[a]);
+        }
+    }
+    float half_area() const {
+        const float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
+        return dx * dy + dx * dz + dy * dz;
+    }
+};
+
+struct FlatBVH {
+    std::vector<float> bounds;     // n_nodes * 6
+    std::vector<uint32_t> a;       // leaf: first ordered slot | interior: second child
+    std::vector<uint32_t> flags;   // leaf: n << 2 | 3 | interior: axis
+    std::vector<uint32_t> order;   // ordered slot -> caller primitive index
+    uint32_t max_depth = 0;
+};
+
+class BVHBuilder {
+   public:
+    BVHBuilder(const std::vector<HostAABB>& prim_bounds, int max_node_prims) : pb_(prim_bounds), max_leaf_(std::max(1, std::min(255, max_node_prims))) {}
+
+    FlatBVH build() {
+        const uint32_t n = (uint32_t)pb_.size();
+        idx_.resize(n);
+        cen_.resize((size_t)n * 3);
+        for (uint32_t i = 0; i < n; ++i) {
+            idx_[i] = i;
+            for (int a = 0; a < 3; ++a) cen_[3 * (size_t)i + a] = 0.5f * pb_[i].mn[a] + 0.5f * pb_[i].mx[a];  // bvh.jl:12
+        }
+        out_.bounds.reserve((size_t)n * 12);
+        out_.a.reserve((size_t)n * 2);
+        out_.flags.reserve((size_t)n * 2);
+        out_.order.reserve(n);
+        if (n) recurse(0, n, 1);
+        return std::move(out_);
+    }
+
+   private:
+    static constexpr int kBins = 16;
+    const std::vector<HostAABB>& pb_;
+    int max_leaf_;
+    std::vector<uint32_t> idx_;
+    std::vector<float> cen_;
+    FlatBVH out_;
+
+    uint32_t emit_node(const HostAABB& b) {
+        const uint32_t id = (uint32_t)out_.a.size();
+        out_.bounds.insert(out_.bounds.end(), {b.mn[0], b.mn[1], b.mn[2], b.mx[0], b.mx[1], b.mx[2]});
+        out_.a.push_back(0);
+        out_.flags.push_back(0);
+        return id;
+    }
+    void make_leaf(uint32_t node, uint32_t lo, uint32_t hi) {
+        out_.a[node] = (uint32_t)out_.order.size();
+        out_.flags[node] = ((hi - lo) << 2) | 3u;
+        for (uint32_t i = lo; i < hi; ++i) out_.order.push_back(idx_[i]);
+    }
+    void recurse(uint32_t lo, uint32_t hi, uint32_t depth) {
+        out_.max_depth = std::max(out_.max_depth, depth);
+        HostAABB b, cb;
+        b.reset();
+        cb.reset();
+        for (uint32_t i = lo; i < hi; ++i) {
+            b.grow(pb_[idx_[i]]);
+            cb.grow_point(&cen_[3 * (size_t)idx_[i]]);
+        }
+        const uint32_t node = emit_node(b);
+        const uint32_t n = hi - lo;
+        if (n == 1) {
+            make_leaf(node, lo, hi);
+            return;
+        }
+        // choose the split: binned SAH over the three axes
+        int best_axis = -1, best_bin = -1;
+        float best_cost = INFINITY;
+        for (int ax = 0; ax < 3; ++ax) {
+            const float c0 = cb.mn[ax], c1 = cb.mx[ax];
+            if (!(c1 > c0)) continue;
+            HostAABB bb[kBins];
+            uint32_t cnt[kBins];
+            for (int k = 0; k < kBins; ++k) {
+                bb[k].reset();
+                cnt[k] = 0;
+            }
+            const float scale = (float)kBins / (c1 - c0);
+            for (uint32_t i = lo; i < hi; ++i) {
+                int k = (int)((cen_[3 * (size_t)idx_[i] + ax] - c0) * scale);
+                k = std::min(kBins - 1, std::max(0, k));
+                bb[k].grow(pb_[idx_[i]]);
+                cnt[k]++;
+            }
+            float right_area[kBins];
+            uint32_t right_cnt[kBins];
+            HostAABB acc;
+            acc.reset();
+            uint32_t c = 0;
+            for (int k = kBins - 1; k > 0; --k) {
+                acc.grow(bb[k]);
+                c += cnt[k];
+                right_area[k] = acc.half_area();
+                right_cnt[k] = c;
+            }
+            acc.reset();
+            c = 0;
+            for (int k = 0; k < kBins - 1; ++k) {
+                acc.grow(bb[k]);
+                c += cnt[k];
+                if (c == 0 || right_cnt[k + 1] == 0) continue;
+                const float cost = acc.half_area() * (float)c + right_area[k + 1] * (float)right_cnt[k + 1];
+                if (cost < best_cost) {
+                    best_cost = cost;
+                    best_axis = ax;
+                    best_bin = k;
+                }
+            }
+        }
+        if (best_axis < 0) {  // all centroids coincide: the reference makes a leaf too (bvh.jl:113-118)
+            make_leaf(node, lo, hi);
+            return;
+        }
+        if ((int)n <= max_leaf_) {
+            const float leaf_cost = (float)n * b.half_area();
+            if (best_cost + 0.125f * b.half_area() >= leaf_cost) {
+                make_leaf(node, lo, hi);
+                return;
+            }
+        }
+        const float c0 = cb.mn[best_axis], c1 = cb.mx[best_axis];
+        const float scale = (float)kBins / (c1 - c0);
+        uint32_t* first = idx_.data() + lo;
+        uint32_t* last = idx_.data() + hi;
+        uint32_t* midp = std::partition(first, last, [&](uint32_t id) {
+            int k = (int)((cen_[3 * (size_t)id + best_axis] - c0) * scale);
+            k = std::min(kBins - 1, std::max(0, k));
+            return k <= best_bin;
+        });
+        uint32_t mid = (uint32_t)(midp - idx_.data());
+        // Traversal keeps the reference's 64-entry stack (bvh.jl:222): past depth 40 split at the median so the tree
+        // cannot get deeper than 40 + log2(n) levels.
+        if (mid == lo || mid == hi || depth >= 40) {
+            mid = lo + n / 2;
+            std::nth_element(first, idx_.data() + mid, last,
+                             [&](uint32_t x, uint32_t y) { return cen_[3 * (size_t)x + best_axis] < cen_[3 * (size_t)y + best_axis]; });
+        }
+        out_.flags[node] = (uint32_t)best_axis;
+        recurse(lo, mid, depth + 1);
+        out_.a[node] = (uint32_t)out_.a.size();  // second child follows the whole first subtree
+        recurse(mid, hi, depth + 1);
+    }
+};
+
+}  // namespace th

@@ -1,0 +1,605 @@
+// th_kernels.h — the gfx950 kernels of the wavefront engine.
+//
+//   k_raygen          camera samples -> ray queue            (sampler/sampler.jl:135-139, camera/perspective.jl:85-114)
+//   k_trace<ANY,…>    BVH2 closest-hit / any-hit traversal    (accel/bvh.jl:212-299, bounds.jl:186-206, shapes/*.jl)
+//   k_shade_path      PathIntegrator vertex: interaction, BSDF, light sample -> shadow queue, sample_f + RR -> next queue
+//   k_film_gather     add_sample! + merge_film_tile! as a deterministic gather in the reference's summation order
+//
+// Execution model: persistent grid-stride kernels (no host round trip per bounce: queue sizes live in HBM),
+// one ray per lane, 64-wide waves, per-lane traversal stack staged in LDS as stack[level][lane] (conflict-free: lane l
+// and l+32 hit the same bank in different half-wave groups), live paths compacted per bounce with a 64-bit ballot +
+// popcount prefix and ONE atomic per wave.  No MFMA anywhere: the path is branchy gather, not a contraction.
+#pragma once
+#include "th_device.h"
+
+namespace th {
+
+constexpr int kBlock = 256;
+constexpr int kStackLds = 32;    // stack levels kept in LDS (8 KiB per wave)
+constexpr int kStackSpill = 32;  // further levels in scratch; 64 in total like bvh.jl:222
+
+struct PathQueue {
+    float4* o;     // o.xyz, as_float(slot)
+    float4* d;     // d.xyz, unused
+    float4* beta;  // β.rgb, unused
+};
+struct ShadowQueue {
+    float4* o;  // o.xyz, as_float(slot)
+    float4* d;  // d.xyz, as_float(poison bits: bit c set = β[c] is not finite)
+    float4* c;  // β·Ld to add when unoccluded
+};
+struct Counters {  // device-resident
+    uint32_t n_queue[2];
+    uint32_t n_shadow;
+    uint32_t pad;
+    unsigned long long closest_total, shadow_total, nodes_closest, prims_closest, nodes_shadow, prims_shadow;
+};
+
+TH_D uint32_t lane_id() { return __lane_id(); }
+// wave-level compaction: returns this lane's output index (valid when `alive`), one atomic per wave
+TH_D uint32_t wave_compact(bool alive, uint32_t* counter) {
+    const unsigned long long mask = __ballot(alive);
+    const uint32_t n = (uint32_t)__popcll(mask);
+    uint32_t base = 0;
+    const uint32_t lane = lane_id();
+    const int leader = __ffsll((long long)mask) - 1;
+    if (n && (int)lane == leader) base = atomicAdd(counter, n);
+    base = __shfl(base, leader < 0 ? 0 : leader);
+    return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
+TH_D unsigned long long wave_sum(unsigned long long v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    return v;
+}
+
+// ---- sampler helpers ------------------------------------------------------------------------------------------------------
+struct SlotInfo {
+    int px, py;       // 1-based raster pixel (may be <= 0 in the filter border)
+    uint32_t pix;     // linear sample-pixel index
+    uint32_t sample;  // sample index within this render call
+};
+TH_D SlotInfo slot_info(const DeviceSensor& se, uint32_t slot) {
+    const uint32_t npix = (uint32_t)(se.sb_w * se.sb_h);
+    SlotInfo r;
+    r.sample = slot / npix;
+    r.pix = slot - r.sample * npix;
+    const uint32_t y = r.pix / (uint32_t)se.sb_w;
+    r.px = se.sb_min[0] + (int)(r.pix - y * (uint32_t)se.sb_w);
+    r.py = se.sb_min[1] + (int)y;
+    return r;
+}
+
+// ---- camera (camera/perspective.jl:85-114) ----------------------------------------------------------------------------------
+TH_D void generate_ray(const DeviceSensor& se, f2 film, f2 lens, float time_u, f3& o, f3& d, float& time) {
+    const f3 p_camera = xf_point(se.raster_to_camera, mk3(film.x, film.y, 0.0f));
+    o = splat3(0.0f);
+    d = normalize(p_camera);
+    if (se.lens_radius > 0.0f) {
+        const f2 pl = concentric_sample_disk(lens);
+        const f2 p_lens{se.lens_radius * pl.x, se.lens_radius * pl.y};
+        const float t = se.focal_distance / d.z;
+        const f3 p_focus = o + d * t;
+        o = mk3(p_lens.x, p_lens.y, 0.0f);
+        d = normalize(p_focus - o);
+    }
+    time = (1 - time_u) * se.shutter_open + time_u * se.shutter_close;  // lerp bounds.jl:126
+    o = xf_point(se.camera_to_world, o);
+    d = xf_vec(se.camera_to_world, d);
+    d = normalize(d);
+}
+
+__global__ __launch_bounds__(kBlock) void k_raygen(const DeviceSensor* __restrict__ sep, uint32_t slot0, uint32_t n, uint64_t seed, uint32_t sample_offset,
+                                                   PathQueue q, Counters* ctr) {
+    const DeviceSensor& se = *sep;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const uint32_t slot = slot0 + i;
+        const SlotInfo si = slot_info(se, slot);
+        const uint64_t key = ts_stream_key(seed, si.px, si.py, sample_offset + si.sample);
+        const f2 film{(float)si.px + ts_uniform(key, TS_DIM_FILM_X), (float)si.py + ts_uniform(key, TS_DIM_FILM_Y)};
+        const f2 lens{ts_uniform(key, TS_DIM_LENS_X), ts_uniform(key, TS_DIM_LENS_Y)};
+        f3 o, d;
+        float time;
+        generate_ray(se, film, lens, ts_uniform(key, TS_DIM_TIME), o, d, time);
+        d = check_direction(d);  // intersect!(bvh, ray) starts with check_direction! (bvh.jl:217)
+        q.o[i] = make_float4(o.x, o.y, o.z, __uint_as_float(slot));
+        q.d[i] = make_float4(d.x, d.y, d.z, 0.0f);
+        q.beta[i] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctr->n_queue[0] = n;
+}
+
+// ---- traversal ------------------------------------------------------------------------------------------------------------------
+struct Hit {
+    float t;
+    int prim;
+    float b1, b2;
+};
+// bounds.jl:186-206 (`ty_max > tx_max && (tx_max = ty_max)` as written)
+TH_D bool slab_test(float4 n0, float4 n1, f3 o, f3 inv_d, bool negx, bool negy, bool negz, float t_max) {
+    float tx_min = ((negx ? n1.x : n0.x) - o.x) * inv_d.x;
+    float tx_max = ((negx ? n0.x : n1.x) - o.x) * inv_d.x;
+    const float ty_min = ((negy ? n1.y : n0.y) - o.y) * inv_d.y;
+    const float ty_max = ((negy ? n0.y : n1.y) - o.y) * inv_d.y;
+    if (tx_min > ty_max || ty_min > tx_max) return false;
+    if (ty_min > tx_min) tx_min = ty_min;
+    if (ty_max > tx_max) tx_max = ty_max;
+    const float tz_min = ((negz ? n1.z : n0.z) - o.z) * inv_d.z;
+    const float tz_max = ((negz ? n0.z : n1.z) - o.z) * inv_d.z;
+    if (tx_min > tz_max || tz_min > tx_max) return false;
+    if (tz_min > tx_min) tx_min = tz_min;
+    if (tz_max < tx_max) tx_max = tz_max;
+    return tx_min < t_max && tx_max > 0.0f;
+}
+
+// One ray through the BVH in the reference's order (near child first by dir_is_neg[split_axis], bvh.jl:239-246).
+// ANY: intersect_p (returns at the first accepted primitive); otherwise closest hit with "later equal-t hit wins".
+template <bool ANY, bool COUNT>
+TH_D bool traverse(const DeviceScene& sc, f3 o, f3 d, float t_max, uint32_t (*stk)[kBlock], Hit* hit, uint32_t& n_nodes, uint32_t& n_prims) {
+    const f3 inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const bool negx = d.x < 0.0f, negy = d.y < 0.0f, negz = d.z < 0.0f;
+    uint32_t spill[kStackSpill];
+    int sp = 0;
+    uint32_t cur = 0;
+    bool found = false;
+    if (sc.n_nodes == 0) return false;
+    const uint32_t tid = threadIdx.x;
+    while (true) {
+        const float4 n0 = sc.nodes[2 * cur], n1 = sc.nodes[2 * cur + 1];
+        if (COUNT) n_nodes++;
+        bool pop = true;
+        if (slab_test(n0, n1, o, inv_d, negx, negy, negz, t_max)) {
+            const uint32_t a = __float_as_uint(n0.w), flags = __float_as_uint(n1.w);
+            if ((flags & 3u) == 3u) {
+                const uint32_t cnt = flags >> 2;
+                for (uint32_t k = 0; k < cnt; ++k) {
+                    const uint32_t slot = a + k;
+                    const float4 p0 = sc.prims[3 * slot];
+                    const uint32_t meta = __float_as_uint(p0.w);
+                    if (COUNT) n_prims++;
+                    if (meta & PRIM_SPHERE) {
+                        SphereHit sh;
+                        if (sphere_intersect(sc.spheres[__float_as_uint(p0.x)], o, d, t_max, sh)) {
+                            if (ANY) return true;
+                            t_max = sh.t;  // primitive.jl:17 (unconditional)
+                            found = true;
+                            hit->prim = (int)slot;
+                            hit->b1 = hit->b2 = 0.0f;
+                        }
+                    } else {
+                        const float4 p1 = sc.prims[3 * slot + 1], p2 = sc.prims[3 * slot + 2];
+                        TriTest tt;
+                        if (tri_intersect<!ANY>(mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z), o, d, t_max, &tt)) {
+                            if (ANY) return true;
+                            t_max = tt.t;
+                            found = true;
+                            hit->prim = (int)slot;
+                            hit->b1 = tt.bary.x;
+                            hit->b2 = tt.bary.y;
+                        }
+                    }
+                }
+            } else {
+                const uint32_t axis = flags & 3u;
+                const bool neg = axis == 0 ? negx : (axis == 1 ? negy : negz);
+                const uint32_t far_child = neg ? cur + 1 : a;
+                cur = neg ? a : cur + 1;
+                if (sp < kStackLds)
+                    stk[sp][tid] = far_child;
+                else if (sp < kStackLds + kStackSpill)
+                    spill[sp - kStackLds] = far_child;
+                // deeper than 64: the reference would throw a BoundsError (bvh.jl:222); the entry is dropped
+                sp++;
+                pop = false;
+            }
+        }
+        if (pop) {
+            if (sp == 0) break;
+            sp--;
+            cur = sp < kStackLds ? stk[sp][tid] : (sp < kStackLds + kStackSpill ? spill[sp - kStackLds] : 0u);
+        }
+    }
+    if (!ANY) hit->t = t_max;
+    return found;
+}
+
+// Closest hit over a queue.  hits[i] = {t or +Inf, slot or -1, b1, b2}.
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_trace_closest(DeviceScene sc, const float4* __restrict__ ro, const float4* __restrict__ rd, const float* __restrict__ tmax_or_null,
+                                                          const uint32_t* __restrict__ count_ptr, uint32_t n_max, float4* __restrict__ hits, Counters* ctr) {
+    __shared__ uint32_t stk[kStackLds][kBlock];
+    const uint32_t n = count_ptr ? min(*count_ptr, n_max) : n_max;
+    uint32_t nn = 0, np = 0;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const float4 o4 = ro[i], d4 = rd[i];
+        Hit h;
+        h.prim = -1;
+        h.b1 = h.b2 = 0.0f;
+        const float t0 = tmax_or_null ? tmax_or_null[i] : kInf;
+        const bool found = traverse<false, COUNT>(sc, mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z), t0, stk, &h, nn, np);
+        hits[i] = make_float4(found ? h.t : kInf, __int_as_float(found ? h.prim : -1), h.b1, h.b2);
+    }
+    if (ctr) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctr->closest_total, (unsigned long long)n);
+        if (COUNT) {
+            const unsigned long long sn = wave_sum(nn), spr = wave_sum(np);
+            if (lane_id() == 0) {
+                atomicAdd(&ctr->nodes_closest, sn);
+                atomicAdd(&ctr->prims_closest, spr);
+            }
+        }
+    }
+}
+
+// Any-hit over the shadow queue; unoccluded rays add their contribution to the per-sample radiance buffer
+// (estimate_direct, sppm.jl:536-541: `!unoccluded && (Li = 0)`).  If L is null, writes occluded[i] instead.
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_trace_any(DeviceScene sc, const float4* __restrict__ ro, const float4* __restrict__ rd, const float4* __restrict__ contrib,
+                                                      const float* __restrict__ tmax_or_null, const uint32_t* __restrict__ count_ptr, uint32_t n_max,
+                                                      float4* __restrict__ L, uint8_t* __restrict__ occluded, Counters* ctr) {
+    __shared__ uint32_t stk[kStackLds][kBlock];
+    const uint32_t n = count_ptr ? min(*count_ptr, n_max) : n_max;
+    uint32_t nn = 0, np = 0;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const float4 o4 = ro[i], d4 = rd[i];
+        const float t0 = tmax_or_null ? tmax_or_null[i] : kInf;
+        const bool occ = traverse<true, COUNT>(sc, mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z), t0, stk, nullptr, nn, np);
+        if (L) {
+            const uint32_t slot = __float_as_uint(o4.w);
+            if (!occ) {
+                const float4 c = contrib[i];
+                float4 l = L[slot];
+                l.x += c.x;
+                l.y += c.y;
+                l.z += c.z;
+                L[slot] = l;
+            } else {
+                const uint32_t poison = __float_as_uint(d4.w);  // β·0 is NaN where β is not finite
+                if (poison) {
+                    float4 l = L[slot];
+                    const float nanv = __builtin_nanf("");
+                    if (poison & 1u) l.x += nanv;
+                    if (poison & 2u) l.y += nanv;
+                    if (poison & 4u) l.z += nanv;
+                    L[slot] = l;
+                }
+            }
+        } else {
+            occluded[i] = occ ? 1 : 0;
+        }
+    }
+    if (ctr) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctr->shadow_total, (unsigned long long)n);
+        if (COUNT) {
+            const unsigned long long sn = wave_sum(nn), spr = wave_sum(np);
+            if (lane_id() == 0) {
+                atomicAdd(&ctr->nodes_shadow, sn);
+                atomicAdd(&ctr->prims_shadow, spr);
+            }
+        }
+    }
+}
+
+// ---- shading ---------------------------------------------------------------------------------------------------------------------
+// Rebuild the SurfaceInteraction of a closest hit from the one hit primitive (re-running its intersection with
+// t_max = Inf reproduces the accepted candidate's barycentrics / hit point bit-for-bit: they do not depend on t_max).
+TH_D bool rebuild_shading(const DeviceScene& sc, int prim, f3 o, f3 d, Shading& sh, uint32_t& material) {
+    const float4 p0 = sc.prims[3 * prim];
+    const uint32_t meta = __float_as_uint(p0.w);
+    material = meta & PRIM_MATERIAL_MASK;
+    if (meta & PRIM_SPHERE) {
+        const SphereRec& s = sc.spheres[__float_as_uint(p0.x)];
+        SphereHit h;
+        if (!sphere_intersect(s, o, d, kInf, h)) return false;
+        sh = shade_sphere(s, h, d);
+        return true;
+    }
+    const float4 p1 = sc.prims[3 * prim + 1], p2 = sc.prims[3 * prim + 2];
+    const f3 v0 = mk3(p0.x, p0.y, p0.z), v1 = mk3(p1.x, p1.y, p1.z), v2 = mk3(p2.x, p2.y, p2.z);
+    TriTest tt;
+    if (!tri_intersect<true>(v0, v1, v2, o, d, kInf, &tt)) return false;
+    const bool has_n = (meta & PRIM_HAS_NORMALS) != 0;
+    f3 n0 = splat3(0.0f), n1 = n0, n2 = n0;
+    if (has_n) {
+        const float4 a = sc.tri_nrm[3 * prim], b = sc.tri_nrm[3 * prim + 1], c = sc.tri_nrm[3 * prim + 2];
+        n0 = mk3(a.x, a.y, a.z);
+        n1 = mk3(b.x, b.y, b.z);
+        n2 = mk3(c.x, c.y, c.z);
+    }
+    sh = shade_triangle(v0, v1, v2, has_n, n0, n1, n2, (meta & PRIM_FLIP) != 0, tt.bary, d);
+    return true;
+}
+
+// One PathIntegrator vertex (DESIGN.md "PathIntegrator"; sppm.jl:208-266 without the visible-point early-out, β on the
+// direct term, RR as :257-263; uniform_sample_one_light / estimate_direct sppm.jl:503-554).
+__global__ __launch_bounds__(kBlock) void k_shade_path(DeviceScene sc, const DeviceSensor* __restrict__ sep, PathQueue qin, PathQueue qout, ShadowQueue sq,
+                                                       const float4* __restrict__ hits, float4* __restrict__ L, Counters* ctr, int cur, int depth, int max_depth,
+                                                       uint64_t seed, uint32_t sample_offset) {
+    const DeviceSensor& se = *sep;
+    const uint32_t n = ctr->n_queue[cur];
+    const uint32_t n_round = (n + 63u) & ~63u;  // keep whole waves in the loop so ballots see every lane
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n_round; i += gridDim.x * kBlock) {
+        bool want_shadow = false, want_next = false;
+        float4 so4, sd4, sc4, no4, nd4, nb4;
+        if (i < n) {
+            const float4 h4 = hits[i];
+            const int prim = __float_as_int(h4.y);
+            if (prim >= 0) {
+                const float4 o4 = qin.o[i], d4 = qin.d[i], b4 = qin.beta[i];
+                const uint32_t slot = __float_as_uint(o4.w);
+                const f3 o = mk3(o4.x, o4.y, o4.z), d = mk3(d4.x, d4.y, d4.z);
+                f3 beta = mk3(b4.x, b4.y, b4.z);
+                Shading sh;
+                uint32_t material;
+                if (rebuild_shading(sc, prim, o, d, sh, material) && material != PRIM_NO_MATERIAL) {
+                    const LobeSet& bsdf = sc.materials[material].set[1];  // compute_scattering!(si, ray, true)
+                    const SlotInfo sl = slot_info(se, slot);
+                    const uint64_t key = ts_stream_key(seed, sl.px, sl.py, sample_offset + sl.sample);
+                    const uint32_t v = (uint32_t)(depth - 1);
+                    const f3 wo = -d;  // sppm.jl:224
+                    const uint32_t poison = ((isnan_(beta.x) || isinf_(beta.x)) ? 1u : 0u) | ((isnan_(beta.y) || isinf_(beta.y)) ? 2u : 0u) |
+                                            ((isnan_(beta.z) || isinf_(beta.z)) ? 4u : 0u);
+                    // ---- uniform_sample_one_light ----
+                    bool direct_added = false;
+                    if (sc.n_lights > 0) {
+                        const int nl = (int)sc.n_lights;
+                        int ln = (int)__builtin_ceilf(ts_uniform(key, ts_vertex_dim(v, TS_V_LIGHT_PICK)) * (float)nl);
+                        if (ln > nl) ln = nl;
+                        if (ln < 1) ln = 1;
+                        const float light_pdf = 1.0f / (float)nl;
+                        const LightRec& light = sc.lights[ln - 1];
+                        const LightSample ls = sample_li(light, sh.p);
+                        if (ls.pdf > 0.0f && !is_black(ls.radiance)) {
+                            const f3 f = bsdf_f(bsdf, sh, sh.wo, ls.wi, BSDF_ALL & ~BSDF_SPECULAR) * fabs_(dot(ls.wi, sh.ns));
+                            if (!is_black(f)) {
+                                const f3 Ld = (splat3(0.0f) + f * ls.radiance / ls.pdf) / light_pdf;
+                                const f3 c = beta * Ld;
+                                const f3 lp = mk3(light.position[0], light.position[1], light.position[2]);
+                                const f3 dir = lp - sh.p;                       // spawn_ray(p0, p1) Trace.jl:196-202
+                                const f3 org = sh.p + 1e-6f * dir;
+                                const f3 cd = check_direction(dir);
+                                so4 = make_float4(org.x, org.y, org.z, __uint_as_float(slot));
+                                sd4 = make_float4(cd.x, cd.y, cd.z, __uint_as_float(poison));
+                                sc4 = make_float4(c.x, c.y, c.z, 0.0f);
+                                want_shadow = true;
+                                direct_added = true;
+                            }
+                        }
+                    }
+                    if (!direct_added && poison) {  // L += β · 0 with a non-finite β
+                        float4 l = L[slot];
+                        const float nanv = __builtin_nanf("");
+                        if (poison & 1u) l.x += nanv;
+                        if (poison & 2u) l.y += nanv;
+                        if (poison & 4u) l.z += nanv;
+                        L[slot] = l;
+                    }
+                    // ---- continue the path ----
+                    if (depth < max_depth) {
+                        const f2 u{ts_uniform(key, ts_vertex_dim(v, TS_V_BSDF_U0)), ts_uniform(key, ts_vertex_dim(v, TS_V_BSDF_U1))};
+                        const BsdfSample bs = bsdf_sample_f(bsdf, sh, wo, u, BSDF_ALL);
+                        if (!(bs.pdf == 0.0f || is_black(bs.f))) {
+                            beta = beta * (bs.f * fabs_(dot(bs.wi, sh.ns)) / bs.pdf);
+                            const float by = to_Y(beta);
+                            bool alive = true;
+                            if (by < 0.25f) {
+                                const float cont = jmin(1.0f, by);
+                                if (ts_uniform(key, ts_vertex_dim(v, TS_V_RR)) > cont)
+                                    alive = false;
+                                else
+                                    beta = beta / cont;
+                            }
+                            if (alive) {
+                                const f3 org = sh.p + 1e-6f * bs.wi;  // spawn_ray(si, wi) Trace.jl:206-211
+                                const f3 nd = check_direction(bs.wi);
+                                no4 = make_float4(org.x, org.y, org.z, __uint_as_float(slot));
+                                nd4 = make_float4(nd.x, nd.y, nd.z, 0.0f);
+                                nb4 = make_float4(beta.x, beta.y, beta.z, 0.0f);
+                                want_next = true;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        const uint32_t si = wave_compact(want_shadow, &ctr->n_shadow);
+        if (want_shadow) {
+            sq.o[si] = so4;
+            sq.d[si] = sd4;
+            sq.c[si] = sc4;
+        }
+        const uint32_t ni = wave_compact(want_next, &ctr->n_queue[cur ^ 1]);
+        if (want_next) {
+            qout.o[ni] = no4;
+            qout.d[ni] = nd4;
+            qout.beta[ni] = nb4;
+        }
+    }
+}
+
+// ---- film -------------------------------------------------------------------------------------------------------------------------
+// add_sample! (film.jl:134-164) + merge_film_tile! (film.jl:182-193) for every sample of the frame, evaluated as a gather:
+// film pixel (X, Y) visits the few sample-pixels whose filter footprint can reach it, tile by tile in k order
+// (integrators/sampler.jl:24-31), inside a tile in Bounds2 iteration order (x fastest, bounds.jl:39-47), samples in order —
+// i.e. exactly the reference's (single-threaded) summation order, with no atomics and no race (the reference's
+// merge_film_tile! is unsynchronised).  out = xyz sums + filter_weight_sum.
+__global__ __launch_bounds__(kBlock) void k_film_gather(const DeviceSensor* __restrict__ sep, const float* __restrict__ table, const float4* __restrict__ L, uint32_t spp,
+                                                        uint64_t seed, uint32_t sample_offset, float4* __restrict__ out) {
+    const DeviceSensor& se = *sep;
+    const uint32_t npx = (uint32_t)(se.film_w * se.film_h);
+    const uint32_t npix = (uint32_t)(se.sb_w * se.sb_h);
+    const float rx = se.filter_radius[0], ry = se.filter_radius[1];
+    const float inv_rx = 1.0f / rx, inv_ry = 1.0f / ry;
+    for (uint32_t idx = blockIdx.x * kBlock + threadIdx.x; idx < npx; idx += gridDim.x * kBlock) {
+        const int fy = (int)(idx / (uint32_t)se.film_w), fx = (int)(idx - (uint32_t)fy * (uint32_t)se.film_w);
+        const float X = se.crop_min[0] + (float)fx, Y = se.crop_min[1] + (float)fy;
+        // sample-pixels that can reach (X, Y): sx in (X - 1.5 - r, X + r + 0.5]
+        int sx_lo = (int)__builtin_floorf(X - 1.5f - rx), sx_hi = (int)__builtin_ceilf(X + rx + 0.5f);
+        int sy_lo = (int)__builtin_floorf(Y - 1.5f - ry), sy_hi = (int)__builtin_ceilf(Y + ry + 0.5f);
+        sx_lo = max(sx_lo, se.sb_min[0]);
+        sy_lo = max(sy_lo, se.sb_min[1]);
+        sx_hi = min(sx_hi, se.sb_max[0]);
+        sy_hi = min(sy_hi, se.sb_max[1]);
+        f3 xyz = splat3(0.0f);
+        float wsum = 0.0f;
+        if (sx_lo <= sx_hi && sy_lo <= sy_hi) {
+            const int ty_lo = (sy_lo - se.sb_min[1]) >> 4, ty_hi = (sy_hi - se.sb_min[1]) >> 4;
+            const int tx_lo = (sx_lo - se.sb_min[0]) >> 4, tx_hi = (sx_hi - se.sb_min[0]) >> 4;
+            for (int ty = ty_lo; ty <= ty_hi; ++ty)
+                for (int tx = tx_lo; tx <= tx_hi; ++tx) {
+                    // tile sample bounds (integrators/sampler.jl:29-31) and FilmTile bounds (film.jl:120-125)
+                    const float tbx0 = (float)se.sb_min[0] + (float)tx * 16.0f, tby0 = (float)se.sb_min[1] + (float)ty * 16.0f;
+                    const float tbx1 = jmin(tbx0 + 15.0f, (float)se.sb_max[0]), tby1 = jmin(tby0 + 15.0f, (float)se.sb_max[1]);
+                    const float bx0 = jmax(__builtin_ceilf(tbx0 - 0.5f - rx), se.crop_min[0]), by0 = jmax(__builtin_ceilf(tby0 - 0.5f - ry), se.crop_min[1]);
+                    const float bx1 = jmin(__builtin_floorf(tbx1 - 0.5f + rx) + 1.0f, se.crop_max[0]), by1 = jmin(__builtin_floorf(tby1 - 0.5f + ry) + 1.0f, se.crop_max[1]);
+                    if (X < bx0 || X > bx1 || Y < by0 || Y > by1) continue;  // pixel not in this FilmTile: merge does not touch it
+                    f3 csum = splat3(0.0f);
+                    float fws = 0.0f;
+                    const int y0 = max(sy_lo, (int)tby0), y1 = min(sy_hi, (int)tby1);
+                    const int x0 = max(sx_lo, (int)tbx0), x1 = min(sx_hi, (int)tbx1);
+                    for (int sy = y0; sy <= y1; ++sy)
+                        for (int sx = x0; sx <= x1; ++sx) {
+                            const uint32_t pix = (uint32_t)(sy - se.sb_min[1]) * (uint32_t)se.sb_w + (uint32_t)(sx - se.sb_min[0]);
+                            const uint64_t pkey = ts_mix64(seed ^ ((uint64_t)(uint32_t)sx | ((uint64_t)(uint32_t)sy << 32)));
+                            for (uint32_t s = 0; s < spp; ++s) {
+                                const uint64_t key = ts_mix64(pkey + (uint64_t)(sample_offset + s) * TS_GOLDEN);  // == ts_stream_key
+                                const float pfx = (float)sx + ts_uniform(key, TS_DIM_FILM_X), pfy = (float)sy + ts_uniform(key, TS_DIM_FILM_Y);
+                                const float dpx = pfx - 0.5f, dpy = pfy - 0.5f;
+                                float p0x = __builtin_ceilf(dpx - rx), p0y = __builtin_ceilf(dpy - ry);
+                                float p1x = __builtin_floorf(dpx + rx) + 1.0f, p1y = __builtin_floorf(dpy + ry) + 1.0f;
+                                p0x = jmax(p0x, jmax(bx0, 1.0f));
+                                p0y = jmax(p0y, jmax(by0, 1.0f));
+                                p1x = jmin(p1x, bx1);
+                                p1y = jmin(p1y, by1);
+                                if (X < p0x || X > p1x || Y < p0y || Y > p1y) continue;
+                                const float ffx = fabs_((X - dpx) * inv_rx * 16.0f), ffy = fabs_((Y - dpy) * inv_ry * 16.0f);
+                                const int ox = (int)jclamp(__builtin_ceilf(ffx), 1.0f, 16.0f);   // ceil for x …
+                                const int oy = (int)jclamp(__builtin_floorf(ffy), 1.0f, 16.0f);  // … floor for y (A.9)
+                                const float w = table[(oy - 1) * 16 + (ox - 1)];
+                                const float4 l4 = L[(size_t)s * npix + pix];
+                                f3 l = mk3(l4.x, l4.y, l4.z);
+                                if (has_nan(l)) l = splat3(0.0f);  // integrators/sampler.jl:46
+                                csum = csum + l * 1.0f * w;
+                                fws += w;
+                            }
+                        }
+                    xyz = xyz + rgb_to_xyz(csum);
+                    wsum += fws;
+                }
+        }
+        out[idx] = make_float4(xyz.x, xyz.y, xyz.z, wsum);
+    }
+}
+
+// save(film) up to the encoder (film.jl:204-222)
+__global__ void k_film_to_rgb(const float4* __restrict__ xyzw, uint32_t n, float scale, float* __restrict__ rgb) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = xyzw[i];
+    f3 c = xyz_to_rgb(mk3(p.x, p.y, p.z));
+    if (p.w != 0.0f) {
+        const float inv_w = 1.0f / p.w;
+        c = mk3(jmax(0.0f, c.x * inv_w), jmax(0.0f, c.y * inv_w), jmax(0.0f, c.z * inv_w));
+    }
+    c = c + 1.0f * xyz_to_rgb(splat3(0.0f));
+    c = c * scale;
+    rgb[3 * i] = jclamp(c.x, 0.0f, 1.0f);
+    rgb[3 * i + 1] = jclamp(c.y, 0.0f, 1.0f);
+    rgb[3 * i + 2] = jclamp(c.z, 0.0f, 1.0f);
+}
+
+// ---- test / inspection kernels -----------------------------------------------------------------------------------------------------
+__global__ void k_hit_geometry(DeviceScene sc, const float4* __restrict__ ro, const float4* __restrict__ rd, const float4* __restrict__ hits, uint32_t n, float* __restrict__ out15) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float* g = out15 + 15 * (size_t)i;
+    const int prim = __float_as_int(hits[i].y);
+    Shading sh;
+    uint32_t material;
+    const float4 o4 = ro[i], d4 = rd[i];
+    if (prim < 0 || !rebuild_shading(sc, prim, mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z), sh, material)) {
+        for (int k = 0; k < 15; ++k) g[k] = 0.0f;
+        return;
+    }
+    const float v[15] = {sh.p.x, sh.p.y, sh.p.z, sh.ng.x, sh.ng.y, sh.ng.z, sh.ns.x, sh.ns.y, sh.ns.z, sh.wo.x, sh.wo.y, sh.wo.z, sh.ss.x, sh.ss.y, sh.ss.z};
+    for (int k = 0; k < 15; ++k) g[k] = v[k];
+}
+__global__ void k_prepare_rays(const float* __restrict__ rays8, uint32_t n, float4* __restrict__ ro, float4* __restrict__ rd, float* __restrict__ tmax) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* r = rays8 + 8 * (size_t)i;
+    const f3 d = check_direction(mk3(r[4], r[5], r[6]));  // bvh.jl:217 / :265
+    ro[i] = make_float4(r[0], r[1], r[2], 0.0f);
+    rd[i] = make_float4(d.x, d.y, d.z, 0.0f);
+    tmax[i] = r[3];
+}
+__global__ void k_generate_rays(const DeviceSensor* __restrict__ sep, const float* __restrict__ samples5, uint32_t n, float* __restrict__ out8) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* c = samples5 + 5 * (size_t)i;
+    f3 o, d;
+    float time;
+    generate_ray(*sep, f2{c[0], c[1]}, f2{c[2], c[3]}, c[4], o, d, time);
+    float* r = out8 + 8 * (size_t)i;
+    r[0] = o.x;
+    r[1] = o.y;
+    r[2] = o.z;
+    r[3] = kInf;
+    r[4] = d.x;
+    r[5] = d.y;
+    r[6] = d.z;
+    r[7] = time;
+}
+__global__ void k_bsdf_query(DeviceScene sc, uint32_t material, int multi, int mode, int flags, const float* __restrict__ frame9, const float* __restrict__ dirs6, uint32_t n,
+                             float* __restrict__ out8) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* fr = frame9 + 9 * (size_t)i;
+    const float* dd = dirs6 + 6 * (size_t)i;
+    Shading sh;
+    sh.p = splat3(0.0f);
+    sh.wo = splat3(0.0f);
+    sh.ng = mk3(fr[0], fr[1], fr[2]);
+    sh.ns = mk3(fr[3], fr[4], fr[5]);
+    sh.ss = normalize(mk3(fr[6], fr[7], fr[8]));
+    sh.ts = cross(sh.ns, sh.ss);
+    const LobeSet& b = sc.materials[material].set[multi ? 1 : 0];
+    const f3 wo = mk3(dd[0], dd[1], dd[2]);
+    float* o = out8 + 8 * (size_t)i;
+    if (mode == 0) {
+        const f3 wi = mk3(dd[3], dd[4], dd[5]);
+        const f3 f = bsdf_f(b, sh, wo, wi, flags);
+        o[0] = f.x;
+        o[1] = f.y;
+        o[2] = f.z;
+        o[3] = bsdf_pdf(b, sh, wo, wi, flags);
+        o[4] = o[5] = o[6] = o[7] = 0.0f;
+    } else {
+        const BsdfSample s = bsdf_sample_f(b, sh, wo, f2{dd[3], dd[4]}, flags);
+        o[0] = s.wi.x;
+        o[1] = s.wi.y;
+        o[2] = s.wi.z;
+        o[3] = s.f.x;
+        o[4] = s.f.y;
+        o[5] = s.f.z;
+        o[6] = s.pdf;
+        o[7] = (float)s.sampled_type;
+    }
+}
+// Per-sample radiance read-back: float4 L -> rgb with the NaN rule of integrators/sampler.jl:46
+__global__ void k_export_L(const float4* __restrict__ L, uint64_t n, float* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 l = L[i];
+    f3 c = mk3(l.x, l.y, l.z);
+    if (has_nan(c)) c = splat3(0.0f);
+    out[3 * i] = c.x;
+    out[3 * i + 1] = c.y;
+    out[3 * i + 2] = c.z;
+}
+__global__ void k_import_L(const float* __restrict__ in, uint64_t n, float4* __restrict__ L) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    L[i] = make_float4(in[3 * i], in[3 * i + 1], in[3 * i + 2], 0.0f);
+}
+
+}  // namespace th

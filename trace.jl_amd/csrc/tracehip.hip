@@ -1,0 +1,944 @@
+// tracehip.hip — host side of libtracehip.so: the C ABI of include/tracehip.h, scene flattening into HBM, BVH build,
+// and the wavefront launch loop.  gfx950 only; there is no CPU fallback: every entry point that computes needs a GPU.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/tracehip.h"
+#include "th_bvh.h"
+#include "th_kernels.h"
+
+using namespace th;
+
+// ---- context ------------------------------------------------------------------------------------------------------------------
+namespace {
+thread_local std::string g_init_error;
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+}  // namespace
+
+struct trhip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    int num_cu = 256;
+    // options
+    bool count_visits = false;
+    bool timing = true;
+    uint64_t batch_paths = 16ull << 20;
+    // workspace (grown on demand, reused across calls)
+    DevBuf q[2][3], sq[3], hits, Lbuf, counters, sensor, table, film, scratch[4];
+    uint64_t last_L_count = 0;  // float4 entries valid in Lbuf
+};
+
+struct HostPrim {
+    uint32_t kind;       // 0 triangle, 1 sphere
+    float v[9];          // triangle vertices (world)
+    float n[9];          // vertex normals
+    uint32_t meta;       // material | flags
+    uint32_t sphere_id;  // for spheres
+};
+
+struct trhip_scene {
+    trhip_ctx* ctx = nullptr;
+    std::vector<MaterialRec> materials;
+    std::vector<HostPrim> prims;  // caller order
+    std::vector<SphereRec> spheres;
+    std::vector<HostAABB> sphere_bounds;
+    std::vector<LightRec> lights;
+    FlatBVH bvh;
+    bool committed = false;
+    DevBuf d_nodes, d_prims, d_nrm, d_spheres, d_materials, d_lights;
+    DeviceScene dev{};
+};
+
+namespace {
+
+int fail(trhip_ctx* ctx, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx)
+        ctx->err = buf;
+    else
+        g_init_error = buf;
+    return code;
+}
+#define HIP_TRY(ctx, expr)                                                                                       \
+    do {                                                                                                         \
+        hipError_t e_ = (expr);                                                                                  \
+        if (e_ != hipSuccess) return fail(ctx, TRHIP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+int ensure(trhip_ctx* ctx, DevBuf& b, size_t bytes) {
+    if (b.bytes >= bytes && b.p) return 0;
+    if (b.p) HIP_TRY(ctx, hipFree(b.p));
+    b.p = nullptr;
+    b.bytes = 0;
+    if (bytes == 0) bytes = 16;
+    HIP_TRY(ctx, hipMalloc(&b.p, bytes));
+    b.bytes = bytes;
+    return 0;
+}
+void release(DevBuf& b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.bytes = 0;
+}
+int upload(trhip_ctx* ctx, DevBuf& b, const void* src, size_t bytes) {
+    if (int rc = ensure(ctx, b, bytes)) return rc;
+    if (bytes) HIP_TRY(ctx, hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
+    return 0;
+}
+int grid_for(const trhip_ctx* ctx, uint64_t n, int blocks_per_cu) {
+    const uint64_t need = (n + kBlock - 1) / kBlock;
+    const uint64_t cap = (uint64_t)ctx->num_cu * blocks_per_cu;
+    return (int)std::max<uint64_t>(1, std::min(need, cap));
+}
+
+// ---- materials: the lobes each Material adds (materials/material.jl), precomputed per material ---------------------------------
+float roughness_to_alpha(float roughness) {  // microfacet.jl:82-87
+    roughness = jmax(1e-3f, roughness);
+    const float x = tm_logf(roughness);
+    return 1.62142f + 0.819955f * x + 0.1734f * (x * x) + 0.0171201f * (x * x * x) + 0.000640711f * pow4(x);
+}
+void clamp_rgb(const float* in, float* out) {  // clamp(spectrum) spectrum.jl:34-38
+    for (int i = 0; i < 3; ++i) out[i] = jclamp(in[i], 0.0f, kInf);
+}
+bool black(const float* c) { return c[0] == 0.0f && c[1] == 0.0f && c[2] == 0.0f; }
+Lobe base_lobe(int kind, int type) {
+    Lobe l;
+    std::memset(&l, 0, sizeof l);
+    l.kind = kind;
+    l.type = type;
+    l.fresnel = FRESNEL_NOOP;
+    l.eta_a = l.eta_b = l.fr_eta_i = l.fr_eta_t = 1.0f;
+    return l;
+}
+void set_rgb(float* dst, const float* src) {
+    dst[0] = src[0];
+    dst[1] = src[1];
+    dst[2] = src[2];
+}
+Lobe microfacet_lobe(int kind, int type, const float* rgb, float ax, float ay) {
+    Lobe l = base_lobe(kind, type);
+    set_rgb(l.r, rgb);
+    l.a = jmax(1e-3f, ax);  // TrowbridgeReitzDistribution ctor microfacet.jl:61-65
+    l.b = jmax(1e-3f, ay);
+    return l;
+}
+int build_material(int kind, const float* p, int n, MaterialRec& m) {
+    std::memset(&m, 0, sizeof m);
+    for (int multi = 0; multi < 2; ++multi) {
+        LobeSet& s = m.set[multi];
+        s.n = 0;
+        s.eta = 1.0f;
+        switch (kind) {
+        case TRHIP_MATTE: {  // material.jl:16-31
+            if (n != 4) return -1;
+            float r[3];
+            clamp_rgb(p, r);
+            if (black(r)) break;
+            const float sigma = jclamp(p[3], 0.0f, 90.0f);
+            if (sigma == 0.0f) {
+                Lobe l = base_lobe(LOBE_LAMBERT_R, BSDF_DIFFUSE | BSDF_REFLECTION);
+                set_rgb(l.r, r);
+                s.lobe[s.n++] = l;
+            } else {  // OrenNayar ctor microfacet.jl:12-19
+                Lobe l = base_lobe(LOBE_OREN_NAYAR, BSDF_DIFFUSE | BSDF_REFLECTION);
+                set_rgb(l.r, r);
+                const float sg = deg2rad(sigma);
+                const float s2 = sg * sg;
+                l.a = 1.0f - (s2 / (2.0f * (s2 + 0.33f)));
+                l.b = 0.45f * s2 / (s2 + 0.09f);
+                s.lobe[s.n++] = l;
+            }
+            break;
+        }
+        case TRHIP_MIRROR: {  // material.jl:39-46
+            if (n != 3) return -1;
+            float r[3];
+            clamp_rgb(p, r);
+            if (black(r)) break;
+            Lobe l = base_lobe(LOBE_SPECULAR_R, BSDF_SPECULAR | BSDF_REFLECTION);
+            set_rgb(l.r, r);
+            s.lobe[s.n++] = l;
+            break;
+        }
+        case TRHIP_GLASS: {  // material.jl:75-116
+            if (n != 10) return -1;
+            const float eta = p[8];
+            float ur = p[6], vr = p[7];
+            const bool remap = p[9] != 0.0f;
+            s.eta = eta;
+            float r[3], t[3];
+            clamp_rgb(p, r);
+            clamp_rgb(p + 3, t);
+            if (black(r) && black(t)) break;
+            const bool is_specular = ur == 0.0f && vr == 0.0f;
+            if (is_specular && multi) {
+                Lobe l = base_lobe(LOBE_FRESNEL_SPECULAR, BSDF_SPECULAR | BSDF_TRANSMISSION | BSDF_REFLECTION);
+                set_rgb(l.r, r);
+                set_rgb(l.t, t);
+                l.eta_a = 1.0f;
+                l.eta_b = eta;
+                s.lobe[s.n++] = l;
+                break;
+            }
+            if (remap) {
+                ur = roughness_to_alpha(ur);
+                vr = roughness_to_alpha(vr);
+            }
+            if (!black(r)) {
+                Lobe l = is_specular ? base_lobe(LOBE_SPECULAR_R, BSDF_SPECULAR | BSDF_REFLECTION) : microfacet_lobe(LOBE_MICROFACET_R, BSDF_REFLECTION | BSDF_GLOSSY, r, ur, vr);
+                set_rgb(l.r, r);
+                l.fresnel = FRESNEL_DIELECTRIC;
+                l.fr_eta_i = 1.0f;
+                l.fr_eta_t = eta;
+                s.lobe[s.n++] = l;
+            }
+            if (!black(t)) {
+                Lobe l = is_specular ? base_lobe(LOBE_SPECULAR_T, BSDF_SPECULAR | BSDF_TRANSMISSION) : microfacet_lobe(LOBE_MICROFACET_T, BSDF_TRANSMISSION | BSDF_GLOSSY, t, ur, vr);
+                set_rgb(l.r, t);
+                l.eta_a = 1.0f;
+                l.eta_b = eta;
+                l.fresnel = FRESNEL_DIELECTRIC;  // FresnelDielectric(η_a, η_b) specular.jl:60, microfacet.jl:275
+                l.fr_eta_i = 1.0f;
+                l.fr_eta_t = eta;
+                s.lobe[s.n++] = l;
+            }
+            break;
+        }
+        case TRHIP_PLASTIC: {  // material.jl:135-151
+            if (n != 8) return -1;
+            float kd[3], ks[3];
+            clamp_rgb(p, kd);
+            if (!black(kd)) {
+                Lobe l = base_lobe(LOBE_LAMBERT_R, BSDF_DIFFUSE | BSDF_REFLECTION);
+                set_rgb(l.r, kd);
+                s.lobe[s.n++] = l;
+            }
+            clamp_rgb(p + 3, ks);
+            if (black(ks)) break;
+            float rough = p[6];
+            if (p[7] != 0.0f) rough = roughness_to_alpha(rough);
+            Lobe l = microfacet_lobe(LOBE_MICROFACET_R, BSDF_REFLECTION | BSDF_GLOSSY, ks, rough, rough);
+            l.fresnel = FRESNEL_DIELECTRIC;
+            l.fr_eta_i = 1.5f;
+            l.fr_eta_t = 1.0f;
+            s.lobe[s.n++] = l;
+            break;
+        }
+        default: return -1;
+        }
+    }
+    return 0;
+}
+
+// world_bound(sphere) = object_to_world(object_bound) (Shape.jl:17-19, transformations.jl:141-143)
+HostAABB sphere_world_bound(const SphereRec& s) {
+    HostAABB b;
+    b.reset();
+    const float lo[3] = {-s.radius, -s.radius, s.z_min}, hi[3] = {s.radius, s.radius, s.z_max};
+    for (int c = 0; c < 8; ++c) {
+        const f3 p = xf_point(s.o2w, mk3((c & 1) ? hi[0] : lo[0], (c & 2) ? hi[1] : lo[1], (c & 4) ? hi[2] : lo[2]));
+        const float q[3] = {p.x, p.y, p.z};
+        b.grow_point(q);
+    }
+    return b;
+}
+float det3(const float* m) {  // rows of the upper-left 3x3 of a row-major 4x4
+    return m[0] * (m[5] * m[10] - m[6] * m[9]) - m[1] * (m[4] * m[10] - m[6] * m[8]) + m[2] * (m[4] * m[9] - m[5] * m[8]);
+}
+
+int upload_scene(trhip_scene* s) {
+    trhip_ctx* ctx = s->ctx;
+    const uint32_t n_nodes = (uint32_t)s->bvh.a.size(), n_prims = (uint32_t)s->bvh.order.size();
+    std::vector<float4> nodes((size_t)n_nodes * 2), prims((size_t)n_prims * 3), nrm((size_t)n_prims * 3);
+    for (uint32_t i = 0; i < n_nodes; ++i) {
+        const float* b = &s->bvh.bounds[6 * (size_t)i];
+        nodes[2 * (size_t)i] = make_float4(b[0], b[1], b[2], __builtin_bit_cast(float, s->bvh.a[i]));
+        nodes[2 * (size_t)i + 1] = make_float4(b[3], b[4], b[5], __builtin_bit_cast(float, s->bvh.flags[i]));
+    }
+    for (uint32_t k = 0; k < n_prims; ++k) {
+        const HostPrim& p = s->prims[s->bvh.order[k]];
+        if (p.kind == 1) {
+            prims[3 * (size_t)k] = make_float4(__builtin_bit_cast(float, p.sphere_id), 0, 0, __builtin_bit_cast(float, p.meta));
+            prims[3 * (size_t)k + 1] = prims[3 * (size_t)k + 2] = make_float4(0, 0, 0, 0);
+            nrm[3 * (size_t)k] = nrm[3 * (size_t)k + 1] = nrm[3 * (size_t)k + 2] = make_float4(0, 0, 0, 0);
+        } else {
+            prims[3 * (size_t)k] = make_float4(p.v[0], p.v[1], p.v[2], __builtin_bit_cast(float, p.meta));
+            prims[3 * (size_t)k + 1] = make_float4(p.v[3], p.v[4], p.v[5], 0);
+            prims[3 * (size_t)k + 2] = make_float4(p.v[6], p.v[7], p.v[8], 0);
+            for (int j = 0; j < 3; ++j) nrm[3 * (size_t)k + j] = make_float4(p.n[3 * j], p.n[3 * j + 1], p.n[3 * j + 2], 0);
+        }
+    }
+    if (int rc = upload(ctx, s->d_nodes, nodes.data(), nodes.size() * sizeof(float4))) return rc;
+    if (int rc = upload(ctx, s->d_prims, prims.data(), prims.size() * sizeof(float4))) return rc;
+    if (int rc = upload(ctx, s->d_nrm, nrm.data(), nrm.size() * sizeof(float4))) return rc;
+    if (int rc = upload(ctx, s->d_spheres, s->spheres.data(), s->spheres.size() * sizeof(SphereRec))) return rc;
+    if (int rc = upload(ctx, s->d_materials, s->materials.data(), s->materials.size() * sizeof(MaterialRec))) return rc;
+    if (int rc = upload(ctx, s->d_lights, s->lights.data(), s->lights.size() * sizeof(LightRec))) return rc;
+    s->dev.nodes = (const float4*)s->d_nodes.p;
+    s->dev.prims = (const float4*)s->d_prims.p;
+    s->dev.tri_nrm = (const float4*)s->d_nrm.p;
+    s->dev.spheres = (const SphereRec*)s->d_spheres.p;
+    s->dev.materials = (const MaterialRec*)s->d_materials.p;
+    s->dev.lights = (const LightRec*)s->d_lights.p;
+    s->dev.n_nodes = n_nodes;
+    s->dev.n_prims = n_prims;
+    s->dev.n_spheres = (uint32_t)s->spheres.size();
+    s->dev.n_materials = (uint32_t)s->materials.size();
+    s->dev.n_lights = (uint32_t)s->lights.size();
+    s->committed = true;
+    return 0;
+}
+
+// Film / sample-grid geometry derived from the sensor (film.jl:68-73, integrators/sampler.jl:13-20)
+void derive_sensor(const trhip_sensor* sn, DeviceSensor& d) {
+    std::memcpy(d.raster_to_camera, sn->raster_to_camera, sizeof d.raster_to_camera);
+    std::memcpy(d.camera_to_world, sn->camera_to_world, sizeof d.camera_to_world);
+    d.lens_radius = sn->lens_radius;
+    d.focal_distance = sn->focal_distance;
+    d.shutter_open = sn->shutter_open;
+    d.shutter_close = sn->shutter_close;
+    for (int i = 0; i < 2; ++i) {
+        d.crop_min[i] = sn->crop_min[i];
+        d.crop_max[i] = sn->crop_max[i];
+        d.filter_radius[i] = sn->filter_radius[i];
+        d.sb_min[i] = (int)std::floor(sn->crop_min[i] + 0.5f - sn->filter_radius[i]);
+        d.sb_max[i] = (int)std::ceil(sn->crop_max[i] - 0.5f + sn->filter_radius[i]);
+    }
+    d.scale = sn->scale;
+    d.sb_w = d.sb_max[0] - d.sb_min[0] + 1;
+    d.sb_h = d.sb_max[1] - d.sb_min[1] + 1;
+    d.film_w = (int)std::fabs(sn->crop_max[0] - (sn->crop_min[0] - 1.0f));  // inclusive_sides bounds.jl:100-102
+    d.film_h = (int)std::fabs(sn->crop_max[1] - (sn->crop_min[1] - 1.0f));
+    d.tiles_x = (int)std::floor(((float)(d.sb_max[0] - d.sb_min[0]) + 16.0f) / 16.0f);
+    d.tiles_y = (int)std::floor(((float)(d.sb_max[1] - d.sb_min[1]) + 16.0f) / 16.0f);
+}
+
+struct Timer {
+    trhip_ctx* ctx;
+    bool on;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[5];
+    explicit Timer(trhip_ctx* c, bool enable) : ctx(c), on(enable) {}
+    ~Timer() {
+        for (auto& v : ev)
+            for (auto& p : v) {
+                (void)hipEventDestroy(p.first);
+                (void)hipEventDestroy(p.second);
+            }
+    }
+    void begin(int cls) {
+        if (!on) return;
+        hipEvent_t a, b;
+        (void)hipEventCreate(&a);
+        (void)hipEventCreate(&b);
+        (void)hipEventRecord(a, ctx->stream);
+        ev[cls].push_back({a, b});
+    }
+    void end(int cls) {
+        if (!on) return;
+        (void)hipEventRecord(ev[cls].back().second, ctx->stream);
+    }
+    double total(int cls, uint32_t* launches) {
+        double ms = 0;
+        for (auto& p : ev[cls]) {
+            float t = 0;
+            (void)hipEventElapsedTime(&t, p.first, p.second);
+            ms += t;
+        }
+        *launches = (uint32_t)ev[cls].size();
+        return ms;
+    }
+};
+
+int render_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sensor* sensor, int integrator, uint32_t spp, int max_depth, uint64_t seed,
+                uint32_t sample_offset, void* out, bool out_is_device, trhip_stats* stats) {
+    if (!ctx || !scene || !sensor || !out) return fail(ctx, TRHIP_ERR_INVALID, "null argument");
+    if (!scene->committed) return fail(ctx, TRHIP_ERR_INVALID, "scene not committed");
+    if (integrator != 1) return fail(ctx, TRHIP_ERR_UNSUPPORTED, "WhittedIntegrator is not accelerated yet");
+    if (spp == 0 || max_depth < 1) return fail(ctx, TRHIP_ERR_INVALID, "spp and max_depth must be >= 1");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DeviceSensor ds;
+    derive_sensor(sensor, ds);
+    if (ds.film_w <= 0 || ds.film_h <= 0 || ds.sb_w <= 0 || ds.sb_h <= 0) return fail(ctx, TRHIP_ERR_INVALID, "empty film");
+    const uint64_t npix = (uint64_t)ds.sb_w * ds.sb_h;
+    const uint64_t total_slots = npix * spp;
+    if (total_slots >= (1ull << 32)) return fail(ctx, TRHIP_ERR_UNSUPPORTED, "more than 2^32 camera samples in one call: split spp over calls/ranks");
+    // batch = whole sample passes
+    uint64_t spp_batch = std::max<uint64_t>(1, ctx->batch_paths / npix);
+    spp_batch = std::min<uint64_t>(spp_batch, spp);
+    const uint64_t P = npix * spp_batch;
+    if (int rc = upload(ctx, ctx->sensor, &ds, sizeof ds)) return rc;
+    if (int rc = upload(ctx, ctx->table, sensor->filter_table, 256 * sizeof(float))) return rc;
+    for (int k = 0; k < 2; ++k)
+        for (int j = 0; j < 3; ++j)
+            if (int rc = ensure(ctx, ctx->q[k][j], P * sizeof(float4))) return rc;
+    for (int j = 0; j < 3; ++j)
+        if (int rc = ensure(ctx, ctx->sq[j], P * sizeof(float4))) return rc;
+    if (int rc = ensure(ctx, ctx->hits, P * sizeof(float4))) return rc;
+    if (int rc = ensure(ctx, ctx->Lbuf, total_slots * sizeof(float4))) return rc;
+    if (int rc = ensure(ctx, ctx->counters, sizeof(Counters))) return rc;
+    const size_t film_bytes = (size_t)ds.film_w * ds.film_h * sizeof(float4);
+    void* d_film = out;
+    if (!out_is_device) {
+        if (int rc = ensure(ctx, ctx->film, film_bytes)) return rc;
+        d_film = ctx->film.p;
+    }
+    hipStream_t st = ctx->stream;
+    Counters* ctr = (Counters*)ctx->counters.p;
+    const DeviceSensor* dsp = (const DeviceSensor*)ctx->sensor.p;
+    PathQueue pq[2];
+    for (int k = 0; k < 2; ++k) pq[k] = PathQueue{(float4*)ctx->q[k][0].p, (float4*)ctx->q[k][1].p, (float4*)ctx->q[k][2].p};
+    ShadowQueue sq{(float4*)ctx->sq[0].p, (float4*)ctx->sq[1].p, (float4*)ctx->sq[2].p};
+    float4* L = (float4*)ctx->Lbuf.p;
+    float4* hits = (float4*)ctx->hits.p;
+
+    Timer tm(ctx, ctx->timing && stats);
+    hipEvent_t e0, e1;
+    HIP_TRY(ctx, hipEventCreate(&e0));
+    HIP_TRY(ctx, hipEventCreate(&e1));
+    HIP_TRY(ctx, hipEventRecord(e0, st));
+    HIP_TRY(ctx, hipMemsetAsync(ctr, 0, sizeof(Counters), st));
+    HIP_TRY(ctx, hipMemsetAsync(L, 0, total_slots * sizeof(float4), st));
+    const int g_trace = ctx->num_cu * 5, g_shade = ctx->num_cu * 4;
+    uint32_t n_batches = 0;
+    for (uint64_t s0 = 0; s0 < spp; s0 += spp_batch) {
+        const uint64_t nb = std::min<uint64_t>(spp_batch, spp - s0) * npix;
+        n_batches++;
+        tm.begin(0);
+        hipLaunchKernelGGL(k_raygen, dim3(grid_for(ctx, nb, 8)), dim3(kBlock), 0, st, dsp, (uint32_t)(s0 * npix), (uint32_t)nb, seed, sample_offset, pq[0], ctr);
+        tm.end(0);
+        int cur = 0;
+        for (int depth = 1; depth <= max_depth; ++depth) {
+            tm.begin(1);
+            if (ctx->count_visits)
+                hipLaunchKernelGGL(k_trace_closest<true>, dim3(g_trace), dim3(kBlock), 0, st, scene->dev, pq[cur].o, pq[cur].d, (const float*)nullptr, &ctr->n_queue[cur], (uint32_t)nb, hits, ctr);
+            else
+                hipLaunchKernelGGL(k_trace_closest<false>, dim3(g_trace), dim3(kBlock), 0, st, scene->dev, pq[cur].o, pq[cur].d, (const float*)nullptr, &ctr->n_queue[cur], (uint32_t)nb, hits, ctr);
+            tm.end(1);
+            HIP_TRY(ctx, hipMemsetAsync(&ctr->n_queue[cur ^ 1], 0, sizeof(uint32_t), st));
+            HIP_TRY(ctx, hipMemsetAsync(&ctr->n_shadow, 0, sizeof(uint32_t), st));
+            tm.begin(2);
+            hipLaunchKernelGGL(k_shade_path, dim3(g_shade), dim3(kBlock), 0, st, scene->dev, dsp, pq[cur], pq[cur ^ 1], sq, hits, L, ctr, cur, depth, max_depth, seed, sample_offset);
+            tm.end(2);
+            tm.begin(3);
+            if (ctx->count_visits)
+                hipLaunchKernelGGL(k_trace_any<true>, dim3(g_trace), dim3(kBlock), 0, st, scene->dev, sq.o, sq.d, sq.c, (const float*)nullptr, &ctr->n_shadow, (uint32_t)nb, L, (uint8_t*)nullptr, ctr);
+            else
+                hipLaunchKernelGGL(k_trace_any<false>, dim3(g_trace), dim3(kBlock), 0, st, scene->dev, sq.o, sq.d, sq.c, (const float*)nullptr, &ctr->n_shadow, (uint32_t)nb, L, (uint8_t*)nullptr, ctr);
+            tm.end(3);
+            cur ^= 1;
+        }
+    }
+    tm.begin(4);
+    hipLaunchKernelGGL(k_film_gather, dim3(grid_for(ctx, (uint64_t)ds.film_w * ds.film_h, 8)), dim3(kBlock), 0, st, dsp, (const float*)ctx->table.p, L, spp, seed, sample_offset, (float4*)d_film);
+    tm.end(4);
+    HIP_TRY(ctx, hipEventRecord(e1, st));
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    ctx->last_L_count = total_slots;
+    if (!out_is_device) HIP_TRY(ctx, hipMemcpy(out, d_film, film_bytes, hipMemcpyDeviceToHost));
+    if (stats) {
+        std::memset(stats, 0, sizeof *stats);
+        Counters h;
+        HIP_TRY(ctx, hipMemcpy(&h, ctr, sizeof h, hipMemcpyDeviceToHost));
+        stats->camera_samples = total_slots;
+        stats->closest_rays = h.closest_total;
+        stats->shadow_rays = h.shadow_total;
+        stats->nodes_visited = h.nodes_closest;
+        stats->prims_tested = h.prims_closest;
+        stats->nodes_visited_shadow = h.nodes_shadow;
+        stats->prims_tested_shadow = h.prims_shadow;
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        stats->ms_total = ms;
+        stats->ms_raygen = tm.total(0, &stats->launches_raygen);
+        stats->ms_trace_closest = tm.total(1, &stats->launches_trace_closest);
+        stats->ms_shade = tm.total(2, &stats->launches_shade);
+        stats->ms_trace_any = tm.total(3, &stats->launches_trace_any);
+        stats->ms_film = tm.total(4, &stats->launches_film);
+        stats->n_batches = n_batches;
+        stats->max_depth_reached = (uint32_t)max_depth;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return 0;
+}
+
+// Stage host rays into SoA device buffers (scratch[0..2]) and return their count-checked size.
+int stage_rays(trhip_ctx* ctx, const float* rays, uint64_t n) {
+    if (n >= (1ull << 31)) return fail(ctx, TRHIP_ERR_INVALID, "too many rays in one call");
+    if (int rc = upload(ctx, ctx->scratch[3], rays, n * 8 * sizeof(float))) return rc;
+    if (int rc = ensure(ctx, ctx->scratch[0], n * sizeof(float4))) return rc;
+    if (int rc = ensure(ctx, ctx->scratch[1], n * sizeof(float4))) return rc;
+    if (int rc = ensure(ctx, ctx->scratch[2], n * sizeof(float))) return rc;
+    if (n) hipLaunchKernelGGL(k_prepare_rays, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const float*)ctx->scratch[3].p, (uint32_t)n, (float4*)ctx->scratch[0].p,
+                              (float4*)ctx->scratch[1].p, (float*)ctx->scratch[2].p);
+    return 0;
+}
+
+}  // namespace
+
+// ---- C ABI ------------------------------------------------------------------------------------------------------------------------
+extern "C" {
+
+int trhip_version(void) { return 1000; }
+
+int trhip_init(trhip_ctx** out, int device_id) {
+    if (!out) return fail(nullptr, TRHIP_ERR_INVALID, "ctx out pointer is null");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0) return fail(nullptr, TRHIP_ERR_HIP, "no HIP device available (%s): libtracehip has no CPU fallback", hipGetErrorString(e));
+    if (device_id < 0 || device_id >= n) return fail(nullptr, TRHIP_ERR_INVALID, "device %d out of range (%d devices)", device_id, n);
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess) return fail(nullptr, TRHIP_ERR_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return fail(nullptr, TRHIP_ERR_HIP, "device %d is %s; this library is built for gfx950 only", device_id, prop.gcnArchName);
+    auto ctx = new trhip_ctx();
+    ctx->device = device_id;
+    ctx->num_cu = prop.multiProcessorCount;
+    if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreate(&ctx->stream)) != hipSuccess) {
+        delete ctx;
+        return fail(nullptr, TRHIP_ERR_HIP, "stream creation failed: %s", hipGetErrorString(e));
+    }
+    *out = ctx;
+    return 0;
+}
+void trhip_shutdown(trhip_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    for (auto& a : ctx->q)
+        for (auto& b : a) release(b);
+    for (auto& b : ctx->sq) release(b);
+    for (auto& b : ctx->scratch) release(b);
+    release(ctx->hits);
+    release(ctx->Lbuf);
+    release(ctx->counters);
+    release(ctx->sensor);
+    release(ctx->table);
+    release(ctx->film);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+const char* trhip_last_error(const trhip_ctx* ctx) { return ctx ? ctx->err.c_str() : g_init_error.c_str(); }
+
+int trhip_set_option(trhip_ctx* ctx, const char* name, int64_t value) {
+    if (!ctx || !name) return fail(ctx, TRHIP_ERR_INVALID, "null argument");
+    if (!std::strcmp(name, "count_visits"))
+        ctx->count_visits = value != 0;
+    else if (!std::strcmp(name, "timing"))
+        ctx->timing = value != 0;
+    else if (!std::strcmp(name, "batch_paths")) {
+        if (value < 1) return fail(ctx, TRHIP_ERR_INVALID, "batch_paths must be positive");
+        ctx->batch_paths = (uint64_t)value;
+    } else
+        return fail(ctx, TRHIP_ERR_INVALID, "unknown option %s", name);
+    return 0;
+}
+
+int trhip_scene_new(trhip_ctx* ctx, trhip_scene** out) {
+    if (!ctx || !out) return fail(ctx, TRHIP_ERR_INVALID, "null argument");
+    auto s = new trhip_scene();
+    s->ctx = ctx;
+    *out = s;
+    return 0;
+}
+void trhip_scene_free(trhip_scene* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->ctx->device);
+    release(s->d_nodes);
+    release(s->d_prims);
+    release(s->d_nrm);
+    release(s->d_spheres);
+    release(s->d_materials);
+    release(s->d_lights);
+    delete s;
+}
+int trhip_scene_add_material(trhip_scene* s, int kind, const float* params, int n_params, uint32_t* id_out) {
+    if (!s || !params) return fail(s ? s->ctx : nullptr, TRHIP_ERR_INVALID, "null argument");
+    MaterialRec m;
+    if (build_material(kind, params, n_params, m)) return fail(s->ctx, TRHIP_ERR_INVALID, "bad material kind %d / parameter count %d", kind, n_params);
+    if (s->materials.size() >= PRIM_NO_MATERIAL) return fail(s->ctx, TRHIP_ERR_INVALID, "too many materials");
+    s->materials.push_back(m);
+    if (id_out) *id_out = (uint32_t)s->materials.size() - 1;
+    s->committed = false;
+    return 0;
+}
+int trhip_scene_add_triangles(trhip_scene* s, const float* xyz, uint32_t n_verts, const uint32_t* idx, uint32_t n_tris, const float* normals, const uint32_t* mat, int flip,
+                              uint32_t* first_out) {
+    if (!s || !xyz || !idx) return fail(s ? s->ctx : nullptr, TRHIP_ERR_INVALID, "null argument");
+    const uint32_t first = (uint32_t)s->prims.size();
+    s->prims.reserve(s->prims.size() + n_tris);
+    for (uint32_t k = 0; k < n_tris; ++k) {
+        HostPrim p;
+        std::memset(&p, 0, sizeof p);
+        p.kind = 0;
+        for (int j = 0; j < 3; ++j) {
+            const uint32_t vi = idx[3 * (size_t)k + j];
+            if (vi < 1 || vi > n_verts) return fail(s->ctx, TRHIP_ERR_INVALID, "triangle %u: index %u outside 1..%u (indices are 1-based)", k, vi, n_verts);
+            std::memcpy(&p.v[3 * j], &xyz[3 * (size_t)(vi - 1)], 3 * sizeof(float));
+            if (normals) std::memcpy(&p.n[3 * j], &normals[3 * (size_t)(vi - 1)], 3 * sizeof(float));
+        }
+        uint32_t m = mat ? mat[k] : PRIM_NO_MATERIAL;
+        if (mat && m >= s->materials.size()) return fail(s->ctx, TRHIP_ERR_INVALID, "triangle %u: material %u not defined", k, m);
+        p.meta = (m & PRIM_MATERIAL_MASK) | (normals ? PRIM_HAS_NORMALS : 0u) | (flip ? PRIM_FLIP : 0u);
+        s->prims.push_back(p);
+    }
+    if (first_out) *first_out = first;
+    s->committed = false;
+    return 0;
+}
+int trhip_scene_add_sphere(trhip_scene* s, const float* o2w, const float* o2w_inv, int reverse, float radius, float z_min, float z_max, float phi_max_deg, uint32_t material,
+                           uint32_t* prim_out) {
+    if (!s || !o2w || !o2w_inv) return fail(s ? s->ctx : nullptr, TRHIP_ERR_INVALID, "null argument");
+    if (material != PRIM_NO_MATERIAL && material >= s->materials.size()) return fail(s->ctx, TRHIP_ERR_INVALID, "material %u not defined", material);
+    SphereRec r;
+    std::memset(&r, 0, sizeof r);
+    std::memcpy(r.o2w, o2w, sizeof r.o2w);
+    std::memcpy(r.o2w_inv, o2w_inv, sizeof r.o2w_inv);
+    r.radius = radius;  // Sphere ctor sphere.jl:13-26
+    r.z_min = jclamp(jmin(z_min, z_max), -radius, radius);
+    r.z_max = jclamp(jmax(z_min, z_max), -radius, radius);
+    r.theta_min = tm_acosf(jclamp(jmin(z_min, z_max) / radius, -1.0f, 1.0f));
+    r.theta_max = tm_acosf(jclamp(jmax(z_min, z_max) / radius, -1.0f, 1.0f));
+    r.phi_max = deg2rad(jclamp(phi_max_deg, 0.0f, 360.0f));
+    const bool swaps = det3(o2w) < 0.0f;  // transformations.jl:161-163
+    r.flip = ((reverse != 0) != swaps) ? 1u : 0u;
+    HostPrim p;
+    std::memset(&p, 0, sizeof p);
+    p.kind = 1;
+    p.sphere_id = (uint32_t)s->spheres.size();
+    p.meta = (material & PRIM_MATERIAL_MASK) | PRIM_SPHERE;
+    s->spheres.push_back(r);
+    s->sphere_bounds.push_back(sphere_world_bound(r));
+    if (prim_out) *prim_out = (uint32_t)s->prims.size();
+    s->prims.push_back(p);
+    s->committed = false;
+    return 0;
+}
+static int add_light(trhip_scene* s, int kind, const float* l2w, const float* l2w_inv, const float* I, float total_deg, float falloff_deg) {
+    if (!s || !l2w || !l2w_inv || !I) return fail(s ? s->ctx : nullptr, TRHIP_ERR_INVALID, "null argument");
+    LightRec l;
+    std::memset(&l, 0, sizeof l);
+    l.kind = kind;
+    const f3 pos = xf_point(l2w, splat3(0.0f));  // light_to_world(Point3f(0)) point.jl:23, spot.jl:16
+    l.position[0] = pos.x;
+    l.position[1] = pos.y;
+    l.position[2] = pos.z;
+    std::memcpy(l.I, I, 3 * sizeof(float));
+    if (kind == 1) {
+        l.cos_total_width = tm_cosf(deg2rad(total_deg));  // spot.jl:17
+        l.cos_falloff_start = tm_cosf(deg2rad(falloff_deg));
+    }
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) l.w2l[3 * r + c] = l2w_inv[4 * r + c];  // world_to_light = inv(light_to_world): .m = inv_m
+    s->lights.push_back(l);
+    s->committed = false;
+    return 0;
+}
+int trhip_scene_add_point_light(trhip_scene* s, const float* l2w, const float* l2w_inv, const float* I) { return add_light(s, 0, l2w, l2w_inv, I, 0, 0); }
+int trhip_scene_add_spot_light(trhip_scene* s, const float* l2w, const float* l2w_inv, const float* I, float total_deg, float falloff_deg) {
+    return add_light(s, 1, l2w, l2w_inv, I, total_deg, falloff_deg);
+}
+
+int trhip_scene_commit(trhip_scene* s, int max_node_primitives) {
+    if (!s) return fail(nullptr, TRHIP_ERR_INVALID, "null scene");
+    HIP_TRY(s->ctx, hipSetDevice(s->ctx->device));
+    std::vector<HostAABB> pb(s->prims.size());
+    for (size_t i = 0; i < s->prims.size(); ++i) {
+        const HostPrim& p = s->prims[i];
+        if (p.kind == 1) {
+            pb[i] = s->sphere_bounds[p.sphere_id];
+        } else {  // world_bound(triangle) triangle_mesh.jl:97
+            pb[i].reset();
+            for (int j = 0; j < 3; ++j) pb[i].grow_point(&p.v[3 * j]);
+        }
+    }
+    BVHBuilder builder(pb, max_node_primitives);
+    s->bvh = builder.build();
+    if (s->bvh.max_depth > (uint32_t)(kStackLds + kStackSpill))
+        return fail(s->ctx, TRHIP_ERR_UNSUPPORTED, "BVH depth %u exceeds the 64-entry traversal stack (bvh.jl:222)", s->bvh.max_depth);
+    return upload_scene(s);
+}
+int trhip_scene_bvh_size(const trhip_scene* s, uint32_t* n_nodes, uint32_t* n_prims) {
+    if (!s) return TRHIP_ERR_INVALID;
+    if (n_nodes) *n_nodes = (uint32_t)s->bvh.a.size();
+    if (n_prims) *n_prims = (uint32_t)s->bvh.order.size();
+    return 0;
+}
+int trhip_scene_get_bvh(const trhip_scene* s, float* bounds, uint32_t* a, uint32_t* flags, uint32_t* order) {
+    if (!s) return TRHIP_ERR_INVALID;
+    if (bounds) std::memcpy(bounds, s->bvh.bounds.data(), s->bvh.bounds.size() * sizeof(float));
+    if (a) std::memcpy(a, s->bvh.a.data(), s->bvh.a.size() * sizeof(uint32_t));
+    if (flags) std::memcpy(flags, s->bvh.flags.data(), s->bvh.flags.size() * sizeof(uint32_t));
+    if (order) std::memcpy(order, s->bvh.order.data(), s->bvh.order.size() * sizeof(uint32_t));
+    return 0;
+}
+int trhip_scene_set_bvh(trhip_scene* s, const float* bounds, const uint32_t* a, const uint32_t* flags, uint32_t n_nodes, const uint32_t* order, uint32_t n_prims) {
+    if (!s || !bounds || !a || !flags || !order) return fail(s ? s->ctx : nullptr, TRHIP_ERR_INVALID, "null argument");
+    for (uint32_t i = 0; i < n_prims; ++i)
+        if (order[i] >= s->prims.size()) return fail(s->ctx, TRHIP_ERR_INVALID, "prim_order[%u] = %u out of range", i, order[i]);
+    for (uint32_t i = 0; i < n_nodes; ++i) {
+        if ((flags[i] & 3u) == 3u) {
+            if ((uint64_t)a[i] + (flags[i] >> 2) > n_prims) return fail(s->ctx, TRHIP_ERR_INVALID, "leaf %u references primitives outside the list", i);
+        } else if (a[i] >= n_nodes || i + 1 >= n_nodes)
+            return fail(s->ctx, TRHIP_ERR_INVALID, "interior node %u has a child outside the array", i);
+    }
+    s->bvh.bounds.assign(bounds, bounds + 6 * (size_t)n_nodes);
+    s->bvh.a.assign(a, a + n_nodes);
+    s->bvh.flags.assign(flags, flags + n_nodes);
+    s->bvh.order.assign(order, order + n_prims);
+    s->bvh.max_depth = 0;
+    HIP_TRY(s->ctx, hipSetDevice(s->ctx->device));
+    return upload_scene(s);
+}
+
+int trhip_render_path(trhip_ctx* ctx, const trhip_scene* sc, const trhip_sensor* sn, uint32_t spp, int max_depth, uint64_t seed, uint32_t off, float* out, trhip_stats* st) {
+    return render_impl(ctx, sc, sn, 1, spp, max_depth, seed, off, out, false, st);
+}
+int trhip_render_path_device(trhip_ctx* ctx, const trhip_scene* sc, const trhip_sensor* sn, uint32_t spp, int max_depth, uint64_t seed, uint32_t off, void* d_out, trhip_stats* st) {
+    return render_impl(ctx, sc, sn, 1, spp, max_depth, seed, off, d_out, true, st);
+}
+int trhip_render_whitted(trhip_ctx* ctx, const trhip_scene* sc, const trhip_sensor* sn, uint32_t spp, int max_depth, uint64_t seed, uint32_t off, float* out, trhip_stats* st) {
+    return render_impl(ctx, sc, sn, 0, spp, max_depth, seed, off, out, false, st);
+}
+int trhip_render_whitted_device(trhip_ctx* ctx, const trhip_scene* sc, const trhip_sensor* sn, uint32_t spp, int max_depth, uint64_t seed, uint32_t off, void* d_out, trhip_stats* st) {
+    return render_impl(ctx, sc, sn, 0, spp, max_depth, seed, off, d_out, true, st);
+}
+int trhip_last_sample_radiance(trhip_ctx* ctx, float* out, uint64_t n_floats) {
+    if (!ctx || !out) return fail(ctx, TRHIP_ERR_INVALID, "null argument");
+    if (n_floats != ctx->last_L_count * 3) return fail(ctx, TRHIP_ERR_INVALID, "expected %llu floats", (unsigned long long)(ctx->last_L_count * 3));
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (int rc = ensure(ctx, ctx->scratch[0], n_floats * sizeof(float))) return rc;
+    const uint64_t n = ctx->last_L_count;
+    if (n) hipLaunchKernelGGL(k_export_L, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const float4*)ctx->Lbuf.p, n, (float*)ctx->scratch[0].p);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(out, ctx->scratch[0].p, n_floats * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+int trhip_film_to_rgb(trhip_ctx* ctx, const float* xyzw, uint32_t w, uint32_t h, float scale, float* out) {
+    if (!ctx || !xyzw || !out) return fail(ctx, TRHIP_ERR_INVALID, "null argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint32_t n = w * h;
+    if (int rc = upload(ctx, ctx->scratch[0], xyzw, (size_t)n * 4 * sizeof(float))) return rc;
+    if (int rc = ensure(ctx, ctx->scratch[1], (size_t)n * 3 * sizeof(float))) return rc;
+    if (n) hipLaunchKernelGGL(k_film_to_rgb, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, (const float4*)ctx->scratch[0].p, n, scale, (float*)ctx->scratch[1].p);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(out, ctx->scratch[1].p, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int trhip_trace_closest(trhip_ctx* ctx, const trhip_scene* sc, const float* rays, uint64_t n, trhip_hit* out) {
+    if (!ctx || !sc || !rays || !out) return fail(ctx, TRHIP_ERR_INVALID, "null argument");
+    if (!sc->committed) return fail(ctx, TRHIP_ERR_INVALID, "scene not committed");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (int rc = stage_rays(ctx, rays, n)) return rc;
+    if (int rc = ensure(ctx, ctx->hits, n * sizeof(float4))) return rc;
+    if (n) hipLaunchKernelGGL(k_trace_closest<false>, dim3(grid_for(ctx, n, 5)), dim3(kBlock), 0, ctx->stream, sc->dev, (const float4*)ctx->scratch[0].p, (const float4*)ctx->scratch[1].p,
+                              (const float*)ctx->scratch[2].p, (const uint32_t*)nullptr, (uint32_t)n, (float4*)ctx->hits.p, (Counters*)nullptr);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    static_assert(sizeof(trhip_hit) == sizeof(float4), "trhip_hit layout");
+    HIP_TRY(ctx, hipMemcpy(out, ctx->hits.p, n * sizeof(float4), hipMemcpyDeviceToHost));
+    return 0;
+}
+int trhip_trace_any(trhip_ctx* ctx, const trhip_scene* sc, const float* rays, uint64_t n, uint8_t* occluded) {
+    if (!ctx || !sc || !rays || !occluded) return fail(ctx, TRHIP_ERR_INVALID, "null argument");
+    if (!sc->committed) return fail(ctx, TRHIP_ERR_INVALID, "scene not committed");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (int rc = stage_rays(ctx, rays, n)) return rc;
+    if (int rc = ensure(ctx, ctx->hits, n)) return rc;
+    if (n) hipLaunchKernelGGL(k_trace_any<false>, dim3(grid_for(ctx, n, 5)), dim3(kBlock), 0, ctx->stream, sc->dev, (const float4*)ctx->scratch[0].p, (const float4*)ctx->scratch[1].p,
+                              (const float4*)nullptr, (const float*)ctx->scratch[2].p, (const uint32_t*)nullptr, (uint32_t)n, (float4*)nullptr, (uint8_t*)ctx->hits.p, (Counters*)nullptr);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(occluded, ctx->hits.p, n, hipMemcpyDeviceToHost));
+    return 0;
+}
+// d_rays: n*8 floats on the device (same layout as the host entry points); d_hits: n trhip_hit
+int trhip_trace_closest_device(trhip_ctx* ctx, const trhip_scene* sc, const void* d_rays, uint64_t n, void* d_hits, int repeat, double* avg_ms) {
+    if (!ctx || !sc || !d_rays || !d_hits) return fail(ctx, TRHIP_ERR_INVALID, "null argument");
+    if (!sc->committed) return fail(ctx, TRHIP_ERR_INVALID, "scene not committed");
+    if (n >= (1ull << 31)) return fail(ctx, TRHIP_ERR_INVALID, "too many rays");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    for (int j = 0; j < 2; ++j)
+        if (int rc = ensure(ctx, ctx->scratch[j], n * sizeof(float4))) return rc;
+    if (int rc = ensure(ctx, ctx->scratch[2], n * sizeof(float))) return rc;
+    if (int rc = ensure(ctx, ctx->counters, sizeof(Counters))) return rc;
+    if (n) hipLaunchKernelGGL(k_prepare_rays, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const float*)d_rays, (uint32_t)n, (float4*)ctx->scratch[0].p,
+                              (float4*)ctx->scratch[1].p, (float*)ctx->scratch[2].p);
+    HIP_TRY(ctx, hipMemsetAsync(ctx->counters.p, 0, sizeof(Counters), ctx->stream));
+    hipEvent_t e0, e1;
+    HIP_TRY(ctx, hipEventCreate(&e0));
+    HIP_TRY(ctx, hipEventCreate(&e1));
+    repeat = std::max(1, repeat);
+    HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
+    for (int r = 0; r < repeat; ++r) {
+        if (ctx->count_visits)
+            hipLaunchKernelGGL(k_trace_closest<true>, dim3(ctx->num_cu * 5), dim3(kBlock), 0, ctx->stream, sc->dev, (const float4*)ctx->scratch[0].p, (const float4*)ctx->scratch[1].p,
+                               (const float*)ctx->scratch[2].p, (const uint32_t*)nullptr, (uint32_t)n, (float4*)d_hits, (Counters*)ctx->counters.p);
+        else
+            hipLaunchKernelGGL(k_trace_closest<false>, dim3(ctx->num_cu * 5), dim3(kBlock), 0, ctx->stream, sc->dev, (const float4*)ctx->scratch[0].p, (const float4*)ctx->scratch[1].p,
+                               (const float*)ctx->scratch[2].p, (const uint32_t*)nullptr, (uint32_t)n, (float4*)d_hits, (Counters*)ctx->counters.p);
+    }
+    HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    if (avg_ms) *avg_ms = ms / repeat;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return 0;
+}
+int trhip_trace_any_device(trhip_ctx* ctx, const trhip_scene* sc, const void* d_rays, uint64_t n, void* d_occ, int repeat, double* avg_ms) {
+    if (!ctx || !sc || !d_rays || !d_occ) return fail(ctx, TRHIP_ERR_INVALID, "null argument");
+    if (!sc->committed) return fail(ctx, TRHIP_ERR_INVALID, "scene not committed");
+    if (n >= (1ull << 31)) return fail(ctx, TRHIP_ERR_INVALID, "too many rays");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    for (int j = 0; j < 2; ++j)
+        if (int rc = ensure(ctx, ctx->scratch[j], n * sizeof(float4))) return rc;
+    if (int rc = ensure(ctx, ctx->scratch[2], n * sizeof(float))) return rc;
+    if (int rc = ensure(ctx, ctx->counters, sizeof(Counters))) return rc;
+    if (n) hipLaunchKernelGGL(k_prepare_rays, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const float*)d_rays, (uint32_t)n, (float4*)ctx->scratch[0].p,
+                              (float4*)ctx->scratch[1].p, (float*)ctx->scratch[2].p);
+    HIP_TRY(ctx, hipMemsetAsync(ctx->counters.p, 0, sizeof(Counters), ctx->stream));
+    hipEvent_t e0, e1;
+    HIP_TRY(ctx, hipEventCreate(&e0));
+    HIP_TRY(ctx, hipEventCreate(&e1));
+    repeat = std::max(1, repeat);
+    HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
+    for (int r = 0; r < repeat; ++r) {
+        if (ctx->count_visits)
+            hipLaunchKernelGGL(k_trace_any<true>, dim3(ctx->num_cu * 5), dim3(kBlock), 0, ctx->stream, sc->dev, (const float4*)ctx->scratch[0].p, (const float4*)ctx->scratch[1].p,
+                               (const float4*)nullptr, (const float*)ctx->scratch[2].p, (const uint32_t*)nullptr, (uint32_t)n, (float4*)nullptr, (uint8_t*)d_occ, (Counters*)ctx->counters.p);
+        else
+            hipLaunchKernelGGL(k_trace_any<false>, dim3(ctx->num_cu * 5), dim3(kBlock), 0, ctx->stream, sc->dev, (const float4*)ctx->scratch[0].p, (const float4*)ctx->scratch[1].p,
+                               (const float4*)nullptr, (const float*)ctx->scratch[2].p, (const uint32_t*)nullptr, (uint32_t)n, (float4*)nullptr, (uint8_t*)d_occ, (Counters*)ctx->counters.p);
+    }
+    HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    if (avg_ms) *avg_ms = ms / repeat;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return 0;
+}
+// visit counters of the last *_device trace call (when "count_visits" is on): nodes, prims for closest then shadow
+int trhip_last_visit_counts(trhip_ctx* ctx, uint64_t* out4) {
+    if (!ctx || !out4 || !ctx->counters.p) return fail(ctx, TRHIP_ERR_INVALID, "no counters");
+    Counters h;
+    HIP_TRY(ctx, hipMemcpy(&h, ctx->counters.p, sizeof h, hipMemcpyDeviceToHost));
+    out4[0] = h.nodes_closest;
+    out4[1] = h.prims_closest;
+    out4[2] = h.nodes_shadow;
+    out4[3] = h.prims_shadow;
+    return 0;
+}
+
+int trhip_hit_geometry(trhip_ctx* ctx, const trhip_scene* sc, const float* rays, uint64_t n, float* out15) {
+    if (!ctx || !sc || !rays || !out15) return fail(ctx, TRHIP_ERR_INVALID, "null argument");
+    if (!sc->committed) return fail(ctx, TRHIP_ERR_INVALID, "scene not committed");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (int rc = stage_rays(ctx, rays, n)) return rc;
+    if (int rc = ensure(ctx, ctx->hits, n * sizeof(float4))) return rc;
+    if (int rc = ensure(ctx, ctx->film, n * 15 * sizeof(float))) return rc;
+    if (n) {
+        hipLaunchKernelGGL(k_trace_closest<false>, dim3(grid_for(ctx, n, 5)), dim3(kBlock), 0, ctx->stream, sc->dev, (const float4*)ctx->scratch[0].p, (const float4*)ctx->scratch[1].p,
+                           (const float*)ctx->scratch[2].p, (const uint32_t*)nullptr, (uint32_t)n, (float4*)ctx->hits.p, (Counters*)nullptr);
+        hipLaunchKernelGGL(k_hit_geometry, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, sc->dev, (const float4*)ctx->scratch[0].p, (const float4*)ctx->scratch[1].p,
+                           (const float4*)ctx->hits.p, (uint32_t)n, (float*)ctx->film.p);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(out15, ctx->film.p, n * 15 * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+int trhip_generate_rays(trhip_ctx* ctx, const trhip_sensor* sn, const float* samples5, uint64_t n, float* out8) {
+    if (!ctx || !sn || !samples5 || !out8) return fail(ctx, TRHIP_ERR_INVALID, "null argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DeviceSensor ds;
+    derive_sensor(sn, ds);
+    if (int rc = upload(ctx, ctx->sensor, &ds, sizeof ds)) return rc;
+    if (int rc = upload(ctx, ctx->scratch[0], samples5, n * 5 * sizeof(float))) return rc;
+    if (int rc = ensure(ctx, ctx->scratch[1], n * 8 * sizeof(float))) return rc;
+    if (n) hipLaunchKernelGGL(k_generate_rays, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const DeviceSensor*)ctx->sensor.p, (const float*)ctx->scratch[0].p, (uint32_t)n,
+                              (float*)ctx->scratch[1].p);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(out8, ctx->scratch[1].p, n * 8 * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+int trhip_bsdf_query(trhip_ctx* ctx, const trhip_scene* sc, uint32_t material, int multi, int mode, int flags, const float* frame9, const float* dirs6, uint64_t n, float* out8) {
+    if (!ctx || !sc || !frame9 || !dirs6 || !out8) return fail(ctx, TRHIP_ERR_INVALID, "null argument");
+    if (!sc->committed) return fail(ctx, TRHIP_ERR_INVALID, "scene not committed");
+    if (material >= sc->materials.size()) return fail(ctx, TRHIP_ERR_INVALID, "material %u not defined", material);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (int rc = upload(ctx, ctx->scratch[0], frame9, n * 9 * sizeof(float))) return rc;
+    if (int rc = upload(ctx, ctx->scratch[1], dirs6, n * 6 * sizeof(float))) return rc;
+    if (int rc = ensure(ctx, ctx->scratch[2], n * 8 * sizeof(float))) return rc;
+    if (n) hipLaunchKernelGGL(k_bsdf_query, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, sc->dev, material, multi, mode, flags, (const float*)ctx->scratch[0].p,
+                              (const float*)ctx->scratch[1].p, (uint32_t)n, (float*)ctx->scratch[2].p);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(out8, ctx->scratch[2].p, n * 8 * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+int trhip_film_accumulate(trhip_ctx* ctx, const trhip_sensor* sn, uint32_t spp, uint64_t seed, uint32_t sample_offset, const float* sample_L, float* out_xyzw) {
+    if (!ctx || !sn || !sample_L || !out_xyzw) return fail(ctx, TRHIP_ERR_INVALID, "null argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DeviceSensor ds;
+    derive_sensor(sn, ds);
+    const uint64_t n = (uint64_t)ds.sb_w * ds.sb_h * spp;
+    if (int rc = upload(ctx, ctx->sensor, &ds, sizeof ds)) return rc;
+    if (int rc = upload(ctx, ctx->table, sn->filter_table, 256 * sizeof(float))) return rc;
+    if (int rc = upload(ctx, ctx->scratch[0], sample_L, n * 3 * sizeof(float))) return rc;
+    if (int rc = ensure(ctx, ctx->Lbuf, n * sizeof(float4))) return rc;
+    const size_t film_bytes = (size_t)ds.film_w * ds.film_h * sizeof(float4);
+    if (int rc = ensure(ctx, ctx->film, film_bytes)) return rc;
+    if (n) hipLaunchKernelGGL(k_import_L, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const float*)ctx->scratch[0].p, n, (float4*)ctx->Lbuf.p);
+    hipLaunchKernelGGL(k_film_gather, dim3(grid_for(ctx, (uint64_t)ds.film_w * ds.film_h, 8)), dim3(kBlock), 0, ctx->stream, (const DeviceSensor*)ctx->sensor.p, (const float*)ctx->table.p,
+                       (const float4*)ctx->Lbuf.p, spp, seed, sample_offset, (float4*)ctx->film.p);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->last_L_count = n;
+    HIP_TRY(ctx, hipMemcpy(out_xyzw, ctx->film.p, film_bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+}  // extern "C"
+
+// Host utility: the deterministic elementary functions of include/trace_detmath.h for hosts that cannot include a C
+// header (the Python mirror needs tan() for perspective(), transformations.jl:128).  fn: 0 sin 1 cos 2 tan 3 atan2(y,x)
+// 4 acos 5 log.  This is specification math evaluated on the host, not a fallback of any device path.
+extern "C" int trhip_detmath_f32(int fn, const float* x, const float* y, uint64_t n, float* out) {
+    if (!x || !out || (fn == 3 && !y)) return TRHIP_ERR_INVALID;
+    for (uint64_t i = 0; i < n; ++i) {
+        switch (fn) {
+        case 0: out[i] = tm_sinf(x[i]); break;
+        case 1: out[i] = tm_cosf(x[i]); break;
+        case 2: out[i] = tm_tanf(x[i]); break;
+        case 3: out[i] = tm_atan2f(y[i], x[i]); break;
+        case 4: out[i] = tm_acosf(x[i]); break;
+        case 5: out[i] = tm_logf(x[i]); break;
+        default: return TRHIP_ERR_INVALID;
+        }
+    }
+    return 0;
+}
