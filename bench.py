@@ -1,0 +1,179 @@
+#!/usr/bin/env python
+"""bench.py — the reference's headline metric on MI355X: Mray/s (all bounces, closest-hit + shadow rays) at 1024x1024,
+depth 8 (BASELINE.json), PathIntegrator on the synthetic Cornell box (configs[1]) by default.
+
+    python bench.py --gpus N --steps K --warmup W [--workload cornell|shadows|mesh_64k|mesh_870k|mesh_1m] [--spp S]
+
+One "step" = one full render of the workload on every rank (weak scaling: each of the N ranks renders `spp` samples per
+pixel with its own sample-index range) followed, for N > 1, by the RCCL sum-reduce of the film accumulators to rank 0.
+Inputs (scene, BVH) are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def build_workload(T, name: str, res: int):
+    if name == "cornell":
+        return T.scenes.cornell_scene(), T.scenes.cornell_camera(res), "S-cornell: 2 spheres + 10 triangles, PointLight"
+    if name == "shadows":
+        return T.scenes.shadows_scene(), T.scenes.shadows_camera(res), "docs/src/shadows.md scene: 4 spheres + 4 triangles, PointLight"
+    if name in T.scenes.MESH_N:
+        n = T.scenes.MESH_N[name]
+        return T.scenes.mesh_scene(n), T.scenes.cornell_camera(res), f"S-mesh: Cornell box + {2 * n * n} triangle height field"
+    raise SystemExit(f"unknown workload {name}")
+
+
+def traversal_bytes(rays, nodes, prims, hit_bytes):
+    """per ray 32 B ray load + hit store (16 B closest / 1 B any) + 32 B per node visited + 48 B per primitive tested."""
+    return 32 * rays + hit_bytes * rays + 32 * nodes + 48 * prims
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="cornell")
+    ap.add_argument("--res", type=int, default=1024)
+    ap.add_argument("--spp", type=int, default=256)
+    ap.add_argument("--depth", type=int, default=8)
+    ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED0001)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-spp", type=int, default=0, help="spp of the bounded CPU-baseline sample (0 = auto)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import __graft_entry__ as graft
+    if rank == 0 or not os.path.exists(os.path.join(ROOT, "trace.jl_amd", "libtracehip.so")):
+        graft.build_library()
+    if world > 1:
+        dist.barrier()
+    T = graft.load_package()
+    ctx = T.Context(local_rank)
+
+    scene, cam, desc = build_workload(T, args.workload, args.res)
+    t0 = time.time()
+    flat = scene.flatten(ctx)  # BVH build + upload: outside the timed region
+    t_build = time.time() - t0
+    h, w = cam.film.size
+    film = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+    integ = T.PathIntegrator(cam, T.SeededSampler(args.spp, seed=args.seed, sample_offset=rank * args.spp), args.depth)
+
+    def step():
+        integ.render(scene, ctx, device_out=film.data_ptr())
+        if world > 1:
+            dist.reduce(film, dst=0, op=dist.ReduceOp.SUM)  # Film pixels are additive (film.jl:161-162, 190-191)
+        return integ.stats
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t_start = time.perf_counter()
+    agg = {"rays": 0, "samples": 0, "ms": {k: 0.0 for k in ("raygen", "trace_closest", "shade", "trace_any", "film")}, "launches": {}, "closest": 0, "shadow": 0}
+    for _ in range(args.steps):
+        st = step()
+        agg["closest"] += st.closest_rays
+        agg["shadow"] += st.shadow_rays
+        agg["samples"] += st.camera_samples
+        for k in agg["ms"]:
+            agg["ms"][k] += getattr(st, "ms_" + k)
+            agg["launches"][k] = agg["launches"].get(k, 0) + getattr(st, "launches_" + k)
+    sync()
+    elapsed = time.perf_counter() - t_start
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    counts = torch.tensor([agg["closest"] + agg["shadow"], agg["samples"]], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+    elapsed = float(tmax.item())
+    total_rays, total_samples = float(counts[0].item()), float(counts[1].item())
+
+    result = None
+    if rank == 0:
+        # ---- roofline of the dominant kernel (rank 0's launches), live HIP-event durations from the timed region ----
+        ctx.set_option("count_visits", 1)
+        integ.render(scene, ctx, device_out=film.data_ptr())  # untimed, instrumented: node / primitive visit counts
+        sv = integ.stats
+        ctx.set_option("count_visits", 0)
+        per_step = {
+            "trace_closest": traversal_bytes(sv.closest_rays, sv.nodes_visited, sv.prims_tested, 16),
+            "trace_any": traversal_bytes(sv.shadow_rays, sv.nodes_visited_shadow, sv.prims_tested_shadow, 1),
+            "shade": 364 * sv.closest_rays,   # §8(d): ≈364 B per path vertex (ray, hit, state, geometry, material in; next ray, shadow ray, state out)
+            "film": 16 * sv.camera_samples + 16 * h * w,
+            "raygen": 80 * sv.camera_samples,
+        }
+        dominant = max(agg["ms"], key=lambda k: agg["ms"][k])
+        dom_ms = agg["ms"][dominant] / max(1, agg["launches"][dominant])
+        dom_bytes = per_step[dominant] * args.steps / max(1, agg["launches"][dominant])
+        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        roofline = {"bound": "hbm", "kernel": "k_" + dominant + ("_path" if dominant == "shade" else ""), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "avg_launch_ms": round(dom_ms, 4), "launches": agg["launches"][dominant],
+                    "algorithmic_bytes_per_launch": int(dom_bytes),
+                    "visits_per_ray": {"closest_nodes": round(sv.nodes_visited / max(1, sv.closest_rays), 2), "closest_prims": round(sv.prims_tested / max(1, sv.closest_rays), 2),
+                                       "shadow_nodes": round(sv.nodes_visited_shadow / max(1, sv.shadow_rays), 2), "shadow_prims": round(sv.prims_tested_shadow / max(1, sv.shadow_rays), 2)},
+                    "kernel_ms_per_step": {k: round(v / args.steps, 3) for k, v in agg["ms"].items()},
+                    "kernel_GBps": {k: round(per_step[k] / (agg["ms"][k] / args.steps * 1e-3) / 1e9, 1) if agg["ms"][k] > 0 else None for k in per_step}}
+        # ---- CPU baseline: the oracle (faithful restatement, OpenMP over the reference's 16x16 tiles) on a bounded sample ----
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            graft.build_oracle()
+            import oracle_bridge as ob
+            osc = ob.OracleScene.from_scene(scene, bvh=flat.bvh())
+            threads = ob.lib().orc_num_threads()
+            cpu_spp = args.cpu_spp
+            if cpu_spp <= 0:  # calibrate on one pass, then size the sample for ~15 s
+                t1 = time.perf_counter()
+                osc.render(cam, "path", 1, args.depth, seed=args.seed, threads=threads)
+                one = time.perf_counter() - t1
+                cpu_spp = int(max(1, min(args.spp, round(15.0 / max(one, 1e-3)))))
+            t1 = time.perf_counter()
+            _, _, cst = osc.render(cam, "path", cpu_spp, args.depth, seed=args.seed, threads=threads)
+            dt = time.perf_counter() - t1
+            cpu = {"value": round((cst.closest_rays + cst.shadow_rays) / dt / 1e6, 3), "unit": "Mray/s", "cores": threads, "kind": "port",
+                   "sample": f"same scene, {args.res}x{args.res}, depth {args.depth}, {cpu_spp} spp of {args.spp} ({cst.camera_samples} camera samples, {dt:.1f} s)",
+                   "Msample_per_s": round(cst.camera_samples / dt / 1e6, 4)}
+        result = {
+            "metric": "Mray/s (all bounces)", "value": round(total_rays / elapsed / 1e6, 2), "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "Msample_per_s": round(total_samples / elapsed / 1e6, 3),
+            "config": {"workload": f"{args.workload}: {desc}; {args.res}x{args.res}, {args.spp} spp per GPU, max depth {args.depth}, PathIntegrator, seed {args.seed:#x}",
+                       "rays_per_step": int(total_rays / args.steps), "samples_per_step": int(total_samples / args.steps), "bvh_build_upload_s": round(t_build, 3),
+                       "parallelism": f"sample-index sharding x{world} + RCCL film sum-reduce" if world > 1 else "single GPU"},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return result
+
+
+if __name__ == "__main__":
+    main()

@@ -219,7 +219,12 @@ class OracleScene:
         i = 0
         while i < len(prims):
             p = prims[i]
-            if isinstance(p.shape, T.Sphere):
+            if isinstance(p, T.MeshPrimitives):
+                mesh = p.mesh
+                idx = mesh.indices.reshape(-1, 3)
+                s.add_triangle_mesh(mesh.core.object_to_world, mesh.core.reverse_orientation, mesh.object_vertices, idx, mesh.normals, np.full(idx.shape[0], mid(p.material), np.int32))
+                i += 1
+            elif isinstance(p.shape, T.Sphere):
                 sp = p.shape
                 s.add_sphere(sp.core.object_to_world, sp.core.reverse_orientation, float(sp.radius), float(sp.z_min), float(sp.z_max), float(sp.phi_max_deg), mid(p.material))
                 i += 1

@@ -285,6 +285,18 @@ class GeometricPrimitive:  # primitive.jl:1-9
     material: object = None
 
 
+@dataclass
+class MeshPrimitives:
+    """Bulk form of `[GeometricPrimitive(t, material) for t in create_triangle_mesh(...)]` for million-triangle meshes
+    (one Python object instead of one per triangle); expands to exactly that list, in order."""
+    mesh: "TriangleMesh"
+    material: object = None
+
+
+def create_mesh_primitives(core: ShapeCore, indices, vertices, normals=None, material=None) -> MeshPrimitives:
+    return MeshPrimitives(TriangleMesh(core, indices, vertices, normals), material)
+
+
 class BVHAccel:  # accel/bvh.jl:50-79: the tree itself is built inside the library at Scene flattening
     def __init__(self, primitives: Sequence[GeometricPrimitive], max_node_primitives: int = 1):
         self.primitives = list(primitives)
@@ -477,12 +489,22 @@ class FlatScene:
         i = 0
         while i < len(prims):
             p = prims[i]
-            if isinstance(p.shape, Sphere):
+            if not isinstance(p, MeshPrimitives) and isinstance(p.shape, Sphere):
                 s = p.shape
                 o2w = s.core.object_to_world
                 m, im = _ffi.f32(o2w.m), _ffi.f32(o2w.inv_m)
                 ctx.check(L.trhip_scene_add_sphere(self._h, _ffi.fptr(m), _ffi.fptr(im), int(s.core.reverse_orientation), float(s.radius), float(s.z_min), float(s.z_max),
                                                    float(s.phi_max_deg), material_id(p.material), None))
+                i += 1
+            elif isinstance(p, MeshPrimitives):
+                mesh = p.mesh
+                idx = np.ascontiguousarray(mesh.indices.reshape(-1, 3), dtype=np.uint32)
+                mats = np.full(idx.shape[0], material_id(p.material), dtype=np.uint32)
+                core = mesh.core
+                flip = int(core.reverse_orientation != core.transform_swaps_handedness)
+                nrm = mesh.normals
+                ctx.check(L.trhip_scene_add_triangles(self._h, _ffi.fptr(mesh.vertices), mesh.vertices.shape[0], _ffi.u32ptr(idx), idx.shape[0],
+                                                      _ffi.fptr(nrm) if nrm is not None else None, _ffi.u32ptr(mats), flip, None))
                 i += 1
             elif isinstance(p.shape, Triangle):
                 # batch consecutive triangles of the same mesh into one call (caller order is preserved)

@@ -170,8 +170,7 @@ def mesh_scene(n: int, seed: int = 1234):
     prims, _ = cornell_primitives()
     grey = T.MatteMaterial(T.ConstantTexture(T.RGBSpectrum(0.8)), T.ConstantTexture(0.0))
     verts, idx, nrm = heightfield_mesh(n, seed)
-    tris = T.create_triangle_mesh(T.ShapeCore(T.translate([0, 0, 0]), False), idx.size // 3, idx, verts.shape[0], verts, nrm)
-    prims = prims + [T.GeometricPrimitive(t, grey) for t in tris]
+    prims = prims + [T.create_mesh_primitives(T.ShapeCore(T.translate([0, 0, 0]), False), idx, verts, nrm, grey)]
     return T.Scene(cornell_lights(), T.BVHAccel(prims, 1))
 
 
