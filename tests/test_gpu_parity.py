@@ -8,6 +8,15 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=[2, 1], ids=["trace2", "trace1"])
+def traversal(request, ctx):
+    """Every parity test runs with both traversal kernels: 2 = k_trace2 (children-in-parent nodes, per-lane ray
+    replacement; the default), 1 = the literal accel/bvh.jl loop."""
+    ctx.set_option("traversal", request.param)
+    yield request.param
+    ctx.set_option("traversal", 2)
+
+
 def bits(a):
     return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
 

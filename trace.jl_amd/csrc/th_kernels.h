@@ -28,10 +28,14 @@ struct ShadowQueue {
     float4* d;  // d.xyz, as_float(poison bits: bit c set = β[c] is not finite)
     float4* c;  // β·Ld to add when unoccluded
 };
+constexpr int kMaxDepth = 62;
 struct Counters {  // device-resident
-    uint32_t n_queue[2];
-    uint32_t n_shadow;
-    uint32_t pad;
+    // per wavefront batch (zeroed by one memset at batch start): index d = path depth - 1
+    uint32_t n_queue[kMaxDepth + 2];       // live paths entering depth d+1
+    uint32_t n_shadow[kMaxDepth + 2];      // shadow rays emitted at depth d+1
+    uint32_t work_closest[kMaxDepth + 2];  // k_trace2 dynamic ray fetch cursors
+    uint32_t work_shadow[kMaxDepth + 2];
+    // per render call
     unsigned long long closest_total, shadow_total, nodes_closest, prims_closest, nodes_shadow, prims_shadow;
 };
 
@@ -315,7 +319,7 @@ __global__ __launch_bounds__(kBlock) void k_shade_path(DeviceScene sc, const Dev
                                                        const float4* __restrict__ hits, float4* __restrict__ L, Counters* ctr, int cur, int depth, int max_depth,
                                                        uint64_t seed, uint32_t sample_offset) {
     const DeviceSensor& se = *sep;
-    const uint32_t n = ctr->n_queue[cur];
+    const uint32_t n = ctr->n_queue[depth - 1];
     const uint32_t n_round = (n + 63u) & ~63u;  // keep whole waves in the loop so ballots see every lane
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n_round; i += gridDim.x * kBlock) {
         bool want_shadow = false, want_next = false;
@@ -401,13 +405,13 @@ __global__ __launch_bounds__(kBlock) void k_shade_path(DeviceScene sc, const Dev
                 }
             }
         }
-        const uint32_t si = wave_compact(want_shadow, &ctr->n_shadow);
+        const uint32_t si = wave_compact(want_shadow, &ctr->n_shadow[depth - 1]);
         if (want_shadow) {
             sq.o[si] = so4;
             sq.d[si] = sd4;
             sq.c[si] = sc4;
         }
-        const uint32_t ni = wave_compact(want_next, &ctr->n_queue[cur ^ 1]);
+        const uint32_t ni = wave_compact(want_next, &ctr->n_queue[depth]);
         if (want_next) {
             qout.o[ni] = no4;
             qout.d[ni] = nd4;

@@ -1,0 +1,271 @@
+// th_trace2.h — traversal kernel v2: same results, bit for bit, as accel/bvh.jl:212-299 walked in the reference's order
+// (k_trace in th_kernels.h is the literal form), restructured for gfx950:
+//
+//  * "children-in-parent" nodes (64 B, one 4 x dwordx4 burst per interior node): both child boxes + child refs + split
+//    axis.  Every node's box is still tested with the reference's slab arithmetic (bounds.jl:186-206) exactly once; the
+//    far child is tested when its parent is fetched instead of when it is popped, so its t_max-dependent clause
+//    (`tx_min < ray.t_max`) is deferred: tx_min travels on the stack and is compared with the CURRENT t_max at pop time,
+//    which is what the reference evaluates then (t_max can even grow: sphere.jl:137-138 / primitive.jl:17, A.8).
+//    Leaves are not fetched at all (a leaf is a child ref = first primitive slot + count).  Dependent loads per ray
+//    halve.
+//  * persistent waves with per-lane ray replacement: a lane whose ray finished pulls the next ray index (one atomic per
+//    wave per refill, ballot + popcount ranks) instead of idling until the slowest of its 63 neighbours is done —
+//    visit counts per ray are heavy-tailed (grazing rays over a height field visit 10-100x the mean).
+//  * stack entries {ref, tx_min}: 16 levels per lane in LDS as stack[level][lane] (conflict-free), deeper levels in a
+//    global overflow slab laid out [level][thread] (coalesced); 64 levels in total like bvh.jl:222.
+#pragma once
+#include "th_kernels.h"
+
+namespace th {
+
+constexpr int kStack2Lds = 16;
+constexpr int kStack2Total = 64;
+constexpr uint32_t kRefNone = 0xffffffffu;
+
+struct WideScene {            // device view of the v2 node array
+    const float4* wnodes;     // 4 float4 per interior node
+    float root_box[6];        // bounds of flat node 0 (tested first, bvh.jl:226)
+    uint32_t root_ref, root_cnt;  // root_cnt > 0: the root is a leaf with that many primitives starting at root_ref
+    uint32_t n_wnodes;
+};
+
+// The t_max-independent part of bounds.jl:186-206; returns false when the box is certainly missed, otherwise tx_min (to be
+// compared with t_max by the caller: `tx_min < ray.t_max`).
+TH_D bool slab_test2(float bx0, float by0, float bz0, float bx1, float by1, float bz1, f3 o, f3 inv_d, bool negx, bool negy, bool negz, float& tmin_out) {
+    float tx_min = ((negx ? bx1 : bx0) - o.x) * inv_d.x;
+    float tx_max = ((negx ? bx0 : bx1) - o.x) * inv_d.x;
+    const float ty_min = ((negy ? by1 : by0) - o.y) * inv_d.y;
+    const float ty_max = ((negy ? by0 : by1) - o.y) * inv_d.y;
+    if (tx_min > ty_max || ty_min > tx_max) return false;
+    if (ty_min > tx_min) tx_min = ty_min;
+    if (ty_max > tx_max) tx_max = ty_max;
+    const float tz_min = ((negz ? bz1 : bz0) - o.z) * inv_d.z;
+    const float tz_max = ((negz ? bz0 : bz1) - o.z) * inv_d.z;
+    if (tx_min > tz_max || tz_min > tx_max) return false;
+    if (tz_min > tx_min) tx_min = tz_min;
+    if (tz_max < tx_max) tx_max = tz_max;
+    tmin_out = tx_min;
+    return tx_max > 0.0f;
+}
+
+struct TraceOut {
+    float4* hits;            // closest: {t, prim, b1, b2}
+    float4* L;               // any-hit + accumulate mode
+    const float4* contrib;
+    uint8_t* occluded;       // any-hit, plain mode
+};
+
+template <bool ANY, bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_trace2(DeviceScene sc, WideScene ws, const float4* __restrict__ ro, const float4* __restrict__ rd, const float* __restrict__ tmax_or_null,
+                                                   const uint32_t* __restrict__ count_ptr, uint32_t n_max, TraceOut out, uint32_t* __restrict__ work_counter,
+                                                   uint2* __restrict__ overflow, Counters* ctr) {
+    __shared__ uint32_t s_ref[kStack2Lds][kBlock];
+    __shared__ float s_tmin[kStack2Lds][kBlock];
+    const uint32_t n = count_ptr ? min(*count_ptr, n_max) : n_max;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t gthreads = gridDim.x * kBlock;
+    const uint32_t gtid = blockIdx.x * kBlock + tid;
+    const uint32_t lane = lane_id();
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+
+    bool active = false, exhausted = false;
+    uint32_t idx = 0, cur = kRefNone, cur_cnt = 0;
+    int sp = 0;
+    f3 o = splat3(0.0f), d = splat3(0.0f), inv_d = splat3(0.0f);
+    bool negx = false, negy = false, negz = false;
+    float t_max = 0.0f, b1 = 0.0f, b2 = 0.0f, slot_w = 0.0f, flag_w = 0.0f;
+    int hit_prim = -1;
+    bool found = false;
+    uint32_t nn = 0, np = 0;
+
+    while (true) {
+        // ---- refill idle lanes -------------------------------------------------------------------------------------------
+        const unsigned long long idle = __ballot(!active);
+        const uint32_t n_idle = (uint32_t)__popcll(idle);
+        if (n_idle == 64u || (!exhausted && n_idle >= 12u)) {
+            if (!exhausted) {
+                uint32_t base = 0;
+                const int leader = __ffsll((long long)idle) - 1;
+                if ((int)lane == leader) base = atomicAdd(work_counter, n_idle);
+                base = __shfl(base, leader);
+                if (base + n_idle >= n) exhausted = true;
+                if (!active) {
+                    idx = base + (uint32_t)__popcll(idle & lt_mask);
+                    if (idx < n) {
+                        const float4 o4 = ro[idx], d4 = rd[idx];
+                        o = mk3(o4.x, o4.y, o4.z);
+                        d = mk3(d4.x, d4.y, d4.z);
+                        slot_w = o4.w;
+                        flag_w = d4.w;
+                        inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                        negx = d.x < 0.0f;
+                        negy = d.y < 0.0f;
+                        negz = d.z < 0.0f;
+                        t_max = tmax_or_null ? tmax_or_null[idx] : kInf;
+                        sp = 0;
+                        found = false;
+                        hit_prim = -1;
+                        b1 = b2 = 0.0f;
+                        active = true;
+                        float tmin;
+                        if (COUNT) nn++;
+                        if (ws.root_ref != kRefNone && slab_test2(ws.root_box[0], ws.root_box[1], ws.root_box[2], ws.root_box[3], ws.root_box[4], ws.root_box[5], o, inv_d, negx, negy, negz, tmin) &&
+                            tmin < t_max) {
+                            cur = ws.root_ref;
+                            cur_cnt = ws.root_cnt;
+                        } else {
+                            cur = kRefNone;
+                        }
+                    }
+                }
+            }
+            if (__ballot(active) == 0ull) break;
+        }
+        // ---- a few traversal steps ------------------------------------------------------------------------------------------
+#pragma unroll 1
+        for (int rep = 0; rep < 4; ++rep) {
+            if (!active) continue;
+            bool pop = true;
+            bool finished = false;
+            if (cur == kRefNone) {
+                pop = true;
+            } else if (cur_cnt > 0) {
+                // leaf: primitives in slot order, later equal-t hit wins (bvh.jl:229-237, triangle_mesh.jl:211-214)
+                for (uint32_t k = 0; k < cur_cnt; ++k) {
+                    const uint32_t slot = cur + k;
+                    const float4 p0 = sc.prims[3 * slot];
+                    const float4 p1 = sc.prims[3 * slot + 1], p2 = sc.prims[3 * slot + 2];
+                    const uint32_t meta = __float_as_uint(p0.w);
+                    if (COUNT) np++;
+                    if (meta & PRIM_SPHERE) {
+                        SphereHit sh;
+                        if (sphere_intersect(sc.spheres[__float_as_uint(p0.x)], o, d, t_max, sh)) {
+                            if (ANY) {
+                                found = true;
+                                finished = true;
+                                break;
+                            }
+                            t_max = sh.t;
+                            found = true;
+                            hit_prim = (int)slot;
+                            b1 = b2 = 0.0f;
+                        }
+                    } else {
+                        TriTest tt;
+                        if (tri_intersect<!ANY>(mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z), o, d, t_max, &tt)) {
+                            if (ANY) {
+                                found = true;
+                                finished = true;
+                                break;
+                            }
+                            t_max = tt.t;
+                            found = true;
+                            hit_prim = (int)slot;
+                            b1 = tt.bary.x;
+                            b2 = tt.bary.y;
+                        }
+                    }
+                }
+            } else {
+                // interior: one 64-byte burst, both child boxes
+                const float4 a0 = ws.wnodes[4 * (size_t)cur], a1 = ws.wnodes[4 * (size_t)cur + 1], a2 = ws.wnodes[4 * (size_t)cur + 2], a3 = ws.wnodes[4 * (size_t)cur + 3];
+                if (COUNT) nn += 2;  // two node boxes tested (the reference would visit these two nodes)
+                float tl, tr;
+                const bool hl = slab_test2(a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, o, inv_d, negx, negy, negz, tl);
+                const bool hr = slab_test2(a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, o, inv_d, negx, negy, negz, tr);
+                const uint32_t lref = __float_as_uint(a3.x), rref = __float_as_uint(a3.y), packed = __float_as_uint(a3.z);
+                const uint32_t lcnt = packed & 0xffu, rcnt = (packed >> 8) & 0xffu, axis = (packed >> 16) & 3u;
+                const bool neg = axis == 0 ? negx : (axis == 1 ? negy : negz);  // bvh.jl:239: dir_is_neg[split_axis] == 2 -> second child first
+                const bool hn = neg ? hr : hl, hf = neg ? hl : hr;
+                const float tn = neg ? tr : tl, tf = neg ? tl : tr;
+                const uint32_t nref = neg ? rref : lref, fref = neg ? lref : rref, ncnt = neg ? rcnt : lcnt, fcnt = neg ? lcnt : rcnt;
+                const bool near_ok = hn && tn < t_max;
+                if (near_ok) {
+                    if (hf) {  // push the far child with its tx_min; the t_max clause is re-evaluated at pop time
+                        const uint32_t enc = fref | (fcnt << 24);
+                        if (sp < kStack2Lds) {
+                            s_ref[sp][tid] = enc;
+                            s_tmin[sp][tid] = tf;
+                        } else if (sp < kStack2Total) {
+                            overflow[(size_t)(sp - kStack2Lds) * gthreads + gtid] = make_uint2(enc, __float_as_uint(tf));
+                        }
+                        sp++;
+                    }
+                    cur = nref;
+                    cur_cnt = ncnt;
+                    pop = false;
+                } else if (hf && tf < t_max) {  // near child missed: the reference pops the far child next, with the same t_max
+                    cur = fref;
+                    cur_cnt = fcnt;
+                    pop = false;
+                }
+            }
+            if (pop && !finished) {
+                finished = true;
+                while (sp > 0) {
+                    sp--;
+                    uint32_t enc;
+                    float tm;
+                    if (sp < kStack2Lds) {
+                        enc = s_ref[sp][tid];
+                        tm = s_tmin[sp][tid];
+                    } else if (sp < kStack2Total) {
+                        const uint2 e = overflow[(size_t)(sp - kStack2Lds) * gthreads + gtid];
+                        enc = e.x;
+                        tm = __uint_as_float(e.y);
+                    } else {
+                        continue;  // beyond 64 levels the reference throws (bvh.jl:222); entries were dropped
+                    }
+                    if (tm < t_max) {
+                        cur = enc & 0x00ffffffu;
+                        cur_cnt = enc >> 24;
+                        finished = false;
+                        break;
+                    }
+                }
+            }
+            if (finished) {
+                active = false;
+                if (ANY) {
+                    if (out.L) {
+                        const uint32_t slot = __float_as_uint(slot_w);
+                        if (!found) {
+                            const float4 c = out.contrib[idx];
+                            float4 l = out.L[slot];
+                            l.x += c.x;
+                            l.y += c.y;
+                            l.z += c.z;
+                            out.L[slot] = l;
+                        } else {
+                            const uint32_t poison = __float_as_uint(flag_w);
+                            if (poison) {
+                                float4 l = out.L[slot];
+                                const float nanv = __builtin_nanf("");
+                                if (poison & 1u) l.x += nanv;
+                                if (poison & 2u) l.y += nanv;
+                                if (poison & 4u) l.z += nanv;
+                                out.L[slot] = l;
+                            }
+                        }
+                    } else {
+                        out.occluded[idx] = found ? 1 : 0;
+                    }
+                } else {
+                    out.hits[idx] = make_float4(found ? t_max : kInf, __int_as_float(found ? hit_prim : -1), b1, b2);
+                }
+            }
+        }
+    }
+    if (ctr) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(ANY ? &ctr->shadow_total : &ctr->closest_total, (unsigned long long)n);
+        if (COUNT) {
+            const unsigned long long sn = wave_sum(nn), spr = wave_sum(np);
+            if (lane_id() == 0) {
+                atomicAdd(ANY ? &ctr->nodes_shadow : &ctr->nodes_closest, sn);
+                atomicAdd(ANY ? &ctr->prims_shadow : &ctr->prims_closest, spr);
+            }
+        }
+    }
+}
+
+}  // namespace th

@@ -13,6 +13,7 @@
 #include "../../include/tracehip.h"
 #include "th_bvh.h"
 #include "th_kernels.h"
+#include "th_trace2.h"
 
 using namespace th;
 
@@ -35,8 +36,9 @@ struct trhip_ctx {
     bool count_visits = false;
     bool timing = true;
     uint64_t batch_paths = 16ull << 20;
+    int traversal = 2;  // 1 = literal accel/bvh.jl loop, 2 = children-in-parent nodes + per-lane ray replacement
     // workspace (grown on demand, reused across calls)
-    DevBuf q[2][3], sq[3], hits, Lbuf, counters, sensor, table, film, scratch[4];
+    DevBuf q[2][3], sq[3], hits, Lbuf, counters, sensor, table, film, scratch[4], overflow;
     uint64_t last_L_count = 0;  // float4 entries valid in Lbuf
 };
 
@@ -57,8 +59,10 @@ struct trhip_scene {
     std::vector<LightRec> lights;
     FlatBVH bvh;
     bool committed = false;
-    DevBuf d_nodes, d_prims, d_nrm, d_spheres, d_materials, d_lights;
+    DevBuf d_nodes, d_prims, d_nrm, d_spheres, d_materials, d_lights, d_wnodes;
     DeviceScene dev{};
+    WideScene wide{};
+    bool wide_ok = false;
 };
 
 namespace {
@@ -301,6 +305,55 @@ int upload_scene(trhip_scene* s) {
     s->dev.n_spheres = (uint32_t)s->spheres.size();
     s->dev.n_materials = (uint32_t)s->materials.size();
     s->dev.n_lights = (uint32_t)s->lights.size();
+    // ---- children-in-parent nodes for k_trace2 (th_trace2.h) ----
+    s->wide_ok = false;
+    std::memset(&s->wide, 0, sizeof s->wide);
+    s->wide.root_ref = kRefNone;
+    if (n_nodes > 0 && n_prims < (1u << 24)) {
+        std::vector<uint32_t> widx(n_nodes, 0);
+        uint32_t n_int = 0;
+        for (uint32_t i = 0; i < n_nodes; ++i)
+            if ((s->bvh.flags[i] & 3u) != 3u) widx[i] = n_int++;
+        bool ok = n_int < (1u << 24);
+        std::vector<float4> wn((size_t)n_int * 4);
+        for (uint32_t i = 0; i < n_nodes && ok; ++i) {
+            if ((s->bvh.flags[i] & 3u) == 3u) continue;
+            const uint32_t c[2] = {i + 1, s->bvh.a[i]};
+            uint32_t ref[2], cnt[2];
+            for (int k = 0; k < 2; ++k) {
+                if ((s->bvh.flags[c[k]] & 3u) == 3u) {
+                    ref[k] = s->bvh.a[c[k]];
+                    cnt[k] = s->bvh.flags[c[k]] >> 2;
+                    if (cnt[k] == 0 || cnt[k] > 255) ok = false;  // empty / oversized leaves only come from foreign BVHs: use the literal kernel
+                } else {
+                    ref[k] = widx[c[k]];
+                    cnt[k] = 0;
+                }
+            }
+            const float* l = &s->bvh.bounds[6 * (size_t)c[0]];
+            const float* r = &s->bvh.bounds[6 * (size_t)c[1]];
+            float4* w = &wn[4 * (size_t)widx[i]];
+            w[0] = make_float4(l[0], l[1], l[2], l[3]);
+            w[1] = make_float4(l[4], l[5], r[0], r[1]);
+            w[2] = make_float4(r[2], r[3], r[4], r[5]);
+            w[3] = make_float4(__builtin_bit_cast(float, ref[0]), __builtin_bit_cast(float, ref[1]), __builtin_bit_cast(float, cnt[0] | (cnt[1] << 8) | ((s->bvh.flags[i] & 3u) << 16)), 0.0f);
+        }
+        if (ok) {
+            if (int rc = upload(ctx, s->d_wnodes, wn.data(), wn.size() * sizeof(float4))) return rc;
+            s->wide.wnodes = (const float4*)s->d_wnodes.p;
+            s->wide.n_wnodes = n_int;
+            std::memcpy(s->wide.root_box, &s->bvh.bounds[0], 6 * sizeof(float));
+            if ((s->bvh.flags[0] & 3u) == 3u) {
+                s->wide.root_ref = s->bvh.a[0];
+                s->wide.root_cnt = s->bvh.flags[0] >> 2;
+                ok = s->wide.root_cnt > 0 && s->wide.root_cnt <= 255;
+            } else {
+                s->wide.root_ref = 0;
+                s->wide.root_cnt = 0;
+            }
+            s->wide_ok = ok;
+        }
+    }
     s->committed = true;
     return 0;
 }
@@ -327,6 +380,50 @@ void derive_sensor(const trhip_sensor* sn, DeviceSensor& d) {
     d.film_h = (int)std::fabs(sn->crop_max[1] - (sn->crop_min[1] - 1.0f));
     d.tiles_x = (int)std::floor(((float)(d.sb_max[0] - d.sb_min[0]) + 16.0f) / 16.0f);
     d.tiles_y = (int)std::floor(((float)(d.sb_max[1] - d.sb_min[1]) + 16.0f) / 16.0f);
+}
+
+int trace_grid(const trhip_ctx* ctx) { return ctx->num_cu * 5; }  // 5 x 256 threads x 32 KiB of LDS stack per CU
+
+// k_trace2 keeps stack levels 16..63 of every resident thread in a global slab laid out [level][thread].
+int ensure_overflow(trhip_ctx* ctx) {
+    const size_t threads = (size_t)trace_grid(ctx) * kBlock;
+    return ensure(ctx, ctx->overflow, threads * (size_t)(kStack2Total - kStack2Lds) * sizeof(uint2));
+}
+
+// One traversal launch over a queue (count in HBM at count_ptr, or n_max when count_ptr is null).
+// ctx->traversal == 1: the literal accel/bvh.jl loop (k_trace_closest / k_trace_any); 2: k_trace2 (same results).
+void launch_trace(trhip_ctx* ctx, const trhip_scene* sc, bool any, const float4* ro, const float4* rd, const float* tmax, const uint32_t* count_ptr, uint32_t n_max, TraceOut out,
+                  uint32_t* work_counter, Counters* ctr) {
+    hipStream_t st = ctx->stream;
+    const dim3 grid(trace_grid(ctx)), block(kBlock);
+    const bool v2 = ctx->traversal == 2 && sc->wide_ok;
+    const bool cnt = ctx->count_visits;
+    if (v2) {
+        uint2* ov = (uint2*)ctx->overflow.p;
+        if (any) {
+            if (cnt)
+                hipLaunchKernelGGL((k_trace2<true, true>), grid, block, 0, st, sc->dev, sc->wide, ro, rd, tmax, count_ptr, n_max, out, work_counter, ov, ctr);
+            else
+                hipLaunchKernelGGL((k_trace2<true, false>), grid, block, 0, st, sc->dev, sc->wide, ro, rd, tmax, count_ptr, n_max, out, work_counter, ov, ctr);
+        } else {
+            if (cnt)
+                hipLaunchKernelGGL((k_trace2<false, true>), grid, block, 0, st, sc->dev, sc->wide, ro, rd, tmax, count_ptr, n_max, out, work_counter, ov, ctr);
+            else
+                hipLaunchKernelGGL((k_trace2<false, false>), grid, block, 0, st, sc->dev, sc->wide, ro, rd, tmax, count_ptr, n_max, out, work_counter, ov, ctr);
+        }
+        return;
+    }
+    if (any) {
+        if (cnt)
+            hipLaunchKernelGGL(k_trace_any<true>, grid, block, 0, st, sc->dev, ro, rd, out.contrib, tmax, count_ptr, n_max, out.L, out.occluded, ctr);
+        else
+            hipLaunchKernelGGL(k_trace_any<false>, grid, block, 0, st, sc->dev, ro, rd, out.contrib, tmax, count_ptr, n_max, out.L, out.occluded, ctr);
+    } else {
+        if (cnt)
+            hipLaunchKernelGGL(k_trace_closest<true>, grid, block, 0, st, sc->dev, ro, rd, tmax, count_ptr, n_max, out.hits, ctr);
+        else
+            hipLaunchKernelGGL(k_trace_closest<false>, grid, block, 0, st, sc->dev, ro, rd, tmax, count_ptr, n_max, out.hits, ctr);
+    }
 }
 
 struct Timer {
@@ -370,7 +467,7 @@ int render_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sensor* se
     if (!ctx || !scene || !sensor || !out) return fail(ctx, TRHIP_ERR_INVALID, "null argument");
     if (!scene->committed) return fail(ctx, TRHIP_ERR_INVALID, "scene not committed");
     if (integrator != 1) return fail(ctx, TRHIP_ERR_UNSUPPORTED, "WhittedIntegrator is not accelerated yet");
-    if (spp == 0 || max_depth < 1) return fail(ctx, TRHIP_ERR_INVALID, "spp and max_depth must be >= 1");
+    if (spp == 0 || max_depth < 1 || max_depth > kMaxDepth) return fail(ctx, TRHIP_ERR_INVALID, "spp must be >= 1 and max_depth in 1..%d", kMaxDepth);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     DeviceSensor ds;
     derive_sensor(sensor, ds);
@@ -414,32 +511,26 @@ int render_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sensor* se
     HIP_TRY(ctx, hipEventRecord(e0, st));
     HIP_TRY(ctx, hipMemsetAsync(ctr, 0, sizeof(Counters), st));
     HIP_TRY(ctx, hipMemsetAsync(L, 0, total_slots * sizeof(float4), st));
-    const int g_trace = ctx->num_cu * 5, g_shade = ctx->num_cu * 4;
+    if (int rc = ensure_overflow(ctx)) return rc;
+    const int g_shade = ctx->num_cu * 4;
     uint32_t n_batches = 0;
     for (uint64_t s0 = 0; s0 < spp; s0 += spp_batch) {
         const uint64_t nb = std::min<uint64_t>(spp_batch, spp - s0) * npix;
         n_batches++;
+        HIP_TRY(ctx, hipMemsetAsync(ctr, 0, offsetof(Counters, closest_total), st));  // queue sizes + work cursors of this batch
         tm.begin(0);
         hipLaunchKernelGGL(k_raygen, dim3(grid_for(ctx, nb, 8)), dim3(kBlock), 0, st, dsp, (uint32_t)(s0 * npix), (uint32_t)nb, seed, sample_offset, pq[0], ctr);
         tm.end(0);
         int cur = 0;
         for (int depth = 1; depth <= max_depth; ++depth) {
             tm.begin(1);
-            if (ctx->count_visits)
-                hipLaunchKernelGGL(k_trace_closest<true>, dim3(g_trace), dim3(kBlock), 0, st, scene->dev, pq[cur].o, pq[cur].d, (const float*)nullptr, &ctr->n_queue[cur], (uint32_t)nb, hits, ctr);
-            else
-                hipLaunchKernelGGL(k_trace_closest<false>, dim3(g_trace), dim3(kBlock), 0, st, scene->dev, pq[cur].o, pq[cur].d, (const float*)nullptr, &ctr->n_queue[cur], (uint32_t)nb, hits, ctr);
+            launch_trace(ctx, scene, false, pq[cur].o, pq[cur].d, nullptr, &ctr->n_queue[depth - 1], (uint32_t)nb, TraceOut{hits, nullptr, nullptr, nullptr}, &ctr->work_closest[depth - 1], ctr);
             tm.end(1);
-            HIP_TRY(ctx, hipMemsetAsync(&ctr->n_queue[cur ^ 1], 0, sizeof(uint32_t), st));
-            HIP_TRY(ctx, hipMemsetAsync(&ctr->n_shadow, 0, sizeof(uint32_t), st));
             tm.begin(2);
             hipLaunchKernelGGL(k_shade_path, dim3(g_shade), dim3(kBlock), 0, st, scene->dev, dsp, pq[cur], pq[cur ^ 1], sq, hits, L, ctr, cur, depth, max_depth, seed, sample_offset);
             tm.end(2);
             tm.begin(3);
-            if (ctx->count_visits)
-                hipLaunchKernelGGL(k_trace_any<true>, dim3(g_trace), dim3(kBlock), 0, st, scene->dev, sq.o, sq.d, sq.c, (const float*)nullptr, &ctr->n_shadow, (uint32_t)nb, L, (uint8_t*)nullptr, ctr);
-            else
-                hipLaunchKernelGGL(k_trace_any<false>, dim3(g_trace), dim3(kBlock), 0, st, scene->dev, sq.o, sq.d, sq.c, (const float*)nullptr, &ctr->n_shadow, (uint32_t)nb, L, (uint8_t*)nullptr, ctr);
+            launch_trace(ctx, scene, true, sq.o, sq.d, nullptr, &ctr->n_shadow[depth - 1], (uint32_t)nb, TraceOut{nullptr, L, sq.c, nullptr}, &ctr->work_shadow[depth - 1], ctr);
             tm.end(3);
             cur ^= 1;
         }
@@ -476,18 +567,6 @@ int render_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sensor* se
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
-    return 0;
-}
-
-// Stage host rays into SoA device buffers (scratch[0..2]) and return their count-checked size.
-int stage_rays(trhip_ctx* ctx, const float* rays, uint64_t n) {
-    if (n >= (1ull << 31)) return fail(ctx, TRHIP_ERR_INVALID, "too many rays in one call");
-    if (int rc = upload(ctx, ctx->scratch[3], rays, n * 8 * sizeof(float))) return rc;
-    if (int rc = ensure(ctx, ctx->scratch[0], n * sizeof(float4))) return rc;
-    if (int rc = ensure(ctx, ctx->scratch[1], n * sizeof(float4))) return rc;
-    if (int rc = ensure(ctx, ctx->scratch[2], n * sizeof(float))) return rc;
-    if (n) hipLaunchKernelGGL(k_prepare_rays, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const float*)ctx->scratch[3].p, (uint32_t)n, (float4*)ctx->scratch[0].p,
-                              (float4*)ctx->scratch[1].p, (float*)ctx->scratch[2].p);
     return 0;
 }
 
@@ -531,6 +610,7 @@ void trhip_shutdown(trhip_ctx* ctx) {
     release(ctx->sensor);
     release(ctx->table);
     release(ctx->film);
+    release(ctx->overflow);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -542,7 +622,10 @@ int trhip_set_option(trhip_ctx* ctx, const char* name, int64_t value) {
         ctx->count_visits = value != 0;
     else if (!std::strcmp(name, "timing"))
         ctx->timing = value != 0;
-    else if (!std::strcmp(name, "batch_paths")) {
+    else if (!std::strcmp(name, "traversal")) {
+        if (value != 1 && value != 2) return fail(ctx, TRHIP_ERR_INVALID, "traversal must be 1 or 2");
+        ctx->traversal = (int)value;
+    } else if (!std::strcmp(name, "batch_paths")) {
         if (value < 1) return fail(ctx, TRHIP_ERR_INVALID, "batch_paths must be positive");
         ctx->batch_paths = (uint64_t)value;
     } else
@@ -566,6 +649,7 @@ void trhip_scene_free(trhip_scene* s) {
     release(s->d_spheres);
     release(s->d_materials);
     release(s->d_lights);
+    release(s->d_wnodes);
     delete s;
 }
 int trhip_scene_add_material(trhip_scene* s, int kind, const float* params, int n_params, uint32_t* id_out) {
@@ -742,103 +826,69 @@ int trhip_film_to_rgb(trhip_ctx* ctx, const float* xyzw, uint32_t w, uint32_t h,
     return 0;
 }
 
-int trhip_trace_closest(trhip_ctx* ctx, const trhip_scene* sc, const float* rays, uint64_t n, trhip_hit* out) {
-    if (!ctx || !sc || !rays || !out) return fail(ctx, TRHIP_ERR_INVALID, "null argument");
+// Shared body of the four kernel-level trace entry points: stage rays (host or device, n*8 floats) into SoA, run the
+// traversal `repeat` times, time it with HIP events on the library's stream.
+static int api_trace(trhip_ctx* ctx, const trhip_scene* sc, bool any, const void* rays, bool rays_on_device, uint64_t n, void* d_out, int repeat, double* avg_ms) {
     if (!sc->committed) return fail(ctx, TRHIP_ERR_INVALID, "scene not committed");
+    if (n >= (1ull << 31)) return fail(ctx, TRHIP_ERR_INVALID, "too many rays in one call");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (int rc = stage_rays(ctx, rays, n)) return rc;
-    if (int rc = ensure(ctx, ctx->hits, n * sizeof(float4))) return rc;
-    if (n) hipLaunchKernelGGL(k_trace_closest<false>, dim3(grid_for(ctx, n, 5)), dim3(kBlock), 0, ctx->stream, sc->dev, (const float4*)ctx->scratch[0].p, (const float4*)ctx->scratch[1].p,
-                              (const float*)ctx->scratch[2].p, (const uint32_t*)nullptr, (uint32_t)n, (float4*)ctx->hits.p, (Counters*)nullptr);
+    const float* d_rays = (const float*)rays;
+    if (!rays_on_device) {
+        if (int rc = upload(ctx, ctx->scratch[3], rays, n * 8 * sizeof(float))) return rc;
+        d_rays = (const float*)ctx->scratch[3].p;
+    }
+    for (int j = 0; j < 2; ++j)
+        if (int rc = ensure(ctx, ctx->scratch[j], n * sizeof(float4))) return rc;
+    if (int rc = ensure(ctx, ctx->scratch[2], n * sizeof(float))) return rc;
+    if (int rc = ensure(ctx, ctx->counters, sizeof(Counters))) return rc;
+    if (int rc = ensure_overflow(ctx)) return rc;
+    if (n) hipLaunchKernelGGL(k_prepare_rays, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_rays, (uint32_t)n, (float4*)ctx->scratch[0].p, (float4*)ctx->scratch[1].p,
+                              (float*)ctx->scratch[2].p);
+    Counters* ctr = (Counters*)ctx->counters.p;
+    HIP_TRY(ctx, hipMemsetAsync(ctr, 0, sizeof(Counters), ctx->stream));
+    hipEvent_t e0, e1;
+    HIP_TRY(ctx, hipEventCreate(&e0));
+    HIP_TRY(ctx, hipEventCreate(&e1));
+    repeat = std::max(1, std::min(repeat, kMaxDepth + 1));
+    TraceOut out{any ? nullptr : (float4*)d_out, nullptr, nullptr, any ? (uint8_t*)d_out : nullptr};
+    HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
+    if (n)
+        for (int r = 0; r < repeat; ++r)  // every repetition uses its own (zeroed) work cursor
+            launch_trace(ctx, sc, any, (const float4*)ctx->scratch[0].p, (const float4*)ctx->scratch[1].p, (const float*)ctx->scratch[2].p, nullptr, (uint32_t)n, out,
+                         any ? &ctr->work_shadow[r] : &ctr->work_closest[r], ctr);
+    HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    if (avg_ms) *avg_ms = ms / repeat;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return 0;
+}
+int trhip_trace_closest(trhip_ctx* ctx, const trhip_scene* sc, const float* rays, uint64_t n, trhip_hit* out) {
+    if (!ctx || !sc || !rays || !out) return fail(ctx, TRHIP_ERR_INVALID, "null argument");
     static_assert(sizeof(trhip_hit) == sizeof(float4), "trhip_hit layout");
+    if (int rc = ensure(ctx, ctx->hits, n * sizeof(float4))) return rc;
+    if (int rc = api_trace(ctx, sc, false, rays, false, n, ctx->hits.p, 1, nullptr)) return rc;
     HIP_TRY(ctx, hipMemcpy(out, ctx->hits.p, n * sizeof(float4), hipMemcpyDeviceToHost));
     return 0;
 }
 int trhip_trace_any(trhip_ctx* ctx, const trhip_scene* sc, const float* rays, uint64_t n, uint8_t* occluded) {
     if (!ctx || !sc || !rays || !occluded) return fail(ctx, TRHIP_ERR_INVALID, "null argument");
-    if (!sc->committed) return fail(ctx, TRHIP_ERR_INVALID, "scene not committed");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (int rc = stage_rays(ctx, rays, n)) return rc;
     if (int rc = ensure(ctx, ctx->hits, n)) return rc;
-    if (n) hipLaunchKernelGGL(k_trace_any<false>, dim3(grid_for(ctx, n, 5)), dim3(kBlock), 0, ctx->stream, sc->dev, (const float4*)ctx->scratch[0].p, (const float4*)ctx->scratch[1].p,
-                              (const float4*)nullptr, (const float*)ctx->scratch[2].p, (const uint32_t*)nullptr, (uint32_t)n, (float4*)nullptr, (uint8_t*)ctx->hits.p, (Counters*)nullptr);
-    HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (int rc = api_trace(ctx, sc, true, rays, false, n, ctx->hits.p, 1, nullptr)) return rc;
     HIP_TRY(ctx, hipMemcpy(occluded, ctx->hits.p, n, hipMemcpyDeviceToHost));
     return 0;
 }
-// d_rays: n*8 floats on the device (same layout as the host entry points); d_hits: n trhip_hit
+// d_rays: n*8 floats on the device (same layout as the host entry points); d_hits: n trhip_hit / d_occ: n bytes
 int trhip_trace_closest_device(trhip_ctx* ctx, const trhip_scene* sc, const void* d_rays, uint64_t n, void* d_hits, int repeat, double* avg_ms) {
     if (!ctx || !sc || !d_rays || !d_hits) return fail(ctx, TRHIP_ERR_INVALID, "null argument");
-    if (!sc->committed) return fail(ctx, TRHIP_ERR_INVALID, "scene not committed");
-    if (n >= (1ull << 31)) return fail(ctx, TRHIP_ERR_INVALID, "too many rays");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    for (int j = 0; j < 2; ++j)
-        if (int rc = ensure(ctx, ctx->scratch[j], n * sizeof(float4))) return rc;
-    if (int rc = ensure(ctx, ctx->scratch[2], n * sizeof(float))) return rc;
-    if (int rc = ensure(ctx, ctx->counters, sizeof(Counters))) return rc;
-    if (n) hipLaunchKernelGGL(k_prepare_rays, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const float*)d_rays, (uint32_t)n, (float4*)ctx->scratch[0].p,
-                              (float4*)ctx->scratch[1].p, (float*)ctx->scratch[2].p);
-    HIP_TRY(ctx, hipMemsetAsync(ctx->counters.p, 0, sizeof(Counters), ctx->stream));
-    hipEvent_t e0, e1;
-    HIP_TRY(ctx, hipEventCreate(&e0));
-    HIP_TRY(ctx, hipEventCreate(&e1));
-    repeat = std::max(1, repeat);
-    HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
-    for (int r = 0; r < repeat; ++r) {
-        if (ctx->count_visits)
-            hipLaunchKernelGGL(k_trace_closest<true>, dim3(ctx->num_cu * 5), dim3(kBlock), 0, ctx->stream, sc->dev, (const float4*)ctx->scratch[0].p, (const float4*)ctx->scratch[1].p,
-                               (const float*)ctx->scratch[2].p, (const uint32_t*)nullptr, (uint32_t)n, (float4*)d_hits, (Counters*)ctx->counters.p);
-        else
-            hipLaunchKernelGGL(k_trace_closest<false>, dim3(ctx->num_cu * 5), dim3(kBlock), 0, ctx->stream, sc->dev, (const float4*)ctx->scratch[0].p, (const float4*)ctx->scratch[1].p,
-                               (const float*)ctx->scratch[2].p, (const uint32_t*)nullptr, (uint32_t)n, (float4*)d_hits, (Counters*)ctx->counters.p);
-    }
-    HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
-    HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    float ms = 0;
-    (void)hipEventElapsedTime(&ms, e0, e1);
-    if (avg_ms) *avg_ms = ms / repeat;
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    return 0;
+    return api_trace(ctx, sc, false, d_rays, true, n, d_hits, repeat, avg_ms);
 }
 int trhip_trace_any_device(trhip_ctx* ctx, const trhip_scene* sc, const void* d_rays, uint64_t n, void* d_occ, int repeat, double* avg_ms) {
     if (!ctx || !sc || !d_rays || !d_occ) return fail(ctx, TRHIP_ERR_INVALID, "null argument");
-    if (!sc->committed) return fail(ctx, TRHIP_ERR_INVALID, "scene not committed");
-    if (n >= (1ull << 31)) return fail(ctx, TRHIP_ERR_INVALID, "too many rays");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    for (int j = 0; j < 2; ++j)
-        if (int rc = ensure(ctx, ctx->scratch[j], n * sizeof(float4))) return rc;
-    if (int rc = ensure(ctx, ctx->scratch[2], n * sizeof(float))) return rc;
-    if (int rc = ensure(ctx, ctx->counters, sizeof(Counters))) return rc;
-    if (n) hipLaunchKernelGGL(k_prepare_rays, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const float*)d_rays, (uint32_t)n, (float4*)ctx->scratch[0].p,
-                              (float4*)ctx->scratch[1].p, (float*)ctx->scratch[2].p);
-    HIP_TRY(ctx, hipMemsetAsync(ctx->counters.p, 0, sizeof(Counters), ctx->stream));
-    hipEvent_t e0, e1;
-    HIP_TRY(ctx, hipEventCreate(&e0));
-    HIP_TRY(ctx, hipEventCreate(&e1));
-    repeat = std::max(1, repeat);
-    HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
-    for (int r = 0; r < repeat; ++r) {
-        if (ctx->count_visits)
-            hipLaunchKernelGGL(k_trace_any<true>, dim3(ctx->num_cu * 5), dim3(kBlock), 0, ctx->stream, sc->dev, (const float4*)ctx->scratch[0].p, (const float4*)ctx->scratch[1].p,
-                               (const float4*)nullptr, (const float*)ctx->scratch[2].p, (const uint32_t*)nullptr, (uint32_t)n, (float4*)nullptr, (uint8_t*)d_occ, (Counters*)ctx->counters.p);
-        else
-            hipLaunchKernelGGL(k_trace_any<false>, dim3(ctx->num_cu * 5), dim3(kBlock), 0, ctx->stream, sc->dev, (const float4*)ctx->scratch[0].p, (const float4*)ctx->scratch[1].p,
-                               (const float4*)nullptr, (const float*)ctx->scratch[2].p, (const uint32_t*)nullptr, (uint32_t)n, (float4*)nullptr, (uint8_t*)d_occ, (Counters*)ctx->counters.p);
-    }
-    HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
-    HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    float ms = 0;
-    (void)hipEventElapsedTime(&ms, e0, e1);
-    if (avg_ms) *avg_ms = ms / repeat;
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    return 0;
+    return api_trace(ctx, sc, true, d_rays, true, n, d_occ, repeat, avg_ms);
 }
 // visit counters of the last *_device trace call (when "count_visits" is on): nodes, prims for closest then shadow
 int trhip_last_visit_counts(trhip_ctx* ctx, uint64_t* out4) {
@@ -854,17 +904,11 @@ int trhip_last_visit_counts(trhip_ctx* ctx, uint64_t* out4) {
 
 int trhip_hit_geometry(trhip_ctx* ctx, const trhip_scene* sc, const float* rays, uint64_t n, float* out15) {
     if (!ctx || !sc || !rays || !out15) return fail(ctx, TRHIP_ERR_INVALID, "null argument");
-    if (!sc->committed) return fail(ctx, TRHIP_ERR_INVALID, "scene not committed");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (int rc = stage_rays(ctx, rays, n)) return rc;
     if (int rc = ensure(ctx, ctx->hits, n * sizeof(float4))) return rc;
     if (int rc = ensure(ctx, ctx->film, n * 15 * sizeof(float))) return rc;
-    if (n) {
-        hipLaunchKernelGGL(k_trace_closest<false>, dim3(grid_for(ctx, n, 5)), dim3(kBlock), 0, ctx->stream, sc->dev, (const float4*)ctx->scratch[0].p, (const float4*)ctx->scratch[1].p,
-                           (const float*)ctx->scratch[2].p, (const uint32_t*)nullptr, (uint32_t)n, (float4*)ctx->hits.p, (Counters*)nullptr);
-        hipLaunchKernelGGL(k_hit_geometry, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, sc->dev, (const float4*)ctx->scratch[0].p, (const float4*)ctx->scratch[1].p,
-                           (const float4*)ctx->hits.p, (uint32_t)n, (float*)ctx->film.p);
-    }
+    if (int rc = api_trace(ctx, sc, false, rays, false, n, ctx->hits.p, 1, nullptr)) return rc;
+    if (n) hipLaunchKernelGGL(k_hit_geometry, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, sc->dev, (const float4*)ctx->scratch[0].p, (const float4*)ctx->scratch[1].p,
+                              (const float4*)ctx->hits.p, (uint32_t)n, (float*)ctx->film.p);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemcpy(out15, ctx->film.p, n * 15 * sizeof(float), hipMemcpyDeviceToHost));
