@@ -200,8 +200,14 @@ def test_render_batches_and_sample_offset(T, ob, ctx, shadows):
     try:
         b = T.PathIntegrator(cam, T.SeededSampler(4, seed=9), 4).render(scene).copy()
     finally:
-        ctx.set_option("batch_paths", 16 << 20)
+        ctx.set_option("batch_paths", 0)
     assert_bits_equal(a, b, "batched film")
+    ctx.set_option("overlap", 0)  # single-stream schedule
+    try:
+        c = T.PathIntegrator(cam, T.SeededSampler(4, seed=9), 4).render(scene).copy()
+    finally:
+        ctx.set_option("overlap", 1)
+    assert_bits_equal(a, c, "film without the two-stream overlap")
     # two half renders with offsets sum (in fp32, tolerance) to the full one
     h0 = T.PathIntegrator(cam, T.SeededSampler(2, seed=9, sample_offset=0), 4).render(scene).copy()
     h1 = T.PathIntegrator(cam, T.SeededSampler(2, seed=9, sample_offset=2), 4).render(scene).copy()

@@ -21,6 +21,7 @@ namespace th {
 constexpr int kStack2Lds = 16;
 constexpr int kStack2Total = 64;
 constexpr uint32_t kRefNone = 0xffffffffu;
+constexpr int kChunk = 256;  // ray indices a wave takes from the global cursor per atomic
 
 struct WideScene {            // device view of the v2 node array
     const float4* wnodes;     // 4 float4 per interior node
@@ -69,6 +70,7 @@ __global__ __launch_bounds__(kBlock) void k_trace2(DeviceScene sc, WideScene ws,
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
     bool active = false, exhausted = false;
+    uint32_t pool_next = 0, pool_end = 0;  // wave-uniform: the chunk of ray indices this wave currently owns
     uint32_t idx = 0, cur = kRefNone, cur_cnt = 0;
     int sp = 0;
     f3 o = splat3(0.0f), d = splat3(0.0f), inv_d = splat3(0.0f);
@@ -79,19 +81,25 @@ __global__ __launch_bounds__(kBlock) void k_trace2(DeviceScene sc, WideScene ws,
     uint32_t nn = 0, np = 0;
 
     while (true) {
-        // ---- refill idle lanes -------------------------------------------------------------------------------------------
+        // ---- refill idle lanes: ray indices come in chunks of kChunk per wave (one atomic per chunk) -------------------------
         const unsigned long long idle = __ballot(!active);
         const uint32_t n_idle = (uint32_t)__popcll(idle);
         if (n_idle == 64u || (!exhausted && n_idle >= 12u)) {
             if (!exhausted) {
-                uint32_t base = 0;
-                const int leader = __ffsll((long long)idle) - 1;
-                if ((int)lane == leader) base = atomicAdd(work_counter, n_idle);
-                base = __shfl(base, leader);
-                if (base + n_idle >= n) exhausted = true;
-                if (!active) {
-                    idx = base + (uint32_t)__popcll(idle & lt_mask);
-                    if (idx < n) {
+                if (pool_next >= pool_end) {
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(work_counter, (uint32_t)kChunk);
+                    base = __shfl(base, 0);
+                    pool_next = base;
+                    pool_end = min(base + (uint32_t)kChunk, n);
+                    if (base >= n) {
+                        exhausted = true;
+                        pool_next = pool_end = 0;
+                    }
+                }
+                if (!exhausted && !active) {
+                    idx = pool_next + (uint32_t)__popcll(idle & lt_mask);
+                    if (idx < pool_end) {
                         const float4 o4 = ro[idx], d4 = rd[idx];
                         o = mk3(o4.x, o4.y, o4.z);
                         d = mk3(d4.x, d4.y, d4.z);
@@ -118,8 +126,12 @@ __global__ __launch_bounds__(kBlock) void k_trace2(DeviceScene sc, WideScene ws,
                         }
                     }
                 }
+                pool_next = min(pool_next + n_idle, pool_end);
             }
-            if (__ballot(active) == 0ull) break;
+            if (__ballot(active) == 0ull) {
+                if (exhausted) break;
+                continue;  // chunk ran dry before any lane got a ray: fetch the next chunk
+            }
         }
         // ---- a few traversal steps ------------------------------------------------------------------------------------------
 #pragma unroll 1

@@ -30,12 +30,14 @@ struct DevBuf {
 struct trhip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;  // shadow rays of depth d overlap with the closest-hit rays of depth d+1
     std::string err;
     int num_cu = 256;
     // options
     bool count_visits = false;
     bool timing = true;
-    uint64_t batch_paths = 16ull << 20;
+    uint64_t batch_paths = 0;  // 0 = as many whole sample passes as fit in free HBM (fewer launches, fewer traversal tails)
+    bool overlap = true;  // two-stream overlap of shadow rays (depth d) with closest-hit rays (depth d+1)
     int traversal = 2;  // 1 = literal accel/bvh.jl loop, 2 = children-in-parent nodes + per-lane ray replacement
     // workspace (grown on demand, reused across calls)
     DevBuf q[2][3], sq[3], hits, Lbuf, counters, sensor, table, film, scratch[4], overflow;
@@ -392,9 +394,8 @@ int ensure_overflow(trhip_ctx* ctx) {
 
 // One traversal launch over a queue (count in HBM at count_ptr, or n_max when count_ptr is null).
 // ctx->traversal == 1: the literal accel/bvh.jl loop (k_trace_closest / k_trace_any); 2: k_trace2 (same results).
-void launch_trace(trhip_ctx* ctx, const trhip_scene* sc, bool any, const float4* ro, const float4* rd, const float* tmax, const uint32_t* count_ptr, uint32_t n_max, TraceOut out,
-                  uint32_t* work_counter, Counters* ctr) {
-    hipStream_t st = ctx->stream;
+void launch_trace(trhip_ctx* ctx, hipStream_t st, const trhip_scene* sc, bool any, const float4* ro, const float4* rd, const float* tmax, const uint32_t* count_ptr, uint32_t n_max,
+                  TraceOut out, uint32_t* work_counter, Counters* ctr) {
     const dim3 grid(trace_grid(ctx)), block(kBlock);
     const bool v2 = ctx->traversal == 2 && sc->wide_ok;
     const bool cnt = ctx->count_visits;
@@ -438,17 +439,17 @@ struct Timer {
                 (void)hipEventDestroy(p.second);
             }
     }
-    void begin(int cls) {
+    void begin(int cls, hipStream_t st) {
         if (!on) return;
         hipEvent_t a, b;
         (void)hipEventCreate(&a);
         (void)hipEventCreate(&b);
-        (void)hipEventRecord(a, ctx->stream);
+        (void)hipEventRecord(a, st);
         ev[cls].push_back({a, b});
     }
-    void end(int cls) {
+    void end(int cls, hipStream_t st) {
         if (!on) return;
-        (void)hipEventRecord(ev[cls].back().second, ctx->stream);
+        (void)hipEventRecord(ev[cls].back().second, st);
     }
     double total(int cls, uint32_t* launches) {
         double ms = 0;
@@ -476,8 +477,21 @@ int render_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sensor* se
     const uint64_t total_slots = npix * spp;
     if (total_slots >= (1ull << 32)) return fail(ctx, TRHIP_ERR_UNSUPPORTED, "more than 2^32 camera samples in one call: split spp over calls/ranks");
     // batch = whole sample passes
-    uint64_t spp_batch = std::max<uint64_t>(1, ctx->batch_paths / npix);
+    // wavefront batch = whole sample passes; per path in flight: 2 x 3 queue float4 + 3 shadow float4 + 1 hit float4 = 160 B
+    uint64_t batch_paths = ctx->batch_paths;
+    if (batch_paths == 0) {
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
+        size_t held = ctx->Lbuf.bytes + ctx->hits.bytes + ctx->overflow.bytes;  // reused below, so it counts as available
+        for (auto& a : ctx->q)
+            for (auto& b : a) held += b.bytes;
+        for (auto& b : ctx->sq) held += b.bytes;
+        const double avail = 0.85 * (double)(free_b + held) - (double)total_slots * sizeof(float4) - 256e6;
+        batch_paths = avail > 0 ? (uint64_t)(avail / 160.0) : npix;
+    }
+    uint64_t spp_batch = std::max<uint64_t>(1, batch_paths / npix);
     spp_batch = std::min<uint64_t>(spp_batch, spp);
+    while (npix * spp_batch >= (1ull << 31)) spp_batch = (spp_batch + 1) / 2;  // queue indices are 32-bit
     const uint64_t P = npix * spp_batch;
     if (int rc = upload(ctx, ctx->sensor, &ds, sizeof ds)) return rc;
     if (int rc = upload(ctx, ctx->table, sensor->filter_table, 256 * sizeof(float))) return rc;
@@ -514,30 +528,43 @@ int render_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sensor* se
     if (int rc = ensure_overflow(ctx)) return rc;
     const int g_shade = ctx->num_cu * 4;
     uint32_t n_batches = 0;
+    // Shadow rays of depth d (k_trace any-hit + accumulate) and closest-hit rays of depth d+1 are independent: they run on two
+    // streams so that the long single-ray tail of one overlaps with the bulk of the other (DESIGN.md "tails").
+    hipStream_t st2 = ctx->overlap ? ctx->stream2 : st;
+    hipEvent_t ev_shade, ev_any;
+    HIP_TRY(ctx, hipEventCreateWithFlags(&ev_shade, hipEventDisableTiming));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&ev_any, hipEventDisableTiming));
     for (uint64_t s0 = 0; s0 < spp; s0 += spp_batch) {
         const uint64_t nb = std::min<uint64_t>(spp_batch, spp - s0) * npix;
         n_batches++;
         HIP_TRY(ctx, hipMemsetAsync(ctr, 0, offsetof(Counters, closest_total), st));  // queue sizes + work cursors of this batch
-        tm.begin(0);
+        tm.begin(0, st);
         hipLaunchKernelGGL(k_raygen, dim3(grid_for(ctx, nb, 8)), dim3(kBlock), 0, st, dsp, (uint32_t)(s0 * npix), (uint32_t)nb, seed, sample_offset, pq[0], ctr);
-        tm.end(0);
+        tm.end(0, st);
         int cur = 0;
         for (int depth = 1; depth <= max_depth; ++depth) {
-            tm.begin(1);
-            launch_trace(ctx, scene, false, pq[cur].o, pq[cur].d, nullptr, &ctr->n_queue[depth - 1], (uint32_t)nb, TraceOut{hits, nullptr, nullptr, nullptr}, &ctr->work_closest[depth - 1], ctr);
-            tm.end(1);
-            tm.begin(2);
+            tm.begin(1, st);
+            launch_trace(ctx, st, scene, false, pq[cur].o, pq[cur].d, nullptr, &ctr->n_queue[depth - 1], (uint32_t)nb, TraceOut{hits, nullptr, nullptr, nullptr}, &ctr->work_closest[depth - 1], ctr);
+            tm.end(1, st);
+            if (st2 != st && depth > 1) HIP_TRY(ctx, hipStreamWaitEvent(st, ev_any, 0));  // shade(d) reuses the shadow queue and touches L
+            tm.begin(2, st);
             hipLaunchKernelGGL(k_shade_path, dim3(g_shade), dim3(kBlock), 0, st, scene->dev, dsp, pq[cur], pq[cur ^ 1], sq, hits, L, ctr, cur, depth, max_depth, seed, sample_offset);
-            tm.end(2);
-            tm.begin(3);
-            launch_trace(ctx, scene, true, sq.o, sq.d, nullptr, &ctr->n_shadow[depth - 1], (uint32_t)nb, TraceOut{nullptr, L, sq.c, nullptr}, &ctr->work_shadow[depth - 1], ctr);
-            tm.end(3);
+            tm.end(2, st);
+            if (st2 != st) {
+                HIP_TRY(ctx, hipEventRecord(ev_shade, st));
+                HIP_TRY(ctx, hipStreamWaitEvent(st2, ev_shade, 0));
+            }
+            tm.begin(3, st2);
+            launch_trace(ctx, st2, scene, true, sq.o, sq.d, nullptr, &ctr->n_shadow[depth - 1], (uint32_t)nb, TraceOut{nullptr, L, sq.c, nullptr}, &ctr->work_shadow[depth - 1], ctr);
+            tm.end(3, st2);
+            if (st2 != st) HIP_TRY(ctx, hipEventRecord(ev_any, st2));
             cur ^= 1;
         }
+        if (st2 != st) HIP_TRY(ctx, hipStreamWaitEvent(st, ev_any, 0));  // the next batch (or the film gather) needs every shadow ray resolved
     }
-    tm.begin(4);
+    tm.begin(4, st);
     hipLaunchKernelGGL(k_film_gather, dim3(grid_for(ctx, (uint64_t)ds.film_w * ds.film_h, 8)), dim3(kBlock), 0, st, dsp, (const float*)ctx->table.p, L, spp, seed, sample_offset, (float4*)d_film);
-    tm.end(4);
+    tm.end(4, st);
     HIP_TRY(ctx, hipEventRecord(e1, st));
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(st));
@@ -567,6 +594,8 @@ int render_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sensor* se
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
+    (void)hipEventDestroy(ev_shade);
+    (void)hipEventDestroy(ev_any);
     return 0;
 }
 
@@ -590,7 +619,7 @@ int trhip_init(trhip_ctx** out, int device_id) {
     auto ctx = new trhip_ctx();
     ctx->device = device_id;
     ctx->num_cu = prop.multiProcessorCount;
-    if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreate(&ctx->stream)) != hipSuccess) {
+    if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreate(&ctx->stream)) != hipSuccess || (e = hipStreamCreate(&ctx->stream2)) != hipSuccess) {
         delete ctx;
         return fail(nullptr, TRHIP_ERR_HIP, "stream creation failed: %s", hipGetErrorString(e));
     }
@@ -612,6 +641,7 @@ void trhip_shutdown(trhip_ctx* ctx) {
     release(ctx->film);
     release(ctx->overflow);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     delete ctx;
 }
 const char* trhip_last_error(const trhip_ctx* ctx) { return ctx ? ctx->err.c_str() : g_init_error.c_str(); }
@@ -622,11 +652,13 @@ int trhip_set_option(trhip_ctx* ctx, const char* name, int64_t value) {
         ctx->count_visits = value != 0;
     else if (!std::strcmp(name, "timing"))
         ctx->timing = value != 0;
+    else if (!std::strcmp(name, "overlap"))
+        ctx->overlap = value != 0;
     else if (!std::strcmp(name, "traversal")) {
         if (value != 1 && value != 2) return fail(ctx, TRHIP_ERR_INVALID, "traversal must be 1 or 2");
         ctx->traversal = (int)value;
     } else if (!std::strcmp(name, "batch_paths")) {
-        if (value < 1) return fail(ctx, TRHIP_ERR_INVALID, "batch_paths must be positive");
+        if (value < 0) return fail(ctx, TRHIP_ERR_INVALID, "batch_paths must be >= 0 (0 = auto)");
         ctx->batch_paths = (uint64_t)value;
     } else
         return fail(ctx, TRHIP_ERR_INVALID, "unknown option %s", name);
@@ -854,7 +886,7 @@ static int api_trace(trhip_ctx* ctx, const trhip_scene* sc, bool any, const void
     HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
     if (n)
         for (int r = 0; r < repeat; ++r)  // every repetition uses its own (zeroed) work cursor
-            launch_trace(ctx, sc, any, (const float4*)ctx->scratch[0].p, (const float4*)ctx->scratch[1].p, (const float*)ctx->scratch[2].p, nullptr, (uint32_t)n, out,
+            launch_trace(ctx, ctx->stream, sc, any, (const float4*)ctx->scratch[0].p, (const float4*)ctx->scratch[1].p, (const float*)ctx->scratch[2].p, nullptr, (uint32_t)n, out,
                          any ? &ctr->work_shadow[r] : &ctr->work_closest[r], ctr);
     HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
     HIP_TRY(ctx, hipGetLastError());
