@@ -244,3 +244,36 @@ def test_film_to_rgb(T, ob, ctx, shadows):
     ref = np.empty((h, w, 3), np.float32)
     ob.lib().orc_film_to_rgb(ob.fp(np.ascontiguousarray(xyzw)), w, h, 1.0, ob.fp(ref))
     assert_bits_equal(rgb, ref, "film_to_rgb")
+
+
+def test_partial_spheres_and_transforms(T, ob, ctx):
+    """a9: clipped spheres (z_min / z_max / ϕ_max, sphere.jl:13-26, 65-69), reversed orientation and a scaled
+    (non-rigid) object_to_world — the slow clipping path next to the full-sphere fast path."""
+    mat = T.MatteMaterial(T.ConstantTexture(T.RGBSpectrum(0.7)), T.ConstantTexture(0.0))
+    glass = T.GlassMaterial(T.ConstantTexture(T.RGBSpectrum(1.0)), T.ConstantTexture(T.RGBSpectrum(1.0)), T.ConstantTexture(0.0), T.ConstantTexture(0.0), T.ConstantTexture(1.5), True)
+    prims = [
+        T.GeometricPrimitive(T.Sphere(T.ShapeCore(T.translate([0.25, 0.3, -2.5]), False), 0.2, -0.1, 0.15, 250.0), mat),
+        T.GeometricPrimitive(T.Sphere(T.ShapeCore(T.translate([0.7, 0.3, -2.6]), True), 0.25, -0.25, 0.1, 360.0), glass),
+        T.GeometricPrimitive(T.Sphere(T.ShapeCore(T.translate([0.5, 0.7, -2.4]) * T.scale(1.0, 0.5, 1.5), False), 0.2, 360.0), mat),
+        T.GeometricPrimitive(T.Sphere(T.ShapeCore(T.translate([0.5, 0.15, -2.2]), False), 0.12, 359.0), mat),
+    ]
+    floor = T.create_triangle_mesh(T.ShapeCore(T.translate([0, 0, -3]), True), 2, np.array([1, 2, 3, 1, 3, 4], np.uint32), 4, [[0, 0, 0], [1, 0, 0], [1, 0, 1], [0, 0, 1]])
+    prims += [T.GeometricPrimitive(t, mat) for t in floor]
+    scene = T.Scene([T.PointLight(T.translate([0.5, 0.95, -2.1]), T.RGBSpectrum(3.0)), T.SpotLight(T.translate([0.1, 0.9, -2.0]), T.RGBSpectrum(4.0), 50.0, 30.0)], T.BVHAccel(prims, 1))
+    flat, osc = scene_pair(T, ob, scene)
+    cam = T.scenes.shadows_camera(64)
+    wb = osc.world_bound()
+    rays = np.concatenate([camera_rays(T, ob, cam, seed=21), T.scenes.incoherent_rays(40000, wb[:3] - 0.1, wb[3:] + 0.1, seed=22)])
+    hits = flat.trace_closest(rays)
+    t_ref, prim_ref, geom_ref, _ = osc.trace_closest(rays, want_geom=True)
+    assert len(set(prim_ref[prim_ref >= 0])) == 6
+    assert np.array_equal(hits["prim"], prim_ref)
+    assert_bits_equal(hits["t"], t_ref, "t_hit")
+    assert_bits_equal(flat.hit_geometry(rays), geom_ref, "geometry")
+    occ_ref, _ = osc.trace_any(rays)
+    assert np.array_equal(flat.trace_any(rays), occ_ref)
+    integ = T.PathIntegrator(cam, T.SeededSampler(2, seed=77), 5)
+    xyzw = integ.render(scene)
+    ref_xyzw, ref_L, _ = osc.render(cam, "path", 2, 5, seed=77, want_samples=True)
+    assert_bits_equal(integ.sample_radiance(scene), ref_L, "per-sample radiance (two lights, spot falloff)")
+    assert_bits_equal(xyzw, ref_xyzw, "film")

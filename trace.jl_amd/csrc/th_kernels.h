@@ -162,7 +162,7 @@ TH_D bool traverse(const DeviceScene& sc, f3 o, f3 d, float t_max, uint32_t (*st
                     if (COUNT) n_prims++;
                     if (meta & PRIM_SPHERE) {
                         SphereHit sh;
-                        if (sphere_intersect(sc.spheres[__float_as_uint(p0.x)], o, d, t_max, sh)) {
+                        if (sphere_intersect<false>(sc.spheres[__float_as_uint(p0.x)], o, d, t_max, sh)) {
                             if (ANY) return true;
                             t_max = sh.t;  // primitive.jl:17 (unconditional)
                             found = true;
@@ -293,7 +293,7 @@ TH_D bool rebuild_shading(const DeviceScene& sc, int prim, f3 o, f3 d, Shading& 
     if (meta & PRIM_SPHERE) {
         const SphereRec& s = sc.spheres[__float_as_uint(p0.x)];
         SphereHit h;
-        if (!sphere_intersect(s, o, d, kInf, h)) return false;
+        if (!sphere_intersect<true>(s, o, d, kInf, h)) return false;
         sh = shade_sphere(s, h, d);
         return true;
     }

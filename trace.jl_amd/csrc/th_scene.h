@@ -29,7 +29,7 @@ struct SphereRec {      // shapes/sphere.jl:1-30
     float o2w_inv[16];  // core.object_to_world.inv_m  (== world_to_object.m)
     float radius, z_min, z_max, theta_min, theta_max, phi_max;
     uint32_t flip;  // reverse_orientation XOR transform_swaps_handedness
-    uint32_t pad;
+    uint32_t never_clipped;  // !(z_min > -r) && !(z_max < r) && phi_max >= Float32(2π): test_clipping (sphere.jl:65-69) is constantly false
 };
 
 enum LobeKind : int32_t { LOBE_LAMBERT_R = 0, LOBE_OREN_NAYAR = 1, LOBE_SPECULAR_R = 2, LOBE_SPECULAR_T = 3, LOBE_FRESNEL_SPECULAR = 4, LOBE_MICROFACET_R = 5, LOBE_MICROFACET_T = 6, LOBE_LAMBERT_T = 7 };

@@ -151,7 +151,7 @@ __global__ __launch_bounds__(kBlock) void k_trace2(DeviceScene sc, WideScene ws,
                     if (COUNT) np++;
                     if (meta & PRIM_SPHERE) {
                         SphereHit sh;
-                        if (sphere_intersect(sc.spheres[__float_as_uint(p0.x)], o, d, t_max, sh)) {
+                        if (sphere_intersect<false>(sc.spheres[__float_as_uint(p0.x)], o, d, t_max, sh)) {
                             if (ANY) {
                                 found = true;
                                 finished = true;

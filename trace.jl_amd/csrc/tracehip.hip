@@ -734,6 +734,7 @@ int trhip_scene_add_sphere(trhip_scene* s, const float* o2w, const float* o2w_in
     r.phi_max = deg2rad(jclamp(phi_max_deg, 0.0f, 360.0f));
     const bool swaps = det3(o2w) < 0.0f;  // transformations.jl:161-163
     r.flip = ((reverse != 0) != swaps) ? 1u : 0u;
+    r.never_clipped = (!(r.z_min > -r.radius) && !(r.z_max < r.radius) && r.phi_max >= 2.0f * kPi) ? 1u : 0u;
     HostPrim p;
     std::memset(&p, 0, sizeof p);
     p.kind = 1;
