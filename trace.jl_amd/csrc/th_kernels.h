@@ -287,7 +287,9 @@ __global__ __launch_bounds__(kBlock) void k_trace_any(DeviceScene sc, const floa
 // Rebuild the SurfaceInteraction of a closest hit from the one hit primitive (re-running its intersection with
 // t_max = Inf reproduces the accepted candidate's barycentrics / hit point bit-for-bit: they do not depend on t_max).
 TH_D bool rebuild_shading(const DeviceScene& sc, int prim, f3 o, f3 d, Shading& sh, uint32_t& material) {
-    const float4 p0 = sc.prims[3 * prim];
+    // all six 16-byte loads are issued up front (independent of the sphere / normals flags) so that their latencies overlap
+    const float4 p0 = sc.prims[3 * prim], p1 = sc.prims[3 * prim + 1], p2 = sc.prims[3 * prim + 2];
+    const float4 na = sc.tri_nrm[3 * prim], nb = sc.tri_nrm[3 * prim + 1], nc = sc.tri_nrm[3 * prim + 2];
     const uint32_t meta = __float_as_uint(p0.w);
     material = meta & PRIM_MATERIAL_MASK;
     if (meta & PRIM_SPHERE) {
@@ -297,19 +299,11 @@ TH_D bool rebuild_shading(const DeviceScene& sc, int prim, f3 o, f3 d, Shading& 
         sh = shade_sphere(s, h, d);
         return true;
     }
-    const float4 p1 = sc.prims[3 * prim + 1], p2 = sc.prims[3 * prim + 2];
     const f3 v0 = mk3(p0.x, p0.y, p0.z), v1 = mk3(p1.x, p1.y, p1.z), v2 = mk3(p2.x, p2.y, p2.z);
     TriTest tt;
     if (!tri_intersect<true>(v0, v1, v2, o, d, kInf, &tt)) return false;
     const bool has_n = (meta & PRIM_HAS_NORMALS) != 0;
-    f3 n0 = splat3(0.0f), n1 = n0, n2 = n0;
-    if (has_n) {
-        const float4 a = sc.tri_nrm[3 * prim], b = sc.tri_nrm[3 * prim + 1], c = sc.tri_nrm[3 * prim + 2];
-        n0 = mk3(a.x, a.y, a.z);
-        n1 = mk3(b.x, b.y, b.z);
-        n2 = mk3(c.x, c.y, c.z);
-    }
-    sh = shade_triangle(v0, v1, v2, has_n, n0, n1, n2, (meta & PRIM_FLIP) != 0, tt.bary, d);
+    sh = shade_triangle(v0, v1, v2, has_n, mk3(na.x, na.y, na.z), mk3(nb.x, nb.y, nb.z), mk3(nc.x, nc.y, nc.z), (meta & PRIM_FLIP) != 0, tt.bary, d);
     return true;
 }
 
@@ -426,8 +420,18 @@ __global__ __launch_bounds__(kBlock) void k_shade_path(DeviceScene sc, const Dev
 // (integrators/sampler.jl:24-31), inside a tile in Bounds2 iteration order (x fastest, bounds.jl:39-47), samples in order —
 // i.e. exactly the reference's (single-threaded) summation order, with no atomics and no race (the reference's
 // merge_film_tile! is unsynchronised).  out = xyz sums + filter_weight_sum.
-__global__ __launch_bounds__(kBlock) void k_film_gather(const DeviceSensor* __restrict__ sep, const float* __restrict__ table, const float4* __restrict__ L, uint32_t spp,
-                                                        uint64_t seed, uint32_t sample_offset, float4* __restrict__ out) {
+// camera_sample.film of every slot (p_raster + get_2d, sampler/sampler.jl:135-139): written once so that the gather does not
+// re-derive it from the sampler for each of the ~16 film pixels a sample reaches.
+__global__ __launch_bounds__(kBlock) void k_film_positions(const DeviceSensor* __restrict__ sep, uint64_t n, uint64_t seed, uint32_t sample_offset, float2* __restrict__ pfilm) {
+    const DeviceSensor& se = *sep;
+    for (uint64_t slot = (uint64_t)blockIdx.x * kBlock + threadIdx.x; slot < n; slot += (uint64_t)gridDim.x * kBlock) {
+        const SlotInfo si = slot_info(se, (uint32_t)slot);
+        const uint64_t key = ts_stream_key(seed, si.px, si.py, sample_offset + si.sample);
+        pfilm[slot] = make_float2((float)si.px + ts_uniform(key, TS_DIM_FILM_X), (float)si.py + ts_uniform(key, TS_DIM_FILM_Y));
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_film_gather(const DeviceSensor* __restrict__ sep, const float* __restrict__ table, const float4* __restrict__ L,
+                                                        const float2* __restrict__ pfilm, uint32_t spp, float4* __restrict__ out) {
     const DeviceSensor& se = *sep;
     const uint32_t npx = (uint32_t)(se.film_w * se.film_h);
     const uint32_t npix = (uint32_t)(se.sb_w * se.sb_h);
@@ -463,11 +467,9 @@ __global__ __launch_bounds__(kBlock) void k_film_gather(const DeviceSensor* __re
                     for (int sy = y0; sy <= y1; ++sy)
                         for (int sx = x0; sx <= x1; ++sx) {
                             const uint32_t pix = (uint32_t)(sy - se.sb_min[1]) * (uint32_t)se.sb_w + (uint32_t)(sx - se.sb_min[0]);
-                            const uint64_t pkey = ts_mix64(seed ^ ((uint64_t)(uint32_t)sx | ((uint64_t)(uint32_t)sy << 32)));
                             for (uint32_t s = 0; s < spp; ++s) {
-                                const uint64_t key = ts_mix64(pkey + (uint64_t)(sample_offset + s) * TS_GOLDEN);  // == ts_stream_key
-                                const float pfx = (float)sx + ts_uniform(key, TS_DIM_FILM_X), pfy = (float)sy + ts_uniform(key, TS_DIM_FILM_Y);
-                                const float dpx = pfx - 0.5f, dpy = pfy - 0.5f;
+                                const float2 pf = pfilm[(size_t)s * npix + pix];  // camera_sample.film, from k_film_positions
+                                const float dpx = pf.x - 0.5f, dpy = pf.y - 0.5f;
                                 float p0x = __builtin_ceilf(dpx - rx), p0y = __builtin_ceilf(dpy - ry);
                                 float p1x = __builtin_floorf(dpx + rx) + 1.0f, p1y = __builtin_floorf(dpy + ry) + 1.0f;
                                 p0x = jmax(p0x, jmax(bx0, 1.0f));

@@ -40,7 +40,7 @@ struct trhip_ctx {
     bool overlap = true;  // two-stream overlap of shadow rays (depth d) with closest-hit rays (depth d+1)
     int traversal = 2;  // 1 = literal accel/bvh.jl loop, 2 = children-in-parent nodes + per-lane ray replacement
     // workspace (grown on demand, reused across calls)
-    DevBuf q[2][3], sq[3], hits, Lbuf, counters, sensor, table, film, scratch[4], overflow;
+    DevBuf q[2][3], sq[3], hits, Lbuf, pfilm, counters, sensor, table, film, scratch[4], overflow;
     uint64_t last_L_count = 0;  // float4 entries valid in Lbuf
 };
 
@@ -482,11 +482,11 @@ int render_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sensor* se
     if (batch_paths == 0) {
         size_t free_b = 0, total_b = 0;
         HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
-        size_t held = ctx->Lbuf.bytes + ctx->hits.bytes + ctx->overflow.bytes;  // reused below, so it counts as available
+        size_t held = ctx->Lbuf.bytes + ctx->pfilm.bytes + ctx->hits.bytes + ctx->overflow.bytes;  // reused below, so it counts as available
         for (auto& a : ctx->q)
             for (auto& b : a) held += b.bytes;
         for (auto& b : ctx->sq) held += b.bytes;
-        const double avail = 0.85 * (double)(free_b + held) - (double)total_slots * sizeof(float4) - 256e6;
+        const double avail = 0.85 * (double)(free_b + held) - (double)total_slots * (sizeof(float4) + sizeof(float2)) - 256e6;
         batch_paths = avail > 0 ? (uint64_t)(avail / 160.0) : npix;
     }
     uint64_t spp_batch = std::max<uint64_t>(1, batch_paths / npix);
@@ -502,6 +502,7 @@ int render_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sensor* se
         if (int rc = ensure(ctx, ctx->sq[j], P * sizeof(float4))) return rc;
     if (int rc = ensure(ctx, ctx->hits, P * sizeof(float4))) return rc;
     if (int rc = ensure(ctx, ctx->Lbuf, total_slots * sizeof(float4))) return rc;
+    if (int rc = ensure(ctx, ctx->pfilm, total_slots * sizeof(float2))) return rc;
     if (int rc = ensure(ctx, ctx->counters, sizeof(Counters))) return rc;
     const size_t film_bytes = (size_t)ds.film_w * ds.film_h * sizeof(float4);
     void* d_film = out;
@@ -526,7 +527,7 @@ int render_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sensor* se
     HIP_TRY(ctx, hipMemsetAsync(ctr, 0, sizeof(Counters), st));
     HIP_TRY(ctx, hipMemsetAsync(L, 0, total_slots * sizeof(float4), st));
     if (int rc = ensure_overflow(ctx)) return rc;
-    const int g_shade = ctx->num_cu * 4;
+    const int g_shade = ctx->num_cu * 8;
     uint32_t n_batches = 0;
     // Shadow rays of depth d (k_trace any-hit + accumulate) and closest-hit rays of depth d+1 are independent: they run on two
     // streams so that the long single-ray tail of one overlaps with the bulk of the other (DESIGN.md "tails").
@@ -563,7 +564,9 @@ int render_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sensor* se
         if (st2 != st) HIP_TRY(ctx, hipStreamWaitEvent(st, ev_any, 0));  // the next batch (or the film gather) needs every shadow ray resolved
     }
     tm.begin(4, st);
-    hipLaunchKernelGGL(k_film_gather, dim3(grid_for(ctx, (uint64_t)ds.film_w * ds.film_h, 8)), dim3(kBlock), 0, st, dsp, (const float*)ctx->table.p, L, spp, seed, sample_offset, (float4*)d_film);
+    hipLaunchKernelGGL(k_film_positions, dim3(grid_for(ctx, total_slots, 8)), dim3(kBlock), 0, st, dsp, total_slots, seed, sample_offset, (float2*)ctx->pfilm.p);
+    hipLaunchKernelGGL(k_film_gather, dim3(grid_for(ctx, (uint64_t)ds.film_w * ds.film_h, 8)), dim3(kBlock), 0, st, dsp, (const float*)ctx->table.p, L, (const float2*)ctx->pfilm.p, spp,
+                       (float4*)d_film);
     tm.end(4, st);
     HIP_TRY(ctx, hipEventRecord(e1, st));
     HIP_TRY(ctx, hipGetLastError());
@@ -640,6 +643,7 @@ void trhip_shutdown(trhip_ctx* ctx) {
     release(ctx->table);
     release(ctx->film);
     release(ctx->overflow);
+    release(ctx->pfilm);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     delete ctx;
@@ -989,9 +993,11 @@ int trhip_film_accumulate(trhip_ctx* ctx, const trhip_sensor* sn, uint32_t spp, 
     if (int rc = ensure(ctx, ctx->Lbuf, n * sizeof(float4))) return rc;
     const size_t film_bytes = (size_t)ds.film_w * ds.film_h * sizeof(float4);
     if (int rc = ensure(ctx, ctx->film, film_bytes)) return rc;
+    if (int rc = ensure(ctx, ctx->pfilm, n * sizeof(float2))) return rc;
     if (n) hipLaunchKernelGGL(k_import_L, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const float*)ctx->scratch[0].p, n, (float4*)ctx->Lbuf.p);
+    hipLaunchKernelGGL(k_film_positions, dim3(grid_for(ctx, n, 8)), dim3(kBlock), 0, ctx->stream, (const DeviceSensor*)ctx->sensor.p, n, seed, sample_offset, (float2*)ctx->pfilm.p);
     hipLaunchKernelGGL(k_film_gather, dim3(grid_for(ctx, (uint64_t)ds.film_w * ds.film_h, 8)), dim3(kBlock), 0, ctx->stream, (const DeviceSensor*)ctx->sensor.p, (const float*)ctx->table.p,
-                       (const float4*)ctx->Lbuf.p, spp, seed, sample_offset, (float4*)ctx->film.p);
+                       (const float4*)ctx->Lbuf.p, (const float2*)ctx->pfilm.p, spp, (float4*)ctx->film.p);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->last_L_count = n;
