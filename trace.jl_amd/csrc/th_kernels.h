@@ -29,15 +29,58 @@ struct ShadowQueue {
     float4* c;  // β·Ld to add when unoccluded
 };
 constexpr int kMaxDepth = 62;
+// Queues are split into kSeg segments, each with its own fill counter (and its own k_trace2 work cursor): a single hot
+// counter word serialises at ~88 returning atomics/us on MI355X, which at one atomic per wave per bounce was the whole
+// run time of the shading kernel; 32 words on different L2 channels are not a bottleneck.
+constexpr int kSeg = 32;
+constexpr uint32_t kSegGran = 256;  // a segment's share of the flat work space is padded to a multiple of this
 struct Counters {  // device-resident
-    // per wavefront batch (zeroed by one memset at batch start): index d = path depth - 1
-    uint32_t n_queue[kMaxDepth + 2];       // live paths entering depth d+1
-    uint32_t n_shadow[kMaxDepth + 2];      // shadow rays emitted at depth d+1
-    uint32_t work_closest[kMaxDepth + 2];  // k_trace2 dynamic ray fetch cursors
-    uint32_t work_shadow[kMaxDepth + 2];
+    // per wavefront batch (zeroed by one memset at batch start): first index = path depth - 1
+    uint32_t n_queue[kMaxDepth + 2][kSeg];       // live paths entering that depth, per segment
+    uint32_t n_shadow[kMaxDepth + 2][kSeg];      // shadow rays emitted at that depth
+    uint32_t work_closest[kMaxDepth + 2][kSeg];  // k_trace2 dynamic ray-fetch cursors
+    uint32_t work_shadow[kMaxDepth + 2][kSeg];
     // per render call
     unsigned long long closest_total, shadow_total, nodes_closest, prims_closest, nodes_shadow, prims_shadow;
 };
+// How a kernel sees a queue: kSeg segments of `cap` physical entries with fill counts in HBM, or (counts == nullptr) one
+// dense array of n_dense entries (kernel-level API entry points).
+struct SegQueue {
+    const uint32_t* counts;
+    uint32_t cap;
+    uint32_t n_dense;
+};
+struct SegView {  // per-block copy in LDS
+    uint32_t count[kSeg];
+    uint32_t prefix[kSeg + 1];  // padded prefix sums: the flat work space
+};
+// Block-wide: load the counts and build the padded prefix.  Contains a barrier.
+TH_D void seg_load(const SegQueue& q, SegView& v) {
+    if (threadIdx.x < kSeg) v.count[threadIdx.x] = q.counts ? min(q.counts[threadIdx.x], q.cap) : (threadIdx.x == 0 ? q.n_dense : 0u);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t acc = 0;
+        for (int s = 0; s < kSeg; ++s) {
+            v.prefix[s] = acc;
+            acc += (v.count[s] + kSegGran - 1) / kSegGran * kSegGran;
+        }
+        v.prefix[kSeg] = acc;
+    }
+    __syncthreads();
+}
+TH_D uint32_t seg_total(const SegView& v) {
+    uint32_t t = 0;
+    for (int s = 0; s < kSeg; ++s) t += v.count[s];
+    return t;
+}
+// flat_base: wave-uniform multiple of 64 inside [0, prefix[kSeg]).  Returns the segment and the local index of lane 0.
+TH_D void seg_locate(const SegView& v, uint32_t flat_base, uint32_t& seg, uint32_t& local_base) {
+    uint32_t s = 0;
+    while (s + 1 < (uint32_t)kSeg && flat_base >= v.prefix[s + 1]) ++s;
+    seg = s;
+    local_base = flat_base - v.prefix[s];
+}
+TH_D uint32_t seg_phys(const SegQueue& q, uint32_t seg, uint32_t local) { return q.counts ? seg * q.cap + local : local; }
 
 TH_D uint32_t lane_id() { return __lane_id(); }
 // wave-level compaction: returns this lane's output index (valid when `alive`), one atomic per wave
@@ -93,7 +136,7 @@ TH_D void generate_ray(const DeviceSensor& se, f2 film, f2 lens, float time_u, f
 }
 
 __global__ __launch_bounds__(kBlock) void k_raygen(const DeviceSensor* __restrict__ sep, uint32_t slot0, uint32_t n, uint64_t seed, uint32_t sample_offset,
-                                                   PathQueue q, Counters* ctr) {
+                                                   PathQueue q, uint32_t cap, Counters* ctr) {
     const DeviceSensor& se = *sep;
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
         const uint32_t slot = slot0 + i;
@@ -105,11 +148,19 @@ __global__ __launch_bounds__(kBlock) void k_raygen(const DeviceSensor* __restric
         float time;
         generate_ray(se, film, lens, ts_uniform(key, TS_DIM_TIME), o, d, time);
         d = check_direction(d);  // intersect!(bvh, ray) starts with check_direction! (bvh.jl:217)
-        q.o[i] = make_float4(o.x, o.y, o.z, __uint_as_float(slot));
-        q.d[i] = make_float4(d.x, d.y, d.z, 0.0f);
-        q.beta[i] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+        // wave w of the dense index space goes to segment w % kSeg
+        const uint32_t w = i >> 6;
+        const uint32_t phys = (w % kSeg) * cap + (w / kSeg) * 64u + (i & 63u);
+        q.o[phys] = make_float4(o.x, o.y, o.z, __uint_as_float(slot));
+        q.d[phys] = make_float4(d.x, d.y, d.z, 0.0f);
+        q.beta[phys] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) ctr->n_queue[0] = n;
+    if (blockIdx.x == 0 && threadIdx.x < kSeg) {
+        const uint32_t sgm = threadIdx.x, W = (n + 63u) >> 6;
+        uint32_t cnt = ((W + kSeg - 1 - sgm) / kSeg) * 64u;
+        if (W > 0 && (W - 1) % kSeg == sgm && (n & 63u)) cnt -= 64u - (n & 63u);
+        ctr->n_queue[0][sgm] = cnt;
+    }
 }
 
 // ---- traversal ------------------------------------------------------------------------------------------------------------------
@@ -206,14 +257,21 @@ TH_D bool traverse(const DeviceScene& sc, f3 o, f3 d, float t_max, uint32_t (*st
     return found;
 }
 
-// Closest hit over a queue.  hits[i] = {t or +Inf, slot or -1, b1, b2}.
+// Closest hit over a queue.  hits[phys] = {t or +Inf, slot or -1, b1, b2}.
 template <bool COUNT>
-__global__ __launch_bounds__(kBlock) void k_trace_closest(DeviceScene sc, const float4* __restrict__ ro, const float4* __restrict__ rd, const float* __restrict__ tmax_or_null,
-                                                          const uint32_t* __restrict__ count_ptr, uint32_t n_max, float4* __restrict__ hits, Counters* ctr) {
+__global__ __launch_bounds__(kBlock) void k_trace_closest(DeviceScene sc, SegQueue q, const float4* __restrict__ ro, const float4* __restrict__ rd, const float* __restrict__ tmax_or_null,
+                                                          float4* __restrict__ hits, Counters* ctr) {
     __shared__ uint32_t stk[kStackLds][kBlock];
-    const uint32_t n = count_ptr ? min(*count_ptr, n_max) : n_max;
+    __shared__ SegView sv;
+    seg_load(q, sv);
+    const uint32_t total = sv.prefix[kSeg];
     uint32_t nn = 0, np = 0;
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    for (uint32_t flat = blockIdx.x * kBlock + threadIdx.x; flat < total; flat += gridDim.x * kBlock) {
+        uint32_t seg, lb;
+        seg_locate(sv, flat & ~63u, seg, lb);
+        const uint32_t local = lb + (flat & 63u);
+        if (local >= sv.count[seg]) continue;
+        const uint32_t i = seg_phys(q, seg, local);
         const float4 o4 = ro[i], d4 = rd[i];
         Hit h;
         h.prim = -1;
@@ -223,7 +281,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest(DeviceScene sc, const 
         hits[i] = make_float4(found ? h.t : kInf, __int_as_float(found ? h.prim : -1), h.b1, h.b2);
     }
     if (ctr) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctr->closest_total, (unsigned long long)n);
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctr->closest_total, (unsigned long long)seg_total(sv));
         if (COUNT) {
             const unsigned long long sn = wave_sum(nn), spr = wave_sum(np);
             if (lane_id() == 0) {
@@ -237,13 +295,19 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest(DeviceScene sc, const 
 // Any-hit over the shadow queue; unoccluded rays add their contribution to the per-sample radiance buffer
 // (estimate_direct, sppm.jl:536-541: `!unoccluded && (Li = 0)`).  If L is null, writes occluded[i] instead.
 template <bool COUNT>
-__global__ __launch_bounds__(kBlock) void k_trace_any(DeviceScene sc, const float4* __restrict__ ro, const float4* __restrict__ rd, const float4* __restrict__ contrib,
-                                                      const float* __restrict__ tmax_or_null, const uint32_t* __restrict__ count_ptr, uint32_t n_max,
-                                                      float4* __restrict__ L, uint8_t* __restrict__ occluded, Counters* ctr) {
+__global__ __launch_bounds__(kBlock) void k_trace_any(DeviceScene sc, SegQueue q, const float4* __restrict__ ro, const float4* __restrict__ rd, const float4* __restrict__ contrib,
+                                                      const float* __restrict__ tmax_or_null, float4* __restrict__ L, uint8_t* __restrict__ occluded, Counters* ctr) {
     __shared__ uint32_t stk[kStackLds][kBlock];
-    const uint32_t n = count_ptr ? min(*count_ptr, n_max) : n_max;
+    __shared__ SegView sv;
+    seg_load(q, sv);
+    const uint32_t total = sv.prefix[kSeg];
     uint32_t nn = 0, np = 0;
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    for (uint32_t flat = blockIdx.x * kBlock + threadIdx.x; flat < total; flat += gridDim.x * kBlock) {
+        uint32_t seg, lb;
+        seg_locate(sv, flat & ~63u, seg, lb);
+        const uint32_t local = lb + (flat & 63u);
+        if (local >= sv.count[seg]) continue;
+        const uint32_t i = seg_phys(q, seg, local);
         const float4 o4 = ro[i], d4 = rd[i];
         const float t0 = tmax_or_null ? tmax_or_null[i] : kInf;
         const bool occ = traverse<true, COUNT>(sc, mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z), t0, stk, nullptr, nn, np);
@@ -272,7 +336,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_any(DeviceScene sc, const floa
         }
     }
     if (ctr) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctr->shadow_total, (unsigned long long)n);
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctr->shadow_total, (unsigned long long)seg_total(sv));
         if (COUNT) {
             const unsigned long long sn = wave_sum(nn), spr = wave_sum(np);
             if (lane_id() == 0) {
@@ -309,16 +373,24 @@ TH_D bool rebuild_shading(const DeviceScene& sc, int prim, f3 o, f3 d, Shading& 
 
 // One PathIntegrator vertex (DESIGN.md "PathIntegrator"; sppm.jl:208-266 without the visible-point early-out, β on the
 // direct term, RR as :257-263; uniform_sample_one_light / estimate_direct sppm.jl:503-554).
-__global__ __launch_bounds__(kBlock) void k_shade_path(DeviceScene sc, const DeviceSensor* __restrict__ sep, PathQueue qin, PathQueue qout, ShadowQueue sq,
-                                                       const float4* __restrict__ hits, float4* __restrict__ L, Counters* ctr, int cur, int depth, int max_depth,
-                                                       uint64_t seed, uint32_t sample_offset) {
+__global__ __launch_bounds__(kBlock) void k_shade_path(DeviceScene sc, const DeviceSensor* __restrict__ sep, PathQueue qin, PathQueue qout, ShadowQueue sq, uint32_t cap,
+                                                       const float4* __restrict__ hits, float4* __restrict__ L, Counters* ctr, int depth, int max_depth, uint64_t seed,
+                                                       uint32_t sample_offset) {
     const DeviceSensor& se = *sep;
-    const uint32_t n = ctr->n_queue[depth - 1];
-    const uint32_t n_round = (n + 63u) & ~63u;  // keep whole waves in the loop so ballots see every lane
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n_round; i += gridDim.x * kBlock) {
+    __shared__ SegView sv;
+    const SegQueue qv{ctr->n_queue[depth - 1], cap, 0u};
+    seg_load(qv, sv);
+    const uint32_t total = sv.prefix[kSeg];  // multiple of kSegGran: whole waves stay in the loop, so ballots see every lane
+    for (uint32_t flat = blockIdx.x * kBlock + threadIdx.x; flat < total; flat += gridDim.x * kBlock) {
+        uint32_t seg_in, lb;
+        seg_locate(sv, flat & ~63u, seg_in, lb);
+        const uint32_t local = lb + (flat & 63u);
+        const bool valid = local < sv.count[seg_in];
+        const uint32_t i = seg_in * cap + local;
+        const uint32_t seg_out = (flat >> 6) % kSeg;  // every wave-iteration feeds one output segment: at most cap entries each
         bool want_shadow = false, want_next = false;
         float4 so4, sd4, sc4, no4, nd4, nb4;
-        if (i < n) {
+        if (valid) {
             const float4 h4 = hits[i];
             const int prim = __float_as_int(h4.y);
             if (prim >= 0) {
@@ -399,13 +471,13 @@ __global__ __launch_bounds__(kBlock) void k_shade_path(DeviceScene sc, const Dev
                 }
             }
         }
-        const uint32_t si = wave_compact(want_shadow, &ctr->n_shadow[depth - 1]);
+        const uint32_t si = seg_out * cap + wave_compact(want_shadow, &ctr->n_shadow[depth - 1][seg_out]);
         if (want_shadow) {
             sq.o[si] = so4;
             sq.d[si] = sd4;
             sq.c[si] = sc4;
         }
-        const uint32_t ni = wave_compact(want_next, &ctr->n_queue[depth]);
+        const uint32_t ni = seg_out * cap + wave_compact(want_next, &ctr->n_queue[depth][seg_out]);
         if (want_next) {
             qout.o[ni] = no4;
             qout.d[ni] = nd4;

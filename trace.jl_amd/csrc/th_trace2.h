@@ -1,5 +1,5 @@
 // th_trace2.h — traversal kernel v2: same results, bit for bit, as accel/bvh.jl:212-299 walked in the reference's order
-// (k_trace in th_kernels.h is the literal form), restructured for gfx950:
+// (k_trace_closest / k_trace_any in th_kernels.h are the literal form), restructured for gfx950:
 //
 //  * "children-in-parent" nodes (64 B, one 4 x dwordx4 burst per interior node): both child boxes + child refs + split
 //    axis.  Every node's box is still tested with the reference's slab arithmetic (bounds.jl:186-206) exactly once; the
@@ -8,9 +8,10 @@
 //    which is what the reference evaluates then (t_max can even grow: sphere.jl:137-138 / primitive.jl:17, A.8).
 //    Leaves are not fetched at all (a leaf is a child ref = first primitive slot + count).  Dependent loads per ray
 //    halve.
-//  * persistent waves with per-lane ray replacement: a lane whose ray finished pulls the next ray index (one atomic per
-//    wave per refill, ballot + popcount ranks) instead of idling until the slowest of its 63 neighbours is done —
-//    visit counts per ray are heavy-tailed (grazing rays over a height field visit 10-100x the mean).
+//  * persistent waves with per-lane ray replacement: a lane whose ray finished takes the next ray index from the wave's
+//    chunk (kChunk indices per atomic on one of kSeg per-segment cursors; ballot + popcount ranks) instead of idling until
+//    the slowest of its 63 neighbours is done — visit counts per ray are heavy-tailed (grazing rays over a height field
+//    visit 100-1000x the median).
 //  * stack entries {ref, tx_min}: 16 levels per lane in LDS as stack[level][lane] (conflict-free), deeper levels in a
 //    global overflow slab laid out [level][thread] (coalesced); 64 levels in total like bvh.jl:222.
 #pragma once
@@ -21,7 +22,7 @@ namespace th {
 constexpr int kStack2Lds = 16;
 constexpr int kStack2Total = 64;
 constexpr uint32_t kRefNone = 0xffffffffu;
-constexpr int kChunk = 256;  // ray indices a wave takes from the global cursor per atomic
+constexpr int kChunk = 256;  // ray indices a wave takes from a segment cursor per atomic (== kSegGran)
 
 struct WideScene {            // device view of the v2 node array
     const float4* wnodes;     // 4 float4 per interior node
@@ -57,12 +58,12 @@ struct TraceOut {
 };
 
 template <bool ANY, bool COUNT>
-__global__ __launch_bounds__(kBlock) void k_trace2(DeviceScene sc, WideScene ws, const float4* __restrict__ ro, const float4* __restrict__ rd, const float* __restrict__ tmax_or_null,
-                                                   const uint32_t* __restrict__ count_ptr, uint32_t n_max, TraceOut out, uint32_t* __restrict__ work_counter,
-                                                   uint2* __restrict__ overflow, Counters* ctr) {
+__global__ __launch_bounds__(kBlock) void k_trace2(DeviceScene sc, WideScene ws, SegQueue q, const float4* __restrict__ ro, const float4* __restrict__ rd, const float* __restrict__ tmax_or_null,
+                                                   TraceOut out, uint32_t* __restrict__ work /* kSeg cursors, zeroed */, uint2* __restrict__ overflow, Counters* ctr) {
     __shared__ uint32_t s_ref[kStack2Lds][kBlock];
     __shared__ float s_tmin[kStack2Lds][kBlock];
-    const uint32_t n = count_ptr ? min(*count_ptr, n_max) : n_max;
+    __shared__ SegView sv;
+    seg_load(q, sv);
     const uint32_t tid = threadIdx.x;
     const uint32_t gthreads = gridDim.x * kBlock;
     const uint32_t gtid = blockIdx.x * kBlock + tid;
@@ -70,7 +71,8 @@ __global__ __launch_bounds__(kBlock) void k_trace2(DeviceScene sc, WideScene ws,
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
     bool active = false, exhausted = false;
-    uint32_t pool_next = 0, pool_end = 0;  // wave-uniform: the chunk of ray indices this wave currently owns
+    // wave-uniform: the segment this wave is draining, consecutive drained segments seen, the chunk it currently owns
+    uint32_t wseg = (gtid >> 6) % kSeg, dry = 0, pool_next = 0, pool_end = 0;
     uint32_t idx = 0, cur = kRefNone, cur_cnt = 0;
     int sp = 0;
     f3 o = splat3(0.0f), d = splat3(0.0f), inv_d = splat3(0.0f);
@@ -81,25 +83,31 @@ __global__ __launch_bounds__(kBlock) void k_trace2(DeviceScene sc, WideScene ws,
     uint32_t nn = 0, np = 0;
 
     while (true) {
-        // ---- refill idle lanes: ray indices come in chunks of kChunk per wave (one atomic per chunk) -------------------------
+        // ---- refill idle lanes ------------------------------------------------------------------------------------------------
         const unsigned long long idle = __ballot(!active);
         const uint32_t n_idle = (uint32_t)__popcll(idle);
         if (n_idle == 64u || (!exhausted && n_idle >= 12u)) {
             if (!exhausted) {
-                if (pool_next >= pool_end) {
+                if (pool_next >= pool_end) {  // take the next chunk: try this wave's segment, move on when it is drained
                     uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(work_counter, (uint32_t)kChunk);
+                    if (lane == 0) base = atomicAdd(&work[wseg], (uint32_t)kChunk);
                     base = __shfl(base, 0);
-                    pool_next = base;
-                    pool_end = min(base + (uint32_t)kChunk, n);
-                    if (base >= n) {
-                        exhausted = true;
+                    const uint32_t cnt = sv.count[wseg];
+                    if (base < cnt) {
+                        pool_next = base;
+                        pool_end = min(base + (uint32_t)kChunk, cnt);
+                        dry = 0;
+                    } else {
                         pool_next = pool_end = 0;
+                        wseg = (wseg + 1) % kSeg;
+                        if (++dry >= (uint32_t)kSeg) exhausted = true;
                     }
                 }
-                if (!exhausted && !active) {
-                    idx = pool_next + (uint32_t)__popcll(idle & lt_mask);
-                    if (idx < pool_end) {
+                const uint32_t avail = pool_end - pool_next;
+                if (avail && !active) {
+                    const uint32_t rank = (uint32_t)__popcll(idle & lt_mask);
+                    if (rank < avail) {
+                        idx = seg_phys(q, wseg, pool_next + rank);
                         const float4 o4 = ro[idx], d4 = rd[idx];
                         o = mk3(o4.x, o4.y, o4.z);
                         d = mk3(d4.x, d4.y, d4.z);
@@ -126,11 +134,11 @@ __global__ __launch_bounds__(kBlock) void k_trace2(DeviceScene sc, WideScene ws,
                         }
                     }
                 }
-                pool_next = min(pool_next + n_idle, pool_end);
+                pool_next += min(n_idle, avail);
             }
             if (__ballot(active) == 0ull) {
                 if (exhausted) break;
-                continue;  // chunk ran dry before any lane got a ray: fetch the next chunk
+                continue;  // nothing fetched yet (chunk ran dry / segment drained): try again
             }
         }
         // ---- a few traversal steps ------------------------------------------------------------------------------------------
@@ -269,7 +277,7 @@ __global__ __launch_bounds__(kBlock) void k_trace2(DeviceScene sc, WideScene ws,
         }
     }
     if (ctr) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(ANY ? &ctr->shadow_total : &ctr->closest_total, (unsigned long long)n);
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(ANY ? &ctr->shadow_total : &ctr->closest_total, (unsigned long long)seg_total(sv));
         if (COUNT) {
             const unsigned long long sn = wave_sum(nn), spr = wave_sum(np);
             if (lane_id() == 0) {

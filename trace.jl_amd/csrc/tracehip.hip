@@ -394,8 +394,8 @@ int ensure_overflow(trhip_ctx* ctx) {
 
 // One traversal launch over a queue (count in HBM at count_ptr, or n_max when count_ptr is null).
 // ctx->traversal == 1: the literal accel/bvh.jl loop (k_trace_closest / k_trace_any); 2: k_trace2 (same results).
-void launch_trace(trhip_ctx* ctx, hipStream_t st, const trhip_scene* sc, bool any, const float4* ro, const float4* rd, const float* tmax, const uint32_t* count_ptr, uint32_t n_max,
-                  TraceOut out, uint32_t* work_counter, Counters* ctr) {
+void launch_trace(trhip_ctx* ctx, hipStream_t st, const trhip_scene* sc, bool any, SegQueue q, const float4* ro, const float4* rd, const float* tmax, TraceOut out, uint32_t* work_cursors,
+                  Counters* ctr) {
     const dim3 grid(trace_grid(ctx)), block(kBlock);
     const bool v2 = ctx->traversal == 2 && sc->wide_ok;
     const bool cnt = ctx->count_visits;
@@ -403,27 +403,27 @@ void launch_trace(trhip_ctx* ctx, hipStream_t st, const trhip_scene* sc, bool an
         uint2* ov = (uint2*)ctx->overflow.p;
         if (any) {
             if (cnt)
-                hipLaunchKernelGGL((k_trace2<true, true>), grid, block, 0, st, sc->dev, sc->wide, ro, rd, tmax, count_ptr, n_max, out, work_counter, ov, ctr);
+                hipLaunchKernelGGL((k_trace2<true, true>), grid, block, 0, st, sc->dev, sc->wide, q, ro, rd, tmax, out, work_cursors, ov, ctr);
             else
-                hipLaunchKernelGGL((k_trace2<true, false>), grid, block, 0, st, sc->dev, sc->wide, ro, rd, tmax, count_ptr, n_max, out, work_counter, ov, ctr);
+                hipLaunchKernelGGL((k_trace2<true, false>), grid, block, 0, st, sc->dev, sc->wide, q, ro, rd, tmax, out, work_cursors, ov, ctr);
         } else {
             if (cnt)
-                hipLaunchKernelGGL((k_trace2<false, true>), grid, block, 0, st, sc->dev, sc->wide, ro, rd, tmax, count_ptr, n_max, out, work_counter, ov, ctr);
+                hipLaunchKernelGGL((k_trace2<false, true>), grid, block, 0, st, sc->dev, sc->wide, q, ro, rd, tmax, out, work_cursors, ov, ctr);
             else
-                hipLaunchKernelGGL((k_trace2<false, false>), grid, block, 0, st, sc->dev, sc->wide, ro, rd, tmax, count_ptr, n_max, out, work_counter, ov, ctr);
+                hipLaunchKernelGGL((k_trace2<false, false>), grid, block, 0, st, sc->dev, sc->wide, q, ro, rd, tmax, out, work_cursors, ov, ctr);
         }
         return;
     }
     if (any) {
         if (cnt)
-            hipLaunchKernelGGL(k_trace_any<true>, grid, block, 0, st, sc->dev, ro, rd, out.contrib, tmax, count_ptr, n_max, out.L, out.occluded, ctr);
+            hipLaunchKernelGGL(k_trace_any<true>, grid, block, 0, st, sc->dev, q, ro, rd, out.contrib, tmax, out.L, out.occluded, ctr);
         else
-            hipLaunchKernelGGL(k_trace_any<false>, grid, block, 0, st, sc->dev, ro, rd, out.contrib, tmax, count_ptr, n_max, out.L, out.occluded, ctr);
+            hipLaunchKernelGGL(k_trace_any<false>, grid, block, 0, st, sc->dev, q, ro, rd, out.contrib, tmax, out.L, out.occluded, ctr);
     } else {
         if (cnt)
-            hipLaunchKernelGGL(k_trace_closest<true>, grid, block, 0, st, sc->dev, ro, rd, tmax, count_ptr, n_max, out.hits, ctr);
+            hipLaunchKernelGGL(k_trace_closest<true>, grid, block, 0, st, sc->dev, q, ro, rd, tmax, out.hits, ctr);
         else
-            hipLaunchKernelGGL(k_trace_closest<false>, grid, block, 0, st, sc->dev, ro, rd, tmax, count_ptr, n_max, out.hits, ctr);
+            hipLaunchKernelGGL(k_trace_closest<false>, grid, block, 0, st, sc->dev, q, ro, rd, tmax, out.hits, ctr);
     }
 }
 
@@ -487,20 +487,24 @@ int render_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sensor* se
             for (auto& b : a) held += b.bytes;
         for (auto& b : ctx->sq) held += b.bytes;
         const double avail = 0.85 * (double)(free_b + held) - (double)total_slots * (sizeof(float4) + sizeof(float2)) - 256e6;
-        batch_paths = avail > 0 ? (uint64_t)(avail / 160.0) : npix;
+        batch_paths = avail > 0 ? (uint64_t)(avail / 164.0) : npix;
     }
     uint64_t spp_batch = std::max<uint64_t>(1, batch_paths / npix);
     spp_batch = std::min<uint64_t>(spp_batch, spp);
     while (npix * spp_batch >= (1ull << 31)) spp_batch = (spp_batch + 1) / 2;  // queue indices are 32-bit
     const uint64_t P = npix * spp_batch;
+    // physical queue layout: kSeg segments of `cap` entries (th_kernels.h "SegQueue"); a segment receives at most
+    // P/kSeg + O(kSegGran) entries per bounce by construction
+    const uint32_t cap = (uint32_t)(((P + kSeg - 1) / kSeg + 2 * kSegGran + kSegGran - 1) / kSegGran * kSegGran);
+    const uint64_t Pphys = (uint64_t)cap * kSeg;
     if (int rc = upload(ctx, ctx->sensor, &ds, sizeof ds)) return rc;
     if (int rc = upload(ctx, ctx->table, sensor->filter_table, 256 * sizeof(float))) return rc;
     for (int k = 0; k < 2; ++k)
         for (int j = 0; j < 3; ++j)
-            if (int rc = ensure(ctx, ctx->q[k][j], P * sizeof(float4))) return rc;
+            if (int rc = ensure(ctx, ctx->q[k][j], Pphys * sizeof(float4))) return rc;
     for (int j = 0; j < 3; ++j)
-        if (int rc = ensure(ctx, ctx->sq[j], P * sizeof(float4))) return rc;
-    if (int rc = ensure(ctx, ctx->hits, P * sizeof(float4))) return rc;
+        if (int rc = ensure(ctx, ctx->sq[j], Pphys * sizeof(float4))) return rc;
+    if (int rc = ensure(ctx, ctx->hits, Pphys * sizeof(float4))) return rc;
     if (int rc = ensure(ctx, ctx->Lbuf, total_slots * sizeof(float4))) return rc;
     if (int rc = ensure(ctx, ctx->pfilm, total_slots * sizeof(float2))) return rc;
     if (int rc = ensure(ctx, ctx->counters, sizeof(Counters))) return rc;
@@ -540,23 +544,23 @@ int render_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sensor* se
         n_batches++;
         HIP_TRY(ctx, hipMemsetAsync(ctr, 0, offsetof(Counters, closest_total), st));  // queue sizes + work cursors of this batch
         tm.begin(0, st);
-        hipLaunchKernelGGL(k_raygen, dim3(grid_for(ctx, nb, 8)), dim3(kBlock), 0, st, dsp, (uint32_t)(s0 * npix), (uint32_t)nb, seed, sample_offset, pq[0], ctr);
+        hipLaunchKernelGGL(k_raygen, dim3(grid_for(ctx, nb, 8)), dim3(kBlock), 0, st, dsp, (uint32_t)(s0 * npix), (uint32_t)nb, seed, sample_offset, pq[0], cap, ctr);
         tm.end(0, st);
         int cur = 0;
         for (int depth = 1; depth <= max_depth; ++depth) {
             tm.begin(1, st);
-            launch_trace(ctx, st, scene, false, pq[cur].o, pq[cur].d, nullptr, &ctr->n_queue[depth - 1], (uint32_t)nb, TraceOut{hits, nullptr, nullptr, nullptr}, &ctr->work_closest[depth - 1], ctr);
+            launch_trace(ctx, st, scene, false, SegQueue{ctr->n_queue[depth - 1], cap, 0u}, pq[cur].o, pq[cur].d, nullptr, TraceOut{hits, nullptr, nullptr, nullptr}, ctr->work_closest[depth - 1], ctr);
             tm.end(1, st);
             if (st2 != st && depth > 1) HIP_TRY(ctx, hipStreamWaitEvent(st, ev_any, 0));  // shade(d) reuses the shadow queue and touches L
             tm.begin(2, st);
-            hipLaunchKernelGGL(k_shade_path, dim3(g_shade), dim3(kBlock), 0, st, scene->dev, dsp, pq[cur], pq[cur ^ 1], sq, hits, L, ctr, cur, depth, max_depth, seed, sample_offset);
+            hipLaunchKernelGGL(k_shade_path, dim3(g_shade), dim3(kBlock), 0, st, scene->dev, dsp, pq[cur], pq[cur ^ 1], sq, cap, hits, L, ctr, depth, max_depth, seed, sample_offset);
             tm.end(2, st);
             if (st2 != st) {
                 HIP_TRY(ctx, hipEventRecord(ev_shade, st));
                 HIP_TRY(ctx, hipStreamWaitEvent(st2, ev_shade, 0));
             }
             tm.begin(3, st2);
-            launch_trace(ctx, st2, scene, true, sq.o, sq.d, nullptr, &ctr->n_shadow[depth - 1], (uint32_t)nb, TraceOut{nullptr, L, sq.c, nullptr}, &ctr->work_shadow[depth - 1], ctr);
+            launch_trace(ctx, st2, scene, true, SegQueue{ctr->n_shadow[depth - 1], cap, 0u}, sq.o, sq.d, nullptr, TraceOut{nullptr, L, sq.c, nullptr}, ctr->work_shadow[depth - 1], ctr);
             tm.end(3, st2);
             if (st2 != st) HIP_TRY(ctx, hipEventRecord(ev_any, st2));
             cur ^= 1;
@@ -891,8 +895,8 @@ static int api_trace(trhip_ctx* ctx, const trhip_scene* sc, bool any, const void
     HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
     if (n)
         for (int r = 0; r < repeat; ++r)  // every repetition uses its own (zeroed) work cursor
-            launch_trace(ctx, ctx->stream, sc, any, (const float4*)ctx->scratch[0].p, (const float4*)ctx->scratch[1].p, (const float*)ctx->scratch[2].p, nullptr, (uint32_t)n, out,
-                         any ? &ctr->work_shadow[r] : &ctr->work_closest[r], ctr);
+            launch_trace(ctx, ctx->stream, sc, any, SegQueue{nullptr, (uint32_t)n, (uint32_t)n}, (const float4*)ctx->scratch[0].p, (const float4*)ctx->scratch[1].p, (const float*)ctx->scratch[2].p,
+                         out, any ? ctr->work_shadow[r] : ctr->work_closest[r], ctr);
     HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
