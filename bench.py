@@ -78,12 +78,12 @@ def main():
     t_build = time.time() - t0
     h, w = cam.film.size
     film = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
-    integ = T.PathIntegrator(cam, T.SeededSampler(args.spp, seed=args.seed, sample_offset=rank * args.spp), args.depth)
+    integ = T.PathIntegrator(cam, T.SeededSampler(args.spp, seed=args.seed, sample_offset=T.parallel.shard_sample_offset(rank, args.spp)), args.depth)
 
     def step():
         integ.render(scene, ctx, device_out=film.data_ptr())
         if world > 1:
-            dist.reduce(film, dst=0, op=dist.ReduceOp.SUM)  # Film pixels are additive (film.jl:161-162, 190-191)
+            T.parallel.reduce_film(film, dst=0)  # Film pixels are additive (film.jl:161-162, 190-191)
         return integ.stats
 
     def sync():

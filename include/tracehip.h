@@ -70,10 +70,20 @@ int trhip_scene_add_triangles(trhip_scene* scene, const float* world_xyz, uint32
 int trhip_scene_add_sphere(trhip_scene* scene, const float obj2world_m[16], const float obj2world_inv_m[16], int reverse_orientation, float radius,
                            float z_min, float z_max, float phi_max_deg, uint32_t material_id, uint32_t* prim_out);
 
+/* Same, for hosts that hold an already constructed Trace.Sphere (the Julia shim): the fields exactly as the reference's
+ * constructor derived them (sphere.jl:13-26: clamped z_min/z_max, θ_min, θ_max, ϕ_max in radians), so that no
+ * elementary function is re-evaluated on this side of the boundary. */
+int trhip_scene_add_sphere_fields(trhip_scene* scene, const float obj2world_m[16], const float obj2world_inv_m[16], int reverse_orientation, float radius,
+                                  float z_min, float z_max, float theta_min, float theta_max, float phi_max_rad, uint32_t material_id, uint32_t* prim_out);
+
 /* PointLight(light_to_world, I)  lights/point.jl:19-24 ;  SpotLight(light_to_world, I, total°, falloff_start°)  lights/spot.jl:10-19 */
 int trhip_scene_add_point_light(trhip_scene* scene, const float light2world_m[16], const float light2world_inv_m[16], const float I[3]);
 int trhip_scene_add_spot_light(trhip_scene* scene, const float light2world_m[16], const float light2world_inv_m[16], const float I[3],
                                float total_width_deg, float falloff_start_deg);
+
+/* SpotLight from its constructed fields (cos_total_width, cos_falloff_start; lights/spot.jl:1-8). */
+int trhip_scene_add_spot_light_fields(trhip_scene* scene, const float light2world_m[16], const float light2world_inv_m[16], const float I[3],
+                                      float cos_total_width, float cos_falloff_start);
 
 /* BVHAccel(primitives, max_node_primitives)  accel/bvh.jl:55-79.  Builds a binned-SAH BVH2 on the host (results of
  * traversal do not depend on the topology except for exact-t ties), flattens it in the reference's

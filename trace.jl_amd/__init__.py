@@ -11,4 +11,4 @@ The directory is named ``trace.jl_amd`` (not importable by that name); load it a
 """
 from ._ffi import Context, Sensor, Stats, TraceHipError, default_context, lib  # noqa: F401
 from .api import *  # noqa: F401,F403
-from . import api, scenes  # noqa: F401
+from . import api, parallel, scenes  # noqa: F401

@@ -726,20 +726,10 @@ int trhip_scene_add_triangles(trhip_scene* s, const float* xyz, uint32_t n_verts
     s->committed = false;
     return 0;
 }
-int trhip_scene_add_sphere(trhip_scene* s, const float* o2w, const float* o2w_inv, int reverse, float radius, float z_min, float z_max, float phi_max_deg, uint32_t material,
-                           uint32_t* prim_out) {
-    if (!s || !o2w || !o2w_inv) return fail(s ? s->ctx : nullptr, TRHIP_ERR_INVALID, "null argument");
+static int add_sphere_rec(trhip_scene* s, const float* o2w, const float* o2w_inv, int reverse, SphereRec r, uint32_t material, uint32_t* prim_out) {
     if (material != PRIM_NO_MATERIAL && material >= s->materials.size()) return fail(s->ctx, TRHIP_ERR_INVALID, "material %u not defined", material);
-    SphereRec r;
-    std::memset(&r, 0, sizeof r);
     std::memcpy(r.o2w, o2w, sizeof r.o2w);
     std::memcpy(r.o2w_inv, o2w_inv, sizeof r.o2w_inv);
-    r.radius = radius;  // Sphere ctor sphere.jl:13-26
-    r.z_min = jclamp(jmin(z_min, z_max), -radius, radius);
-    r.z_max = jclamp(jmax(z_min, z_max), -radius, radius);
-    r.theta_min = tm_acosf(jclamp(jmin(z_min, z_max) / radius, -1.0f, 1.0f));
-    r.theta_max = tm_acosf(jclamp(jmax(z_min, z_max) / radius, -1.0f, 1.0f));
-    r.phi_max = deg2rad(jclamp(phi_max_deg, 0.0f, 360.0f));
     const bool swaps = det3(o2w) < 0.0f;  // transformations.jl:161-163
     r.flip = ((reverse != 0) != swaps) ? 1u : 0u;
     r.never_clipped = (!(r.z_min > -r.radius) && !(r.z_max < r.radius) && r.phi_max >= 2.0f * kPi) ? 1u : 0u;
@@ -755,7 +745,33 @@ int trhip_scene_add_sphere(trhip_scene* s, const float* o2w, const float* o2w_in
     s->committed = false;
     return 0;
 }
-static int add_light(trhip_scene* s, int kind, const float* l2w, const float* l2w_inv, const float* I, float total_deg, float falloff_deg) {
+int trhip_scene_add_sphere(trhip_scene* s, const float* o2w, const float* o2w_inv, int reverse, float radius, float z_min, float z_max, float phi_max_deg, uint32_t material,
+                           uint32_t* prim_out) {
+    if (!s || !o2w || !o2w_inv) return fail(s ? s->ctx : nullptr, TRHIP_ERR_INVALID, "null argument");
+    SphereRec r;
+    std::memset(&r, 0, sizeof r);
+    r.radius = radius;  // Sphere ctor sphere.jl:13-26
+    r.z_min = jclamp(jmin(z_min, z_max), -radius, radius);
+    r.z_max = jclamp(jmax(z_min, z_max), -radius, radius);
+    r.theta_min = tm_acosf(jclamp(jmin(z_min, z_max) / radius, -1.0f, 1.0f));
+    r.theta_max = tm_acosf(jclamp(jmax(z_min, z_max) / radius, -1.0f, 1.0f));
+    r.phi_max = deg2rad(jclamp(phi_max_deg, 0.0f, 360.0f));
+    return add_sphere_rec(s, o2w, o2w_inv, reverse, r, material, prim_out);
+}
+int trhip_scene_add_sphere_fields(trhip_scene* s, const float* o2w, const float* o2w_inv, int reverse, float radius, float z_min, float z_max, float theta_min, float theta_max,
+                                  float phi_max_rad, uint32_t material, uint32_t* prim_out) {
+    if (!s || !o2w || !o2w_inv) return fail(s ? s->ctx : nullptr, TRHIP_ERR_INVALID, "null argument");
+    SphereRec r;
+    std::memset(&r, 0, sizeof r);
+    r.radius = radius;
+    r.z_min = z_min;
+    r.z_max = z_max;
+    r.theta_min = theta_min;
+    r.theta_max = theta_max;
+    r.phi_max = phi_max_rad;
+    return add_sphere_rec(s, o2w, o2w_inv, reverse, r, material, prim_out);
+}
+static int add_light(trhip_scene* s, int kind, const float* l2w, const float* l2w_inv, const float* I, float total_deg, float falloff_deg, bool fields = false) {
     if (!s || !l2w || !l2w_inv || !I) return fail(s ? s->ctx : nullptr, TRHIP_ERR_INVALID, "null argument");
     LightRec l;
     std::memset(&l, 0, sizeof l);
@@ -766,8 +782,8 @@ static int add_light(trhip_scene* s, int kind, const float* l2w, const float* l2
     l.position[2] = pos.z;
     std::memcpy(l.I, I, 3 * sizeof(float));
     if (kind == 1) {
-        l.cos_total_width = tm_cosf(deg2rad(total_deg));  // spot.jl:17
-        l.cos_falloff_start = tm_cosf(deg2rad(falloff_deg));
+        l.cos_total_width = fields ? total_deg : tm_cosf(deg2rad(total_deg));  // spot.jl:17
+        l.cos_falloff_start = fields ? falloff_deg : tm_cosf(deg2rad(falloff_deg));
     }
     for (int r = 0; r < 3; ++r)
         for (int c = 0; c < 3; ++c) l.w2l[3 * r + c] = l2w_inv[4 * r + c];  // world_to_light = inv(light_to_world): .m = inv_m
@@ -778,6 +794,10 @@ static int add_light(trhip_scene* s, int kind, const float* l2w, const float* l2
 int trhip_scene_add_point_light(trhip_scene* s, const float* l2w, const float* l2w_inv, const float* I) { return add_light(s, 0, l2w, l2w_inv, I, 0, 0); }
 int trhip_scene_add_spot_light(trhip_scene* s, const float* l2w, const float* l2w_inv, const float* I, float total_deg, float falloff_deg) {
     return add_light(s, 1, l2w, l2w_inv, I, total_deg, falloff_deg);
+}
+
+int trhip_scene_add_spot_light_fields(trhip_scene* s, const float* l2w, const float* l2w_inv, const float* I, float cos_total, float cos_falloff) {
+    return add_light(s, 1, l2w, l2w_inv, I, cos_total, cos_falloff, true);
 }
 
 int trhip_scene_commit(trhip_scene* s, int max_node_primitives) {

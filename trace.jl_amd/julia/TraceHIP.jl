@@ -1,0 +1,190 @@
+# TraceHIP.jl — the shim a Trace.jl user loads to run the render hot path on an MI355X through libtracehip.so.
+#
+# STATUS: written against include/tracehip.h, NEVER EXECUTED — the build image has no Julia runtime (SURVEY.md F5).
+# The tested host over the same C ABI is the Python mirror (trace.jl_amd/api.py); this file is the reference-side
+# binding a maintainer would add (INTEGRATION.md).  Scene scripts stay unchanged: they build Trace.Scene / Trace.Film /
+# Trace.PerspectiveCamera with Trace.jl's own constructors (so every load-bearing matrix bug is the reference's own) and
+# call `integrator(scene)`; the methods below replace the CPU render loops of src/integrators/sampler.jl:12-56.
+module TraceHIP
+
+using Trace
+using GeometryBasics
+using StaticArrays
+
+const LIB = get(ENV, "TRACEHIP_LIB", joinpath(@__DIR__, "..", "libtracehip.so"))
+
+# ---- mirrors of the C structs (include/tracehip.h) -------------------------------------------------------------------
+struct TrhipSensor
+    raster_to_camera::NTuple{16,Float32}
+    camera_to_world::NTuple{16,Float32}
+    lens_radius::Float32
+    focal_distance::Float32
+    shutter_open::Float32
+    shutter_close::Float32
+    crop_min::NTuple{2,Float32}
+    crop_max::NTuple{2,Float32}
+    filter_radius::NTuple{2,Float32}
+    filter_table::NTuple{256,Float32}
+    scale::Float32
+end
+
+mutable struct TrhipStats
+    camera_samples::UInt64
+    closest_rays::UInt64
+    shadow_rays::UInt64
+    nodes_visited::UInt64
+    prims_tested::UInt64
+    nodes_visited_shadow::UInt64
+    prims_tested_shadow::UInt64
+    ms_total::Float64
+    ms_raygen::Float64
+    ms_trace_closest::Float64
+    ms_shade::Float64
+    ms_trace_any::Float64
+    ms_film::Float64
+    launches::NTuple{5,UInt32}
+    n_batches::UInt32
+    max_depth_reached::UInt32
+    TrhipStats() = new(0, 0, 0, 0, 0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, (0, 0, 0, 0, 0), 0, 0)
+end
+
+struct TraceHIPError <: Exception
+    code::Cint
+    msg::String
+end
+
+const CTX = Ref{Ptr{Cvoid}}(C_NULL)
+
+function context()
+    if CTX[] == C_NULL
+        rc = ccall((:trhip_init, LIB), Cint, (Ptr{Ptr{Cvoid}}, Cint), CTX, parse(Cint, get(ENV, "LOCAL_RANK", "0")))
+        rc == 0 || throw(TraceHIPError(rc, unsafe_string(ccall((:trhip_last_error, LIB), Cstring, (Ptr{Cvoid},), C_NULL))))
+    end
+    CTX[]
+end
+
+check(rc) = rc == 0 || throw(TraceHIPError(rc, unsafe_string(ccall((:trhip_last_error, LIB), Cstring, (Ptr{Cvoid},), CTX[]))))
+
+# Mat4f is column-major; the ABI wants row-major m[4*row + col].
+rowmajor(m::Mat4f) = NTuple{16,Float32}(vec(permutedims(Matrix(m))))
+rowmajor_vec(m::Mat4f) = collect(rowmajor(m))
+
+# ---- scene flattening: Scene -> BVHAccel -> GeometricPrimitive -> shape / material --------------------------------------
+const MATTE, MIRROR, GLASS, PLASTIC = Cint(0), Cint(1), Cint(2), Cint(3)
+const NO_MATERIAL = UInt32(0x00ffffff)
+
+rgb(t::Trace.ConstantTexture) = Float32[t.value.c...]
+flt(t::Trace.ConstantTexture) = Float32(t.value)
+material_params(m::Trace.MatteMaterial) = (MATTE, vcat(rgb(m.Kd), flt(m.σ)))
+material_params(m::Trace.MirrorMaterial) = (MIRROR, rgb(m.Kr))
+material_params(m::Trace.GlassMaterial) =
+    (GLASS, vcat(rgb(m.Kr), rgb(m.Kt), flt(m.u_roughness), flt(m.v_roughness), flt(m.index), m.remap_roughness ? 1f0 : 0f0))
+material_params(m::Trace.PlasticMaterial) = (PLASTIC, vcat(rgb(m.Kd), rgb(m.Ks), flt(m.roughness), m.remap_roughness ? 1f0 : 0f0))
+
+function flatten(scene::Trace.Scene)
+    ctx = context()
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:trhip_scene_new, LIB), Cint, (Ptr{Cvoid}, Ptr{Ptr{Cvoid}}), ctx, h))
+    s = h[]
+    mat_ids = IdDict{Any,UInt32}()
+    function material_id(m)
+        m === nothing && return NO_MATERIAL
+        get!(mat_ids, m) do
+            kind, params = material_params(m)
+            id = Ref{UInt32}(0)
+            check(ccall((:trhip_scene_add_material, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Float32}, Cint, Ptr{UInt32}), s, kind, params, length(params), id))
+            id[]
+        end
+    end
+    bvh = scene.aggregate::Trace.BVHAccel
+    # NOTE: bvh.primitives is already the reference builder's ordering; any order gives the same image except exact-t ties.
+    for p in bvh.primitives
+        shape = p.shape
+        if shape isa Trace.Sphere
+            o2w = shape.core.object_to_world
+            check(ccall((:trhip_scene_add_sphere_fields, LIB), Cint,
+                (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Cint, Float32, Float32, Float32, Float32, Float32, Float32, UInt32, Ptr{UInt32}),
+                s, rowmajor_vec(o2w.m), rowmajor_vec(o2w.inv_m), shape.core.reverse_orientation, shape.radius, shape.z_min, shape.z_max,
+                shape.θ_min, shape.θ_max, shape.ϕ_max, material_id(p.material), C_NULL))
+        elseif shape isa Trace.Triangle
+            mesh = shape.mesh
+            verts = reinterpret(Float32, mesh.vertices) |> collect           # already world space (triangle_mesh.jl:23)
+            idx = UInt32[mesh.indices[shape.i+j] for j in 0:2]                # 1-based
+            nrm = mesh.normals === nothing ? C_NULL : collect(reinterpret(Float32, mesh.normals))
+            flip = shape.core.reverse_orientation ⊻ shape.core.transform_swaps_handedness
+            check(ccall((:trhip_scene_add_triangles, LIB), Cint,
+                (Ptr{Cvoid}, Ptr{Float32}, UInt32, Ptr{UInt32}, UInt32, Ptr{Float32}, Ptr{UInt32}, Cint, Ptr{UInt32}),
+                s, verts, mesh.n_vertices, idx, 1, nrm, UInt32[material_id(p.material)], flip, C_NULL))
+        else
+            error("TraceHIP: unsupported shape $(typeof(shape))")
+        end
+    end
+    for l in scene.lights
+        I = Float32[l.i.c...]
+        m, im = rowmajor_vec(l.light_to_world.m), rowmajor_vec(l.light_to_world.inv_m)
+        if l isa Trace.PointLight
+            check(ccall((:trhip_scene_add_point_light, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}), s, m, im, I))
+        elseif l isa Trace.SpotLight
+            check(ccall((:trhip_scene_add_spot_light_fields, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Float32, Float32),
+                s, m, im, I, l.cos_total_width, l.cos_falloff_start))
+        else
+            error("TraceHIP: unsupported light $(typeof(l))")
+        end
+    end
+    check(ccall((:trhip_scene_commit, LIB), Cint, (Ptr{Cvoid}, Cint), s, bvh.max_node_primitives))
+    s
+end
+
+function sensor(camera::Trace.PerspectiveCamera)
+    film = Trace.get_film(camera)
+    pc = camera.core
+    TrhipSensor(rowmajor(pc.raster_to_camera.m), rowmajor(pc.core.camera_to_world.m), pc.lens_radius, pc.focal_distance,
+        pc.core.shutter_open, pc.core.shutter_close, Tuple(film.crop_bounds.p_min), Tuple(film.crop_bounds.p_max), Tuple(film.filter.radius),
+        NTuple{256,Float32}(vec(permutedims(film.filter_table))),   # (y, x) matrix -> table[16*y + x]
+        film.scale)
+end
+
+# ---- the seeded sampler (include/trace_sampler.h) behind UniformSampler's protocol ---------------------------------------
+mutable struct SeededSampler <: Trace.AbstractSampler
+    current_sample::Int64
+    samples_per_pixel::Int64
+    seed::UInt64
+    sample_offset::UInt32
+    SeededSampler(spp::Integer; seed::Integer = 0x5EED0001, sample_offset::Integer = 0) = new(1, spp, seed, sample_offset)
+end
+seed_of(s::SeededSampler) = (s.seed, s.sample_offset)
+seed_of(::Trace.UniformSampler) = (UInt64(0x5EED0001), UInt32(0))   # the reference's sampler has no seed (F7)
+
+struct PathIntegrator <: Trace.SamplerIntegrator
+    camera::Trace.Camera
+    sampler::Trace.AbstractSampler
+    max_depth::Int64
+end
+
+function render!(entry::Symbol, i, scene::Trace.Scene)
+    film = Trace.get_film(i.camera)
+    s = flatten(scene)
+    sn = Ref(sensor(i.camera))
+    h, w = size(film.pixels)
+    out = Vector{Float32}(undef, 4 * h * w)
+    stats = TrhipStats()
+    seed, offset = seed_of(i.sampler)
+    rc = ccall((entry, LIB), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{TrhipSensor}, UInt32, Cint, UInt64, UInt32, Ptr{Float32}, Ptr{TrhipStats}),
+        context(), s, sn, i.sampler.samples_per_pixel, i.max_depth, seed, offset, out, Ref(stats))
+    ccall((:trhip_scene_free, LIB), Cvoid, (Ptr{Cvoid},), s)
+    check(rc)
+    @inbounds for y in 1:h, x in 1:w            # film.pixels is (y, x); out is row-major over (y, x)
+        k = 4 * ((y - 1) * w + (x - 1))
+        px = film.pixels[y, x]
+        px.xyz = Point3f(out[k+1], out[k+2], out[k+3])
+        px.filter_weight_sum = out[k+4]
+    end
+    Trace.save(film)
+end
+
+(i::PathIntegrator)(scene::Trace.Scene) = render!(:trhip_render_path, i, scene)
+# Opt-in replacement of the CPU loop for WhittedIntegrator (shadows integrators/sampler.jl:12):
+accelerate_whitted!() = @eval (i::Trace.WhittedIntegrator)(scene::Trace.Scene) = render!(:trhip_render_whitted, i, scene)
+
+end # module
