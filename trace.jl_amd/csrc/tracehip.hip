@@ -28,6 +28,15 @@ struct DevBuf {
 };
 }  // namespace
 
+constexpr int kMaxPipes = 8;
+// One wavefront pipeline: its own queues, counters and stream pair.  Several batches of one frame run concurrently on
+// different pipelines so that the long single-ray tail of one batch's traversal launch overlaps the bulk of another's.
+struct Pipe {
+    hipStream_t st = nullptr, st2 = nullptr;
+    hipEvent_t ev_shade = nullptr, ev_any = nullptr, ev_done = nullptr;
+    DevBuf q[2][3], sq[3], hits, counters, overflow[2];
+};
+
 struct trhip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -38,6 +47,8 @@ struct trhip_ctx {
     bool count_visits = false;
     bool timing = true;
     uint64_t batch_paths = 0;  // 0 = as many whole sample passes as fit in free HBM (fewer launches, fewer traversal tails)
+    int pipelines = 4;    // concurrent wavefront batches (each on its own stream pair)
+    Pipe pipes[kMaxPipes];
     bool overlap = true;  // two-stream overlap of shadow rays (depth d) with closest-hit rays (depth d+1)
     int traversal = 2;  // 1 = literal accel/bvh.jl loop, 2 = children-in-parent nodes + per-lane ray replacement
     // workspace (grown on demand, reused across calls)
@@ -396,12 +407,12 @@ int ensure_overflow(trhip_ctx* ctx) {
 // One traversal launch over a queue (count in HBM at count_ptr, or n_max when count_ptr is null).
 // ctx->traversal == 1: the literal accel/bvh.jl loop (k_trace_closest / k_trace_any); 2: k_trace2 (same results).
 void launch_trace(trhip_ctx* ctx, hipStream_t st, const trhip_scene* sc, bool any, SegQueue q, const float4* ro, const float4* rd, const float* tmax, TraceOut out, uint32_t* work_cursors,
-                  Counters* ctr) {
+                  Counters* ctr, void* overflow_slab = nullptr) {
     const dim3 grid(trace_grid(ctx)), block(kBlock);
     const bool v2 = ctx->traversal == 2 && sc->wide_ok;
     const bool cnt = ctx->count_visits;
     if (v2) {
-        uint2* ov = (uint2*)ctx->overflow.p;
+        uint2* ov = (uint2*)(overflow_slab ? overflow_slab : ctx->overflow.p);
         if (any) {
             if (cnt)
                 hipLaunchKernelGGL((k_trace2<true, true>), grid, block, 0, st, sc->dev, sc->wide, q, ro, rd, tmax, out, work_cursors, ov, ctr);
@@ -633,16 +644,25 @@ int render_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sensor* se
     if (batch_paths == 0) {
         size_t free_b = 0, total_b = 0;
         HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
-        size_t held = ctx->Lbuf.bytes + ctx->pfilm.bytes + ctx->hits.bytes + ctx->overflow.bytes;  // reused below, so it counts as available
-        for (auto& a : ctx->q)
-            for (auto& b : a) held += b.bytes;
-        for (auto& b : ctx->sq) held += b.bytes;
-        const double avail = 0.85 * (double)(free_b + held) - (double)total_slots * (sizeof(float4) + sizeof(float2)) - 256e6;
+        size_t held = ctx->Lbuf.bytes + ctx->pfilm.bytes;  // reused below, so it counts as available
+        for (auto& pp : ctx->pipes) {
+            held += pp.hits.bytes;
+            for (auto& a : pp.q)
+                for (auto& b : a) held += b.bytes;
+            for (auto& b : pp.sq) held += b.bytes;
+        }
+        const double avail = 0.85 * (double)(free_b + held) - (double)total_slots * (sizeof(float4) + sizeof(float2)) - 2.5e9;
         batch_paths = avail > 0 ? (uint64_t)(avail / 164.0) : npix;
     }
     uint64_t spp_batch = std::max<uint64_t>(1, batch_paths / npix);
     spp_batch = std::min<uint64_t>(spp_batch, spp);
+    // Several batches run concurrently (one per pipeline): the memory budget is shared and the frame is cut into at
+    // least `pipelines` batches when it has that many sample passes.
+    const int want_pipes = std::max(1, std::min(ctx->pipelines, kMaxPipes));
+    spp_batch = std::max<uint64_t>(1, std::min<uint64_t>(spp_batch / want_pipes, (spp + want_pipes - 1) / want_pipes));
     while (npix * spp_batch >= (1ull << 31)) spp_batch = (spp_batch + 1) / 2;  // queue indices are 32-bit
+    const uint64_t n_batches_total = (spp + spp_batch - 1) / spp_batch;
+    const int NP = (int)std::min<uint64_t>(want_pipes, n_batches_total);
     const uint64_t P = npix * spp_batch;
     // physical queue layout: kSeg segments of `cap` entries (th_kernels.h "SegQueue"); a segment receives at most
     // P/kSeg + O(kSegGran) entries per bounce by construction
@@ -650,15 +670,28 @@ int render_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sensor* se
     const uint64_t Pphys = (uint64_t)cap * kSeg;
     if (int rc = upload(ctx, ctx->sensor, &ds, sizeof ds)) return rc;
     if (int rc = upload(ctx, ctx->table, sensor->filter_table, 256 * sizeof(float))) return rc;
-    for (int k = 0; k < 2; ++k)
+    const size_t slab_bytes = (size_t)trace_grid(ctx) * kBlock * (size_t)(kStack2Total - kStack2Lds) * sizeof(uint2);
+    for (int pi = 0; pi < NP; ++pi) {
+        Pipe& pp = ctx->pipes[pi];
+        if (!pp.st) {
+            HIP_TRY(ctx, hipStreamCreate(&pp.st));
+            HIP_TRY(ctx, hipStreamCreate(&pp.st2));
+            HIP_TRY(ctx, hipEventCreateWithFlags(&pp.ev_shade, hipEventDisableTiming));
+            HIP_TRY(ctx, hipEventCreateWithFlags(&pp.ev_any, hipEventDisableTiming));
+            HIP_TRY(ctx, hipEventCreateWithFlags(&pp.ev_done, hipEventDisableTiming));
+        }
+        for (int k = 0; k < 2; ++k)
+            for (int j = 0; j < 3; ++j)
+                if (int rc = ensure(ctx, pp.q[k][j], Pphys * sizeof(float4))) return rc;
         for (int j = 0; j < 3; ++j)
-            if (int rc = ensure(ctx, ctx->q[k][j], Pphys * sizeof(float4))) return rc;
-    for (int j = 0; j < 3; ++j)
-        if (int rc = ensure(ctx, ctx->sq[j], Pphys * sizeof(float4))) return rc;
-    if (int rc = ensure(ctx, ctx->hits, Pphys * sizeof(float4))) return rc;
+            if (int rc = ensure(ctx, pp.sq[j], Pphys * sizeof(float4))) return rc;
+        if (int rc = ensure(ctx, pp.hits, Pphys * sizeof(float4))) return rc;
+        if (int rc = ensure(ctx, pp.counters, sizeof(Counters))) return rc;
+        for (int k = 0; k < 2; ++k)
+            if (int rc = ensure(ctx, pp.overflow[k], slab_bytes)) return rc;
+    }
     if (int rc = ensure(ctx, ctx->Lbuf, total_slots * sizeof(float4))) return rc;
     if (int rc = ensure(ctx, ctx->pfilm, total_slots * sizeof(float2))) return rc;
-    if (int rc = ensure(ctx, ctx->counters, sizeof(Counters))) return rc;
     const size_t film_bytes = (size_t)ds.film_w * ds.film_h * sizeof(float4);
     void* d_film = out;
     if (!out_is_device) {
@@ -666,57 +699,63 @@ int render_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sensor* se
         d_film = ctx->film.p;
     }
     hipStream_t st = ctx->stream;
-    Counters* ctr = (Counters*)ctx->counters.p;
     const DeviceSensor* dsp = (const DeviceSensor*)ctx->sensor.p;
-    PathQueue pq[2];
-    for (int k = 0; k < 2; ++k) pq[k] = PathQueue{(float4*)ctx->q[k][0].p, (float4*)ctx->q[k][1].p, (float4*)ctx->q[k][2].p};
-    ShadowQueue sq{(float4*)ctx->sq[0].p, (float4*)ctx->sq[1].p, (float4*)ctx->sq[2].p};
     float4* L = (float4*)ctx->Lbuf.p;
-    float4* hits = (float4*)ctx->hits.p;
 
     Timer tm(ctx, ctx->timing && stats);
-    hipEvent_t e0, e1;
+    hipEvent_t e0, e1, ev_start;
     HIP_TRY(ctx, hipEventCreate(&e0));
     HIP_TRY(ctx, hipEventCreate(&e1));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&ev_start, hipEventDisableTiming));
     HIP_TRY(ctx, hipEventRecord(e0, st));
-    HIP_TRY(ctx, hipMemsetAsync(ctr, 0, sizeof(Counters), st));
     HIP_TRY(ctx, hipMemsetAsync(L, 0, total_slots * sizeof(float4), st));
-    if (int rc = ensure_overflow(ctx)) return rc;
+    HIP_TRY(ctx, hipEventRecord(ev_start, st));
     const int g_shade = ctx->num_cu * 8;
     uint32_t n_batches = 0;
-    // Shadow rays of depth d (k_trace any-hit + accumulate) and closest-hit rays of depth d+1 are independent: they run on two
-    // streams so that the long single-ray tail of one overlaps with the bulk of the other (DESIGN.md "tails").
-    hipStream_t st2 = ctx->overlap ? ctx->stream2 : st;
-    hipEvent_t ev_shade, ev_any;
-    HIP_TRY(ctx, hipEventCreateWithFlags(&ev_shade, hipEventDisableTiming));
-    HIP_TRY(ctx, hipEventCreateWithFlags(&ev_any, hipEventDisableTiming));
+    for (int pi = 0; pi < NP; ++pi) {
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->pipes[pi].st, ev_start, 0));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->pipes[pi].counters.p, 0, sizeof(Counters), ctx->pipes[pi].st));
+    }
     for (uint64_t s0 = 0; s0 < spp; s0 += spp_batch) {
-        const uint64_t nb = std::min<uint64_t>(spp_batch, spp - s0) * npix;
+        Pipe& pp = ctx->pipes[n_batches % NP];
         n_batches++;
-        HIP_TRY(ctx, hipMemsetAsync(ctr, 0, offsetof(Counters, closest_total), st));  // queue sizes + work cursors of this batch
-        tm.begin(0, st);
-        hipLaunchKernelGGL(k_raygen, dim3(grid_for(ctx, nb, 8)), dim3(kBlock), 0, st, dsp, (uint32_t)(s0 * npix), (uint32_t)nb, seed, sample_offset, pq[0], cap, ctr);
-        tm.end(0, st);
+        const uint64_t nb = std::min<uint64_t>(spp_batch, spp - s0) * npix;
+        // Within a batch, shadow rays of depth d (any-hit + accumulate) and closest-hit rays of depth d+1 are independent: two streams.
+        hipStream_t ps = pp.st, ps2 = ctx->overlap ? pp.st2 : pp.st;
+        Counters* ctr = (Counters*)pp.counters.p;
+        PathQueue pq[2];
+        for (int k = 0; k < 2; ++k) pq[k] = PathQueue{(float4*)pp.q[k][0].p, (float4*)pp.q[k][1].p, (float4*)pp.q[k][2].p};
+        ShadowQueue sq{(float4*)pp.sq[0].p, (float4*)pp.sq[1].p, (float4*)pp.sq[2].p};
+        float4* hits = (float4*)pp.hits.p;
+        HIP_TRY(ctx, hipMemsetAsync(ctr, 0, offsetof(Counters, closest_total), ps));  // queue sizes + work cursors of this batch
+        tm.begin(0, ps);
+        hipLaunchKernelGGL(k_raygen, dim3(grid_for(ctx, nb, 8)), dim3(kBlock), 0, ps, dsp, (uint32_t)(s0 * npix), (uint32_t)nb, seed, sample_offset, pq[0], cap, ctr);
+        tm.end(0, ps);
         int cur = 0;
         for (int depth = 1; depth <= max_depth; ++depth) {
-            tm.begin(1, st);
-            launch_trace(ctx, st, scene, false, SegQueue{ctr->n_queue[depth - 1], cap, 0u}, pq[cur].o, pq[cur].d, nullptr, TraceOut{hits, nullptr, nullptr, nullptr}, ctr->work_closest[depth - 1], ctr);
-            tm.end(1, st);
-            if (st2 != st && depth > 1) HIP_TRY(ctx, hipStreamWaitEvent(st, ev_any, 0));  // shade(d) reuses the shadow queue and touches L
-            tm.begin(2, st);
-            hipLaunchKernelGGL(k_shade_path, dim3(g_shade), dim3(kBlock), 0, st, scene->dev, dsp, pq[cur], pq[cur ^ 1], sq, cap, hits, L, ctr, depth, max_depth, seed, sample_offset);
-            tm.end(2, st);
-            if (st2 != st) {
-                HIP_TRY(ctx, hipEventRecord(ev_shade, st));
-                HIP_TRY(ctx, hipStreamWaitEvent(st2, ev_shade, 0));
+            tm.begin(1, ps);
+            launch_trace(ctx, ps, scene, false, SegQueue{ctr->n_queue[depth - 1], cap, 0u}, pq[cur].o, pq[cur].d, nullptr, TraceOut{hits, nullptr, nullptr, nullptr}, ctr->work_closest[depth - 1], ctr,
+                         pp.overflow[0].p);
+            tm.end(1, ps);
+            if (ps2 != ps && depth > 1) HIP_TRY(ctx, hipStreamWaitEvent(ps, pp.ev_any, 0));  // shade(d) reuses the shadow queue and touches L
+            tm.begin(2, ps);
+            hipLaunchKernelGGL(k_shade_path, dim3(g_shade), dim3(kBlock), 0, ps, scene->dev, dsp, pq[cur], pq[cur ^ 1], sq, cap, hits, L, ctr, depth, max_depth, seed, sample_offset);
+            tm.end(2, ps);
+            if (ps2 != ps) {
+                HIP_TRY(ctx, hipEventRecord(pp.ev_shade, ps));
+                HIP_TRY(ctx, hipStreamWaitEvent(ps2, pp.ev_shade, 0));
             }
-            tm.begin(3, st2);
-            launch_trace(ctx, st2, scene, true, SegQueue{ctr->n_shadow[depth - 1], cap, 0u}, sq.o, sq.d, nullptr, TraceOut{nullptr, L, sq.c, nullptr}, ctr->work_shadow[depth - 1], ctr);
-            tm.end(3, st2);
-            if (st2 != st) HIP_TRY(ctx, hipEventRecord(ev_any, st2));
+            tm.begin(3, ps2);
+            launch_trace(ctx, ps2, scene, true, SegQueue{ctr->n_shadow[depth - 1], cap, 0u}, sq.o, sq.d, nullptr, TraceOut{nullptr, L, sq.c, nullptr}, ctr->work_shadow[depth - 1], ctr, pp.overflow[1].p);
+            tm.end(3, ps2);
+            if (ps2 != ps) HIP_TRY(ctx, hipEventRecord(pp.ev_any, ps2));
             cur ^= 1;
         }
-        if (st2 != st) HIP_TRY(ctx, hipStreamWaitEvent(st, ev_any, 0));  // the next batch (or the film gather) needs every shadow ray resolved
+        if (ps2 != ps) HIP_TRY(ctx, hipStreamWaitEvent(ps, pp.ev_any, 0));  // the pipeline's next batch (or the film gather) needs every shadow ray resolved
+    }
+    for (int pi = 0; pi < NP; ++pi) {
+        HIP_TRY(ctx, hipEventRecord(ctx->pipes[pi].ev_done, ctx->pipes[pi].st));
+        HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->pipes[pi].ev_done, 0));
     }
     tm.begin(4, st);
     hipLaunchKernelGGL(k_film_positions, dim3(grid_for(ctx, total_slots, 8)), dim3(kBlock), 0, st, dsp, total_slots, seed, sample_offset, (float2*)ctx->pfilm.p);
@@ -730,15 +769,17 @@ int render_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sensor* se
     if (!out_is_device) HIP_TRY(ctx, hipMemcpy(out, d_film, film_bytes, hipMemcpyDeviceToHost));
     if (stats) {
         std::memset(stats, 0, sizeof *stats);
-        Counters h;
-        HIP_TRY(ctx, hipMemcpy(&h, ctr, sizeof h, hipMemcpyDeviceToHost));
         stats->camera_samples = total_slots;
-        stats->closest_rays = h.closest_total;
-        stats->shadow_rays = h.shadow_total;
-        stats->nodes_visited = h.nodes_closest;
-        stats->prims_tested = h.prims_closest;
-        stats->nodes_visited_shadow = h.nodes_shadow;
-        stats->prims_tested_shadow = h.prims_shadow;
+        for (int pi = 0; pi < NP; ++pi) {
+            Counters h;
+            HIP_TRY(ctx, hipMemcpy(&h, ctx->pipes[pi].counters.p, sizeof h, hipMemcpyDeviceToHost));
+            stats->closest_rays += h.closest_total;
+            stats->shadow_rays += h.shadow_total;
+            stats->nodes_visited += h.nodes_closest;
+            stats->prims_tested += h.prims_closest;
+            stats->nodes_visited_shadow += h.nodes_shadow;
+            stats->prims_tested_shadow += h.prims_shadow;
+        }
         float ms = 0;
         (void)hipEventElapsedTime(&ms, e0, e1);
         stats->ms_total = ms;
@@ -752,8 +793,7 @@ int render_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sensor* se
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
-    (void)hipEventDestroy(ev_shade);
-    (void)hipEventDestroy(ev_any);
+    (void)hipEventDestroy(ev_start);
     return 0;
 }
 
@@ -799,6 +839,20 @@ void trhip_shutdown(trhip_ctx* ctx) {
     release(ctx->film);
     release(ctx->overflow);
     release(ctx->pfilm);
+    for (auto& pp : ctx->pipes) {
+        for (auto& a : pp.q)
+            for (auto& b : a) release(b);
+        for (auto& b : pp.sq) release(b);
+        release(pp.hits);
+        release(pp.counters);
+        release(pp.overflow[0]);
+        release(pp.overflow[1]);
+        if (pp.ev_shade) (void)hipEventDestroy(pp.ev_shade);
+        if (pp.ev_any) (void)hipEventDestroy(pp.ev_any);
+        if (pp.ev_done) (void)hipEventDestroy(pp.ev_done);
+        if (pp.st) (void)hipStreamDestroy(pp.st);
+        if (pp.st2) (void)hipStreamDestroy(pp.st2);
+    }
     release(ctx->wh_L);
     release(ctx->wh_parent);
     release(ctx->wh_coef);
@@ -817,7 +871,10 @@ int trhip_set_option(trhip_ctx* ctx, const char* name, int64_t value) {
         ctx->count_visits = value != 0;
     else if (!std::strcmp(name, "timing"))
         ctx->timing = value != 0;
-    else if (!std::strcmp(name, "overlap"))
+    else if (!std::strcmp(name, "pipelines")) {
+        if (value < 1 || value > kMaxPipes) return fail(ctx, TRHIP_ERR_INVALID, "pipelines must be in 1..%d", kMaxPipes);
+        ctx->pipelines = (int)value;
+    } else if (!std::strcmp(name, "overlap"))
         ctx->overlap = value != 0;
     else if (!std::strcmp(name, "traversal")) {
         if (value != 1 && value != 2) return fail(ctx, TRHIP_ERR_INVALID, "traversal must be 1 or 2");
