@@ -208,14 +208,14 @@ def test_render_batches_and_sample_offset(T, ob, ctx, shadows):
     finally:
         ctx.set_option("overlap", 1)
     assert_bits_equal(a, c, "film without the two-stream overlap")
-    ctx.set_option("pipelines", 1)  # one batch at a time instead of concurrent pipelines
-    ctx.set_option("batch_paths", 2 * 34 * 34)
+    ctx.set_option("pipelines", 4)  # four batches in flight on separate stream pairs
+    ctx.set_option("batch_paths", 4 * 34 * 34)
     try:
         d = T.PathIntegrator(cam, T.SeededSampler(4, seed=9), 4).render(scene).copy()
     finally:
-        ctx.set_option("pipelines", 4)
+        ctx.set_option("pipelines", 1)
         ctx.set_option("batch_paths", 0)
-    assert_bits_equal(a, d, "film with a single pipeline")
+    assert_bits_equal(a, d, "film with concurrent pipelines")
     # two half renders with offsets sum (in fp32, tolerance) to the full one
     h0 = T.PathIntegrator(cam, T.SeededSampler(2, seed=9, sample_offset=0), 4).render(scene).copy()
     h1 = T.PathIntegrator(cam, T.SeededSampler(2, seed=9, sample_offset=2), 4).render(scene).copy()

@@ -568,6 +568,143 @@ __global__ __launch_bounds__(kBlock) void k_film_gather(const DeviceSensor* __re
     }
 }
 
+// FilmTile bounds of sample tile (ty, tx) (integrators/sampler.jl:29-31 + film.jl:120-125).
+TH_D void film_tile_bounds(const DeviceSensor& se, int ty, int tx, float rx, float ry, float& bx0, float& by0, float& bx1, float& by1) {
+    const float tbx0 = (float)se.sb_min[0] + (float)tx * 16.0f, tby0 = (float)se.sb_min[1] + (float)ty * 16.0f;
+    const float tbx1 = jmin(tbx0 + 15.0f, (float)se.sb_max[0]), tby1 = jmin(tby0 + 15.0f, (float)se.sb_max[1]);
+    bx0 = jmax(__builtin_ceilf(tbx0 - 0.5f - rx), se.crop_min[0]);
+    by0 = jmax(__builtin_ceilf(tby0 - 0.5f - ry), se.crop_min[1]);
+    bx1 = jmin(__builtin_floorf(tbx1 - 0.5f + rx) + 1.0f, se.crop_max[0]);
+    by1 = jmin(__builtin_floorf(tby1 - 0.5f + ry) + 1.0f, se.crop_max[1]);
+}
+
+// k_film_gather with the samples staged through LDS: one block = a 16x16 film tile; for every sample row (ascending) the
+// block stages `cols` sample columns x `ns` samples {p_film, L} once (instead of each of the ~16 film pixels a sample
+// reaches re-reading them from HBM/MALL), then the film pixels in reach accumulate from LDS.  The summation order per film
+// pixel is unchanged: one accumulator per sample tile (at most 2x2 reach a pixel), inside a tile rows ascending, columns
+// ascending, samples ascending; tiles merged in k order (film.jl:182-193).  LDS layout: five planes [s][col], so the lanes
+// of a wave (different columns, same s) read consecutive banks and equal columns broadcast.
+__global__ __launch_bounds__(kBlock) void k_film_gather_tiled(const DeviceSensor* __restrict__ sep, const float* __restrict__ table, const float4* __restrict__ L,
+                                                              const float2* __restrict__ pfilm, uint32_t spp, uint32_t cols, uint32_t ns_stage, float4* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float s_planes[];
+    const DeviceSensor& se = *sep;
+    const uint32_t npix = (uint32_t)(se.sb_w * se.sb_h);
+    const float rx = se.filter_radius[0], ry = se.filter_radius[1];
+    const float inv_rx = 1.0f / rx, inv_ry = 1.0f / ry;
+    const int tid = (int)threadIdx.x, ltx = tid & 15, lty = tid >> 4;
+    const int fx = (int)blockIdx.x * 16 + ltx, fy = (int)blockIdx.y * 16 + lty;
+    const bool in_film = fx < se.film_w && fy < se.film_h;
+    const float X = se.crop_min[0] + (float)fx, Y = se.crop_min[1] + (float)fy;
+    // this pixel's reach (same arithmetic as k_film_gather)
+    int sx_lo = max((int)__builtin_floorf(X - 1.5f - rx), se.sb_min[0]), sx_hi = min((int)__builtin_ceilf(X + rx + 0.5f), se.sb_max[0]);
+    int sy_lo = max((int)__builtin_floorf(Y - 1.5f - ry), se.sb_min[1]), sy_hi = min((int)__builtin_ceilf(Y + ry + 0.5f), se.sb_max[1]);
+    const int ty_lo = (sy_lo - se.sb_min[1]) >> 4, tx_lo = (sx_lo - se.sb_min[0]) >> 4;
+    // block-wide reach
+    const float Xb0 = se.crop_min[0] + (float)(blockIdx.x * 16), Yb0 = se.crop_min[1] + (float)(blockIdx.y * 16);
+    const float Xb1 = jmin(Xb0 + 15.0f, se.crop_max[0]), Yb1 = jmin(Yb0 + 15.0f, se.crop_max[1]);
+    const int SX0 = max((int)__builtin_floorf(Xb0 - 1.5f - rx), se.sb_min[0]), SX1 = min((int)__builtin_ceilf(Xb1 + rx + 0.5f), se.sb_max[0]);
+    const int SY0 = max((int)__builtin_floorf(Yb0 - 1.5f - ry), se.sb_min[1]), SY1 = min((int)__builtin_ceilf(Yb1 + ry + 0.5f), se.sb_max[1]);
+    const int NC = SX1 - SX0 + 1;
+    float* p_fx = s_planes;
+    float* p_fy = p_fx + (size_t)cols * ns_stage;
+    float* p_r = p_fy + (size_t)cols * ns_stage;
+    float* p_g = p_r + (size_t)cols * ns_stage;
+    float* p_b = p_g + (size_t)cols * ns_stage;
+    // accumulators of the (up to) 2 x 2 sample tiles that reach this pixel: [tile row][tile column]
+    f3 c00 = splat3(0.0f), c01 = c00, c10 = c00, c11 = c00;
+    float w00 = 0.0f, w01 = 0.0f, w10 = 0.0f, w11 = 0.0f;
+    for (int sy = SY0; sy <= SY1; ++sy) {
+        for (int c0 = 0; c0 < NC; c0 += (int)cols) {
+            const int ncol = min((int)cols, NC - c0);
+            for (uint32_t s0 = 0; s0 < spp; s0 += ns_stage) {
+                const uint32_t nsn = min(ns_stage, spp - s0);
+                // ---- stage ----
+                for (uint32_t e = (uint32_t)tid; e < (uint32_t)ncol * nsn; e += kBlock) {
+                    const uint32_t c = e % (uint32_t)ncol, sl = e / (uint32_t)ncol;
+                    const uint32_t pix = (uint32_t)(sy - se.sb_min[1]) * (uint32_t)se.sb_w + (uint32_t)(SX0 + c0 + (int)c - se.sb_min[0]);
+                    const size_t idx = (size_t)(s0 + sl) * npix + pix;
+                    const float2 pf = pfilm[idx];
+                    const float4 l4 = L[idx];
+                    f3 l = mk3(l4.x, l4.y, l4.z);
+                    if (has_nan(l)) l = splat3(0.0f);  // integrators/sampler.jl:46
+                    const uint32_t a = sl * cols + c;
+                    p_fx[a] = pf.x;
+                    p_fy[a] = pf.y;
+                    p_r[a] = l.x;
+                    p_g[a] = l.y;
+                    p_b[a] = l.z;
+                }
+                __syncthreads();
+                // ---- accumulate ----
+                if (in_film && sy >= sy_lo && sy <= sy_hi) {
+                    const int xa = max(sx_lo, SX0 + c0), xb = min(sx_hi, SX0 + c0 + ncol - 1);
+                    const int tyi = ((sy - se.sb_min[1]) >> 4) - ty_lo;
+                    for (int sx = xa; sx <= xb; ++sx) {
+                        const int txi = ((sx - se.sb_min[0]) >> 4) - tx_lo;
+                        float bx0, by0, bx1, by1;
+                        film_tile_bounds(se, tyi + ty_lo, txi + tx_lo, rx, ry, bx0, by0, bx1, by1);
+                        if (X < bx0 || X > bx1 || Y < by0 || Y > by1) continue;  // pixel not in this FilmTile
+                        const bool r1 = tyi != 0, q1 = txi != 0;
+                        f3 csum = r1 ? (q1 ? c11 : c10) : (q1 ? c01 : c00);
+                        float fws = r1 ? (q1 ? w11 : w10) : (q1 ? w01 : w00);
+                        const uint32_t c = (uint32_t)(sx - SX0 - c0);
+                        const float lim_x0 = jmax(bx0, 1.0f), lim_y0 = jmax(by0, 1.0f);
+                        for (uint32_t sl = 0; sl < nsn; ++sl) {
+                            const uint32_t a = sl * cols + c;
+                            const float dpx = p_fx[a] - 0.5f, dpy = p_fy[a] - 0.5f;
+                            const float p0x = jmax(__builtin_ceilf(dpx - rx), lim_x0), p0y = jmax(__builtin_ceilf(dpy - ry), lim_y0);
+                            const float p1x = jmin(__builtin_floorf(dpx + rx) + 1.0f, bx1), p1y = jmin(__builtin_floorf(dpy + ry) + 1.0f, by1);
+                            if (X < p0x || X > p1x || Y < p0y || Y > p1y) continue;
+                            const float ffx = fabs_((X - dpx) * inv_rx * 16.0f), ffy = fabs_((Y - dpy) * inv_ry * 16.0f);
+                            const int ox = (int)jclamp(__builtin_ceilf(ffx), 1.0f, 16.0f);
+                            const int oy = (int)jclamp(__builtin_floorf(ffy), 1.0f, 16.0f);
+                            const float w = table[(oy - 1) * 16 + (ox - 1)];
+                            csum = csum + mk3(p_r[a], p_g[a], p_b[a]) * 1.0f * w;
+                            fws += w;
+                        }
+                        if (r1) {
+                            if (q1) {
+                                c11 = csum;
+                                w11 = fws;
+                            } else {
+                                c10 = csum;
+                                w10 = fws;
+                            }
+                        } else {
+                            if (q1) {
+                                c01 = csum;
+                                w01 = fws;
+                            } else {
+                                c00 = csum;
+                                w00 = fws;
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+    if (in_film) {
+        // merge_film_tile! in k order: tile rows ascending, tile columns ascending; a tile whose FilmTile does not contain the
+        // pixel never touched it (its accumulator is still zero and is skipped, as the reference's merge loop skips the pixel)
+        f3 xyz = splat3(0.0f);
+        float wsum = 0.0f;
+        const int ty_hi = (sy_hi - se.sb_min[1]) >> 4, tx_hi = (sx_hi - se.sb_min[0]) >> 4;
+        if (sx_lo <= sx_hi && sy_lo <= sy_hi)
+            for (int ty = ty_lo; ty <= ty_hi; ++ty)
+                for (int tx = tx_lo; tx <= tx_hi; ++tx) {
+                    float bx0, by0, bx1, by1;
+                    film_tile_bounds(se, ty, tx, rx, ry, bx0, by0, bx1, by1);
+                    if (X < bx0 || X > bx1 || Y < by0 || Y > by1) continue;
+                    const bool r1 = ty != ty_lo, q1 = tx != tx_lo;
+                    xyz = xyz + rgb_to_xyz(r1 ? (q1 ? c11 : c10) : (q1 ? c01 : c00));
+                    wsum += r1 ? (q1 ? w11 : w10) : (q1 ? w01 : w00);
+                }
+        out[(size_t)fy * se.film_w + fx] = make_float4(xyz.x, xyz.y, xyz.z, wsum);
+    }
+}
+
 // save(film) up to the encoder (film.jl:204-222)
 __global__ void k_film_to_rgb(const float4* __restrict__ xyzw, uint32_t n, float scale, float* __restrict__ rgb) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -47,8 +47,9 @@ struct trhip_ctx {
     bool count_visits = false;
     bool timing = true;
     uint64_t batch_paths = 0;  // 0 = as many whole sample passes as fit in free HBM (fewer launches, fewer traversal tails)
-    int pipelines = 4;    // concurrent wavefront batches (each on its own stream pair)
+    int pipelines = 1;    // concurrent wavefront batches (each on its own stream pair); measured: no gain, every batch pays every tail
     Pipe pipes[kMaxPipes];
+    bool film_tiled = true;  // LDS-staged film gather (k_film_gather_tiled)
     bool overlap = true;  // two-stream overlap of shadow rays (depth d) with closest-hit rays (depth d+1)
     int traversal = 2;  // 1 = literal accel/bvh.jl loop, 2 = children-in-parent nodes + per-lane ray replacement
     // workspace (grown on demand, reused across calls)
@@ -396,6 +397,30 @@ void derive_sensor(const trhip_sensor* sn, DeviceSensor& d) {
     d.tiles_y = (int)std::floor(((float)(d.sb_max[1] - d.sb_min[1]) + 16.0f) / 16.0f);
 }
 
+// Film accumulation: positions, then the LDS-tiled gather (falls back to the per-pixel gather when a 16x16 film tile is reached
+// by more than two sample tiles per axis, i.e. very wide filters).
+void launch_film(trhip_ctx* ctx, hipStream_t st, const DeviceSensor& ds, const DeviceSensor* dsp, const float4* L, uint64_t total_slots, uint32_t spp, uint64_t seed, uint32_t sample_offset,
+                 float4* d_film) {
+    hipLaunchKernelGGL(k_film_positions, dim3(grid_for(ctx, total_slots, 8)), dim3(kBlock), 0, st, dsp, total_slots, seed, sample_offset, (float2*)ctx->pfilm.p);
+    const float rmax = std::fmax(ds.filter_radius[0], ds.filter_radius[1]);
+    if (ctx->film_tiled && rmax <= 6.0f) {  // reach of a pixel = 2r + 3 sample pixels <= 16: at most 2 x 2 sample tiles
+        const uint32_t budget = 64 * 1024 / 20;  // staged {p_film, L} elements in 64 KiB of LDS
+        const uint32_t nc_max = 16 + 2 * (uint32_t)std::ceil(rmax) + 4;
+        uint32_t cols, ns;
+        if (spp <= budget) {
+            ns = spp;
+            cols = std::max(1u, std::min(nc_max, budget / spp));
+        } else {
+            cols = 1;
+            ns = budget;
+        }
+        const dim3 grid((ds.film_w + 15) / 16, (ds.film_h + 15) / 16);
+        hipLaunchKernelGGL(k_film_gather_tiled, grid, dim3(kBlock), (size_t)cols * ns * 20, st, dsp, (const float*)ctx->table.p, L, (const float2*)ctx->pfilm.p, spp, cols, ns, d_film);
+    } else {
+        hipLaunchKernelGGL(k_film_gather, dim3(grid_for(ctx, (uint64_t)ds.film_w * ds.film_h, 8)), dim3(kBlock), 0, st, dsp, (const float*)ctx->table.p, L, (const float2*)ctx->pfilm.p, spp, d_film);
+    }
+}
+
 int trace_grid(const trhip_ctx* ctx) { return ctx->num_cu * 5; }  // 5 x 256 threads x 32 KiB of LDS stack per CU
 
 // k_trace2 keeps stack levels 16..63 of every resident thread in a global slab laid out [level][thread].
@@ -569,8 +594,7 @@ int render_whitted_impl(trhip_ctx* ctx, const trhip_scene* scene, const DeviceSe
         tm.end(2, st);
     }
     tm.begin(4, st);
-    hipLaunchKernelGGL(k_film_positions, dim3(grid_for(ctx, total_slots, 8)), blk, 0, st, dsp, total_slots, seed, sample_offset, (float2*)ctx->pfilm.p);
-    hipLaunchKernelGGL(k_film_gather, dim3(grid_for(ctx, (uint64_t)ds.film_w * ds.film_h, 8)), blk, 0, st, dsp, (const float*)ctx->table.p, L, (const float2*)ctx->pfilm.p, spp, (float4*)d_film);
+    launch_film(ctx, st, ds, dsp, L, total_slots, spp, seed, sample_offset, (float4*)d_film);
     tm.end(4, st);
     HIP_TRY(ctx, hipEventRecord(e1, st));
     HIP_TRY(ctx, hipGetLastError());
@@ -758,9 +782,7 @@ int render_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sensor* se
         HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->pipes[pi].ev_done, 0));
     }
     tm.begin(4, st);
-    hipLaunchKernelGGL(k_film_positions, dim3(grid_for(ctx, total_slots, 8)), dim3(kBlock), 0, st, dsp, total_slots, seed, sample_offset, (float2*)ctx->pfilm.p);
-    hipLaunchKernelGGL(k_film_gather, dim3(grid_for(ctx, (uint64_t)ds.film_w * ds.film_h, 8)), dim3(kBlock), 0, st, dsp, (const float*)ctx->table.p, L, (const float2*)ctx->pfilm.p, spp,
-                       (float4*)d_film);
+    launch_film(ctx, st, ds, dsp, L, total_slots, spp, seed, sample_offset, (float4*)d_film);
     tm.end(4, st);
     HIP_TRY(ctx, hipEventRecord(e1, st));
     HIP_TRY(ctx, hipGetLastError());
@@ -871,6 +893,8 @@ int trhip_set_option(trhip_ctx* ctx, const char* name, int64_t value) {
         ctx->count_visits = value != 0;
     else if (!std::strcmp(name, "timing"))
         ctx->timing = value != 0;
+    else if (!std::strcmp(name, "film_tiled"))
+        ctx->film_tiled = value != 0;
     else if (!std::strcmp(name, "pipelines")) {
         if (value < 1 || value > kMaxPipes) return fail(ctx, TRHIP_ERR_INVALID, "pipelines must be in 1..%d", kMaxPipes);
         ctx->pipelines = (int)value;
@@ -1233,9 +1257,7 @@ int trhip_film_accumulate(trhip_ctx* ctx, const trhip_sensor* sn, uint32_t spp, 
     if (int rc = ensure(ctx, ctx->film, film_bytes)) return rc;
     if (int rc = ensure(ctx, ctx->pfilm, n * sizeof(float2))) return rc;
     if (n) hipLaunchKernelGGL(k_import_L, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const float*)ctx->scratch[0].p, n, (float4*)ctx->Lbuf.p);
-    hipLaunchKernelGGL(k_film_positions, dim3(grid_for(ctx, n, 8)), dim3(kBlock), 0, ctx->stream, (const DeviceSensor*)ctx->sensor.p, n, seed, sample_offset, (float2*)ctx->pfilm.p);
-    hipLaunchKernelGGL(k_film_gather, dim3(grid_for(ctx, (uint64_t)ds.film_w * ds.film_h, 8)), dim3(kBlock), 0, ctx->stream, (const DeviceSensor*)ctx->sensor.p, (const float*)ctx->table.p,
-                       (const float4*)ctx->Lbuf.p, (const float2*)ctx->pfilm.p, spp, (float4*)ctx->film.p);
+    launch_film(ctx, ctx->stream, ds, (const DeviceSensor*)ctx->sensor.p, (const float4*)ctx->Lbuf.p, n, spp, seed, sample_offset, (float4*)ctx->film.p);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->last_L_count = n;
