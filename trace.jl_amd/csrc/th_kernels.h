@@ -587,11 +587,13 @@ TH_D void film_tile_bounds(const DeviceSensor& se, int ty, int tx, float rx, flo
 __global__ __launch_bounds__(kBlock) void k_film_gather_tiled(const DeviceSensor* __restrict__ sep, const float* __restrict__ table, const float4* __restrict__ L,
                                                               const float2* __restrict__ pfilm, uint32_t spp, uint32_t cols, uint32_t ns_stage, float4* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float s_planes[];
+    __shared__ float s_table[256];
     const DeviceSensor& se = *sep;
     const uint32_t npix = (uint32_t)(se.sb_w * se.sb_h);
     const float rx = se.filter_radius[0], ry = se.filter_radius[1];
     const float inv_rx = 1.0f / rx, inv_ry = 1.0f / ry;
     const int tid = (int)threadIdx.x, ltx = tid & 15, lty = tid >> 4;
+    s_table[tid] = table[tid];  // Film.filter_table (16 x 16), kBlock == 256
     const int fx = (int)blockIdx.x * 16 + ltx, fy = (int)blockIdx.y * 16 + lty;
     const bool in_film = fx < se.film_w && fy < se.film_h;
     const float X = se.crop_min[0] + (float)fx, Y = se.crop_min[1] + (float)fy;
@@ -649,18 +651,22 @@ __global__ __launch_bounds__(kBlock) void k_film_gather_tiled(const DeviceSensor
                         float fws = r1 ? (q1 ? w11 : w10) : (q1 ? w01 : w00);
                         const uint32_t c = (uint32_t)(sx - SX0 - c0);
                         const float lim_x0 = jmax(bx0, 1.0f), lim_y0 = jmax(by0, 1.0f);
-                        for (uint32_t sl = 0; sl < nsn; ++sl) {
+#pragma unroll 4
+                        for (uint32_t sl = 0; sl < nsn; ++sl) {  // branch-free body: the four unrolled iterations' LDS reads overlap
                             const uint32_t a = sl * cols + c;
                             const float dpx = p_fx[a] - 0.5f, dpy = p_fy[a] - 0.5f;
+                            const f3 lrgb = mk3(p_r[a], p_g[a], p_b[a]);
                             const float p0x = jmax(__builtin_ceilf(dpx - rx), lim_x0), p0y = jmax(__builtin_ceilf(dpy - ry), lim_y0);
                             const float p1x = jmin(__builtin_floorf(dpx + rx) + 1.0f, bx1), p1y = jmin(__builtin_floorf(dpy + ry) + 1.0f, by1);
-                            if (X < p0x || X > p1x || Y < p0y || Y > p1y) continue;
+                            const bool reach = !(X < p0x || X > p1x || Y < p0y || Y > p1y);
                             const float ffx = fabs_((X - dpx) * inv_rx * 16.0f), ffy = fabs_((Y - dpy) * inv_ry * 16.0f);
                             const int ox = (int)jclamp(__builtin_ceilf(ffx), 1.0f, 16.0f);
                             const int oy = (int)jclamp(__builtin_floorf(ffy), 1.0f, 16.0f);
-                            const float w = table[(oy - 1) * 16 + (ox - 1)];
-                            csum = csum + mk3(p_r[a], p_g[a], p_b[a]) * 1.0f * w;
-                            fws += w;
+                            const float w = s_table[(oy - 1) * 16 + (ox - 1)];
+                            const f3 cnew = csum + lrgb * 1.0f * w;
+                            const float wnew = fws + w;
+                            csum = reach ? cnew : csum;
+                            fws = reach ? wnew : fws;
                         }
                         if (r1) {
                             if (q1) {

@@ -404,7 +404,7 @@ void launch_film(trhip_ctx* ctx, hipStream_t st, const DeviceSensor& ds, const D
     hipLaunchKernelGGL(k_film_positions, dim3(grid_for(ctx, total_slots, 8)), dim3(kBlock), 0, st, dsp, total_slots, seed, sample_offset, (float2*)ctx->pfilm.p);
     const float rmax = std::fmax(ds.filter_radius[0], ds.filter_radius[1]);
     if (ctx->film_tiled && rmax <= 6.0f) {  // reach of a pixel = 2r + 3 sample pixels <= 16: at most 2 x 2 sample tiles
-        const uint32_t budget = 64 * 1024 / 20;  // staged {p_film, L} elements in 64 KiB of LDS
+        const uint32_t budget = 24 * 1024 / 20;  // staged {p_film, L} elements in 24 KiB of LDS: ~6 blocks per CU
         const uint32_t nc_max = 16 + 2 * (uint32_t)std::ceil(rmax) + 4;
         uint32_t cols, ns;
         if (spp <= budget) {
@@ -415,7 +415,7 @@ void launch_film(trhip_ctx* ctx, hipStream_t st, const DeviceSensor& ds, const D
             ns = budget;
         }
         const dim3 grid((ds.film_w + 15) / 16, (ds.film_h + 15) / 16);
-        hipLaunchKernelGGL(k_film_gather_tiled, grid, dim3(kBlock), (size_t)cols * ns * 20, st, dsp, (const float*)ctx->table.p, L, (const float2*)ctx->pfilm.p, spp, cols, ns, d_film);
+        hipLaunchKernelGGL(k_film_gather_tiled, grid, dim3(kBlock), (size_t)cols * ns * 20 + 16, st, dsp, (const float*)ctx->table.p, L, (const float2*)ctx->pfilm.p, spp, cols, ns, d_film);
     } else {
         hipLaunchKernelGGL(k_film_gather, dim3(grid_for(ctx, (uint64_t)ds.film_w * ds.film_h, 8)), dim3(kBlock), 0, st, dsp, (const float*)ctx->table.p, L, (const float2*)ctx->pfilm.p, spp, d_film);
     }
