@@ -189,8 +189,15 @@ int trhip_film_accumulate(trhip_ctx* ctx, const trhip_sensor* sensor, uint32_t s
 
 /* ---- options ------------------------------------------------------------------------------------------------------- */
 /* "count_visits" (0/1): instrumented traversal kernels fill nodes_visited / prims_tested.
- * "batch_paths": paths in flight per wavefront batch (default 16 Mi).
- * "timing" (0/1): per-kernel HIP-event timing in trhip_stats (default 1). */
+ * "batch_paths": paths in flight per wavefront batch (0 = size from free HBM, the default).
+ * "timing" (0/1): per-kernel HIP-event timing in trhip_stats (default 1).
+ * "traversal" (1/2): 1 = literal accel/bvh.jl loop, 2 = children-in-parent nodes with per-lane ray replacement (default).
+ * "overlap" (0/1): shadow rays of depth d on a second stream beside the closest-hit pass of depth d+1 (default 1).
+ * "pipelines" (1..8): wavefront batches in flight at once (default 1).
+ * "tiny_scene_prims" (0..255): scenes of at most this many primitives are committed as ONE leaf (default 16; 0 = never).
+ *     Read by trhip_scene_commit; results do not depend on it except through the order coincident hits are visited in.
+ * "film_tiled" (0/1): LDS-staged film gather (default 0: measured slower).
+ * "debug_trace_budget": DIAGNOSTIC ONLY, traversal abandons rays after this many node fetches (results wrong). */
 int trhip_set_option(trhip_ctx* ctx, const char* name, int64_t value);
 
 /* The deterministic elementary functions of trace_detmath.h for hosts that cannot include a C header

@@ -45,7 +45,12 @@ def camera_rays(T, ob, cam, spp=1, seed=3):
 @pytest.fixture(scope="module")
 def shadows(T, ob, ctx):
     scene = T.scenes.shadows_scene()
-    flat, osc = scene_pair(T, ob, scene)
+    ctx.set_option("tiny_scene_prims", 0)  # keep the hierarchy: the single-leaf form has its own test below
+    try:
+        flat, osc = scene_pair(T, ob, scene)
+    finally:
+        ctx.set_option("tiny_scene_prims", 16)
+    assert flat.bvh()[1].size > 1
     return scene, flat, osc
 
 
@@ -69,6 +74,23 @@ def test_generate_rays_matches_oracle(T, ob, ctx):
         sn = cam.sensor()
         ctx.check(T.lib().trhip_generate_rays(ctx._h, C.byref(sn), T._ffi.fptr(samples), samples.shape[0], T._ffi.fptr(out)))
         assert_bits_equal(out, ref, f"generate_ray lens_radius={lens_radius}")
+
+
+def test_tiny_scene_is_one_leaf(T, ob, ctx):
+    """Scenes of <= 16 primitives are committed as a single leaf (th_bvh.h): same hits as the oracle walking that leaf,
+    closest and any-hit, camera and incoherent rays."""
+    scene = T.scenes.shadows_scene()
+    flat, osc = scene_pair(T, ob, scene)
+    bounds, a, flags, order = flat.bvh()
+    assert a.size == 1 and (flags[0] & 3) == 3 and (flags[0] >> 2) == order.size == flat.n_prims
+    wb = osc.world_bound()
+    rays = np.concatenate([camera_rays(T, ob, T.scenes.shadows_camera(64)), T.scenes.incoherent_rays(30000, wb[:3] - 0.2, wb[3:] + 0.2)])
+    got = flat.trace_closest(rays)
+    t_ref, prim_ref, _, _ = osc.trace_closest(rays)
+    assert (prim_ref >= 0).sum() > 1000
+    assert np.array_equal(got["prim"], prim_ref)
+    assert_bits_equal(got["t"], t_ref, "t (single leaf)")
+    assert np.array_equal(flat.trace_any(rays), osc.trace_any(rays)[0])
 
 
 @pytest.mark.parametrize("which", ["shadows", "mesh"])
@@ -240,6 +262,13 @@ def test_film_accumulate_matches_oracle_tile_order(T, ob, ctx):
     out = np.empty_like(ref_xyzw)
     ctx.check(T.lib().trhip_film_accumulate(ctx._h, C.byref(sn), spp, 5, 0, T._ffi.fptr(ref_L), T._ffi.fptr(out)))
     assert_bits_equal(out, ref_xyzw, "film accumulate (wide anisotropic filter)")
+    ctx.set_option("film_tiled", 1)  # the LDS-staged variant of the gather
+    try:
+        out2 = np.empty_like(ref_xyzw)
+        ctx.check(T.lib().trhip_film_accumulate(ctx._h, C.byref(sn), spp, 5, 0, T._ffi.fptr(ref_L), T._ffi.fptr(out2)))
+    finally:
+        ctx.set_option("film_tiled", 0)
+    assert_bits_equal(out2, ref_xyzw, "film accumulate, LDS-tiled gather")
 
 
 def test_film_to_rgb(T, ob, ctx, shadows):

@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtracehip.so")
+LIB_PATH = os.environ.get("TRHIP_LIB", os.path.join(_HERE, "libtracehip.so"))  # TRHIP_LIB: A/B builds for tuning (tools/)
 
 
 class TraceHipError(RuntimeError):

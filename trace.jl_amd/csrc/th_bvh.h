@@ -46,7 +46,8 @@ struct FlatBVH {
 
 class BVHBuilder {
    public:
-    BVHBuilder(const std::vector<HostAABB>& prim_bounds, int max_node_prims) : pb_(prim_bounds), max_leaf_(std::max(1, std::min(255, max_node_prims))) {}
+    BVHBuilder(const std::vector<HostAABB>& prim_bounds, int max_node_prims, uint32_t tiny_scene = 16)
+        : pb_(prim_bounds), max_leaf_(std::max(1, std::min(255, max_node_prims))), tiny_(std::min(255u, tiny_scene)) {}
 
     FlatBVH build() {
         const uint32_t n = (uint32_t)pb_.size();
@@ -68,6 +69,7 @@ class BVHBuilder {
     static constexpr int kBins = 16;
     const std::vector<HostAABB>& pb_;
     int max_leaf_;
+    uint32_t tiny_;
     std::vector<uint32_t> idx_;
     std::vector<float> cen_;
     FlatBVH out_;
@@ -95,7 +97,9 @@ class BVHBuilder {
         }
         const uint32_t node = emit_node(b);
         const uint32_t n = hi - lo;
-        if (n == 1) {
+        // A hierarchy over a handful of primitives only adds divergence: a wavefront that walks one leaf tests the same
+        // primitive in every lane.  Scenes of ≤ tiny_ primitives (option tiny_scene_prims, default 16) become a single leaf (the leaf-size hint is a hint).
+        if (n == 1 || (depth == 1 && n <= tiny_)) {
             make_leaf(node, lo, hi);
             return;
         }

@@ -19,7 +19,13 @@
 
 namespace th {
 
-constexpr int kStack2Lds = 16;
+#ifndef TH_STACK2_LDS
+#define TH_STACK2_LDS 16
+#endif
+#ifndef TH_TRACE2_MIN_WAVES
+#define TH_TRACE2_MIN_WAVES 1
+#endif
+constexpr int kStack2Lds = TH_STACK2_LDS;  // stack levels per lane kept in LDS
 constexpr int kStack2Total = 64;
 constexpr uint32_t kRefNone = 0xffffffffu;
 constexpr int kChunk = 256;  // ray indices a wave takes from a segment cursor per atomic (== kSegGran)
@@ -58,8 +64,8 @@ struct TraceOut {
 };
 
 template <bool ANY, bool COUNT>
-__global__ __launch_bounds__(kBlock) void k_trace2(DeviceScene sc, WideScene ws, SegQueue q, const float4* __restrict__ ro, const float4* __restrict__ rd, const float* __restrict__ tmax_or_null,
-                                                   TraceOut out, uint32_t* __restrict__ work /* kSeg cursors, zeroed */, uint2* __restrict__ overflow, Counters* ctr) {
+__global__ __launch_bounds__(kBlock, TH_TRACE2_MIN_WAVES) void k_trace2(DeviceScene sc, WideScene ws, SegQueue q, const float4* __restrict__ ro, const float4* __restrict__ rd, const float* __restrict__ tmax_or_null,
+                                                   TraceOut out, uint32_t* __restrict__ work /* kSeg cursors, zeroed */, uint2* __restrict__ overflow, Counters* ctr, uint32_t debug_budget) {
     __shared__ uint32_t s_ref[kStack2Lds][kBlock];
     __shared__ float s_tmin[kStack2Lds][kBlock];
     __shared__ SegView sv;
@@ -75,6 +81,7 @@ __global__ __launch_bounds__(kBlock) void k_trace2(DeviceScene sc, WideScene ws,
     uint32_t wseg = (gtid >> 6) % kSeg, dry = 0, pool_next = 0, pool_end = 0;
     uint32_t idx = 0, cur = kRefNone, cur_cnt = 0;
     int sp = 0;
+    uint32_t steps = 0;  // interior fetches of the current ray (diagnostic budget)
     f3 o = splat3(0.0f), d = splat3(0.0f), inv_d = splat3(0.0f);
     bool negx = false, negy = false, negz = false;
     float t_max = 0.0f, b1 = 0.0f, b2 = 0.0f, slot_w = 0.0f, flag_w = 0.0f;
@@ -119,6 +126,7 @@ __global__ __launch_bounds__(kBlock) void k_trace2(DeviceScene sc, WideScene ws,
                         negz = d.z < 0.0f;
                         t_max = tmax_or_null ? tmax_or_null[idx] : kInf;
                         sp = 0;
+                        steps = 0;
                         found = false;
                         hit_prim = -1;
                         b1 = b2 = 0.0f;
@@ -190,6 +198,11 @@ __global__ __launch_bounds__(kBlock) void k_trace2(DeviceScene sc, WideScene ws,
                 // interior: one 64-byte burst, both child boxes
                 const float4 a0 = ws.wnodes[4 * (size_t)cur], a1 = ws.wnodes[4 * (size_t)cur + 1], a2 = ws.wnodes[4 * (size_t)cur + 2], a3 = ws.wnodes[4 * (size_t)cur + 3];
                 if (COUNT) nn += 2;  // two node boxes tested (the reference would visit these two nodes)
+                if (debug_budget && ++steps > debug_budget) {  // DIAGNOSTIC ONLY (option "debug_trace_budget"): abandon the ray -> wrong result
+                    sp = 0;
+                    cur = kRefNone;
+                    continue;
+                }
                 float tl, tr;
                 const bool hl = slab_test2(a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, o, inv_d, negx, negy, negz, tl);
                 const bool hr = slab_test2(a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, o, inv_d, negx, negy, negz, tr);

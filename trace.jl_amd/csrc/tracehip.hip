@@ -49,7 +49,9 @@ struct trhip_ctx {
     uint64_t batch_paths = 0;  // 0 = as many whole sample passes as fit in free HBM (fewer launches, fewer traversal tails)
     int pipelines = 1;    // concurrent wavefront batches (each on its own stream pair); measured: no gain, every batch pays every tail
     Pipe pipes[kMaxPipes];
-    bool film_tiled = true;  // LDS-staged film gather (k_film_gather_tiled)
+    uint32_t debug_trace_budget = 0;  // DIAGNOSTIC: k_trace2 abandons rays after this many node fetches (results wrong; measures bulk vs tail)
+    uint32_t tiny_scene_prims = 16;  // scenes of at most this many primitives get a single-leaf BVH (th_bvh.h); 0 = always build the hierarchy
+    bool film_tiled = false;  // LDS-staged film gather (k_film_gather_tiled): bit-identical, measured 2.7x SLOWER than k_film_gather (11 % lane use), kept as an option
     bool overlap = true;  // two-stream overlap of shadow rays (depth d) with closest-hit rays (depth d+1)
     int traversal = 2;  // 1 = literal accel/bvh.jl loop, 2 = children-in-parent nodes + per-lane ray replacement
     // workspace (grown on demand, reused across calls)
@@ -421,7 +423,10 @@ void launch_film(trhip_ctx* ctx, hipStream_t st, const DeviceSensor& ds, const D
     }
 }
 
-int trace_grid(const trhip_ctx* ctx) { return ctx->num_cu * 5; }  // 5 x 256 threads x 32 KiB of LDS stack per CU
+#ifndef TH_TRACE_BLOCKS_PER_CU
+#define TH_TRACE_BLOCKS_PER_CU 5
+#endif
+int trace_grid(const trhip_ctx* ctx) { return ctx->num_cu * TH_TRACE_BLOCKS_PER_CU; }  // persistent blocks per CU (LDS stack: kStack2Lds x 256 x 8 B each)
 
 // k_trace2 keeps stack levels 16..63 of every resident thread in a global slab laid out [level][thread].
 int ensure_overflow(trhip_ctx* ctx) {
@@ -440,14 +445,14 @@ void launch_trace(trhip_ctx* ctx, hipStream_t st, const trhip_scene* sc, bool an
         uint2* ov = (uint2*)(overflow_slab ? overflow_slab : ctx->overflow.p);
         if (any) {
             if (cnt)
-                hipLaunchKernelGGL((k_trace2<true, true>), grid, block, 0, st, sc->dev, sc->wide, q, ro, rd, tmax, out, work_cursors, ov, ctr);
+                hipLaunchKernelGGL((k_trace2<true, true>), grid, block, 0, st, sc->dev, sc->wide, q, ro, rd, tmax, out, work_cursors, ov, ctr, ctx->debug_trace_budget);
             else
-                hipLaunchKernelGGL((k_trace2<true, false>), grid, block, 0, st, sc->dev, sc->wide, q, ro, rd, tmax, out, work_cursors, ov, ctr);
+                hipLaunchKernelGGL((k_trace2<true, false>), grid, block, 0, st, sc->dev, sc->wide, q, ro, rd, tmax, out, work_cursors, ov, ctr, ctx->debug_trace_budget);
         } else {
             if (cnt)
-                hipLaunchKernelGGL((k_trace2<false, true>), grid, block, 0, st, sc->dev, sc->wide, q, ro, rd, tmax, out, work_cursors, ov, ctr);
+                hipLaunchKernelGGL((k_trace2<false, true>), grid, block, 0, st, sc->dev, sc->wide, q, ro, rd, tmax, out, work_cursors, ov, ctr, ctx->debug_trace_budget);
             else
-                hipLaunchKernelGGL((k_trace2<false, false>), grid, block, 0, st, sc->dev, sc->wide, q, ro, rd, tmax, out, work_cursors, ov, ctr);
+                hipLaunchKernelGGL((k_trace2<false, false>), grid, block, 0, st, sc->dev, sc->wide, q, ro, rd, tmax, out, work_cursors, ov, ctr, ctx->debug_trace_budget);
         }
         return;
     }
@@ -893,6 +898,10 @@ int trhip_set_option(trhip_ctx* ctx, const char* name, int64_t value) {
         ctx->count_visits = value != 0;
     else if (!std::strcmp(name, "timing"))
         ctx->timing = value != 0;
+    else if (!std::strcmp(name, "debug_trace_budget"))
+        ctx->debug_trace_budget = (uint32_t)value;
+    else if (!std::strcmp(name, "tiny_scene_prims"))
+        ctx->tiny_scene_prims = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(255, value));
     else if (!std::strcmp(name, "film_tiled"))
         ctx->film_tiled = value != 0;
     else if (!std::strcmp(name, "pipelines")) {
@@ -1051,7 +1060,7 @@ int trhip_scene_commit(trhip_scene* s, int max_node_primitives) {
             for (int j = 0; j < 3; ++j) pb[i].grow_point(&p.v[3 * j]);
         }
     }
-    BVHBuilder builder(pb, max_node_primitives);
+    BVHBuilder builder(pb, max_node_primitives, s->ctx->tiny_scene_prims);
     s->bvh = builder.build();
     if (s->bvh.max_depth > (uint32_t)(kStackLds + kStackSpill))
         return fail(s->ctx, TRHIP_ERR_UNSUPPORTED, "BVH depth %u exceeds the 64-entry traversal stack (bvh.jl:222)", s->bvh.max_depth);
