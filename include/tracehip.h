@@ -146,6 +146,21 @@ int trhip_render_whitted_device(trhip_ctx* ctx, const trhip_scene* scene, const 
  * (film.jl:68-73).  Parity tests compare this with the oracle bit-for-bit. */
 int trhip_last_sample_radiance(trhip_ctx* ctx, float* out_rgb, uint64_t n_floats);
 
+/* SPPMIntegrator(camera, initial_search_radius, max_depth, n_iterations, photons_per_iteration)(scene)
+ * (integrators/sppm.jl:108-173): per iteration a camera pass to the first diffuse vertex, a hash grid over the visible
+ * points, a photon pass (Halton / radical_inverse, sampler/sampling.jl:43-60) and the Float64 pixel update; afterwards
+ * _sppm_to_image + set_image! (film.jl:195-202).  out_xyzw: film_h * film_w * 4 (xyz, filter_weight_sum = 1).
+ * photons_per_iteration <= 0: area(crop_bounds) like sppm.jl:121-124.  The film's crop must start at pixel (1, 1).
+ * The camera pass of iteration k draws from the seeded stream (seed, pixel, sample k-1).  Photon contributions are added
+ * with Float32 atomics as in the reference (sppm.jl:398-399): M, radius, N, Ld and the visible points are reproducible
+ * bit for bit, τ (and the image) up to the summation order of ϕ. */
+int trhip_render_sppm(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sensor* sensor, float initial_search_radius, int max_depth, uint32_t n_iterations,
+                      int64_t photons_per_iteration, uint64_t seed, float* out_xyzw, trhip_stats* stats);
+/* SPPMPixel fields (sppm.jl:65-95) after the last trhip_render_sppm on this context, (film_h, film_w[, 3]) row-major; any
+ * pointer may be NULL.  M, phi, vp_p, vp_beta: the last iteration's values before _update_pixels! cleared them.
+ * info6 = grid resolution x y z, grid entries, photon hits inside the grid (all iterations), photons per iteration. */
+int trhip_sppm_state(trhip_ctx* ctx, float* Ld3, float* tau3, float* radius, double* N, int64_t* M, float* phi3, float* vp_p3, float* vp_beta3, int64_t* info6);
+
 /* save(film) minus the PNG encoder (film.jl:204-222): xyzw -> linear RGB in [0,1], H*W*3, rows not flipped. */
 int trhip_film_to_rgb(trhip_ctx* ctx, const float* xyzw, uint32_t width, uint32_t height, float scale, float* out_rgb);
 

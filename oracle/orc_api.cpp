@@ -7,6 +7,7 @@
 
 #include "orc_build.h"
 #include "orc_render.h"
+#include "orc_sppm.h"
 
 #ifdef _OPENMP
 #include <omp.h>
@@ -693,4 +694,85 @@ void orc_detmath_f64(int fn, const double* x, uint64_t n, double* out) {
     for (uint64_t i = 0; i < n; ++i) out[i] = fn == 0 ? tm_sin(x[i]) : tm_cos(x[i]);
 }
 
+// ---- SPPM (orc_sppm.h) -------------------------------------------------------------------------------------------------------
+// image: (height, width, 3) = _sppm_to_image after the last iteration.  Optional state dumps, all (height, width[, 3]):
+// Ld, tau, radius, N (double), and from the last iteration before _update_pixels!: M (int64), phi, vp_p, vp_beta.
+// info[0..5] = grid resolution xyz, grid entries, photon hits inside the grid (all iterations), photons per iteration.
+int orc_sppm(void* sp, const orc_sensor* sn, float initial_radius, int max_depth, int64_t n_iterations, int64_t photons_per_iteration, uint64_t seed, float* image,
+             float* out_Ld, float* out_tau, float* out_radius, double* out_N, int64_t* out_M, float* out_phi, float* out_vp_p, float* out_vp_beta, int64_t* info,
+             orc_stats* stats) {
+    OrcScene* s = (OrcScene*)sp;
+    if (!s->committed) {
+        g_err = "scene not committed";
+        return -1;
+    }
+    const Film film = make_film(sn);
+    const PerspectiveCamera cam = make_camera(sn);
+    SPPMParams prm;
+    prm.initial_search_radius = initial_radius;
+    prm.max_depth = max_depth;
+    prm.n_iterations = n_iterations;
+    prm.photons_per_iteration = photons_per_iteration;
+    prm.seed = seed;
+    SPPMState st;
+    if (!sppm_render(s->scene, cam, film, prm, st, image)) {
+        g_err = "SPPM needs a film whose crop starts at pixel (1, 1) (sppm.jl:203 indexes pixels[y, x] with raster coordinates)";
+        return -2;
+    }
+    const size_t n = st.pixels.size();
+    for (size_t i = 0; i < n; ++i) {
+        const SPPMPixel& p = st.pixels[i];
+        if (out_Ld) out_Ld[3 * i] = p.Ld.x, out_Ld[3 * i + 1] = p.Ld.y, out_Ld[3 * i + 2] = p.Ld.z;
+        if (out_tau) out_tau[3 * i] = p.tau.x, out_tau[3 * i + 1] = p.tau.y, out_tau[3 * i + 2] = p.tau.z;
+        if (out_radius) out_radius[i] = p.radius;
+        if (out_N) out_N[i] = p.N;
+        if (out_M) out_M[i] = st.last_M[i];
+    }
+    if (out_phi) std::memcpy(out_phi, st.last_phi.data(), 3 * n * sizeof(float));
+    if (out_vp_p) std::memcpy(out_vp_p, st.last_vp_p.data(), 3 * n * sizeof(float));
+    if (out_vp_beta) std::memcpy(out_vp_beta, st.last_vp_beta.data(), 3 * n * sizeof(float));
+    if (info) {
+        info[0] = st.grid_res[0], info[1] = st.grid_res[1], info[2] = st.grid_res[2];
+        info[3] = (int64_t)st.grid_entries;
+        info[4] = (int64_t)st.photon_hits;
+        info[5] = st.photons_per_iteration;
+    }
+    if (stats) {
+        stats->camera_samples = (uint64_t)n * (uint64_t)n_iterations;
+        stats->closest_rays = counters().closest;
+        stats->shadow_rays = counters().shadow;
+        stats->nodes_visited = counters().nodes;
+        stats->prims_tested = counters().prims;
+    }
+    return 0;
+}
+// KAT helpers for the SPPM callees
+float orc_radical_inverse(int64_t base_index, uint64_t a) { return radical_inverse(base_index, a); }
+uint64_t orc_grid_hash(uint64_t x, uint64_t y, uint64_t z, uint64_t n) { return grid_hash(x, y, z, n) + 1; }  // 1-based like sppm.jl:497-501
+// cdf must hold n + 1 floats; returns func_int
+float orc_distribution1d(const float* func, int n, float* cdf) {
+    const Distribution1D d(std::vector<float>(func, func + n));
+    std::memcpy(cdf, d.cdf.data(), (size_t)(n + 1) * sizeof(float));
+    return d.func_int;
+}
+// out3 = offset (1-based), pdf, u_remapped
+void orc_sample_discrete(const float* func, int n, float u, float* out3) {
+    const Distribution1D d(std::vector<float>(func, func + n));
+    const DiscreteSample s = sample_discrete(d, u);
+    out3[0] = (float)s.offset, out3[1] = s.pdf, out3[2] = s.u_remapped;
+}
+// bounds6 = p_min, p_max; res3; out4 = in_bounds, gx, gy, gz
+void orc_to_grid(const float* p3, const float* bounds6, const int64_t* res3, int64_t* out4) {
+    const GridPoint g = to_grid(V3(p3[0], p3[1], p3[2]), Bounds3(V3(bounds6[0], bounds6[1], bounds6[2]), V3(bounds6[3], bounds6[4], bounds6[5])), res3);
+    out4[0] = g.in_bounds, out4[1] = (int64_t)g.g[0], out4[2] = (int64_t)g.g[1], out4[3] = (int64_t)g.g[2];
+}
+// light index into the scene's lights; out11 = le(3) o(3) d(3) pdf_pos pdf_dir
+int orc_sample_le(void* sp, int light, const float* u2, float* out11) {
+    OrcScene* s = (OrcScene*)sp;
+    if (light < 0 || light >= (int)s->scene.lights.size()) return -1;
+    const LeSample ls = sample_le(s->scene.lights[(size_t)light], V2{u2[0], u2[1]});
+    const float v[11] = {ls.le.x, ls.le.y, ls.le.z, ls.ray.o.x, ls.ray.o.y, ls.ray.o.z, ls.ray.d.x, ls.ray.d.y, ls.ray.d.z, ls.pdf_pos, ls.pdf_dir};
+    std::memcpy(out11, v, sizeof v);
+    return 0;
+}
 }  // extern "C"

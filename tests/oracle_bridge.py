@@ -60,6 +60,14 @@ def lib():
             "orc_sensor_derived": (C.c_int, [C.POINTER(OrcSensor), _I32, _F, _F, _F]),
             "orc_generate_rays": (C.c_int, [C.POINTER(OrcSensor), _F, C.c_uint64, _F]),
             "orc_render": (C.c_int, [_VP, C.POINTER(OrcSensor), C.c_int, C.c_int64, C.c_int, C.c_uint64, C.c_uint32, C.c_int, _F, _F, C.POINTER(OrcStats)]),
+            "orc_sppm": (C.c_int, [_VP, C.POINTER(OrcSensor), C.c_float, C.c_int, C.c_int64, C.c_int64, C.c_uint64, _F, _F, _F, _F, C.POINTER(C.c_double),
+                                   C.POINTER(C.c_int64), _F, _F, _F, C.POINTER(C.c_int64), C.POINTER(OrcStats)]),
+            "orc_radical_inverse": (C.c_float, [C.c_int64, C.c_uint64]),
+            "orc_grid_hash": (C.c_uint64, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64]),
+            "orc_distribution1d": (C.c_float, [_F, C.c_int, _F]),
+            "orc_sample_discrete": (None, [_F, C.c_int, C.c_float, _F]),
+            "orc_to_grid": (None, [_F, _F, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+            "orc_sample_le": (C.c_int, [_VP, C.c_int, _F, _F]),
             "orc_film_to_rgb": (C.c_int, [_F, C.c_int, C.c_int, C.c_float, _F]),
             "orc_num_threads": (C.c_int, []),
             "orc_translate": (None, [_F, _F]),
@@ -287,6 +295,26 @@ class OracleScene:
         if rc:
             raise RuntimeError(lib().orc_last_error().decode())
         return xyzw, L, st
+
+    def sppm(self, cam, initial_radius: float, max_depth: int, n_iterations: int, photons_per_iteration: int = -1, seed: int = 0, sensor=None):
+        """SPPMIntegrator (oracle/orc_sppm.h).  Returns a dict: image (h, w, 3), Ld, tau, radius, N, and the last
+        iteration's M / phi / vp_p / vp_beta (before _update_pixels!), info, stats."""
+        sn = sensor or make_sensor(cam)
+        h, w = cam.film.size
+        out = {"image": np.empty((h, w, 3), np.float32), "Ld": np.empty((h, w, 3), np.float32), "tau": np.empty((h, w, 3), np.float32),
+               "radius": np.empty((h, w), np.float32), "N": np.empty((h, w), np.float64), "M": np.empty((h, w), np.int64), "phi": np.empty((h, w, 3), np.float32),
+               "vp_p": np.empty((h, w, 3), np.float32), "vp_beta": np.empty((h, w, 3), np.float32)}
+        info = np.zeros(6, np.int64)
+        st = OrcStats()
+        i64 = C.POINTER(C.c_int64)
+        rc = lib().orc_sppm(self.h, C.byref(sn), float(initial_radius), max_depth, n_iterations, photons_per_iteration, seed, fp(out["image"]), fp(out["Ld"]), fp(out["tau"]),
+                            fp(out["radius"]), out["N"].ctypes.data_as(C.POINTER(C.c_double)), out["M"].ctypes.data_as(i64), fp(out["phi"]), fp(out["vp_p"]), fp(out["vp_beta"]),
+                            info.ctypes.data_as(i64), C.byref(st))
+        if rc:
+            raise RuntimeError(lib().orc_last_error().decode())
+        out["info"] = {"grid_res": info[:3].copy(), "grid_entries": int(info[3]), "photon_hits": int(info[4]), "photons_per_iteration": int(info[5])}
+        out["stats"] = st
+        return out
 
     def bsdf_query(self, material, allow_multiple_lobes, mode, flags, frame9, dirs6):
         frame9, dirs6 = f32a(frame9).reshape(-1, 9), f32a(dirs6).reshape(-1, 6)

@@ -94,6 +94,8 @@ SIGNATURES = {
     "trhip_render_path_device": (C.c_int, [_VP, _VP, C.POINTER(Sensor), C.c_uint32, C.c_int, C.c_uint64, C.c_uint32, _VP, C.POINTER(Stats)]),
     "trhip_render_whitted_device": (C.c_int, [_VP, _VP, C.POINTER(Sensor), C.c_uint32, C.c_int, C.c_uint64, C.c_uint32, _VP, C.POINTER(Stats)]),
     "trhip_last_sample_radiance": (C.c_int, [_VP, _F, C.c_uint64]),
+    "trhip_render_sppm": (C.c_int, [_VP, _VP, C.POINTER(Sensor), C.c_float, C.c_int, C.c_uint32, C.c_int64, C.c_uint64, _F, C.POINTER(Stats)]),
+    "trhip_sppm_state": (C.c_int, [_VP, _F, _F, _F, C.POINTER(C.c_double), C.POINTER(C.c_int64), _F, _F, _F, C.POINTER(C.c_int64)]),
     "trhip_film_to_rgb": (C.c_int, [_VP, _F, C.c_uint32, C.c_uint32, C.c_float, _F]),
     "trhip_trace_closest": (C.c_int, [_VP, _VP, _F, C.c_uint64, _VP]),
     "trhip_trace_any": (C.c_int, [_VP, _VP, _F, C.c_uint64, C.POINTER(C.c_uint8)]),

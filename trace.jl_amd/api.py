@@ -644,3 +644,59 @@ class PathIntegrator(_SamplerIntegrator):
     """Not in the reference; defined in DESIGN.md from integrators/sppm.jl:208-266, 503-554."""
     _entry = "trhip_render_path"
     _entry_device = "trhip_render_path_device"
+
+
+class SPPMIntegrator:  # integrators/sppm.jl:108-130
+    """SPPMIntegrator(camera, initial_search_radius, max_depth, n_iterations, photons_per_iteration = -1, write_frequency = 1).
+
+    ``seed`` selects the seeded sampler stream of the camera pass (the reference draws from the global RNG there);
+    ``write_frequency`` only matters to ``__call__``, which saves the film once at the end (the intermediate images of
+    sppm.jl:166-171 are not written)."""
+
+    def __init__(self, camera: PerspectiveCamera, initial_search_radius, max_depth: int, n_iterations: int, photons_per_iteration: int = -1, write_frequency: int = 1,
+                 seed: int = 0x5EED0001):
+        self.camera = camera
+        self.initial_search_radius = f32(initial_search_radius)
+        self.max_depth, self.n_iterations = int(max_depth), int(n_iterations)
+        crop = camera.film.crop_bounds
+        area = int((f32(crop.p_max[0]) - f32(crop.p_min[0])) * (f32(crop.p_max[1]) - f32(crop.p_min[1])))  # area(crop_bounds) bounds.jl:87-90
+        self.photons_per_iteration = int(photons_per_iteration) if photons_per_iteration > 0 else area  # :121-124
+        self.write_frequency = int(write_frequency)
+        self.seed = int(seed)
+        self.stats: Optional[_ffi.Stats] = None
+        self._ctx = None
+
+    def render(self, scene: Scene, ctx: Optional[_ffi.Context] = None) -> np.ndarray:
+        flat = scene.flatten(ctx)
+        ctx = flat.ctx
+        sn = self.camera.sensor()
+        st = _ffi.Stats()
+        film = self.camera.film
+        h, w = film.size
+        out = np.empty((h, w, 4), dtype=np.float32)
+        ctx.check(_ffi.lib().trhip_render_sppm(ctx._h, flat._h, C.byref(sn), float(self.initial_search_radius), self.max_depth, self.n_iterations, self.photons_per_iteration, self.seed,
+                                               _ffi.fptr(out), C.byref(st)))
+        self.stats = st
+        self._ctx = ctx
+        film.set_xyzw(out)  # set_image!(film, image) film.jl:195-202
+        film.splat_xyz[...] = 0
+        return out
+
+    def state(self) -> dict:
+        """SPPMPixel fields after the last render (see trhip_sppm_state)."""
+        ctx = self._ctx
+        h, w = self.camera.film.size
+        out = {"Ld": np.empty((h, w, 3), np.float32), "tau": np.empty((h, w, 3), np.float32), "radius": np.empty((h, w), np.float32), "N": np.empty((h, w), np.float64),
+               "M": np.empty((h, w), np.int64), "phi": np.empty((h, w, 3), np.float32), "vp_p": np.empty((h, w, 3), np.float32), "vp_beta": np.empty((h, w, 3), np.float32)}
+        info = np.zeros(6, np.int64)
+        i64 = C.POINTER(C.c_int64)
+        ctx.check(_ffi.lib().trhip_sppm_state(ctx._h, _ffi.fptr(out["Ld"]), _ffi.fptr(out["tau"]), _ffi.fptr(out["radius"]), out["N"].ctypes.data_as(C.POINTER(C.c_double)),
+                                              out["M"].ctypes.data_as(i64), _ffi.fptr(out["phi"]), _ffi.fptr(out["vp_p"]), _ffi.fptr(out["vp_beta"]), info.ctypes.data_as(i64)))
+        out["info"] = {"grid_res": info[:3].copy(), "grid_entries": int(info[3]), "photon_hits": int(info[4]), "photons_per_iteration": int(info[5])}
+        return out
+
+    def __call__(self, scene: Scene):
+        self.render(scene)
+        if self.camera.film.filename:
+            return save(self.camera.film)
+        return None

@@ -60,6 +60,7 @@ struct LightRec {  // lights/point.jl:1-24, lights/spot.jl:1-19
     float I[3];
     float cos_total_width, cos_falloff_start;
     float w2l[9];  // world_to_light.m[1:3,1:3] (= light_to_world.inv_m), row-major, for falloff (spot.jl:32-34)
+    float l2w[9];  // light_to_world.m[1:3,1:3], row-major, for sample_le (spot.jl:49)
     float pad;
 };
 

@@ -1,0 +1,602 @@
+// th_sppm.h — SPPMIntegrator (integrators/sppm.jl, whole file) as wavefront passes on the device.
+//
+// One iteration = camera pass (visible points + direct light) -> hash grid of the visible points -> photon pass (deposit
+// ϕ, M with atomics, as the reference does with Threads.Atomic) -> pixel update (Float64, sppm.jl:438-459).
+//   * camera pass: one path per film pixel, level by level like k_shade_path, stopping at the first diffuse (or, at max
+//     depth, glossy) vertex (sppm.jl:208-266).  Direct light goes through the shadow queue WITHOUT β (A.12).  The sampler
+//     stream of iteration k is (seed, pixel, sample k-1).
+//   * grid (sppm.jl:278-318): the reference's linked lists per hash bucket become a counting sort: count per bucket,
+//     exclusive scan, fill.  A visible point registered in two cells that hash alike sits in the bucket twice, as in the
+//     reference, and is then credited twice by a photon landing there.
+//   * photons (sppm.jl:320-436): Halton dimensions by radical inverse (sampler/sampling.jl:43-60), one photon per queue
+//     entry; the emission weight β is never updated along the path (A.13).
+// M, radius, N, Ld and the visible points are bit-exact against the oracle; ϕ/τ are sums of the same terms in another order.
+#pragma once
+#include "th_kernels.h"
+
+namespace th {
+
+// primes.jl: the first primes, 2 omitted.  Dimension k >= 1 of radical_inverse uses kOddPrimes[k - 1].
+__constant__ int kOddPrimes[256] = {
+    3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37, 41, 43, 47, 53, 59,
+    61, 67, 71, 73, 79, 83, 89, 97, 101, 103, 107, 109, 113, 127, 131, 137,
+    139, 149, 151, 157, 163, 167, 173, 179, 181, 191, 193, 197, 199, 211, 223, 227,
+    229, 233, 239, 241, 251, 257, 263, 269, 271, 277, 281, 283, 293, 307, 311, 313,
+    317, 331, 337, 347, 349, 353, 359, 367, 373, 379, 383, 389, 397, 401, 409, 419,
+    421, 431, 433, 439, 443, 449, 457, 461, 463, 467, 479, 487, 491, 499, 503, 509,
+    521, 523, 541, 547, 557, 563, 569, 571, 577, 587, 593, 599, 601, 607, 613, 617,
+    619, 631, 641, 643, 647, 653, 659, 661, 673, 677, 683, 691, 701, 709, 719, 727,
+    733, 739, 743, 751, 757, 761, 769, 773, 787, 797, 809, 811, 821, 823, 827, 829,
+    839, 853, 857, 859, 863, 877, 881, 883, 887, 907, 911, 919, 929, 937, 941, 947,
+    953, 967, 971, 977, 983, 991, 997, 1009, 1013, 1019, 1021, 1031, 1033, 1039, 1049, 1051,
+    1061, 1063, 1069, 1087, 1091, 1093, 1097, 1103, 1109, 1117, 1123, 1129, 1151, 1153, 1163, 1171,
+    1181, 1187, 1193, 1201, 1213, 1217, 1223, 1229, 1231, 1237, 1249, 1259, 1277, 1279, 1283, 1289,
+    1291, 1297, 1301, 1303, 1307, 1319, 1321, 1327, 1361, 1367, 1373, 1381, 1399, 1409, 1423, 1427,
+    1429, 1433, 1439, 1447, 1451, 1453, 1459, 1471, 1481, 1483, 1487, 1489, 1493, 1499, 1511, 1523,
+    1531, 1543, 1549, 1553, 1559, 1567, 1571, 1579, 1583, 1597, 1601, 1607, 1609, 1613, 1619, 1621,
+};
+
+// sampler/sampling.jl:43-60.  The reference takes digits with floor(a / base) in Float64, which equals the integer quotient
+// for every index below 2^53 / base.
+TH_D float radical_inverse(int base_index, uint64_t a) {
+    if (base_index == 0) return (float)((double)__brevll(a) * 5.4210108624275222e-20);
+    const uint32_t base = (uint32_t)kOddPrimes[base_index - 1];
+    const float inv_base = 1.0f / (float)base;
+    uint64_t reversed = 0;
+    float inv_base_n = 1.0f;
+    if (a < (1ull << 32)) {  // 32-bit division is several times cheaper
+        uint32_t a32 = (uint32_t)a;
+        while (a32 > 0) {
+            const uint32_t next = a32 / base;
+            reversed = reversed * base + (a32 - next * base);
+            inv_base_n *= inv_base;
+            a32 = next;
+        }
+    } else {
+        while (a > 0) {
+            const uint64_t next = a / base;
+            reversed = reversed * base + (a - next * base);
+            inv_base_n *= inv_base;
+            a = next;
+        }
+    }
+    return jmin((float)reversed * inv_base_n, 1.0f);
+}
+
+struct LightDistribution {  // Distribution1D over to_Y(power(light)) (sampling.jl:3-31, sppm.jl:564-569), built on the host
+    const float* func;      // n
+    const float* cdf;       // n + 1
+    float func_int;
+    int32_t n;
+};
+
+struct VisiblePoints {  // per film pixel (y, x) row-major; β == 0 <=> no visible point this iteration
+    float4* p_mat;      // p, as_float(material)
+    float4* wo;
+    float4* beta;
+    float4* ng;
+    float4* ns;
+    float4* ss;
+    float4* ts;
+};
+struct PixelStats {
+    float4* Ld;
+    float4* tau;
+    float* radius;
+    double* N;
+    float* phi;    // 3 per pixel, atomics
+    uint32_t* M;   // atomics
+};
+struct GridInfo {  // device-resident
+    uint32_t enc_min[3], enc_max[3], enc_max_radius;  // order-preserving encodings for atomicMin / atomicMax
+    float bmin[3], bmax[3];
+    int32_t res[3];
+    uint32_t valid;
+    uint32_t overflow;  // entries did not fit
+    uint32_t total;     // grid entries
+    unsigned long long photon_hits;
+};
+TH_D uint32_t enc_f32(float f) {
+    const uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+TH_D float dec_f32(uint32_t e) { return __uint_as_float((e & 0x80000000u) ? (e & 0x7fffffffu) : ~e); }
+
+// sppm.jl:479-495 with bounds.jl:134-143
+TH_D bool to_grid(const GridInfo& g, f3 p, uint32_t out[3]) {
+    const f3 o = mk3(p.x - g.bmin[0], p.y - g.bmin[1], p.z - g.bmin[2]);
+    const bool g0 = g.bmax[0] > g.bmin[0], g1 = g.bmax[1] > g.bmin[1], g2 = g.bmax[2] > g.bmin[2];
+    f3 po = o;
+    if (g0 || g1 || g2) po = mk3(o.x / (g0 ? g.bmax[0] - g.bmin[0] : 1.0f), o.y / (g1 ? g.bmax[1] - g.bmin[1] : 1.0f), o.z / (g2 ? g.bmax[2] - g.bmin[2] : 1.0f));
+    const float pf[3] = {po.x, po.y, po.z};
+    bool in_bounds = true;
+    for (int a = 0; a < 3; ++a) {
+        const float fl = __builtin_floorf((float)g.res[a] * pf[a]);
+        // Int64(floor(...)): clamp in float first (|fl| can exceed the int range far outside the grid)
+        const bool inside = fl >= 0.0f && fl < (float)g.res[a];
+        if (!inside) in_bounds = false;
+        int32_t gi = !(fl >= 0.0f) ? 0 : (fl > (float)(g.res[a] - 1) ? g.res[a] - 1 : (int32_t)fl);
+        out[a] = (uint32_t)gi;
+    }
+    return in_bounds;
+}
+TH_D uint32_t grid_hash(uint32_t x, uint32_t y, uint32_t z, uint32_t hash_size) {  // sppm.jl:497-501 (0-based)
+    const uint64_t h = ((uint64_t)x * 73856093ull) ^ ((uint64_t)y * 19349663ull) ^ ((uint64_t)z * 83492791ull);
+    return (uint32_t)(h % (uint64_t)hash_size);
+}
+
+// ---- camera pass ----------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_sppm_raygen(const DeviceSensor* __restrict__ sep, uint32_t n, uint32_t width, uint64_t seed, uint32_t iteration, PathQueue q,
+                                                        uint32_t cap, Counters* ctr) {
+    const DeviceSensor& se = *sep;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const int py = 1 + (int)(i / width), px = 1 + (int)(i - (i / width) * width);  // crop_bounds start at (1, 1)
+        const uint64_t key = ts_stream_key(seed, px, py, iteration - 1u);
+        const f2 film{(float)px + ts_uniform(key, TS_DIM_FILM_X), (float)py + ts_uniform(key, TS_DIM_FILM_Y)};
+        const f2 lens{ts_uniform(key, TS_DIM_LENS_X), ts_uniform(key, TS_DIM_LENS_Y)};
+        f3 o, d;
+        float time;
+        generate_ray(se, film, lens, ts_uniform(key, TS_DIM_TIME), o, d, time);
+        d = check_direction(d);
+        const uint32_t w = i >> 6;
+        const uint32_t phys = (w % kSeg) * cap + (w / kSeg) * 64u + (i & 63u);
+        q.o[phys] = make_float4(o.x, o.y, o.z, __uint_as_float(i));
+        q.d[phys] = make_float4(d.x, d.y, d.z, __uint_as_float(0u));  // .w: specular_bounce
+        q.beta[phys] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < kSeg) {
+        const uint32_t sgm = threadIdx.x, W = (n + 63u) >> 6;
+        uint32_t cnt = ((W + kSeg - 1 - sgm) / kSeg) * 64u;
+        if (W > 0 && (W - 1) % kSeg == sgm && (n & 63u)) cnt -= 64u - (n & 63u);
+        ctr->n_queue[0][sgm] = cnt;
+    }
+}
+
+TH_D void add_nan_where(float4* L, uint32_t slot, uint32_t poison) {  // L += β · 0 with a non-finite β
+    float4 l = L[slot];
+    const float nanv = __builtin_nanf("");
+    if (poison & 1u) l.x += nanv;
+    if (poison & 2u) l.y += nanv;
+    if (poison & 4u) l.z += nanv;
+    L[slot] = l;
+}
+
+// One level of the camera pass (sppm.jl:208-266).
+__global__ __launch_bounds__(kBlock) void k_shade_sppm(DeviceScene sc, PathQueue qin, PathQueue qout, ShadowQueue sq, uint32_t cap, const float4* __restrict__ hits, VisiblePoints vp,
+                                                       float4* __restrict__ Ld, Counters* ctr, int depth, int max_depth, uint64_t seed, uint32_t iteration, uint32_t width) {
+    __shared__ SegView sv;
+    const SegQueue qv{ctr->n_queue[depth - 1], cap, 0u};
+    seg_load(qv, sv);
+    const uint32_t total = sv.prefix[kSeg];
+    for (uint32_t flat = blockIdx.x * kBlock + threadIdx.x; flat < total; flat += gridDim.x * kBlock) {
+        uint32_t seg_in, lb;
+        seg_locate(sv, flat & ~63u, seg_in, lb);
+        const uint32_t local = lb + (flat & 63u);
+        const bool valid = local < sv.count[seg_in];
+        const uint32_t i = seg_in * cap + local;
+        const uint32_t seg_out = (flat >> 6) % kSeg;
+        bool want_shadow = false, want_next = false;
+        float4 so4, sd4, sc4, no4, nd4, nb4;
+        if (valid) {
+            const float4 h4 = hits[i];
+            const int prim = __float_as_int(h4.y);
+            const float4 o4 = qin.o[i], d4 = qin.d[i], b4 = qin.beta[i];
+            const uint32_t slot = __float_as_uint(o4.w);
+            f3 beta = mk3(b4.x, b4.y, b4.z);
+            const uint32_t poison = ((isnan_(beta.x) || isinf_(beta.x)) ? 1u : 0u) | ((isnan_(beta.y) || isinf_(beta.y)) ? 2u : 0u) | ((isnan_(beta.z) || isinf_(beta.z)) ? 4u : 0u);
+            if (prim < 0) {
+                if (poison && sc.n_lights > 0) add_nan_where(Ld, slot, poison);  // Ld += β * le(light, ray) = β * 0 (:211-216)
+            } else {
+                const f3 o = mk3(o4.x, o4.y, o4.z), d = mk3(d4.x, d4.y, d4.z);
+                const bool specular_bounce = __float_as_uint(d4.w) != 0u;
+                Shading sh;
+                uint32_t material;
+                if (rebuild_shading(sc, prim, o, d, sh, material) && material != PRIM_NO_MATERIAL) {
+                    const LobeSet& bsdf = sc.materials[material].set[1];
+                    const int py = 1 + (int)(slot / width), px = 1 + (int)(slot - (slot / width) * width);
+                    const uint64_t key = ts_stream_key(seed, px, py, iteration - 1u);
+                    const uint32_t v = (uint32_t)(depth - 1);
+                    const f3 wo = -d;
+                    if ((depth == 1 || specular_bounce) && poison) add_nan_where(Ld, slot, poison);  // Ld += β * le(si, wo) = β * 0 (:227-229)
+                    // uniform_sample_one_light, not weighted by β (:230-232, A.12)
+                    if (sc.n_lights > 0) {
+                        const int nl = (int)sc.n_lights;
+                        int ln = (int)__builtin_ceilf(ts_uniform(key, ts_vertex_dim(v, TS_V_LIGHT_PICK)) * (float)nl);
+                        if (ln > nl) ln = nl;
+                        if (ln < 1) ln = 1;
+                        const float light_pdf = 1.0f / (float)nl;
+                        const LightRec& light = sc.lights[ln - 1];
+                        const LightSample ls = sample_li(light, sh.p);
+                        if (ls.pdf > 0.0f && !is_black(ls.radiance)) {
+                            const f3 f = bsdf_f(bsdf, sh, sh.wo, ls.wi, BSDF_ALL & ~BSDF_SPECULAR) * fabs_(dot(ls.wi, sh.ns));
+                            if (!is_black(f)) {
+                                const f3 c = (splat3(0.0f) + f * ls.radiance / ls.pdf) / light_pdf;
+                                const f3 lp = mk3(light.position[0], light.position[1], light.position[2]);
+                                const f3 dir = lp - sh.p;
+                                const f3 org = sh.p + 1e-6f * dir;
+                                const f3 cd = check_direction(dir);
+                                so4 = make_float4(org.x, org.y, org.z, __uint_as_float(slot));
+                                sd4 = make_float4(cd.x, cd.y, cd.z, __uint_as_float(0u));
+                                sc4 = make_float4(c.x, c.y, c.z, 0.0f);
+                                want_shadow = true;
+                            }
+                        }
+                    }
+                    const bool is_diffuse = bsdf_num_components(bsdf, BSDF_DIFFUSE | BSDF_REFLECTION | BSDF_TRANSMISSION) > 0;
+                    const bool is_glossy = bsdf_num_components(bsdf, BSDF_GLOSSY | BSDF_REFLECTION | BSDF_TRANSMISSION) > 0;
+                    if (is_diffuse || (is_glossy && depth == max_depth)) {  // :239-245
+                        vp.p_mat[slot] = make_float4(sh.p.x, sh.p.y, sh.p.z, __uint_as_float(material));
+                        vp.wo[slot] = make_float4(wo.x, wo.y, wo.z, 0.0f);
+                        vp.beta[slot] = make_float4(beta.x, beta.y, beta.z, 0.0f);
+                        vp.ng[slot] = make_float4(sh.ng.x, sh.ng.y, sh.ng.z, 0.0f);
+                        vp.ns[slot] = make_float4(sh.ns.x, sh.ns.y, sh.ns.z, 0.0f);
+                        vp.ss[slot] = make_float4(sh.ss.x, sh.ss.y, sh.ss.z, 0.0f);
+                        vp.ts[slot] = make_float4(sh.ts.x, sh.ts.y, sh.ts.z, 0.0f);
+                    } else if (depth < max_depth) {
+                        const f2 u{ts_uniform(key, ts_vertex_dim(v, TS_V_BSDF_U0)), ts_uniform(key, ts_vertex_dim(v, TS_V_BSDF_U1))};
+                        const BsdfSample bs = bsdf_sample_f(bsdf, sh, wo, u, BSDF_ALL);
+                        if (!(bs.pdf == 0.0f || is_black(bs.f))) {
+                            beta = beta * (bs.f * fabs_(dot(bs.wi, sh.ns)) / bs.pdf);
+                            const float by = to_Y(beta);
+                            bool alive = true;
+                            if (by < 0.25f) {
+                                const float cont = jmin(1.0f, by);
+                                if (ts_uniform(key, ts_vertex_dim(v, TS_V_RR)) > cont)
+                                    alive = false;
+                                else
+                                    beta = beta / cont;
+                            }
+                            if (alive) {
+                                const f3 org = sh.p + 1e-6f * bs.wi;
+                                const f3 nd = check_direction(bs.wi);
+                                no4 = make_float4(org.x, org.y, org.z, __uint_as_float(slot));
+                                nd4 = make_float4(nd.x, nd.y, nd.z, __uint_as_float((bs.sampled_type & BSDF_SPECULAR) != 0 ? 1u : 0u));
+                                nb4 = make_float4(beta.x, beta.y, beta.z, 0.0f);
+                                want_next = true;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        const uint32_t si = seg_out * cap + wave_compact(want_shadow, &ctr->n_shadow[depth - 1][seg_out]);
+        if (want_shadow) {
+            sq.o[si] = so4;
+            sq.d[si] = sd4;
+            sq.c[si] = sc4;
+        }
+        const uint32_t ni = seg_out * cap + wave_compact(want_next, &ctr->n_queue[depth][seg_out]);
+        if (want_next) {
+            qout.o[ni] = no4;
+            qout.d[ni] = nd4;
+            qout.beta[ni] = nb4;
+        }
+    }
+}
+
+// ---- grid (sppm.jl:278-318) --------------------------------------------------------------------------------------------------------
+TH_D float wave_min(float v) {
+    for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off));
+    return v;
+}
+TH_D float wave_max(float v) {
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    return v;
+}
+__global__ __launch_bounds__(kBlock) void k_sppm_grid_reset(GridInfo* g) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        for (int a = 0; a < 3; ++a) {
+            g->enc_min[a] = enc_f32(kInf);
+            g->enc_max[a] = enc_f32(-kInf);
+        }
+        g->enc_max_radius = enc_f32(0.0f);
+        g->valid = 0;
+        g->total = 0;  // overflow and photon_hits are per render call
+    }
+}
+// grid_bounds = ∪ expand(Bounds3(vp.p), radius), max_radius (:285-292)
+__global__ __launch_bounds__(kBlock) void k_sppm_grid_bounds(VisiblePoints vp, const float* __restrict__ radius, uint32_t n, GridInfo* g) {
+    float mn[3] = {kInf, kInf, kInf}, mx[3] = {-kInf, -kInf, -kInf}, mr = 0.0f;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const float4 b = vp.beta[i];
+        if (b.x == 0.0f && b.y == 0.0f && b.z == 0.0f) continue;
+        const float4 p = vp.p_mat[i];
+        const float r = radius[i];
+        const float pp[3] = {p.x, p.y, p.z};
+        for (int a = 0; a < 3; ++a) {
+            mn[a] = fminf(mn[a], pp[a] - r);
+            mx[a] = fmaxf(mx[a], pp[a] + r);
+        }
+        mr = fmaxf(mr, r);
+    }
+    for (int a = 0; a < 3; ++a) {
+        mn[a] = wave_min(mn[a]);
+        mx[a] = wave_max(mx[a]);
+    }
+    mr = wave_max(mr);
+    if (lane_id() == 0 && mr > 0.0f) {
+        for (int a = 0; a < 3; ++a) {
+            atomicMin(&g->enc_min[a], enc_f32(mn[a]));
+            atomicMax(&g->enc_max[a], enc_f32(mx[a]));
+        }
+        atomicMax(&g->enc_max_radius, enc_f32(mr));
+    }
+}
+// grid resolution (:293-302)
+__global__ void k_sppm_grid_setup(GridInfo* g) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    const float max_radius = dec_f32(g->enc_max_radius);
+    if (!(max_radius > 0.0f)) {
+        g->valid = 0;
+        g->res[0] = g->res[1] = g->res[2] = 1;
+        return;
+    }
+    float diag[3];
+    for (int a = 0; a < 3; ++a) {
+        g->bmin[a] = dec_f32(g->enc_min[a]);
+        g->bmax[a] = dec_f32(g->enc_max[a]);
+        diag[a] = g->bmax[a] - g->bmin[a];
+    }
+    const float max_diag = jmax(jmax(diag[0], diag[1]), diag[2]);
+    const float base_res = __builtin_floorf(max_diag / max_radius);  // Int64(floor(...)): exact in Float32 below 2^24
+    for (int a = 0; a < 3; ++a) {
+        const float r = __builtin_floorf(base_res * diag[a] / max_diag);
+        g->res[a] = r > 1.0f ? (int32_t)r : 1;
+    }
+    g->valid = 1;
+}
+// pass = 0: count the entries of every bucket; pass = 1: fill (cursor[h] counts down from the bucket size)
+__global__ __launch_bounds__(kBlock) void k_sppm_grid_build(VisiblePoints vp, const float* __restrict__ radius, uint32_t n, uint32_t hash_size, GridInfo* gp, uint32_t* __restrict__ counts,
+                                                            const uint32_t* __restrict__ starts, uint32_t* __restrict__ entries, uint32_t capacity, int pass) {
+    const GridInfo& g = *gp;
+    if (!g.valid) return;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const float4 b = vp.beta[i];
+        if (b.x == 0.0f && b.y == 0.0f && b.z == 0.0f) continue;
+        const float4 p4 = vp.p_mat[i];
+        const float r = radius[i];
+        uint32_t lo[3], hi[3];
+        to_grid(g, mk3(p4.x - r, p4.y - r, p4.z - r), lo);
+        to_grid(g, mk3(p4.x + r, p4.y + r, p4.z + r), hi);
+        for (uint32_t z = lo[2]; z <= hi[2]; ++z)
+            for (uint32_t y = lo[1]; y <= hi[1]; ++y)
+                for (uint32_t x = lo[0]; x <= hi[0]; ++x) {
+                    const uint32_t h = grid_hash(x, y, z, hash_size);
+                    if (pass == 0) {
+                        atomicAdd(&counts[h], 1u);
+                    } else {
+                        const uint32_t k = atomicSub(&counts[h], 1u) - 1u;
+                        const uint32_t pos = starts[h] + k;
+                        if (pos < capacity)
+                            entries[pos] = i;
+                        else
+                            gp->overflow = 1u;
+                    }
+                }
+    }
+}
+// starts[0..n] = exclusive prefix sums of counts[0..n-1]; one block of 1024 threads.
+__global__ __launch_bounds__(1024) void k_sppm_scan(const uint32_t* __restrict__ counts, uint32_t* __restrict__ starts, uint32_t n, GridInfo* g) {
+    __shared__ uint32_t part[1024];
+    const uint32_t t = threadIdx.x;
+    const uint32_t chunk = (n + 1023u) / 1024u;
+    const uint32_t b = min(n, t * chunk), e = min(n, b + chunk);
+    uint32_t s = 0;
+    for (uint32_t i = b; i < e; ++i) s += counts[i];
+    part[t] = s;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
+        const uint32_t v = t >= off ? part[t - off] : 0u;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint32_t acc = t ? part[t - 1] : 0u;
+    for (uint32_t i = b; i < e; ++i) {
+        starts[i] = acc;
+        acc += counts[i];
+    }
+    if (t == 1023) {
+        starts[n] = part[1023];
+        g->total = part[1023];
+    }
+}
+
+// ---- photon pass (sppm.jl:320-436) ----------------------------------------------------------------------------------------------
+// Photon ray leaving the light: sample_discrete over light power, sample_le (point.jl:60-69, spot.jl:46-55), β.
+__global__ __launch_bounds__(kBlock) void k_photon_gen(DeviceScene sc, LightDistribution ld, uint32_t n_photons, uint64_t halton_base, PathQueue q, uint32_t cap, Counters* ctr) {
+    const uint32_t total = (n_photons + 63u) & ~63u;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < total; i += gridDim.x * kBlock) {
+        bool want = false;
+        float4 o4, d4, b4;
+        if (i < n_photons) {
+            const uint64_t hi = halton_base + i;
+            const float light_sample = radical_inverse(0, hi);
+            int offset = 0;  // findlast(cdf[i] ≤ u), 1-based
+            for (int k = ld.n + 1; k >= 1; --k)
+                if (ld.cdf[k - 1] <= light_sample) {
+                    offset = k;
+                    break;
+                }
+            offset = offset < 1 ? 1 : (offset > ld.n ? ld.n : offset);
+            const float light_pdf = ld.func_int > 0.0f ? ld.func[offset - 1] / (ld.func_int * (float)ld.n) : 0.0f;
+            const LightRec& l = sc.lights[offset - 1];
+            const f2 u{radical_inverse(1, hi), radical_inverse(2, hi)};
+            const f3 I = mk3(l.I[0], l.I[1], l.I[2]);
+            f3 dir, le;
+            float pdf_dir;
+            if (l.kind == 0) {  // uniform_sample_sphere Trace.jl:69-74
+                const float z = 1.0f - 2.0f * u.x;
+                const float r = sqrt_(jmax(0.0f, 1.0f - z * z));
+                const float phi = 2.0f * kPi * u.y;
+                dir = mk3(r * tm_cosf(phi), r * tm_sinf(phi), z);
+                pdf_dir = 1.0f / (4.0f * kPi);
+                le = I;
+            } else {  // uniform_sample_cone Trace.jl:76-81, light_to_world on the vector
+                const float c = 1.0f - u.x + u.x * l.cos_total_width;
+                const float s = sqrt_(1.0f - c * c);
+                const float phi = u.y * 2.0f * kPi;
+                const f3 w = mk3(tm_cosf(phi) * s, tm_sinf(phi) * s, c);
+                dir = mk3(l.l2w[0] * w.x + l.l2w[1] * w.y + l.l2w[2] * w.z, l.l2w[3] * w.x + l.l2w[4] * w.y + l.l2w[5] * w.z, l.l2w[6] * w.x + l.l2w[7] * w.y + l.l2w[8] * w.z);
+                pdf_dir = 1.0f / (2.0f * kPi * (1.0f - l.cos_total_width));
+                const f3 wl = normalize(mk3(l.w2l[0] * dir.x + l.w2l[1] * dir.y + l.w2l[2] * dir.z, l.w2l[3] * dir.x + l.w2l[4] * dir.y + l.w2l[5] * dir.z,
+                                            l.w2l[6] * dir.x + l.w2l[7] * dir.y + l.w2l[8] * dir.z));
+                const float ct = wl.z;
+                float fall;
+                if (ct < l.cos_total_width)
+                    fall = 0.0f;
+                else if (ct >= l.cos_falloff_start)
+                    fall = 1.0f;
+                else
+                    fall = pow4((ct - l.cos_total_width) / (l.cos_falloff_start - l.cos_total_width));
+                le = I * fall;
+            }
+            const float pdf_pos = 1.0f;
+            if (!(pdf_dir == 0.0f || is_black(le))) {
+                const f3 beta = fabs_(dot(dir, dir)) * le / (light_pdf * pdf_pos * pdf_dir);  // light_normal = ray.d
+                if (!is_black(beta)) {
+                    const f3 cd = check_direction(dir);
+                    o4 = make_float4(l.position[0], l.position[1], l.position[2], __uint_as_float(i));
+                    d4 = make_float4(cd.x, cd.y, cd.z, 0.0f);
+                    b4 = make_float4(beta.x, beta.y, beta.z, 0.0f);
+                    want = true;
+                }
+            }
+        }
+        const uint32_t seg_out = (i >> 6) % kSeg;
+        const uint32_t k = seg_out * cap + wave_compact(want, &ctr->n_queue[0][seg_out]);
+        if (want) {
+            q.o[k] = o4;
+            q.d[k] = d4;
+            q.beta[k] = b4;
+        }
+    }
+}
+
+// One photon bounce: deposit at depth > 1 (:366-391), then sample the next direction and play Russian roulette (:393-418).
+__global__ __launch_bounds__(kBlock) void k_shade_photon(DeviceScene sc, PathQueue qin, PathQueue qout, uint32_t cap, const float4* __restrict__ hits, VisiblePoints vp, PixelStats px,
+                                                         GridInfo* gp, const uint32_t* __restrict__ starts, const uint32_t* __restrict__ entries, uint32_t hash_size, Counters* ctr,
+                                                         int depth, int max_depth, uint64_t halton_base) {
+    __shared__ SegView sv;
+    const SegQueue qv{ctr->n_queue[depth - 1], cap, 0u};
+    seg_load(qv, sv);
+    const GridInfo& g = *gp;
+    const uint32_t total = sv.prefix[kSeg];
+    unsigned long long n_hits = 0;
+    for (uint32_t flat = blockIdx.x * kBlock + threadIdx.x; flat < total; flat += gridDim.x * kBlock) {
+        uint32_t seg_in, lb;
+        seg_locate(sv, flat & ~63u, seg_in, lb);
+        const uint32_t local = lb + (flat & 63u);
+        const bool valid = local < sv.count[seg_in];
+        const uint32_t i = seg_in * cap + local;
+        const uint32_t seg_out = (flat >> 6) % kSeg;
+        bool want_next = false;
+        float4 no4, nd4, nb4;
+        if (valid) {
+            const float4 h4 = hits[i];
+            const int prim = __float_as_int(h4.y);
+            if (prim >= 0) {
+                const float4 o4 = qin.o[i], d4 = qin.d[i], b4 = qin.beta[i];
+                const uint32_t photon = __float_as_uint(o4.w);
+                const f3 o = mk3(o4.x, o4.y, o4.z), d = mk3(d4.x, d4.y, d4.z);
+                const f3 beta = mk3(b4.x, b4.y, b4.z);
+                Shading sh;
+                uint32_t material;
+                if (rebuild_shading(sc, prim, o, d, sh, material) && material != PRIM_NO_MATERIAL) {
+                    const f3 wi_photon = -d;
+                    if (depth > 1 && g.valid) {
+                        uint32_t gi[3];
+                        if (to_grid(g, sh.p, gi)) {
+                            n_hits++;
+                            const uint32_t h = grid_hash(gi[0], gi[1], gi[2], hash_size);
+                            const uint32_t e0 = starts[h], e1 = starts[h + 1];
+                            for (uint32_t e = e0; e < e1; ++e) {
+                                const uint32_t pid = entries[e];
+                                const float4 p4 = vp.p_mat[pid];
+                                const float r = px.radius[pid];
+                                const f3 dv = mk3(p4.x, p4.y, p4.z) - sh.p;  // distance_squared(vp.p, p)
+                                if (dot(dv, dv) > r * r) continue;
+                                Shading vs;
+                                const float4 wo4 = vp.wo[pid], ng4 = vp.ng[pid], ns4 = vp.ns[pid], ss4 = vp.ss[pid], ts4 = vp.ts[pid];
+                                vs.p = mk3(p4.x, p4.y, p4.z);
+                                vs.wo = mk3(wo4.x, wo4.y, wo4.z);
+                                vs.ng = mk3(ng4.x, ng4.y, ng4.z);
+                                vs.ns = mk3(ns4.x, ns4.y, ns4.z);
+                                vs.ss = mk3(ss4.x, ss4.y, ss4.z);
+                                vs.ts = mk3(ts4.x, ts4.y, ts4.z);
+                                const LobeSet& vb = sc.materials[__float_as_uint(p4.w)].set[1];
+                                const f3 phi = beta * bsdf_f(vb, vs, vs.wo, wi_photon, BSDF_ALL);
+                                atomicAdd(&px.phi[3 * pid + 0], phi.x);
+                                atomicAdd(&px.phi[3 * pid + 1], phi.y);
+                                atomicAdd(&px.phi[3 * pid + 2], phi.z);
+                                atomicAdd(&px.M[pid], 1u);
+                            }
+                        }
+                    }
+                    const LobeSet& bsdf = sc.materials[material].set[1];  // compute_scattering!(…, true, Importance): the mode changes nothing (A.11)
+                    const uint64_t hidx = halton_base + photon;
+                    const int dim = 6 + 3 * (depth - 1);
+                    const f2 u{radical_inverse(dim, hidx), radical_inverse(dim + 1, hidx)};
+                    const BsdfSample bs = bsdf_sample_f(bsdf, sh, wi_photon, u, BSDF_ALL);
+                    if (!(is_black(bs.f) || bs.pdf == 0.0f) && depth < max_depth) {
+                        const f3 beta_new = beta * bs.f * fabs_(dot(bs.wi, sh.ns)) / bs.pdf;
+                        const float q = jmax(0.0f, 1.0f - to_Y(beta_new) / to_Y(beta));
+                        if (!(radical_inverse(dim + 2, hidx) < q)) {
+                            const f3 org = sh.p + 1e-6f * bs.wi;
+                            const f3 nd = check_direction(bs.wi);
+                            no4 = make_float4(org.x, org.y, org.z, __uint_as_float(photon));
+                            nd4 = make_float4(nd.x, nd.y, nd.z, 0.0f);
+                            nb4 = b4;
+                            want_next = true;
+                        }
+                    }
+                }
+            }
+        }
+        const uint32_t ni = seg_out * cap + wave_compact(want_next, &ctr->n_queue[depth][seg_out]);
+        if (want_next) {
+            qout.o[ni] = no4;
+            qout.d[ni] = nd4;
+            qout.beta[ni] = nb4;
+        }
+    }
+    n_hits = wave_sum(n_hits);
+    if (lane_id() == 0 && n_hits) atomicAdd(&gp->photon_hits, n_hits);
+}
+
+// ---- _update_pixels! (sppm.jl:438-459) and _sppm_to_image (:461-472) ------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_sppm_update(uint32_t n, float gamma, PixelStats px, VisiblePoints vp) {
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const uint32_t M = px.M[i];
+        if (M > 0) {
+            const double N = px.N[i];
+            const float radius = px.radius[i];
+            const double n_new = N + (double)(gamma * (float)M);
+            const double radius_new = (double)radius * __builtin_sqrt(n_new / (N + (double)M));
+            const double ratio = radius_new / (double)radius, r2 = ratio * ratio;
+            const float4 t = px.tau[i];
+            const float sx = t.x + px.phi[3 * i], sy = t.y + px.phi[3 * i + 1], sz = t.z + px.phi[3 * i + 2];
+            px.tau[i] = make_float4((float)((double)sx * r2), (float)((double)sy * r2), (float)((double)sz * r2), 0.0f);
+            px.radius[i] = (float)radius_new;
+            px.N[i] = n_new;
+            px.phi[3 * i] = px.phi[3 * i + 1] = px.phi[3 * i + 2] = 0.0f;
+            px.M[i] = 0u;
+        }
+        vp.beta[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+}
+// film pixel = set_image!(film, image): xyz = to_XYZ(image[i]), filter_weight_sum = 1 (film.jl:195-202)
+__global__ __launch_bounds__(kBlock) void k_sppm_image(uint32_t n, uint32_t iteration, uint64_t photons_per_iteration, PixelStats px, float4* __restrict__ film) {
+    const double Np = (double)((uint64_t)iteration * photons_per_iteration) * 3.141592653589793;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const float4 ld = px.Ld[i], t = px.tau[i];
+        const float r = px.radius[i];
+        const f3 a = mk3(ld.x, ld.y, ld.z) / (float)iteration;
+        const double den = Np * (double)(r * r);
+        const f3 b = mk3((float)((double)t.x / den), (float)((double)t.y / den), (float)((double)t.z / den));
+        const f3 xyz = rgb_to_xyz(a + b);
+        film[i] = make_float4(xyz.x, xyz.y, xyz.z, 1.0f);
+    }
+}
+
+}  // namespace th
