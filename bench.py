@@ -30,6 +30,8 @@ def build_workload(T, name: str, res: int):
     if name in T.scenes.MESH_N:
         n = T.scenes.MESH_N[name]
         return T.scenes.mesh_scene(n), T.scenes.cornell_camera(res), f"S-mesh: Cornell box + {2 * n * n} triangle height field"
+    if name == "caustic":
+        return T.scenes.caustic_scene(), T.scenes.caustic_camera(res), "S-caustic: procedural glass goblet (~88k triangles) on a plastic floor, SpotLight (docs/code/caustic_glass.jl)"
     raise SystemExit(f"unknown workload {name}")
 
 

@@ -211,6 +211,8 @@ int trhip_film_accumulate(trhip_ctx* ctx, const trhip_sensor* sensor, uint32_t s
  * "pipelines" (1..8): wavefront batches in flight at once (default 1).
  * "tiny_scene_prims" (0..255): scenes of at most this many primitives are committed as ONE leaf (default 16; 0 = never).
  *     Read by trhip_scene_commit; results do not depend on it except through the order coincident hits are visited in.
+ * "sppm_batch": SPPM iterations whose camera / photon paths share the traversal launches (default 0 = as many as fit in
+ *     free HBM, at most 32); the result does not depend on it.
  * "film_tiled" (0/1): LDS-staged film gather (default 0: measured slower).
  * "debug_trace_budget": DIAGNOSTIC ONLY, traversal abandons rays after this many node fetches (results wrong). */
 int trhip_set_option(trhip_ctx* ctx, const char* name, int64_t value);

@@ -69,12 +69,17 @@ def check_pair(T, xyzw, got, ref, iters):
     assert np.all(xyzw[..., 3] == 1.0)
 
 
-@pytest.mark.parametrize("iters", [1, 3])
-def test_sppm_cornell_point_light(T, ob, ctx, iters):
-    """Matte walls, mirror and glass spheres: specular chains before the visible point, photons through glass."""
+@pytest.mark.parametrize("iters,batch", [(1, 0), (3, 0), (3, 1), (3, 2), (5, 2)])
+def test_sppm_cornell_point_light(T, ob, ctx, iters, batch):
+    """Matte walls, mirror and glass spheres: specular chains before the visible point, photons through glass.
+    ``sppm_batch``: iterations sharing the traversal launches (0 = all that fit); the result may not depend on it."""
     scene = T.scenes.cornell_scene()
     cam = T.scenes.cornell_camera(48)
-    _, xyzw, got, ref = run_pair(T, ob, ctx, scene, cam, 0.08, 5, iters, 20000, seed=11)
+    ctx.set_option("sppm_batch", batch)
+    try:
+        _, xyzw, got, ref = run_pair(T, ob, ctx, scene, cam, 0.08, 5, iters, 20000, seed=11)
+    finally:
+        ctx.set_option("sppm_batch", 0)
     check_pair(T, xyzw, got, ref, iters)
     assert (got["radius"] < np.float32(0.08)).any()
 

@@ -1,0 +1,77 @@
+#!/usr/bin/env python
+"""SPPM throughput on one MI355X (BASELINE.json configs[3]: caustic glass, 1024x1024, 100 iterations, depth 8).
+
+    python tools/sppm_bench.py [--res 1024] [--iterations 100] [--depth 8] [--radius 0.075] [--model path.ply] [--cpu-iterations 0]
+
+Prints one JSON line: rays (closest + shadow) per second over the whole SPPMIntegrator call, ms per iteration and the
+library's per-kernel-class HIP-event times.  The glass is the procedural goblet of scenes.caustic_scene unless --model
+names a PLY (the reference's caustic-glass.ply does not travel to the GPU box).  --cpu-iterations N > 0 also times the
+single-threaded oracle on N iterations of the same scene (a reported baseline).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--res", type=int, default=1024)
+    ap.add_argument("--iterations", type=int, default=100)
+    ap.add_argument("--depth", type=int, default=8)
+    ap.add_argument("--radius", type=float, default=0.075)
+    ap.add_argument("--photons", type=int, default=-1)
+    ap.add_argument("--model", default="")
+    ap.add_argument("--repeat", type=int, default=2)
+    ap.add_argument("--cpu-iterations", type=int, default=0)
+    ap.add_argument("--png", default="")
+    args = ap.parse_args()
+    import __graft_entry__ as g
+    T = g.load_package()
+    scene = T.scenes.caustic_scene(args.model)
+    cam = T.scenes.caustic_camera(args.res, args.png)
+    ctx = T.default_context()
+    t0 = time.time()
+    flat = scene.flatten(ctx)
+    build_s = time.time() - t0
+    integ = T.SPPMIntegrator(cam, args.radius, args.depth, args.iterations, args.photons)
+    best = None
+    for _ in range(max(1, args.repeat)):
+        t0 = time.time()
+        integ.render(scene, ctx)
+        wall = time.time() - t0
+        st = integ.stats
+        if best is None or st.ms_total < best[0].ms_total:
+            best = (st, wall)
+    st, wall = best
+    rays = st.closest_rays + st.shadow_rays
+    info = integ.state()["info"]
+    out = {"metric": "Mray/s (SPPM: camera + shadow + photon rays)", "value": round(rays / st.ms_total / 1e3, 2), "unit": "Mray/s", "n_gpus": 1,
+           "ms_per_iteration": round(st.ms_total / args.iterations, 3), "ms_total": round(st.ms_total, 2), "wall_s": round(wall, 3), "dtype": "f32 (+f64 pixel update)",
+           "config": {"workload": f"S-caustic ({'PLY ' + os.path.basename(args.model) if args.model else 'procedural goblet'}, {flat.n_prims} primitives, SpotLight), "
+                                  f"{args.res}x{args.res}, {args.iterations} iterations, {info['photons_per_iteration']} photons/iteration, depth {args.depth}, radius {args.radius}",
+                      "bvh_build_upload_s": round(build_s, 3)},
+           "rays": {"closest": st.closest_rays, "shadow": st.shadow_rays},
+           "kernel_ms": {"raygen+photon_gen": round(st.ms_raygen, 2), "trace_closest": round(st.ms_trace_closest, 2), "shade+grid+update": round(st.ms_shade, 2),
+                         "trace_any": round(st.ms_trace_any, 2), "image": round(st.ms_film, 3)},
+           "grid": {"res": [int(x) for x in info["grid_res"]], "entries": info["grid_entries"], "photon_hits": info["photon_hits"]}}
+    if args.png:
+        T.save(cam.film, ctx)
+    if args.cpu_iterations > 0:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_bridge as ob
+        osc = ob.OracleScene.from_scene(scene, bvh=flat.bvh())
+        t0 = time.time()
+        r = osc.sppm(cam, args.radius, args.depth, args.cpu_iterations, args.photons)
+        dt = time.time() - t0
+        out["cpu_baseline"] = {"value": round((r["stats"].closest_rays + r["stats"].shadow_rays) / dt / 1e6, 3), "unit": "Mray/s", "cores": 1, "kind": "port",
+                               "sample": f"{args.cpu_iterations} iterations of the same configuration, {dt:.1f} s"}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

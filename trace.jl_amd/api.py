@@ -700,3 +700,88 @@ class SPPMIntegrator:  # integrators/sppm.jl:108-130
         if self.camera.film.filename:
             return save(self.camera.film)
         return None
+
+
+# ---- model_loader.jl:1-11 without Assimp: a minimal PLY reader ---------------------------------------------------------------------
+_PLY_TYPES = {"char": "i1", "int8": "i1", "uchar": "u1", "uint8": "u1", "short": "i2", "int16": "i2", "ushort": "u2", "uint16": "u2", "int": "i4", "int32": "i4",
+              "uint": "u4", "uint32": "u4", "float": "f4", "float32": "f4", "double": "f8", "float64": "f8"}
+
+
+def read_ply(path: str):
+    """(vertices (n, 3) Float32, normals (n, 3) Float32 or None, faces (m, 3) 0-based UInt32) of an ascii / binary PLY with
+    triangle faces (a list property on the face element) — the subset docs/src/assets/models needs."""
+    with open(path, "rb") as f:
+        if f.readline().strip() != b"ply":
+            raise ValueError(f"{path}: not a PLY file")
+        fmt, elements = None, []
+        while True:
+            line = f.readline()
+            if not line:
+                raise ValueError(f"{path}: truncated PLY header")
+            tok = line.decode("ascii", "replace").split()
+            if not tok or tok[0] == "comment" or tok[0] == "obj_info":
+                continue
+            if tok[0] == "format":
+                fmt = tok[1]
+            elif tok[0] == "element":
+                elements.append({"name": tok[1], "count": int(tok[2]), "props": []})
+            elif tok[0] == "property":
+                if tok[1] == "list":
+                    elements[-1]["props"].append(("list", tok[2], tok[3], tok[4]))
+                else:
+                    elements[-1]["props"].append(("scalar", tok[1], tok[2]))
+            elif tok[0] == "end_header":
+                break
+        if fmt not in ("ascii", "binary_little_endian", "binary_big_endian"):
+            raise ValueError(f"{path}: unsupported PLY format {fmt}")
+        end = ">" if fmt == "binary_big_endian" else "<"
+        verts = normals = faces = None
+        for el in elements:
+            n, props = el["count"], el["props"]
+            if all(p[0] == "scalar" for p in props):
+                names = [p[2] for p in props]
+                if fmt == "ascii":
+                    rows = np.array([f.readline().split() for _ in range(n)], dtype=np.float64).reshape(n, len(props))
+                    cols = {nm: rows[:, i] for i, nm in enumerate(names)}
+                else:
+                    dt = np.dtype([(p[2], end + _PLY_TYPES[p[1]]) for p in props])
+                    rec = np.frombuffer(f.read(dt.itemsize * n), dtype=dt, count=n)
+                    cols = {nm: rec[nm] for nm in names}
+                if el["name"] == "vertex":
+                    verts = np.stack([cols["x"], cols["y"], cols["z"]], axis=1).astype(np.float32)
+                    if all(k in cols for k in ("nx", "ny", "nz")):
+                        normals = np.stack([cols["nx"], cols["ny"], cols["nz"]], axis=1).astype(np.float32)
+            else:
+                if len(props) != 1:
+                    raise ValueError(f"{path}: element {el['name']}: only a single list property is supported")
+                _, ct, it, _ = props[0]
+                if fmt == "ascii":
+                    rows = [f.readline().split() for _ in range(n)]
+                    if any(int(r[0]) != 3 for r in rows):
+                        raise ValueError("Only triangles supported.")  # model_loader.jl:29
+                    idx = np.array([r[1:4] for r in rows], dtype=np.int64).reshape(n, 3)
+                else:
+                    dt = np.dtype([("n", end + _PLY_TYPES[ct]), ("i", end + _PLY_TYPES[it], (3,))])
+                    rec = np.frombuffer(f.read(dt.itemsize * n), dtype=dt, count=n)
+                    if n and np.any(rec["n"] != 3):
+                        raise ValueError("Only triangles supported.")
+                    idx = rec["i"].astype(np.int64)
+                if el["name"] == "face":
+                    faces = idx.astype(np.uint32)
+        if verts is None or faces is None:
+            raise ValueError(f"{path}: no vertex / face element")
+        if faces.size and int(faces.max()) >= verts.shape[0]:
+            raise ValueError(f"{path}: face index out of range")
+        return verts, normals, faces
+
+
+def load_triangle_mesh(model_file: str, core: Optional[ShapeCore] = None):
+    """model_loader.jl:1-11: (triangle_meshes, triangles).  The reference goes through Assimp; PLY is read directly here.
+    Like the reference it requires one normal per vertex (model_loader.jl:30)."""
+    core = core or ShapeCore(Transformation(), False)
+    verts, normals, faces = read_ply(model_file)
+    if normals is None or normals.shape[0] != verts.shape[0]:
+        raise ValueError("Number of normals is different from the number of vertices")
+    indices = (faces.reshape(-1) + 1).astype(np.uint32)  # 1-based (model_loader.jl:36)
+    triangles = create_triangle_mesh(core, faces.shape[0], indices, verts.shape[0], verts, normals)
+    return [triangles[0].mesh] if triangles else [], triangles

@@ -126,12 +126,15 @@ TH_D uint32_t grid_hash(uint32_t x, uint32_t y, uint32_t z, uint32_t hash_size) 
 }
 
 // ---- camera pass ----------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_sppm_raygen(const DeviceSensor* __restrict__ sep, uint32_t n, uint32_t width, uint64_t seed, uint32_t iteration, PathQueue q,
+// Camera rays of a BATCH of iterations: entry e = (iteration it0 + e / n_pix, pixel e % n_pix).  The camera paths of different
+// iterations do not depend on each other (only Ld accumulates, in order, see k_sppm_fold_ld), so they share the launches.
+__global__ __launch_bounds__(kBlock) void k_sppm_raygen(const DeviceSensor* __restrict__ sep, uint32_t n, uint32_t n_pix, uint32_t width, uint64_t seed, uint32_t it0, PathQueue q,
                                                         uint32_t cap, Counters* ctr) {
     const DeviceSensor& se = *sep;
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-        const int py = 1 + (int)(i / width), px = 1 + (int)(i - (i / width) * width);  // crop_bounds start at (1, 1)
-        const uint64_t key = ts_stream_key(seed, px, py, iteration - 1u);
+        const uint32_t it_local = i / n_pix, pix = i - it_local * n_pix;
+        const int py = 1 + (int)(pix / width), px = 1 + (int)(pix - (pix / width) * width);  // crop_bounds start at (1, 1)
+        const uint64_t key = ts_stream_key(seed, px, py, it0 + it_local - 1u);
         const f2 film{(float)px + ts_uniform(key, TS_DIM_FILM_X), (float)py + ts_uniform(key, TS_DIM_FILM_Y)};
         const f2 lens{ts_uniform(key, TS_DIM_LENS_X), ts_uniform(key, TS_DIM_LENS_Y)};
         f3 o, d;
@@ -161,9 +164,12 @@ TH_D void add_nan_where(float4* L, uint32_t slot, uint32_t poison) {  // L += β
     L[slot] = l;
 }
 
-// One level of the camera pass (sppm.jl:208-266).
+// One level of the camera pass (sppm.jl:208-266) for a batch of iterations.  slot = it_local * n_pix + pixel indexes the
+// visible points of the batch; what the reference adds to pixel.Ld at this depth goes to the term slot
+// ((it_local * max_depth + depth - 1) * n_pix + pixel) of a zeroed buffer — written by at most one path, so the `+=` of the
+// shadow kernel is race-free — and k_sppm_fold_ld adds the terms to Ld in the reference's order afterwards.
 __global__ __launch_bounds__(kBlock) void k_shade_sppm(DeviceScene sc, PathQueue qin, PathQueue qout, ShadowQueue sq, uint32_t cap, const float4* __restrict__ hits, VisiblePoints vp,
-                                                       float4* __restrict__ Ld, Counters* ctr, int depth, int max_depth, uint64_t seed, uint32_t iteration, uint32_t width) {
+                                                       float4* __restrict__ Ld, Counters* ctr, int depth, int max_depth, uint64_t seed, uint32_t it0, uint32_t n_pix, uint32_t width) {
     __shared__ SegView sv;
     const SegQueue qv{ctr->n_queue[depth - 1], cap, 0u};
     seg_load(qv, sv);
@@ -182,10 +188,12 @@ __global__ __launch_bounds__(kBlock) void k_shade_sppm(DeviceScene sc, PathQueue
             const int prim = __float_as_int(h4.y);
             const float4 o4 = qin.o[i], d4 = qin.d[i], b4 = qin.beta[i];
             const uint32_t slot = __float_as_uint(o4.w);
+            const uint32_t it_local = slot / n_pix, pix = slot - it_local * n_pix;
+            const uint32_t term = (it_local * (uint32_t)max_depth + (uint32_t)(depth - 1)) * n_pix + pix;
             f3 beta = mk3(b4.x, b4.y, b4.z);
             const uint32_t poison = ((isnan_(beta.x) || isinf_(beta.x)) ? 1u : 0u) | ((isnan_(beta.y) || isinf_(beta.y)) ? 2u : 0u) | ((isnan_(beta.z) || isinf_(beta.z)) ? 4u : 0u);
             if (prim < 0) {
-                if (poison && sc.n_lights > 0) add_nan_where(Ld, slot, poison);  // Ld += β * le(light, ray) = β * 0 (:211-216)
+                if (poison && sc.n_lights > 0) add_nan_where(Ld, term, poison);  // Ld += β * le(light, ray) = β * 0 (:211-216)
             } else {
                 const f3 o = mk3(o4.x, o4.y, o4.z), d = mk3(d4.x, d4.y, d4.z);
                 const bool specular_bounce = __float_as_uint(d4.w) != 0u;
@@ -193,11 +201,11 @@ __global__ __launch_bounds__(kBlock) void k_shade_sppm(DeviceScene sc, PathQueue
                 uint32_t material;
                 if (rebuild_shading(sc, prim, o, d, sh, material) && material != PRIM_NO_MATERIAL) {
                     const LobeSet& bsdf = sc.materials[material].set[1];
-                    const int py = 1 + (int)(slot / width), px = 1 + (int)(slot - (slot / width) * width);
-                    const uint64_t key = ts_stream_key(seed, px, py, iteration - 1u);
+                    const int py = 1 + (int)(pix / width), px = 1 + (int)(pix - (pix / width) * width);
+                    const uint64_t key = ts_stream_key(seed, px, py, it0 + it_local - 1u);
                     const uint32_t v = (uint32_t)(depth - 1);
                     const f3 wo = -d;
-                    if ((depth == 1 || specular_bounce) && poison) add_nan_where(Ld, slot, poison);  // Ld += β * le(si, wo) = β * 0 (:227-229)
+                    if ((depth == 1 || specular_bounce) && poison) add_nan_where(Ld, term, poison);  // Ld += β * le(si, wo) = β * 0 (:227-229)
                     // uniform_sample_one_light, not weighted by β (:230-232, A.12)
                     if (sc.n_lights > 0) {
                         const int nl = (int)sc.n_lights;
@@ -215,7 +223,7 @@ __global__ __launch_bounds__(kBlock) void k_shade_sppm(DeviceScene sc, PathQueue
                                 const f3 dir = lp - sh.p;
                                 const f3 org = sh.p + 1e-6f * dir;
                                 const f3 cd = check_direction(dir);
-                                so4 = make_float4(org.x, org.y, org.z, __uint_as_float(slot));
+                                so4 = make_float4(org.x, org.y, org.z, __uint_as_float(term));
                                 sd4 = make_float4(cd.x, cd.y, cd.z, __uint_as_float(0u));
                                 sc4 = make_float4(c.x, c.y, c.z, 0.0f);
                                 want_shadow = true;
@@ -473,16 +481,25 @@ __global__ __launch_bounds__(kBlock) void k_photon_gen(DeviceScene sc, LightDist
     }
 }
 
-// One photon bounce: deposit at depth > 1 (:366-391), then sample the next direction and play Russian roulette (:393-418).
-__global__ __launch_bounds__(kBlock) void k_shade_photon(DeviceScene sc, PathQueue qin, PathQueue qout, uint32_t cap, const float4* __restrict__ hits, VisiblePoints vp, PixelStats px,
-                                                         GridInfo* gp, const uint32_t* __restrict__ starts, const uint32_t* __restrict__ entries, uint32_t hash_size, Counters* ctr,
-                                                         int depth, int max_depth, uint64_t halton_base) {
+// Photon hits of a batch of iterations.  Photon paths do not depend on the pixels (β is never updated, the grid is only
+// read when depositing), so the photons of several iterations are traced together and every hit at depth >= 2 is recorded
+// in the slot ((depth - 2) * n_batch_photons + photon): no counter, no atomics.  k_sppm_deposit replays the records of one
+// iteration against that iteration's grid.
+struct PhotonRecords {
+    float4* p;       // hit point, unused
+    float4* wi;      // -photon_ray.d, unused
+    float4* beta;    // emission weight β
+    uint8_t* valid;  // zeroed per batch
+};
+
+// One photon bounce: record the hit at depth > 1 (:366-391 happens in k_sppm_deposit), then sample the next direction and play
+// Russian roulette (:393-418).
+__global__ __launch_bounds__(kBlock) void k_shade_photon(DeviceScene sc, PathQueue qin, PathQueue qout, uint32_t cap, const float4* __restrict__ hits, PhotonRecords rec,
+                                                         uint32_t n_batch_photons, Counters* ctr, int depth, int max_depth, uint64_t halton_base) {
     __shared__ SegView sv;
     const SegQueue qv{ctr->n_queue[depth - 1], cap, 0u};
     seg_load(qv, sv);
-    const GridInfo& g = *gp;
     const uint32_t total = sv.prefix[kSeg];
-    unsigned long long n_hits = 0;
     for (uint32_t flat = blockIdx.x * kBlock + threadIdx.x; flat < total; flat += gridDim.x * kBlock) {
         uint32_t seg_in, lb;
         seg_locate(sv, flat & ~63u, seg_in, lb);
@@ -504,34 +521,12 @@ __global__ __launch_bounds__(kBlock) void k_shade_photon(DeviceScene sc, PathQue
                 uint32_t material;
                 if (rebuild_shading(sc, prim, o, d, sh, material) && material != PRIM_NO_MATERIAL) {
                     const f3 wi_photon = -d;
-                    if (depth > 1 && g.valid) {
-                        uint32_t gi[3];
-                        if (to_grid(g, sh.p, gi)) {
-                            n_hits++;
-                            const uint32_t h = grid_hash(gi[0], gi[1], gi[2], hash_size);
-                            const uint32_t e0 = starts[h], e1 = starts[h + 1];
-                            for (uint32_t e = e0; e < e1; ++e) {
-                                const uint32_t pid = entries[e];
-                                const float4 p4 = vp.p_mat[pid];
-                                const float r = px.radius[pid];
-                                const f3 dv = mk3(p4.x, p4.y, p4.z) - sh.p;  // distance_squared(vp.p, p)
-                                if (dot(dv, dv) > r * r) continue;
-                                Shading vs;
-                                const float4 wo4 = vp.wo[pid], ng4 = vp.ng[pid], ns4 = vp.ns[pid], ss4 = vp.ss[pid], ts4 = vp.ts[pid];
-                                vs.p = mk3(p4.x, p4.y, p4.z);
-                                vs.wo = mk3(wo4.x, wo4.y, wo4.z);
-                                vs.ng = mk3(ng4.x, ng4.y, ng4.z);
-                                vs.ns = mk3(ns4.x, ns4.y, ns4.z);
-                                vs.ss = mk3(ss4.x, ss4.y, ss4.z);
-                                vs.ts = mk3(ts4.x, ts4.y, ts4.z);
-                                const LobeSet& vb = sc.materials[__float_as_uint(p4.w)].set[1];
-                                const f3 phi = beta * bsdf_f(vb, vs, vs.wo, wi_photon, BSDF_ALL);
-                                atomicAdd(&px.phi[3 * pid + 0], phi.x);
-                                atomicAdd(&px.phi[3 * pid + 1], phi.y);
-                                atomicAdd(&px.phi[3 * pid + 2], phi.z);
-                                atomicAdd(&px.M[pid], 1u);
-                            }
-                        }
+                    if (depth > 1) {
+                        const size_t r = (size_t)(depth - 2) * n_batch_photons + photon;
+                        rec.p[r] = make_float4(sh.p.x, sh.p.y, sh.p.z, 0.0f);
+                        rec.wi[r] = make_float4(wi_photon.x, wi_photon.y, wi_photon.z, 0.0f);
+                        rec.beta[r] = b4;
+                        rec.valid[r] = 1;
                     }
                     const LobeSet& bsdf = sc.materials[material].set[1];  // compute_scattering!(…, true, Importance): the mode changes nothing (A.11)
                     const uint64_t hidx = halton_base + photon;
@@ -560,8 +555,69 @@ __global__ __launch_bounds__(kBlock) void k_shade_photon(DeviceScene sc, PathQue
             qout.beta[ni] = nb4;
         }
     }
+}
+
+// `pixel.ϕ += β · f_vp(wo_vp, wi)`, `pixel.M += 1` for every visible point of the photon's grid cell within its radius
+// (sppm.jl:366-391), for the photon hits of ONE iteration: record slots (d, first_photon + i), d < n_depths, i < n_photons.
+__global__ __launch_bounds__(kBlock) void k_sppm_deposit(DeviceScene sc, PhotonRecords rec, uint32_t n_batch_photons, uint32_t first_photon, uint32_t n_photons, uint32_t n_depths,
+                                                         VisiblePoints vp, PixelStats px, GridInfo* gp, const uint32_t* __restrict__ starts, const uint32_t* __restrict__ entries,
+                                                         uint32_t hash_size) {
+    const GridInfo& g = *gp;
+    if (!g.valid) return;
+    const uint32_t total = n_photons * n_depths;
+    unsigned long long n_hits = 0;
+    for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < total; k += gridDim.x * kBlock) {
+        const uint32_t d = k / n_photons, i = k - d * n_photons;
+        const size_t r = (size_t)d * n_batch_photons + first_photon + i;
+        if (!rec.valid[r]) continue;
+        const float4 hp = rec.p[r];
+        const f3 p = mk3(hp.x, hp.y, hp.z);
+        uint32_t gi[3];
+        if (!to_grid(g, p, gi)) continue;
+        n_hits++;
+        const float4 w4 = rec.wi[r], b4 = rec.beta[r];
+        const f3 wi_photon = mk3(w4.x, w4.y, w4.z), beta = mk3(b4.x, b4.y, b4.z);
+        const uint32_t h = grid_hash(gi[0], gi[1], gi[2], hash_size);
+        const uint32_t e0 = starts[h], e1 = starts[h + 1];
+        for (uint32_t e = e0; e < e1; ++e) {
+            const uint32_t pid = entries[e];
+            const float4 p4 = vp.p_mat[pid];
+            const float rad = px.radius[pid];
+            const f3 dv = mk3(p4.x, p4.y, p4.z) - p;  // distance_squared(vp.p, p)
+            if (dot(dv, dv) > rad * rad) continue;
+            Shading vs;
+            const float4 wo4 = vp.wo[pid], ng4 = vp.ng[pid], ns4 = vp.ns[pid], ss4 = vp.ss[pid], ts4 = vp.ts[pid];
+            vs.p = mk3(p4.x, p4.y, p4.z);
+            vs.wo = mk3(wo4.x, wo4.y, wo4.z);
+            vs.ng = mk3(ng4.x, ng4.y, ng4.z);
+            vs.ns = mk3(ns4.x, ns4.y, ns4.z);
+            vs.ss = mk3(ss4.x, ss4.y, ss4.z);
+            vs.ts = mk3(ts4.x, ts4.y, ts4.z);
+            const LobeSet& vb = sc.materials[__float_as_uint(p4.w)].set[1];
+            const f3 phi = beta * bsdf_f(vb, vs, vs.wo, wi_photon, BSDF_ALL);
+            atomicAdd(&px.phi[3 * pid + 0], phi.x);
+            atomicAdd(&px.phi[3 * pid + 1], phi.y);
+            atomicAdd(&px.phi[3 * pid + 2], phi.z);
+            atomicAdd(&px.M[pid], 1u);
+        }
+    }
     n_hits = wave_sum(n_hits);
     if (lane_id() == 0 && n_hits) atomicAdd(&gp->photon_hits, n_hits);
+}
+
+// pixel.Ld += every term of the batch in the reference's order: iterations ascending, inside an iteration by depth
+// (sppm.jl:211-232).  A depth nothing was added at holds +0, and x + 0 == x for every x this sum can take.
+__global__ __launch_bounds__(kBlock) void k_sppm_fold_ld(uint32_t n_pix, uint32_t n_iter, uint32_t max_depth, const float4* __restrict__ terms, float4* __restrict__ Ld) {
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n_pix; i += gridDim.x * kBlock) {
+        float4 l = Ld[i];
+        for (uint32_t k = 0; k < n_iter * max_depth; ++k) {
+            const float4 t = terms[(size_t)k * n_pix + i];
+            l.x += t.x;
+            l.y += t.y;
+            l.z += t.z;
+        }
+        Ld[i] = l;
+    }
 }
 
 // ---- _update_pixels! (sppm.jl:438-459) and _sppm_to_image (:461-472) ------------------------------------------------------------------

@@ -60,6 +60,8 @@ struct trhip_ctx {
     uint64_t last_L_count = 0;  // float4 entries valid in Lbuf
     // SPPM state (th_sppm.h): per film pixel, kept after trhip_render_sppm for trhip_sppm_state
     DevBuf sp_vp[7], sp_Ld, sp_tau, sp_radius, sp_N, sp_phi, sp_M, sp_counts, sp_starts, sp_entries, sp_grid, sp_ldist, sp_snap_M, sp_snap_phi, sp_snap_p, sp_snap_beta;
+    DevBuf sp_terms, sp_rec[3], sp_rec_valid;
+    uint64_t sppm_batch = 0;  // SPPM iterations per wavefront batch (0 = from free HBM, at most 32)
     uint32_t sp_pixels = 0;
     int64_t sp_photons = 0;
 };
@@ -872,8 +874,22 @@ int render_sppm_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
         if (int rc = upload(ctx, ctx->sp_ldist, ld_host.data(), ld_host.size() * sizeof(float))) return rc;
     }
     const LightDistribution ldist{(const float*)ctx->sp_ldist.p, (const float*)ctx->sp_ldist.p + n_lights, func_int, (int32_t)n_lights};
-    // queues sized for max(pixels, photons)
-    const uint64_t Q = std::max<uint64_t>(n, (uint64_t)P);
+    // Iterations are processed in batches of B: the camera paths and the photon paths of different iterations are
+    // independent of the pixel statistics, so B iterations share every traversal / shading launch (B x the rays per
+    // launch, 1/B the launches and traversal tails); only grid -> deposit -> update runs once per iteration, in order.
+    const uint64_t Qit = std::max<uint64_t>(n, (uint64_t)P);
+    const int ndep = std::max(1, max_depth - 1);
+    const double per_iter = (double)n * (7 * 16.0 + max_depth * 16.0) + (double)P * ndep * 49.0 + (double)Qit * 10 * 16.0;
+    uint64_t B = ctx->sppm_batch;
+    if (B == 0) {
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
+        B = (uint64_t)std::max(1.0, 0.5 * (double)free_b / per_iter);
+        B = std::min<uint64_t>(B, 32);
+    }
+    B = std::min<uint64_t>(B, n_iterations);
+    while (B > 1 && (B * Qit >= (1ull << 31) || B * (uint64_t)max_depth * n >= (1ull << 32) || B * (uint64_t)P >= (1ull << 31))) B = (B + 1) / 2;
+    const uint64_t Q = B * Qit;
     const uint32_t cap = (uint32_t)(((Q + kSeg - 1) / kSeg + 2 * kSegGran + kSegGran - 1) / kSegGran * kSegGran);
     const uint64_t Pphys = (uint64_t)cap * kSeg;
     Pipe& pp = ctx->pipes[0];
@@ -894,7 +910,13 @@ int render_sppm_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
     const size_t slab_bytes = (size_t)trace_grid(ctx) * kBlock * (size_t)(kStack2Total - kStack2Lds) * sizeof(uint2);
     if (int rc = ensure(ctx, pp.overflow[0], slab_bytes)) return rc;
     for (auto& b : ctx->sp_vp)
-        if (int rc = ensure(ctx, b, (size_t)n * sizeof(float4))) return rc;
+        if (int rc = ensure(ctx, b, (size_t)B * n * sizeof(float4))) return rc;
+    const size_t n_terms = (size_t)B * max_depth * n;
+    const size_t n_rec = (size_t)B * (size_t)P * ndep;
+    if (int rc = ensure(ctx, ctx->sp_terms, n_terms * sizeof(float4))) return rc;
+    for (auto& b : ctx->sp_rec)
+        if (int rc = ensure(ctx, b, n_rec * sizeof(float4))) return rc;
+    if (int rc = ensure(ctx, ctx->sp_rec_valid, n_rec)) return rc;
     const uint32_t entry_cap = 32u * n;  // a visible point spans at most 3 cells per axis (cell side >= max radius)
     if (int rc = ensure(ctx, ctx->sp_Ld, (size_t)n * sizeof(float4))) return rc;
     if (int rc = ensure(ctx, ctx->sp_tau, (size_t)n * sizeof(float4))) return rc;
@@ -922,9 +944,15 @@ int render_sppm_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
     for (int k = 0; k < 2; ++k) pq[k] = PathQueue{(float4*)pp.q[k][0].p, (float4*)pp.q[k][1].p, (float4*)pp.q[k][2].p};
     ShadowQueue sq{(float4*)pp.sq[0].p, (float4*)pp.sq[1].p, (float4*)pp.sq[2].p};
     float4* hits = (float4*)pp.hits.p;
-    VisiblePoints vp{(float4*)ctx->sp_vp[0].p, (float4*)ctx->sp_vp[1].p, (float4*)ctx->sp_vp[2].p, (float4*)ctx->sp_vp[3].p, (float4*)ctx->sp_vp[4].p, (float4*)ctx->sp_vp[5].p,
-                     (float4*)ctx->sp_vp[6].p};
+    const VisiblePoints vp_all{(float4*)ctx->sp_vp[0].p, (float4*)ctx->sp_vp[1].p, (float4*)ctx->sp_vp[2].p, (float4*)ctx->sp_vp[3].p, (float4*)ctx->sp_vp[4].p,
+                               (float4*)ctx->sp_vp[5].p, (float4*)ctx->sp_vp[6].p};
+    auto vp_slice = [&](uint64_t j) {
+        const size_t o = (size_t)j * n;
+        return VisiblePoints{vp_all.p_mat + o, vp_all.wo + o, vp_all.beta + o, vp_all.ng + o, vp_all.ns + o, vp_all.ss + o, vp_all.ts + o};
+    };
     PixelStats px{(float4*)ctx->sp_Ld.p, (float4*)ctx->sp_tau.p, (float*)ctx->sp_radius.p, (double*)ctx->sp_N.p, (float*)ctx->sp_phi.p, (uint32_t*)ctx->sp_M.p};
+    float4* terms = (float4*)ctx->sp_terms.p;
+    const PhotonRecords rec{(float4*)ctx->sp_rec[0].p, (float4*)ctx->sp_rec[1].p, (float4*)ctx->sp_rec[2].p, (uint8_t*)ctx->sp_rec_valid.p};
     uint32_t* counts = (uint32_t*)ctx->sp_counts.p;
     uint32_t* starts = (uint32_t*)ctx->sp_starts.p;
     uint32_t* entries = (uint32_t*)ctx->sp_entries.p;
@@ -935,7 +963,6 @@ int render_sppm_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
     HIP_TRY(ctx, hipEventCreate(&e1));
     HIP_TRY(ctx, hipEventRecord(e0, st));
     // pixels = [SPPMPixel(radius = initial_search_radius) …] (:136-139)
-    for (auto& b : ctx->sp_vp) HIP_TRY(ctx, hipMemsetAsync(b.p, 0, (size_t)n * sizeof(float4), st));
     HIP_TRY(ctx, hipMemsetAsync(px.Ld, 0, (size_t)n * sizeof(float4), st));
     HIP_TRY(ctx, hipMemsetAsync(px.tau, 0, (size_t)n * sizeof(float4), st));
     HIP_TRY(ctx, hipMemsetAsync(px.N, 0, (size_t)n * sizeof(double), st));
@@ -950,11 +977,16 @@ int render_sppm_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
     }
     const dim3 blk(kBlock), g_pix(grid_for(ctx, n, 8)), g_shade(ctx->num_cu * 8);
     const float gamma = 2.0f / 3.0f;
-    for (uint32_t it = 1; it <= n_iterations; ++it) {
-        // ---- camera pass (:175-270) ----
+    uint32_t n_batches = 0;
+    for (uint32_t it0 = 1; it0 <= n_iterations; it0 += (uint32_t)B) {
+        const uint32_t nb = (uint32_t)std::min<uint64_t>(B, n_iterations - it0 + 1);
+        n_batches++;
+        // ---- camera pass of iterations it0 .. it0 + nb - 1 (:175-270) ----
+        for (auto& b : ctx->sp_vp) HIP_TRY(ctx, hipMemsetAsync(b.p, 0, (size_t)nb * n * sizeof(float4), st));  // vp.β = 0: no visible point
+        HIP_TRY(ctx, hipMemsetAsync(terms, 0, (size_t)nb * max_depth * n * sizeof(float4), st));
         HIP_TRY(ctx, hipMemsetAsync(ctr, 0, offsetof(Counters, closest_total), st));
         tm.begin(0, st);
-        hipLaunchKernelGGL(k_sppm_raygen, g_pix, blk, 0, st, dsp, n, W, seed, it, pq[0], cap, ctr);
+        hipLaunchKernelGGL(k_sppm_raygen, dim3(grid_for(ctx, (uint64_t)nb * n, 8)), blk, 0, st, dsp, nb * n, n, W, seed, it0, pq[0], cap, ctr);
         tm.end(0, st);
         int cur = 0;
         for (int depth = 1; depth <= max_depth; ++depth) {
@@ -963,30 +995,25 @@ int render_sppm_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
                          pp.overflow[0].p);
             tm.end(1, st);
             tm.begin(2, st);
-            hipLaunchKernelGGL(k_shade_sppm, g_shade, blk, 0, st, scene->dev, pq[cur], pq[cur ^ 1], sq, cap, hits, vp, px.Ld, ctr, depth, max_depth, seed, it, W);
+            hipLaunchKernelGGL(k_shade_sppm, g_shade, blk, 0, st, scene->dev, pq[cur], pq[cur ^ 1], sq, cap, hits, vp_all, terms, ctr, depth, max_depth, seed, it0, n, W);
             tm.end(2, st);
             tm.begin(3, st);
-            launch_trace(ctx, st, scene, true, SegQueue{ctr->n_shadow[depth - 1], cap, 0u}, sq.o, sq.d, nullptr, TraceOut{nullptr, px.Ld, sq.c, nullptr}, ctr->work_shadow[depth - 1], ctr,
+            launch_trace(ctx, st, scene, true, SegQueue{ctr->n_shadow[depth - 1], cap, 0u}, sq.o, sq.d, nullptr, TraceOut{nullptr, terms, sq.c, nullptr}, ctr->work_shadow[depth - 1], ctr,
                          pp.overflow[0].p);
             tm.end(3, st);
             cur ^= 1;
         }
-        // ---- grid (:272-318) ----
         tm.begin(2, st);
-        HIP_TRY(ctx, hipMemsetAsync(counts, 0, (size_t)n * sizeof(uint32_t), st));
-        hipLaunchKernelGGL(k_sppm_grid_reset, dim3(1), blk, 0, st, grid);
-        hipLaunchKernelGGL(k_sppm_grid_bounds, g_pix, blk, 0, st, vp, (const float*)px.radius, n, grid);
-        hipLaunchKernelGGL(k_sppm_grid_setup, dim3(1), dim3(64), 0, st, grid);
-        hipLaunchKernelGGL(k_sppm_grid_build, g_pix, blk, 0, st, vp, (const float*)px.radius, n, n, grid, counts, (const uint32_t*)starts, entries, entry_cap, 0);
-        hipLaunchKernelGGL(k_sppm_scan, dim3(1), dim3(1024), 0, st, (const uint32_t*)counts, starts, n, grid);
-        hipLaunchKernelGGL(k_sppm_grid_build, g_pix, blk, 0, st, vp, (const float*)px.radius, n, n, grid, counts, (const uint32_t*)starts, entries, entry_cap, 1);
+        hipLaunchKernelGGL(k_sppm_fold_ld, g_pix, blk, 0, st, n, nb, (uint32_t)max_depth, (const float4*)terms, px.Ld);
         tm.end(2, st);
-        // ---- photon pass (:320-436) ----
+        // ---- photon paths of the same iterations (:320-365, 393-418): Halton indices (it0 - 1) * P .. (it0 - 1 + nb) * P - 1 ----
+        const uint32_t NP = nb * (uint32_t)P;
         if (n_lights) {
-            const uint64_t halton_base = (uint64_t)(it - 1) * (uint64_t)P;
+            const uint64_t halton_base = (uint64_t)(it0 - 1) * (uint64_t)P;
+            HIP_TRY(ctx, hipMemsetAsync(rec.valid, 0, (size_t)NP * ndep, st));
             HIP_TRY(ctx, hipMemsetAsync(ctr, 0, offsetof(Counters, closest_total), st));
             tm.begin(0, st);
-            hipLaunchKernelGGL(k_photon_gen, dim3(grid_for(ctx, (uint64_t)P, 8)), blk, 0, st, scene->dev, ldist, (uint32_t)P, halton_base, pq[0], cap, ctr);
+            hipLaunchKernelGGL(k_photon_gen, dim3(grid_for(ctx, NP, 8)), blk, 0, st, scene->dev, ldist, NP, halton_base, pq[0], cap, ctr);
             tm.end(0, st);
             cur = 0;
             for (int depth = 1; depth <= max_depth; ++depth) {
@@ -995,22 +1022,36 @@ int render_sppm_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
                              ctr, pp.overflow[0].p);
                 tm.end(1, st);
                 tm.begin(2, st);
-                hipLaunchKernelGGL(k_shade_photon, g_shade, blk, 0, st, scene->dev, pq[cur], pq[cur ^ 1], cap, hits, vp, px, grid, (const uint32_t*)starts, (const uint32_t*)entries, n, ctr, depth,
-                                   max_depth, halton_base);
+                hipLaunchKernelGGL(k_shade_photon, g_shade, blk, 0, st, scene->dev, pq[cur], pq[cur ^ 1], cap, hits, rec, NP, ctr, depth, max_depth, halton_base);
                 tm.end(2, st);
                 cur ^= 1;
             }
         }
-        if (it == n_iterations) {  // snapshot for trhip_sppm_state: the last iteration's M, ϕ and visible points
-            HIP_TRY(ctx, hipMemcpyAsync(ctx->sp_snap_M.p, px.M, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
-            HIP_TRY(ctx, hipMemcpyAsync(ctx->sp_snap_phi.p, px.phi, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToDevice, st));
-            HIP_TRY(ctx, hipMemcpyAsync(ctx->sp_snap_p.p, vp.p_mat, (size_t)n * sizeof(float4), hipMemcpyDeviceToDevice, st));
-            HIP_TRY(ctx, hipMemcpyAsync(ctx->sp_snap_beta.p, vp.beta, (size_t)n * sizeof(float4), hipMemcpyDeviceToDevice, st));
+        // ---- per iteration, in order: grid (:272-318), photon contributions (:366-391), _update_pixels! (:438-459) ----
+        for (uint32_t j = 0; j < nb; ++j) {
+            const VisiblePoints vp = vp_slice(j);
+            tm.begin(2, st);
+            HIP_TRY(ctx, hipMemsetAsync(counts, 0, (size_t)n * sizeof(uint32_t), st));
+            hipLaunchKernelGGL(k_sppm_grid_reset, dim3(1), blk, 0, st, grid);
+            hipLaunchKernelGGL(k_sppm_grid_bounds, g_pix, blk, 0, st, vp, (const float*)px.radius, n, grid);
+            hipLaunchKernelGGL(k_sppm_grid_setup, dim3(1), dim3(64), 0, st, grid);
+            hipLaunchKernelGGL(k_sppm_grid_build, g_pix, blk, 0, st, vp, (const float*)px.radius, n, n, grid, counts, (const uint32_t*)starts, entries, entry_cap, 0);
+            hipLaunchKernelGGL(k_sppm_scan, dim3(1), dim3(1024), 0, st, (const uint32_t*)counts, starts, n, grid);
+            hipLaunchKernelGGL(k_sppm_grid_build, g_pix, blk, 0, st, vp, (const float*)px.radius, n, n, grid, counts, (const uint32_t*)starts, entries, entry_cap, 1);
+            if (n_lights)
+                hipLaunchKernelGGL(k_sppm_deposit, dim3(grid_for(ctx, (uint64_t)P * ndep, 8)), blk, 0, st, scene->dev, rec, NP, j * (uint32_t)P, (uint32_t)P, (uint32_t)(max_depth - 1), vp, px, grid,
+                                   (const uint32_t*)starts, (const uint32_t*)entries, n);
+            tm.end(2, st);
+            if (it0 + j == n_iterations) {  // snapshot for trhip_sppm_state: the last iteration's M, ϕ and visible points
+                HIP_TRY(ctx, hipMemcpyAsync(ctx->sp_snap_M.p, px.M, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+                HIP_TRY(ctx, hipMemcpyAsync(ctx->sp_snap_phi.p, px.phi, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToDevice, st));
+                HIP_TRY(ctx, hipMemcpyAsync(ctx->sp_snap_p.p, vp.p_mat, (size_t)n * sizeof(float4), hipMemcpyDeviceToDevice, st));
+                HIP_TRY(ctx, hipMemcpyAsync(ctx->sp_snap_beta.p, vp.beta, (size_t)n * sizeof(float4), hipMemcpyDeviceToDevice, st));
+            }
+            tm.begin(2, st);
+            hipLaunchKernelGGL(k_sppm_update, g_pix, blk, 0, st, n, gamma, px, vp);
+            tm.end(2, st);
         }
-        // ---- _update_pixels! (:438-459) ----
-        tm.begin(2, st);
-        hipLaunchKernelGGL(k_sppm_update, g_pix, blk, 0, st, n, gamma, px, vp);
-        tm.end(2, st);
     }
     tm.begin(4, st);
     hipLaunchKernelGGL(k_sppm_image, g_pix, blk, 0, st, n, n_iterations, (uint64_t)P, px, (float4*)ctx->film.p);
@@ -1040,7 +1081,7 @@ int render_sppm_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
         stats->ms_shade = tm.total(2, &stats->launches_shade);
         stats->ms_trace_any = tm.total(3, &stats->launches_trace_any);
         stats->ms_film = tm.total(4, &stats->launches_film);
-        stats->n_batches = n_iterations;
+        stats->n_batches = n_batches;
         stats->max_depth_reached = (uint32_t)max_depth;
     }
     (void)hipEventDestroy(e0);
@@ -1113,7 +1154,8 @@ void trhip_shutdown(trhip_ctx* ctx) {
     release(ctx->occl);
     for (auto& b : ctx->sp_vp) release(b);
     for (DevBuf* b : {&ctx->sp_Ld, &ctx->sp_tau, &ctx->sp_radius, &ctx->sp_N, &ctx->sp_phi, &ctx->sp_M, &ctx->sp_counts, &ctx->sp_starts, &ctx->sp_entries, &ctx->sp_grid, &ctx->sp_ldist,
-                      &ctx->sp_snap_M, &ctx->sp_snap_phi, &ctx->sp_snap_p, &ctx->sp_snap_beta})
+                      &ctx->sp_snap_M, &ctx->sp_snap_phi, &ctx->sp_snap_p, &ctx->sp_snap_beta, &ctx->sp_terms, &ctx->sp_rec[0], &ctx->sp_rec[1], &ctx->sp_rec[2],
+                      &ctx->sp_rec_valid})
         release(*b);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
@@ -1129,6 +1171,8 @@ int trhip_set_option(trhip_ctx* ctx, const char* name, int64_t value) {
         ctx->timing = value != 0;
     else if (!std::strcmp(name, "debug_trace_budget"))
         ctx->debug_trace_budget = (uint32_t)value;
+    else if (!std::strcmp(name, "sppm_batch"))
+        ctx->sppm_batch = (uint64_t)std::max<int64_t>(0, value);
     else if (!std::strcmp(name, "tiny_scene_prims"))
         ctx->tiny_scene_prims = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(255, value));
     else if (!std::strcmp(name, "film_tiled"))

@@ -210,3 +210,76 @@ def camera_sample_grid(camera, spp: int = 1, seed: int = 0x5EED0001) -> np.ndarr
                       ts_uniform(key, 4)], axis=1)
         out.append(c)
     return np.concatenate(out, axis=0).astype(np.float32)
+
+
+# ---- S-caustic: docs/code/caustic_glass.jl with a procedural glass (the reference's PLY cannot travel) ------------------------------
+def goblet_mesh(n_theta: int = 256, n_profile: int = 172):
+    """A glass goblet as a surface of revolution (outer wall up to the rim, inner wall back down): ~2 * n_theta * n_profile
+    triangles with smooth vertex normals, inside the bounding box of docs/src/assets/models/caustic-glass.ply after its
+    translate (x 0.2..2.3, y 0..2, z -98.6..-96.5).  Returns (vertices (n, 3), 1-based indices, normals)."""
+    prof = np.array([[0.0, 0.0], [0.62, 0.0], [0.62, 0.05], [0.09, 0.13], [0.07, 0.85], [0.45, 1.05], [0.88, 1.55], [0.84, 2.0],   # outer, bottom to rim
+                     [0.79, 2.0], [0.83, 1.56], [0.42, 1.1], [0.0, 0.98]], dtype=np.float64)                                       # inner, rim to bottom
+    seg = np.sqrt(((prof[1:] - prof[:-1]) ** 2).sum(1))
+    s = np.concatenate([[0.0], np.cumsum(seg)])
+    t = np.linspace(0.0, s[-1], n_profile + 1)
+    r = np.interp(t, s, prof[:, 0])
+    y = np.interp(t, s, prof[:, 1])
+    r[0] = r[-1] = 0.0
+    th = np.arange(n_theta, dtype=np.float64) * (2.0 * np.pi / n_theta)
+    cx, cz = 1.27, -97.57
+    vx = cx + r[:, None] * np.cos(th)[None, :]
+    vz = cz + r[:, None] * np.sin(th)[None, :]
+    vy = 0.01 + np.repeat(y[:, None], n_theta, axis=1)
+    verts = np.stack([vx, vy, vz], axis=-1).reshape(-1, 3).astype(np.float32)
+    i, j = np.meshgrid(np.arange(n_profile), np.arange(n_theta), indexing="ij")
+    a = i * n_theta + j
+    b = i * n_theta + (j + 1) % n_theta
+    c = (i + 1) * n_theta + (j + 1) % n_theta
+    d = (i + 1) * n_theta + j
+    t1 = np.stack([a, d, c], axis=-1).reshape(-1, 3)
+    t2 = np.stack([a, c, b], axis=-1).reshape(-1, 3)
+    tris = np.concatenate([t1, t2], axis=0)
+    p = verts.astype(np.float64)
+    fn = np.cross(p[tris[:, 1]] - p[tris[:, 0]], p[tris[:, 2]] - p[tris[:, 0]])
+    keep = np.sqrt((fn ** 2).sum(1)) > 1e-12  # the rings on the axis collapse one triangle of every quad
+    tris, fn = tris[keep], fn[keep]
+    nrm = np.zeros_like(p)
+    for k in range(3):
+        np.add.at(nrm, tris[:, k], fn)
+    ln = np.sqrt((nrm ** 2).sum(1, keepdims=True))
+    nrm = np.where(ln > 0, nrm / np.maximum(ln, 1e-30), np.array([0.0, 1.0, 0.0]))
+    return verts, (tris + 1).astype(np.uint32).reshape(-1), nrm.astype(np.float32)
+
+
+def caustic_scene(model: str = "", n_theta: int = 256, n_profile: int = 172):
+    """docs/code/caustic_glass.jl:5-79: glass object on a plastic floor under a SpotLight.  ``model``: path of a PLY to load
+    with load_triangle_mesh (the reference's caustic-glass.ply); empty = the procedural goblet of the same size."""
+    glass = T.GlassMaterial(T.ConstantTexture(T.RGBSpectrum(1.0)), T.ConstantTexture(T.RGBSpectrum(1.0)), T.ConstantTexture(0.0), T.ConstantTexture(0.0),
+                            T.ConstantTexture(1.25), True)
+    plastic = T.PlasticMaterial(T.ConstantTexture(T.RGBSpectrum(0.6399999857, 0.6399999857, 0.6399999857)),
+                                T.ConstantTexture(T.RGBSpectrum(0.1000000015, 0.1000000015, 0.1000000015)), T.ConstantTexture(0.010408001), True)
+    prims = []
+    if model:
+        _, triangles = T.load_triangle_mesh(model, T.ShapeCore(T.translate([5, -1.49, -100]), False))
+        mesh = triangles[0].mesh
+        prims.append(T.create_mesh_primitives(T.ShapeCore(T.translate([0, 0, 0]), False), mesh.indices, mesh.vertices, mesh.normals, glass))
+    else:
+        verts, idx, nrm = goblet_mesh(n_theta, n_profile)
+        prims.append(T.create_mesh_primitives(T.ShapeCore(T.translate([0, 0, 0]), False), idx, verts, nrm, glass))
+    floor = T.create_triangle_mesh(T.ShapeCore(T.translate([-10, 0, -87]), False), 2, np.array([1, 2, 3, 1, 4, 3], dtype=np.uint32), 4,
+                                   [[0, 0, 0], [0, 0, -30], [30, 0, -30], [30, 0, 0]], [[0, 1, 0]] * 4)
+    prims += [T.GeometricPrimitive(t, plastic) for t in floor]
+    frm, to = np.float32([0, 2, 0]), np.float32([-5, 0, 5])
+    d = (to - frm) / np.float32(np.sqrt(np.float32(((to - frm) ** 2).sum())))
+    d, du, dv = T.coordinate_system(d)
+    m = np.eye(4, dtype=np.float32)
+    m[0, :3], m[1, :3], m[2, :3] = du, dv, d
+    light_to_world = T.translate([4.5, 0, -101]) * T.translate(frm) * T.inv(T.Transformation(m))
+    lights = [T.SpotLight(light_to_world, T.RGBSpectrum(60.0), 30.0, 20.0)]
+    return T.Scene(lights, T.BVHAccel(prims, 1))
+
+
+def caustic_camera(resolution: int = 1024, filename: str = ""):
+    """docs/code/caustic_glass.jl:81-100."""
+    film = T.Film([resolution, resolution], T.Bounds2(np.float32([0, 0]), np.float32([1, 1])), T.LanczosSincFilter([1.0, 1.0], 3.0), 1.0, 1.0, filename)
+    return T.PerspectiveCamera(T.look_at([0, 150, 150], [-3, 0, -91], [0, 1, 0]), T.Bounds2(np.float32([-1, -1]), np.float32([1, 1])), 0.0, 1.0, 0.0, 1e6, 90.0, film)
