@@ -1,15 +1,17 @@
 // th_sppm.h — SPPMIntegrator (integrators/sppm.jl, whole file) as wavefront passes on the device.
 //
-// One iteration = camera pass (visible points + direct light) -> hash grid of the visible points -> photon pass (deposit
-// ϕ, M with atomics, as the reference does with Threads.Atomic) -> pixel update (Float64, sppm.jl:438-459).
-//   * camera pass: one path per film pixel, level by level like k_shade_path, stopping at the first diffuse (or, at max
-//     depth, glossy) vertex (sppm.jl:208-266).  Direct light goes through the shadow queue WITHOUT β (A.12).  The sampler
-//     stream of iteration k is (seed, pixel, sample k-1).
-//   * grid (sppm.jl:278-318): the reference's linked lists per hash bucket become a counting sort: count per bucket,
-//     exclusive scan, fill.  A visible point registered in two cells that hash alike sits in the bucket twice, as in the
-//     reference, and is then credited twice by a photon landing there.
-//   * photons (sppm.jl:320-436): Halton dimensions by radical inverse (sampler/sampling.jl:43-60), one photon per queue
-//     entry; the emission weight β is never updated along the path (A.13).
+// The reference's iteration is camera pass -> grid of visible points -> photon pass (atomic ϕ, M) -> pixel update.  Here:
+//   * camera paths and photon paths do not depend on the pixel statistics, so a BATCH of iterations shares every traversal
+//     and shading launch (k_sppm_raygen / k_shade_sppm, k_photon_gen / k_shade_photon): B x the rays per launch instead of
+//     B x the launches.  Camera: one path per (iteration, pixel), stopping at the first diffuse (or, at max depth, glossy)
+//     vertex (sppm.jl:208-266); direct light goes through the shadow queue WITHOUT β (A.12) into per-depth term slots that
+//     k_sppm_fold_ld adds to Ld in the reference's order.  The sampler stream of iteration k is (seed, pixel, sample k-1).
+//     Photons: Halton dimensions by radical inverse (sampler/sampling.jl:43-60); the emission weight β is never updated
+//     along the path (A.13); every hit at depth >= 2 is recorded.
+//   * then per iteration, in order: grid bounds / resolution from the visible points and the current radii (:278-302), the
+//     iteration's photon hits counting-sorted by the hash of their cell, a per-pixel gather of ϕ and M over the buckets of
+//     the cells the visible point registers in (the same pairs the reference's bucket walk finds, k_sppm_gather), and the
+//     Float64 pixel update (:438-459).
 // M, radius, N, Ld and the visible points are bit-exact against the oracle; ϕ/τ are sums of the same terms in another order.
 #pragma once
 #include "th_kernels.h"
@@ -92,9 +94,11 @@ struct GridInfo {  // device-resident
     float bmin[3], bmax[3];
     int32_t res[3];
     uint32_t valid;
-    uint32_t overflow;  // entries did not fit
-    uint32_t total;     // grid entries
-    unsigned long long photon_hits;
+    uint32_t overflow;  // unused
+    uint32_t total;     // in-bounds photon hits of the last iteration
+    unsigned long long photon_hits;    // in-bounds photon hits, all iterations of the call
+    unsigned long long registrations;  // (visible point, cell) pairs = list nodes of the reference's grid, last iteration
+    uint32_t n_hot;                    // pixels deferred to k_sppm_gather_hot
 };
 TH_D uint32_t enc_f32(float f) {
     const uint32_t b = __float_as_uint(f);
@@ -299,7 +303,9 @@ __global__ __launch_bounds__(kBlock) void k_sppm_grid_reset(GridInfo* g) {
         }
         g->enc_max_radius = enc_f32(0.0f);
         g->valid = 0;
-        g->total = 0;  // overflow and photon_hits are per render call
+        g->total = 0;  // photon_hits is per render call
+        g->registrations = 0;
+        g->n_hot = 0;
     }
 }
 // grid_bounds = ∪ expand(Bounds3(vp.p), radius), max_radius (:285-292)
@@ -353,34 +359,74 @@ __global__ void k_sppm_grid_setup(GridInfo* g) {
     }
     g->valid = 1;
 }
-// pass = 0: count the entries of every bucket; pass = 1: fill (cursor[h] counts down from the bucket size)
-__global__ __launch_bounds__(kBlock) void k_sppm_grid_build(VisiblePoints vp, const float* __restrict__ radius, uint32_t n, uint32_t hash_size, GridInfo* gp, uint32_t* __restrict__ counts,
-                                                            const uint32_t* __restrict__ starts, uint32_t* __restrict__ entries, uint32_t capacity, int pass) {
+// The reference hangs every visible point into the hash buckets of the cells its sphere overlaps and lets each photon walk
+// the bucket of its own cell, adding to the pixels with atomics (:303-318, :366-391).  The same set of (registration, photon
+// hit) pairs — equal bucket, distance <= radius; a visible point registered in two cells that hash alike is credited twice,
+// as in the reference — is enumerated here from the other side: the photon hits of the iteration are counting-sorted by the
+// hash of their cell, and every pixel walks the buckets of the cells it would have registered in.  One thread owns a pixel:
+// ϕ and M are plain sums in registers, no atomics, no contention under a caustic.
+struct PhotonRecords;
+// pass = 0: count the in-bounds photon hits per bucket; pass = 1: fill (counts[h] counts down from the bucket size).
+// Record slots of one iteration: (d, first_photon + i), d < n_depths, i < n_photons.
+__global__ __launch_bounds__(kBlock) void k_sppm_hit_bin(const float4* __restrict__ rec_p, const uint8_t* __restrict__ rec_valid, uint32_t n_batch_photons, uint32_t first_photon,
+                                                         uint32_t n_photons, uint32_t n_depths, uint32_t hash_size, GridInfo* gp, uint32_t* __restrict__ counts,
+                                                         const uint32_t* __restrict__ starts, uint32_t* __restrict__ hit_slot, int pass) {
     const GridInfo& g = *gp;
     if (!g.valid) return;
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-        const float4 b = vp.beta[i];
-        if (b.x == 0.0f && b.y == 0.0f && b.z == 0.0f) continue;
-        const float4 p4 = vp.p_mat[i];
-        const float r = radius[i];
-        uint32_t lo[3], hi[3];
-        to_grid(g, mk3(p4.x - r, p4.y - r, p4.z - r), lo);
-        to_grid(g, mk3(p4.x + r, p4.y + r, p4.z + r), hi);
-        for (uint32_t z = lo[2]; z <= hi[2]; ++z)
-            for (uint32_t y = lo[1]; y <= hi[1]; ++y)
-                for (uint32_t x = lo[0]; x <= hi[0]; ++x) {
-                    const uint32_t h = grid_hash(x, y, z, hash_size);
-                    if (pass == 0) {
-                        atomicAdd(&counts[h], 1u);
-                    } else {
-                        const uint32_t k = atomicSub(&counts[h], 1u) - 1u;
-                        const uint32_t pos = starts[h] + k;
-                        if (pos < capacity)
-                            entries[pos] = i;
-                        else
-                            gp->overflow = 1u;
-                    }
-                }
+    const uint32_t total = n_photons * n_depths;
+    unsigned long long n_hits = 0;
+    for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < total; k += gridDim.x * kBlock) {
+        const uint32_t d = k / n_photons, i = k - d * n_photons;
+        const uint32_t r = d * n_batch_photons + first_photon + i;
+        if (!rec_valid[r]) continue;
+        const float4 hp = rec_p[r];
+        uint32_t gi[3];
+        if (!to_grid(g, mk3(hp.x, hp.y, hp.z), gi)) continue;  // `in_bounds` (:370-373)
+        const uint32_t h = grid_hash(gi[0], gi[1], gi[2], hash_size);
+        if (pass == 0) {
+            n_hits++;
+            atomicAdd(&counts[h], 1u);
+        } else {
+            hit_slot[starts[h] + atomicSub(&counts[h], 1u) - 1u] = r;
+        }
+    }
+    if (pass == 0) {
+        n_hits = wave_sum(n_hits);
+        if (lane_id() == 0 && n_hits) atomicAdd(&gp->photon_hits, n_hits);
+    }
+}
+// Exclusive prefix sums of the bucket sizes in three launches: tiles of kScanTile counts (local prefix + tile total), the
+// tile totals (k_sppm_scan, one block), then the tile offsets added back.
+constexpr uint32_t kScanTile = 1024;
+__global__ __launch_bounds__(kBlock) void k_sppm_scan_tiles(const uint32_t* __restrict__ counts, uint32_t* __restrict__ starts, uint32_t n, uint32_t* __restrict__ tile_sums) {
+    __shared__ uint32_t wsum[kBlock / 64];
+    const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * 4u;
+    uint32_t v[4];
+    for (int k = 0; k < 4; ++k) v[k] = base + k < n ? counts[base + k] : 0u;
+    const uint32_t mine = v[0] + v[1] + v[2] + v[3];
+    uint32_t incl = mine;  // inclusive scan across the wave
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t up = __shfl_up(incl, off);
+        if ((int)lane_id() >= off) incl += up;
+    }
+    const uint32_t w = threadIdx.x >> 6;
+    if (lane_id() == 63) wsum[w] = incl;
+    __syncthreads();
+    uint32_t before = 0;
+    for (uint32_t k = 0; k < w; ++k) before += wsum[k];
+    uint32_t acc = before + incl - mine;
+    for (int k = 0; k < 4; ++k) {
+        if (base + k < n) starts[base + k] = acc;
+        acc += v[k];
+    }
+    if (threadIdx.x == kBlock - 1) tile_sums[blockIdx.x] = acc;
+}
+__global__ __launch_bounds__(kBlock) void k_sppm_scan_add(uint32_t* __restrict__ starts, uint32_t n, const uint32_t* __restrict__ tile_offsets, uint32_t n_tiles) {
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i <= n; i += gridDim.x * kBlock) {
+        if (i == n)
+            starts[n] = tile_offsets[n_tiles];
+        else
+            starts[i] += tile_offsets[i / kScanTile];
     }
 }
 // starts[0..n] = exclusive prefix sums of counts[0..n-1]; one block of 1024 threads.
@@ -557,52 +603,120 @@ __global__ __launch_bounds__(kBlock) void k_shade_photon(DeviceScene sc, PathQue
     }
 }
 
-// `pixel.ϕ += β · f_vp(wo_vp, wi)`, `pixel.M += 1` for every visible point of the photon's grid cell within its radius
-// (sppm.jl:366-391), for the photon hits of ONE iteration: record slots (d, first_photon + i), d < n_depths, i < n_photons.
-__global__ __launch_bounds__(kBlock) void k_sppm_deposit(DeviceScene sc, PhotonRecords rec, uint32_t n_batch_photons, uint32_t first_photon, uint32_t n_photons, uint32_t n_depths,
-                                                         VisiblePoints vp, PixelStats px, GridInfo* gp, const uint32_t* __restrict__ starts, const uint32_t* __restrict__ entries,
-                                                         uint32_t hash_size) {
+// `pixel.ϕ += β · f_vp(wo_vp, wi)`, `pixel.M += 1` (sppm.jl:374-391) for one iteration, gathered per pixel: for every cell the
+// visible point registers in (:306-317) walk the bucket of photon hits with that hash and take those within the radius.
+// A caustic puts thousands of photons into the radius of a few thousand pixels (and a handful into the rest): pixels with
+// more than kHotCandidates candidates are deferred to k_sppm_gather_hot, where a whole wave shares one pixel's buckets.
+constexpr uint32_t kHotCandidates = 192;
+struct GatherSum {
+    f3 phi;
+    uint32_t M;
+};
+// Candidates e0 + first, e0 + first + stride, … of every bucket the visible point registers in.
+TH_D GatherSum gather_pixel(const DeviceScene& sc, const PhotonRecords& rec, const VisiblePoints& vp, uint32_t i, float4 p4, float rad, const uint32_t lo[3], const uint32_t hi[3],
+                            const uint32_t* __restrict__ starts, const uint32_t* __restrict__ hit_slot, uint32_t hash_size, uint32_t first, uint32_t stride) {
+    const f3 vpp = mk3(p4.x, p4.y, p4.z);
+    Shading vs;
+    bool have_frame = false;
+    GatherSum s{splat3(0.0f), 0u};
+    for (uint32_t z = lo[2]; z <= hi[2]; ++z)
+        for (uint32_t y = lo[1]; y <= hi[1]; ++y)
+            for (uint32_t x = lo[0]; x <= hi[0]; ++x) {
+                const uint32_t h = grid_hash(x, y, z, hash_size);
+                const uint32_t e0 = starts[h], e1 = starts[h + 1];
+                for (uint32_t e = e0 + first; e < e1; e += stride) {
+                    const uint32_t r = hit_slot[e];
+                    const float4 hp = rec.p[r];
+                    const f3 dv = vpp - mk3(hp.x, hp.y, hp.z);  // distance_squared(vp.p, p)
+                    if (dot(dv, dv) > rad * rad) continue;
+                    if (!have_frame) {
+                        const float4 wo4 = vp.wo[i], ng4 = vp.ng[i], ns4 = vp.ns[i], ss4 = vp.ss[i], ts4 = vp.ts[i];
+                        vs.p = vpp;
+                        vs.wo = mk3(wo4.x, wo4.y, wo4.z);
+                        vs.ng = mk3(ng4.x, ng4.y, ng4.z);
+                        vs.ns = mk3(ns4.x, ns4.y, ns4.z);
+                        vs.ss = mk3(ss4.x, ss4.y, ss4.z);
+                        vs.ts = mk3(ts4.x, ts4.y, ts4.z);
+                        have_frame = true;
+                    }
+                    const float4 w4 = rec.wi[r], b4 = rec.beta[r];
+                    const LobeSet& vb = sc.materials[__float_as_uint(p4.w)].set[1];
+                    s.phi = s.phi + mk3(b4.x, b4.y, b4.z) * bsdf_f(vb, vs, vs.wo, mk3(w4.x, w4.y, w4.z), BSDF_ALL);
+                    s.M++;
+                }
+            }
+    return s;
+}
+// One thread per pixel; also counts the registrations (the reference's list nodes) for trhip_sppm_state.
+__global__ __launch_bounds__(kBlock) void k_sppm_gather(DeviceScene sc, PhotonRecords rec, VisiblePoints vp, PixelStats px, uint32_t n, GridInfo* gp, const uint32_t* __restrict__ starts,
+                                                        const uint32_t* __restrict__ hit_slot, uint32_t hash_size, uint32_t* __restrict__ hot_list) {
     const GridInfo& g = *gp;
     if (!g.valid) return;
-    const uint32_t total = n_photons * n_depths;
-    unsigned long long n_hits = 0;
-    for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < total; k += gridDim.x * kBlock) {
-        const uint32_t d = k / n_photons, i = k - d * n_photons;
-        const size_t r = (size_t)d * n_batch_photons + first_photon + i;
-        if (!rec.valid[r]) continue;
-        const float4 hp = rec.p[r];
-        const f3 p = mk3(hp.x, hp.y, hp.z);
-        uint32_t gi[3];
-        if (!to_grid(g, p, gi)) continue;
-        n_hits++;
-        const float4 w4 = rec.wi[r], b4 = rec.beta[r];
-        const f3 wi_photon = mk3(w4.x, w4.y, w4.z), beta = mk3(b4.x, b4.y, b4.z);
-        const uint32_t h = grid_hash(gi[0], gi[1], gi[2], hash_size);
-        const uint32_t e0 = starts[h], e1 = starts[h + 1];
-        for (uint32_t e = e0; e < e1; ++e) {
-            const uint32_t pid = entries[e];
-            const float4 p4 = vp.p_mat[pid];
-            const float rad = px.radius[pid];
-            const f3 dv = mk3(p4.x, p4.y, p4.z) - p;  // distance_squared(vp.p, p)
-            if (dot(dv, dv) > rad * rad) continue;
-            Shading vs;
-            const float4 wo4 = vp.wo[pid], ng4 = vp.ng[pid], ns4 = vp.ns[pid], ss4 = vp.ss[pid], ts4 = vp.ts[pid];
-            vs.p = mk3(p4.x, p4.y, p4.z);
-            vs.wo = mk3(wo4.x, wo4.y, wo4.z);
-            vs.ng = mk3(ng4.x, ng4.y, ng4.z);
-            vs.ns = mk3(ns4.x, ns4.y, ns4.z);
-            vs.ss = mk3(ss4.x, ss4.y, ss4.z);
-            vs.ts = mk3(ts4.x, ts4.y, ts4.z);
-            const LobeSet& vb = sc.materials[__float_as_uint(p4.w)].set[1];
-            const f3 phi = beta * bsdf_f(vb, vs, vs.wo, wi_photon, BSDF_ALL);
-            atomicAdd(&px.phi[3 * pid + 0], phi.x);
-            atomicAdd(&px.phi[3 * pid + 1], phi.y);
-            atomicAdd(&px.phi[3 * pid + 2], phi.z);
-            atomicAdd(&px.M[pid], 1u);
+    unsigned long long n_reg = 0;
+    const uint32_t total = (n + 63u) & ~63u;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < total; i += gridDim.x * kBlock) {
+        bool hot = false;
+        if (i < n) {
+            const float4 b = vp.beta[i];
+            if (!(b.x == 0.0f && b.y == 0.0f && b.z == 0.0f)) {
+                const float4 p4 = vp.p_mat[i];
+                const float rad = px.radius[i];
+                uint32_t lo[3], hi[3];
+                to_grid(g, mk3(p4.x - rad, p4.y - rad, p4.z - rad), lo);
+                to_grid(g, mk3(p4.x + rad, p4.y + rad, p4.z + rad), hi);
+                uint32_t candidates = 0;
+                for (uint32_t z = lo[2]; z <= hi[2]; ++z)
+                    for (uint32_t y = lo[1]; y <= hi[1]; ++y)
+                        for (uint32_t x = lo[0]; x <= hi[0]; ++x) {
+                            n_reg++;
+                            const uint32_t h = grid_hash(x, y, z, hash_size);
+                            candidates += starts[h + 1] - starts[h];
+                        }
+                hot = candidates > kHotCandidates;
+                if (!hot && candidates) {
+                    const GatherSum s = gather_pixel(sc, rec, vp, i, p4, rad, lo, hi, starts, hit_slot, hash_size, 0u, 1u);
+                    if (s.M) {  // ϕ and M are zero between iterations (_update_pixels! clears them)
+                        px.phi[3 * i + 0] = s.phi.x;
+                        px.phi[3 * i + 1] = s.phi.y;
+                        px.phi[3 * i + 2] = s.phi.z;
+                        px.M[i] = s.M;
+                    }
+                }
+            }
+        }
+        const uint32_t k = wave_compact(hot, &gp->n_hot);
+        if (hot) hot_list[k] = i;
+    }
+    n_reg = wave_sum(n_reg);
+    if (lane_id() == 0 && n_reg) atomicAdd(&gp->registrations, n_reg);
+}
+// One wave per hot pixel: the lanes stride through each bucket, ϕ and M are reduced across the wave.
+__global__ __launch_bounds__(kBlock) void k_sppm_gather_hot(DeviceScene sc, PhotonRecords rec, VisiblePoints vp, PixelStats px, GridInfo* gp, const uint32_t* __restrict__ starts,
+                                                            const uint32_t* __restrict__ hit_slot, uint32_t hash_size, const uint32_t* __restrict__ hot_list) {
+    const GridInfo& g = *gp;
+    const uint32_t n_hot = g.n_hot;
+    const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6, n_waves = (gridDim.x * kBlock) >> 6;
+    for (uint32_t w = wave; w < n_hot; w += n_waves) {
+        const uint32_t i = hot_list[w];
+        const float4 p4 = vp.p_mat[i];
+        const float rad = px.radius[i];
+        uint32_t lo[3], hi[3];
+        to_grid(g, mk3(p4.x - rad, p4.y - rad, p4.z - rad), lo);
+        to_grid(g, mk3(p4.x + rad, p4.y + rad, p4.z + rad), hi);
+        GatherSum s = gather_pixel(sc, rec, vp, i, p4, rad, lo, hi, starts, hit_slot, hash_size, lane_id(), 64u);
+        for (int off = 32; off > 0; off >>= 1) {
+            s.phi.x += __shfl_down(s.phi.x, off);
+            s.phi.y += __shfl_down(s.phi.y, off);
+            s.phi.z += __shfl_down(s.phi.z, off);
+            s.M += __shfl_down(s.M, off);
+        }
+        if (lane_id() == 0 && s.M) {
+            px.phi[3 * i + 0] = s.phi.x;
+            px.phi[3 * i + 1] = s.phi.y;
+            px.phi[3 * i + 2] = s.phi.z;
+            px.M[i] = s.M;
         }
     }
-    n_hits = wave_sum(n_hits);
-    if (lane_id() == 0 && n_hits) atomicAdd(&gp->photon_hits, n_hits);
 }
 
 // pixel.Ld += every term of the batch in the reference's order: iterations ascending, inside an iteration by depth

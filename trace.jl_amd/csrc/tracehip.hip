@@ -888,7 +888,8 @@ int render_sppm_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
         B = std::min<uint64_t>(B, 32);
     }
     B = std::min<uint64_t>(B, n_iterations);
-    while (B > 1 && (B * Qit >= (1ull << 31) || B * (uint64_t)max_depth * n >= (1ull << 32) || B * (uint64_t)P >= (1ull << 31))) B = (B + 1) / 2;
+    while (B > 1 && (B * Qit >= (1ull << 31) || B * (uint64_t)max_depth * n >= (1ull << 32) || B * (uint64_t)P * ndep >= (1ull << 32))) B = (B + 1) / 2;
+    if ((uint64_t)P * ndep >= (1ull << 32)) return fail(ctx, TRHIP_ERR_UNSUPPORTED, "SPPM: photons_per_iteration x (max_depth - 1) must stay below 2^32");
     const uint64_t Q = B * Qit;
     const uint32_t cap = (uint32_t)(((Q + kSeg - 1) / kSeg + 2 * kSegGran + kSegGran - 1) / kSegGran * kSegGran);
     const uint64_t Pphys = (uint64_t)cap * kSeg;
@@ -917,7 +918,7 @@ int render_sppm_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
     for (auto& b : ctx->sp_rec)
         if (int rc = ensure(ctx, b, n_rec * sizeof(float4))) return rc;
     if (int rc = ensure(ctx, ctx->sp_rec_valid, n_rec)) return rc;
-    const uint32_t entry_cap = 32u * n;  // a visible point spans at most 3 cells per axis (cell side >= max radius)
+    const size_t entry_cap = (size_t)P * ndep;  // photon hits of one iteration, sorted by bucket
     if (int rc = ensure(ctx, ctx->sp_Ld, (size_t)n * sizeof(float4))) return rc;
     if (int rc = ensure(ctx, ctx->sp_tau, (size_t)n * sizeof(float4))) return rc;
     if (int rc = ensure(ctx, ctx->sp_radius, (size_t)n * sizeof(float))) return rc;
@@ -956,6 +957,13 @@ int render_sppm_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
     uint32_t* counts = (uint32_t*)ctx->sp_counts.p;
     uint32_t* starts = (uint32_t*)ctx->sp_starts.p;
     uint32_t* entries = (uint32_t*)ctx->sp_entries.p;
+    const uint32_t n_tiles = (n + kScanTile - 1) / kScanTile;
+    if (int rc = ensure(ctx, ctx->scratch[0], (size_t)n_tiles * sizeof(uint32_t))) return rc;
+    if (int rc = ensure(ctx, ctx->scratch[1], ((size_t)n_tiles + 1) * sizeof(uint32_t))) return rc;
+    uint32_t* tile_sums = (uint32_t*)ctx->scratch[0].p;
+    uint32_t* tile_offsets = (uint32_t*)ctx->scratch[1].p;
+    if (int rc = ensure(ctx, ctx->scratch[2], (size_t)n * sizeof(uint32_t))) return rc;
+    uint32_t* hot_list = (uint32_t*)ctx->scratch[2].p;
 
     Timer tm(ctx, ctx->timing && stats);
     hipEvent_t e0, e1;
@@ -1033,14 +1041,20 @@ int render_sppm_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
             tm.begin(2, st);
             HIP_TRY(ctx, hipMemsetAsync(counts, 0, (size_t)n * sizeof(uint32_t), st));
             hipLaunchKernelGGL(k_sppm_grid_reset, dim3(1), blk, 0, st, grid);
-            hipLaunchKernelGGL(k_sppm_grid_bounds, g_pix, blk, 0, st, vp, (const float*)px.radius, n, grid);
+            hipLaunchKernelGGL(k_sppm_grid_bounds, dim3(ctx->num_cu), blk, 0, st, vp, (const float*)px.radius, n, grid);  // few waves: 7 same-address atomics each
             hipLaunchKernelGGL(k_sppm_grid_setup, dim3(1), dim3(64), 0, st, grid);
-            hipLaunchKernelGGL(k_sppm_grid_build, g_pix, blk, 0, st, vp, (const float*)px.radius, n, n, grid, counts, (const uint32_t*)starts, entries, entry_cap, 0);
-            hipLaunchKernelGGL(k_sppm_scan, dim3(1), dim3(1024), 0, st, (const uint32_t*)counts, starts, n, grid);
-            hipLaunchKernelGGL(k_sppm_grid_build, g_pix, blk, 0, st, vp, (const float*)px.radius, n, n, grid, counts, (const uint32_t*)starts, entries, entry_cap, 1);
+            const dim3 g_rec(grid_for(ctx, (uint64_t)P * ndep, 8));
             if (n_lights)
-                hipLaunchKernelGGL(k_sppm_deposit, dim3(grid_for(ctx, (uint64_t)P * ndep, 8)), blk, 0, st, scene->dev, rec, NP, j * (uint32_t)P, (uint32_t)P, (uint32_t)(max_depth - 1), vp, px, grid,
-                                   (const uint32_t*)starts, (const uint32_t*)entries, n);
+                hipLaunchKernelGGL(k_sppm_hit_bin, g_rec, blk, 0, st, (const float4*)rec.p, (const uint8_t*)rec.valid, NP, j * (uint32_t)P, (uint32_t)P, (uint32_t)(max_depth - 1), n, grid, counts,
+                                   (const uint32_t*)starts, entries, 0);
+            hipLaunchKernelGGL(k_sppm_scan_tiles, dim3(n_tiles), blk, 0, st, (const uint32_t*)counts, starts, n, tile_sums);
+            hipLaunchKernelGGL(k_sppm_scan, dim3(1), dim3(1024), 0, st, (const uint32_t*)tile_sums, tile_offsets, n_tiles, grid);
+            hipLaunchKernelGGL(k_sppm_scan_add, g_pix, blk, 0, st, starts, n, (const uint32_t*)tile_offsets, n_tiles);
+            if (n_lights)
+                hipLaunchKernelGGL(k_sppm_hit_bin, g_rec, blk, 0, st, (const float4*)rec.p, (const uint8_t*)rec.valid, NP, j * (uint32_t)P, (uint32_t)P, (uint32_t)(max_depth - 1), n, grid, counts,
+                                   (const uint32_t*)starts, entries, 1);
+            hipLaunchKernelGGL(k_sppm_gather, g_pix, blk, 0, st, scene->dev, rec, vp, px, n, grid, (const uint32_t*)starts, (const uint32_t*)entries, n, hot_list);
+            hipLaunchKernelGGL(k_sppm_gather_hot, g_shade, blk, 0, st, scene->dev, rec, vp, px, grid, (const uint32_t*)starts, (const uint32_t*)entries, n, (const uint32_t*)hot_list);
             tm.end(2, st);
             if (it0 + j == n_iterations) {  // snapshot for trhip_sppm_state: the last iteration's M, ϕ and visible points
                 HIP_TRY(ctx, hipMemcpyAsync(ctx->sp_snap_M.p, px.M, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
@@ -1086,7 +1100,6 @@ int render_sppm_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
-    if (gi.overflow) return fail(ctx, TRHIP_ERR_UNSUPPORTED, "SPPM grid outgrew its entry buffer (%u entries)", gi.total);
     return 0;
 }
 
@@ -1420,7 +1433,7 @@ int trhip_sppm_state(trhip_ctx* ctx, float* Ld3, float* tau3, float* radius, dou
         GridInfo gi;
         HIP_TRY(ctx, hipMemcpy(&gi, ctx->sp_grid.p, sizeof gi, hipMemcpyDeviceToHost));
         info6[0] = gi.res[0], info6[1] = gi.res[1], info6[2] = gi.res[2];
-        info6[3] = gi.total;
+        info6[3] = (int64_t)gi.registrations;
         info6[4] = (int64_t)gi.photon_hits;
         info6[5] = ctx->sp_photons;
     }
