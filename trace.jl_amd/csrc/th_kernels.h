@@ -374,7 +374,7 @@ TH_D bool rebuild_shading(const DeviceScene& sc, int prim, f3 o, f3 d, Shading& 
 // One PathIntegrator vertex (DESIGN.md "PathIntegrator"; sppm.jl:208-266 without the visible-point early-out, β on the
 // direct term, RR as :257-263; uniform_sample_one_light / estimate_direct sppm.jl:503-554).
 #ifndef TH_SHADE_WAVES
-#define TH_SHADE_WAVES 2  // waves per SIMD the register allocator must leave room for (2 = what 175 VGPRs allow)
+#define TH_SHADE_WAVES 4  // waves per SIMD the register allocator must leave room for: 128 VGPRs + 136 B scratch instead of 175 VGPRs at 2 waves; measured 37.0 -> 32.2 ms (S-cornell, 64 spp)
 #endif
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TH_SHADE_WAVES))) void k_shade_path(DeviceScene sc, const DeviceSensor* __restrict__ sep, PathQueue qin, PathQueue qout, ShadowQueue sq, uint32_t cap,
                                                        const float4* __restrict__ hits, float4* __restrict__ L, Counters* ctr, int depth, int max_depth, uint64_t seed,
