@@ -25,6 +25,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 def build_workload(T, name: str, res: int):
     if name == "cornell":
         return T.scenes.cornell_scene(), T.scenes.cornell_camera(res), "S-cornell: 2 spheres + 10 triangles, PointLight"
+    if name == "cornell_walls":  # profiling aid: one material, one shape kind
+        return T.scenes.cornell_scene(False), T.scenes.cornell_camera(res), "S-cornell without the spheres: 10 matte triangles, PointLight"
     if name == "shadows":
         return T.scenes.shadows_scene(), T.scenes.shadows_camera(res), "docs/src/shadows.md scene: 4 spheres + 4 triangles, PointLight"
     if name in T.scenes.MESH_N:

@@ -108,6 +108,22 @@ TM_HD double tm_cos(double x) {
     }
 }
 TM_HD double tm_tan(double x) { return tm_sin(x) / tm_cos(x); }
+/* sin and cos of the same argument: one reduction, each kernel once, the quadrant applied by selection.  The values are
+ * those of tm_sin(x) and tm_cos(x) bit for bit (negation is exact); on a GPU the lanes of a wave no longer serialise over
+ * the four quadrant cases of two switches. */
+TM_HD void tm_sincos(double x, double* s_out, double* c_out) {
+    if (!(x == x) || x - x != 0.0) {
+        *s_out = *c_out = x - x;
+        return;
+    }
+    long long k;
+    const double r = tm_rem_pio2(x, &k);
+    const double sk = tm_sin_kernel(r), ck = tm_cos_kernel(r);
+    const int q = (int)(k & 3);
+    const double s = (q & 1) ? ck : sk, c = (q & 1) ? sk : ck;
+    *s_out = (q & 2) ? -s : s;
+    *c_out = (q == 1 || q == 2) ? -c : c;
+}
 
 /* atan for t >= 0. */
 TM_HD double tm_atan_pos(double t) {
@@ -210,6 +226,12 @@ TM_HD double tm_log(double x) {
 /* Float32 front ends: one rounding from the Float64 kernel. */
 TM_HD float tm_sinf(float x) { return (float)tm_sin((double)x); }
 TM_HD float tm_cosf(float x) { return (float)tm_cos((double)x); }
+TM_HD void tm_sincosf(float x, float* s_out, float* c_out) { /* == tm_sinf(x), tm_cosf(x) */
+    double s, c;
+    tm_sincos((double)x, &s, &c);
+    *s_out = (float)s;
+    *c_out = (float)c;
+}
 TM_HD float tm_tanf(float x) { return (float)tm_tan((double)x); }
 TM_HD float tm_atanf(float x) { return (float)tm_atan((double)x); }
 TM_HD float tm_atan2f(float y, float x) { return (float)tm_atan2((double)y, (double)x); }

@@ -218,7 +218,8 @@ int trhip_film_accumulate(trhip_ctx* ctx, const trhip_sensor* sensor, uint32_t s
 int trhip_set_option(trhip_ctx* ctx, const char* name, int64_t value);
 
 /* The deterministic elementary functions of trace_detmath.h for hosts that cannot include a C header
- * (fn: 0 sin, 1 cos, 2 tan, 3 atan2(y, x), 4 acos, 5 log); y may be NULL unless fn == 3.  Needs no GPU. */
+ * (fn: 0 sin, 1 cos, 2 tan, 3 atan2(y, x), 4 acos, 5 log, 6 / 7 the sin / cos part of tm_sincosf); y may be NULL unless
+ * fn == 3.  Needs no GPU. */
 int trhip_detmath_f32(int fn, const float* x, const float* y, uint64_t n, float* out);
 
 #ifdef __cplusplus

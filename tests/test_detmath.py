@@ -85,3 +85,17 @@ def test_sampler_matches_numpy_model_and_is_uniform(T, ob):
     assert abs(u0.mean() - 0.5) < 0.005 and abs(u0.var() - 1 / 12) < 0.002
     assert abs(np.corrcoef(u0, u1)[0, 1]) < 0.01
     assert abs(np.corrcoef(u0[:-1], u0[1:])[0, 1]) < 0.01
+
+
+def test_sincos_equals_separate_calls(T):
+    """tm_sincosf (one reduction, both kernels, quadrant by selection) returns tm_sinf / tm_cosf bit for bit, signed zeros,
+    quadrant boundaries and non-finite arguments included."""
+    rng = np.random.default_rng(7)
+    x = np.concatenate([rng.uniform(-40, 40, 400000), rng.uniform(-1e3, 1e3, 100000), np.arange(-64, 65) * (np.pi / 4),
+                        [0.0, -0.0, 1e-30, -1e-30, np.inf, -np.inf, np.nan, 3.1415927, 1.5707964, 6.2831855]]).astype(np.float32)
+    s, c = T._ffi.detmath(0, x), T._ffi.detmath(1, x)
+    s2, c2 = T._ffi.detmath(6, x), T._ffi.detmath(7, x)
+    fin = np.isfinite(x)
+    assert np.array_equal(s[fin].view(np.uint32), s2[fin].view(np.uint32))
+    assert np.array_equal(c[fin].view(np.uint32), c2[fin].view(np.uint32))
+    assert np.isnan(s2[~fin]).all() and np.isnan(c2[~fin]).all()

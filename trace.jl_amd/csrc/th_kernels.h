@@ -34,12 +34,14 @@ constexpr int kMaxDepth = 62;
 // run time of the shading kernel; 32 words on different L2 channels are not a bottleneck.
 constexpr int kSeg = 32;
 constexpr uint32_t kSegGran = 256;  // a segment's share of the flat work space is padded to a multiple of this
+constexpr uint32_t kCtrStride = 32;  // words between the counters of neighbouring segments: one 128-byte line each, so that the
+                                     // atomics of different segments go to different L2 channels instead of queueing on one line
 struct Counters {  // device-resident
-    // per wavefront batch (zeroed by one memset at batch start): first index = path depth - 1
-    uint32_t n_queue[kMaxDepth + 2][kSeg];       // live paths entering that depth, per segment
-    uint32_t n_shadow[kMaxDepth + 2][kSeg];      // shadow rays emitted at that depth
-    uint32_t work_closest[kMaxDepth + 2][kSeg];  // k_trace2 dynamic ray-fetch cursors
-    uint32_t work_shadow[kMaxDepth + 2][kSeg];
+    // per wavefront batch (zeroed by one memset at batch start): first index = path depth - 1, second = segment * kCtrStride
+    uint32_t n_queue[kMaxDepth + 2][kSeg * kCtrStride];       // live paths entering that depth, per segment
+    uint32_t n_shadow[kMaxDepth + 2][kSeg * kCtrStride];      // shadow rays emitted at that depth
+    uint32_t work_closest[kMaxDepth + 2][kSeg * kCtrStride];  // k_trace2 dynamic ray-fetch cursors
+    uint32_t work_shadow[kMaxDepth + 2][kSeg * kCtrStride];
     // per render call
     unsigned long long closest_total, shadow_total, nodes_closest, prims_closest, nodes_shadow, prims_shadow;
 };
@@ -56,7 +58,7 @@ struct SegView {  // per-block copy in LDS
 };
 // Block-wide: load the counts and build the padded prefix.  Contains a barrier.
 TH_D void seg_load(const SegQueue& q, SegView& v) {
-    if (threadIdx.x < kSeg) v.count[threadIdx.x] = q.counts ? min(q.counts[threadIdx.x], q.cap) : (threadIdx.x == 0 ? q.n_dense : 0u);
+    if (threadIdx.x < kSeg) v.count[threadIdx.x] = q.counts ? min(q.counts[threadIdx.x * kCtrStride], q.cap) : (threadIdx.x == 0 ? q.n_dense : 0u);
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t acc = 0;
@@ -93,6 +95,22 @@ TH_D uint32_t wave_compact(bool alive, uint32_t* counter) {
     if (n && (int)lane == leader) base = atomicAdd(counter, n);
     base = __shfl(base, leader < 0 ? 0 : leader);
     return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
+// Two compactions at once: both returning atomics are in flight before either result is needed (one L2 round trip, not two).
+TH_D void wave_compact2(bool alive_a, uint32_t* counter_a, bool alive_b, uint32_t* counter_b, uint32_t& idx_a, uint32_t& idx_b) {
+    const unsigned long long ma = __ballot(alive_a), mb = __ballot(alive_b);
+    const uint32_t na = (uint32_t)__popcll(ma), nb = (uint32_t)__popcll(mb);
+    const uint32_t lane = lane_id();
+    uint32_t base_a = 0, base_b = 0;
+    if (lane == 0) {  // ballots are wave-wide: lane 0 of every wave in the loop is active
+        if (na) base_a = atomicAdd(counter_a, na);
+        if (nb) base_b = atomicAdd(counter_b, nb);
+    }
+    base_a = __shfl(base_a, 0);
+    base_b = __shfl(base_b, 0);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    idx_a = base_a + (uint32_t)__popcll(ma & below);
+    idx_b = base_b + (uint32_t)__popcll(mb & below);
 }
 TH_D unsigned long long wave_sum(unsigned long long v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
@@ -152,14 +170,14 @@ __global__ __launch_bounds__(kBlock) void k_raygen(const DeviceSensor* __restric
         const uint32_t w = i >> 6;
         const uint32_t phys = (w % kSeg) * cap + (w / kSeg) * 64u + (i & 63u);
         q.o[phys] = make_float4(o.x, o.y, o.z, __uint_as_float(slot));
-        q.d[phys] = make_float4(d.x, d.y, d.z, 0.0f);
-        q.beta[phys] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+        q.d[phys] = make_float4(d.x, d.y, d.z, __uint_as_float((uint32_t)key));  // the stream key travels with the path (k_shade_path)
+        q.beta[phys] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float((uint32_t)(key >> 32)));
     }
     if (blockIdx.x == 0 && threadIdx.x < kSeg) {
         const uint32_t sgm = threadIdx.x, W = (n + 63u) >> 6;
         uint32_t cnt = ((W + kSeg - 1 - sgm) / kSeg) * 64u;
         if (W > 0 && (W - 1) % kSeg == sgm && (n & 63u)) cnt -= 64u - (n & 63u);
-        ctr->n_queue[0][sgm] = cnt;
+        ctr->n_queue[0][sgm * kCtrStride] = cnt;
     }
 }
 
@@ -350,7 +368,9 @@ __global__ __launch_bounds__(kBlock) void k_trace_any(DeviceScene sc, SegQueue q
 // ---- shading ---------------------------------------------------------------------------------------------------------------------
 // Rebuild the SurfaceInteraction of a closest hit from the one hit primitive (re-running its intersection with
 // t_max = Inf reproduces the accepted candidate's barycentrics / hit point bit-for-bit: they do not depend on t_max).
-TH_D bool rebuild_shading(const DeviceScene& sc, int prim, f3 o, f3 d, Shading& sh, uint32_t& material) {
+// With `bary` (hits written with TraceOut::bary_mode: {b2, prim, b0, b1}) the triangle test is not repeated: the stored
+// barycentrics ARE the accepted candidate's.
+TH_D bool rebuild_shading(const DeviceScene& sc, int prim, f3 o, f3 d, Shading& sh, uint32_t& material, const float4* bary = nullptr) {
     // all six 16-byte loads are issued up front (independent of the sphere / normals flags) so that their latencies overlap
     const float4 p0 = sc.prims[3 * prim], p1 = sc.prims[3 * prim + 1], p2 = sc.prims[3 * prim + 2];
     const float4 na = sc.tri_nrm[3 * prim], nb = sc.tri_nrm[3 * prim + 1], nc = sc.tri_nrm[3 * prim + 2];
@@ -365,7 +385,10 @@ TH_D bool rebuild_shading(const DeviceScene& sc, int prim, f3 o, f3 d, Shading& 
     }
     const f3 v0 = mk3(p0.x, p0.y, p0.z), v1 = mk3(p1.x, p1.y, p1.z), v2 = mk3(p2.x, p2.y, p2.z);
     TriTest tt;
-    if (!tri_intersect<true>(v0, v1, v2, o, d, kInf, &tt)) return false;
+    if (bary)
+        tt.bary = mk3(bary->z, bary->w, bary->x);
+    else if (!tri_intersect<true>(v0, v1, v2, o, d, kInf, &tt))
+        return false;
     const bool has_n = (meta & PRIM_HAS_NORMALS) != 0;
     sh = shade_triangle(v0, v1, v2, has_n, mk3(na.x, na.y, na.z), mk3(nb.x, nb.y, nb.z), mk3(nc.x, nc.y, nc.z), (meta & PRIM_FLIP) != 0, tt.bary, d);
     return true;
@@ -377,12 +400,29 @@ TH_D bool rebuild_shading(const DeviceScene& sc, int prim, f3 o, f3 d, Shading& 
 #define TH_SHADE_WAVES 4  // waves per SIMD the register allocator must leave room for: 128 VGPRs + 136 B scratch instead of 175 VGPRs at 2 waves; measured 37.0 -> 32.2 ms (S-cornell, 64 spp)
 #endif
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TH_SHADE_WAVES))) void k_shade_path(DeviceScene sc, const DeviceSensor* __restrict__ sep, PathQueue qin, PathQueue qout, ShadowQueue sq, uint32_t cap,
-                                                       const float4* __restrict__ hits, float4* __restrict__ L, Counters* ctr, int depth, int max_depth, uint64_t seed,
-                                                       uint32_t sample_offset) {
-    const DeviceSensor& se = *sep;
+                                                       const float4* __restrict__ hits, float4* __restrict__ L, Counters* ctr, int depth, int max_depth, uint32_t hits_have_bary) {
     __shared__ SegView sv;
+    // The kernel is a chain of dependent memory round trips (28 us per wave-iteration at 4 waves/SIMD, VALU 15 % busy): the
+    // material and light tables, reached through two of those trips, are staged in LDS when they are small.
+    __shared__ __attribute__((aligned(16))) uint32_t s_tab[(kLdsMaterials * sizeof(MaterialRec) + kLdsLights * sizeof(LightRec)) / 4];
+#ifndef TH_SHADE_LDS_TABLES
+#define TH_SHADE_LDS_TABLES 0  // measured SLOWER (35.4 vs 32.3 ms): flat loads + 40 B more scratch; kept for reference
+#endif
+#ifndef TH_SHADE_COMPACT2
+#define TH_SHADE_COMPACT2 1
+#endif
+    const bool staged = TH_SHADE_LDS_TABLES && sc.n_materials <= (uint32_t)kLdsMaterials && sc.n_lights <= (uint32_t)kLdsLights;
+    if (staged) {
+        const uint32_t nm = sc.n_materials * (uint32_t)(sizeof(MaterialRec) / 4), nl = sc.n_lights * (uint32_t)(sizeof(LightRec) / 4);
+        const uint32_t* gm = (const uint32_t*)sc.materials;
+        const uint32_t* gl = (const uint32_t*)sc.lights;
+        for (uint32_t k = threadIdx.x; k < nm; k += kBlock) s_tab[k] = gm[k];
+        for (uint32_t k = threadIdx.x; k < nl; k += kBlock) s_tab[kLdsMaterials * (sizeof(MaterialRec) / 4) + k] = gl[k];
+    }
+    const MaterialRec* materials = staged ? (const MaterialRec*)s_tab : sc.materials;
+    const LightRec* lights = staged ? (const LightRec*)(s_tab + kLdsMaterials * (sizeof(MaterialRec) / 4)) : sc.lights;
     const SegQueue qv{ctr->n_queue[depth - 1], cap, 0u};
-    seg_load(qv, sv);
+    seg_load(qv, sv);  // contains the barrier that publishes s_tab
     const uint32_t total = sv.prefix[kSeg];  // multiple of kSegGran: whole waves stay in the loop, so ballots see every lane
     for (uint32_t flat = blockIdx.x * kBlock + threadIdx.x; flat < total; flat += gridDim.x * kBlock) {
         uint32_t seg_in, lb;
@@ -403,10 +443,17 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TH_SHADE
                 f3 beta = mk3(b4.x, b4.y, b4.z);
                 Shading sh;
                 uint32_t material;
-                if (rebuild_shading(sc, prim, o, d, sh, material) && material != PRIM_NO_MATERIAL) {
-                    const LobeSet& bsdf = sc.materials[material].set[1];  // compute_scattering!(si, ray, true)
-                    const SlotInfo sl = slot_info(se, slot);
-                    const uint64_t key = ts_stream_key(seed, sl.px, sl.py, sample_offset + sl.sample);
+#ifdef TH_SHADE_DIAG_MEMORY_ONLY  // DIAGNOSTIC (wrong results): the kernel's memory traffic without its arithmetic
+                if (true) {
+                    so4 = o4, sd4 = d4, sc4 = b4, no4 = make_float4(o4.x + h4.x, o4.y, o4.z, o4.w), nd4 = d4, nb4 = b4;
+                    want_shadow = (prim & 1) == 0;
+                    want_next = depth < max_depth && (prim & 7) != 0;
+                } else
+#endif
+                if (rebuild_shading(sc, prim, o, d, sh, material, hits_have_bary ? &h4 : nullptr) && material != PRIM_NO_MATERIAL) {
+                    const LobeSet& bsdf = materials[material].set[1];  // compute_scattering!(si, ray, true)
+                    // the sampler stream key of this camera sample rides in the queue (k_raygen): no slot -> pixel division, no re-hash
+                    const uint64_t key = ((uint64_t)__float_as_uint(b4.w) << 32) | (uint64_t)__float_as_uint(d4.w);
                     const uint32_t v = (uint32_t)(depth - 1);
                     const f3 wo = -d;  // sppm.jl:224
                     const uint32_t poison = ((isnan_(beta.x) || isinf_(beta.x)) ? 1u : 0u) | ((isnan_(beta.y) || isinf_(beta.y)) ? 2u : 0u) |
@@ -419,12 +466,15 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TH_SHADE
                         if (ln > nl) ln = nl;
                         if (ln < 1) ln = 1;
                         const float light_pdf = 1.0f / (float)nl;
-                        const LightRec& light = sc.lights[ln - 1];
+                        const LightRec& light = lights[ln - 1];
                         const LightSample ls = sample_li(light, sh.p);
                         if (ls.pdf > 0.0f && !is_black(ls.radiance)) {
                             const f3 f = bsdf_f(bsdf, sh, sh.wo, ls.wi, BSDF_ALL & ~BSDF_SPECULAR) * fabs_(dot(ls.wi, sh.ns));
                             if (!is_black(f)) {
-                                const f3 Ld = (splat3(0.0f) + f * ls.radiance / ls.pdf) / light_pdf;
+                                // x / 1 == x exactly: δ-lights have pdf 1, a single light has light_pdf 1 (6 correctly rounded divisions saved)
+                                const f3 fl = f * ls.radiance;
+                                const f3 Ld1 = splat3(0.0f) + (ls.pdf == 1.0f ? fl : fl / ls.pdf);
+                                const f3 Ld = light_pdf == 1.0f ? Ld1 : Ld1 / light_pdf;
                                 const f3 c = beta * Ld;
                                 const f3 lp = mk3(light.position[0], light.position[1], light.position[2]);
                                 const f3 dir = lp - sh.p;                       // spawn_ray(p0, p1) Trace.jl:196-202
@@ -465,8 +515,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TH_SHADE
                                 const f3 org = sh.p + 1e-6f * bs.wi;  // spawn_ray(si, wi) Trace.jl:206-211
                                 const f3 nd = check_direction(bs.wi);
                                 no4 = make_float4(org.x, org.y, org.z, __uint_as_float(slot));
-                                nd4 = make_float4(nd.x, nd.y, nd.z, 0.0f);
-                                nb4 = make_float4(beta.x, beta.y, beta.z, 0.0f);
+                                nd4 = make_float4(nd.x, nd.y, nd.z, d4.w);
+                                nb4 = make_float4(beta.x, beta.y, beta.z, b4.w);
                                 want_next = true;
                             }
                         }
@@ -474,13 +524,20 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TH_SHADE
                 }
             }
         }
-        const uint32_t si = seg_out * cap + wave_compact(want_shadow, &ctr->n_shadow[depth - 1][seg_out]);
+        uint32_t si, ni;
+#if TH_SHADE_COMPACT2
+        wave_compact2(want_shadow, &ctr->n_shadow[depth - 1][seg_out * kCtrStride], want_next, &ctr->n_queue[depth][seg_out * kCtrStride], si, ni);
+#else
+        si = wave_compact(want_shadow, &ctr->n_shadow[depth - 1][seg_out * kCtrStride]);
+        ni = wave_compact(want_next, &ctr->n_queue[depth][seg_out * kCtrStride]);
+#endif
+        si += seg_out * cap;
+        ni += seg_out * cap;
         if (want_shadow) {
             sq.o[si] = so4;
             sq.d[si] = sd4;
             sq.c[si] = sc4;
         }
-        const uint32_t ni = seg_out * cap + wave_compact(want_next, &ctr->n_queue[depth][seg_out]);
         if (want_next) {
             qout.o[ni] = no4;
             qout.d[ni] = nd4;

@@ -155,7 +155,7 @@ __global__ __launch_bounds__(kBlock) void k_sppm_raygen(const DeviceSensor* __re
         const uint32_t sgm = threadIdx.x, W = (n + 63u) >> 6;
         uint32_t cnt = ((W + kSeg - 1 - sgm) / kSeg) * 64u;
         if (W > 0 && (W - 1) % kSeg == sgm && (n & 63u)) cnt -= 64u - (n & 63u);
-        ctr->n_queue[0][sgm] = cnt;
+        ctr->n_queue[0][sgm * kCtrStride] = cnt;
     }
 }
 
@@ -271,13 +271,13 @@ __global__ __launch_bounds__(kBlock) void k_shade_sppm(DeviceScene sc, PathQueue
                 }
             }
         }
-        const uint32_t si = seg_out * cap + wave_compact(want_shadow, &ctr->n_shadow[depth - 1][seg_out]);
+        const uint32_t si = seg_out * cap + wave_compact(want_shadow, &ctr->n_shadow[depth - 1][seg_out * kCtrStride]);
         if (want_shadow) {
             sq.o[si] = so4;
             sq.d[si] = sd4;
             sq.c[si] = sc4;
         }
-        const uint32_t ni = seg_out * cap + wave_compact(want_next, &ctr->n_queue[depth][seg_out]);
+        const uint32_t ni = seg_out * cap + wave_compact(want_next, &ctr->n_queue[depth][seg_out * kCtrStride]);
         if (want_next) {
             qout.o[ni] = no4;
             qout.d[ni] = nd4;
@@ -518,7 +518,7 @@ __global__ __launch_bounds__(kBlock) void k_photon_gen(DeviceScene sc, LightDist
             }
         }
         const uint32_t seg_out = (i >> 6) % kSeg;
-        const uint32_t k = seg_out * cap + wave_compact(want, &ctr->n_queue[0][seg_out]);
+        const uint32_t k = seg_out * cap + wave_compact(want, &ctr->n_queue[0][seg_out * kCtrStride]);
         if (want) {
             q.o[k] = o4;
             q.d[k] = d4;
@@ -594,7 +594,7 @@ __global__ __launch_bounds__(kBlock) void k_shade_photon(DeviceScene sc, PathQue
                 }
             }
         }
-        const uint32_t ni = seg_out * cap + wave_compact(want_next, &ctr->n_queue[depth][seg_out]);
+        const uint32_t ni = seg_out * cap + wave_compact(want_next, &ctr->n_queue[depth][seg_out * kCtrStride]);
         if (want_next) {
             qout.o[ni] = no4;
             qout.d[ni] = nd4;

@@ -61,6 +61,8 @@ struct TraceOut {
     float4* L;               // any-hit + accumulate mode
     const float4* contrib;
     uint8_t* occluded;       // any-hit, plain mode
+    uint32_t bary_mode;      // closest, 1: hits.x = third barycentric of a triangle hit instead of t (the shading kernels then
+                             // skip re-running the triangle test); spheres keep t
 };
 
 template <bool ANY, bool COUNT>
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(kBlock, TH_TRACE2_MIN_WAVES) void k_trace2(DeviceSc
     uint32_t steps = 0;  // interior fetches of the current ray (diagnostic budget)
     f3 o = splat3(0.0f), d = splat3(0.0f), inv_d = splat3(0.0f);
     bool negx = false, negy = false, negz = false;
-    float t_max = 0.0f, b1 = 0.0f, b2 = 0.0f, slot_w = 0.0f, flag_w = 0.0f;
+    float t_max = 0.0f, b1 = 0.0f, b2 = 0.0f, hx = 0.0f, slot_w = 0.0f, flag_w = 0.0f;
     int hit_prim = -1;
     bool found = false;
     uint32_t nn = 0, np = 0;
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(kBlock, TH_TRACE2_MIN_WAVES) void k_trace2(DeviceSc
             if (!exhausted) {
                 if (pool_next >= pool_end) {  // take the next chunk: try this wave's segment, move on when it is drained
                     uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(&work[wseg], (uint32_t)kChunk);
+                    if (lane == 0) base = atomicAdd(&work[wseg * kCtrStride], (uint32_t)kChunk);
                     base = __shfl(base, 0);
                     const uint32_t cnt = sv.count[wseg];
                     if (base < cnt) {
@@ -177,6 +179,7 @@ __global__ __launch_bounds__(kBlock, TH_TRACE2_MIN_WAVES) void k_trace2(DeviceSc
                             found = true;
                             hit_prim = (int)slot;
                             b1 = b2 = 0.0f;
+                            hx = sh.t;
                         }
                     } else {
                         TriTest tt;
@@ -191,6 +194,7 @@ __global__ __launch_bounds__(kBlock, TH_TRACE2_MIN_WAVES) void k_trace2(DeviceSc
                             hit_prim = (int)slot;
                             b1 = tt.bary.x;
                             b2 = tt.bary.y;
+                            hx = out.bary_mode ? tt.bary.z : tt.t;
                         }
                     }
                 }
@@ -284,7 +288,7 @@ __global__ __launch_bounds__(kBlock, TH_TRACE2_MIN_WAVES) void k_trace2(DeviceSc
                         out.occluded[idx] = found ? 1 : 0;
                     }
                 } else {
-                    out.hits[idx] = make_float4(found ? t_max : kInf, __int_as_float(found ? hit_prim : -1), b1, b2);
+                    out.hits[idx] = make_float4(found ? hx : kInf, __int_as_float(found ? hit_prim : -1), b1, b2);
                 }
             }
         }

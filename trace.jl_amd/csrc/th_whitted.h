@@ -75,7 +75,7 @@ __global__ __launch_bounds__(kBlock) void k_shade_whitted(DeviceScene sc, PathQu
                     }
                 }
             }
-            const uint32_t k = wave_compact(want, &ctr->n_shadow[depth - 1][seg_out]);
+            const uint32_t k = wave_compact(want, &ctr->n_shadow[depth - 1][seg_out * kCtrStride]);
             if (want) {
                 if (k < cap_shadow) {
                     const uint32_t si = seg_out * cap_shadow + k;
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(kBlock) void k_shade_whitted(DeviceScene sc, PathQu
                         want = true;
                     }
                 }
-                const uint32_t k = wave_compact(want, &ctr->n_queue[depth][seg_out]);
+                const uint32_t k = wave_compact(want, &ctr->n_queue[depth][seg_out * kCtrStride]);
                 if (want) {
                     if (k < cap) {
                         const uint32_t ni = seg_out * cap + k;

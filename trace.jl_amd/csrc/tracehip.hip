@@ -747,6 +747,7 @@ int render_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sensor* se
     HIP_TRY(ctx, hipMemsetAsync(L, 0, total_slots * sizeof(float4), st));
     HIP_TRY(ctx, hipEventRecord(ev_start, st));
     const int g_shade = ctx->num_cu * 8;
+    const uint32_t bary_mode = (ctx->traversal == 2 && scene->wide_ok) ? 1u : 0u;  // k_trace2 hands the barycentrics to the shading kernel
     uint32_t n_batches = 0;
     for (int pi = 0; pi < NP; ++pi) {
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->pipes[pi].st, ev_start, 0));
@@ -770,12 +771,12 @@ int render_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sensor* se
         int cur = 0;
         for (int depth = 1; depth <= max_depth; ++depth) {
             tm.begin(1, ps);
-            launch_trace(ctx, ps, scene, false, SegQueue{ctr->n_queue[depth - 1], cap, 0u}, pq[cur].o, pq[cur].d, nullptr, TraceOut{hits, nullptr, nullptr, nullptr}, ctr->work_closest[depth - 1], ctr,
+            launch_trace(ctx, ps, scene, false, SegQueue{ctr->n_queue[depth - 1], cap, 0u}, pq[cur].o, pq[cur].d, nullptr, TraceOut{hits, nullptr, nullptr, nullptr, bary_mode}, ctr->work_closest[depth - 1], ctr,
                          pp.overflow[0].p);
             tm.end(1, ps);
             if (ps2 != ps && depth > 1) HIP_TRY(ctx, hipStreamWaitEvent(ps, pp.ev_any, 0));  // shade(d) reuses the shadow queue and touches L
             tm.begin(2, ps);
-            hipLaunchKernelGGL(k_shade_path, dim3(g_shade), dim3(kBlock), 0, ps, scene->dev, dsp, pq[cur], pq[cur ^ 1], sq, cap, hits, L, ctr, depth, max_depth, seed, sample_offset);
+            hipLaunchKernelGGL(k_shade_path, dim3(g_shade), dim3(kBlock), 0, ps, scene->dev, dsp, pq[cur], pq[cur ^ 1], sq, cap, hits, L, ctr, depth, max_depth, bary_mode);
             tm.end(2, ps);
             if (ps2 != ps) {
                 HIP_TRY(ctx, hipEventRecord(pp.ev_shade, ps));
@@ -1617,6 +1618,13 @@ extern "C" int trhip_detmath_f32(int fn, const float* x, const float* y, uint64_
         case 3: out[i] = tm_atan2f(y[i], x[i]); break;
         case 4: out[i] = tm_acosf(x[i]); break;
         case 5: out[i] = tm_logf(x[i]); break;
+        case 6:
+        case 7: {  // tm_sincosf: sin part / cos part
+            float sn, cs;
+            tm_sincosf(x[i], &sn, &cs);
+            out[i] = fn == 6 ? sn : cs;
+            break;
+        }
         default: return TRHIP_ERR_INVALID;
         }
     }

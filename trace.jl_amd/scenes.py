@@ -75,7 +75,7 @@ def _quad(core, p0, p1, p2, p3, normal):
     return T.create_triangle_mesh(core, 2, np.array([1, 2, 3, 1, 3, 4], dtype=np.uint32), 4, [p0, p1, p2, p3], [normal] * 4)
 
 
-def cornell_primitives():
+def cornell_primitives(spheres: bool = True):
     red = T.MatteMaterial(T.ConstantTexture(T.RGBSpectrum(0.796, 0.235, 0.2)), T.ConstantTexture(0.0))
     blue = T.MatteMaterial(T.ConstantTexture(T.RGBSpectrum(0.251, 0.388, 0.847)), T.ConstantTexture(0.0))
     white = T.MatteMaterial(T.ConstantTexture(T.RGBSpectrum(1.0)), T.ConstantTexture(0.0))
@@ -94,8 +94,9 @@ def cornell_primitives():
     for (p0, p1, p2, p3), n, m in walls:
         for t in _quad(core, p0, p1, p2, p3, n):
             prims.append(T.GeometricPrimitive(t, m))
-    prims.append(T.GeometricPrimitive(T.Sphere(T.ShapeCore(T.translate([0.3, 0.25, -2.7]), False), 0.25, 360.0), mirror))
-    prims.append(T.GeometricPrimitive(T.Sphere(T.ShapeCore(T.translate([0.7, 0.2, -2.35]), False), 0.2, 360.0), glass))
+    if spheres:
+        prims.append(T.GeometricPrimitive(T.Sphere(T.ShapeCore(T.translate([0.3, 0.25, -2.7]), False), 0.25, 360.0), mirror))
+        prims.append(T.GeometricPrimitive(T.Sphere(T.ShapeCore(T.translate([0.7, 0.2, -2.35]), False), 0.2, 360.0), glass))
     return prims, white
 
 
@@ -103,8 +104,8 @@ def cornell_lights():
     return [T.PointLight(T.translate([0.5, 0.9, -2.5]), T.RGBSpectrum(2.5))]
 
 
-def cornell_scene():
-    prims, _ = cornell_primitives()
+def cornell_scene(spheres: bool = True):
+    prims, _ = cornell_primitives(spheres)
     return T.Scene(cornell_lights(), T.BVHAccel(prims, 1))
 
 
