@@ -34,7 +34,10 @@ constexpr int kMaxDepth = 62;
 // run time of the shading kernel; 32 words on different L2 channels are not a bottleneck.
 constexpr int kSeg = 32;
 constexpr uint32_t kSegGran = 256;  // a segment's share of the flat work space is padded to a multiple of this
-constexpr uint32_t kCtrStride = 32;  // words between the counters of neighbouring segments: one 128-byte line each, so that the
+#ifndef TH_CTR_STRIDE
+#define TH_CTR_STRIDE 32
+#endif
+constexpr uint32_t kCtrStride = TH_CTR_STRIDE;  // words between the counters of neighbouring segments: one 128-byte line each, so that the
                                      // atomics of different segments go to different L2 channels instead of queueing on one line
 struct Counters {  // device-resident
     // per wavefront batch (zeroed by one memset at batch start): first index = path depth - 1, second = segment * kCtrStride
@@ -636,6 +639,112 @@ TH_D void film_tile_bounds(const DeviceSensor& se, int ty, int tx, float rx, flo
     by0 = jmax(__builtin_ceilf(tby0 - 0.5f - ry), se.crop_min[1]);
     bx1 = jmin(__builtin_floorf(tbx1 - 0.5f + rx) + 1.0f, se.crop_max[0]);
     by1 = jmin(__builtin_floorf(tby1 - 0.5f + ry) + 1.0f, se.crop_max[1]);
+}
+
+// k_film_gather for a BX x BY block of film pixels per thread.  k_film_gather is bound by re-reading every sample for each of
+// the ~(2r+3)^2 film pixels in whose reach it lies; here a sample is loaded once per block and offered to all BX*BY pixels
+// (reach of the block: (BX + 2r + 2) x (BY + 2r + 2) sample pixels), and the filter index is computed once per row / column.
+// Per film pixel nothing changes: tiles in k order, sample pixels in Bounds2 order, samples in order, one csum per tile; a
+// tile or sample outside a pixel's own reach fails the same bounds tests as in k_film_gather and contributes nothing.
+template <int BX, int BY>
+__global__ __launch_bounds__(kBlock) void k_film_gather_block(const DeviceSensor* __restrict__ sep, const float* __restrict__ table, const float4* __restrict__ L,
+                                                              const float2* __restrict__ pfilm, uint32_t spp, float4* __restrict__ out) {
+    const DeviceSensor& se = *sep;
+    const uint32_t npix = (uint32_t)(se.sb_w * se.sb_h);
+    const float rx = se.filter_radius[0], ry = se.filter_radius[1];
+    const float inv_rx = 1.0f / rx, inv_ry = 1.0f / ry;
+    const uint32_t nbx = ((uint32_t)se.film_w + BX - 1) / BX, nby = ((uint32_t)se.film_h + BY - 1) / BY;
+    for (uint32_t bidx = blockIdx.x * kBlock + threadIdx.x; bidx < nbx * nby; bidx += gridDim.x * kBlock) {
+        const int fy0 = (int)(bidx / nbx) * BY, fx0 = (int)(bidx - (bidx / nbx) * nbx) * BX;
+        float X[BX], Y[BY];
+        for (int i = 0; i < BX; ++i) X[i] = se.crop_min[0] + (float)(fx0 + i);
+        for (int j = 0; j < BY; ++j) Y[j] = se.crop_min[1] + (float)(fy0 + j);
+        // union of the pixels' reaches (k_film_gather: sx in (X - 1.5 - r, X + r + 0.5])
+        int sx_lo = max((int)__builtin_floorf(X[0] - 1.5f - rx), se.sb_min[0]), sx_hi = min((int)__builtin_ceilf(X[BX - 1] + rx + 0.5f), se.sb_max[0]);
+        int sy_lo = max((int)__builtin_floorf(Y[0] - 1.5f - ry), se.sb_min[1]), sy_hi = min((int)__builtin_ceilf(Y[BY - 1] + ry + 0.5f), se.sb_max[1]);
+        f3 xyz[BY][BX];
+        float wsum[BY][BX];
+        for (int j = 0; j < BY; ++j)
+            for (int i = 0; i < BX; ++i) {
+                xyz[j][i] = splat3(0.0f);
+                wsum[j][i] = 0.0f;
+            }
+        if (sx_lo <= sx_hi && sy_lo <= sy_hi) {
+            const int ty_lo = (sy_lo - se.sb_min[1]) >> 4, ty_hi = (sy_hi - se.sb_min[1]) >> 4;
+            const int tx_lo = (sx_lo - se.sb_min[0]) >> 4, tx_hi = (sx_hi - se.sb_min[0]) >> 4;
+            for (int ty = ty_lo; ty <= ty_hi; ++ty)
+                for (int tx = tx_lo; tx <= tx_hi; ++tx) {
+                    float bx0, by0, bx1, by1;
+                    film_tile_bounds(se, ty, tx, rx, ry, bx0, by0, bx1, by1);
+                    const float tbx0 = (float)se.sb_min[0] + (float)tx * 16.0f, tby0 = (float)se.sb_min[1] + (float)ty * 16.0f;
+                    const float tbx1 = jmin(tbx0 + 15.0f, (float)se.sb_max[0]), tby1 = jmin(tby0 + 15.0f, (float)se.sb_max[1]);
+                    bool in_tile[BY][BX];  // merge_film_tile! touches the pixel (film.jl:182-193)
+                    bool any_in = false;
+                    for (int j = 0; j < BY; ++j)
+                        for (int i = 0; i < BX; ++i) {
+                            in_tile[j][i] = !(X[i] < bx0 || X[i] > bx1 || Y[j] < by0 || Y[j] > by1);
+                            any_in = any_in || in_tile[j][i];
+                        }
+                    if (!any_in) continue;
+                    f3 csum[BY][BX];
+                    float fws[BY][BX];
+                    for (int j = 0; j < BY; ++j)
+                        for (int i = 0; i < BX; ++i) {
+                            csum[j][i] = splat3(0.0f);
+                            fws[j][i] = 0.0f;
+                        }
+                    const int y0 = max(sy_lo, (int)tby0), y1 = min(sy_hi, (int)tby1);
+                    const int x0 = max(sx_lo, (int)tbx0), x1 = min(sx_hi, (int)tbx1);
+                    for (int sy = y0; sy <= y1; ++sy)
+                        for (int sx = x0; sx <= x1; ++sx) {
+                            const uint32_t pix = (uint32_t)(sy - se.sb_min[1]) * (uint32_t)se.sb_w + (uint32_t)(sx - se.sb_min[0]);
+                            for (uint32_t s = 0; s < spp; ++s) {
+                                const float2 pf = pfilm[(size_t)s * npix + pix];
+                                const float dpx = pf.x - 0.5f, dpy = pf.y - 0.5f;
+                                float p0x = __builtin_ceilf(dpx - rx), p0y = __builtin_ceilf(dpy - ry);
+                                float p1x = __builtin_floorf(dpx + rx) + 1.0f, p1y = __builtin_floorf(dpy + ry) + 1.0f;
+                                p0x = jmax(p0x, jmax(bx0, 1.0f));
+                                p0y = jmax(p0y, jmax(by0, 1.0f));
+                                p1x = jmin(p1x, bx1);
+                                p1y = jmin(p1y, by1);
+                                bool okx[BX], oky[BY];
+                                bool anyx = false, anyy = false;
+                                for (int i = 0; i < BX; ++i) {
+                                    okx[i] = !(X[i] < p0x || X[i] > p1x);
+                                    anyx = anyx || okx[i];
+                                }
+                                for (int j = 0; j < BY; ++j) {
+                                    oky[j] = !(Y[j] < p0y || Y[j] > p1y);
+                                    anyy = anyy || oky[j];
+                                }
+                                if (!(anyx && anyy)) continue;
+                                const float4 l4 = L[(size_t)s * npix + pix];
+                                f3 l = mk3(l4.x, l4.y, l4.z);
+                                if (has_nan(l)) l = splat3(0.0f);  // integrators/sampler.jl:46
+                                int ox[BX], oy[BY];
+                                for (int i = 0; i < BX; ++i) ox[i] = (int)jclamp(__builtin_ceilf(fabs_((X[i] - dpx) * inv_rx * 16.0f)), 1.0f, 16.0f) - 1;   // ceil for x …
+                                for (int j = 0; j < BY; ++j) oy[j] = ((int)jclamp(__builtin_floorf(fabs_((Y[j] - dpy) * inv_ry * 16.0f)), 1.0f, 16.0f) - 1) * 16;  // … floor for y (A.9)
+                                for (int j = 0; j < BY; ++j)
+                                    for (int i = 0; i < BX; ++i)
+                                        if (okx[i] && oky[j]) {
+                                            const float w = table[oy[j] + ox[i]];
+                                            csum[j][i] = csum[j][i] + l * 1.0f * w;
+                                            fws[j][i] += w;
+                                        }
+                            }
+                        }
+                    for (int j = 0; j < BY; ++j)
+                        for (int i = 0; i < BX; ++i)
+                            if (in_tile[j][i]) {
+                                xyz[j][i] = xyz[j][i] + rgb_to_xyz(csum[j][i]);
+                                wsum[j][i] += fws[j][i];
+                            }
+                }
+        }
+        for (int j = 0; j < BY; ++j)
+            for (int i = 0; i < BX; ++i)
+                if (fx0 + i < se.film_w && fy0 + j < se.film_h) out[(size_t)(fy0 + j) * (size_t)se.film_w + (size_t)(fx0 + i)] = make_float4(xyz[j][i].x, xyz[j][i].y, xyz[j][i].z, wsum[j][i]);
+    }
 }
 
 // k_film_gather with the samples staged through LDS: one block = a 16x16 film tile; for every sample row (ascending) the

@@ -52,6 +52,7 @@ struct trhip_ctx {
     Pipe pipes[kMaxPipes];
     uint32_t debug_trace_budget = 0;  // DIAGNOSTIC: k_trace2 abandons rays after this many node fetches (results wrong; measures bulk vs tail)
     uint32_t tiny_scene_prims = 16;  // scenes of at most this many primitives get a single-leaf BVH (th_bvh.h); 0 = always build the hierarchy
+    int film_block = 1;  // film gather: 0 = one film pixel per thread, 1 = 2 x 2 pixels per thread (default), 2 = TH_FILM_BX x TH_FILM_BY
     bool film_tiled = false;  // LDS-staged film gather (k_film_gather_tiled): bit-identical, measured 2.7x SLOWER than k_film_gather (11 % lane use), kept as an option
     bool overlap = true;  // two-stream overlap of shadow rays (depth d) with closest-hit rays (depth d+1)
     int traversal = 2;  // 1 = literal accel/bvh.jl loop, 2 = children-in-parent nodes + per-lane ray replacement
@@ -408,6 +409,10 @@ void derive_sensor(const trhip_sensor* sn, DeviceSensor& d) {
 
 // Film accumulation: positions, then the LDS-tiled gather (falls back to the per-pixel gather when a 16x16 film tile is reached
 // by more than two sample tiles per axis, i.e. very wide filters).
+#ifndef TH_FILM_BX
+#define TH_FILM_BX 1  // film_block = 2; measured at 1024^2, 256 spp: 1x1 69 ms, 2x2 43, 1x4 44, 2x4 55, 4x2 67, 3x3 94
+#define TH_FILM_BY 4
+#endif
 void launch_film(trhip_ctx* ctx, hipStream_t st, const DeviceSensor& ds, const DeviceSensor* dsp, const float4* L, uint64_t total_slots, uint32_t spp, uint64_t seed, uint32_t sample_offset,
                  float4* d_film) {
     hipLaunchKernelGGL(k_film_positions, dim3(grid_for(ctx, total_slots, 8)), dim3(kBlock), 0, st, dsp, total_slots, seed, sample_offset, (float2*)ctx->pfilm.p);
@@ -426,7 +431,13 @@ void launch_film(trhip_ctx* ctx, hipStream_t st, const DeviceSensor& ds, const D
         const dim3 grid((ds.film_w + 15) / 16, (ds.film_h + 15) / 16);
         hipLaunchKernelGGL(k_film_gather_tiled, grid, dim3(kBlock), (size_t)cols * ns * 20 + 16, st, dsp, (const float*)ctx->table.p, L, (const float2*)ctx->pfilm.p, spp, cols, ns, d_film);
     } else {
-        hipLaunchKernelGGL(k_film_gather, dim3(grid_for(ctx, (uint64_t)ds.film_w * ds.film_h, 8)), dim3(kBlock), 0, st, dsp, (const float*)ctx->table.p, L, (const float2*)ctx->pfilm.p, spp, d_film);
+        const uint64_t npx = (uint64_t)ds.film_w * ds.film_h;
+        if (ctx->film_block == 1)
+            hipLaunchKernelGGL((k_film_gather_block<2, 2>), dim3(grid_for(ctx, (npx + 3) / 4, 8)), dim3(kBlock), 0, st, dsp, (const float*)ctx->table.p, L, (const float2*)ctx->pfilm.p, spp, d_film);
+        else if (ctx->film_block == 2)
+            hipLaunchKernelGGL((k_film_gather_block<TH_FILM_BX, TH_FILM_BY>), dim3(grid_for(ctx, (npx + TH_FILM_BX * TH_FILM_BY - 1) / (TH_FILM_BX * TH_FILM_BY), 8)), dim3(kBlock), 0, st, dsp, (const float*)ctx->table.p, L, (const float2*)ctx->pfilm.p, spp, d_film);
+        else
+            hipLaunchKernelGGL(k_film_gather, dim3(grid_for(ctx, npx, 8)), dim3(kBlock), 0, st, dsp, (const float*)ctx->table.p, L, (const float2*)ctx->pfilm.p, spp, d_film);
     }
 }
 
@@ -1189,6 +1200,8 @@ int trhip_set_option(trhip_ctx* ctx, const char* name, int64_t value) {
         ctx->sppm_batch = (uint64_t)std::max<int64_t>(0, value);
     else if (!std::strcmp(name, "tiny_scene_prims"))
         ctx->tiny_scene_prims = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(255, value));
+    else if (!std::strcmp(name, "film_block"))
+        ctx->film_block = (int)std::max<int64_t>(0, std::min<int64_t>(2, value));
     else if (!std::strcmp(name, "film_tiled"))
         ctx->film_tiled = value != 0;
     else if (!std::strcmp(name, "pipelines")) {
