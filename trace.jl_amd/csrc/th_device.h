@@ -639,6 +639,44 @@ TH_D BsdfSample bsdf_sample_f(const LobeSet& b, const Shading& s, f3 wo_w, f2 u,
     return r;
 }
 
+// ---- the commonest BSDF, specialised ---------------------------------------------------------------------------------------
+// A BSDF that is exactly one LambertianReflection lobe (MatteMaterial with σ = 0, material.jl:16-31; type DIFFUSE|REFLECTION,
+// which every flag set the integrators pass matches).  bsdf_f / bsdf_sample_f evaluated for that case: the same operations
+// in the same order, without the lobe loops and kind switches the general code needs (they cost registers and ~40 % of the
+// shading kernel's instructions).
+TH_D bool bsdf_is_single_lambert(const LobeSet& b) { return b.n == 1 && b.lobe[0].kind == LOBE_LAMBERT_R; }
+TH_D f3 lambert_bsdf_f(const Lobe& l, const Shading& s, f3 wo_w, f3 wi_w) {
+    const f3 wo = bsdf_to_local(s, wo_w);
+    if (wo.z == 0.0f) return splat3(0.0f);
+    const bool refl = (dot(wi_w, s.ng) * dot(wo_w, s.ng)) > 0.0f;
+    f3 out = splat3(0.0f);
+    if (refl) out = out + lobe_r(l) * kInvPi;
+    return out;
+}
+TH_D BsdfSample lambert_bsdf_sample_f(const Lobe& l, const Shading& s, f3 wo_w, f2 u) {
+    BsdfSample r;
+    r.wi = splat3(0.0f);
+    r.f = splat3(0.0f);
+    r.pdf = 0.0f;
+    r.sampled_type = BSDF_NONE;
+    const f2 ur{jmin(u.x * 1.0f - 0.0f, 1.0f), u.y};  // one matching lobe: component 1, remapped u (bsdf.jl:118-131)
+    const f3 wo = bsdf_to_local(s, wo_w);
+    if (wo.z == 0.0f) return r;
+    f3 wi = cosine_sample_hemisphere(ur);  // bxdf.jl:34-42
+    if (wo.z < 0.0f) wi = mk3(wi.x, wi.y, -wi.z);
+    const float pdf = same_hemisphere(wo, wi) ? fabs_(cos_theta(wi)) * kInvPi : 0.0f;  // bxdf.jl:23-25
+    if (pdf == 0.0f) return r;
+    const f3 wi_w = bsdf_to_world(s, wi);
+    const bool refl = (dot(wi_w, s.ng) * dot(wo_w, s.ng)) > 0.0f;
+    f3 f = splat3(0.0f);
+    if (refl) f = f + lobe_r(l) * kInvPi;
+    r.wi = wi_w;
+    r.f = f;
+    r.pdf = pdf;
+    r.sampled_type = l.type;
+    return r;
+}
+
 // ---- lights (lights/point.jl:50-58, lights/spot.jl:22-40) -----------------------------------------------------------------
 struct LightSample {
     f3 radiance;

@@ -455,6 +455,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TH_SHADE
 #endif
                 if (rebuild_shading(sc, prim, o, d, sh, material, hits_have_bary ? &h4 : nullptr) && material != PRIM_NO_MATERIAL) {
                     const LobeSet& bsdf = materials[material].set[1];  // compute_scattering!(si, ray, true)
+                    const bool lambert = bsdf_is_single_lambert(bsdf);      // specialised evaluation of the same arithmetic (th_device.h)
                     // the sampler stream key of this camera sample rides in the queue (k_raygen): no slot -> pixel division, no re-hash
                     const uint64_t key = ((uint64_t)__float_as_uint(b4.w) << 32) | (uint64_t)__float_as_uint(d4.w);
                     const uint32_t v = (uint32_t)(depth - 1);
@@ -463,7 +464,19 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TH_SHADE
                                             ((isnan_(beta.z) || isinf_(beta.z)) ? 4u : 0u);
                     // ---- uniform_sample_one_light ----
                     bool direct_added = false;
-                    if (sc.n_lights > 0) {
+#ifdef TH_SHADE_DIAG_LEVEL  // DIAGNOSTIC (wrong results): 1 = interaction only, 2 = + direct light; the condition is always true at run time
+                    const bool diag_skip = hits_have_bary < 2u;
+                    so4 = make_float4(sh.p.x, sh.p.y, sh.p.z, o4.w), sd4 = make_float4(sh.ns.x, sh.ns.y, sh.ns.z, 0.0f), sc4 = make_float4(sh.ss.x, sh.ts.y, sh.ng.z, 0.0f);
+                    no4 = so4, nd4 = make_float4(wo.x, wo.y, wo.z, d4.w), nb4 = b4;
+                    want_shadow = (prim & 1) == 0;
+                    want_next = depth < max_depth && (prim & 7) != 0;
+#define TH_DIAG_SKIP_DIRECT (TH_SHADE_DIAG_LEVEL == 1 && diag_skip)
+#define TH_DIAG_SKIP_SAMPLE (TH_SHADE_DIAG_LEVEL <= 2 && diag_skip)
+#else
+#define TH_DIAG_SKIP_DIRECT false
+#define TH_DIAG_SKIP_SAMPLE false
+#endif
+                    if (sc.n_lights > 0 && !TH_DIAG_SKIP_DIRECT) {
                         const int nl = (int)sc.n_lights;
                         int ln = (int)__builtin_ceilf(ts_uniform(key, ts_vertex_dim(v, TS_V_LIGHT_PICK)) * (float)nl);
                         if (ln > nl) ln = nl;
@@ -472,7 +485,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TH_SHADE
                         const LightRec& light = lights[ln - 1];
                         const LightSample ls = sample_li(light, sh.p);
                         if (ls.pdf > 0.0f && !is_black(ls.radiance)) {
-                            const f3 f = bsdf_f(bsdf, sh, sh.wo, ls.wi, BSDF_ALL & ~BSDF_SPECULAR) * fabs_(dot(ls.wi, sh.ns));
+                            const f3 f = (lambert ? lambert_bsdf_f(bsdf.lobe[0], sh, sh.wo, ls.wi) : bsdf_f(bsdf, sh, sh.wo, ls.wi, BSDF_ALL & ~BSDF_SPECULAR)) * fabs_(dot(ls.wi, sh.ns));
                             if (!is_black(f)) {
                                 // x / 1 == x exactly: δ-lights have pdf 1, a single light has light_pdf 1 (6 correctly rounded divisions saved)
                                 const f3 fl = f * ls.radiance;
@@ -500,9 +513,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TH_SHADE
                         L[slot] = l;
                     }
                     // ---- continue the path ----
-                    if (depth < max_depth) {
+                    if (depth < max_depth && !TH_DIAG_SKIP_SAMPLE) {
                         const f2 u{ts_uniform(key, ts_vertex_dim(v, TS_V_BSDF_U0)), ts_uniform(key, ts_vertex_dim(v, TS_V_BSDF_U1))};
-                        const BsdfSample bs = bsdf_sample_f(bsdf, sh, wo, u, BSDF_ALL);
+                        const BsdfSample bs = lambert ? lambert_bsdf_sample_f(bsdf.lobe[0], sh, wo, u) : bsdf_sample_f(bsdf, sh, wo, u, BSDF_ALL);
                         if (!(bs.pdf == 0.0f || is_black(bs.f))) {
                             beta = beta * (bs.f * fabs_(dot(bs.wi, sh.ns)) / bs.pdf);
                             const float by = to_Y(beta);
