@@ -20,23 +20,45 @@ TH_D bool tri_degenerate(f3 v0, f3 v1, f3 v2) {
     return dot(v, v) == 0.0f;
 }
 // :99-123 + :189-218 (== :247-270).  t_max test is inclusive of equality (A.6); no kx/ky swap (A.7).
+// What the triangle test derives from the ray alone (:99-114): the dominant axis and the shear.  Computed once per ray by the
+// traversal kernels instead of once per triangle (one correctly rounded division among it).
+struct RayShear {
+    int kz;
+    float sx, sy, sz;
+};
+TH_HD RayShear ray_shear(f3 d) {
+    const float ax = fabs_(d.x), ay = fabs_(d.y), az = fabs_(d.z);
+    RayShear r;
+    r.kz = 0;
+    float am = ax;
+    if (ay > am) {
+        r.kz = 1;
+        am = ay;
+    }
+    if (az > am) r.kz = 2;
+    const float dpx = r.kz == 0 ? d.y : (r.kz == 1 ? d.z : d.x), dpy = r.kz == 0 ? d.z : (r.kz == 1 ? d.x : d.y), dpz = r.kz == 0 ? d.x : (r.kz == 1 ? d.y : d.z);
+    const float denom = 1.0f / dpz;
+    r.sx = -dpx * denom;
+    r.sy = -dpy * denom;
+    r.sz = denom;
+    return r;
+}
+template <bool WANT_HIT>
+TH_D bool tri_intersect_sheared(f3 v0, f3 v1, f3 v2, f3 o, const RayShear& rs, float t_max, TriTest* out);
 template <bool WANT_HIT>
 TH_D bool tri_intersect(f3 v0, f3 v1, f3 v2, f3 o, f3 d, float t_max, TriTest* out) {
     if (tri_degenerate(v0, v1, v2)) return false;
-    const float ax = fabs_(d.x), ay = fabs_(d.y), az = fabs_(d.z);
-    int kz = 0;
-    float am = ax;
-    if (ay > am) {
-        kz = 1;
-        am = ay;
-    }
-    if (az > am) kz = 2;
+    return tri_intersect_sheared<WANT_HIT>(v0, v1, v2, o, ray_shear(d), t_max, out);
+}
+// The test proper, for a triangle already known not to be degenerate (PRIM_DEGENERATE is set at scene commit).
+template <bool WANT_HIT>
+TH_D bool tri_intersect_sheared(f3 v0, f3 v1, f3 v2, f3 o, const RayShear& rs, float t_max, TriTest* out) {
+    const int kz = rs.kz;
     // permute so that kz is last: (kx, ky, kz) = (kz+1, kz+2, kz) mod 3
-    f3 dp, a0, a1, a2;
+    f3 a0, a1, a2;
     const f3 p0 = v0 - o, p1 = v1 - o, p2 = v2 - o;
     float dz0, dz1, dz2;  // vertices[i][kz] - ray.o[kz] (recomputed exactly as :116-117 do)
     if (kz == 0) {
-        dp = mk3(d.y, d.z, d.x);
         a0 = mk3(p0.y, p0.z, p0.x);
         a1 = mk3(p1.y, p1.z, p1.x);
         a2 = mk3(p2.y, p2.z, p2.x);
@@ -44,7 +66,6 @@ TH_D bool tri_intersect(f3 v0, f3 v1, f3 v2, f3 o, f3 d, float t_max, TriTest* o
         dz1 = v1.x - o.x;
         dz2 = v2.x - o.x;
     } else if (kz == 1) {
-        dp = mk3(d.z, d.x, d.y);
         a0 = mk3(p0.z, p0.x, p0.y);
         a1 = mk3(p1.z, p1.x, p1.y);
         a2 = mk3(p2.z, p2.x, p2.y);
@@ -52,7 +73,6 @@ TH_D bool tri_intersect(f3 v0, f3 v1, f3 v2, f3 o, f3 d, float t_max, TriTest* o
         dz1 = v1.y - o.y;
         dz2 = v2.y - o.y;
     } else {
-        dp = d;
         a0 = p0;
         a1 = p1;
         a2 = p2;
@@ -60,8 +80,7 @@ TH_D bool tri_intersect(f3 v0, f3 v1, f3 v2, f3 o, f3 d, float t_max, TriTest* o
         dz1 = v1.z - o.z;
         dz2 = v2.z - o.z;
     }
-    const float denom = 1.0f / dp.z;
-    const float sx = -dp.x * denom, sy = -dp.y * denom, sz = denom;
+    const float sx = rs.sx, sy = rs.sy, sz = rs.sz;
     const float x0 = a0.x + sx * dz0, y0 = a0.y + sy * dz0, z0 = a0.z + 0.0f;
     const float x1 = a1.x + sx * dz1, y1 = a1.y + sy * dz1, z1 = a1.z + 0.0f;
     const float x2 = a2.x + sx * dz2, y2 = a2.y + sy * dz2, z2 = a2.z + 0.0f;

@@ -85,6 +85,7 @@ __global__ __launch_bounds__(kBlock, TH_TRACE2_MIN_WAVES) void k_trace2(DeviceSc
     int sp = 0;
     uint32_t steps = 0;  // interior fetches of the current ray (diagnostic budget)
     f3 o = splat3(0.0f), d = splat3(0.0f), inv_d = splat3(0.0f);
+    RayShear shear{0, 0.0f, 0.0f, 0.0f};  // the triangle test's per-ray part (th_device.h)
     bool negx = false, negy = false, negz = false;
     float t_max = 0.0f, b1 = 0.0f, b2 = 0.0f, hx = 0.0f, slot_w = 0.0f, flag_w = 0.0f;
     int hit_prim = -1;
@@ -123,6 +124,7 @@ __global__ __launch_bounds__(kBlock, TH_TRACE2_MIN_WAVES) void k_trace2(DeviceSc
                         slot_w = o4.w;
                         flag_w = d4.w;
                         inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                        shear = ray_shear(d);
                         negx = d.x < 0.0f;
                         negy = d.y < 0.0f;
                         negz = d.z < 0.0f;
@@ -183,7 +185,7 @@ __global__ __launch_bounds__(kBlock, TH_TRACE2_MIN_WAVES) void k_trace2(DeviceSc
                         }
                     } else {
                         TriTest tt;
-                        if (tri_intersect<!ANY>(mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z), o, d, t_max, &tt)) {
+                        if (!(meta & PRIM_DEGENERATE) && tri_intersect_sheared<!ANY>(mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z), o, shear, t_max, &tt)) {
                             if (ANY) {
                                 found = true;
                                 finished = true;

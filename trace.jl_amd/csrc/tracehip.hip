@@ -1266,7 +1266,11 @@ int trhip_scene_add_triangles(trhip_scene* s, const float* xyz, uint32_t n_verts
         }
         uint32_t m = mat ? mat[k] : PRIM_NO_MATERIAL;
         if (mat && m >= s->materials.size()) return fail(s->ctx, TRHIP_ERR_INVALID, "triangle %u: material %u not defined", k, m);
-        p.meta = (m & PRIM_MATERIAL_MASK) | (normals ? PRIM_HAS_NORMALS : 0u) | (flip ? PRIM_FLIP : 0u);
+        // is_degenerate (triangle_mesh.jl:65-68) depends on the triangle alone: evaluated here, once, in the kernels' arithmetic
+        const f3 tv0 = mk3(p.v[0], p.v[1], p.v[2]), tv1 = mk3(p.v[3], p.v[4], p.v[5]), tv2 = mk3(p.v[6], p.v[7], p.v[8]);
+        const f3 tn = cross(tv2 - tv0, tv1 - tv0);
+        const bool degenerate = dot(tn, tn) == 0.0f;
+        p.meta = (m & PRIM_MATERIAL_MASK) | (normals ? PRIM_HAS_NORMALS : 0u) | (flip ? PRIM_FLIP : 0u) | (degenerate ? PRIM_DEGENERATE : 0u);
         s->prims.push_back(p);
     }
     if (first_out) *first_out = first;
