@@ -184,6 +184,32 @@ function render!(entry::Symbol, i, scene::Trace.Scene)
 end
 
 (i::PathIntegrator)(scene::Trace.Scene) = render!(:trhip_render_path, i, scene)
+
+# SPPMIntegrator (integrators/sppm.jl:132-173) on the device: trhip_render_sppm returns the film after set_image!
+# (film.jl:195-202).  `seed` selects the seeded stream of the camera pass (the reference draws from the global RNG there).
+function render_sppm!(i::Trace.SPPMIntegrator, scene::Trace.Scene; seed::Integer = 0x5EED0001)
+    film = Trace.get_film(i.camera)
+    s = flatten(scene)
+    sn = Ref(sensor(i.camera))
+    h, w = size(film.pixels)
+    out = Vector{Float32}(undef, 4 * h * w)
+    stats = TrhipStats()
+    rc = ccall((:trhip_render_sppm, LIB), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{TrhipSensor}, Cfloat, Cint, UInt32, Int64, UInt64, Ptr{Float32}, Ptr{TrhipStats}),
+        context(), s, sn, i.initial_search_radius, i.max_depth, i.n_iterations, i.photons_per_iteration, UInt64(seed), out, Ref(stats))
+    ccall((:trhip_scene_free, LIB), Cvoid, (Ptr{Cvoid},), s)
+    check(rc)
+    @inbounds for y in 1:h, x in 1:w
+        k = 4 * ((y - 1) * w + (x - 1))
+        px = film.pixels[y, x]
+        px.xyz = Point3f(out[k+1], out[k+2], out[k+3])
+        px.filter_weight_sum = out[k+4]          # 1 after set_image!
+        px.splat_xyz = Point3f(0f0)
+    end
+    Trace.save(film)
+end
+# Opt-in replacement of the CPU loop for SPPMIntegrator (shadows integrators/sppm.jl:132):
+accelerate_sppm!() = @eval (i::Trace.SPPMIntegrator)(scene::Trace.Scene) = render_sppm!(i, scene)
 # Opt-in replacement of the CPU loop for WhittedIntegrator (shadows integrators/sampler.jl:12):
 accelerate_whitted!() = @eval (i::Trace.WhittedIntegrator)(scene::Trace.Scene) = render!(:trhip_render_whitted, i, scene)
 
