@@ -211,6 +211,10 @@ int trhip_film_accumulate(trhip_ctx* ctx, const trhip_sensor* sensor, uint32_t s
  * "pipelines" (1..8): wavefront batches in flight at once (default 1).
  * "tiny_scene_prims" (0..255): scenes of at most this many primitives are committed as ONE leaf (default 16; 0 = never).
  *     Read by trhip_scene_commit; results do not depend on it except through the order coincident hits are visited in.
+ * "streaming" (-1/0/1): PathIntegrator on scenes with a real BVH as a streaming wavefront: rays that exceed a fetch budget
+ *     are suspended and resumed in the next round instead of holding up their launch; same result bit for bit.  -1 (default):
+ *     automatic, for frames of at most 32 Mi camera samples, where launch tails dominate; 0 never; 1 always.
+ *     "stream_budget_min" (default 2048), "stream_budget_shift" (12) and "stream_list_cap" (0 = automatic) tune it.
  * "sppm_batch": SPPM iterations whose camera / photon paths share the traversal launches (default 0 = as many as fit in
  *     free HBM, at most 32); the result does not depend on it.
  * "film_block" (0/1/2): film pixels per thread of the film gather: 1, 2 x 2 (default), 1 x 4; same film bit for bit.

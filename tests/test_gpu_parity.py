@@ -322,3 +322,39 @@ def test_partial_spheres_and_transforms(T, ob, ctx):
     ref_xyzw, ref_L, _ = osc.render(cam, "path", 2, 5, seed=77, want_samples=True)
     assert_bits_equal(integ.sample_radiance(scene), ref_L, "per-sample radiance (two lights, spot falloff)")
     assert_bits_equal(xyzw, ref_xyzw, "film")
+
+
+def test_streaming_wavefront_matches_classic_and_oracle(T, ob, ctx, traversal):
+    """PathIntegrator as a streaming wavefront (th_trace2.h): rays over the fetch budget are suspended with their traversal
+    stack and resumed in the next round; per-depth radiance terms are folded in order.  Film and per-sample radiance must
+    equal the classic per-depth wavefront and the oracle bit for bit, whatever the budget (1 = every ray is cut at every
+    interior node) and the list capacity (a full list makes rays run to their end in place)."""
+    if traversal != 2:
+        pytest.skip("streaming is built on k_trace2")
+    scene = T.scenes.mesh_scene(24)
+    cam = T.scenes.cornell_camera(32)
+    flat = scene.flatten(ctx)
+    osc = ob.OracleScene.from_scene(scene, bvh=flat.bvh())
+    ref, ref_L, _ = osc.render(cam, "path", 4, 6, seed=21, want_samples=True)
+
+    def render(**opts):
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        try:
+            integ = T.PathIntegrator(cam, T.SeededSampler(4, seed=21), 6)
+            film = integ.render(scene, ctx).copy()
+            return film, integ.sample_radiance(scene).copy(), integ.stats
+        finally:
+            ctx.set_option("streaming", -1)
+            ctx.set_option("stream_budget_min", 2048)
+            ctx.set_option("stream_list_cap", 0)
+            ctx.set_option("overlap", 1)
+
+    classic, classic_L, st0 = render(streaming=0)
+    assert_bits_equal(classic, ref, "classic film")
+    for opts in ({"streaming": 1}, {"streaming": 1, "stream_budget_min": 1}, {"streaming": 1, "stream_budget_min": 7}, {"streaming": 1, "stream_budget_min": 3, "stream_list_cap": 64},
+                 {"streaming": 1, "stream_budget_min": 2, "overlap": 0}):
+        film, L, st = render(**opts)
+        assert_bits_equal(L, classic_L, f"per-sample radiance, {opts}")
+        assert_bits_equal(film, ref, f"film, {opts}")
+        assert st.closest_rays == st0.closest_rays and st.shadow_rays == st0.shadow_rays, opts

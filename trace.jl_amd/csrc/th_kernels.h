@@ -402,8 +402,19 @@ TH_D bool rebuild_shading(const DeviceScene& sc, int prim, f3 o, f3 d, Shading& 
 #ifndef TH_SHADE_WAVES
 #define TH_SHADE_WAVES 4  // waves per SIMD the register allocator must leave room for: 128 VGPRs + 136 B scratch instead of 175 VGPRs at 2 waves; measured 37.0 -> 32.2 ms (S-cornell, 64 spp)
 #endif
+// STREAM (streaming wavefront, th_trace2.h): the queue of a ROUND holds paths of mixed depths — `row` is the round, every entry
+// carries its depth tag (tags_in / tags_out), and what the path adds to its sample's radiance at depth d goes to the term slot
+// L[(d - 1) * term_stride + slot] (k_fold_terms adds the slots in depth order afterwards).  Entries whose ray was suspended
+// (hit primitive -2) are skipped like misses; they come back in a later round.  Classic: row = depth - 1, tags unused.
+struct ShadeStream {
+    const uint32_t* tags_in;
+    uint32_t* tags_out;
+    uint32_t term_stride;
+};
+template <bool STREAM>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TH_SHADE_WAVES))) void k_shade_path(DeviceScene sc, const DeviceSensor* __restrict__ sep, PathQueue qin, PathQueue qout, ShadowQueue sq, uint32_t cap,
-                                                       const float4* __restrict__ hits, float4* __restrict__ L, Counters* ctr, int depth, int max_depth, uint32_t hits_have_bary) {
+                                                       const float4* __restrict__ hits, float4* __restrict__ L, Counters* ctr, int row, int depth_fixed, int max_depth, uint32_t hits_have_bary,
+                                                       ShadeStream ss) {
     __shared__ SegView sv;
     // The kernel is a chain of dependent memory round trips (28 us per wave-iteration at 4 waves/SIMD, VALU 15 % busy): the
     // material and light tables, reached through two of those trips, are staged in LDS when they are small.
@@ -424,7 +435,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TH_SHADE
     }
     const MaterialRec* materials = staged ? (const MaterialRec*)s_tab : sc.materials;
     const LightRec* lights = staged ? (const LightRec*)(s_tab + kLdsMaterials * (sizeof(MaterialRec) / 4)) : sc.lights;
-    const SegQueue qv{ctr->n_queue[depth - 1], cap, 0u};
+    const SegQueue qv{ctr->n_queue[row], cap, 0u};
     seg_load(qv, sv);  // contains the barrier that publishes s_tab
     const uint32_t total = sv.prefix[kSeg];  // multiple of kSegGran: whole waves stay in the loop, so ballots see every lane
     for (uint32_t flat = blockIdx.x * kBlock + threadIdx.x; flat < total; flat += gridDim.x * kBlock) {
@@ -436,12 +447,15 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TH_SHADE
         const uint32_t seg_out = (flat >> 6) % kSeg;  // every wave-iteration feeds one output segment: at most cap entries each
         bool want_shadow = false, want_next = false;
         float4 so4, sd4, sc4, no4, nd4, nb4;
+        uint32_t next_depth = 0;
         if (valid) {
             const float4 h4 = hits[i];
             const int prim = __float_as_int(h4.y);
             if (prim >= 0) {
                 const float4 o4 = qin.o[i], d4 = qin.d[i], b4 = qin.beta[i];
-                const uint32_t slot = __float_as_uint(o4.w);
+                const int depth = STREAM ? (int)ss.tags_in[i] : depth_fixed;
+                // where this vertex's radiance terms go: the sample's slot, or (STREAM) its per-depth term slot
+                const uint32_t slot = STREAM ? (uint32_t)(depth - 1) * ss.term_stride + __float_as_uint(o4.w) : __float_as_uint(o4.w);
                 const f3 o = mk3(o4.x, o4.y, o4.z), d = mk3(d4.x, d4.y, d4.z);
                 f3 beta = mk3(b4.x, b4.y, b4.z);
                 Shading sh;
@@ -530,8 +544,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TH_SHADE
                             if (alive) {
                                 const f3 org = sh.p + 1e-6f * bs.wi;  // spawn_ray(si, wi) Trace.jl:206-211
                                 const f3 nd = check_direction(bs.wi);
-                                no4 = make_float4(org.x, org.y, org.z, __uint_as_float(slot));
+                                no4 = make_float4(org.x, org.y, org.z, o4.w);
                                 nd4 = make_float4(nd.x, nd.y, nd.z, d4.w);
+                                next_depth = (uint32_t)(depth + 1);
                                 nb4 = make_float4(beta.x, beta.y, beta.z, b4.w);
                                 want_next = true;
                             }
@@ -542,10 +557,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TH_SHADE
         }
         uint32_t si, ni;
 #if TH_SHADE_COMPACT2
-        wave_compact2(want_shadow, &ctr->n_shadow[depth - 1][seg_out * kCtrStride], want_next, &ctr->n_queue[depth][seg_out * kCtrStride], si, ni);
+        wave_compact2(want_shadow, &ctr->n_shadow[row][seg_out * kCtrStride], want_next, &ctr->n_queue[row + 1][seg_out * kCtrStride], si, ni);
 #else
-        si = wave_compact(want_shadow, &ctr->n_shadow[depth - 1][seg_out * kCtrStride]);
-        ni = wave_compact(want_next, &ctr->n_queue[depth][seg_out * kCtrStride]);
+        si = wave_compact(want_shadow, &ctr->n_shadow[row][seg_out * kCtrStride]);
+        ni = wave_compact(want_next, &ctr->n_queue[row + 1][seg_out * kCtrStride]);
 #endif
         si += seg_out * cap;
         ni += seg_out * cap;
@@ -558,8 +573,27 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TH_SHADE
             qout.o[ni] = no4;
             qout.d[ni] = nd4;
             qout.beta[ni] = nb4;
+            if (STREAM) ss.tags_out[ni] = next_depth;
         }
     }
+}
+// STREAM: per-sample radiance = its per-depth terms added in depth order, which is the order the classic wavefront (and the
+// reference's loop) adds them in.  A depth that contributed nothing holds +0, and x + 0 == x for every x this sum can take.
+__global__ __launch_bounds__(kBlock) void k_fold_terms(const float4* __restrict__ terms, uint64_t n_slots, uint32_t n_depths, float4* __restrict__ L) {
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n_slots; i += (uint64_t)gridDim.x * kBlock) {
+        float4 l = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        for (uint32_t dd = 0; dd < n_depths; ++dd) {
+            const float4 t = terms[(uint64_t)dd * n_slots + i];
+            l.x += t.x;
+            l.y += t.y;
+            l.z += t.z;
+        }
+        L[i] = l;
+    }
+}
+// depth tag 1 for every camera ray of a streaming batch
+__global__ __launch_bounds__(kBlock) void k_fill_u32(uint32_t* __restrict__ p, uint64_t n, uint32_t v) {
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) p[i] = v;
 }
 
 // ---- film -------------------------------------------------------------------------------------------------------------------------

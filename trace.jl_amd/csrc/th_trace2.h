@@ -65,9 +65,43 @@ struct TraceOut {
                              // skip re-running the triangle test); spheres keep t
 };
 
-template <bool ANY, bool COUNT>
+// ---- streaming wavefront (DESIGN.md "Stragglers") ---------------------------------------------------------------------------
+// Node visits per ray are heavy-tailed; a launch that waits for its slowest ray pays a 10^5-fetch chain alone.  With STREAM
+// a ray that exceeds the round's fetch budget is SUSPENDED: its traversal state (current node, stack, best hit so far) and
+// what the path needs to go on are copied to a list; the next round's launch resumes the list first, next to its fresh rays
+// (longest jobs first), so a straggler costs a lane for a few rounds instead of the whole GPU for its tail.  Resuming
+// restores the exact state, so the result of a ray does not depend on where it was cut.
+struct SuspendList {   // SoA over `cap` entries
+    float4* o;         // closest: ray o | slot        any: o | term index into L
+    float4* d;         // closest: ray d | key lo      any: d | poison bits
+    float4* b;         // closest: β | key hi          any: contribution β·Ld
+    float4* trav;      // t_max, hx, b1, b2
+    uint4* st;         // cur, cur_cnt, sp, found << 31 | (hit_prim + 1)
+    uint32_t* depth;   // closest: the path's depth tag
+    uint2* stack;      // [kStack2Total][cap]: {ref | cnt << 24, tx_min}
+    uint32_t cap;
+};
+struct StreamCtl {
+    SuspendList in, out;        // in: suspended in the previous round, resumed first; out: receives this round's suspensions
+    const uint32_t* in_count;   // entries of `in`
+    uint32_t* in_cursor;        // claim cursor over `in` (zeroed before the launch)
+    uint32_t* out_count;        // entries of `out` (zeroed before the launch)
+    uint32_t budget_min;        // a ray is suspended after max(budget_min, fresh rays >> budget_shift) interior fetches; 0 = never (drain round)
+    uint32_t budget_shift;
+    // closest: β and depth tags of the fresh rays (copied when one is suspended), and where a resumed ray that finished
+    // re-joins the round: appended to the live queue behind the fresh entries (the launch fetches through frozen counts)
+    const float4* beta_in;
+    const uint32_t* depth_in;
+    float4 *app_o, *app_d, *app_b, *app_hits;
+    uint32_t* app_depth;
+    uint32_t* app_counts;  // live fill counters of the queue (row of Counters::n_queue)
+    uint32_t app_cap;
+};
+
+template <bool ANY, bool COUNT, bool STREAM = false>
 __global__ __launch_bounds__(kBlock, TH_TRACE2_MIN_WAVES) void k_trace2(DeviceScene sc, WideScene ws, SegQueue q, const float4* __restrict__ ro, const float4* __restrict__ rd, const float* __restrict__ tmax_or_null,
-                                                   TraceOut out, uint32_t* __restrict__ work /* kSeg cursors, zeroed */, uint2* __restrict__ overflow, Counters* ctr, uint32_t debug_budget) {
+                                                   TraceOut out, uint32_t* __restrict__ work /* kSeg cursors, zeroed */, uint2* __restrict__ overflow, Counters* ctr, uint32_t debug_budget,
+                                                   StreamCtl sx = StreamCtl{}) {
     __shared__ uint32_t s_ref[kStack2Lds][kBlock];
     __shared__ float s_tmin[kStack2Lds][kBlock];
     __shared__ SegView sv;
@@ -91,11 +125,65 @@ __global__ __launch_bounds__(kBlock, TH_TRACE2_MIN_WAVES) void k_trace2(DeviceSc
     int hit_prim = -1;
     bool found = false;
     uint32_t nn = 0, np = 0;
+    // STREAM: resume bookkeeping
+    bool resume_done = !STREAM, resumed = false, no_suspend = false;
+    uint32_t rj = 0;
+    const uint32_t n_in = STREAM ? min(*sx.in_count, sx.in.cap) : 0u;
+    const uint32_t budget = STREAM && sx.budget_min ? max(sx.budget_min, sv.prefix[kSeg] >> sx.budget_shift) : 0u;
 
     while (true) {
         // ---- refill idle lanes ------------------------------------------------------------------------------------------------
         const unsigned long long idle = __ballot(!active);
         const uint32_t n_idle = (uint32_t)__popcll(idle);
+        if (STREAM && !resume_done && n_idle > 0u) {  // suspended rays of the previous round first
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(sx.in_cursor, n_idle);
+            base = __shfl(base, 0);
+            if (base >= n_in) {
+                resume_done = true;
+            } else {
+                if (!active) {
+                    const uint32_t j = base + (uint32_t)__popcll(idle & lt_mask);
+                    if (j < n_in) {
+                        const float4 o4 = sx.in.o[j], d4 = sx.in.d[j], tv = sx.in.trav[j];
+                        const uint4 st = sx.in.st[j];
+                        o = mk3(o4.x, o4.y, o4.z);
+                        d = mk3(d4.x, d4.y, d4.z);
+                        slot_w = o4.w;
+                        flag_w = d4.w;
+                        inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                        shear = ray_shear(d);
+                        negx = d.x < 0.0f;
+                        negy = d.y < 0.0f;
+                        negz = d.z < 0.0f;
+                        t_max = tv.x;
+                        hx = tv.y;
+                        b1 = tv.z;
+                        b2 = tv.w;
+                        cur = st.x;
+                        cur_cnt = st.y;
+                        sp = (int)st.z;
+                        found = (st.w >> 31) != 0u;
+                        hit_prim = (int)(st.w & 0x7fffffffu) - 1;
+                        for (int lvl = 0; lvl < sp && lvl < kStack2Total; ++lvl) {
+                            const uint2 e = sx.in.stack[(size_t)lvl * sx.in.cap + j];
+                            if (lvl < kStack2Lds) {
+                                s_ref[lvl][tid] = e.x;
+                                s_tmin[lvl][tid] = __uint_as_float(e.y);
+                            } else {
+                                overflow[(size_t)(lvl - kStack2Lds) * gthreads + gtid] = e;
+                            }
+                        }
+                        steps = 0;
+                        resumed = true;
+                        no_suspend = false;
+                        rj = j;
+                        active = true;
+                    }
+                }
+                continue;  // re-evaluate the idle lanes
+            }
+        }
         if (n_idle == 64u || (!exhausted && n_idle >= 12u)) {
             if (!exhausted) {
                 if (pool_next >= pool_end) {  // take the next chunk: try this wave's segment, move on when it is drained
@@ -134,6 +222,8 @@ __global__ __launch_bounds__(kBlock, TH_TRACE2_MIN_WAVES) void k_trace2(DeviceSc
                         found = false;
                         hit_prim = -1;
                         b1 = b2 = 0.0f;
+                        resumed = false;
+                        no_suspend = false;
                         active = true;
                         float tmin;
                         if (COUNT) nn++;
@@ -149,7 +239,7 @@ __global__ __launch_bounds__(kBlock, TH_TRACE2_MIN_WAVES) void k_trace2(DeviceSc
                 pool_next += min(n_idle, avail);
             }
             if (__ballot(active) == 0ull) {
-                if (exhausted) break;
+                if (exhausted && resume_done) break;
                 continue;  // nothing fetched yet (chunk ran dry / segment drained): try again
             }
         }
@@ -209,6 +299,33 @@ __global__ __launch_bounds__(kBlock, TH_TRACE2_MIN_WAVES) void k_trace2(DeviceSc
                     cur = kRefNone;
                     continue;
                 }
+                if (STREAM && budget && !no_suspend && ++steps > budget) {  // suspend: the next round goes on from exactly here
+                    const uint32_t j = atomicAdd(sx.out_count, 1u);
+                    if (j < sx.out.cap) {
+                        sx.out.o[j] = make_float4(o.x, o.y, o.z, slot_w);
+                        sx.out.d[j] = make_float4(d.x, d.y, d.z, flag_w);
+                        if (ANY) {
+                            sx.out.b[j] = resumed ? sx.in.b[rj] : out.contrib[idx];
+                        } else {
+                            sx.out.b[j] = resumed ? sx.in.b[rj] : sx.beta_in[idx];
+                            sx.out.depth[j] = resumed ? sx.in.depth[rj] : sx.depth_in[idx];
+                            if (!resumed) out.hits[idx] = make_float4(0.0f, __int_as_float(-2), 0.0f, 0.0f);  // pending: the shading kernel skips it
+                        }
+                        sx.out.trav[j] = make_float4(t_max, hx, b1, b2);
+                        sx.out.st[j] = make_uint4(cur, cur_cnt, (uint32_t)sp, (found ? 0x80000000u : 0u) | (uint32_t)(hit_prim + 1));
+                        for (int lvl = 0; lvl < sp && lvl < kStack2Total; ++lvl) {
+                            uint2 e;
+                            if (lvl < kStack2Lds)
+                                e = make_uint2(s_ref[lvl][tid], __float_as_uint(s_tmin[lvl][tid]));
+                            else
+                                e = overflow[(size_t)(lvl - kStack2Lds) * gthreads + gtid];
+                            sx.out.stack[(size_t)lvl * sx.out.cap + j] = e;
+                        }
+                        active = false;
+                        continue;
+                    }
+                    no_suspend = true;  // the list is full: this ray runs to its end here
+                }
                 float tl, tr;
                 const bool hl = slab_test2(a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, o, inv_d, negx, negy, negz, tl);
                 const bool hr = slab_test2(a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, o, inv_d, negx, negy, negz, tr);
@@ -252,6 +369,9 @@ __global__ __launch_bounds__(kBlock, TH_TRACE2_MIN_WAVES) void k_trace2(DeviceSc
                         const uint2 e = overflow[(size_t)(sp - kStack2Lds) * gthreads + gtid];
                         enc = e.x;
                         tm = __uint_as_float(e.y);
+#ifdef TH_DIAG_OVERFLOW_POPS
+                        if (COUNT) np += 1000u;  // DIAGNOSTIC: pops served by the global slab, reported through prims_tested / 1e3
+#endif
                     } else {
                         continue;  // beyond 64 levels the reference throws (bvh.jl:222); entries were dropped
                     }
@@ -269,7 +389,7 @@ __global__ __launch_bounds__(kBlock, TH_TRACE2_MIN_WAVES) void k_trace2(DeviceSc
                     if (out.L) {
                         const uint32_t slot = __float_as_uint(slot_w);
                         if (!found) {
-                            const float4 c = out.contrib[idx];
+                            const float4 c = (STREAM && resumed) ? sx.in.b[rj] : out.contrib[idx];
                             float4 l = out.L[slot];
                             l.x += c.x;
                             l.y += c.y;
@@ -288,6 +408,17 @@ __global__ __launch_bounds__(kBlock, TH_TRACE2_MIN_WAVES) void k_trace2(DeviceSc
                         }
                     } else {
                         out.occluded[idx] = found ? 1 : 0;
+                    }
+                } else if (STREAM && resumed) {  // re-join the round: append path + hit behind the fresh entries of the live queue
+                    const uint32_t seg = rj % (uint32_t)kSeg;
+                    const uint32_t k = atomicAdd(&sx.app_counts[seg * kCtrStride], 1u);
+                    if (k < sx.app_cap) {  // cannot fail: every segment keeps list-capacity / kSeg + 1 spare entries
+                        const uint32_t a = seg * sx.app_cap + k;
+                        sx.app_o[a] = make_float4(o.x, o.y, o.z, slot_w);
+                        sx.app_d[a] = make_float4(d.x, d.y, d.z, flag_w);
+                        sx.app_b[a] = sx.in.b[rj];
+                        sx.app_depth[a] = sx.in.depth[rj];
+                        sx.app_hits[a] = make_float4(found ? hx : kInf, __int_as_float(found ? hit_prim : -1), b1, b2);
                     }
                 } else {
                     out.hits[idx] = make_float4(found ? hx : kInf, __int_as_float(found ? hit_prim : -1), b1, b2);

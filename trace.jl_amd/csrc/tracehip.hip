@@ -62,6 +62,14 @@ struct trhip_ctx {
     // SPPM state (th_sppm.h): per film pixel, kept after trhip_render_sppm for trhip_sppm_state
     DevBuf sp_vp[7], sp_Ld, sp_tau, sp_radius, sp_N, sp_phi, sp_M, sp_counts, sp_starts, sp_entries, sp_grid, sp_ldist, sp_snap_M, sp_snap_phi, sp_snap_p, sp_snap_beta;
     DevBuf sp_terms, sp_rec[3], sp_rec_valid;
+    // streaming wavefront (render_stream_impl)
+    DevBuf st_terms, st_tags[2], st_frozen, st_counts, st_list[2][2][7];  // [closest|any][ping-pong][o, d, b, trav, st, depth, stack]
+    int streaming = -1;            // PathIntegrator on scenes with a real hierarchy: suspend / resume stragglers.  1 = always, 0 = never (classic
+                                   // per-depth launches), -1 = automatic: when a launch holds few rays (<= 32 M camera samples), which is where
+                                   // the traversal tails dominate (measured, 1 M triangles: 16 spp 1170 -> 716 ms; 256 spp 3742 vs 3823 ms)
+    uint32_t stream_budget_shift = 12;  // budget = max(stream_budget_min, fresh rays of the round >> shift)
+    uint32_t stream_list_cap = 0;       // suspended-ray list capacity (0 = max(65536, paths / 128)); tests shrink it
+    uint32_t stream_budget_min = 2048;  // interior fetches before a ray may be suspended (tests lower it to force suspensions)
     uint64_t sppm_batch = 0;  // SPPM iterations per wavefront batch (0 = from free HBM, at most 32)
     uint32_t sp_pixels = 0;
     int64_t sp_photons = 0;
@@ -641,6 +649,203 @@ int render_whitted_impl(trhip_ctx* ctx, const trhip_scene* scene, const DeviceSe
     return 0;
 }
 
+// PathIntegrator as a STREAMING wavefront (th_trace2.h "streaming wavefront"): rounds instead of depths.  A round
+// traces every queued ray with a fetch budget, resumes the rays suspended in the round before, shades what finished (entries
+// carry their own depth), and traces the shadow rays the same way.  max_depth + 16 budgeted rounds, then max_depth rounds
+// without a budget, which complete whatever is left.  Radiance terms go to per-depth slots and are folded in depth order, so
+// the per-sample radiance (and the film) is bit-identical to the classic per-depth wavefront.
+int render_stream_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sensor* sensor, const DeviceSensor& ds, uint32_t spp, int max_depth, uint64_t seed, uint32_t sample_offset, void* out,
+                       bool out_is_device, trhip_stats* stats, bool* declined) {
+    *declined = true;
+    const uint64_t npix = (uint64_t)ds.sb_w * ds.sb_h;
+    const uint64_t total_slots = npix * spp;
+    const int R_b = max_depth + 16, R = R_b + max_depth;
+    if (R + 1 > kMaxDepth + 1) return 0;
+    if ((uint64_t)max_depth * total_slots >= (1ull << 32)) return 0;
+    if (total_slots >= (1ull << 31)) return 0;  // one batch: queue indices are 32-bit
+    const uint64_t P = total_slots;
+    const uint32_t list_cap = ctx->stream_list_cap ? ctx->stream_list_cap : (uint32_t)std::max<uint64_t>(65536, P / 128);
+    const uint32_t cap = (uint32_t)(((P + kSeg - 1) / kSeg + 2 * kSegGran + list_cap / kSeg + 64 + kSegGran - 1) / kSegGran * kSegGran);
+    const uint64_t Pphys = (uint64_t)cap * kSeg;
+    const size_t list_bytes = (size_t)list_cap * (4 * 16 + 16 + 4 + (size_t)kStack2Total * 8);
+    const size_t terms_bytes = (size_t)max_depth * total_slots * sizeof(float4);
+    const size_t need = terms_bytes + Pphys * (10 * 16 + 2 * 4) + 4 * list_bytes + total_slots * 24 + (3ull << 30);
+    {
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
+        size_t held = ctx->Lbuf.bytes + ctx->pfilm.bytes + ctx->st_terms.bytes + ctx->st_tags[0].bytes + ctx->st_tags[1].bytes;
+        Pipe& p0 = ctx->pipes[0];
+        held += p0.hits.bytes;
+        for (auto& a : p0.q)
+            for (auto& b : a) held += b.bytes;
+        for (auto& b : p0.sq) held += b.bytes;
+        for (auto& a : ctx->st_list)
+            for (auto& b : a)
+                for (auto& c : b) held += c.bytes;
+        if ((double)need > 0.9 * (double)(free_b + held)) return 0;  // does not fit as one batch: the classic path cuts the frame into batches
+    }
+    *declined = false;
+    Pipe& pp = ctx->pipes[0];
+    if (!pp.st) {
+        HIP_TRY(ctx, hipStreamCreate(&pp.st));
+        HIP_TRY(ctx, hipStreamCreate(&pp.st2));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&pp.ev_shade, hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&pp.ev_any, hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&pp.ev_done, hipEventDisableTiming));
+    }
+    if (int rc = upload(ctx, ctx->sensor, &ds, sizeof ds)) return rc;
+    if (int rc = upload(ctx, ctx->table, sensor->filter_table, 256 * sizeof(float))) return rc;
+    for (int k = 0; k < 2; ++k)
+        for (int j = 0; j < 3; ++j)
+            if (int rc = ensure(ctx, pp.q[k][j], Pphys * sizeof(float4))) return rc;
+    for (int j = 0; j < 3; ++j)
+        if (int rc = ensure(ctx, pp.sq[j], Pphys * sizeof(float4))) return rc;
+    if (int rc = ensure(ctx, pp.hits, Pphys * sizeof(float4))) return rc;
+    if (int rc = ensure(ctx, pp.counters, sizeof(Counters))) return rc;
+    const size_t slab_bytes = (size_t)trace_grid(ctx) * kBlock * (size_t)(kStack2Total - kStack2Lds) * sizeof(uint2);
+    for (int k = 0; k < 2; ++k)
+        if (int rc = ensure(ctx, pp.overflow[k], slab_bytes)) return rc;
+    if (int rc = ensure(ctx, ctx->Lbuf, total_slots * sizeof(float4))) return rc;
+    if (int rc = ensure(ctx, ctx->pfilm, total_slots * sizeof(float2))) return rc;
+    if (int rc = ensure(ctx, ctx->st_terms, terms_bytes)) return rc;
+    for (int k = 0; k < 2; ++k)
+        if (int rc = ensure(ctx, ctx->st_tags[k], Pphys * sizeof(uint32_t))) return rc;
+    const size_t row_bytes = (size_t)kSeg * kCtrStride * sizeof(uint32_t);
+    if (int rc = ensure(ctx, ctx->st_frozen, row_bytes)) return rc;
+    if (int rc = ensure(ctx, ctx->st_counts, 16 * sizeof(uint32_t))) return rc;
+    const size_t field_bytes[7] = {16, 16, 16, 16, 16, 4, (size_t)kStack2Total * 8};
+    for (int kind = 0; kind < 2; ++kind)
+        for (int pg = 0; pg < 2; ++pg)
+            for (int f = 0; f < 7; ++f)
+                if (int rc = ensure(ctx, ctx->st_list[kind][pg][f], (size_t)list_cap * field_bytes[f])) return rc;
+    const size_t film_bytes = (size_t)ds.film_w * ds.film_h * sizeof(float4);
+    void* d_film = out;
+    if (!out_is_device) {
+        if (int rc = ensure(ctx, ctx->film, film_bytes)) return rc;
+        d_film = ctx->film.p;
+    }
+    auto list_of = [&](int kind, int pg) {
+        DevBuf* b = ctx->st_list[kind][pg];
+        return SuspendList{(float4*)b[0].p, (float4*)b[1].p, (float4*)b[2].p, (float4*)b[3].p, (uint4*)b[4].p, (uint32_t*)b[5].p, (uint2*)b[6].p, list_cap};
+    };
+    uint32_t* lc = (uint32_t*)ctx->st_counts.p;  // [0..1] closest list counts (ping-pong), [2] closest cursor, [4..5] any counts, [6] any cursor
+    hipStream_t st = ctx->stream, ps = pp.st, ps2 = ctx->overlap ? pp.st2 : pp.st;
+    const DeviceSensor* dsp = (const DeviceSensor*)ctx->sensor.p;
+    float4* L = (float4*)ctx->Lbuf.p;
+    float4* terms = (float4*)ctx->st_terms.p;
+    Counters* ctr = (Counters*)pp.counters.p;
+    PathQueue pq[2];
+    for (int k = 0; k < 2; ++k) pq[k] = PathQueue{(float4*)pp.q[k][0].p, (float4*)pp.q[k][1].p, (float4*)pp.q[k][2].p};
+    uint32_t* tags[2] = {(uint32_t*)ctx->st_tags[0].p, (uint32_t*)ctx->st_tags[1].p};
+    ShadowQueue sq{(float4*)pp.sq[0].p, (float4*)pp.sq[1].p, (float4*)pp.sq[2].p};
+    float4* hits = (float4*)pp.hits.p;
+    uint32_t* frozen = (uint32_t*)ctx->st_frozen.p;
+    const bool cnt = ctx->count_visits;
+
+    Timer tm(ctx, ctx->timing && stats);
+    hipEvent_t e0, e1, ev_start;
+    HIP_TRY(ctx, hipEventCreate(&e0));
+    HIP_TRY(ctx, hipEventCreate(&e1));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&ev_start, hipEventDisableTiming));
+    HIP_TRY(ctx, hipEventRecord(e0, st));
+    HIP_TRY(ctx, hipMemsetAsync(terms, 0, terms_bytes, st));
+    HIP_TRY(ctx, hipEventRecord(ev_start, st));
+    HIP_TRY(ctx, hipStreamWaitEvent(ps, ev_start, 0));
+    HIP_TRY(ctx, hipMemsetAsync(ctr, 0, sizeof(Counters), ps));
+    HIP_TRY(ctx, hipMemsetAsync(lc, 0, 16 * sizeof(uint32_t), ps));
+    tm.begin(0, ps);
+    hipLaunchKernelGGL(k_raygen, dim3(grid_for(ctx, P, 8)), dim3(kBlock), 0, ps, dsp, 0u, (uint32_t)P, seed, sample_offset, pq[0], cap, ctr);
+    hipLaunchKernelGGL(k_fill_u32, dim3(grid_for(ctx, Pphys, 8)), dim3(kBlock), 0, ps, tags[0], Pphys, 1u);
+    tm.end(0, ps);
+    const dim3 grid(trace_grid(ctx)), block(kBlock);
+    const int g_shade = ctx->num_cu * 8;
+    int cur = 0;
+    for (int r = 0; r < R; ++r) {
+        const uint32_t budget_min = r < R_b ? ctx->stream_budget_min : 0u;  // the last max_depth rounds run every ray to its end
+        const int in_pg = r & 1, out_pg = (r + 1) & 1;
+        // ---- closest hits: fresh rays through frozen counts (finished resumed rays are appended to the live queue) ----
+        HIP_TRY(ctx, hipMemcpyAsync(frozen, ctr->n_queue[r], row_bytes, hipMemcpyDeviceToDevice, ps));
+        HIP_TRY(ctx, hipMemsetAsync(&lc[out_pg], 0, sizeof(uint32_t), ps));
+        HIP_TRY(ctx, hipMemsetAsync(&lc[2], 0, sizeof(uint32_t), ps));
+        StreamCtl sc_c{list_of(0, in_pg), list_of(0, out_pg), &lc[in_pg], &lc[2], &lc[out_pg], budget_min, ctx->stream_budget_shift, pq[cur].beta, tags[cur], pq[cur].o, pq[cur].d, pq[cur].beta, hits, tags[cur],
+                       ctr->n_queue[r], cap};
+        const SegQueue qc{frozen, cap, 0u};
+        const TraceOut oc{hits, nullptr, nullptr, nullptr, 1u};
+        tm.begin(1, ps);
+        if (cnt)
+            hipLaunchKernelGGL((k_trace2<false, true, true>), grid, block, 0, ps, scene->dev, scene->wide, qc, pq[cur].o, pq[cur].d, nullptr, oc, ctr->work_closest[r], (uint2*)pp.overflow[0].p, ctr, 0u, sc_c);
+        else
+            hipLaunchKernelGGL((k_trace2<false, false, true>), grid, block, 0, ps, scene->dev, scene->wide, qc, pq[cur].o, pq[cur].d, nullptr, oc, ctr->work_closest[r], (uint2*)pp.overflow[0].p, ctr, 0u, sc_c);
+        tm.end(1, ps);
+        if (ps2 != ps && r > 0) HIP_TRY(ctx, hipStreamWaitEvent(ps, pp.ev_any, 0));  // shade(r) reuses the shadow queue
+        tm.begin(2, ps);
+        hipLaunchKernelGGL(k_shade_path<true>, dim3(g_shade), dim3(kBlock), 0, ps, scene->dev, dsp, pq[cur], pq[cur ^ 1], sq, cap, hits, terms, ctr, r, 0, max_depth, 1u,
+                           ShadeStream{tags[cur], tags[cur ^ 1], (uint32_t)total_slots});
+        tm.end(2, ps);
+        if (ps2 != ps) {
+            HIP_TRY(ctx, hipEventRecord(pp.ev_shade, ps));
+            HIP_TRY(ctx, hipStreamWaitEvent(ps2, pp.ev_shade, 0));
+        }
+        // ---- shadow rays: unoccluded ones add their contribution to the term slot ----
+        HIP_TRY(ctx, hipMemsetAsync(&lc[4 + out_pg], 0, sizeof(uint32_t), ps2));
+        HIP_TRY(ctx, hipMemsetAsync(&lc[6], 0, sizeof(uint32_t), ps2));
+        StreamCtl sc_a{list_of(1, in_pg), list_of(1, out_pg), &lc[4 + in_pg], &lc[6], &lc[4 + out_pg], budget_min, ctx->stream_budget_shift, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0u};
+        const SegQueue qa{ctr->n_shadow[r], cap, 0u};
+        const TraceOut oa{nullptr, terms, sq.c, nullptr, 0u};
+        tm.begin(3, ps2);
+        if (cnt)
+            hipLaunchKernelGGL((k_trace2<true, true, true>), grid, block, 0, ps2, scene->dev, scene->wide, qa, sq.o, sq.d, nullptr, oa, ctr->work_shadow[r], (uint2*)pp.overflow[1].p, ctr, 0u, sc_a);
+        else
+            hipLaunchKernelGGL((k_trace2<true, false, true>), grid, block, 0, ps2, scene->dev, scene->wide, qa, sq.o, sq.d, nullptr, oa, ctr->work_shadow[r], (uint2*)pp.overflow[1].p, ctr, 0u, sc_a);
+        tm.end(3, ps2);
+        if (ps2 != ps) HIP_TRY(ctx, hipEventRecord(pp.ev_any, ps2));
+        cur ^= 1;
+    }
+    if (ps2 != ps) HIP_TRY(ctx, hipStreamWaitEvent(ps, pp.ev_any, 0));
+    tm.begin(2, ps);
+    hipLaunchKernelGGL(k_fold_terms, dim3(grid_for(ctx, total_slots, 8)), dim3(kBlock), 0, ps, (const float4*)terms, total_slots, (uint32_t)max_depth, L);
+    tm.end(2, ps);
+    HIP_TRY(ctx, hipEventRecord(pp.ev_done, ps));
+    HIP_TRY(ctx, hipStreamWaitEvent(st, pp.ev_done, 0));
+    tm.begin(4, st);
+    launch_film(ctx, st, ds, dsp, L, total_slots, spp, seed, sample_offset, (float4*)d_film);
+    tm.end(4, st);
+    HIP_TRY(ctx, hipEventRecord(e1, st));
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    ctx->last_L_count = total_slots;
+    if (!out_is_device) HIP_TRY(ctx, hipMemcpy(out, d_film, film_bytes, hipMemcpyDeviceToHost));
+    uint32_t left[8];
+    HIP_TRY(ctx, hipMemcpy(left, lc, sizeof left, hipMemcpyDeviceToHost));
+    if (stats) {
+        std::memset(stats, 0, sizeof *stats);
+        stats->camera_samples = total_slots;
+        Counters h;
+        HIP_TRY(ctx, hipMemcpy(&h, ctr, sizeof h, hipMemcpyDeviceToHost));
+        stats->closest_rays = h.closest_total;
+        stats->shadow_rays = h.shadow_total;
+        stats->nodes_visited = h.nodes_closest;
+        stats->prims_tested = h.prims_closest;
+        stats->nodes_visited_shadow = h.nodes_shadow;
+        stats->prims_tested_shadow = h.prims_shadow;
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        stats->ms_total = ms;
+        stats->ms_raygen = tm.total(0, &stats->launches_raygen);
+        stats->ms_trace_closest = tm.total(1, &stats->launches_trace_closest);
+        stats->ms_shade = tm.total(2, &stats->launches_shade);
+        stats->ms_trace_any = tm.total(3, &stats->launches_trace_any);
+        stats->ms_film = tm.total(4, &stats->launches_film);
+        stats->n_batches = 1;
+        stats->max_depth_reached = (uint32_t)max_depth;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipEventDestroy(ev_start);
+    if (left[R & 1] || left[4 + (R & 1)]) return fail(ctx, TRHIP_ERR_HIP, "streaming wavefront: %u + %u rays still suspended after the drain rounds", left[R & 1], left[4 + (R & 1)]);
+    return 0;
+}
+
 int render_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sensor* sensor, int integrator, uint32_t spp, int max_depth, uint64_t seed,
                 uint32_t sample_offset, void* out, bool out_is_device, trhip_stats* stats) {
     if (!ctx || !scene || !sensor || !out) return fail(ctx, TRHIP_ERR_INVALID, "null argument");
@@ -685,6 +890,11 @@ int render_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sensor* se
             stats->max_depth_reached = (uint32_t)max_depth;
         }
         return 0;
+    }
+    if ((ctx->streaming == 1 || (ctx->streaming < 0 && total_slots <= (32ull << 20))) && ctx->traversal == 2 && scene->wide_ok && scene->wide.root_cnt == 0 && scene->wide.root_ref != kRefNone && ctx->batch_paths == 0 && ctx->pipelines <= 1) {
+        bool declined = false;
+        const int rc = render_stream_impl(ctx, scene, sensor, ds, spp, max_depth, seed, sample_offset, out, out_is_device, stats, &declined);
+        if (!declined) return rc;
     }
     // wavefront batch = whole sample passes; per path in flight: 2 x 3 queue float4 + 3 shadow float4 + 1 hit float4 = 160 B
     uint64_t batch_paths = ctx->batch_paths;
@@ -787,7 +997,7 @@ int render_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sensor* se
             tm.end(1, ps);
             if (ps2 != ps && depth > 1) HIP_TRY(ctx, hipStreamWaitEvent(ps, pp.ev_any, 0));  // shade(d) reuses the shadow queue and touches L
             tm.begin(2, ps);
-            hipLaunchKernelGGL(k_shade_path, dim3(g_shade), dim3(kBlock), 0, ps, scene->dev, dsp, pq[cur], pq[cur ^ 1], sq, cap, hits, L, ctr, depth, max_depth, bary_mode);
+            hipLaunchKernelGGL(k_shade_path<false>, dim3(g_shade), dim3(kBlock), 0, ps, scene->dev, dsp, pq[cur], pq[cur ^ 1], sq, cap, hits, L, ctr, depth - 1, depth, max_depth, bary_mode, ShadeStream{nullptr, nullptr, 0u});
             tm.end(2, ps);
             if (ps2 != ps) {
                 HIP_TRY(ctx, hipEventRecord(pp.ev_shade, ps));
@@ -1178,6 +1388,14 @@ void trhip_shutdown(trhip_ctx* ctx) {
     release(ctx->wh_flags);
     release(ctx->occl);
     for (auto& b : ctx->sp_vp) release(b);
+    release(ctx->st_terms);
+    release(ctx->st_tags[0]);
+    release(ctx->st_tags[1]);
+    release(ctx->st_frozen);
+    release(ctx->st_counts);
+    for (auto& a : ctx->st_list)
+        for (auto& b : a)
+            for (auto& c : b) release(c);
     for (DevBuf* b : {&ctx->sp_Ld, &ctx->sp_tau, &ctx->sp_radius, &ctx->sp_N, &ctx->sp_phi, &ctx->sp_M, &ctx->sp_counts, &ctx->sp_starts, &ctx->sp_entries, &ctx->sp_grid, &ctx->sp_ldist,
                       &ctx->sp_snap_M, &ctx->sp_snap_phi, &ctx->sp_snap_p, &ctx->sp_snap_beta, &ctx->sp_terms, &ctx->sp_rec[0], &ctx->sp_rec[1], &ctx->sp_rec[2],
                       &ctx->sp_rec_valid})
@@ -1196,6 +1414,14 @@ int trhip_set_option(trhip_ctx* ctx, const char* name, int64_t value) {
         ctx->timing = value != 0;
     else if (!std::strcmp(name, "debug_trace_budget"))
         ctx->debug_trace_budget = (uint32_t)value;
+    else if (!std::strcmp(name, "streaming"))
+        ctx->streaming = value < 0 ? -1 : (value != 0 ? 1 : 0);
+    else if (!std::strcmp(name, "stream_budget_shift"))
+        ctx->stream_budget_shift = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(31, value));
+    else if (!std::strcmp(name, "stream_list_cap"))
+        ctx->stream_list_cap = (uint32_t)std::max<int64_t>(0, value);
+    else if (!std::strcmp(name, "stream_budget_min"))
+        ctx->stream_budget_min = (uint32_t)std::max<int64_t>(1, value);
     else if (!std::strcmp(name, "sppm_batch"))
         ctx->sppm_batch = (uint64_t)std::max<int64_t>(0, value);
     else if (!std::strcmp(name, "tiny_scene_prims"))
