@@ -206,7 +206,8 @@ int trhip_film_accumulate(trhip_ctx* ctx, const trhip_sensor* sensor, uint32_t s
 /* "count_visits" (0/1): instrumented traversal kernels fill nodes_visited / prims_tested.
  * "batch_paths": paths in flight per wavefront batch (0 = size from free HBM, the default).
  * "timing" (0/1): per-kernel HIP-event timing in trhip_stats (default 1).
- * "traversal" (1/2): 1 = literal accel/bvh.jl loop, 2 = children-in-parent nodes with per-lane ray replacement (default).
+ * "traversal" (1/2/3): 1 = literal accel/bvh.jl loop, 2 = children-in-parent nodes with per-lane ray replacement,
+ *     3 = 2 with the leaves of a wave postponed and tested together (default).  Same results bit for bit.
  * "overlap" (0/1): shadow rays of depth d on a second stream beside the closest-hit pass of depth d+1 (default 1).
  * "pipelines" (1..8): wavefront batches in flight at once (default 1).
  * "tiny_scene_prims" (0..255): scenes of at most this many primitives are committed as ONE leaf (default 16; 0 = never).

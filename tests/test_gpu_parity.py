@@ -8,13 +8,13 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=[2, 1], ids=["trace2", "trace1"])
+@pytest.fixture(autouse=True, params=[2, 3, 1], ids=["trace2", "trace3", "trace1"])
 def traversal(request, ctx):
-    """Every parity test runs with both traversal kernels: 2 = k_trace2 (children-in-parent nodes, per-lane ray
-    replacement; the default), 1 = the literal accel/bvh.jl loop."""
+    """Every parity test runs with all traversal kernels: 2 = k_trace2 (children-in-parent nodes, per-lane ray
+    replacement), 3 = k_trace3 (the same with leaves postponed and tested together), 1 = the literal accel/bvh.jl loop."""
     ctx.set_option("traversal", request.param)
     yield request.param
-    ctx.set_option("traversal", 2)
+    ctx.set_option("traversal", 3)
 
 
 def bits(a):
@@ -329,7 +329,7 @@ def test_streaming_wavefront_matches_classic_and_oracle(T, ob, ctx, traversal):
     stack and resumed in the next round; per-depth radiance terms are folded in order.  Film and per-sample radiance must
     equal the classic per-depth wavefront and the oracle bit for bit, whatever the budget (1 = every ray is cut at every
     interior node) and the list capacity (a full list makes rays run to their end in place)."""
-    if traversal != 2:
+    if traversal == 1:
         pytest.skip("streaming is built on k_trace2")
     scene = T.scenes.mesh_scene(24)
     cam = T.scenes.cornell_camera(32)

@@ -25,7 +25,7 @@ def main():
     ap.add_argument("--workload", default="mesh_1m")
     ap.add_argument("--rays", type=int, default=1 << 22)
     ap.add_argument("--repeat", type=int, default=5)
-    ap.add_argument("--traversal", type=int, nargs="+", default=[1, 2])
+    ap.add_argument("--traversal", type=int, nargs="+", default=[1, 2, 3])
     ap.add_argument("--res", type=int, default=1024)
     args = ap.parse_args()
     import torch

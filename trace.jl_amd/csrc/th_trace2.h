@@ -438,4 +438,255 @@ __global__ __launch_bounds__(kBlock, TH_TRACE2_MIN_WAVES) void k_trace2(DeviceSc
     }
 }
 
+// ---- k_trace3: k_trace2 with the work of a wave re-grouped ("while-while") ------------------------------------------------------
+// Measured on the 1 M-triangle scene, k_trace2 keeps 11.6 of 64 lanes busy per VALU instruction: in every step the lanes at an
+// interior node, the lanes at a leaf and the lanes popping run one after the other.  Here a wave alternates between two
+// phases: (A) lanes pop and step through interior nodes while lanes that reached a leaf wait, until at most kLeafWait lanes
+// are still descending; (B) every lane that holds a leaf tests its primitives.  Each ray performs exactly the operations it
+// performs in k_trace2, in the same order; only the interleaving across lanes differs, so the results are the same bit for bit.
+#ifndef TH_TRACE3_LEAF_WAIT
+#define TH_TRACE3_LEAF_WAIT 20
+#endif
+#ifndef TH_TRACE3_MAX_A
+#define TH_TRACE3_MAX_A 12
+#endif
+template <bool ANY, bool COUNT>
+__global__ __launch_bounds__(kBlock, TH_TRACE2_MIN_WAVES) void k_trace3(DeviceScene sc, WideScene ws, SegQueue q, const float4* __restrict__ ro, const float4* __restrict__ rd, const float* __restrict__ tmax_or_null,
+                                                   TraceOut out, uint32_t* __restrict__ work, uint2* __restrict__ overflow, Counters* ctr) {
+    __shared__ uint32_t s_ref[kStack2Lds][kBlock];
+    __shared__ float s_tmin[kStack2Lds][kBlock];
+    __shared__ SegView sv;
+    seg_load(q, sv);
+    const uint32_t tid = threadIdx.x;
+    const uint32_t gthreads = gridDim.x * kBlock;
+    const uint32_t gtid = blockIdx.x * kBlock + tid;
+    const uint32_t lane = lane_id();
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+
+    bool active = false, exhausted = false;
+    uint32_t wseg = (gtid >> 6) % kSeg, dry = 0, pool_next = 0, pool_end = 0;
+    uint32_t idx = 0, cur = kRefNone, cur_cnt = 0;
+    int sp = 0;
+    f3 o = splat3(0.0f), d = splat3(0.0f), inv_d = splat3(0.0f);
+    RayShear shear{0, 0.0f, 0.0f, 0.0f};
+    bool negx = false, negy = false, negz = false;
+    float t_max = 0.0f, b1 = 0.0f, b2 = 0.0f, hx = 0.0f, slot_w = 0.0f, flag_w = 0.0f;
+    int hit_prim = -1;
+    bool found = false;
+    uint32_t nn = 0, np = 0;
+
+    while (true) {
+        // ---- refill idle lanes (as k_trace2) ----------------------------------------------------------------------------------
+        const unsigned long long idle = __ballot(!active);
+        const uint32_t n_idle = (uint32_t)__popcll(idle);
+        if (n_idle == 64u || (!exhausted && n_idle >= 12u)) {
+            if (!exhausted) {
+                if (pool_next >= pool_end) {
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(&work[wseg * kCtrStride], (uint32_t)kChunk);
+                    base = __shfl(base, 0);
+                    const uint32_t cnt = sv.count[wseg];
+                    if (base < cnt) {
+                        pool_next = base;
+                        pool_end = min(base + (uint32_t)kChunk, cnt);
+                        dry = 0;
+                    } else {
+                        pool_next = pool_end = 0;
+                        wseg = (wseg + 1) % kSeg;
+                        if (++dry >= (uint32_t)kSeg) exhausted = true;
+                    }
+                }
+                const uint32_t avail = pool_end - pool_next;
+                if (avail && !active) {
+                    const uint32_t rank = (uint32_t)__popcll(idle & lt_mask);
+                    if (rank < avail) {
+                        idx = seg_phys(q, wseg, pool_next + rank);
+                        const float4 o4 = ro[idx], d4 = rd[idx];
+                        o = mk3(o4.x, o4.y, o4.z);
+                        d = mk3(d4.x, d4.y, d4.z);
+                        slot_w = o4.w;
+                        flag_w = d4.w;
+                        inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                        shear = ray_shear(d);
+                        negx = d.x < 0.0f;
+                        negy = d.y < 0.0f;
+                        negz = d.z < 0.0f;
+                        t_max = tmax_or_null ? tmax_or_null[idx] : kInf;
+                        sp = 0;
+                        found = false;
+                        hit_prim = -1;
+                        b1 = b2 = 0.0f;
+                        active = true;
+                        float tmin;
+                        if (COUNT) nn++;
+                        if (ws.root_ref != kRefNone && slab_test2(ws.root_box[0], ws.root_box[1], ws.root_box[2], ws.root_box[3], ws.root_box[4], ws.root_box[5], o, inv_d, negx, negy, negz, tmin) &&
+                            tmin < t_max) {
+                            cur = ws.root_ref;
+                            cur_cnt = ws.root_cnt;
+                        } else {
+                            cur = kRefNone;
+                            cur_cnt = 0;
+                        }
+                    }
+                }
+                pool_next += min(n_idle, avail);
+            }
+            if (__ballot(active) == 0ull) {
+                if (exhausted) break;
+                continue;
+            }
+        }
+        // ---- phase A: pop / interior steps; lanes holding a leaf wait ---------------------------------------------------------------
+#pragma unroll 1
+        for (int it = 0; it < TH_TRACE3_MAX_A; ++it) {
+            bool finished = false;
+            if (active && cur == kRefNone) {  // pop the next entry whose tx_min is still below t_max (bvh.jl:247-250 with the deferred clause)
+                finished = true;
+                while (sp > 0) {
+                    sp--;
+                    uint32_t enc;
+                    float tm;
+                    if (sp < kStack2Lds) {
+                        enc = s_ref[sp][tid];
+                        tm = s_tmin[sp][tid];
+                    } else if (sp < kStack2Total) {
+                        const uint2 e = overflow[(size_t)(sp - kStack2Lds) * gthreads + gtid];
+                        enc = e.x;
+                        tm = __uint_as_float(e.y);
+                    } else {
+                        continue;
+                    }
+                    if (tm < t_max) {
+                        cur = enc & 0x00ffffffu;
+                        cur_cnt = enc >> 24;
+                        finished = false;
+                        break;
+                    }
+                }
+            }
+            if (finished) {  // the ray is done: deliver (as k_trace2)
+                active = false;
+                if (ANY) {
+                    if (out.L) {
+                        const uint32_t slot = __float_as_uint(slot_w);
+                        if (!found) {
+                            const float4 c = out.contrib[idx];
+                            float4 l = out.L[slot];
+                            l.x += c.x;
+                            l.y += c.y;
+                            l.z += c.z;
+                            out.L[slot] = l;
+                        } else {
+                            const uint32_t poison = __float_as_uint(flag_w);
+                            if (poison) {
+                                float4 l = out.L[slot];
+                                const float nanv = __builtin_nanf("");
+                                if (poison & 1u) l.x += nanv;
+                                if (poison & 2u) l.y += nanv;
+                                if (poison & 4u) l.z += nanv;
+                                out.L[slot] = l;
+                            }
+                        }
+                    } else {
+                        out.occluded[idx] = found ? 1 : 0;
+                    }
+                } else {
+                    out.hits[idx] = make_float4(found ? hx : kInf, __int_as_float(found ? hit_prim : -1), b1, b2);
+                }
+            }
+            if (active && cur != kRefNone && cur_cnt == 0) {  // interior: one 64-byte burst, both child boxes
+                const float4 a0 = ws.wnodes[4 * (size_t)cur], a1 = ws.wnodes[4 * (size_t)cur + 1], a2 = ws.wnodes[4 * (size_t)cur + 2], a3 = ws.wnodes[4 * (size_t)cur + 3];
+                if (COUNT) nn += 2;
+                float tl, tr;
+                const bool hl = slab_test2(a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, o, inv_d, negx, negy, negz, tl);
+                const bool hr = slab_test2(a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, o, inv_d, negx, negy, negz, tr);
+                const uint32_t lref = __float_as_uint(a3.x), rref = __float_as_uint(a3.y), packed = __float_as_uint(a3.z);
+                const uint32_t lcnt = packed & 0xffu, rcnt = (packed >> 8) & 0xffu, axis = (packed >> 16) & 3u;
+                const bool neg = axis == 0 ? negx : (axis == 1 ? negy : negz);
+                const bool hn = neg ? hr : hl, hf = neg ? hl : hr;
+                const float tn = neg ? tr : tl, tf = neg ? tl : tr;
+                const uint32_t nref = neg ? rref : lref, fref = neg ? lref : rref, ncnt = neg ? rcnt : lcnt, fcnt = neg ? lcnt : rcnt;
+                if (hn && tn < t_max) {
+                    if (hf) {
+                        const uint32_t enc = fref | (fcnt << 24);
+                        if (sp < kStack2Lds) {
+                            s_ref[sp][tid] = enc;
+                            s_tmin[sp][tid] = tf;
+                        } else if (sp < kStack2Total) {
+                            overflow[(size_t)(sp - kStack2Lds) * gthreads + gtid] = make_uint2(enc, __float_as_uint(tf));
+                        }
+                        sp++;
+                    }
+                    cur = nref;
+                    cur_cnt = ncnt;
+                } else if (hf && tf < t_max) {
+                    cur = fref;
+                    cur_cnt = fcnt;
+                } else {
+                    cur = kRefNone;
+                    cur_cnt = 0;
+                }
+            }
+            // lanes that can go on without touching a leaf; when few are left, everybody's leaves are tested together
+            const uint32_t n_desc = (uint32_t)__popcll(__ballot(active && cur_cnt == 0));
+            if (n_desc <= (uint32_t)TH_TRACE3_LEAF_WAIT) break;
+        }
+        // ---- phase B: leaves, primitives in slot order, later equal-t hit wins (bvh.jl:229-237, triangle_mesh.jl:211-214) ----------
+        if (active && cur != kRefNone && cur_cnt > 0) {
+            bool hit_any = false;
+            for (uint32_t k = 0; k < cur_cnt; ++k) {
+                const uint32_t slot = cur + k;
+                const float4 p0 = sc.prims[3 * slot];
+                const float4 p1 = sc.prims[3 * slot + 1], p2 = sc.prims[3 * slot + 2];
+                const uint32_t meta = __float_as_uint(p0.w);
+                if (COUNT) np++;
+                if (meta & PRIM_SPHERE) {
+                    SphereHit sh;
+                    if (sphere_intersect<false>(sc.spheres[__float_as_uint(p0.x)], o, d, t_max, sh)) {
+                        if (ANY) {
+                            hit_any = true;
+                            break;
+                        }
+                        t_max = sh.t;
+                        found = true;
+                        hit_prim = (int)slot;
+                        b1 = b2 = 0.0f;
+                        hx = sh.t;
+                    }
+                } else {
+                    TriTest tt;
+                    if (!(meta & PRIM_DEGENERATE) && tri_intersect_sheared<!ANY>(mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z), o, shear, t_max, &tt)) {
+                        if (ANY) {
+                            hit_any = true;
+                            break;
+                        }
+                        t_max = tt.t;
+                        found = true;
+                        hit_prim = (int)slot;
+                        b1 = tt.bary.x;
+                        b2 = tt.bary.y;
+                        hx = out.bary_mode ? tt.bary.z : tt.t;
+                    }
+                }
+            }
+            cur = kRefNone;
+            cur_cnt = 0;
+            if (ANY && hit_any) {  // intersect_p returns at the first accepted primitive: drop the stack, the pop in phase A delivers
+                found = true;
+                sp = 0;
+            }
+        }
+    }
+    if (ctr) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(ANY ? &ctr->shadow_total : &ctr->closest_total, (unsigned long long)seg_total(sv));
+        if (COUNT) {
+            const unsigned long long sn = wave_sum(nn), spr = wave_sum(np);
+            if (lane_id() == 0) {
+                atomicAdd(ANY ? &ctr->nodes_shadow : &ctr->nodes_closest, sn);
+                atomicAdd(ANY ? &ctr->prims_shadow : &ctr->prims_closest, spr);
+            }
+        }
+    }
+}
+
 }  // namespace th

@@ -55,7 +55,7 @@ struct trhip_ctx {
     int film_block = 1;  // film gather: 0 = one film pixel per thread, 1 = 2 x 2 pixels per thread (default), 2 = TH_FILM_BX x TH_FILM_BY
     bool film_tiled = false;  // LDS-staged film gather (k_film_gather_tiled): bit-identical, measured 2.7x SLOWER than k_film_gather (11 % lane use), kept as an option
     bool overlap = true;  // two-stream overlap of shadow rays (depth d) with closest-hit rays (depth d+1)
-    int traversal = 2;  // 1 = literal accel/bvh.jl loop, 2 = children-in-parent nodes + per-lane ray replacement
+    int traversal = 3;  // 1 = literal accel/bvh.jl loop, 2 = children-in-parent nodes + per-lane ray replacement, 3 = 2 with leaves postponed (while-while)
     // workspace (grown on demand, reused across calls)
     DevBuf q[2][3], sq[3], hits, Lbuf, pfilm, counters, sensor, table, film, scratch[4], overflow, wh_L, wh_parent, wh_coef, wh_pdf, wh_flags, occl;
     uint64_t last_L_count = 0;  // float4 entries valid in Lbuf
@@ -465,8 +465,24 @@ int ensure_overflow(trhip_ctx* ctx) {
 void launch_trace(trhip_ctx* ctx, hipStream_t st, const trhip_scene* sc, bool any, SegQueue q, const float4* ro, const float4* rd, const float* tmax, TraceOut out, uint32_t* work_cursors,
                   Counters* ctr, void* overflow_slab = nullptr) {
     const dim3 grid(trace_grid(ctx)), block(kBlock);
-    const bool v2 = ctx->traversal == 2 && sc->wide_ok;
+    const bool v2 = ctx->traversal >= 2 && sc->wide_ok;
     const bool cnt = ctx->count_visits;
+    if (v2 && ctx->traversal == 3 && sc->wide.root_cnt == 0) {  // k_trace3: leaves postponed and tested together ("while-while"); a single-leaf scene
+                                                                   // has nothing to postpone and runs k_trace2 (65 vs 73 ms on S-cornell)
+        uint2* ov = (uint2*)(overflow_slab ? overflow_slab : ctx->overflow.p);
+        if (any) {
+            if (cnt)
+                hipLaunchKernelGGL((k_trace3<true, true>), grid, block, 0, st, sc->dev, sc->wide, q, ro, rd, tmax, out, work_cursors, ov, ctr);
+            else
+                hipLaunchKernelGGL((k_trace3<true, false>), grid, block, 0, st, sc->dev, sc->wide, q, ro, rd, tmax, out, work_cursors, ov, ctr);
+        } else {
+            if (cnt)
+                hipLaunchKernelGGL((k_trace3<false, true>), grid, block, 0, st, sc->dev, sc->wide, q, ro, rd, tmax, out, work_cursors, ov, ctr);
+            else
+                hipLaunchKernelGGL((k_trace3<false, false>), grid, block, 0, st, sc->dev, sc->wide, q, ro, rd, tmax, out, work_cursors, ov, ctr);
+        }
+        return;
+    }
     if (v2) {
         uint2* ov = (uint2*)(overflow_slab ? overflow_slab : ctx->overflow.p);
         if (any) {
@@ -891,7 +907,7 @@ int render_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sensor* se
         }
         return 0;
     }
-    if ((ctx->streaming == 1 || (ctx->streaming < 0 && total_slots <= (32ull << 20))) && ctx->traversal == 2 && scene->wide_ok && scene->wide.root_cnt == 0 && scene->wide.root_ref != kRefNone && ctx->batch_paths == 0 && ctx->pipelines <= 1) {
+    if ((ctx->streaming == 1 || (ctx->streaming < 0 && total_slots <= (32ull << 20))) && ctx->traversal >= 2 && scene->wide_ok && scene->wide.root_cnt == 0 && scene->wide.root_ref != kRefNone && ctx->batch_paths == 0 && ctx->pipelines <= 1) {
         bool declined = false;
         const int rc = render_stream_impl(ctx, scene, sensor, ds, spp, max_depth, seed, sample_offset, out, out_is_device, stats, &declined);
         if (!declined) return rc;
@@ -968,7 +984,7 @@ int render_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sensor* se
     HIP_TRY(ctx, hipMemsetAsync(L, 0, total_slots * sizeof(float4), st));
     HIP_TRY(ctx, hipEventRecord(ev_start, st));
     const int g_shade = ctx->num_cu * 8;
-    const uint32_t bary_mode = (ctx->traversal == 2 && scene->wide_ok) ? 1u : 0u;  // k_trace2 hands the barycentrics to the shading kernel
+    const uint32_t bary_mode = (ctx->traversal >= 2 && scene->wide_ok) ? 1u : 0u;  // k_trace2 hands the barycentrics to the shading kernel
     uint32_t n_batches = 0;
     for (int pi = 0; pi < NP; ++pi) {
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->pipes[pi].st, ev_start, 0));
@@ -1436,7 +1452,7 @@ int trhip_set_option(trhip_ctx* ctx, const char* name, int64_t value) {
     } else if (!std::strcmp(name, "overlap"))
         ctx->overlap = value != 0;
     else if (!std::strcmp(name, "traversal")) {
-        if (value != 1 && value != 2) return fail(ctx, TRHIP_ERR_INVALID, "traversal must be 1 or 2");
+        if (value < 1 || value > 3) return fail(ctx, TRHIP_ERR_INVALID, "traversal must be 1, 2 or 3");
         ctx->traversal = (int)value;
     } else if (!std::strcmp(name, "batch_paths")) {
         if (value < 0) return fail(ctx, TRHIP_ERR_INVALID, "batch_paths must be >= 0 (0 = auto)");
