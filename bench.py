@@ -42,6 +42,49 @@ def traversal_bytes(rays, nodes, prims, hit_bytes):
     return 32 * rays + hit_bytes * rays + 32 * nodes + 48 * prims
 
 
+KERNEL_OF = {"trace_closest": "k_trace", "trace_any": "k_trace", "shade": "k_shade_path", "film": "k_film_gather", "raygen": "k_raygen"}
+
+
+def measure_traffic(args, dominant: str):
+    """HBM-side bytes per launch of the dominant kernel: FETCH_SIZE and WRITE_SIZE from two separate `rocprofv3 --pmc` child
+    runs of this same command (one step, no baseline), corrected as MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE
+    tallies 128-byte requests at 64 B: doubled; both counters are in KiB).  None when rocprofv3 is unavailable or fails."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None
+    want_any = dominant == "trace_any"
+    totals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out = tempfile.mkdtemp(prefix="trhip_pmc_", dir="/tmp")
+        cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "1", "--warmup", "0",
+               "--workload", args.workload, "--res", str(args.res), "--spp", str(args.spp), "--depth", str(args.depth), "--seed", str(args.seed), "--no-cpu-baseline", "--no-traffic"]
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600, check=True)
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            kb, n = 0.0, 0
+            for r in csv.DictReader(open(files[0])):
+                name = r["Kernel_Name"]
+                if KERNEL_OF[dominant] not in name or r["Counter_Name"] != counter:
+                    continue
+                if dominant.startswith("trace") and (("<true" in name) != want_any):
+                    continue
+                kb += float(r["Counter_Value"])
+                n += 1
+            if n == 0:
+                return None
+            totals[counter] = kb * 1024.0 / n
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+    return int(2.0 * totals["FETCH_SIZE"] + totals["WRITE_SIZE"])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -54,6 +97,7 @@ def main():
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED0001)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-spp", type=int, default=0, help="spp of the bounded CPU-baseline sample (0 = auto)")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child runs that fill roofline.traffic")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -143,6 +187,9 @@ def main():
                                        "shadow_nodes": round(sv.nodes_visited_shadow / max(1, sv.shadow_rays), 2), "shadow_prims": round(sv.prims_tested_shadow / max(1, sv.shadow_rays), 2)},
                     "kernel_ms_per_step": {k: round(v / args.steps, 3) for k, v in agg["ms"].items()},
                     "kernel_GBps": {k: round(per_step[k] / (agg["ms"][k] / args.steps * 1e-3) / 1e9, 1) if agg["ms"][k] > 0 else None for k in per_step}}
+        if world == 1 and not args.no_traffic:
+            roofline["traffic"] = measure_traffic(args, dominant)
+            roofline["traffic_note"] = "bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (rocprofv3 --pmc, separate child runs of this command with --steps 1; gfx950 correction)"
         # ---- CPU baseline: the oracle (faithful restatement, OpenMP over the reference's 16x16 tiles) on a bounded sample ----
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
