@@ -214,7 +214,7 @@ int trhip_film_accumulate(trhip_ctx* ctx, const trhip_sensor* sensor, uint32_t s
  *     Read by trhip_scene_commit; results do not depend on it except through the order coincident hits are visited in.
  * "streaming" (-1/0/1): PathIntegrator on scenes with a real BVH as a streaming wavefront: rays that exceed a fetch budget
  *     are suspended and resumed in the next round instead of holding up their launch; same result bit for bit.  -1 (default):
- *     automatic, for frames of at most 32 Mi camera samples, where launch tails dominate; 0 never; 1 always.
+ *     automatic, for frames of at most 96 camera samples per primitive, where launch tails dominate; 0 never; 1 always.
  *     "stream_budget_min" (default 2048), "stream_budget_shift" (12) and "stream_list_cap" (0 = automatic) tune it.
  * "sppm_batch": SPPM iterations whose camera / photon paths share the traversal launches (default 0 = as many as fit in
  *     free HBM, at most 32); the result does not depend on it.

@@ -65,8 +65,9 @@ struct trhip_ctx {
     // streaming wavefront (render_stream_impl)
     DevBuf st_terms, st_tags[2], st_frozen, st_counts, st_list[2][2][7];  // [closest|any][ping-pong][o, d, b, trav, st, depth, stack]
     int streaming = -1;            // PathIntegrator on scenes with a real hierarchy: suspend / resume stragglers.  1 = always, 0 = never (classic
-                                   // per-depth launches), -1 = automatic: when a launch holds few rays (<= 32 M camera samples), which is where
-                                   // the traversal tails dominate (measured, 1 M triangles: 16 spp 1170 -> 716 ms; 256 spp 3742 vs 3823 ms)
+                                   // per-depth launches), -1 = automatic: when the frame has at most 96 camera samples per primitive, which is where the
+                                   // traversal tails dominate (measured, 1 M triangles: 16 spp 1170 -> 716 ms, 64 spp 1700 -> 1443, 128 spp 2288 vs
+                                   // 2412, 256 spp 3742 vs 3823; 10 M triangles, depth 16: 32 spp 6075 -> 2465 ms, 128 spp 8364 -> 4913)
     uint32_t stream_budget_shift = 12;  // budget = max(stream_budget_min, fresh rays of the round >> shift)
     uint32_t stream_list_cap = 0;       // suspended-ray list capacity (0 = max(65536, paths / 128)); tests shrink it
     uint32_t stream_budget_min = 2048;  // interior fetches before a ray may be suspended (tests lower it to force suspensions)
@@ -907,7 +908,7 @@ int render_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sensor* se
         }
         return 0;
     }
-    if ((ctx->streaming == 1 || (ctx->streaming < 0 && total_slots <= (32ull << 20))) && ctx->traversal >= 2 && scene->wide_ok && scene->wide.root_cnt == 0 && scene->wide.root_ref != kRefNone && ctx->batch_paths == 0 && ctx->pipelines <= 1) {
+    if ((ctx->streaming == 1 || (ctx->streaming < 0 && total_slots <= 96ull * scene->prims.size())) && ctx->traversal >= 2 && scene->wide_ok && scene->wide.root_cnt == 0 && scene->wide.root_ref != kRefNone && ctx->batch_paths == 0 && ctx->pipelines <= 1) {
         bool declined = false;
         const int rc = render_stream_impl(ctx, scene, sensor, ds, spp, max_depth, seed, sample_offset, out, out_is_device, stats, &declined);
         if (!declined) return rc;
