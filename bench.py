@@ -32,6 +32,8 @@ def build_workload(T, name: str, res: int):
     if name in T.scenes.MESH_N:
         n = T.scenes.MESH_N[name]
         return T.scenes.mesh_scene(n), T.scenes.cornell_camera(res), f"S-mesh: Cornell box + {2 * n * n} triangle height field"
+    if name == "blob_870k":
+        return T.scenes.blob_scene(270), T.scenes.cornell_camera(res), "S-blob: Cornell walls + a closed bumpy object of ~870 k triangles (stand-in for configs[2], Dragon in Cornell box)"
     if name == "caustic":
         return T.scenes.caustic_scene(), T.scenes.caustic_camera(res), "S-caustic: procedural glass goblet (~88k triangles) on a plastic floor, SpotLight (docs/code/caustic_glass.jl)"
     raise SystemExit(f"unknown workload {name}")

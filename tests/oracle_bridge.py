@@ -240,7 +240,7 @@ class OracleScene:
                 mesh = p.shape.mesh
                 j = i
                 ks, mats = [], []
-                while j < len(prims) and isinstance(prims[j].shape, T.Triangle) and prims[j].shape.mesh is mesh:
+                while j < len(prims) and not isinstance(prims[j], T.MeshPrimitives) and isinstance(prims[j].shape, T.Triangle) and prims[j].shape.mesh is mesh:
                     ks.append(prims[j].shape.k)
                     mats.append(mid(prims[j].material))
                     j += 1

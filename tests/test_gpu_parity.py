@@ -358,3 +358,18 @@ def test_streaming_wavefront_matches_classic_and_oracle(T, ob, ctx, traversal):
         assert_bits_equal(L, classic_L, f"per-sample radiance, {opts}")
         assert_bits_equal(film, ref, f"film, {opts}")
         assert st.closest_rays == st0.closest_rays and st.shadow_rays == st0.shadow_rays, opts
+
+
+def test_render_closed_mesh_scene(T, ob, ctx):
+    """S-blob (a closed displaced cube-sphere in the Cornell walls; triangle primitives directly followed by a mesh group in the
+    scene list): film and per-sample radiance bit-exact."""
+    scene = T.scenes.blob_scene(10)
+    cam = T.scenes.cornell_camera(28)
+    flat = scene.flatten(ctx)
+    assert flat.bvh()[3].size == 10 + 12 * 10 * 10
+    osc = ob.OracleScene.from_scene(scene, bvh=flat.bvh())
+    ref, ref_L, _ = osc.render(cam, "path", 3, 5, seed=77, want_samples=True)
+    integ = T.PathIntegrator(cam, T.SeededSampler(3, seed=77), 5)
+    film = integ.render(scene, ctx)
+    assert_bits_equal(integ.sample_radiance(scene), ref_L, "per-sample radiance (S-blob)")
+    assert_bits_equal(film, ref, "film (S-blob)")

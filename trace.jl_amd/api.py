@@ -511,7 +511,7 @@ class FlatScene:
                 mesh = p.shape.mesh
                 j = i
                 ks, mats = [], []
-                while j < len(prims) and isinstance(prims[j].shape, Triangle) and prims[j].shape.mesh is mesh:
+                while j < len(prims) and not isinstance(prims[j], MeshPrimitives) and isinstance(prims[j].shape, Triangle) and prims[j].shape.mesh is mesh:
                     ks.append(prims[j].shape.k)
                     mats.append(material_id(prims[j].material))
                     j += 1

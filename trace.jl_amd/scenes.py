@@ -284,3 +284,62 @@ def caustic_camera(resolution: int = 1024, filename: str = ""):
     """docs/code/caustic_glass.jl:81-100."""
     film = T.Film([resolution, resolution], T.Bounds2(np.float32([0, 0]), np.float32([1, 1])), T.LanczosSincFilter([1.0, 1.0], 3.0), 1.0, 1.0, filename)
     return T.PerspectiveCamera(T.look_at([0, 150, 150], [-3, 0, -91], [0, 1, 0]), T.Bounds2(np.float32([-1, -1]), np.float32([1, 1])), 0.0, 1.0, 0.0, 1e6, 90.0, film)
+
+
+# ---- S-blob: a closed, bumpy object in the Cornell box (a stand-in for BASELINE.json configs[2], "Stanford Dragon in Cornell box") ----
+def blob_mesh(n: int, seed: int = 4321, amplitude: float = 0.05):
+    """A cube-sphere (6 faces of n x n quads, so the triangles are near-uniform) of radius 0.28 at (0.5, 0.4, -2.5), displaced
+    along the normal by a smooth function of the direction: 12 n^2 triangles, smooth vertex normals, shared vertices along the
+    cube edges (closed surface).  Returns (vertices (m, 3), 1-based indices, normals)."""
+    t = np.linspace(-1.0, 1.0, n + 1)
+    a, b = np.meshgrid(t, t, indexing="ij")
+    one = np.ones_like(a)
+    faces = [np.stack(c, -1) for c in ((one, a, b), (-one, b, a), (b, one, a), (a, -one, b), (a, b, one), (b, a, -one))]
+    pts = np.concatenate([f.reshape(-1, 3) for f in faces], axis=0)
+    # weld the duplicated edge / corner vertices: key on the exactly representable lattice coordinates
+    key = np.round((pts + 1.0) * (n / 2.0)).astype(np.int64)
+    uniq, inv = np.unique(key[:, 0] * (n + 1) ** 2 + key[:, 1] * (n + 1) + key[:, 2], return_inverse=True)
+    first = np.zeros(uniq.size, dtype=np.int64)
+    first[inv[::-1]] = np.arange(pts.shape[0])[::-1]
+    cube = pts[first]
+    dirs = cube / np.sqrt((cube ** 2).sum(1, keepdims=True))
+    x, y, z = dirs[:, 0], dirs[:, 1], dirs[:, 2]
+    rng = np.random.default_rng(seed)
+    bump = np.zeros_like(x)
+    for k in range(24):  # a few dozen smooth lobes: folds and creases like a scanned figure, no slivers
+        w = rng.normal(size=3)
+        w /= np.linalg.norm(w)
+        f = rng.uniform(3.0, 14.0)
+        bump += rng.uniform(0.3, 1.0) * np.sin(f * (x * w[0] + y * w[1] + z * w[2]) + rng.uniform(0, 6.28))
+    r = 0.28 + amplitude * bump / 6.0
+    verts = (np.array([0.5, 0.4, -2.5]) + r[:, None] * dirs).astype(np.float32)
+    i, j = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+    tris = []
+    for f in range(6):
+        base = f * (n + 1) ** 2
+        v00 = inv[base + i * (n + 1) + j]
+        v10 = inv[base + (i + 1) * (n + 1) + j]
+        v11 = inv[base + (i + 1) * (n + 1) + j + 1]
+        v01 = inv[base + i * (n + 1) + j + 1]
+        tris.append(np.stack([v00, v10, v11], -1).reshape(-1, 3))
+        tris.append(np.stack([v00, v11, v01], -1).reshape(-1, 3))
+    tris = np.concatenate(tris, axis=0)
+    pd = verts.astype(np.float64)
+    fn = np.cross(pd[tris[:, 1]] - pd[tris[:, 0]], pd[tris[:, 2]] - pd[tris[:, 0]])
+    out = (fn * (pd[tris[:, 0]] - np.array([0.5, 0.4, -2.5]))).sum(1) < 0  # orient every triangle outwards
+    tris[out] = tris[out][:, [0, 2, 1]]
+    fn[out] = -fn[out]
+    nrm = np.zeros_like(pd)
+    for k in range(3):
+        np.add.at(nrm, tris[:, k], fn)
+    nrm /= np.maximum(np.sqrt((nrm ** 2).sum(1, keepdims=True)), 1e-30)
+    return verts, (tris + 1).astype(np.uint32).reshape(-1), nrm.astype(np.float32)
+
+
+def blob_scene(n_lat: int = 270):
+    """S-blob: the Cornell walls + one closed bumpy matte object of 12 n² triangles (270 -> 874 800)."""
+    prims, _ = cornell_primitives(spheres=False)
+    grey = T.MatteMaterial(T.ConstantTexture(T.RGBSpectrum(0.75, 0.7, 0.6)), T.ConstantTexture(0.0))
+    verts, idx, nrm = blob_mesh(n_lat)
+    prims = prims + [T.create_mesh_primitives(T.ShapeCore(T.translate([0, 0, 0]), False), idx, verts, nrm, grey)]
+    return T.Scene(cornell_lights(), T.BVHAccel(prims, 1))
