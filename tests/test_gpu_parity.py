@@ -373,3 +373,41 @@ def test_render_closed_mesh_scene(T, ob, ctx):
     film = integ.render(scene, ctx)
     assert_bits_equal(integ.sample_radiance(scene), ref_L, "per-sample radiance (S-blob)")
     assert_bits_equal(film, ref, "film (S-blob)")
+
+
+def test_device_built_lbvh(T, ob, ctx):
+    """BVHAccel built on the device (th_lbvh.h, option bvh_builder = 1): a valid BVH2 in the reference's flat layout — every
+    primitive in exactly one leaf, first child = i + 1, child boxes inside their parent's, leaf boxes = primitive bounds — and
+    the same hits / film as the oracle walking that tree."""
+    ctx.set_option("bvh_builder", 1)
+    try:
+        scene = T.scenes.mesh_scene(40)  # 3 200 triangles + Cornell box + 2 spheres
+        flat = scene.flatten(ctx)
+    finally:
+        ctx.set_option("bvh_builder", -1)
+    bounds, a, flags, order = flat.bvh()
+    n = order.size
+    assert a.size == 2 * n - 1 and sorted(order.tolist()) == list(range(n))
+    leaf = (flags & 3) == 3
+    assert leaf.sum() == n and np.all(flags[leaf] >> 2 == 1) and sorted(a[leaf].tolist()) == list(range(n))
+    inner = np.flatnonzero(~leaf)
+    assert np.all(a[inner] > inner + 1) and np.all(a[inner] < a.size) and np.all(flags[inner] <= 2)
+    for child in (inner + 1, a[inner]):  # both children lie inside the parent box
+        assert np.all(bounds[child, :3] >= bounds[inner, :3]) and np.all(bounds[child, 3:] <= bounds[inner, 3:])
+    # subtree sizes: the second child starts right after the first child's subtree, the root spans everything
+    size = np.ones(a.size, np.int64)
+    for i in inner[::-1]:
+        size[i] = 1 + size[i + 1] + size[a[i]]
+        assert a[i] == i + 1 + size[i + 1]
+    assert size[0] == a.size
+    osc = ob.OracleScene.from_scene(scene, bvh=(bounds, a, flags, order))
+    wb = osc.world_bound()
+    rays = np.concatenate([camera_rays(T, ob, T.scenes.cornell_camera(64)), T.scenes.incoherent_rays(40000, wb[:3] - 0.2, wb[3:] + 0.2)])
+    got = flat.trace_closest(rays)
+    t_ref, prim_ref, _, _ = osc.trace_closest(rays)
+    assert np.array_equal(got["prim"], prim_ref)
+    assert_bits_equal(got["t"], t_ref, "t (device-built BVH)")
+    assert np.array_equal(flat.trace_any(rays), osc.trace_any(rays)[0])
+    cam = T.scenes.cornell_camera(24)
+    ref, _, _ = osc.render(cam, "path", 2, 5, seed=4)
+    assert_bits_equal(T.PathIntegrator(cam, T.SeededSampler(2, seed=4), 5).render(scene, ctx), ref, "film (device-built BVH)")
