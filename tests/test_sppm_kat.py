@@ -109,3 +109,24 @@ def test_sample_le_point_light(T, ob):
     # uniform_sample_sphere(0.5, 0.25): z = 0, r = 1, ϕ = π/2 (Trace.jl:69-74)
     assert abs(out[6]) < 1e-6 and out[7] == 1.0 and out[8] == 0.0
     assert out[9] == 1.0 and out[10] == f32(1.0) / (f32(4.0) * f32(np.pi))
+
+
+def test_sppm_first_iteration_update_formula(T, ob):
+    """_update_pixels! after one iteration (sppm.jl:438-459) from its formulas: N = Float32(2/3) * M (Float32 product, widened),
+    radius = Float32(r0 * sqrt(N / M)) evaluated in Float64, τ = (0 + ϕ) * (radius_new / r0)^2 rounded once."""
+    scene = T.scenes.cornell_scene()
+    cam = T.scenes.cornell_camera(24)
+    osc = ob.OracleScene.from_scene(scene)
+    r0 = np.float32(0.09)
+    r = osc.sppm(cam, r0, 4, 1, 4000, seed=2)
+    M, N, rad = r["M"], r["N"], r["radius"]
+    hit = M > 0
+    assert hit.sum() > 50
+    n_expect = (np.float32(2.0) / np.float32(3.0) * M[hit].astype(np.float32)).astype(np.float64)
+    assert np.array_equal(N[hit], n_expect)
+    rad_new64 = np.float64(r0) * np.sqrt(n_expect / M[hit].astype(np.float64))
+    assert np.array_equal(rad[hit], rad_new64.astype(np.float32))
+    assert np.all(rad[~hit] == r0) and np.all(N[~hit] == 0)
+    ratio2 = (rad_new64 / np.float64(r0)) ** 2
+    tau_expect = (r["phi"][hit].astype(np.float32).astype(np.float64) * ratio2[:, None]).astype(np.float32)
+    assert np.array_equal(r["tau"][hit], tau_expect)
