@@ -373,13 +373,14 @@ __global__ __launch_bounds__(kBlock) void k_trace_any(DeviceScene sc, SegQueue q
 // t_max = Inf reproduces the accepted candidate's barycentrics / hit point bit-for-bit: they do not depend on t_max).
 // With `bary` (hits written with TraceOut::bary_mode: {b2, prim, b0, b1}) the triangle test is not repeated: the stored
 // barycentrics ARE the accepted candidate's.
+template <bool TRI_ONLY = false>
 TH_D bool rebuild_shading(const DeviceScene& sc, int prim, f3 o, f3 d, Shading& sh, uint32_t& material, const float4* bary = nullptr) {
     // all six 16-byte loads are issued up front (independent of the sphere / normals flags) so that their latencies overlap
     const float4 p0 = sc.prims[3 * prim], p1 = sc.prims[3 * prim + 1], p2 = sc.prims[3 * prim + 2];
     const float4 na = sc.tri_nrm[3 * prim], nb = sc.tri_nrm[3 * prim + 1], nc = sc.tri_nrm[3 * prim + 2];
     const uint32_t meta = __float_as_uint(p0.w);
     material = meta & PRIM_MATERIAL_MASK;
-    if (meta & PRIM_SPHERE) {
+    if (!TRI_ONLY && (meta & PRIM_SPHERE)) {
         const SphereRec& s = sc.spheres[__float_as_uint(p0.x)];
         SphereHit h;
         if (!sphere_intersect<true>(s, o, d, kInf, h)) return false;
@@ -411,170 +412,178 @@ struct ShadeStream {
     uint32_t* tags_out;
     uint32_t term_stride;
 };
+struct ShadeOut {  // what one vertex emits: a shadow ray and / or the continuation of the path
+    bool want_shadow, want_next;
+    float4 so4, sd4, sc4, no4, nd4, nb4;
+    uint32_t next_depth;
+};
+// One PathIntegrator vertex for queue entry i (a real hit).  FAST: the caller has established that the hit is a triangle whose
+// material is a single LambertianReflection lobe; the sphere path and the general BSDF code are then not even compiled in.
+template <bool STREAM, bool FAST>
+TH_D void shade_vertex(const DeviceScene& sc, const PathQueue& qin, const float4* __restrict__ hits, float4* __restrict__ L, uint32_t i, int depth_fixed, int max_depth,
+                       uint32_t hits_have_bary, const ShadeStream& ss, ShadeOut& out) {
+    const float4 h4 = hits[i];
+    const int prim = __float_as_int(h4.y);
+    const float4 o4 = qin.o[i], d4 = qin.d[i], b4 = qin.beta[i];
+    const int depth = STREAM ? (int)ss.tags_in[i] : depth_fixed;
+    // where this vertex's radiance terms go: the sample's slot, or (STREAM) its per-depth term slot
+    const uint32_t slot = STREAM ? (uint32_t)(depth - 1) * ss.term_stride + __float_as_uint(o4.w) : __float_as_uint(o4.w);
+    const f3 o = mk3(o4.x, o4.y, o4.z), d = mk3(d4.x, d4.y, d4.z);
+    f3 beta = mk3(b4.x, b4.y, b4.z);
+    Shading sh;
+    uint32_t material;
+    if (!(rebuild_shading<FAST>(sc, prim, o, d, sh, material, hits_have_bary ? &h4 : nullptr) && material != PRIM_NO_MATERIAL)) return;
+    const LobeSet& bsdf = sc.materials[material].set[1];  // compute_scattering!(si, ray, true)
+    const bool lambert = FAST || bsdf_is_single_lambert(bsdf);  // specialised evaluation of the same arithmetic (th_device.h)
+    // the sampler stream key of this camera sample rides in the queue (k_raygen): no slot -> pixel division, no re-hash
+    const uint64_t key = ((uint64_t)__float_as_uint(b4.w) << 32) | (uint64_t)__float_as_uint(d4.w);
+    const uint32_t v = (uint32_t)(depth - 1);
+    const f3 wo = -d;  // sppm.jl:224
+    const uint32_t poison = ((isnan_(beta.x) || isinf_(beta.x)) ? 1u : 0u) | ((isnan_(beta.y) || isinf_(beta.y)) ? 2u : 0u) | ((isnan_(beta.z) || isinf_(beta.z)) ? 4u : 0u);
+    // ---- uniform_sample_one_light ----
+    bool direct_added = false;
+    if (sc.n_lights > 0) {
+        const int nl = (int)sc.n_lights;
+        int ln = (int)__builtin_ceilf(ts_uniform(key, ts_vertex_dim(v, TS_V_LIGHT_PICK)) * (float)nl);
+        if (ln > nl) ln = nl;
+        if (ln < 1) ln = 1;
+        const float light_pdf = 1.0f / (float)nl;
+        const LightRec& light = sc.lights[ln - 1];
+        const LightSample ls = sample_li(light, sh.p);
+        if (ls.pdf > 0.0f && !is_black(ls.radiance)) {
+            const f3 f = (lambert ? lambert_bsdf_f(bsdf.lobe[0], sh, sh.wo, ls.wi) : bsdf_f(bsdf, sh, sh.wo, ls.wi, BSDF_ALL & ~BSDF_SPECULAR)) * fabs_(dot(ls.wi, sh.ns));
+            if (!is_black(f)) {
+                // x / 1 == x exactly: δ-lights have pdf 1, a single light has light_pdf 1 (6 correctly rounded divisions saved)
+                const f3 fl = f * ls.radiance;
+                const f3 Ld1 = splat3(0.0f) + (ls.pdf == 1.0f ? fl : fl / ls.pdf);
+                const f3 Ld = light_pdf == 1.0f ? Ld1 : Ld1 / light_pdf;
+                const f3 c = beta * Ld;
+                const f3 lp = mk3(light.position[0], light.position[1], light.position[2]);
+                const f3 dir = lp - sh.p;  // spawn_ray(p0, p1) Trace.jl:196-202
+                const f3 org = sh.p + 1e-6f * dir;
+                const f3 cd = check_direction(dir);
+                out.so4 = make_float4(org.x, org.y, org.z, __uint_as_float(slot));
+                out.sd4 = make_float4(cd.x, cd.y, cd.z, __uint_as_float(poison));
+                out.sc4 = make_float4(c.x, c.y, c.z, 0.0f);
+                out.want_shadow = true;
+                direct_added = true;
+            }
+        }
+    }
+    if (!direct_added && poison) {  // L += β · 0 with a non-finite β
+        float4 l = L[slot];
+        const float nanv = __builtin_nanf("");
+        if (poison & 1u) l.x += nanv;
+        if (poison & 2u) l.y += nanv;
+        if (poison & 4u) l.z += nanv;
+        L[slot] = l;
+    }
+    // ---- continue the path ----
+    if (depth < max_depth) {
+        const f2 u{ts_uniform(key, ts_vertex_dim(v, TS_V_BSDF_U0)), ts_uniform(key, ts_vertex_dim(v, TS_V_BSDF_U1))};
+        const BsdfSample bs = lambert ? lambert_bsdf_sample_f(bsdf.lobe[0], sh, wo, u) : bsdf_sample_f(bsdf, sh, wo, u, BSDF_ALL);
+        if (!(bs.pdf == 0.0f || is_black(bs.f))) {
+            beta = beta * (bs.f * fabs_(dot(bs.wi, sh.ns)) / bs.pdf);
+            const float by = to_Y(beta);
+            bool alive = true;
+            if (by < 0.25f) {
+                const float cont = jmin(1.0f, by);
+                if (ts_uniform(key, ts_vertex_dim(v, TS_V_RR)) > cont)
+                    alive = false;
+                else
+                    beta = beta / cont;
+            }
+            if (alive) {
+                const f3 org = sh.p + 1e-6f * bs.wi;  // spawn_ray(si, wi) Trace.jl:206-211
+                const f3 nd = check_direction(bs.wi);
+                out.no4 = make_float4(org.x, org.y, org.z, o4.w);
+                out.nd4 = make_float4(nd.x, nd.y, nd.z, d4.w);
+                out.nb4 = make_float4(beta.x, beta.y, beta.z, b4.w);
+                out.next_depth = (uint32_t)(depth + 1);
+                out.want_next = true;
+            }
+        }
+    }
+}
+
+// The kernel proper.  Most vertices of most scenes are triangle hits on a matte surface; the rest (spheres, specular or
+// multi-lobe materials) run several times as many instructions.  Mixed in one wave they serialise (S-cornell: 108 ms against
+// 58 ms for the same box without its two spheres), so every wave shades its FAST entries at once and parks the indices of the
+// others in an LDS ring; whenever 64 are parked they are shaded together by the general code, with all lanes busy.
 template <bool STREAM>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TH_SHADE_WAVES))) void k_shade_path(DeviceScene sc, const DeviceSensor* __restrict__ sep, PathQueue qin, PathQueue qout, ShadowQueue sq, uint32_t cap,
                                                        const float4* __restrict__ hits, float4* __restrict__ L, Counters* ctr, int row, int depth_fixed, int max_depth, uint32_t hits_have_bary,
                                                        ShadeStream ss) {
     __shared__ SegView sv;
-    // The kernel is a chain of dependent memory round trips (28 us per wave-iteration at 4 waves/SIMD, VALU 15 % busy): the
-    // material and light tables, reached through two of those trips, are staged in LDS when they are small.
-    __shared__ __attribute__((aligned(16))) uint32_t s_tab[(kLdsMaterials * sizeof(MaterialRec) + kLdsLights * sizeof(LightRec)) / 4];
-#ifndef TH_SHADE_LDS_TABLES
-#define TH_SHADE_LDS_TABLES 0  // measured SLOWER (35.4 vs 32.3 ms): flat loads + 40 B more scratch; kept for reference
-#endif
-#ifndef TH_SHADE_COMPACT2
-#define TH_SHADE_COMPACT2 1
-#endif
-    const bool staged = TH_SHADE_LDS_TABLES && sc.n_materials <= (uint32_t)kLdsMaterials && sc.n_lights <= (uint32_t)kLdsLights;
-    if (staged) {
-        const uint32_t nm = sc.n_materials * (uint32_t)(sizeof(MaterialRec) / 4), nl = sc.n_lights * (uint32_t)(sizeof(LightRec) / 4);
-        const uint32_t* gm = (const uint32_t*)sc.materials;
-        const uint32_t* gl = (const uint32_t*)sc.lights;
-        for (uint32_t k = threadIdx.x; k < nm; k += kBlock) s_tab[k] = gm[k];
-        for (uint32_t k = threadIdx.x; k < nl; k += kBlock) s_tab[kLdsMaterials * (sizeof(MaterialRec) / 4) + k] = gl[k];
-    }
-    const MaterialRec* materials = staged ? (const MaterialRec*)s_tab : sc.materials;
-    const LightRec* lights = staged ? (const LightRec*)(s_tab + kLdsMaterials * (sizeof(MaterialRec) / 4)) : sc.lights;
+    __shared__ uint32_t s_ring[kBlock / 64][128];
     const SegQueue qv{ctr->n_queue[row], cap, 0u};
-    seg_load(qv, sv);  // contains the barrier that publishes s_tab
+    seg_load(qv, sv);
     const uint32_t total = sv.prefix[kSeg];  // multiple of kSegGran: whole waves stay in the loop, so ballots see every lane
+    const uint32_t lane = lane_id(), wv = threadIdx.x >> 6;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    // every wave-iteration of a wave feeds the same output segment (the grid is a multiple of kSeg waves): at most cap entries each
+    const uint32_t seg_out = ((blockIdx.x * kBlock + threadIdx.x) >> 6) % kSeg;
+    uint32_t ring_head = 0, ring_cnt = 0;  // wave-uniform
+    auto emit = [&](const ShadeOut& e) {   // called by all 64 lanes together
+        uint32_t si, ni;
+        wave_compact2(e.want_shadow, &ctr->n_shadow[row][seg_out * kCtrStride], e.want_next, &ctr->n_queue[row + 1][seg_out * kCtrStride], si, ni);
+        si += seg_out * cap;
+        ni += seg_out * cap;
+        if (e.want_shadow) {
+            sq.o[si] = e.so4;
+            sq.d[si] = e.sd4;
+            sq.c[si] = e.sc4;
+        }
+        if (e.want_next) {
+            qout.o[ni] = e.no4;
+            qout.d[ni] = e.nd4;
+            qout.beta[ni] = e.nb4;
+            if (STREAM) ss.tags_out[ni] = e.next_depth;
+        }
+    };
     for (uint32_t flat = blockIdx.x * kBlock + threadIdx.x; flat < total; flat += gridDim.x * kBlock) {
         uint32_t seg_in, lb;
         seg_locate(sv, flat & ~63u, seg_in, lb);
         const uint32_t local = lb + (flat & 63u);
-        const bool valid = local < sv.count[seg_in];
         const uint32_t i = seg_in * cap + local;
-        const uint32_t seg_out = (flat >> 6) % kSeg;  // every wave-iteration feeds one output segment: at most cap entries each
-        bool want_shadow = false, want_next = false;
-        float4 so4, sd4, sc4, no4, nd4, nb4;
-        uint32_t next_depth = 0;
-        if (valid) {
-            const float4 h4 = hits[i];
-            const int prim = __float_as_int(h4.y);
+        int cls = 0;  // 0: nothing to shade (padding, miss, suspended ray), 1: FAST, 2: general
+        if (local < sv.count[seg_in]) {
+            const int prim = __float_as_int(hits[i].y);
             if (prim >= 0) {
-                const float4 o4 = qin.o[i], d4 = qin.d[i], b4 = qin.beta[i];
-                const int depth = STREAM ? (int)ss.tags_in[i] : depth_fixed;
-                // where this vertex's radiance terms go: the sample's slot, or (STREAM) its per-depth term slot
-                const uint32_t slot = STREAM ? (uint32_t)(depth - 1) * ss.term_stride + __float_as_uint(o4.w) : __float_as_uint(o4.w);
-                const f3 o = mk3(o4.x, o4.y, o4.z), d = mk3(d4.x, d4.y, d4.z);
-                f3 beta = mk3(b4.x, b4.y, b4.z);
-                Shading sh;
-                uint32_t material;
-#ifdef TH_SHADE_DIAG_MEMORY_ONLY  // DIAGNOSTIC (wrong results): the kernel's memory traffic without its arithmetic
-                if (true) {
-                    so4 = o4, sd4 = d4, sc4 = b4, no4 = make_float4(o4.x + h4.x, o4.y, o4.z, o4.w), nd4 = d4, nb4 = b4;
-                    want_shadow = (prim & 1) == 0;
-                    want_next = depth < max_depth && (prim & 7) != 0;
-                } else
-#endif
-                if (rebuild_shading(sc, prim, o, d, sh, material, hits_have_bary ? &h4 : nullptr) && material != PRIM_NO_MATERIAL) {
-                    const LobeSet& bsdf = materials[material].set[1];  // compute_scattering!(si, ray, true)
-                    const bool lambert = bsdf_is_single_lambert(bsdf);      // specialised evaluation of the same arithmetic (th_device.h)
-                    // the sampler stream key of this camera sample rides in the queue (k_raygen): no slot -> pixel division, no re-hash
-                    const uint64_t key = ((uint64_t)__float_as_uint(b4.w) << 32) | (uint64_t)__float_as_uint(d4.w);
-                    const uint32_t v = (uint32_t)(depth - 1);
-                    const f3 wo = -d;  // sppm.jl:224
-                    const uint32_t poison = ((isnan_(beta.x) || isinf_(beta.x)) ? 1u : 0u) | ((isnan_(beta.y) || isinf_(beta.y)) ? 2u : 0u) |
-                                            ((isnan_(beta.z) || isinf_(beta.z)) ? 4u : 0u);
-                    // ---- uniform_sample_one_light ----
-                    bool direct_added = false;
-#ifdef TH_SHADE_DIAG_LEVEL  // DIAGNOSTIC (wrong results): 1 = interaction only, 2 = + direct light; the condition is always true at run time
-                    const bool diag_skip = hits_have_bary < 2u;
-                    so4 = make_float4(sh.p.x, sh.p.y, sh.p.z, o4.w), sd4 = make_float4(sh.ns.x, sh.ns.y, sh.ns.z, 0.0f), sc4 = make_float4(sh.ss.x, sh.ts.y, sh.ng.z, 0.0f);
-                    no4 = so4, nd4 = make_float4(wo.x, wo.y, wo.z, d4.w), nb4 = b4;
-                    want_shadow = (prim & 1) == 0;
-                    want_next = depth < max_depth && (prim & 7) != 0;
-#define TH_DIAG_SKIP_DIRECT (TH_SHADE_DIAG_LEVEL == 1 && diag_skip)
-#define TH_DIAG_SKIP_SAMPLE (TH_SHADE_DIAG_LEVEL <= 2 && diag_skip)
-#else
-#define TH_DIAG_SKIP_DIRECT false
-#define TH_DIAG_SKIP_SAMPLE false
-#endif
-                    if (sc.n_lights > 0 && !TH_DIAG_SKIP_DIRECT) {
-                        const int nl = (int)sc.n_lights;
-                        int ln = (int)__builtin_ceilf(ts_uniform(key, ts_vertex_dim(v, TS_V_LIGHT_PICK)) * (float)nl);
-                        if (ln > nl) ln = nl;
-                        if (ln < 1) ln = 1;
-                        const float light_pdf = 1.0f / (float)nl;
-                        const LightRec& light = lights[ln - 1];
-                        const LightSample ls = sample_li(light, sh.p);
-                        if (ls.pdf > 0.0f && !is_black(ls.radiance)) {
-                            const f3 f = (lambert ? lambert_bsdf_f(bsdf.lobe[0], sh, sh.wo, ls.wi) : bsdf_f(bsdf, sh, sh.wo, ls.wi, BSDF_ALL & ~BSDF_SPECULAR)) * fabs_(dot(ls.wi, sh.ns));
-                            if (!is_black(f)) {
-                                // x / 1 == x exactly: δ-lights have pdf 1, a single light has light_pdf 1 (6 correctly rounded divisions saved)
-                                const f3 fl = f * ls.radiance;
-                                const f3 Ld1 = splat3(0.0f) + (ls.pdf == 1.0f ? fl : fl / ls.pdf);
-                                const f3 Ld = light_pdf == 1.0f ? Ld1 : Ld1 / light_pdf;
-                                const f3 c = beta * Ld;
-                                const f3 lp = mk3(light.position[0], light.position[1], light.position[2]);
-                                const f3 dir = lp - sh.p;                       // spawn_ray(p0, p1) Trace.jl:196-202
-                                const f3 org = sh.p + 1e-6f * dir;
-                                const f3 cd = check_direction(dir);
-                                so4 = make_float4(org.x, org.y, org.z, __uint_as_float(slot));
-                                sd4 = make_float4(cd.x, cd.y, cd.z, __uint_as_float(poison));
-                                sc4 = make_float4(c.x, c.y, c.z, 0.0f);
-                                want_shadow = true;
-                                direct_added = true;
-                            }
-                        }
-                    }
-                    if (!direct_added && poison) {  // L += β · 0 with a non-finite β
-                        float4 l = L[slot];
-                        const float nanv = __builtin_nanf("");
-                        if (poison & 1u) l.x += nanv;
-                        if (poison & 2u) l.y += nanv;
-                        if (poison & 4u) l.z += nanv;
-                        L[slot] = l;
-                    }
-                    // ---- continue the path ----
-                    if (depth < max_depth && !TH_DIAG_SKIP_SAMPLE) {
-                        const f2 u{ts_uniform(key, ts_vertex_dim(v, TS_V_BSDF_U0)), ts_uniform(key, ts_vertex_dim(v, TS_V_BSDF_U1))};
-                        const BsdfSample bs = lambert ? lambert_bsdf_sample_f(bsdf.lobe[0], sh, wo, u) : bsdf_sample_f(bsdf, sh, wo, u, BSDF_ALL);
-                        if (!(bs.pdf == 0.0f || is_black(bs.f))) {
-                            beta = beta * (bs.f * fabs_(dot(bs.wi, sh.ns)) / bs.pdf);
-                            const float by = to_Y(beta);
-                            bool alive = true;
-                            if (by < 0.25f) {
-                                const float cont = jmin(1.0f, by);
-                                if (ts_uniform(key, ts_vertex_dim(v, TS_V_RR)) > cont)
-                                    alive = false;
-                                else
-                                    beta = beta / cont;
-                            }
-                            if (alive) {
-                                const f3 org = sh.p + 1e-6f * bs.wi;  // spawn_ray(si, wi) Trace.jl:206-211
-                                const f3 nd = check_direction(bs.wi);
-                                no4 = make_float4(org.x, org.y, org.z, o4.w);
-                                nd4 = make_float4(nd.x, nd.y, nd.z, d4.w);
-                                next_depth = (uint32_t)(depth + 1);
-                                nb4 = make_float4(beta.x, beta.y, beta.z, b4.w);
-                                want_next = true;
-                            }
-                        }
-                    }
-                }
+                const uint32_t meta = __float_as_uint(sc.prims[3 * prim].w), material = meta & PRIM_MATERIAL_MASK;
+                cls = (!(meta & PRIM_SPHERE) && material != PRIM_NO_MATERIAL && bsdf_is_single_lambert(sc.materials[material].set[1])) ? 1 : 2;
             }
         }
-        uint32_t si, ni;
-#if TH_SHADE_COMPACT2
-        wave_compact2(want_shadow, &ctr->n_shadow[row][seg_out * kCtrStride], want_next, &ctr->n_queue[row + 1][seg_out * kCtrStride], si, ni);
-#else
-        si = wave_compact(want_shadow, &ctr->n_shadow[row][seg_out * kCtrStride]);
-        ni = wave_compact(want_next, &ctr->n_queue[row + 1][seg_out * kCtrStride]);
-#endif
-        si += seg_out * cap;
-        ni += seg_out * cap;
-        if (want_shadow) {
-            sq.o[si] = so4;
-            sq.d[si] = sd4;
-            sq.c[si] = sc4;
+        ShadeOut e;
+        e.want_shadow = e.want_next = false;
+        e.next_depth = 0;
+        if (cls == 1) shade_vertex<STREAM, true>(sc, qin, hits, L, i, depth_fixed, max_depth, hits_have_bary, ss, e);
+        emit(e);
+        // park the others
+        const unsigned long long m2 = __ballot(cls == 2);
+        if (m2) {
+            if (cls == 2) s_ring[wv][(ring_head + ring_cnt + (uint32_t)__popcll(m2 & lt_mask)) & 127u] = i;
+            ring_cnt += (uint32_t)__popcll(m2);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (ring_cnt >= 64u) {
+                const uint32_t j = s_ring[wv][(ring_head + lane) & 127u];
+                ShadeOut g;
+                g.want_shadow = g.want_next = false;
+                g.next_depth = 0;
+                shade_vertex<STREAM, false>(sc, qin, hits, L, j, depth_fixed, max_depth, hits_have_bary, ss, g);
+                emit(g);
+                ring_head = (ring_head + 64u) & 127u;
+                ring_cnt -= 64u;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            }
         }
-        if (want_next) {
-            qout.o[ni] = no4;
-            qout.d[ni] = nd4;
-            qout.beta[ni] = nb4;
-            if (STREAM) ss.tags_out[ni] = next_depth;
-        }
+    }
+    if (ring_cnt) {  // the last, partial batch
+        ShadeOut g;
+        g.want_shadow = g.want_next = false;
+        g.next_depth = 0;
+        if (lane < ring_cnt) shade_vertex<STREAM, false>(sc, qin, hits, L, s_ring[wv][(ring_head + lane) & 127u], depth_fixed, max_depth, hits_have_bary, ss, g);
+        emit(g);
     }
 }
 // STREAM: per-sample radiance = its per-depth terms added in depth order, which is the order the classic wavefront (and the
