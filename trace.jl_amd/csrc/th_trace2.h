@@ -441,14 +441,14 @@ __global__ __launch_bounds__(kBlock, TH_TRACE2_MIN_WAVES) void k_trace2(DeviceSc
 // ---- k_trace3: k_trace2 with the work of a wave re-grouped ("while-while") ------------------------------------------------------
 // Measured on the 1 M-triangle scene, k_trace2 keeps 11.6 of 64 lanes busy per VALU instruction: in every step the lanes at an
 // interior node, the lanes at a leaf and the lanes popping run one after the other.  Here a wave alternates between two
-// phases: (A) lanes pop and step through interior nodes while lanes that reached a leaf wait, until at most kLeafWait lanes
+// phases: (A) lanes pop and step through interior nodes while lanes that reached a leaf wait, until at most TH_TRACE3_LEAF_WAIT lanes
 // are still descending; (B) every lane that holds a leaf tests its primitives.  Each ray performs exactly the operations it
 // performs in k_trace2, in the same order; only the interleaving across lanes differs, so the results are the same bit for bit.
 #ifndef TH_TRACE3_LEAF_WAIT
-#define TH_TRACE3_LEAF_WAIT 20
+#define TH_TRACE3_LEAF_WAIT 32  // measured (128 spp, S-blob / S-mesh frame ms): 20: 694 / 2250, 32: 654 / 2207, 40: 659 / 2202, 48: 696 / 2265
 #endif
 #ifndef TH_TRACE3_MAX_A
-#define TH_TRACE3_MAX_A 12
+#define TH_TRACE3_MAX_A 8
 #endif
 template <bool ANY, bool COUNT>
 __global__ __launch_bounds__(kBlock, TH_TRACE2_MIN_WAVES) void k_trace3(DeviceScene sc, WideScene ws, SegQueue q, const float4* __restrict__ ro, const float4* __restrict__ rd, const float* __restrict__ tmax_or_null,
