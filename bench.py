@@ -2,7 +2,7 @@
 """bench.py — the reference's headline metric on MI355X: Mray/s (all bounces, closest-hit + shadow rays) at 1024x1024,
 depth 8 (BASELINE.json), PathIntegrator on the synthetic Cornell box (configs[1]) by default.
 
-    python bench.py --gpus N --steps K --warmup W [--workload cornell|shadows|mesh_64k|mesh_870k|mesh_1m] [--spp S]
+    python bench.py --gpus N --steps K --warmup W [--workload cornell|shadows|blob_870k|mesh_1m|mesh_10m|caustic|caustic_sppm] [--spp S]
 
 One "step" = one full render of the workload on every rank (weak scaling: each of the N ranks renders `spp` samples per
 pixel with its own sample-index range) followed, for N > 1, by the RCCL sum-reduce of the film accumulators to rank 0.
@@ -87,6 +87,64 @@ def measure_traffic(args, dominant: str):
     return int(2.0 * totals["FETCH_SIZE"] + totals["WRITE_SIZE"])
 
 
+def run_sppm(args, T, ctx, graft):
+    """BASELINE.json configs[3]: docs/code/caustic_glass.jl with SPPMIntegrator (procedural goblet: the reference's PLY does not
+    travel), 1024x1024, 100 iterations, depth 8.  A step = one whole SPPMIntegrator call; rays = camera + shadow + photon rays."""
+    import torch
+    scene, cam = T.scenes.caustic_scene(), T.scenes.caustic_camera(args.res)
+    t0 = time.time()
+    flat = scene.flatten(ctx)
+    t_build = time.time() - t0
+    integ = T.SPPMIntegrator(cam, args.radius, args.depth, args.iterations, -1, seed=args.seed)
+    for _ in range(args.warmup):
+        integ.render(scene, ctx)
+    torch.cuda.synchronize()
+    t_start = time.perf_counter()
+    rays, ms, launches = 0, {k: 0.0 for k in ("raygen", "trace_closest", "shade", "trace_any", "film")}, {}
+    for _ in range(args.steps):
+        integ.render(scene, ctx)
+        st = integ.stats
+        rays += st.closest_rays + st.shadow_rays
+        for k in ms:
+            ms[k] += getattr(st, "ms_" + k)
+            launches[k] = launches.get(k, 0) + getattr(st, "launches_" + k)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t_start
+    ctx.set_option("count_visits", 1)
+    integ.render(scene, ctx)
+    sv = integ.stats
+    ctx.set_option("count_visits", 0)
+    dom_bytes = traversal_bytes(sv.closest_rays, sv.nodes_visited, sv.prims_tested, 16) * args.steps / max(1, launches["trace_closest"])
+    dom_ms = ms["trace_closest"] / max(1, launches["trace_closest"])
+    achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "kernel": "k_trace3<closest>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "avg_launch_ms": round(dom_ms, 4), "launches": launches["trace_closest"], "algorithmic_bytes_per_launch": int(dom_bytes),
+                "visits_per_ray": {"closest_nodes": round(sv.nodes_visited / max(1, sv.closest_rays), 2), "closest_prims": round(sv.prims_tested / max(1, sv.closest_rays), 2)},
+                "kernel_ms_per_step": {"raygen+photon_gen": round(ms["raygen"] / args.steps, 2), "trace_closest": round(ms["trace_closest"] / args.steps, 2),
+                                       "shade+grid+gather+update": round(ms["shade"] / args.steps, 2), "trace_any": round(ms["trace_any"] / args.steps, 2), "image": round(ms["film"] / args.steps, 3)}}
+    cpu = None
+    if not args.no_cpu_baseline:  # the oracle, single-threaded (its photon pass is sequential), on a bounded number of iterations
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        graft.build_oracle()
+        import oracle_bridge as ob
+        osc = ob.OracleScene.from_scene(scene, bvh=flat.bvh())
+        n_it = max(1, min(args.iterations, 2))
+        t1 = time.perf_counter()
+        r = osc.sppm(cam, args.radius, args.depth, n_it, -1, seed=args.seed)
+        dt = time.perf_counter() - t1
+        cpu = {"value": round((r["stats"].closest_rays + r["stats"].shadow_rays) / dt / 1e6, 3), "unit": "Mray/s", "cores": 1, "kind": "port",
+               "sample": f"{n_it} of {args.iterations} iterations of the same configuration ({dt:.1f} s)"}
+    info = integ.state()["info"]
+    result = {"metric": "Mray/s (all bounces)", "value": round(rays / elapsed / 1e6, 2), "unit": "Mray/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+              "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 (f64 pixel update)", "data": "synthetic",
+              "config": {"workload": f"caustic_sppm: S-caustic (procedural goblet, {flat.bvh()[3].size} primitives, SpotLight), SPPMIntegrator, {args.res}x{args.res}, "
+                                     f"{args.iterations} iterations, {info['photons_per_iteration']} photons per iteration, max depth {args.depth}, radius {args.radius}, seed {args.seed:#x}",
+                         "rays_per_step": int(rays / args.steps), "ms_per_iteration": round(elapsed / args.steps / args.iterations * 1e3, 3), "bvh_build_upload_s": round(t_build, 3)},
+              "roofline": roofline, "cpu_baseline": cpu}
+    print(json.dumps(result), flush=True)
+    return result
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -100,6 +158,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-spp", type=int, default=0, help="spp of the bounded CPU-baseline sample (0 = auto)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child runs that fill roofline.traffic")
+    ap.add_argument("--iterations", type=int, default=100, help="caustic_sppm: SPPM iterations per step")
+    ap.add_argument("--radius", type=float, default=0.075, help="caustic_sppm: initial search radius")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -122,6 +182,10 @@ def main():
     T = graft.load_package()
     ctx = T.Context(local_rank)
 
+    if args.workload == "caustic_sppm":
+        if world != 1:
+            raise SystemExit("caustic_sppm runs on one GPU")
+        return run_sppm(args, T, ctx, graft)
     scene, cam, desc = build_workload(T, args.workload, args.res)
     t0 = time.time()
     flat = scene.flatten(ctx)  # BVH build + upload: outside the timed region

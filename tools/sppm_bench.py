@@ -1,12 +1,12 @@
 #!/usr/bin/env python
 """SPPM throughput on one MI355X (BASELINE.json configs[3]: caustic glass, 1024x1024, 100 iterations, depth 8).
 
-    python tools/sppm_bench.py [--res 1024] [--iterations 100] [--depth 8] [--radius 0.075] [--model path.ply] [--cpu-iterations 0]
+    python tools/sppm_bench.py [--res 1024] [--iterations 100] [--depth 8] [--radius 0.075] [--model path.ply] [--png out.png]
 
 Prints one JSON line: rays (closest + shadow) per second over the whole SPPMIntegrator call, ms per iteration and the
 library's per-kernel-class HIP-event times.  The glass is the procedural goblet of scenes.caustic_scene unless --model
-names a PLY (the reference's caustic-glass.ply does not travel to the GPU box).  --cpu-iterations N > 0 also times the
-single-threaded oracle on N iterations of the same scene (a reported baseline).
+names a PLY (the reference's caustic-glass.ply does not travel to the GPU box).  The bench line with roofline and CPU
+baseline is `python bench.py --workload caustic_sppm`.
 """
 import argparse
 import json
@@ -27,7 +27,6 @@ def main():
     ap.add_argument("--photons", type=int, default=-1)
     ap.add_argument("--model", default="")
     ap.add_argument("--repeat", type=int, default=2)
-    ap.add_argument("--cpu-iterations", type=int, default=0)
     ap.add_argument("--png", default="")
     args = ap.parse_args()
     import __graft_entry__ as g
@@ -61,15 +60,6 @@ def main():
            "grid": {"res": [int(x) for x in info["grid_res"]], "entries": info["grid_entries"], "photon_hits": info["photon_hits"]}}
     if args.png:
         T.save(cam.film, ctx)
-    if args.cpu_iterations > 0:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import oracle_bridge as ob
-        osc = ob.OracleScene.from_scene(scene, bvh=flat.bvh())
-        t0 = time.time()
-        r = osc.sppm(cam, args.radius, args.depth, args.cpu_iterations, args.photons)
-        dt = time.time() - t0
-        out["cpu_baseline"] = {"value": round((r["stats"].closest_rays + r["stats"].shadow_rays) / dt / 1e6, 3), "unit": "Mray/s", "cores": 1, "kind": "port",
-                               "sample": f"{args.cpu_iterations} iterations of the same configuration, {dt:.1f} s"}
     print(json.dumps(out))
 
 
