@@ -99,3 +99,25 @@ def test_sincos_equals_separate_calls(T):
     assert np.array_equal(s[fin].view(np.uint32), s2[fin].view(np.uint32))
     assert np.array_equal(c[fin].view(np.uint32), c2[fin].view(np.uint32))
     assert np.isnan(s2[~fin]).all() and np.isnan(c2[~fin]).all()
+
+
+def test_python_sampler_protocol_matches_the_specification(T, ob):
+    """The Python mirror's sampler walks UniformSampler's protocol (sampler/sampler.jl:129-151) over the seeded stream of
+    include/trace_sampler.h: camera sample = dimensions 0-4, path vertex v starts at 5 + 8 v."""
+    smp = T.SeededSampler(3, seed=0xABCDEF, sample_offset=7)
+    L = ob.lib()
+    smp.start_pixel((12, -3))
+    n = 0
+    while smp.has_next_sample():
+        s = 7 + smp.current_sample - 1
+        film, lens, time = smp.get_camera_sample(np.float32([12, -3]))
+        want = [L.orc_sampler_u(0xABCDEF, 12, -3, s, d) for d in range(5)]
+        assert film[0] == np.float32(12) + np.float32(want[0]) and film[1] == np.float32(-3) + np.float32(want[1])
+        assert lens[0] == np.float32(want[2]) and lens[1] == np.float32(want[3]) and time == np.float32(want[4])
+        for v in (0, 1, 4):
+            smp.start_vertex(v)
+            got = [smp.get_1d()] + list(smp.get_2d()) + list(smp.get_2d()) + list(smp.get_2d()) + [smp.get_1d()]
+            assert got == [np.float32(L.orc_sampler_u(0xABCDEF, 12, -3, s, 5 + 8 * v + k)) for k in range(8)]
+        smp.start_next_sample()
+        n += 1
+    assert n == 3

@@ -456,6 +456,44 @@ class SeededSampler:
         self.seed = int(seed)
         self.sample_offset = int(sample_offset)
         self.current_sample = 1
+        self._pixel = (0, 0)
+        self._dim = 0
+
+    # -- the AbstractSampler protocol the render loops call (sampler/sampler.jl:129-151); values from include/trace_sampler.h.
+    #    The kernels address dimensions directly (camera 0-4, path vertex v at 5 + 8 v); a host that walks the protocol
+    #    sequentially consumes the same stream as long as it positions itself with start_vertex(v) at every path vertex.
+    def _u(self, dim: int) -> np.float32:
+        from . import scenes
+        key = scenes.ts_stream_key(self.seed, self._pixel[0], self._pixel[1], self.sample_offset + self.current_sample - 1)
+        return np.float32(scenes.ts_uniform(key, dim))
+
+    def start_pixel(self, p):  # start_pixel! :147-149
+        self.current_sample = 1
+        self._pixel = (int(p[0]), int(p[1]))
+        self._dim = 0
+
+    def has_next_sample(self) -> bool:  # :141-143
+        return self.current_sample <= self.samples_per_pixel
+
+    def start_next_sample(self):  # start_next_sample! :144-146
+        self.current_sample += 1
+        self._dim = 0
+
+    def start_vertex(self, v: int):
+        self._dim = 5 + 8 * int(v)
+
+    def get_1d(self) -> np.float32:  # :131
+        self._dim += 1
+        return self._u(self._dim - 1)
+
+    def get_2d(self) -> np.ndarray:  # :132-134
+        return np.array([self.get_1d(), self.get_1d()], dtype=np.float32)
+
+    def get_camera_sample(self, p_raster):  # :135-139: (p_film, p_lens, time)
+        self._dim = 0
+        p = np.asarray(p_raster, dtype=np.float32)
+        film = p + self.get_2d()
+        return film.astype(np.float32), self.get_2d(), self.get_1d()
 
 
 def UniformSampler(samples_per_pixel: int) -> SeededSampler:
