@@ -75,7 +75,7 @@ struct trhip_ctx {
     uint32_t stream_budget_shift = 12;  // budget = max(stream_budget_min, fresh rays of the round >> shift)
     uint32_t stream_list_cap = 0;       // suspended-ray list capacity (0 = max(65536, paths / 128)); tests shrink it
     uint32_t stream_budget_min = 2048;  // interior fetches before a ray may be suspended (tests lower it to force suspensions)
-    uint64_t sppm_batch = 0;  // SPPM iterations per wavefront batch (0 = from free HBM, at most 32)
+    uint64_t sppm_batch = 0;  // SPPM iterations per wavefront batch (0 = from free HBM, at most 128)
     uint32_t sp_pixels = 0;
     int64_t sp_photons = 0;
 };
@@ -1193,7 +1193,7 @@ int render_sppm_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
         size_t free_b = 0, total_b = 0;
         HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
         B = (uint64_t)std::max(1.0, 0.5 * (double)free_b / per_iter);
-        B = std::min<uint64_t>(B, 32);
+        B = std::min<uint64_t>(B, 128);  // measured on C4: 32 iterations per batch 906 ms, 50: 769 ms, 100: 701 ms
     }
     B = std::min<uint64_t>(B, n_iterations);
     while (B > 1 && (B * Qit >= (1ull << 31) || B * (uint64_t)max_depth * n >= (1ull << 32) || B * (uint64_t)P * ndep >= (1ull << 32))) B = (B + 1) / 2;
