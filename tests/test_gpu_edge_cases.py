@@ -1,0 +1,123 @@
+"""Edge cases of the hot path on the GPU, against the oracle: degenerate inputs, limits and the combinations the main parity
+tests do not reach (cropped films, scenes without lights or without geometry, zero-area triangles, several lights of both kinds
+in the path integrator, depth 1, the single-leaf threshold)."""
+import numpy as np
+import pytest
+
+from test_gpu_parity import assert_bits_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def cornell_tris(T, material=None):
+    prims, white = T.scenes.cornell_primitives(spheres=False)
+    return prims, white
+
+
+def test_scene_without_lights_and_depth_one(T, ob, ctx):
+    prims, _ = T.scenes.cornell_primitives()
+    scene = T.Scene([], T.BVHAccel(prims, 1))
+    cam = T.scenes.cornell_camera(24)
+    osc = ob.OracleScene.from_scene(scene, bvh=scene.flatten(ctx).bvh())
+    for depth in (1, 4):
+        ref, _, st = osc.render(cam, "path", 2, depth, seed=3)
+        integ = T.PathIntegrator(cam, T.SeededSampler(2, seed=3), depth)
+        film = integ.render(scene, ctx)
+        assert_bits_equal(film, ref, f"film without lights, depth {depth}")
+        assert integ.stats.shadow_rays == 0 == st.shadow_rays and integ.stats.closest_rays == st.closest_rays
+    assert np.all(film[..., :3] == 0) and np.all(film[..., 3] != 0)
+
+
+def test_empty_scene(T, ctx):
+    """No primitives at all: every ray misses, the film keeps only its filter weights."""
+    scene = T.Scene(T.scenes.cornell_lights(), T.BVHAccel([], 1))
+    cam = T.scenes.cornell_camera(16)
+    integ = T.PathIntegrator(cam, T.SeededSampler(2, seed=1), 3)
+    film = integ.render(scene, ctx)
+    assert np.all(film[..., :3] == 0) and np.all(film[..., 3] != 0)
+    assert integ.stats.closest_rays == 18 * 18 * 2 and integ.stats.shadow_rays == 0
+    rays = T.scenes.incoherent_rays(1000, np.float32([-1, -1, -1]), np.float32([1, 1, 1]))
+    flat = scene.flatten(ctx)
+    assert np.all(flat.trace_closest(rays)["prim"] == -1) and not flat.trace_any(rays).any()
+
+
+def test_cropped_film(T, ob, ctx):
+    """Film crop window (film.jl:41-44): sample bounds, tiles and the gather all start away from (1, 1)."""
+    flt = T.LanczosSincFilter([1.0, 1.0], 3.0)
+    film = T.Film([40, 30], T.Bounds2([0.3, 0.2], [0.8, 0.9]), flt, 1.0, 1.0, "")
+    base = T.scenes.cornell_camera(40)
+    cam = T.PerspectiveCamera(base.camera_to_world, T.Bounds2([-1.0, -1.0], [1.0, 1.0]), 0.0, 1.0, 0.0, 1e6, 90.0, film)
+    scene = T.scenes.cornell_scene()
+    osc = ob.OracleScene.from_scene(scene, bvh=scene.flatten(ctx).bvh())
+    sn = ob.make_sensor(cam, crop=(0.3, 0.2, 0.8, 0.9))
+    ref, ref_L, _ = osc.render(cam, "path", 3, 4, seed=8, want_samples=True, sensor=sn)
+    integ = T.PathIntegrator(cam, T.SeededSampler(3, seed=8), 4)
+    got = integ.render(scene, ctx)
+    assert got.shape == ref.shape == (21, 20, 4)
+    assert_bits_equal(integ.sample_radiance(scene), ref_L, "per-sample radiance (cropped film)")
+    assert_bits_equal(got, ref, "cropped film")
+    for mode in (0, 2):
+        ctx.set_option("film_block", mode)
+        try:
+            assert_bits_equal(T.PathIntegrator(cam, T.SeededSampler(3, seed=8), 4).render(scene, ctx), ref, f"cropped film, film_block {mode}")
+        finally:
+            ctx.set_option("film_block", 1)
+
+
+def test_degenerate_triangles_and_single_leaf_threshold(T, ob, ctx):
+    """Zero-area triangles are never hit (is_degenerate, triangle_mesh.jl:65-68; flagged at commit); 16 primitives make one
+    leaf, 17 a hierarchy."""
+    white = T.MatteMaterial(T.ConstantTexture(T.RGBSpectrum(0.9)), T.ConstantTexture(0.0))
+    core = T.ShapeCore(T.translate([0, 0, 0]), False)
+    verts = np.float32([[0, 0, -2.5], [1, 0, -2.5], [1, 1, -2.5], [0, 1, -2.5], [0.5, 0.5, -2.2], [0.5, 0.5, -2.2], [0.2, 0.2, -2.3], [0.4, 0.4, -2.3], [0.8, 0.8, -2.3]])
+    idx = np.uint32([1, 2, 3, 1, 3, 4, 5, 6, 7, 7, 8, 9])  # two real triangles, a point triangle, a collinear one
+    for extra in (12, 13):  # 4 + 12 = 16 primitives -> one leaf; 17 -> a tree
+        prims = [T.GeometricPrimitive(t, white) for t in T.create_triangle_mesh(core, 4, idx, 9, verts)]
+        for k in range(extra):
+            prims.append(T.GeometricPrimitive(T.Sphere(T.ShapeCore(T.translate([0.1 + 0.07 * k, 0.5, -2.4]), False), 0.03, 360.0), white))
+        scene = T.Scene(T.scenes.cornell_lights(), T.BVHAccel(prims, 1))
+        flat = scene.flatten(ctx)
+        bounds, a, flags, order = flat.bvh()
+        assert (a.size == 1) == (extra == 12)
+        osc = ob.OracleScene.from_scene(scene, bvh=(bounds, a, flags, order))
+        cam = T.scenes.cornell_camera(32)
+        rays = np.concatenate([ob.generate_rays(cam, T.scenes.camera_sample_grid(cam, 1, 3)), T.scenes.incoherent_rays(20000, np.float32([0, 0, -2.6]), np.float32([1, 1, -2.0]))])
+        got = flat.trace_closest(rays)
+        t_ref, prim_ref, _, _ = osc.trace_closest(rays)
+        assert np.array_equal(got["prim"], prim_ref)
+        assert_bits_equal(got["t"], t_ref, "t")
+        hit_slots = set(prim_ref[prim_ref >= 0].tolist())
+        degenerate_slots = {int(np.flatnonzero(order == k)[0]) for k in (2, 3)}
+        assert not (hit_slots & degenerate_slots)
+        ref, _, _ = osc.render(cam, "path", 2, 3, seed=6)
+        assert_bits_equal(T.PathIntegrator(cam, T.SeededSampler(2, seed=6), 3).render(scene, ctx), ref, f"film ({a.size} nodes)")
+
+
+def test_path_integrator_with_point_and_spot_lights_and_all_materials(T, ob, ctx):
+    """uniform_sample_one_light over three lights (two kinds) on matte / Oren-Nayar / mirror / glass / rough glass / plastic."""
+    from test_gpu_parity import MATERIALS
+    from test_gpu_sppm import spot_light
+    prims, _ = T.scenes.cornell_primitives(spheres=False)
+    for k, name in enumerate(MATERIALS):
+        prims.append(T.GeometricPrimitive(T.Sphere(T.ShapeCore(T.translate([0.15 + 0.14 * k, 0.13 + 0.05 * (k % 2), -2.3 - 0.08 * k]), False), 0.08, 360.0), MATERIALS[name](T)))
+    lights = T.scenes.cornell_lights() + [spot_light(T), T.PointLight(T.translate([0.2, 0.5, -2.1]), T.RGBSpectrum(0.4, 0.6, 0.9))]
+    scene = T.Scene(lights, T.BVHAccel(prims, 1))
+    cam = T.scenes.cornell_camera(40)
+    osc = ob.OracleScene.from_scene(scene, bvh=scene.flatten(ctx).bvh())
+    ref, ref_L, _ = osc.render(cam, "path", 4, 6, seed=12, want_samples=True)
+    integ = T.PathIntegrator(cam, T.SeededSampler(4, seed=12), 6)
+    got = integ.render(scene, ctx)
+    assert_bits_equal(integ.sample_radiance(scene), ref_L, "per-sample radiance")
+    assert_bits_equal(got, ref, "film")
+
+
+def test_material_less_primitive_is_rejected_by_render_but_traced(T, ctx):
+    core = T.ShapeCore(T.translate([0, 0, 0]), False)
+    tris = T.create_triangle_mesh(core, 1, np.uint32([1, 2, 3]), 3, np.float32([[0, 0, -2.5], [1, 0, -2.5], [1, 1, -2.5]]))
+    scene = T.Scene(T.scenes.cornell_lights(), T.BVHAccel([T.GeometricPrimitive(tris[0], None)], 1))
+    cam = T.scenes.cornell_camera(16)
+    flat = scene.flatten(ctx)
+    rays = T.scenes.incoherent_rays(2000, np.float32([0, 0, -2.6]), np.float32([1, 1, -2.0]))
+    assert (flat.trace_closest(rays)["prim"] >= -1).all()
+    with pytest.raises(T.TraceHipError, match="material-less"):
+        T.PathIntegrator(cam, T.SeededSampler(1), 2).render(scene, ctx)

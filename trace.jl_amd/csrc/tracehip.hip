@@ -937,6 +937,11 @@ int render_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sensor* se
     if (!ctx || !scene || !sensor || !out) return fail(ctx, TRHIP_ERR_INVALID, "null argument");
     if (!scene->committed) return fail(ctx, TRHIP_ERR_INVALID, "scene not committed");
     if (integrator != 0 && integrator != 1) return fail(ctx, TRHIP_ERR_INVALID, "unknown integrator %d", integrator);
+    // A GeometricPrimitive without a material makes the reference re-spawn the ray behind the hit without counting a bounce
+    // (sppm.jl:219-222; Whitted calls a method that does not exist, sampler.jl:77-80).  The wavefront does not model that.
+    for (const HostPrim& hp : scene->prims)
+        if ((hp.meta & PRIM_MATERIAL_MASK) == PRIM_NO_MATERIAL)
+            return fail(ctx, TRHIP_ERR_UNSUPPORTED, "rendering a scene with a material-less primitive is not supported (the trace entry points accept it)");
     if (spp == 0 || max_depth < 1 || max_depth > kMaxDepth) return fail(ctx, TRHIP_ERR_INVALID, "spp must be >= 1 and max_depth in 1..%d", kMaxDepth);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     DeviceSensor ds;
@@ -1579,7 +1584,7 @@ int trhip_scene_add_triangles(trhip_scene* s, const float* xyz, uint32_t n_verts
             if (normals) std::memcpy(&p.n[3 * j], &normals[3 * (size_t)(vi - 1)], 3 * sizeof(float));
         }
         uint32_t m = mat ? mat[k] : PRIM_NO_MATERIAL;
-        if (mat && m >= s->materials.size()) return fail(s->ctx, TRHIP_ERR_INVALID, "triangle %u: material %u not defined", k, m);
+        if (mat && m != PRIM_NO_MATERIAL && m >= s->materials.size()) return fail(s->ctx, TRHIP_ERR_INVALID, "triangle %u: material %u not defined", k, m);
         // is_degenerate (triangle_mesh.jl:65-68) depends on the triangle alone: evaluated here, once, in the kernels' arithmetic
         const f3 tv0 = mk3(p.v[0], p.v[1], p.v[2]), tv1 = mk3(p.v[3], p.v[4], p.v[5]), tv2 = mk3(p.v[6], p.v[7], p.v[8]);
         const f3 tn = cross(tv2 - tv0, tv1 - tv0);
