@@ -121,3 +121,29 @@ def test_material_less_primitive_is_rejected_by_render_but_traced(T, ctx):
     assert (flat.trace_closest(rays)["prim"] >= -1).all()
     with pytest.raises(T.TraceHipError, match="material-less"):
         T.PathIntegrator(cam, T.SeededSampler(1), 2).render(scene, ctx)
+
+
+def test_bench_size_properties(T, ctx):
+    """At the size of the bench (1024 x 1024, S-cornell, depth 8; 64 of the 256 spp to keep the suite short) the oracle is too
+    slow to compare against; size-independent properties instead: the render is reproducible bit for bit, does not depend on
+    the traversal kernel, the film-gather variant or the batch size, and the two halves of the sample range add up to the whole."""
+    scene, cam = T.scenes.cornell_scene(), T.scenes.cornell_camera(1024)
+
+    def render(spp=64, offset=0, **opts):
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        try:
+            return T.PathIntegrator(cam, T.SeededSampler(spp, seed=0x5EED0001, sample_offset=offset), 8).render(scene, ctx).copy()
+        finally:
+            for k, v in {"traversal": 3, "film_block": 1, "batch_paths": 0, "overlap": 1}.items():
+                ctx.set_option(k, v)
+
+    a = render()
+    assert np.isfinite(a).all() and a[..., 3].min() > 0
+    assert_bits_equal(render(), a, "second run")
+    assert_bits_equal(render(traversal=1), a, "literal traversal kernel")
+    assert_bits_equal(render(film_block=0), a, "one film pixel per thread")
+    assert_bits_equal(render(batch_paths=16 * 1026 * 1026, overlap=0), a, "four batches, one stream")
+    h0, h1 = render(32, 0), render(32, 32)
+    np.testing.assert_allclose(h0 + h1, a, rtol=3e-5, atol=1e-5)
+    assert np.array_equal((h0 + h1)[..., 3] > 0, a[..., 3] > 0)
