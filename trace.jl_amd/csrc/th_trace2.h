@@ -28,6 +28,9 @@ namespace th {
 constexpr int kStack2Lds = TH_STACK2_LDS;  // stack levels per lane kept in LDS
 constexpr int kStack2Total = 64;
 constexpr uint32_t kRefNone = 0xffffffffu;
+#ifndef TH_TRACE_REFILL
+#define TH_TRACE_REFILL 12  // idle lanes of a wave that trigger a refill from the queue
+#endif
 constexpr int kChunk = 256;  // ray indices a wave takes from a segment cursor per atomic (== kSegGran)
 
 struct WideScene {            // device view of the v2 node array
@@ -184,7 +187,7 @@ __global__ __launch_bounds__(kBlock, TH_TRACE2_MIN_WAVES) void k_trace2(DeviceSc
                 continue;  // re-evaluate the idle lanes
             }
         }
-        if (n_idle == 64u || (!exhausted && n_idle >= 12u)) {
+        if (n_idle == 64u || (!exhausted && n_idle >= (uint32_t)TH_TRACE_REFILL)) {
             if (!exhausted) {
                 if (pool_next >= pool_end) {  // take the next chunk: try this wave's segment, move on when it is drained
                     uint32_t base = 0;
@@ -479,7 +482,7 @@ __global__ __launch_bounds__(kBlock, TH_TRACE2_MIN_WAVES) void k_trace3(DeviceSc
         // ---- refill idle lanes (as k_trace2) ----------------------------------------------------------------------------------
         const unsigned long long idle = __ballot(!active);
         const uint32_t n_idle = (uint32_t)__popcll(idle);
-        if (n_idle == 64u || (!exhausted && n_idle >= 12u)) {
+        if (n_idle == 64u || (!exhausted && n_idle >= (uint32_t)TH_TRACE_REFILL)) {
             if (!exhausted) {
                 if (pool_next >= pool_end) {
                     uint32_t base = 0;
