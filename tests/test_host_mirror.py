@@ -1,0 +1,72 @@
+"""The Python mirror of the Trace.jl host API (trace.jl_amd/api.py: the code a scene script runs before anything reaches the
+GPU) against the oracle's restated constructors, bit for bit: transformations incl. the load-bearing quirks (`*` multiplies
+the inverses in the same order, A.3; `perspective` fills its matrix column-major without transposing, A.4), `look_at`,
+`coordinate_system`, and everything `trhip_sensor` carries (film geometry, filter table, raster_to_camera)."""
+import numpy as np
+import pytest
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def orc32(fn, *args):
+    out = np.empty(32, np.float32)
+    fn(*args, out.ctypes.data_as(__import__("ctypes").POINTER(__import__("ctypes").c_float)))
+    return out[:16].reshape(4, 4), out[16:].reshape(4, 4)
+
+
+def same(t, mm, what):
+    m, inv = mm
+    assert np.array_equal(bits(t.m), bits(m)), f"{what}: m differs\n{t.m}\n{m}"
+    assert np.array_equal(bits(t.inv_m), bits(inv)), f"{what}: inv_m differs\n{t.inv_m}\n{inv}"
+
+
+def test_transformations_match_the_restated_constructors(T, ob):
+    L = ob.lib()
+    rng = np.random.default_rng(5)
+    for _ in range(20):
+        d = rng.normal(size=3).astype(np.float32) * 10
+        same(T.translate(d), orc32(L.orc_translate, ob.fp(d)), "translate")
+        sx, sy, sz = (rng.uniform(0.1, 5, 3)).astype(np.float32)
+        same(T.scale(sx, sy, sz), orc32(L.orc_scale, float(sx), float(sy), float(sz)), "scale")
+        pos, tgt = rng.normal(size=3).astype(np.float32) * 20, rng.normal(size=3).astype(np.float32) * 5
+        up = np.float32([0, 1, 0])
+        same(T.look_at(pos, tgt, up), orc32(L.orc_look_at, ob.fp(pos), ob.fp(tgt), ob.fp(up)), "look_at")
+        fov = np.float32(rng.uniform(20, 120))
+        same(T.perspective(fov, 0.01, 1000.0), orc32(L.orc_perspective, float(fov), 0.01, 1000.0), "perspective")
+        a, b = T.translate(d) * T.scale(sx, sy, sz), T.look_at(pos, tgt, up)
+        pa = np.concatenate([a.m.reshape(-1), a.inv_m.reshape(-1)]).astype(np.float32)
+        pb = np.concatenate([b.m.reshape(-1), b.inv_m.reshape(-1)]).astype(np.float32)
+        same(a * b, orc32(L.orc_transform_mul, ob.fp(pa), ob.fp(pb)), "Transformation * Transformation (inverses in the same order)")
+        m = rng.normal(size=(4, 4)).astype(np.float32)
+        m[3] = [0, 0, 0, 1]
+        same(T.Transformation(m), orc32(L.orc_transform_from_matrix, ob.fp(np.ascontiguousarray(m))), "Transformation(::Mat4f)")
+        p = rng.normal(size=3).astype(np.float32)
+        out = np.empty(3, np.float32)
+        L.orc_transform_point(ob.fp(pb), ob.fp(p), ob.fp(out))
+        assert np.array_equal(bits(b.point(p)), bits(out))
+        v = rng.normal(size=3).astype(np.float32)
+        v /= np.float32(np.sqrt(np.float32(v @ v)))
+        out6 = np.empty(6, np.float32)
+        L.orc_coordinate_system(ob.fp(v), ob.fp(out6))
+        _, v2, v3 = T.coordinate_system(v)
+        assert np.array_equal(bits(v2), bits(out6[:3])) and np.array_equal(bits(v3), bits(out6[3:]))
+
+
+@pytest.mark.parametrize("res,radius,crop", [((341, 341), (1.0, 1.0), (0.0, 0.0, 1.0, 1.0)), ((64, 48), (2.5, 1.5), (0.0, 0.0, 1.0, 1.0)), ((40, 30), (1.0, 1.0), (0.3, 0.2, 0.8, 0.9))])
+def test_sensor_fields_match_the_restated_film_and_camera(T, ob, res, radius, crop):
+    """trhip_sensor as the Python host fills it == what the oracle derives from the raw constructor arguments with its own Film /
+    PerspectiveCamera restatement (film.jl:34-73, camera/perspective.jl:11-40, 58-80)."""
+    film = T.Film(list(res), T.Bounds2(list(crop[:2]), list(crop[2:])), T.LanczosSincFilter(list(radius), 3.0), 1.0, 1.0, "")
+    cam = T.PerspectiveCamera(T.look_at([0, 15, 50], [0, 0, -2], [0, 1, 0]), T.Bounds2([-1.0, -1.0], [1.0, 1.0]), 0.0, 1.0, 0.0, 1e6, 90.0, film)
+    i6, crop4, table, r2c = ob.sensor_derived(cam, sensor=ob.make_sensor(cam, crop=crop))
+    sn = cam.sensor()
+    h, w = film.size
+    sb = film.get_sample_bounds()
+    assert [w, h] == list(i6[:2])
+    assert [int(sb.p_min[0]), int(sb.p_min[1]), int(sb.p_max[0]), int(sb.p_max[1])] == list(i6[2:])
+    assert np.array_equal(bits(np.float32(list(sn.crop_min) + list(sn.crop_max))), bits(crop4))
+    assert np.array_equal(bits(np.float32(list(sn.filter_table))), bits(table.reshape(-1)))
+    assert np.array_equal(bits(np.float32(list(sn.raster_to_camera))), bits(r2c.reshape(-1)))
+    assert np.array_equal(bits(np.float32(list(sn.camera_to_world))), bits(cam.camera_to_world.m.reshape(-1)))
