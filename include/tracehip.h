@@ -221,7 +221,7 @@ int trhip_film_accumulate(trhip_ctx* ctx, const trhip_sensor* sensor, uint32_t s
  *     "stream_budget_min" (default 2048), "stream_budget_shift" (12) and "stream_list_cap" (0 = automatic) tune it.
  * "sppm_batch": SPPM iterations whose camera / photon paths share the traversal launches (default 0 = as many as fit in
  *     free HBM, at most 128); the result does not depend on it.
- * "film_block" (0/1/2): film pixels per thread of the film gather: 1, 2 x 2 (default), 1 x 4; same film bit for bit.
+ * "film_block" (0/1/2): film pixels per thread of the film gather: 1, 2 x 2, 1 x 4 (default); same film bit for bit.
  * "film_tiled" (0/1): LDS-staged film gather (default 0: measured slower).
  * "debug_trace_budget": DIAGNOSTIC ONLY, traversal abandons rays after this many node fetches (results wrong). */
 int trhip_set_option(trhip_ctx* ctx, const char* name, int64_t value);

@@ -269,13 +269,13 @@ def test_film_accumulate_matches_oracle_tile_order(T, ob, ctx):
     finally:
         ctx.set_option("film_tiled", 0)
     assert_bits_equal(out2, ref_xyzw, "film accumulate, LDS-tiled gather")
-    for mode in (0, 2, 1):  # one film pixel per thread, 4 x 2 blocks, 2 x 2 blocks (the default; odd film sizes: 37 x 29)
+    for mode in (0, 1, 2):  # one film pixel per thread, 2 x 2 blocks, 1 x 4 blocks (the default; odd film sizes: 37 x 29)
         ctx.set_option("film_block", mode)
         try:
             out3 = np.empty_like(ref_xyzw)
             ctx.check(T.lib().trhip_film_accumulate(ctx._h, C.byref(sn), spp, 5, 0, T._ffi.fptr(ref_L), T._ffi.fptr(out3)))
         finally:
-            ctx.set_option("film_block", 1)
+            ctx.set_option("film_block", 2)
         assert_bits_equal(out3, ref_xyzw, f"film accumulate, film_block={mode}")
 
 

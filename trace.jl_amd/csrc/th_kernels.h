@@ -754,8 +754,9 @@ __global__ __launch_bounds__(kBlock) void k_film_gather_block(const DeviceSensor
                     for (int sy = y0; sy <= y1; ++sy)
                         for (int sx = x0; sx <= x1; ++sx) {
                             const uint32_t pix = (uint32_t)(sy - se.sb_min[1]) * (uint32_t)se.sb_w + (uint32_t)(sx - se.sb_min[0]);
-                            for (uint32_t s = 0; s < spp; ++s) {
-                                const float2 pf = pfilm[(size_t)s * npix + pix];
+                            // kFilmUnroll samples per trip: their p_film and L loads are issued together (the gather is a chain of
+                            // dependent trips otherwise), then they are splatted one after the other, in sample order
+                            auto splat = [&](float2 pf, float4 l4) {
                                 const float dpx = pf.x - 0.5f, dpy = pf.y - 0.5f;
                                 float p0x = __builtin_ceilf(dpx - rx), p0y = __builtin_ceilf(dpy - ry);
                                 float p1x = __builtin_floorf(dpx + rx) + 1.0f, p1y = __builtin_floorf(dpy + ry) + 1.0f;
@@ -773,8 +774,7 @@ __global__ __launch_bounds__(kBlock) void k_film_gather_block(const DeviceSensor
                                     oky[j] = !(Y[j] < p0y || Y[j] > p1y);
                                     anyy = anyy || oky[j];
                                 }
-                                if (!(anyx && anyy)) continue;
-                                const float4 l4 = L[(size_t)s * npix + pix];
+                                if (!(anyx && anyy)) return;
                                 f3 l = mk3(l4.x, l4.y, l4.z);
                                 if (has_nan(l)) l = splat3(0.0f);  // integrators/sampler.jl:46
                                 int ox[BX], oy[BY];
@@ -787,7 +787,24 @@ __global__ __launch_bounds__(kBlock) void k_film_gather_block(const DeviceSensor
                                             csum[j][i] = csum[j][i] + l * 1.0f * w;
                                             fws[j][i] += w;
                                         }
+                            };
+#ifndef TH_FILM_UNROLL
+#define TH_FILM_UNROLL 4
+#endif
+                            constexpr uint32_t kFilmUnroll = TH_FILM_UNROLL;
+                            uint32_t s = 0;
+                            for (; s + kFilmUnroll <= spp; s += kFilmUnroll) {
+                                float2 pfv[kFilmUnroll];
+                                float4 lv[kFilmUnroll];
+#pragma unroll
+                                for (uint32_t u = 0; u < kFilmUnroll; ++u) {
+                                    pfv[u] = pfilm[(size_t)(s + u) * npix + pix];
+                                    lv[u] = L[(size_t)(s + u) * npix + pix];
+                                }
+#pragma unroll
+                                for (uint32_t u = 0; u < kFilmUnroll; ++u) splat(pfv[u], lv[u]);
                             }
+                            for (; s < spp; ++s) splat(pfilm[(size_t)s * npix + pix], L[(size_t)s * npix + pix]);
                         }
                     for (int j = 0; j < BY; ++j)
                         for (int i = 0; i < BX; ++i)

@@ -56,7 +56,7 @@ struct trhip_ctx {
                            // -1 = automatic: the device builder above 16 Mi primitives.  Measured: commit 0.72 -> 0.13 s (1 M triangles), 8.0 -> 1.5 s
                            // (10 M); the LBVH costs 25-35 % more node visits per ray (frame +4 % at 1 M / 64 spp, +37 % at 10 M / 16 spp)
     uint32_t tiny_scene_prims = 16;  // scenes of at most this many primitives get a single-leaf BVH (th_bvh.h); 0 = always build the hierarchy
-    int film_block = 1;  // film gather: 0 = one film pixel per thread, 1 = 2 x 2 pixels per thread (default), 2 = TH_FILM_BX x TH_FILM_BY
+    int film_block = 2;  // film gather: 0 = one film pixel per thread, 1 = 2 x 2 pixels per thread, 2 = TH_FILM_BX x TH_FILM_BY = 1 x 4 (default)
     bool film_tiled = false;  // LDS-staged film gather (k_film_gather_tiled): bit-identical, measured 2.7x SLOWER than k_film_gather (11 % lane use), kept as an option
     bool overlap = true;  // two-stream overlap of shadow rays (depth d) with closest-hit rays (depth d+1)
     int traversal = 3;  // 1 = literal accel/bvh.jl loop, 2 = children-in-parent nodes + per-lane ray replacement, 3 = 2 with leaves postponed (while-while)
@@ -423,7 +423,7 @@ void derive_sensor(const trhip_sensor* sn, DeviceSensor& d) {
 // Film accumulation: positions, then the LDS-tiled gather (falls back to the per-pixel gather when a 16x16 film tile is reached
 // by more than two sample tiles per axis, i.e. very wide filters).
 #ifndef TH_FILM_BX
-#define TH_FILM_BX 1  // film_block = 2; measured at 1024^2, 256 spp: 1x1 69 ms, 2x2 43, 1x4 44, 2x4 55, 4x2 67, 3x3 94
+#define TH_FILM_BX 1  // film_block = 2; measured at 1024^2, 256 spp, 4 samples in flight per thread: 1x1 67 ms, 2x2 40, 1x4 32, 1x6 47, 1x8 42, 2x4 39
 #define TH_FILM_BY 4
 #endif
 void launch_film(trhip_ctx* ctx, hipStream_t st, const DeviceSensor& ds, const DeviceSensor* dsp, const float4* L, uint64_t total_slots, uint32_t spp, uint64_t seed, uint32_t sample_offset,
