@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--repeat", type=int, default=5)
     ap.add_argument("--traversal", type=int, nargs="+", default=[1, 2, 3])
     ap.add_argument("--res", type=int, default=1024)
+    ap.add_argument("--sorted-sets", action="store_true", help="also time the bounce / incoherent rays grouped by octant and origin cell")
     args = ap.parse_args()
     import torch
     import __graft_entry__ as graft
@@ -64,6 +65,24 @@ def main():
     bnd = flat.bvh()[0][0]
     incoherent = T.scenes.incoherent_rays(n, bnd[:3], bnd[3:])
     sets = {"primary": primary, "bounce": bounce, "incoherent": incoherent}
+    if args.sorted_sets:
+        # what would ray reordering buy?  the same rays grouped by direction octant, and by octant + origin cell
+        def octant(r):
+            return ((r[:, 4] < 0).astype(np.int64) << 2) | ((r[:, 5] < 0).astype(np.int64) << 1) | (r[:, 6] < 0).astype(np.int64)
+
+        def cell(r, bits):
+            lo, hi = bnd[:3], bnd[3:]
+            q = np.clip(((r[:, 0:3] - lo) / np.maximum(hi - lo, 1e-20) * (1 << bits)).astype(np.int64), 0, (1 << bits) - 1)
+            key = np.zeros(r.shape[0], np.int64)
+            for b in range(bits - 1, -1, -1):
+                for a in range(3):
+                    key = (key << 1) | ((q[:, a] >> b) & 1)
+            return key
+        for nm in ("bounce", "incoherent"):
+            r = sets[nm]
+            sets[nm + "_oct"] = r[np.argsort(octant(r), kind="stable")]
+            sets[nm + "_oct_cell"] = r[np.argsort((octant(r) << 15) | cell(r, 5), kind="stable")]
+            sets[nm + "_cell_oct"] = r[np.argsort((cell(r, 5) << 3) | octant(r), kind="stable")]
     counts = np.zeros(4, np.uint64)
     for name, rays in sets.items():
         d_rays = torch.from_numpy(np.ascontiguousarray(rays)).cuda()

@@ -38,21 +38,49 @@ struct WideScene {            // device view of the v2 node array
     float root_box[6];        // bounds of flat node 0 (tested first, bvh.jl:226)
     uint32_t root_ref, root_cnt;  // root_cnt > 0: the root is a leaf with that many primitives starting at root_ref
     uint32_t n_wnodes;
+    float tight_scale;        // slab_test2's margin as a fraction of the ray's reach (2^-14); 0: the reference's loose test alone
 };
 
 // The t_max-independent part of bounds.jl:186-206; returns false when the box is certainly missed, otherwise tx_min (to be
 // compared with t_max by the caller: `tx_min < ray.t_max`).
-TH_D bool slab_test2(float bx0, float by0, float bz0, float bx1, float by1, float bz1, f3 o, f3 inv_d, bool negx, bool negy, bool negz, float& tmin_out) {
+//
+// The reference's test is LOOSE: `ty_max > tx_max && (tx_max = ty_max)` (bounds.jl:190) keeps the LARGER of the x and y
+// exits, so the earlier of the two never bounds the z entry and a box wholly behind the ray in x or y still passes.  That only
+// costs visits — a box the ray does not pierce holds no primitive the ray can hit — but it costs a lot: a near-horizontal
+// ray leaving a height field visits every box whose y range holds it (measured 8·10⁴ node fetches for single rays of the
+// 1 M-triangle scene, the whole traversal tail).  The kernels here therefore AND the reference's test with the two clauses it
+// lost, made conservative: z entry ≤ min(x exit, y exit) and min(x exit, y exit) ≥ 0, evaluated on the box GROWN by
+// `em` = 2⁻¹⁴ · (largest |coordinate offset| between the ray origin and the scene bound) per axis, in t units (slab_margin).
+// Why that is result-neutral: the reference accepts a primitive only through its own float test (watertight triangle,
+// triangle_mesh.jl:187-243; sphere quadratic, sphere.jl:120-150), whose accepted hit point lies within a few ulps of
+// |v - o| ≤ D of the primitive (translate, shear and edge-function roundings: < 40 ε D), hence inside its leaf box and
+// every ancestor box grown by 2⁻¹⁴ D = 1024 ε D; the slab arithmetic's own error (3 ε per t) is far below the same margin.
+// So every box that holds an acceptable hit passes; boxes the reference rejects are still rejected (its clauses are all
+// kept), and the visit ORDER among the boxes that remain is unchanged, so equal-t ties resolve as before (A.6).
+// Spheres are the exception: the fp32 quadratic (sphere.jl:120-150) carries an absolute error ~ 8 ε |o - c|² in its discriminant,
+// so the reference "hits" spheres the ray passes at up to ~ |o - c| sqrt(8 ε) ≈ 10⁻³ |o - c|; boxes on the path to a sphere
+// (bit 18 / 19 of the node's packed word, set at upload) keep the reference's test alone (`tight` = false), as does the root.
+// NaN (0 · Inf on a face-grazing axis-parallel ray) never rejects: the added comparisons are false on NaN, as the reference's.
+// The literal kernels (traversal 1, th_kernels.h) keep the reference's test alone and serve as the on-device A/B.
+TH_D f3 slab_margin(const float* __restrict__ root_box, float scale, f3 o, f3 inv_d) {
+    const float D = fmaxf(fmaxf(fmaxf(fabsf(root_box[0] - o.x), fabsf(root_box[3] - o.x)), fmaxf(fabsf(root_box[1] - o.y), fabsf(root_box[4] - o.y))),
+                          fmaxf(fabsf(root_box[2] - o.z), fabsf(root_box[5] - o.z)));
+    const float e = D * scale;
+    return mk3(e * fabsf(inv_d.x), e * fabsf(inv_d.y), e * fabsf(inv_d.z));
+}
+TH_D bool slab_test2(float bx0, float by0, float bz0, float bx1, float by1, float bz1, f3 o, f3 inv_d, f3 em, bool tight, bool negx, bool negy, bool negz, float& tmin_out) {
     float tx_min = ((negx ? bx1 : bx0) - o.x) * inv_d.x;
     float tx_max = ((negx ? bx0 : bx1) - o.x) * inv_d.x;
     const float ty_min = ((negy ? by1 : by0) - o.y) * inv_d.y;
     const float ty_max = ((negy ? by0 : by1) - o.y) * inv_d.y;
     if (tx_min > ty_max || ty_min > tx_max) return false;
+    const float exit_xy = fminf(tx_max + em.x, ty_max + em.y);  // fminf drops a NaN operand: no constraint from that axis
     if (ty_min > tx_min) tx_min = ty_min;
     if (ty_max > tx_max) tx_max = ty_max;
     const float tz_min = ((negz ? bz1 : bz0) - o.z) * inv_d.z;
     const float tz_max = ((negz ? bz0 : bz1) - o.z) * inv_d.z;
     if (tx_min > tz_max || tz_min > tx_max) return false;
+    if (tight && (tz_min - em.z > exit_xy || exit_xy < 0.0f)) return false;
     if (tz_min > tx_min) tx_min = tz_min;
     if (tz_max < tx_max) tx_max = tz_max;
     tmin_out = tx_min;
@@ -121,7 +149,8 @@ __global__ __launch_bounds__(kBlock, TH_TRACE2_MIN_WAVES) void k_trace2(DeviceSc
     uint32_t idx = 0, cur = kRefNone, cur_cnt = 0;
     int sp = 0;
     uint32_t steps = 0;  // interior fetches of the current ray (diagnostic budget)
-    f3 o = splat3(0.0f), d = splat3(0.0f), inv_d = splat3(0.0f);
+    f3 o = splat3(0.0f), d = splat3(0.0f), inv_d = splat3(0.0f), em = splat3(0.0f);
+    const bool tight_on = ws.tight_scale > 0.0f;
     RayShear shear{0, 0.0f, 0.0f, 0.0f};  // the triangle test's per-ray part (th_device.h)
     bool negx = false, negy = false, negz = false;
     float t_max = 0.0f, b1 = 0.0f, b2 = 0.0f, hx = 0.0f, slot_w = 0.0f, flag_w = 0.0f;
@@ -155,6 +184,7 @@ __global__ __launch_bounds__(kBlock, TH_TRACE2_MIN_WAVES) void k_trace2(DeviceSc
                         slot_w = o4.w;
                         flag_w = d4.w;
                         inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                        em = slab_margin(ws.root_box, ws.tight_scale, o, inv_d);
                         shear = ray_shear(d);
                         negx = d.x < 0.0f;
                         negy = d.y < 0.0f;
@@ -215,6 +245,7 @@ __global__ __launch_bounds__(kBlock, TH_TRACE2_MIN_WAVES) void k_trace2(DeviceSc
                         slot_w = o4.w;
                         flag_w = d4.w;
                         inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                        em = slab_margin(ws.root_box, ws.tight_scale, o, inv_d);
                         shear = ray_shear(d);
                         negx = d.x < 0.0f;
                         negy = d.y < 0.0f;
@@ -230,7 +261,7 @@ __global__ __launch_bounds__(kBlock, TH_TRACE2_MIN_WAVES) void k_trace2(DeviceSc
                         active = true;
                         float tmin;
                         if (COUNT) nn++;
-                        if (ws.root_ref != kRefNone && slab_test2(ws.root_box[0], ws.root_box[1], ws.root_box[2], ws.root_box[3], ws.root_box[4], ws.root_box[5], o, inv_d, negx, negy, negz, tmin) &&
+                        if (ws.root_ref != kRefNone && slab_test2(ws.root_box[0], ws.root_box[1], ws.root_box[2], ws.root_box[3], ws.root_box[4], ws.root_box[5], o, inv_d, em, false, negx, negy, negz, tmin) &&
                             tmin < t_max) {
                             cur = ws.root_ref;
                             cur_cnt = ws.root_cnt;
@@ -330,8 +361,8 @@ __global__ __launch_bounds__(kBlock, TH_TRACE2_MIN_WAVES) void k_trace2(DeviceSc
                     no_suspend = true;  // the list is full: this ray runs to its end here
                 }
                 float tl, tr;
-                const bool hl = slab_test2(a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, o, inv_d, negx, negy, negz, tl);
-                const bool hr = slab_test2(a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, o, inv_d, negx, negy, negz, tr);
+                const bool hl = slab_test2(a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, o, inv_d, em, tight_on && !(__float_as_uint(a3.z) & (1u << 18)), negx, negy, negz, tl);
+                const bool hr = slab_test2(a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, o, inv_d, em, tight_on && !(__float_as_uint(a3.z) & (1u << 19)), negx, negy, negz, tr);
                 const uint32_t lref = __float_as_uint(a3.x), rref = __float_as_uint(a3.y), packed = __float_as_uint(a3.z);
                 const uint32_t lcnt = packed & 0xffu, rcnt = (packed >> 8) & 0xffu, axis = (packed >> 16) & 3u;
                 const bool neg = axis == 0 ? negx : (axis == 1 ? negy : negz);  // bvh.jl:239: dir_is_neg[split_axis] == 2 -> second child first
@@ -470,13 +501,17 @@ __global__ __launch_bounds__(kBlock, TH_TRACE2_MIN_WAVES) void k_trace3(DeviceSc
     uint32_t wseg = (gtid >> 6) % kSeg, dry = 0, pool_next = 0, pool_end = 0;
     uint32_t idx = 0, cur = kRefNone, cur_cnt = 0;
     int sp = 0;
-    f3 o = splat3(0.0f), d = splat3(0.0f), inv_d = splat3(0.0f);
+    f3 o = splat3(0.0f), d = splat3(0.0f), inv_d = splat3(0.0f), em = splat3(0.0f);
+    const bool tight_on = ws.tight_scale > 0.0f;
     RayShear shear{0, 0.0f, 0.0f, 0.0f};
     bool negx = false, negy = false, negz = false;
     float t_max = 0.0f, b1 = 0.0f, b2 = 0.0f, hx = 0.0f, slot_w = 0.0f, flag_w = 0.0f;
     int hit_prim = -1;
     bool found = false;
     uint32_t nn = 0, np = 0;
+#ifdef TH_DIAG_RAY_VISITS
+    uint32_t rn = 0;  // DIAGNOSTIC build only: interior fetches of the current ray, delivered in hits[].x (tools/visit_probe.py)
+#endif
 
     while (true) {
         // ---- refill idle lanes (as k_trace2) ----------------------------------------------------------------------------------
@@ -510,6 +545,7 @@ __global__ __launch_bounds__(kBlock, TH_TRACE2_MIN_WAVES) void k_trace3(DeviceSc
                         slot_w = o4.w;
                         flag_w = d4.w;
                         inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                        em = slab_margin(ws.root_box, ws.tight_scale, o, inv_d);
                         shear = ray_shear(d);
                         negx = d.x < 0.0f;
                         negy = d.y < 0.0f;
@@ -521,8 +557,11 @@ __global__ __launch_bounds__(kBlock, TH_TRACE2_MIN_WAVES) void k_trace3(DeviceSc
                         b1 = b2 = 0.0f;
                         active = true;
                         float tmin;
+#ifdef TH_DIAG_RAY_VISITS
+                        rn = 0;
+#endif
                         if (COUNT) nn++;
-                        if (ws.root_ref != kRefNone && slab_test2(ws.root_box[0], ws.root_box[1], ws.root_box[2], ws.root_box[3], ws.root_box[4], ws.root_box[5], o, inv_d, negx, negy, negz, tmin) &&
+                        if (ws.root_ref != kRefNone && slab_test2(ws.root_box[0], ws.root_box[1], ws.root_box[2], ws.root_box[3], ws.root_box[4], ws.root_box[5], o, inv_d, em, false, negx, negy, negz, tmin) &&
                             tmin < t_max) {
                             cur = ws.root_ref;
                             cur_cnt = ws.root_cnt;
@@ -595,14 +634,20 @@ __global__ __launch_bounds__(kBlock, TH_TRACE2_MIN_WAVES) void k_trace3(DeviceSc
                     }
                 } else {
                     out.hits[idx] = make_float4(found ? hx : kInf, __int_as_float(found ? hit_prim : -1), b1, b2);
+#ifdef TH_DIAG_RAY_VISITS
+                    out.hits[idx].x = (float)rn;
+#endif
                 }
             }
             if (active && cur != kRefNone && cur_cnt == 0) {  // interior: one 64-byte burst, both child boxes
                 const float4 a0 = ws.wnodes[4 * (size_t)cur], a1 = ws.wnodes[4 * (size_t)cur + 1], a2 = ws.wnodes[4 * (size_t)cur + 2], a3 = ws.wnodes[4 * (size_t)cur + 3];
                 if (COUNT) nn += 2;
+#ifdef TH_DIAG_RAY_VISITS
+                rn++;
+#endif
                 float tl, tr;
-                const bool hl = slab_test2(a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, o, inv_d, negx, negy, negz, tl);
-                const bool hr = slab_test2(a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, o, inv_d, negx, negy, negz, tr);
+                const bool hl = slab_test2(a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, o, inv_d, em, tight_on && !(__float_as_uint(a3.z) & (1u << 18)), negx, negy, negz, tl);
+                const bool hr = slab_test2(a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, o, inv_d, em, tight_on && !(__float_as_uint(a3.z) & (1u << 19)), negx, negy, negz, tr);
                 const uint32_t lref = __float_as_uint(a3.x), rref = __float_as_uint(a3.y), packed = __float_as_uint(a3.z);
                 const uint32_t lcnt = packed & 0xffu, rcnt = (packed >> 8) & 0xffu, axis = (packed >> 16) & 3u;
                 const bool neg = axis == 0 ? negx : (axis == 1 ? negy : negz);

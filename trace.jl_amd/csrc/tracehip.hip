@@ -55,6 +55,8 @@ struct trhip_ctx {
     int bvh_builder = -1;  // BVHAccel construction: 0 = binned SAH on the host (th_bvh.h), 1 = linear BVH on the device (th_lbvh.h),
                            // -1 = automatic: the device builder above 16 Mi primitives.  Measured: commit 0.72 -> 0.13 s (1 M triangles), 8.0 -> 1.5 s
                            // (10 M); the LBVH costs 25-35 % more node visits per ray (frame +4 % at 1 M / 64 spp, +37 % at 10 M / 16 spp)
+    int slab_margin_log2 = 14;       // k_trace2 / k_trace3 add the slab clauses the reference's box test lost, on boxes grown by 2^-this x the ray's reach
+                                     // (th_trace2.h, slab_test2); 0 = the reference's loose test alone (its exact visit set)
     uint32_t tiny_scene_prims = 16;  // scenes of at most this many primitives get a single-leaf BVH (th_bvh.h); 0 = always build the hierarchy
     int film_block = 2;  // film gather: 0 = one film pixel per thread, 1 = 2 x 2 pixels per thread, 2 = TH_FILM_BX x TH_FILM_BY = 1 x 4 (default)
     bool film_tiled = false;  // LDS-staged film gather (k_film_gather_tiled): bit-identical, measured 2.7x SLOWER than k_film_gather (11 % lane use), kept as an option
@@ -354,6 +356,17 @@ int upload_scene(trhip_scene* s) {
             if ((s->bvh.flags[i] & 3u) != 3u) widx[i] = n_int++;
         bool ok = n_int < (1u << 24);
         std::vector<float4> wn((size_t)n_int * 4);
+        // subtrees that hold a sphere keep the reference's loose slab test (th_trace2.h, slab_test2): the fp32 sphere quadratic
+        // (sphere.jl:120-150) accepts rays that pass the sphere at a distance far beyond the tight test's margin
+        std::vector<uint8_t> has_sphere(n_nodes, 0);
+        for (uint32_t i = n_nodes; i-- > 0;) {
+            if ((s->bvh.flags[i] & 3u) == 3u) {
+                const uint32_t first = s->bvh.a[i], cnt = s->bvh.flags[i] >> 2;
+                for (uint32_t k = first; k < first + cnt && k < n_prims; ++k) has_sphere[i] |= s->prims[s->bvh.order[k]].kind == 1;
+            } else {
+                has_sphere[i] = has_sphere[i + 1] | (s->bvh.a[i] < n_nodes ? has_sphere[s->bvh.a[i]] : 1);
+            }
+        }
         for (uint32_t i = 0; i < n_nodes && ok; ++i) {
             if ((s->bvh.flags[i] & 3u) == 3u) continue;
             const uint32_t c[2] = {i + 1, s->bvh.a[i]};
@@ -374,7 +387,8 @@ int upload_scene(trhip_scene* s) {
             w[0] = make_float4(l[0], l[1], l[2], l[3]);
             w[1] = make_float4(l[4], l[5], r[0], r[1]);
             w[2] = make_float4(r[2], r[3], r[4], r[5]);
-            w[3] = make_float4(__builtin_bit_cast(float, ref[0]), __builtin_bit_cast(float, ref[1]), __builtin_bit_cast(float, cnt[0] | (cnt[1] << 8) | ((s->bvh.flags[i] & 3u) << 16)), 0.0f);
+            w[3] = make_float4(__builtin_bit_cast(float, ref[0]), __builtin_bit_cast(float, ref[1]), __builtin_bit_cast(float, cnt[0] | (cnt[1] << 8) | ((s->bvh.flags[i] & 3u) << 16) | ((uint32_t)has_sphere[c[0]] << 18) | ((uint32_t)has_sphere[c[1]] << 19)),
+                               0.0f);
         }
         if (ok) {
             if (int rc = upload(ctx, s->d_wnodes, wn.data(), wn.size() * sizeof(float4))) return rc;
@@ -465,6 +479,13 @@ int ensure_overflow(trhip_ctx* ctx) {
     return ensure(ctx, ctx->overflow, threads * (size_t)(kStack2Total - kStack2Lds) * sizeof(uint2));
 }
 
+// the scene's children-in-parent view with the context's slab margin (option "slab_margin_log2")
+WideScene wide_view(const trhip_ctx* ctx, const trhip_scene* sc) {
+    WideScene w = sc->wide;
+    w.tight_scale = ctx->slab_margin_log2 > 0 ? std::ldexp(1.0f, -ctx->slab_margin_log2) : 0.0f;
+    return w;
+}
+
 // One traversal launch over a queue (count in HBM at count_ptr, or n_max when count_ptr is null).
 // ctx->traversal == 1: the literal accel/bvh.jl loop (k_trace_closest / k_trace_any); 2: k_trace2 (same results).
 void launch_trace(trhip_ctx* ctx, hipStream_t st, const trhip_scene* sc, bool any, SegQueue q, const float4* ro, const float4* rd, const float* tmax, TraceOut out, uint32_t* work_cursors,
@@ -477,14 +498,14 @@ void launch_trace(trhip_ctx* ctx, hipStream_t st, const trhip_scene* sc, bool an
         uint2* ov = (uint2*)(overflow_slab ? overflow_slab : ctx->overflow.p);
         if (any) {
             if (cnt)
-                hipLaunchKernelGGL((k_trace3<true, true>), grid, block, 0, st, sc->dev, sc->wide, q, ro, rd, tmax, out, work_cursors, ov, ctr);
+                hipLaunchKernelGGL((k_trace3<true, true>), grid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, work_cursors, ov, ctr);
             else
-                hipLaunchKernelGGL((k_trace3<true, false>), grid, block, 0, st, sc->dev, sc->wide, q, ro, rd, tmax, out, work_cursors, ov, ctr);
+                hipLaunchKernelGGL((k_trace3<true, false>), grid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, work_cursors, ov, ctr);
         } else {
             if (cnt)
-                hipLaunchKernelGGL((k_trace3<false, true>), grid, block, 0, st, sc->dev, sc->wide, q, ro, rd, tmax, out, work_cursors, ov, ctr);
+                hipLaunchKernelGGL((k_trace3<false, true>), grid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, work_cursors, ov, ctr);
             else
-                hipLaunchKernelGGL((k_trace3<false, false>), grid, block, 0, st, sc->dev, sc->wide, q, ro, rd, tmax, out, work_cursors, ov, ctr);
+                hipLaunchKernelGGL((k_trace3<false, false>), grid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, work_cursors, ov, ctr);
         }
         return;
     }
@@ -492,14 +513,14 @@ void launch_trace(trhip_ctx* ctx, hipStream_t st, const trhip_scene* sc, bool an
         uint2* ov = (uint2*)(overflow_slab ? overflow_slab : ctx->overflow.p);
         if (any) {
             if (cnt)
-                hipLaunchKernelGGL((k_trace2<true, true>), grid, block, 0, st, sc->dev, sc->wide, q, ro, rd, tmax, out, work_cursors, ov, ctr, ctx->debug_trace_budget);
+                hipLaunchKernelGGL((k_trace2<true, true>), grid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, work_cursors, ov, ctr, ctx->debug_trace_budget);
             else
-                hipLaunchKernelGGL((k_trace2<true, false>), grid, block, 0, st, sc->dev, sc->wide, q, ro, rd, tmax, out, work_cursors, ov, ctr, ctx->debug_trace_budget);
+                hipLaunchKernelGGL((k_trace2<true, false>), grid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, work_cursors, ov, ctr, ctx->debug_trace_budget);
         } else {
             if (cnt)
-                hipLaunchKernelGGL((k_trace2<false, true>), grid, block, 0, st, sc->dev, sc->wide, q, ro, rd, tmax, out, work_cursors, ov, ctr, ctx->debug_trace_budget);
+                hipLaunchKernelGGL((k_trace2<false, true>), grid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, work_cursors, ov, ctr, ctx->debug_trace_budget);
             else
-                hipLaunchKernelGGL((k_trace2<false, false>), grid, block, 0, st, sc->dev, sc->wide, q, ro, rd, tmax, out, work_cursors, ov, ctr, ctx->debug_trace_budget);
+                hipLaunchKernelGGL((k_trace2<false, false>), grid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, work_cursors, ov, ctr, ctx->debug_trace_budget);
         }
         return;
     }
@@ -859,9 +880,9 @@ int render_stream_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sen
         const TraceOut oc{hits, nullptr, nullptr, nullptr, 1u};
         tm.begin(1, ps);
         if (cnt)
-            hipLaunchKernelGGL((k_trace2<false, true, true>), grid, block, 0, ps, scene->dev, scene->wide, qc, pq[cur].o, pq[cur].d, nullptr, oc, ctr->work_closest[r], (uint2*)pp.overflow[0].p, ctr, 0u, sc_c);
+            hipLaunchKernelGGL((k_trace2<false, true, true>), grid, block, 0, ps, scene->dev, wide_view(ctx, scene), qc, pq[cur].o, pq[cur].d, nullptr, oc, ctr->work_closest[r], (uint2*)pp.overflow[0].p, ctr, 0u, sc_c);
         else
-            hipLaunchKernelGGL((k_trace2<false, false, true>), grid, block, 0, ps, scene->dev, scene->wide, qc, pq[cur].o, pq[cur].d, nullptr, oc, ctr->work_closest[r], (uint2*)pp.overflow[0].p, ctr, 0u, sc_c);
+            hipLaunchKernelGGL((k_trace2<false, false, true>), grid, block, 0, ps, scene->dev, wide_view(ctx, scene), qc, pq[cur].o, pq[cur].d, nullptr, oc, ctr->work_closest[r], (uint2*)pp.overflow[0].p, ctr, 0u, sc_c);
         tm.end(1, ps);
         if (ps2 != ps && r > 0) HIP_TRY(ctx, hipStreamWaitEvent(ps, pp.ev_any, 0));  // shade(r) reuses the shadow queue
         tm.begin(2, ps);
@@ -880,9 +901,9 @@ int render_stream_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sen
         const TraceOut oa{nullptr, terms, sq.c, nullptr, 0u};
         tm.begin(3, ps2);
         if (cnt)
-            hipLaunchKernelGGL((k_trace2<true, true, true>), grid, block, 0, ps2, scene->dev, scene->wide, qa, sq.o, sq.d, nullptr, oa, ctr->work_shadow[r], (uint2*)pp.overflow[1].p, ctr, 0u, sc_a);
+            hipLaunchKernelGGL((k_trace2<true, true, true>), grid, block, 0, ps2, scene->dev, wide_view(ctx, scene), qa, sq.o, sq.d, nullptr, oa, ctr->work_shadow[r], (uint2*)pp.overflow[1].p, ctr, 0u, sc_a);
         else
-            hipLaunchKernelGGL((k_trace2<true, false, true>), grid, block, 0, ps2, scene->dev, scene->wide, qa, sq.o, sq.d, nullptr, oa, ctr->work_shadow[r], (uint2*)pp.overflow[1].p, ctr, 0u, sc_a);
+            hipLaunchKernelGGL((k_trace2<true, false, true>), grid, block, 0, ps2, scene->dev, wide_view(ctx, scene), qa, sq.o, sq.d, nullptr, oa, ctr->work_shadow[r], (uint2*)pp.overflow[1].p, ctr, 0u, sc_a);
         tm.end(3, ps2);
         if (ps2 != ps) HIP_TRY(ctx, hipEventRecord(pp.ev_any, ps2));
         cur ^= 1;
@@ -1517,6 +1538,8 @@ int trhip_set_option(trhip_ctx* ctx, const char* name, int64_t value) {
         ctx->sppm_batch = (uint64_t)std::max<int64_t>(0, value);
     else if (!std::strcmp(name, "bvh_builder"))
         ctx->bvh_builder = value < 0 ? -1 : (value != 0 ? 1 : 0);
+    else if (!std::strcmp(name, "slab_margin_log2"))
+        ctx->slab_margin_log2 = (int)std::max<int64_t>(0, std::min<int64_t>(20, value));
     else if (!std::strcmp(name, "tiny_scene_prims"))
         ctx->tiny_scene_prims = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(255, value));
     else if (!std::strcmp(name, "film_block"))
