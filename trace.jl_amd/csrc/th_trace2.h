@@ -69,22 +69,24 @@ TH_D f3 slab_margin(const float* __restrict__ root_box, float scale, f3 o, f3 in
     return mk3(e * fabsf(inv_d.x), e * fabsf(inv_d.y), e * fabsf(inv_d.z));
 }
 TH_D bool slab_test2(float bx0, float by0, float bz0, float bx1, float by1, float bz1, f3 o, f3 inv_d, f3 em, bool tight, bool negx, bool negy, bool negz, float& tmin_out) {
-    float tx_min = ((negx ? bx1 : bx0) - o.x) * inv_d.x;
-    float tx_max = ((negx ? bx0 : bx1) - o.x) * inv_d.x;
+    // branch-free on purpose: every value is computed, the clauses are combined with `|` — the whole 64-byte node is then
+    // loaded at once (with early returns the compiler sinks the z loads behind the x-y clause: a second dependent round trip)
+    const float tx_min = ((negx ? bx1 : bx0) - o.x) * inv_d.x;
+    const float tx_max = ((negx ? bx0 : bx1) - o.x) * inv_d.x;
     const float ty_min = ((negy ? by1 : by0) - o.y) * inv_d.y;
     const float ty_max = ((negy ? by0 : by1) - o.y) * inv_d.y;
-    if (tx_min > ty_max || ty_min > tx_max) return false;
-    const float exit_xy = fminf(tx_max + em.x, ty_max + em.y);  // fminf drops a NaN operand: no constraint from that axis
-    if (ty_min > tx_min) tx_min = ty_min;
-    if (ty_max > tx_max) tx_max = ty_max;
     const float tz_min = ((negz ? bz1 : bz0) - o.z) * inv_d.z;
     const float tz_max = ((negz ? bz0 : bz1) - o.z) * inv_d.z;
-    if (tx_min > tz_max || tz_min > tx_max) return false;
-    if (tight && (tz_min - em.z > exit_xy || exit_xy < 0.0f)) return false;
-    if (tz_min > tx_min) tx_min = tz_min;
-    if (tz_max < tx_max) tx_max = tz_max;
-    tmin_out = tx_min;
-    return tx_max > 0.0f;
+    const bool miss_xy = (tx_min > ty_max) | (ty_min > tx_max);     // bounds.jl:188
+    const float a = ty_min > tx_min ? ty_min : tx_min;              // :189
+    const float b = ty_max > tx_max ? ty_max : tx_max;              // :190 (the larger exit: see above)
+    const bool miss_z = (a > tz_max) | (tz_min > b);                // :194
+    const float t_in = tz_min > a ? tz_min : a;                     // :196
+    const float t_out = tz_max < b ? tz_max : b;                    // :197
+    const float exit_xy = fminf(tx_max + em.x, ty_max + em.y);      // fminf drops a NaN operand: no constraint from that axis
+    const bool miss_tight = tight & ((tz_min - em.z > exit_xy) | (exit_xy < 0.0f));
+    tmin_out = t_in;
+    return !(miss_xy | miss_z | miss_tight) & (t_out > 0.0f);       // :198 without its t_max clause (the caller's)
 }
 
 struct TraceOut {
