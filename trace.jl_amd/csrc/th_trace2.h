@@ -363,10 +363,10 @@ __global__ __launch_bounds__(kBlock, TH_TRACE2_MIN_WAVES) void k_trace2(DeviceSc
                     no_suspend = true;  // the list is full: this ray runs to its end here
                 }
                 float tl, tr;
-                const bool hl = slab_test2(a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, o, inv_d, em, tight_on && !(__float_as_uint(a3.z) & (1u << 18)), negx, negy, negz, tl);
-                const bool hr = slab_test2(a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, o, inv_d, em, tight_on && !(__float_as_uint(a3.z) & (1u << 19)), negx, negy, negz, tr);
-                const uint32_t lref = __float_as_uint(a3.x), rref = __float_as_uint(a3.y), packed = __float_as_uint(a3.z);
-                const uint32_t lcnt = packed & 0xffu, rcnt = (packed >> 8) & 0xffu, axis = (packed >> 16) & 3u;
+                const bool hl = slab_test2(a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, o, inv_d, em, tight_on && !(__float_as_uint(a3.z) & 4u), negx, negy, negz, tl);
+                const bool hr = slab_test2(a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, o, inv_d, em, tight_on && !(__float_as_uint(a3.z) & 8u), negx, negy, negz, tr);
+                const uint32_t lenc = __float_as_uint(a3.x), renc = __float_as_uint(a3.y), axis = __float_as_uint(a3.z) & 3u;
+                const uint32_t lref = lenc & 0x00ffffffu, rref = renc & 0x00ffffffu, lcnt = lenc >> 24, rcnt = renc >> 24;
                 const bool neg = axis == 0 ? negx : (axis == 1 ? negy : negz);  // bvh.jl:239: dir_is_neg[split_axis] == 2 -> second child first
                 const bool hn = neg ? hr : hl, hf = neg ? hl : hr;
                 const float tn = neg ? tr : tl, tf = neg ? tl : tr;
@@ -646,37 +646,35 @@ __global__ __launch_bounds__(kBlock, TH_TRACE2_MIN_WAVES) void k_trace3(DeviceSc
                 if (COUNT) nn += 2;
 #ifdef TH_DIAG_RAY_VISITS
                 rn++;
-#endif
+                const uint32_t lenc = __float_as_uint(a3.x), renc = __float_as_uint(a3.y), meta = __float_as_uint(a3.z);
                 float tl, tr;
-                const bool hl = slab_test2(a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, o, inv_d, em, tight_on && !(__float_as_uint(a3.z) & (1u << 18)), negx, negy, negz, tl);
-                const bool hr = slab_test2(a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, o, inv_d, em, tight_on && !(__float_as_uint(a3.z) & (1u << 19)), negx, negy, negz, tr);
-                const uint32_t lref = __float_as_uint(a3.x), rref = __float_as_uint(a3.y), packed = __float_as_uint(a3.z);
-                const uint32_t lcnt = packed & 0xffu, rcnt = (packed >> 8) & 0xffu, axis = (packed >> 16) & 3u;
-                const bool neg = axis == 0 ? negx : (axis == 1 ? negy : negz);
-                const bool hn = neg ? hr : hl, hf = neg ? hl : hr;
-                const float tn = neg ? tr : tl, tf = neg ? tl : tr;
-                const uint32_t nref = neg ? rref : lref, fref = neg ? lref : rref, ncnt = neg ? rcnt : lcnt, fcnt = neg ? lcnt : rcnt;
-                if (hn && tn < t_max) {
-                    if (hf) {
-                        const uint32_t enc = fref | (fcnt << 24);
-                        if (sp < kStack2Lds) {
-                            s_ref[sp][tid] = enc;
-                            s_tmin[sp][tid] = tf;
-                        } else if (sp < kStack2Total) {
-                            overflow[(size_t)(sp - kStack2Lds) * gthreads + gtid] = make_uint2(enc, __float_as_uint(tf));
-                        }
-                        sp++;
+                const bool hl = slab_test2(a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, o, inv_d, em, tight_on && !(meta & 4u), negx, negy, negz, tl);
+                const bool hr = slab_test2(a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, o, inv_d, em, tight_on && !(meta & 8u), negx, negy, negz, tr);
+                // a missed child gets tx_min = +Inf: it then fails `tx_min < t_max` like a hit one beyond t_max (a NaN tx_min fails it too, as in bounds.jl:198)
+                const float tlh = hl ? tl : kInf, trh = hr ? tr : kInf;
+                const uint32_t axis = meta & 3u;
+                const bool neg = axis == 0 ? negx : (axis == 1 ? negy : negz);  // bvh.jl:239: dir_is_neg[split_axis] == 2 -> second child first
+                const float tn = neg ? trh : tlh, tf = neg ? tlh : trh;
+                const uint32_t nenc = neg ? renc : lenc, fenc = neg ? lenc : renc;
+                const bool go_n = tn < t_max, go_f = tf < t_max;
+                // The far child waits on the stack whenever its box is hit at all, NOT only when tx_min < t_max now: t_max is not
+                // monotonic in the reference — a sphere entered from inside returns t1 without looking at t_max (sphere.jl:143-147)
+                // and raises it — so the clause has to be evaluated when the entry is popped, as bvh.jl:226 does at visit time.
+                if (go_n & (tf < kInf)) {
+                    if (sp < kStack2Lds) {
+                        s_ref[sp][tid] = fenc;
+                        s_tmin[sp][tid] = tf;
+                    } else if (sp < kStack2Total) {
+                        overflow[(size_t)(sp - kStack2Lds) * gthreads + gtid] = make_uint2(fenc, __float_as_uint(tf));
                     }
-                    cur = nref;
-                    cur_cnt = ncnt;
-                } else if (hf && tf < t_max) {
-                    cur = fref;
-                    cur_cnt = fcnt;
-                } else {
-                    cur = kRefNone;
-                    cur_cnt = 0;
+                    sp++;
                 }
+                const uint32_t nxt = go_n ? nenc : fenc;
+                const bool any_child = go_n | go_f;
+                cur = any_child ? (nxt & 0x00ffffffu) : kRefNone;
+                cur_cnt = any_child ? (nxt >> 24) : 0u;
             }
+#endif
             // lanes that can go on without touching a leaf; when few are left, everybody's leaves are tested together
             const uint32_t n_desc = (uint32_t)__popcll(__ballot(active && cur_cnt == 0));
             if (n_desc <= (uint32_t)TH_TRACE3_LEAF_WAIT) break;

@@ -387,8 +387,9 @@ int upload_scene(trhip_scene* s) {
             w[0] = make_float4(l[0], l[1], l[2], l[3]);
             w[1] = make_float4(l[4], l[5], r[0], r[1]);
             w[2] = make_float4(r[2], r[3], r[4], r[5]);
-            w[3] = make_float4(__builtin_bit_cast(float, ref[0]), __builtin_bit_cast(float, ref[1]), __builtin_bit_cast(float, cnt[0] | (cnt[1] << 8) | ((s->bvh.flags[i] & 3u) << 16) | ((uint32_t)has_sphere[c[0]] << 18) | ((uint32_t)has_sphere[c[1]] << 19)),
-                               0.0f);
+            // child word = ref | count << 24 (the stack entry format); meta = split axis | "subtree holds a sphere" bits 2 (first) / 3 (second)
+            w[3] = make_float4(__builtin_bit_cast(float, ref[0] | (cnt[0] << 24)), __builtin_bit_cast(float, ref[1] | (cnt[1] << 24)),
+                               __builtin_bit_cast(float, (s->bvh.flags[i] & 3u) | ((uint32_t)has_sphere[c[0]] << 2) | ((uint32_t)has_sphere[c[1]] << 3)), 0.0f);
         }
         if (ok) {
             if (int rc = upload(ctx, s->d_wnodes, wn.data(), wn.size() * sizeof(float4))) return rc;
