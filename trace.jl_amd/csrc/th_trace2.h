@@ -646,6 +646,7 @@ __global__ __launch_bounds__(kBlock, TH_TRACE2_MIN_WAVES) void k_trace3(DeviceSc
                 if (COUNT) nn += 2;
 #ifdef TH_DIAG_RAY_VISITS
                 rn++;
+#endif
                 const uint32_t lenc = __float_as_uint(a3.x), renc = __float_as_uint(a3.y), meta = __float_as_uint(a3.z);
                 float tl, tr;
                 const bool hl = slab_test2(a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, o, inv_d, em, tight_on && !(meta & 4u), negx, negy, negz, tl);
@@ -674,7 +675,6 @@ __global__ __launch_bounds__(kBlock, TH_TRACE2_MIN_WAVES) void k_trace3(DeviceSc
                 cur = any_child ? (nxt & 0x00ffffffu) : kRefNone;
                 cur_cnt = any_child ? (nxt >> 24) : 0u;
             }
-#endif
             // lanes that can go on without touching a leaf; when few are left, everybody's leaves are tested together
             const uint32_t n_desc = (uint32_t)__popcll(__ballot(active && cur_cnt == 0));
             if (n_desc <= (uint32_t)TH_TRACE3_LEAF_WAIT) break;
