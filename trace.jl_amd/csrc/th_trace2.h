@@ -27,6 +27,13 @@ namespace th {
 #endif
 constexpr int kStack2Lds = TH_STACK2_LDS;  // stack levels per lane kept in LDS
 constexpr int kStack2Total = 64;
+#ifndef TH_TRACE3_ANY_WAVES
+#define TH_TRACE3_ANY_WAVES 5  // k_trace3<ANY = true>: waves per SIMD asked of the compiler (96 VGPRs), with TH_TRACE3_ANY_LDS stack levels in LDS
+#endif
+#ifndef TH_TRACE3_ANY_LDS
+#define TH_TRACE3_ANY_LDS 12
+#endif
+constexpr int kStackMinLds = kStack2Lds < TH_TRACE3_ANY_LDS ? kStack2Lds : TH_TRACE3_ANY_LDS;  // the global overflow slab holds the levels above this
 constexpr uint32_t kRefNone = 0xffffffffu;
 #ifndef TH_TRACE_REFILL
 #define TH_TRACE_REFILL 12  // idle lanes of a wave that trigger a refill from the queue
@@ -487,10 +494,13 @@ __global__ __launch_bounds__(kBlock, TH_TRACE2_MIN_WAVES) void k_trace2(DeviceSc
 #define TH_TRACE3_MAX_A 8
 #endif
 template <bool ANY, bool COUNT>
-__global__ __launch_bounds__(kBlock, TH_TRACE2_MIN_WAVES) void k_trace3(DeviceScene sc, WideScene ws, SegQueue q, const float4* __restrict__ ro, const float4* __restrict__ rd, const float* __restrict__ tmax_or_null,
+__global__ __launch_bounds__(kBlock, ANY ? TH_TRACE3_ANY_WAVES : TH_TRACE2_MIN_WAVES) void k_trace3(DeviceScene sc, WideScene ws, SegQueue q, const float4* __restrict__ ro, const float4* __restrict__ rd, const float* __restrict__ tmax_or_null,
                                                    TraceOut out, uint32_t* __restrict__ work, uint2* __restrict__ overflow, Counters* ctr) {
-    __shared__ uint32_t s_ref[kStack2Lds][kBlock];
-    __shared__ float s_tmin[kStack2Lds][kBlock];
+    // the any-hit variant fits 96 VGPRs without spilling: 5 waves per SIMD when its LDS stack is 12 levels (24 KB per block);
+    // the closest-hit variant needs ~120 VGPRs (4 waves) either way and keeps 16 (measured: S-mesh any-hit 170 -> 152 ms)
+    constexpr int kLds = ANY ? TH_TRACE3_ANY_LDS : kStack2Lds;
+    __shared__ uint32_t s_ref[kLds][kBlock];
+    __shared__ float s_tmin[kLds][kBlock];
     __shared__ SegView sv;
     seg_load(q, sv);
     const uint32_t tid = threadIdx.x;
@@ -590,11 +600,11 @@ __global__ __launch_bounds__(kBlock, TH_TRACE2_MIN_WAVES) void k_trace3(DeviceSc
                     sp--;
                     uint32_t enc;
                     float tm;
-                    if (sp < kStack2Lds) {
+                    if (sp < kLds) {
                         enc = s_ref[sp][tid];
                         tm = s_tmin[sp][tid];
                     } else if (sp < kStack2Total) {
-                        const uint2 e = overflow[(size_t)(sp - kStack2Lds) * gthreads + gtid];
+                        const uint2 e = overflow[(size_t)(sp - kLds) * gthreads + gtid];
                         enc = e.x;
                         tm = __uint_as_float(e.y);
                     } else {
@@ -662,11 +672,11 @@ __global__ __launch_bounds__(kBlock, TH_TRACE2_MIN_WAVES) void k_trace3(DeviceSc
                 // monotonic in the reference — a sphere entered from inside returns t1 without looking at t_max (sphere.jl:143-147)
                 // and raises it — so the clause has to be evaluated when the entry is popped, as bvh.jl:226 does at visit time.
                 if (go_n & (tf < kInf)) {
-                    if (sp < kStack2Lds) {
+                    if (sp < kLds) {
                         s_ref[sp][tid] = fenc;
                         s_tmin[sp][tid] = tf;
                     } else if (sp < kStack2Total) {
-                        overflow[(size_t)(sp - kStack2Lds) * gthreads + gtid] = make_uint2(fenc, __float_as_uint(tf));
+                        overflow[(size_t)(sp - kLds) * gthreads + gtid] = make_uint2(fenc, __float_as_uint(tf));
                     }
                     sp++;
                 }

@@ -477,7 +477,7 @@ int trace_grid(const trhip_ctx* ctx) { return ctx->num_cu * TH_TRACE_BLOCKS_PER_
 // k_trace2 keeps stack levels 16..63 of every resident thread in a global slab laid out [level][thread].
 int ensure_overflow(trhip_ctx* ctx) {
     const size_t threads = (size_t)trace_grid(ctx) * kBlock;
-    return ensure(ctx, ctx->overflow, threads * (size_t)(kStack2Total - kStack2Lds) * sizeof(uint2));
+    return ensure(ctx, ctx->overflow, threads * (size_t)(kStack2Total - kStackMinLds) * sizeof(uint2));
 }
 
 // the scene's children-in-parent view with the context's slab margin (option "slab_margin_log2")
@@ -810,7 +810,7 @@ int render_stream_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sen
         if (int rc = ensure(ctx, pp.sq[j], Pphys * sizeof(float4))) return rc;
     if (int rc = ensure(ctx, pp.hits, Pphys * sizeof(float4))) return rc;
     if (int rc = ensure(ctx, pp.counters, sizeof(Counters))) return rc;
-    const size_t slab_bytes = (size_t)trace_grid(ctx) * kBlock * (size_t)(kStack2Total - kStack2Lds) * sizeof(uint2);
+    const size_t slab_bytes = (size_t)trace_grid(ctx) * kBlock * (size_t)(kStack2Total - kStackMinLds) * sizeof(uint2);
     for (int k = 0; k < 2; ++k)
         if (int rc = ensure(ctx, pp.overflow[k], slab_bytes)) return rc;
     if (int rc = ensure(ctx, ctx->Lbuf, total_slots * sizeof(float4))) return rc;
@@ -1040,7 +1040,7 @@ int render_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sensor* se
     const uint64_t Pphys = (uint64_t)cap * kSeg;
     if (int rc = upload(ctx, ctx->sensor, &ds, sizeof ds)) return rc;
     if (int rc = upload(ctx, ctx->table, sensor->filter_table, 256 * sizeof(float))) return rc;
-    const size_t slab_bytes = (size_t)trace_grid(ctx) * kBlock * (size_t)(kStack2Total - kStack2Lds) * sizeof(uint2);
+    const size_t slab_bytes = (size_t)trace_grid(ctx) * kBlock * (size_t)(kStack2Total - kStackMinLds) * sizeof(uint2);
     for (int pi = 0; pi < NP; ++pi) {
         Pipe& pp = ctx->pipes[pi];
         if (!pp.st) {
@@ -1243,7 +1243,7 @@ int render_sppm_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
         if (int rc = ensure(ctx, pp.sq[j], Pphys * sizeof(float4))) return rc;
     if (int rc = ensure(ctx, pp.hits, Pphys * sizeof(float4))) return rc;
     if (int rc = ensure(ctx, pp.counters, sizeof(Counters))) return rc;
-    const size_t slab_bytes = (size_t)trace_grid(ctx) * kBlock * (size_t)(kStack2Total - kStack2Lds) * sizeof(uint2);
+    const size_t slab_bytes = (size_t)trace_grid(ctx) * kBlock * (size_t)(kStack2Total - kStackMinLds) * sizeof(uint2);
     if (int rc = ensure(ctx, pp.overflow[0], slab_bytes)) return rc;
     for (auto& b : ctx->sp_vp)
         if (int rc = ensure(ctx, b, (size_t)B * n * sizeof(float4))) return rc;
