@@ -27,13 +27,23 @@ namespace th {
 #endif
 constexpr int kStack2Lds = TH_STACK2_LDS;  // stack levels per lane kept in LDS
 constexpr int kStack2Total = 64;
-#ifndef TH_TRACE3_ANY_WAVES
-#define TH_TRACE3_ANY_WAVES 5  // k_trace3<ANY = true>: waves per SIMD asked of the compiler (96 VGPRs), with TH_TRACE3_ANY_LDS stack levels in LDS
+// k_trace3 occupancy: waves per SIMD asked of the compiler and stack levels kept in LDS (levels x 2 KB per block of 256 lanes).
+// Measured on the S-mesh frame (ms): closest-hit 4 waves / 16 levels 360, 5 / 12 (spills ~10 of its 106 VGPRs) 330, 6 / 10 397;
+// any-hit (93 VGPRs) 4 / 16: 170, 5 / 12: 155, 6 / 10: 144.
+#ifndef TH_TRACE3_WAVES_CLOSEST
+#define TH_TRACE3_WAVES_CLOSEST 5
 #endif
-#ifndef TH_TRACE3_ANY_LDS
-#define TH_TRACE3_ANY_LDS 12
+#ifndef TH_TRACE3_LDS_CLOSEST
+#define TH_TRACE3_LDS_CLOSEST 12
 #endif
-constexpr int kStackMinLds = kStack2Lds < TH_TRACE3_ANY_LDS ? kStack2Lds : TH_TRACE3_ANY_LDS;  // the global overflow slab holds the levels above this
+#ifndef TH_TRACE3_WAVES_ANY
+#define TH_TRACE3_WAVES_ANY 6
+#endif
+#ifndef TH_TRACE3_LDS_ANY
+#define TH_TRACE3_LDS_ANY 10
+#endif
+constexpr int kStack3MinLds = TH_TRACE3_LDS_CLOSEST < TH_TRACE3_LDS_ANY ? TH_TRACE3_LDS_CLOSEST : TH_TRACE3_LDS_ANY;
+constexpr int kStackMinLds = kStack2Lds < kStack3MinLds ? kStack2Lds : kStack3MinLds;  // the global overflow slab holds the levels above this
 constexpr uint32_t kRefNone = 0xffffffffu;
 #ifndef TH_TRACE_REFILL
 #define TH_TRACE_REFILL 12  // idle lanes of a wave that trigger a refill from the queue
@@ -494,11 +504,9 @@ __global__ __launch_bounds__(kBlock, TH_TRACE2_MIN_WAVES) void k_trace2(DeviceSc
 #define TH_TRACE3_MAX_A 8
 #endif
 template <bool ANY, bool COUNT>
-__global__ __launch_bounds__(kBlock, ANY ? TH_TRACE3_ANY_WAVES : TH_TRACE2_MIN_WAVES) void k_trace3(DeviceScene sc, WideScene ws, SegQueue q, const float4* __restrict__ ro, const float4* __restrict__ rd, const float* __restrict__ tmax_or_null,
+__global__ __launch_bounds__(kBlock, ANY ? TH_TRACE3_WAVES_ANY : TH_TRACE3_WAVES_CLOSEST) void k_trace3(DeviceScene sc, WideScene ws, SegQueue q, const float4* __restrict__ ro, const float4* __restrict__ rd, const float* __restrict__ tmax_or_null,
                                                    TraceOut out, uint32_t* __restrict__ work, uint2* __restrict__ overflow, Counters* ctr) {
-    // the any-hit variant fits 96 VGPRs without spilling: 5 waves per SIMD when its LDS stack is 12 levels (24 KB per block);
-    // the closest-hit variant needs ~120 VGPRs (4 waves) either way and keeps 16 (measured: S-mesh any-hit 170 -> 152 ms)
-    constexpr int kLds = ANY ? TH_TRACE3_ANY_LDS : kStack2Lds;
+    constexpr int kLds = ANY ? TH_TRACE3_LDS_ANY : TH_TRACE3_LDS_CLOSEST;
     __shared__ uint32_t s_ref[kLds][kBlock];
     __shared__ float s_tmin[kLds][kBlock];
     __shared__ SegView sv;
@@ -513,7 +521,7 @@ __global__ __launch_bounds__(kBlock, ANY ? TH_TRACE3_ANY_WAVES : TH_TRACE2_MIN_W
     uint32_t wseg = (gtid >> 6) % kSeg, dry = 0, pool_next = 0, pool_end = 0;
     uint32_t idx = 0, cur = kRefNone, cur_cnt = 0;
     int sp = 0;
-    f3 o = splat3(0.0f), d = splat3(0.0f), inv_d = splat3(0.0f), em = splat3(0.0f);
+    f3 o = splat3(0.0f), inv_d = splat3(0.0f), em = splat3(0.0f);  // the direction itself is not kept: only spheres need it (reloaded there)
     const bool tight_on = ws.tight_scale > 0.0f;
     RayShear shear{0, 0.0f, 0.0f, 0.0f};
     bool negx = false, negy = false, negz = false;
@@ -553,7 +561,7 @@ __global__ __launch_bounds__(kBlock, ANY ? TH_TRACE3_ANY_WAVES : TH_TRACE2_MIN_W
                         idx = seg_phys(q, wseg, pool_next + rank);
                         const float4 o4 = ro[idx], d4 = rd[idx];
                         o = mk3(o4.x, o4.y, o4.z);
-                        d = mk3(d4.x, d4.y, d4.z);
+                        const f3 d = mk3(d4.x, d4.y, d4.z);
                         slot_w = o4.w;
                         flag_w = d4.w;
                         inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
@@ -699,8 +707,16 @@ __global__ __launch_bounds__(kBlock, ANY ? TH_TRACE3_ANY_WAVES : TH_TRACE2_MIN_W
                 const uint32_t meta = __float_as_uint(p0.w);
                 if (COUNT) np++;
                 if (meta & PRIM_SPHERE) {
+                    // rare: fetch the direction again, and rebuild what derives from it afterwards — that way none of it is live across
+                    // the sphere code (transform, quadratic, divisions), which otherwise sets the kernel's register count
+                    const float4 d4 = rd[idx];
+                    const f3 d = mk3(d4.x, d4.y, d4.z);
                     SphereHit sh;
-                    if (sphere_intersect<false>(sc.spheres[__float_as_uint(p0.x)], o, d, t_max, sh)) {
+                    const bool sphere_hit = sphere_intersect<false>(sc.spheres[__float_as_uint(p0.x)], o, d, t_max, sh);
+                    inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                    em = slab_margin(ws.root_box, ws.tight_scale, o, inv_d);
+                    shear = ray_shear(d);
+                    if (sphere_hit) {
                         if (ANY) {
                             hit_any = true;
                             break;

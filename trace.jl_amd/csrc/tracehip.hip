@@ -470,7 +470,7 @@ void launch_film(trhip_ctx* ctx, hipStream_t st, const DeviceSensor& ds, const D
 }
 
 #ifndef TH_TRACE_BLOCKS_PER_CU
-#define TH_TRACE_BLOCKS_PER_CU 5
+#define TH_TRACE_BLOCKS_PER_CU 6
 #endif
 int trace_grid(const trhip_ctx* ctx) { return ctx->num_cu * TH_TRACE_BLOCKS_PER_CU; }  // persistent blocks per CU (LDS stack: kStack2Lds x 256 x 8 B each)
 
