@@ -67,7 +67,7 @@ struct WideScene {            // device view of the v2 node array
 // ray leaving a height field visits every box whose y range holds it (measured 8·10⁴ node fetches for single rays of the
 // 1 M-triangle scene, the whole traversal tail).  The kernels here therefore AND the reference's test with the two clauses it
 // lost, made conservative: z entry ≤ min(x exit, y exit) and min(x exit, y exit) ≥ 0, evaluated on the box GROWN by
-// `em` = 2⁻¹⁴ · (largest |coordinate offset| between the ray origin and the scene bound) per axis, in t units (slab_margin).
+// `em` = 2⁻¹⁴ · (largest |coordinate offset| between the ray origin and the scene bound), per axis in t units (slab_margin).
 // Why that is result-neutral: the reference accepts a primitive only through its own float test (watertight triangle,
 // triangle_mesh.jl:187-243; sphere quadratic, sphere.jl:120-150), whose accepted hit point lies within a few ulps of
 // |v - o| ≤ D of the primitive (translate, shear and edge-function roundings: < 40 ε D), hence inside its leaf box and
@@ -79,13 +79,12 @@ struct WideScene {            // device view of the v2 node array
 // (bit 18 / 19 of the node's packed word, set at upload) keep the reference's test alone (`tight` = false), as does the root.
 // NaN (0 · Inf on a face-grazing axis-parallel ray) never rejects: the added comparisons are false on NaN, as the reference's.
 // The literal kernels (traversal 1, th_kernels.h) keep the reference's test alone and serve as the on-device A/B.
-TH_D f3 slab_margin(const float* __restrict__ root_box, float scale, f3 o, f3 inv_d) {
+TH_D float slab_margin(const float* __restrict__ root_box, float scale, f3 o) {
     const float D = fmaxf(fmaxf(fmaxf(fabsf(root_box[0] - o.x), fabsf(root_box[3] - o.x)), fmaxf(fabsf(root_box[1] - o.y), fabsf(root_box[4] - o.y))),
                           fmaxf(fabsf(root_box[2] - o.z), fabsf(root_box[5] - o.z)));
-    const float e = D * scale;
-    return mk3(e * fabsf(inv_d.x), e * fabsf(inv_d.y), e * fabsf(inv_d.z));
+    return D * scale;  // in length units; slab_test2 turns it into t units per axis (x |1 / d|)
 }
-TH_D bool slab_test2(float bx0, float by0, float bz0, float bx1, float by1, float bz1, f3 o, f3 inv_d, f3 em, bool tight, bool negx, bool negy, bool negz, float& tmin_out) {
+TH_D bool slab_test2(float bx0, float by0, float bz0, float bx1, float by1, float bz1, f3 o, f3 inv_d, float em, bool tight, bool negx, bool negy, bool negz, float& tmin_out) {
     // branch-free on purpose: every value is computed, the clauses are combined with `|` — the whole 64-byte node is then
     // loaded at once (with early returns the compiler sinks the z loads behind the x-y clause: a second dependent round trip)
     const float tx_min = ((negx ? bx1 : bx0) - o.x) * inv_d.x;
@@ -100,8 +99,9 @@ TH_D bool slab_test2(float bx0, float by0, float bz0, float bx1, float by1, floa
     const bool miss_z = (a > tz_max) | (tz_min > b);                // :194
     const float t_in = tz_min > a ? tz_min : a;                     // :196
     const float t_out = tz_max < b ? tz_max : b;                    // :197
-    const float exit_xy = fminf(tx_max + em.x, ty_max + em.y);      // fminf drops a NaN operand: no constraint from that axis
-    const bool miss_tight = tight & ((tz_min - em.z > exit_xy) | (exit_xy < 0.0f));
+    // margins by explicit fma (one instruction each; their rounding is immaterial); fminf drops a NaN operand: no constraint from that axis
+    const float exit_xy = fminf(__fmaf_rn(em, fabsf(inv_d.x), tx_max), __fmaf_rn(em, fabsf(inv_d.y), ty_max));
+    const bool miss_tight = tight & ((__fmaf_rn(-em, fabsf(inv_d.z), tz_min) > exit_xy) | (exit_xy < 0.0f));
     tmin_out = t_in;
     return !(miss_xy | miss_z | miss_tight) & (t_out > 0.0f);       // :198 without its t_max clause (the caller's)
 }
@@ -168,7 +168,8 @@ __global__ __launch_bounds__(kBlock, TH_TRACE2_MIN_WAVES) void k_trace2(DeviceSc
     uint32_t idx = 0, cur = kRefNone, cur_cnt = 0;
     int sp = 0;
     uint32_t steps = 0;  // interior fetches of the current ray (diagnostic budget)
-    f3 o = splat3(0.0f), d = splat3(0.0f), inv_d = splat3(0.0f), em = splat3(0.0f);
+    f3 o = splat3(0.0f), d = splat3(0.0f), inv_d = splat3(0.0f);
+    float em = 0.0f;
     const bool tight_on = ws.tight_scale > 0.0f;
     RayShear shear{0, 0.0f, 0.0f, 0.0f};  // the triangle test's per-ray part (th_device.h)
     bool negx = false, negy = false, negz = false;
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(kBlock, TH_TRACE2_MIN_WAVES) void k_trace2(DeviceSc
                         slot_w = o4.w;
                         flag_w = d4.w;
                         inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-                        em = slab_margin(ws.root_box, ws.tight_scale, o, inv_d);
+                        em = slab_margin(ws.root_box, ws.tight_scale, o);
                         shear = ray_shear(d);
                         negx = d.x < 0.0f;
                         negy = d.y < 0.0f;
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(kBlock, TH_TRACE2_MIN_WAVES) void k_trace2(DeviceSc
                         slot_w = o4.w;
                         flag_w = d4.w;
                         inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-                        em = slab_margin(ws.root_box, ws.tight_scale, o, inv_d);
+                        em = slab_margin(ws.root_box, ws.tight_scale, o);
                         shear = ray_shear(d);
                         negx = d.x < 0.0f;
                         negy = d.y < 0.0f;
@@ -518,15 +519,15 @@ __global__ __launch_bounds__(kBlock, ANY ? TH_TRACE3_WAVES_ANY : TH_TRACE3_WAVES
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
     bool active = false, exhausted = false;
-    uint32_t wseg = (gtid >> 6) % kSeg, dry = 0, pool_next = 0, pool_end = 0;
+    uint32_t wseg = __builtin_amdgcn_readfirstlane((gtid >> 6) % kSeg), dry = 0, pool_next = 0, pool_end = 0;  // wave-uniform: scalar registers
     uint32_t idx = 0, cur = kRefNone, cur_cnt = 0;
     int sp = 0;
-    f3 o = splat3(0.0f), inv_d = splat3(0.0f), em = splat3(0.0f);  // the direction itself is not kept: only spheres need it (reloaded there)
+    f3 o = splat3(0.0f), inv_d = splat3(0.0f);  // the direction itself is not kept: only spheres need it (reloaded there)
+    float em = 0.0f;
     const bool tight_on = ws.tight_scale > 0.0f;
     RayShear shear{0, 0.0f, 0.0f, 0.0f};
     bool negx = false, negy = false, negz = false;
-    float t_max = 0.0f, b1 = 0.0f, b2 = 0.0f, hx = 0.0f, slot_w = 0.0f, flag_w = 0.0f;
-    int hit_prim = -1;
+    float t_max = 0.0f, slot_w = 0.0f, flag_w = 0.0f;
     bool found = false;
     uint32_t nn = 0, np = 0;
 #ifdef TH_DIAG_RAY_VISITS
@@ -542,8 +543,8 @@ __global__ __launch_bounds__(kBlock, ANY ? TH_TRACE3_WAVES_ANY : TH_TRACE3_WAVES
                 if (pool_next >= pool_end) {
                     uint32_t base = 0;
                     if (lane == 0) base = atomicAdd(&work[wseg * kCtrStride], (uint32_t)kChunk);
-                    base = __shfl(base, 0);
-                    const uint32_t cnt = sv.count[wseg];
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    const uint32_t cnt = __builtin_amdgcn_readfirstlane(sv.count[wseg]);
                     if (base < cnt) {
                         pool_next = base;
                         pool_end = min(base + (uint32_t)kChunk, cnt);
@@ -565,7 +566,7 @@ __global__ __launch_bounds__(kBlock, ANY ? TH_TRACE3_WAVES_ANY : TH_TRACE3_WAVES
                         slot_w = o4.w;
                         flag_w = d4.w;
                         inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-                        em = slab_margin(ws.root_box, ws.tight_scale, o, inv_d);
+                        em = slab_margin(ws.root_box, ws.tight_scale, o);
                         shear = ray_shear(d);
                         negx = d.x < 0.0f;
                         negy = d.y < 0.0f;
@@ -573,8 +574,6 @@ __global__ __launch_bounds__(kBlock, ANY ? TH_TRACE3_WAVES_ANY : TH_TRACE3_WAVES
                         t_max = tmax_or_null ? tmax_or_null[idx] : kInf;
                         sp = 0;
                         found = false;
-                        hit_prim = -1;
-                        b1 = b2 = 0.0f;
                         active = true;
                         float tmin;
 #ifdef TH_DIAG_RAY_VISITS
@@ -653,7 +652,7 @@ __global__ __launch_bounds__(kBlock, ANY ? TH_TRACE3_WAVES_ANY : TH_TRACE3_WAVES
                         out.occluded[idx] = found ? 1 : 0;
                     }
                 } else {
-                    out.hits[idx] = make_float4(found ? hx : kInf, __int_as_float(found ? hit_prim : -1), b1, b2);
+                    if (!found) out.hits[idx] = make_float4(kInf, __int_as_float(-1), 0.0f, 0.0f);  // a hit was stored when it was accepted
 #ifdef TH_DIAG_RAY_VISITS
                     out.hits[idx].x = (float)rn;
 #endif
@@ -714,7 +713,7 @@ __global__ __launch_bounds__(kBlock, ANY ? TH_TRACE3_WAVES_ANY : TH_TRACE3_WAVES
                     SphereHit sh;
                     const bool sphere_hit = sphere_intersect<false>(sc.spheres[__float_as_uint(p0.x)], o, d, t_max, sh);
                     inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-                    em = slab_margin(ws.root_box, ws.tight_scale, o, inv_d);
+                    em = slab_margin(ws.root_box, ws.tight_scale, o);
                     shear = ray_shear(d);
                     if (sphere_hit) {
                         if (ANY) {
@@ -723,9 +722,7 @@ __global__ __launch_bounds__(kBlock, ANY ? TH_TRACE3_WAVES_ANY : TH_TRACE3_WAVES
                         }
                         t_max = sh.t;
                         found = true;
-                        hit_prim = (int)slot;
-                        b1 = b2 = 0.0f;
-                        hx = sh.t;
+                        out.hits[idx] = make_float4(sh.t, __int_as_float((int)slot), 0.0f, 0.0f);  // stored at once: a later accepted hit overwrites it
                     }
                 } else {
                     TriTest tt;
@@ -736,10 +733,7 @@ __global__ __launch_bounds__(kBlock, ANY ? TH_TRACE3_WAVES_ANY : TH_TRACE3_WAVES
                         }
                         t_max = tt.t;
                         found = true;
-                        hit_prim = (int)slot;
-                        b1 = tt.bary.x;
-                        b2 = tt.bary.y;
-                        hx = out.bary_mode ? tt.bary.z : tt.t;
+                        out.hits[idx] = make_float4(out.bary_mode ? tt.bary.z : tt.t, __int_as_float((int)slot), tt.bary.x, tt.bary.y);
                     }
                 }
             }
