@@ -213,6 +213,10 @@ int trhip_film_accumulate(trhip_ctx* ctx, const trhip_sensor* sensor, uint32_t s
  * "bvh_builder" (-1/0/1): how trhip_scene_commit builds the BVH: 0 = binned SAH on the host, 1 = linear BVH on the device
  *     (Morton keys, radix sort, Karras hierarchy; ~6x faster to build, 25-35 % more node visits per ray), -1 (default) = the
  *     device builder above 16 Mi primitives.  Either tree is a valid BVHAccel: results differ only in exact-t ties.
+ * "slab_margin_log2" (0..20, default 14): traversal 2 / 3 add to the reference's box test (bounds.jl:180-200) the two slab
+ *     clauses it lost — it keeps the larger of the x and y exits — evaluated on boxes grown by 2^-N x the ray's reach; boxes on
+ *     the path to a sphere keep the reference's test alone.  Fewer boxes visited, same results bit for bit;
+ *     0 = the reference's test alone (its exact visit set, and the traversal tail that comes with it).
  * "tiny_scene_prims" (0..255): scenes of at most this many primitives are committed as ONE leaf (default 16; 0 = never).
  *     Read by trhip_scene_commit; results do not depend on it except through the order coincident hits are visited in.
  * "streaming" (-1/0/1): PathIntegrator on scenes with a real BVH as a streaming wavefront: rays that exceed a fetch budget

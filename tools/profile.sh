@@ -14,5 +14,5 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python $B "$
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVES --output-format csv -d $OUT/pmc_sq -- python $B "$@" > $OUT/bench_pmc_sq.log 2>&1
 rocprofv3 --pmc VALUBusy MemUnitStalled SALUBusy TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_busy -- python $B "$@" > $OUT/bench_pmc_busy.log 2>&1
 cd $GRAFT_REPO_ROOT && python tools/summarize_pmc.py gpurun_out/prof_$TAG > $OUT/summary.txt 2>&1
-tail -1 $OUT/bench_stats.log > $OUT/bench_line.json
+grep "^{\"metric\"" $OUT/bench_stats.log | tail -1 > $OUT/bench_line.json
 ls $OUT
