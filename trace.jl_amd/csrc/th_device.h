@@ -154,7 +154,9 @@ struct SphereHit {
     float phi;
 };
 // :125-158 / :166-191 up to the interaction.  `t0 < 0 && (t0 = t1)` without re-checking t_max (A.8).
-template <bool WANT_POINT>
+// FULL_ONLY: the caller guarantees `never_clipped` for every sphere of the scene (trhip_scene: partial_spheres == false), and the
+// clipped-sphere code — a Float64 atan2 that sets the register count of every kernel it is inlined into — is compiled out.
+template <bool WANT_POINT, bool FULL_ONLY = false>
 TH_D bool sphere_intersect(const SphereRec& s, f3 o, f3 d, float t_max, SphereHit& h) {
     const f3 oo = xf_point(s.o2w_inv, o);
     const f3 od = xf_vec(s.o2w_inv, d);
@@ -168,7 +170,7 @@ TH_D bool sphere_intersect(const SphereRec& s, f3 o, f3 d, float t_max, SphereHi
     if (t0 > t_max || t1 < 0.0f) return false;
     if (t0 < 0) t0 = t1;
     float shape_hit = t0;
-    if (s.never_clipped) {
+    if (FULL_ONLY || s.never_clipped) {
         // Full sphere: test_clipping (sphere.jl:65-69) is false for every hit point — the z clauses are off and ϕ, which is
         // atan(y, x) (+ 2π if negative) and therefore never exceeds Float32(2π), cannot exceed ϕ_max >= Float32(2π).
         // The Float64 atan2 and, for traversal, the refined hit point are not needed to decide the hit.

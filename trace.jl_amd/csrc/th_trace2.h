@@ -492,6 +492,145 @@ __global__ __launch_bounds__(kBlock, TH_TRACE2_MIN_WAVES) void k_trace2(DeviceSc
     }
 }
 
+// ---- k_trace_leaf: scenes committed as ONE leaf (th_bvh.h, tiny_scene_prims: S-cornell, the shadows scene) ---------------------
+// Every ray tests the same primitives in the same order, so there is nothing to schedule: a wave takes 64 queue entries, tests
+// the root box (bvh.jl:226) and walks the leaf with a wave-uniform index — the primitive and sphere records arrive through
+// scalar loads, the triangle / sphere branch is uniform, no stack, no per-lane replacement, ~60 VGPRs.  Same operations per ray
+// in the same order as k_trace2 on this scene (which it replaces there): results are bit-identical (parity tests, traversal 2/3
+// vs 1).  Any-hit lanes stop at their first accepted primitive (intersect_p returns, bvh.jl:283-287); the wave ends when all have.
+#ifndef TH_TRACE_LEAF_WAVES
+#define TH_TRACE_LEAF_WAVES 5
+#endif
+// read-only scene data addressed wave-uniformly: viewed through the constant address space so that the loads are scalar (s_load)
+// and their results live in SGPRs (the scene is never written while a traversal kernel runs)
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const __attribute__((address_space(4))) float4* ConstF4;
+typedef const __attribute__((address_space(4))) SphereRec* ConstSphere;
+TH_D float4 uniform_load(const float4* p, uint32_t i) { return ((ConstF4)(uintptr_t)p)[i]; }
+TH_D SphereRec uniform_load(const SphereRec* p, uint32_t i) { return ((ConstSphere)(uintptr_t)p)[i]; }
+#else
+TH_D float4 uniform_load(const float4* p, uint32_t i) { return p[i]; }
+TH_D SphereRec uniform_load(const SphereRec* p, uint32_t i) { return p[i]; }
+#endif
+template <bool ANY, bool COUNT, bool FULL_ONLY>
+__global__ __launch_bounds__(kBlock, FULL_ONLY ? TH_TRACE_LEAF_WAVES : 4) void k_trace_leaf(DeviceScene sc, WideScene ws, SegQueue q, const float4* __restrict__ ro, const float4* __restrict__ rd,
+                                                                            const float* __restrict__ tmax_or_null, TraceOut out, Counters* ctr) {
+    __shared__ SegView sv;
+    seg_load(q, sv);
+    const uint32_t total = sv.prefix[kSeg];
+    const uint32_t first = ws.root_ref, cnt = ws.root_cnt;
+    uint32_t nn = 0, np = 0;
+    for (uint32_t flat = blockIdx.x * kBlock + threadIdx.x; flat < total; flat += gridDim.x * kBlock) {
+        uint32_t seg, lb;
+        seg_locate(sv, flat & ~63u, seg, lb);
+        const uint32_t local = lb + (flat & 63u);
+        const bool valid = local < sv.count[seg];
+        const uint32_t idx = valid ? seg_phys(q, seg, local) : 0u;
+        float4 o4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), d4 = make_float4(0.0f, 0.0f, 1.0f, 0.0f);
+        if (valid) {
+            o4 = ro[idx];
+            d4 = rd[idx];
+        }
+        const f3 o = mk3(o4.x, o4.y, o4.z), d = mk3(d4.x, d4.y, d4.z);
+        float t_max = (valid && tmax_or_null) ? tmax_or_null[idx] : kInf;
+        bool live = false;  // still has primitives to test
+        if (valid) {
+            const f3 inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+            float tmin;
+            if (COUNT) nn++;
+            live = slab_test2(ws.root_box[0], ws.root_box[1], ws.root_box[2], ws.root_box[3], ws.root_box[4], ws.root_box[5], o, inv_d, 0.0f, false, d.x < 0.0f, d.y < 0.0f, d.z < 0.0f, tmin) &&
+                   tmin < t_max;
+        }
+        const RayShear shear = ray_shear(d);
+        bool found = false;
+        int hit_prim = -1;
+        float hx = 0.0f, b1 = 0.0f, b2 = 0.0f;
+#pragma unroll 1
+        for (uint32_t k = 0; k < cnt; ++k) {
+            if (__ballot(live) == 0ull) break;
+            const uint32_t slot = first + k;  // wave-uniform: scalar loads
+            const float4 p0 = uniform_load(sc.prims, 3 * slot);
+            const uint32_t meta = __float_as_uint(p0.w);
+            if (meta & PRIM_SPHERE) {
+                const SphereRec sr = uniform_load(sc.spheres, __float_as_uint(p0.x));
+                if (live) {
+                    if (COUNT) np++;
+                    SphereHit sh;
+                    if (sphere_intersect<false, FULL_ONLY>(sr, o, d, t_max, sh)) {
+                        found = true;
+                        if (ANY) {
+                            live = false;
+                        } else {
+                            t_max = sh.t;
+                            hit_prim = (int)slot;
+                            b1 = b2 = 0.0f;
+                            hx = sh.t;
+                        }
+                    }
+                }
+            } else if (!(meta & PRIM_DEGENERATE)) {
+                const float4 p1 = uniform_load(sc.prims, 3 * slot + 1), p2 = uniform_load(sc.prims, 3 * slot + 2);
+                if (live) {
+                    if (COUNT) np++;
+                    TriTest tt;
+                    if (tri_intersect_sheared<!ANY>(mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z), o, shear, t_max, &tt)) {
+                        found = true;
+                        if (ANY) {
+                            live = false;
+                        } else {
+                            t_max = tt.t;
+                            hit_prim = (int)slot;
+                            b1 = tt.bary.x;
+                            b2 = tt.bary.y;
+                            hx = out.bary_mode ? tt.bary.z : tt.t;
+                        }
+                    }
+                }
+            } else if (COUNT && live) {
+                np++;  // k_trace2 counts the degenerate triangle it skips
+            }
+        }
+        if (!valid) continue;
+        if (ANY) {
+            if (out.L) {
+                const uint32_t slot = __float_as_uint(o4.w);
+                if (!found) {
+                    const float4 c = out.contrib[idx];
+                    float4 l = out.L[slot];
+                    l.x += c.x;
+                    l.y += c.y;
+                    l.z += c.z;
+                    out.L[slot] = l;
+                } else {
+                    const uint32_t poison = __float_as_uint(d4.w);
+                    if (poison) {
+                        float4 l = out.L[slot];
+                        const float nanv = __builtin_nanf("");
+                        if (poison & 1u) l.x += nanv;
+                        if (poison & 2u) l.y += nanv;
+                        if (poison & 4u) l.z += nanv;
+                        out.L[slot] = l;
+                    }
+                }
+            } else {
+                out.occluded[idx] = found ? 1 : 0;
+            }
+        } else {
+            out.hits[idx] = make_float4(found ? hx : kInf, __int_as_float(found ? hit_prim : -1), b1, b2);
+        }
+    }
+    if (ctr) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(ANY ? &ctr->shadow_total : &ctr->closest_total, (unsigned long long)seg_total(sv));
+        if (COUNT) {
+            const unsigned long long sn = wave_sum(nn), spr = wave_sum(np);
+            if (lane_id() == 0) {
+                atomicAdd(ANY ? &ctr->nodes_shadow : &ctr->nodes_closest, sn);
+                atomicAdd(ANY ? &ctr->prims_shadow : &ctr->prims_closest, spr);
+            }
+        }
+    }
+}
+
 // ---- k_trace3: k_trace2 with the work of a wave re-grouped ("while-while") ------------------------------------------------------
 // Measured on the 1 M-triangle scene, k_trace2 keeps 11.6 of 64 lanes busy per VALU instruction: in every step the lanes at an
 // interior node, the lanes at a leaf and the lanes popping run one after the other.  Here a wave alternates between two
@@ -504,7 +643,7 @@ __global__ __launch_bounds__(kBlock, TH_TRACE2_MIN_WAVES) void k_trace2(DeviceSc
 #ifndef TH_TRACE3_MAX_A
 #define TH_TRACE3_MAX_A 8
 #endif
-template <bool ANY, bool COUNT>
+template <bool ANY, bool COUNT, bool FULL_ONLY>
 __global__ __launch_bounds__(kBlock, ANY ? TH_TRACE3_WAVES_ANY : TH_TRACE3_WAVES_CLOSEST) void k_trace3(DeviceScene sc, WideScene ws, SegQueue q, const float4* __restrict__ ro, const float4* __restrict__ rd, const float* __restrict__ tmax_or_null,
                                                    TraceOut out, uint32_t* __restrict__ work, uint2* __restrict__ overflow, Counters* ctr) {
     constexpr int kLds = ANY ? TH_TRACE3_LDS_ANY : TH_TRACE3_LDS_CLOSEST;
@@ -711,7 +850,7 @@ __global__ __launch_bounds__(kBlock, ANY ? TH_TRACE3_WAVES_ANY : TH_TRACE3_WAVES
                     const float4 d4 = rd[idx];
                     const f3 d = mk3(d4.x, d4.y, d4.z);
                     SphereHit sh;
-                    const bool sphere_hit = sphere_intersect<false>(sc.spheres[__float_as_uint(p0.x)], o, d, t_max, sh);
+                    const bool sphere_hit = sphere_intersect<false, FULL_ONLY>(sc.spheres[__float_as_uint(p0.x)], o, d, t_max, sh);
                     inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
                     em = slab_margin(ws.root_box, ws.tight_scale, o);
                     shear = ray_shear(d);

@@ -55,6 +55,7 @@ struct trhip_ctx {
     int bvh_builder = -1;  // BVHAccel construction: 0 = binned SAH on the host (th_bvh.h), 1 = linear BVH on the device (th_lbvh.h),
                            // -1 = automatic: the device builder above 16 Mi primitives.  Measured: commit 0.72 -> 0.13 s (1 M triangles), 8.0 -> 1.5 s
                            // (10 M); the LBVH costs 25-35 % more node visits per ray (frame +4 % at 1 M / 64 spp, +37 % at 10 M / 16 spp)
+    bool leaf_kernel = true;         // one-leaf scenes run k_trace_leaf instead of k_trace2 (option "leaf_kernel", for A/B)
     int slab_margin_log2 = 14;       // k_trace2 / k_trace3 add the slab clauses the reference's box test lost, on boxes grown by 2^-this x the ray's reach
                                      // (th_trace2.h, slab_test2); 0 = the reference's loose test alone (its exact visit set)
     uint32_t tiny_scene_prims = 16;  // scenes of at most this many primitives get a single-leaf BVH (th_bvh.h); 0 = always build the hierarchy
@@ -102,6 +103,7 @@ struct trhip_scene {
     DevBuf d_nodes, d_prims, d_nrm, d_spheres, d_materials, d_lights, d_wnodes;
     DeviceScene dev{};
     WideScene wide{};
+    bool partial_spheres = false;  // some sphere is clipped (z range or ϕ_max): traversal kernels with the general sphere test
     bool wide_ok = false;
 };
 
@@ -494,23 +496,39 @@ void launch_trace(trhip_ctx* ctx, hipStream_t st, const trhip_scene* sc, bool an
     const dim3 grid(trace_grid(ctx)), block(kBlock);
     const bool v2 = ctx->traversal >= 2 && sc->wide_ok;
     const bool cnt = ctx->count_visits;
+    const bool full_only = !sc->partial_spheres;  // no clipped sphere in the scene: kernels without the Float64 atan2 path
     if (v2 && ctx->traversal == 3 && sc->wide.root_cnt == 0) {  // k_trace3: leaves postponed and tested together ("while-while"); a single-leaf scene
                                                                    // has nothing to postpone and runs k_trace2 (65 vs 73 ms on S-cornell)
         uint2* ov = (uint2*)(overflow_slab ? overflow_slab : ctx->overflow.p);
         if (any) {
             if (cnt)
-                hipLaunchKernelGGL((k_trace3<true, true>), grid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, work_cursors, ov, ctr);
+                { if (full_only) hipLaunchKernelGGL((k_trace3<true, true, true>), grid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, work_cursors, ov, ctr); else hipLaunchKernelGGL((k_trace3<true, true, false>), grid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, work_cursors, ov, ctr); }
             else
-                hipLaunchKernelGGL((k_trace3<true, false>), grid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, work_cursors, ov, ctr);
+                { if (full_only) hipLaunchKernelGGL((k_trace3<true, false, true>), grid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, work_cursors, ov, ctr); else hipLaunchKernelGGL((k_trace3<true, false, false>), grid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, work_cursors, ov, ctr); }
         } else {
             if (cnt)
-                hipLaunchKernelGGL((k_trace3<false, true>), grid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, work_cursors, ov, ctr);
+                { if (full_only) hipLaunchKernelGGL((k_trace3<false, true, true>), grid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, work_cursors, ov, ctr); else hipLaunchKernelGGL((k_trace3<false, true, false>), grid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, work_cursors, ov, ctr); }
             else
-                hipLaunchKernelGGL((k_trace3<false, false>), grid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, work_cursors, ov, ctr);
+                { if (full_only) hipLaunchKernelGGL((k_trace3<false, false, true>), grid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, work_cursors, ov, ctr); else hipLaunchKernelGGL((k_trace3<false, false, false>), grid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, work_cursors, ov, ctr); }
         }
         return;
     }
     if (v2) {
+        if (sc->wide.root_cnt > 0 && ctx->debug_trace_budget == 0 && ctx->leaf_kernel) {  // one-leaf scene: the dedicated kernel (th_trace2.h, k_trace_leaf)
+            const dim3 lgrid(ctx->num_cu * 8);
+            if (any) {
+                if (cnt)
+                    { if (full_only) hipLaunchKernelGGL((k_trace_leaf<true, true, true>), lgrid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, ctr); else hipLaunchKernelGGL((k_trace_leaf<true, true, false>), lgrid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, ctr); }
+                else
+                    { if (full_only) hipLaunchKernelGGL((k_trace_leaf<true, false, true>), lgrid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, ctr); else hipLaunchKernelGGL((k_trace_leaf<true, false, false>), lgrid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, ctr); }
+            } else {
+                if (cnt)
+                    { if (full_only) hipLaunchKernelGGL((k_trace_leaf<false, true, true>), lgrid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, ctr); else hipLaunchKernelGGL((k_trace_leaf<false, true, false>), lgrid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, ctr); }
+                else
+                    { if (full_only) hipLaunchKernelGGL((k_trace_leaf<false, false, true>), lgrid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, ctr); else hipLaunchKernelGGL((k_trace_leaf<false, false, false>), lgrid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, ctr); }
+            }
+            return;
+        }
         uint2* ov = (uint2*)(overflow_slab ? overflow_slab : ctx->overflow.p);
         if (any) {
             if (cnt)
@@ -1539,6 +1557,8 @@ int trhip_set_option(trhip_ctx* ctx, const char* name, int64_t value) {
         ctx->sppm_batch = (uint64_t)std::max<int64_t>(0, value);
     else if (!std::strcmp(name, "bvh_builder"))
         ctx->bvh_builder = value < 0 ? -1 : (value != 0 ? 1 : 0);
+    else if (!std::strcmp(name, "leaf_kernel"))
+        ctx->leaf_kernel = value != 0;
     else if (!std::strcmp(name, "slab_margin_log2"))
         ctx->slab_margin_log2 = (int)std::max<int64_t>(0, std::min<int64_t>(20, value));
     else if (!std::strcmp(name, "tiny_scene_prims"))
@@ -1627,6 +1647,7 @@ static int add_sphere_rec(trhip_scene* s, const float* o2w, const float* o2w_inv
     const bool swaps = det3(o2w) < 0.0f;  // transformations.jl:161-163
     r.flip = ((reverse != 0) != swaps) ? 1u : 0u;
     r.never_clipped = (!(r.z_min > -r.radius) && !(r.z_max < r.radius) && r.phi_max >= 2.0f * kPi) ? 1u : 0u;
+    if (!r.never_clipped) s->partial_spheres = true;
     HostPrim p;
     std::memset(&p, 0, sizeof p);
     p.kind = 1;
