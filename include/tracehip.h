@@ -227,6 +227,8 @@ int trhip_film_accumulate(trhip_ctx* ctx, const trhip_sensor* sensor, uint32_t s
  *     free HBM, at most 128); the result does not depend on it.
  * "film_block" (0/1/2): film pixels per thread of the film gather: 1, 2 x 2, 1 x 4 (default); same film bit for bit.
  * "film_tiled" (0/1): LDS-staged film gather (default 0: measured slower).
+ * "film_transpose" (0/1): film pass on pixel-group-major copies of the per-sample radiance / film positions (default 0: no gain).
+ * "leaf_kernel" (0/1): one-leaf scenes (tiny_scene_prims) run the dedicated uniform-walk kernel instead of traversal 2 (default 1).
  * "debug_trace_budget": DIAGNOSTIC ONLY, traversal abandons rays after this many node fetches (results wrong). */
 int trhip_set_option(trhip_ctx* ctx, const char* name, int64_t value);
 

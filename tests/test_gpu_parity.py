@@ -322,6 +322,24 @@ def test_partial_spheres_and_transforms(T, ob, ctx):
     ref_xyzw, ref_L, _ = osc.render(cam, "path", 2, 5, seed=77, want_samples=True)
     assert_bits_equal(integ.sample_radiance(scene), ref_L, "per-sample radiance (two lights, spot falloff)")
     assert_bits_equal(xyzw, ref_xyzw, "film")
+    # the same primitives under a hierarchy (k_trace3 / k_trace2 built WITH the clipped-sphere code) instead of one leaf (k_trace_leaf)
+    ctx.set_option("tiny_scene_prims", 0)
+    try:
+        scene2 = T.Scene(scene.lights, T.BVHAccel(prims, 1))
+        flat2 = scene2.flatten(ctx)
+        assert flat2.bvh()[1].size > 1
+        osc2 = ob.OracleScene.from_scene(scene2, bvh=flat2.bvh())
+        t2, prim2, _, _ = osc2.trace_closest(rays)
+        occ2, _ = osc2.trace_any(rays)
+        for trav in (3, 2, 1):
+            ctx.set_option("traversal", trav)
+            h2 = flat2.trace_closest(rays)
+            assert np.array_equal(h2["prim"], prim2), trav
+            assert_bits_equal(h2["t"], t2, f"t_hit (hierarchy, traversal {trav})")
+            assert np.array_equal(flat2.trace_any(rays), occ2), trav
+    finally:
+        ctx.set_option("tiny_scene_prims", 16)
+        ctx.set_option("traversal", 3)
 
 
 def test_streaming_wavefront_matches_classic_and_oracle(T, ob, ctx, traversal):

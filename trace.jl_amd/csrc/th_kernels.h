@@ -613,16 +613,35 @@ __global__ __launch_bounds__(kBlock) void k_fill_u32(uint32_t* __restrict__ p, u
 // merge_film_tile! is unsynchronised).  out = xyz sums + filter_weight_sum.
 // camera_sample.film of every slot (p_raster + get_2d, sampler/sampler.jl:135-139): written once so that the gather does not
 // re-derive it from the sampler for each of the ~16 film pixels a sample reaches.
-__global__ __launch_bounds__(kBlock) void k_film_positions(const DeviceSensor* __restrict__ sep, uint64_t n, uint64_t seed, uint32_t sample_offset, float2* __restrict__ pfilm) {
+// Where sample s of sample-pixel pix lives in the film pass's inputs.  The integrators write L sample-major ([s][pix]: what the
+// queues want); the gather walks ALL samples of a pixel before it moves to the next pixel (the reference's order), i.e. with a
+// stride of npix * 16 bytes (16 MB at 1024²) between consecutive loads — a new page for every one.  launch_film therefore
+// re-lays L (k_film_transpose) and writes p_film pixel-group-major: [group of 64 sample-pixels][s][lane]; consecutive samples
+// are then 1 KB apart and a wave's load is one contiguous chunk as before.  layout 0 = sample-major (option film_transpose 0).
+TH_D size_t film_index(uint32_t layout, uint32_t npix, uint32_t spp, uint32_t s, uint32_t pix) {
+    return layout ? ((size_t)(pix >> 6) * spp + s) * 64u + (pix & 63u) : (size_t)s * npix + pix;
+}
+__global__ __launch_bounds__(kBlock) void k_film_transpose(const float4* __restrict__ L, uint32_t npix, uint32_t spp, float4* __restrict__ Lt) {
+    const uint32_t groups = (npix + 63u) >> 6;
+    const uint64_t chunks = (uint64_t)groups * spp;
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint64_t c = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) >> 6; c < chunks; c += ((uint64_t)gridDim.x * kBlock) >> 6) {
+        const uint32_t s = (uint32_t)(c / groups), g = (uint32_t)(c - (uint64_t)s * groups);  // consecutive waves read consecutive chunks
+        const uint32_t pix = g * 64u + lane;
+        if (pix < npix) Lt[film_index(1u, npix, spp, s, pix)] = L[(size_t)s * npix + pix];
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_film_positions(const DeviceSensor* __restrict__ sep, uint64_t n, uint64_t seed, uint32_t sample_offset, float2* __restrict__ pfilm, uint32_t layout,
+                                                           uint32_t spp) {
     const DeviceSensor& se = *sep;
     for (uint64_t slot = (uint64_t)blockIdx.x * kBlock + threadIdx.x; slot < n; slot += (uint64_t)gridDim.x * kBlock) {
         const SlotInfo si = slot_info(se, (uint32_t)slot);
         const uint64_t key = ts_stream_key(seed, si.px, si.py, sample_offset + si.sample);
-        pfilm[slot] = make_float2((float)si.px + ts_uniform(key, TS_DIM_FILM_X), (float)si.py + ts_uniform(key, TS_DIM_FILM_Y));
+        pfilm[film_index(layout, (uint32_t)(se.sb_w * se.sb_h), spp, si.sample, si.pix)] = make_float2((float)si.px + ts_uniform(key, TS_DIM_FILM_X), (float)si.py + ts_uniform(key, TS_DIM_FILM_Y));
     }
 }
 __global__ __launch_bounds__(kBlock) void k_film_gather(const DeviceSensor* __restrict__ sep, const float* __restrict__ table, const float4* __restrict__ L,
-                                                        const float2* __restrict__ pfilm, uint32_t spp, float4* __restrict__ out) {
+                                                        const float2* __restrict__ pfilm, uint32_t spp, uint32_t layout, float4* __restrict__ out) {
     const DeviceSensor& se = *sep;
     const uint32_t npx = (uint32_t)(se.film_w * se.film_h);
     const uint32_t npix = (uint32_t)(se.sb_w * se.sb_h);
@@ -659,7 +678,7 @@ __global__ __launch_bounds__(kBlock) void k_film_gather(const DeviceSensor* __re
                         for (int sx = x0; sx <= x1; ++sx) {
                             const uint32_t pix = (uint32_t)(sy - se.sb_min[1]) * (uint32_t)se.sb_w + (uint32_t)(sx - se.sb_min[0]);
                             for (uint32_t s = 0; s < spp; ++s) {
-                                const float2 pf = pfilm[(size_t)s * npix + pix];  // camera_sample.film, from k_film_positions
+                                const float2 pf = pfilm[film_index(layout, npix, spp, s, pix)];  // camera_sample.film, from k_film_positions
                                 const float dpx = pf.x - 0.5f, dpy = pf.y - 0.5f;
                                 float p0x = __builtin_ceilf(dpx - rx), p0y = __builtin_ceilf(dpy - ry);
                                 float p1x = __builtin_floorf(dpx + rx) + 1.0f, p1y = __builtin_floorf(dpy + ry) + 1.0f;
@@ -672,7 +691,7 @@ __global__ __launch_bounds__(kBlock) void k_film_gather(const DeviceSensor* __re
                                 const int ox = (int)jclamp(__builtin_ceilf(ffx), 1.0f, 16.0f);   // ceil for x …
                                 const int oy = (int)jclamp(__builtin_floorf(ffy), 1.0f, 16.0f);  // … floor for y (A.9)
                                 const float w = table[(oy - 1) * 16 + (ox - 1)];
-                                const float4 l4 = L[(size_t)s * npix + pix];
+                                const float4 l4 = L[film_index(layout, npix, spp, s, pix)];
                                 f3 l = mk3(l4.x, l4.y, l4.z);
                                 if (has_nan(l)) l = splat3(0.0f);  // integrators/sampler.jl:46
                                 csum = csum + l * 1.0f * w;
@@ -704,8 +723,13 @@ TH_D void film_tile_bounds(const DeviceSensor& se, int ty, int tx, float rx, flo
 // tile or sample outside a pixel's own reach fails the same bounds tests as in k_film_gather and contributes nothing.
 template <int BX, int BY>
 __global__ __launch_bounds__(kBlock) void k_film_gather_block(const DeviceSensor* __restrict__ sep, const float* __restrict__ table, const float4* __restrict__ L,
-                                                              const float2* __restrict__ pfilm, uint32_t spp, float4* __restrict__ out) {
+                                                              const float2* __restrict__ pfilm, uint32_t spp, uint32_t layout, float4* __restrict__ out) {
     const DeviceSensor& se = *sep;
+    // the 16 x 16 filter table in LDS: a lookup in global memory queues behind the sample loads in flight (vector loads return in
+    // order), so every weight waited for the whole next batch
+    __shared__ float s_table[256];
+    for (uint32_t t = threadIdx.x; t < 256u; t += kBlock) s_table[t] = table[t];
+    __syncthreads();
     const uint32_t npix = (uint32_t)(se.sb_w * se.sb_h);
     const float rx = se.filter_radius[0], ry = se.filter_radius[1];
     const float inv_rx = 1.0f / rx, inv_ry = 1.0f / ry;
@@ -783,7 +807,7 @@ __global__ __launch_bounds__(kBlock) void k_film_gather_block(const DeviceSensor
                                 for (int j = 0; j < BY; ++j)
                                     for (int i = 0; i < BX; ++i)
                                         if (okx[i] && oky[j]) {
-                                            const float w = table[oy[j] + ox[i]];
+                                            const float w = s_table[oy[j] + ox[i]];
                                             csum[j][i] = csum[j][i] + l * 1.0f * w;
                                             fws[j][i] += w;
                                         }
@@ -798,13 +822,14 @@ __global__ __launch_bounds__(kBlock) void k_film_gather_block(const DeviceSensor
                                 float4 lv[kFilmUnroll];
 #pragma unroll
                                 for (uint32_t u = 0; u < kFilmUnroll; ++u) {
-                                    pfv[u] = pfilm[(size_t)(s + u) * npix + pix];
-                                    lv[u] = L[(size_t)(s + u) * npix + pix];
+                                    const size_t at = film_index(layout, npix, spp, s + u, pix);
+                                    pfv[u] = pfilm[at];
+                                    lv[u] = L[at];
                                 }
 #pragma unroll
                                 for (uint32_t u = 0; u < kFilmUnroll; ++u) splat(pfv[u], lv[u]);
                             }
-                            for (; s < spp; ++s) splat(pfilm[(size_t)s * npix + pix], L[(size_t)s * npix + pix]);
+                            for (; s < spp; ++s) splat(pfilm[film_index(layout, npix, spp, s, pix)], L[film_index(layout, npix, spp, s, pix)]);
                         }
                     for (int j = 0; j < BY; ++j)
                         for (int i = 0; i < BX; ++i)
@@ -827,7 +852,7 @@ __global__ __launch_bounds__(kBlock) void k_film_gather_block(const DeviceSensor
 // ascending, samples ascending; tiles merged in k order (film.jl:182-193).  LDS layout: five planes [s][col], so the lanes
 // of a wave (different columns, same s) read consecutive banks and equal columns broadcast.
 __global__ __launch_bounds__(kBlock) void k_film_gather_tiled(const DeviceSensor* __restrict__ sep, const float* __restrict__ table, const float4* __restrict__ L,
-                                                              const float2* __restrict__ pfilm, uint32_t spp, uint32_t cols, uint32_t ns_stage, float4* __restrict__ out) {
+                                                              const float2* __restrict__ pfilm, uint32_t spp, uint32_t layout, uint32_t cols, uint32_t ns_stage, float4* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float s_planes[];
     __shared__ float s_table[256];
     const DeviceSensor& se = *sep;
@@ -866,7 +891,7 @@ __global__ __launch_bounds__(kBlock) void k_film_gather_tiled(const DeviceSensor
                 for (uint32_t e = (uint32_t)tid; e < (uint32_t)ncol * nsn; e += kBlock) {
                     const uint32_t c = e % (uint32_t)ncol, sl = e / (uint32_t)ncol;
                     const uint32_t pix = (uint32_t)(sy - se.sb_min[1]) * (uint32_t)se.sb_w + (uint32_t)(SX0 + c0 + (int)c - se.sb_min[0]);
-                    const size_t idx = (size_t)(s0 + sl) * npix + pix;
+                    const size_t idx = film_index(layout, npix, spp, s0 + sl, pix);
                     const float2 pf = pfilm[idx];
                     const float4 l4 = L[idx];
                     f3 l = mk3(l4.x, l4.y, l4.z);

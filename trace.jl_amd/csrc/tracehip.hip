@@ -55,6 +55,7 @@ struct trhip_ctx {
     int bvh_builder = -1;  // BVHAccel construction: 0 = binned SAH on the host (th_bvh.h), 1 = linear BVH on the device (th_lbvh.h),
                            // -1 = automatic: the device builder above 16 Mi primitives.  Measured: commit 0.72 -> 0.13 s (1 M triangles), 8.0 -> 1.5 s
                            // (10 M); the LBVH costs 25-35 % more node visits per ray (frame +4 % at 1 M / 64 spp, +37 % at 10 M / 16 spp)
+    bool film_transpose = false;     // film pass on pixel-group-major copies of p_film / L (option "film_transpose"; launch_film)
     bool leaf_kernel = true;         // one-leaf scenes run k_trace_leaf instead of k_trace2 (option "leaf_kernel", for A/B)
     int slab_margin_log2 = 14;       // k_trace2 / k_trace3 add the slab clauses the reference's box test lost, on boxes grown by 2^-this x the ray's reach
                                      // (th_trace2.h, slab_test2); 0 = the reference's loose test alone (its exact visit set)
@@ -64,7 +65,7 @@ struct trhip_ctx {
     bool overlap = true;  // two-stream overlap of shadow rays (depth d) with closest-hit rays (depth d+1)
     int traversal = 3;  // 1 = literal accel/bvh.jl loop, 2 = children-in-parent nodes + per-lane ray replacement, 3 = 2 with leaves postponed (while-while)
     // workspace (grown on demand, reused across calls)
-    DevBuf q[2][3], sq[3], hits, Lbuf, pfilm, counters, sensor, table, film, scratch[4], overflow, wh_L, wh_parent, wh_coef, wh_pdf, wh_flags, occl;
+    DevBuf q[2][3], sq[3], hits, Lbuf, pfilm, counters, sensor, table, film, scratch[4], overflow, wh_L, wh_parent, wh_coef, wh_pdf, wh_flags, occl, film_Lt;
     uint64_t last_L_count = 0;  // float4 entries valid in Lbuf
     // SPPM state (th_sppm.h): per film pixel, kept after trhip_render_sppm for trhip_sppm_state
     DevBuf sp_vp[7], sp_Ld, sp_tau, sp_radius, sp_N, sp_phi, sp_M, sp_counts, sp_starts, sp_entries, sp_grid, sp_ldist, sp_snap_M, sp_snap_phi, sp_snap_p, sp_snap_beta;
@@ -445,7 +446,17 @@ void derive_sensor(const trhip_sensor* sn, DeviceSensor& d) {
 #endif
 void launch_film(trhip_ctx* ctx, hipStream_t st, const DeviceSensor& ds, const DeviceSensor* dsp, const float4* L, uint64_t total_slots, uint32_t spp, uint64_t seed, uint32_t sample_offset,
                  float4* d_film) {
-    hipLaunchKernelGGL(k_film_positions, dim3(grid_for(ctx, total_slots, 8)), dim3(kBlock), 0, st, dsp, total_slots, seed, sample_offset, (float2*)ctx->pfilm.p);
+    // pixel-group-major inputs for the gather (th_kernels.h, film_index): p_film is written that way, L is re-laid into a second buffer
+    // (the frame's radiance, 16 B per sample, once more); without room for it the gather reads the sample-major arrays as before
+    const uint32_t npix = (uint32_t)(ds.sb_w * ds.sb_h);
+    const uint64_t padded = (uint64_t)((npix + 63u) / 64u) * 64u * spp;
+    uint32_t layout = 0;
+    if (ctx->film_transpose && spp > 1 && total_slots == (uint64_t)npix * spp && ensure(ctx, ctx->pfilm, padded * sizeof(float2)) == 0 && ensure(ctx, ctx->film_Lt, padded * sizeof(float4)) == 0) {
+        layout = 1;
+        hipLaunchKernelGGL(k_film_transpose, dim3(grid_for(ctx, padded, 8)), dim3(kBlock), 0, st, L, npix, spp, (float4*)ctx->film_Lt.p);
+        L = (const float4*)ctx->film_Lt.p;
+    }
+    hipLaunchKernelGGL(k_film_positions, dim3(grid_for(ctx, total_slots, 8)), dim3(kBlock), 0, st, dsp, total_slots, seed, sample_offset, (float2*)ctx->pfilm.p, layout, spp);
     const float rmax = std::fmax(ds.filter_radius[0], ds.filter_radius[1]);
     if (ctx->film_tiled && rmax <= 6.0f) {  // reach of a pixel = 2r + 3 sample pixels <= 16: at most 2 x 2 sample tiles
         const uint32_t budget = 24 * 1024 / 20;  // staged {p_film, L} elements in 24 KiB of LDS: ~6 blocks per CU
@@ -459,15 +470,15 @@ void launch_film(trhip_ctx* ctx, hipStream_t st, const DeviceSensor& ds, const D
             ns = budget;
         }
         const dim3 grid((ds.film_w + 15) / 16, (ds.film_h + 15) / 16);
-        hipLaunchKernelGGL(k_film_gather_tiled, grid, dim3(kBlock), (size_t)cols * ns * 20 + 16, st, dsp, (const float*)ctx->table.p, L, (const float2*)ctx->pfilm.p, spp, cols, ns, d_film);
+        hipLaunchKernelGGL(k_film_gather_tiled, grid, dim3(kBlock), (size_t)cols * ns * 20 + 16, st, dsp, (const float*)ctx->table.p, L, (const float2*)ctx->pfilm.p, spp, layout, cols, ns, d_film);
     } else {
         const uint64_t npx = (uint64_t)ds.film_w * ds.film_h;
         if (ctx->film_block == 1)
-            hipLaunchKernelGGL((k_film_gather_block<2, 2>), dim3(grid_for(ctx, (npx + 3) / 4, 8)), dim3(kBlock), 0, st, dsp, (const float*)ctx->table.p, L, (const float2*)ctx->pfilm.p, spp, d_film);
+            hipLaunchKernelGGL((k_film_gather_block<2, 2>), dim3(grid_for(ctx, (npx + 3) / 4, 8)), dim3(kBlock), 0, st, dsp, (const float*)ctx->table.p, L, (const float2*)ctx->pfilm.p, spp, layout, d_film);
         else if (ctx->film_block == 2)
-            hipLaunchKernelGGL((k_film_gather_block<TH_FILM_BX, TH_FILM_BY>), dim3(grid_for(ctx, (npx + TH_FILM_BX * TH_FILM_BY - 1) / (TH_FILM_BX * TH_FILM_BY), 8)), dim3(kBlock), 0, st, dsp, (const float*)ctx->table.p, L, (const float2*)ctx->pfilm.p, spp, d_film);
+            hipLaunchKernelGGL((k_film_gather_block<TH_FILM_BX, TH_FILM_BY>), dim3(grid_for(ctx, (npx + TH_FILM_BX * TH_FILM_BY - 1) / (TH_FILM_BX * TH_FILM_BY), 8)), dim3(kBlock), 0, st, dsp, (const float*)ctx->table.p, L, (const float2*)ctx->pfilm.p, spp, layout, d_film);
         else
-            hipLaunchKernelGGL(k_film_gather, dim3(grid_for(ctx, npx, 8)), dim3(kBlock), 0, st, dsp, (const float*)ctx->table.p, L, (const float2*)ctx->pfilm.p, spp, d_film);
+            hipLaunchKernelGGL(k_film_gather, dim3(grid_for(ctx, npx, 8)), dim3(kBlock), 0, st, dsp, (const float*)ctx->table.p, L, (const float2*)ctx->pfilm.p, spp, layout, d_film);
     }
 }
 
@@ -1518,6 +1529,7 @@ void trhip_shutdown(trhip_ctx* ctx) {
     release(ctx->wh_pdf);
     release(ctx->wh_flags);
     release(ctx->occl);
+    release(ctx->film_Lt);
     for (auto& b : ctx->sp_vp) release(b);
     release(ctx->st_terms);
     release(ctx->st_tags[0]);
@@ -1557,6 +1569,8 @@ int trhip_set_option(trhip_ctx* ctx, const char* name, int64_t value) {
         ctx->sppm_batch = (uint64_t)std::max<int64_t>(0, value);
     else if (!std::strcmp(name, "bvh_builder"))
         ctx->bvh_builder = value < 0 ? -1 : (value != 0 ? 1 : 0);
+    else if (!std::strcmp(name, "film_transpose"))
+        ctx->film_transpose = value != 0;
     else if (!std::strcmp(name, "leaf_kernel"))
         ctx->leaf_kernel = value != 0;
     else if (!std::strcmp(name, "slab_margin_log2"))
