@@ -9,6 +9,19 @@
 
 namespace th {
 
+// Read-only scene data addressed wave-uniformly (same index in every lane): viewed through the constant address space so that the
+// loads are scalar (s_load) and their results live in SGPRs.  The scene is never written while a kernel that reads it runs.
+template <class T>
+TH_D T uniform_load(const T* p, uint32_t i) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const __attribute__((address_space(4))) T* ConstPtr;
+    return ((ConstPtr)(uintptr_t)p)[i];
+#else
+    return p[i];
+#endif
+}
+
+
 // ---- triangle (shapes/triangle_mesh.jl) ---------------------------------------------------------------------------------
 struct TriTest {
     float t;

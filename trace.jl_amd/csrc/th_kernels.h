@@ -374,12 +374,13 @@ __global__ __launch_bounds__(kBlock) void k_trace_any(DeviceScene sc, SegQueue q
 // With `bary` (hits written with TraceOut::bary_mode: {b2, prim, b0, b1}) the triangle test is not repeated: the stored
 // barycentrics ARE the accepted candidate's.
 template <bool TRI_ONLY = false>
-TH_D bool rebuild_shading(const DeviceScene& sc, int prim, f3 o, f3 d, Shading& sh, uint32_t& material, const float4* bary = nullptr) {
+TH_D bool rebuild_shading(const DeviceScene& sc, int prim, f3 o, f3 d, Shading& sh, uint32_t& material, const float4* bary = nullptr, f3* fast_r = nullptr) {
     // all six 16-byte loads are issued up front (independent of the sphere / normals flags) so that their latencies overlap
     const float4 p0 = sc.prims[3 * prim], p1 = sc.prims[3 * prim + 1], p2 = sc.prims[3 * prim + 2];
     const float4 na = sc.tri_nrm[3 * prim], nb = sc.tri_nrm[3 * prim + 1], nc = sc.tri_nrm[3 * prim + 2];
     const uint32_t meta = __float_as_uint(p0.w);
     material = meta & PRIM_MATERIAL_MASK;
+    if (fast_r) *fast_r = mk3(na.w, nb.w, nc.w);  // PRIM_FAST: the single Lambert lobe's reflectance
     if (!TRI_ONLY && (meta & PRIM_SPHERE)) {
         const SphereRec& s = sc.spheres[__float_as_uint(p0.x)];
         SphereHit h;
@@ -432,9 +433,20 @@ TH_D void shade_vertex(const DeviceScene& sc, const PathQueue& qin, const float4
     f3 beta = mk3(b4.x, b4.y, b4.z);
     Shading sh;
     uint32_t material;
-    if (!(rebuild_shading<FAST>(sc, prim, o, d, sh, material, hits_have_bary ? &h4 : nullptr) && material != PRIM_NO_MATERIAL)) return;
-    const LobeSet& bsdf = sc.materials[material].set[1];  // compute_scattering!(si, ray, true)
+    f3 fast_r;
+    if (!(rebuild_shading<FAST>(sc, prim, o, d, sh, material, hits_have_bary ? &h4 : nullptr, &fast_r) && material != PRIM_NO_MATERIAL)) return;
+    const LobeSet& bsdf = sc.materials[FAST ? 0u : material].set[1];  // compute_scattering!(si, ray, true); FAST never reads it
     const bool lambert = FAST || bsdf_is_single_lambert(bsdf);  // specialised evaluation of the same arithmetic (th_device.h)
+    Lobe lam;  // the one lobe of a `lambert` vertex: FAST rebuilds it from the reflectance stored beside the normals
+    if (FAST) {
+        lam.kind = LOBE_LAMBERT_R;
+        lam.type = BSDF_DIFFUSE | BSDF_REFLECTION;
+        lam.r[0] = fast_r.x;
+        lam.r[1] = fast_r.y;
+        lam.r[2] = fast_r.z;
+    } else if (lambert) {
+        lam = bsdf.lobe[0];
+    }
     // the sampler stream key of this camera sample rides in the queue (k_raygen): no slot -> pixel division, no re-hash
     const uint64_t key = ((uint64_t)__float_as_uint(b4.w) << 32) | (uint64_t)__float_as_uint(d4.w);
     const uint32_t v = (uint32_t)(depth - 1);
@@ -448,10 +460,11 @@ TH_D void shade_vertex(const DeviceScene& sc, const PathQueue& qin, const float4
         if (ln > nl) ln = nl;
         if (ln < 1) ln = 1;
         const float light_pdf = 1.0f / (float)nl;
-        const LightRec& light = sc.lights[ln - 1];
+        // one light (every scene of the reference): its record comes through scalar loads, off the vector-memory queue
+        const LightRec light = nl == 1 ? uniform_load(sc.lights, 0u) : sc.lights[ln - 1];
         const LightSample ls = sample_li(light, sh.p);
         if (ls.pdf > 0.0f && !is_black(ls.radiance)) {
-            const f3 f = (lambert ? lambert_bsdf_f(bsdf.lobe[0], sh, sh.wo, ls.wi) : bsdf_f(bsdf, sh, sh.wo, ls.wi, BSDF_ALL & ~BSDF_SPECULAR)) * fabs_(dot(ls.wi, sh.ns));
+            const f3 f = (lambert ? lambert_bsdf_f(lam, sh, sh.wo, ls.wi) : bsdf_f(bsdf, sh, sh.wo, ls.wi, BSDF_ALL & ~BSDF_SPECULAR)) * fabs_(dot(ls.wi, sh.ns));
             if (!is_black(f)) {
                 // x / 1 == x exactly: δ-lights have pdf 1, a single light has light_pdf 1 (6 correctly rounded divisions saved)
                 const f3 fl = f * ls.radiance;
@@ -481,7 +494,7 @@ TH_D void shade_vertex(const DeviceScene& sc, const PathQueue& qin, const float4
     // ---- continue the path ----
     if (depth < max_depth) {
         const f2 u{ts_uniform(key, ts_vertex_dim(v, TS_V_BSDF_U0)), ts_uniform(key, ts_vertex_dim(v, TS_V_BSDF_U1))};
-        const BsdfSample bs = lambert ? lambert_bsdf_sample_f(bsdf.lobe[0], sh, wo, u) : bsdf_sample_f(bsdf, sh, wo, u, BSDF_ALL);
+        const BsdfSample bs = lambert ? lambert_bsdf_sample_f(lam, sh, wo, u) : bsdf_sample_f(bsdf, sh, wo, u, BSDF_ALL);
         if (!(bs.pdf == 0.0f || is_black(bs.f))) {
             beta = beta * (bs.f * fabs_(dot(bs.wi, sh.ns)) / bs.pdf);
             const float by = to_Y(beta);
@@ -550,8 +563,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TH_SHADE
         if (local < sv.count[seg_in]) {
             const int prim = __float_as_int(hits[i].y);
             if (prim >= 0) {
-                const uint32_t meta = __float_as_uint(sc.prims[3 * prim].w), material = meta & PRIM_MATERIAL_MASK;
-                cls = (!(meta & PRIM_SPHERE) && material != PRIM_NO_MATERIAL && bsdf_is_single_lambert(sc.materials[material].set[1])) ? 1 : 2;
+                cls = (__float_as_uint(sc.prims[3 * prim].w) & PRIM_FAST) ? 1 : 2;  // flag set at upload: no material fetch to classify
             }
         }
         ShadeOut e;

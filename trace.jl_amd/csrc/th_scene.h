@@ -20,7 +20,10 @@ enum : uint32_t {
     PRIM_SPHERE = 1u << 24,       // slot holds a sphere reference
     PRIM_HAS_NORMALS = 1u << 25,  // triangle mesh has vertex normals
     PRIM_FLIP = 1u << 26,         // reverse_orientation XOR transform_swaps_handedness
-    PRIM_DEGENERATE = 1u << 27,   // is_degenerate(triangle) (triangle_mesh.jl:65-68), evaluated once at scene commit
+    PRIM_DEGENERATE = 1u << 27,
+    PRIM_FAST = 1u << 28,         // triangle whose material (compute_scattering! with multiple lobes) is ONE LambertianReflection lobe: its
+                                  // reflectance rides in the .w lanes of the three normal records (upload_scene), the shading kernel
+                                  // classifies and shades it without touching the material table   // is_degenerate(triangle) (triangle_mesh.jl:65-68), evaluated once at scene commit
     PRIM_MATERIAL_MASK = 0x00ffffffu,
     PRIM_NO_MATERIAL = 0x00ffffffu
 };

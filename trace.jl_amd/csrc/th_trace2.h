@@ -501,17 +501,6 @@ __global__ __launch_bounds__(kBlock, TH_TRACE2_MIN_WAVES) void k_trace2(DeviceSc
 #ifndef TH_TRACE_LEAF_WAVES
 #define TH_TRACE_LEAF_WAVES 5
 #endif
-// read-only scene data addressed wave-uniformly: viewed through the constant address space so that the loads are scalar (s_load)
-// and their results live in SGPRs (the scene is never written while a traversal kernel runs)
-#if defined(__HIP_DEVICE_COMPILE__)
-typedef const __attribute__((address_space(4))) float4* ConstF4;
-typedef const __attribute__((address_space(4))) SphereRec* ConstSphere;
-TH_D float4 uniform_load(const float4* p, uint32_t i) { return ((ConstF4)(uintptr_t)p)[i]; }
-TH_D SphereRec uniform_load(const SphereRec* p, uint32_t i) { return ((ConstSphere)(uintptr_t)p)[i]; }
-#else
-TH_D float4 uniform_load(const float4* p, uint32_t i) { return p[i]; }
-TH_D SphereRec uniform_load(const SphereRec* p, uint32_t i) { return p[i]; }
-#endif
 template <bool ANY, bool COUNT, bool FULL_ONLY>
 __global__ __launch_bounds__(kBlock, FULL_ONLY ? TH_TRACE_LEAF_WAVES : 4) void k_trace_leaf(DeviceScene sc, WideScene ws, SegQueue q, const float4* __restrict__ ro, const float4* __restrict__ rd,
                                                                             const float* __restrict__ tmax_or_null, TraceOut out, Counters* ctr) {

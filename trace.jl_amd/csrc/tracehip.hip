@@ -328,7 +328,10 @@ int upload_scene(trhip_scene* s) {
             prims[3 * (size_t)k] = make_float4(p.v[0], p.v[1], p.v[2], __builtin_bit_cast(float, p.meta));
             prims[3 * (size_t)k + 1] = make_float4(p.v[3], p.v[4], p.v[5], 0);
             prims[3 * (size_t)k + 2] = make_float4(p.v[6], p.v[7], p.v[8], 0);
-            for (int j = 0; j < 3; ++j) nrm[3 * (size_t)k + j] = make_float4(p.n[3 * j], p.n[3 * j + 1], p.n[3 * j + 2], 0);
+            const uint32_t mat = p.meta & PRIM_MATERIAL_MASK;
+            const bool fast = mat != PRIM_NO_MATERIAL && mat < s->materials.size() && s->materials[mat].set[1].n == 1 && s->materials[mat].set[1].lobe[0].kind == LOBE_LAMBERT_R;
+            if (fast) prims[3 * (size_t)k].w = __builtin_bit_cast(float, p.meta | PRIM_FAST);
+            for (int j = 0; j < 3; ++j) nrm[3 * (size_t)k + j] = make_float4(p.n[3 * j], p.n[3 * j + 1], p.n[3 * j + 2], fast ? s->materials[mat].set[1].lobe[0].r[j] : 0.0f);
         }
     }
     if (int rc = upload(ctx, s->d_nodes, nodes.data(), nodes.size() * sizeof(float4))) return rc;
