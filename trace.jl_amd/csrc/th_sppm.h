@@ -370,7 +370,7 @@ struct PhotonRecords;
 // Record slots of one iteration: (d, first_photon + i), d < n_depths, i < n_photons.
 __global__ __launch_bounds__(kBlock) void k_sppm_hit_bin(const float4* __restrict__ rec_p, const uint8_t* __restrict__ rec_valid, uint32_t n_batch_photons, uint32_t first_photon,
                                                          uint32_t n_photons, uint32_t n_depths, uint32_t hash_size, GridInfo* gp, uint32_t* __restrict__ counts,
-                                                         const uint32_t* __restrict__ starts, uint32_t* __restrict__ hit_slot, int pass) {
+                                                         const uint32_t* __restrict__ starts, float4* __restrict__ hit_sorted, int pass) {
     const GridInfo& g = *gp;
     if (!g.valid) return;
     const uint32_t total = n_photons * n_depths;
@@ -387,7 +387,9 @@ __global__ __launch_bounds__(kBlock) void k_sppm_hit_bin(const float4* __restric
             n_hits++;
             atomicAdd(&counts[h], 1u);
         } else {
-            hit_slot[starts[h] + atomicSub(&counts[h], 1u) - 1u] = r;
+            // the position travels with the record index: the gather rejects most candidates on the distance alone, without a second,
+            // dependent fetch through the index
+            hit_sorted[starts[h] + atomicSub(&counts[h], 1u) - 1u] = make_float4(hp.x, hp.y, hp.z, __uint_as_float(r));
         }
     }
     if (pass == 0) {
@@ -614,7 +616,7 @@ struct GatherSum {
 };
 // Candidates e0 + first, e0 + first + stride, … of every bucket the visible point registers in.
 TH_D GatherSum gather_pixel(const DeviceScene& sc, const PhotonRecords& rec, const VisiblePoints& vp, uint32_t i, float4 p4, float rad, const uint32_t lo[3], const uint32_t hi[3],
-                            const uint32_t* __restrict__ starts, const uint32_t* __restrict__ hit_slot, uint32_t hash_size, uint32_t first, uint32_t stride) {
+                            const uint32_t* __restrict__ starts, const float4* __restrict__ hit_sorted, uint32_t hash_size, uint32_t first, uint32_t stride) {
     const f3 vpp = mk3(p4.x, p4.y, p4.z);
     Shading vs;
     bool have_frame = false;
@@ -625,8 +627,8 @@ TH_D GatherSum gather_pixel(const DeviceScene& sc, const PhotonRecords& rec, con
                 const uint32_t h = grid_hash(x, y, z, hash_size);
                 const uint32_t e0 = starts[h], e1 = starts[h + 1];
                 for (uint32_t e = e0 + first; e < e1; e += stride) {
-                    const uint32_t r = hit_slot[e];
-                    const float4 hp = rec.p[r];
+                    const float4 hp = hit_sorted[e];
+                    const uint32_t r = __float_as_uint(hp.w);
                     const f3 dv = vpp - mk3(hp.x, hp.y, hp.z);  // distance_squared(vp.p, p)
                     if (dot(dv, dv) > rad * rad) continue;
                     if (!have_frame) {
@@ -649,7 +651,7 @@ TH_D GatherSum gather_pixel(const DeviceScene& sc, const PhotonRecords& rec, con
 }
 // One thread per pixel; also counts the registrations (the reference's list nodes) for trhip_sppm_state.
 __global__ __launch_bounds__(kBlock) void k_sppm_gather(DeviceScene sc, PhotonRecords rec, VisiblePoints vp, PixelStats px, uint32_t n, GridInfo* gp, const uint32_t* __restrict__ starts,
-                                                        const uint32_t* __restrict__ hit_slot, uint32_t hash_size, uint32_t* __restrict__ hot_list) {
+                                                        const float4* __restrict__ hit_sorted, uint32_t hash_size, uint32_t* __restrict__ hot_list) {
     const GridInfo& g = *gp;
     if (!g.valid) return;
     unsigned long long n_reg = 0;
@@ -674,7 +676,7 @@ __global__ __launch_bounds__(kBlock) void k_sppm_gather(DeviceScene sc, PhotonRe
                         }
                 hot = candidates > kHotCandidates;
                 if (!hot && candidates) {
-                    const GatherSum s = gather_pixel(sc, rec, vp, i, p4, rad, lo, hi, starts, hit_slot, hash_size, 0u, 1u);
+                    const GatherSum s = gather_pixel(sc, rec, vp, i, p4, rad, lo, hi, starts, hit_sorted, hash_size, 0u, 1u);
                     if (s.M) {  // ϕ and M are zero between iterations (_update_pixels! clears them)
                         px.phi[3 * i + 0] = s.phi.x;
                         px.phi[3 * i + 1] = s.phi.y;
@@ -692,7 +694,7 @@ __global__ __launch_bounds__(kBlock) void k_sppm_gather(DeviceScene sc, PhotonRe
 }
 // One wave per hot pixel: the lanes stride through each bucket, ϕ and M are reduced across the wave.
 __global__ __launch_bounds__(kBlock) void k_sppm_gather_hot(DeviceScene sc, PhotonRecords rec, VisiblePoints vp, PixelStats px, GridInfo* gp, const uint32_t* __restrict__ starts,
-                                                            const uint32_t* __restrict__ hit_slot, uint32_t hash_size, const uint32_t* __restrict__ hot_list) {
+                                                            const float4* __restrict__ hit_sorted, uint32_t hash_size, const uint32_t* __restrict__ hot_list) {
     const GridInfo& g = *gp;
     const uint32_t n_hot = g.n_hot;
     const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6, n_waves = (gridDim.x * kBlock) >> 6;
@@ -703,7 +705,7 @@ __global__ __launch_bounds__(kBlock) void k_sppm_gather_hot(DeviceScene sc, Phot
         uint32_t lo[3], hi[3];
         to_grid(g, mk3(p4.x - rad, p4.y - rad, p4.z - rad), lo);
         to_grid(g, mk3(p4.x + rad, p4.y + rad, p4.z + rad), hi);
-        GatherSum s = gather_pixel(sc, rec, vp, i, p4, rad, lo, hi, starts, hit_slot, hash_size, lane_id(), 64u);
+        GatherSum s = gather_pixel(sc, rec, vp, i, p4, rad, lo, hi, starts, hit_sorted, hash_size, lane_id(), 64u);
         for (int off = 32; off > 0; off >>= 1) {
             s.phi.x += __shfl_down(s.phi.x, off);
             s.phi.y += __shfl_down(s.phi.y, off);

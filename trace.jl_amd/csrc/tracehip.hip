@@ -1294,7 +1294,7 @@ int render_sppm_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
     if (int rc = ensure(ctx, ctx->sp_M, (size_t)n * sizeof(uint32_t))) return rc;
     if (int rc = ensure(ctx, ctx->sp_counts, (size_t)n * sizeof(uint32_t))) return rc;
     if (int rc = ensure(ctx, ctx->sp_starts, ((size_t)n + 1) * sizeof(uint32_t))) return rc;
-    if (int rc = ensure(ctx, ctx->sp_entries, (size_t)entry_cap * sizeof(uint32_t))) return rc;
+    if (int rc = ensure(ctx, ctx->sp_entries, (size_t)entry_cap * sizeof(float4))) return rc;
     if (int rc = ensure(ctx, ctx->sp_grid, sizeof(GridInfo))) return rc;
     if (int rc = ensure(ctx, ctx->sp_snap_M, (size_t)n * sizeof(uint32_t))) return rc;
     if (int rc = ensure(ctx, ctx->sp_snap_phi, (size_t)n * 3 * sizeof(float))) return rc;
@@ -1323,7 +1323,7 @@ int render_sppm_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
     const PhotonRecords rec{(float4*)ctx->sp_rec[0].p, (float4*)ctx->sp_rec[1].p, (float4*)ctx->sp_rec[2].p, (uint8_t*)ctx->sp_rec_valid.p};
     uint32_t* counts = (uint32_t*)ctx->sp_counts.p;
     uint32_t* starts = (uint32_t*)ctx->sp_starts.p;
-    uint32_t* entries = (uint32_t*)ctx->sp_entries.p;
+    float4* entries = (float4*)ctx->sp_entries.p;
     const uint32_t n_tiles = (n + kScanTile - 1) / kScanTile;
     if (int rc = ensure(ctx, ctx->scratch[0], (size_t)n_tiles * sizeof(uint32_t))) return rc;
     if (int rc = ensure(ctx, ctx->scratch[1], ((size_t)n_tiles + 1) * sizeof(uint32_t))) return rc;
@@ -1420,8 +1420,8 @@ int render_sppm_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
             if (n_lights)
                 hipLaunchKernelGGL(k_sppm_hit_bin, g_rec, blk, 0, st, (const float4*)rec.p, (const uint8_t*)rec.valid, NP, j * (uint32_t)P, (uint32_t)P, (uint32_t)(max_depth - 1), n, grid, counts,
                                    (const uint32_t*)starts, entries, 1);
-            hipLaunchKernelGGL(k_sppm_gather, g_pix, blk, 0, st, scene->dev, rec, vp, px, n, grid, (const uint32_t*)starts, (const uint32_t*)entries, n, hot_list);
-            hipLaunchKernelGGL(k_sppm_gather_hot, g_shade, blk, 0, st, scene->dev, rec, vp, px, grid, (const uint32_t*)starts, (const uint32_t*)entries, n, (const uint32_t*)hot_list);
+            hipLaunchKernelGGL(k_sppm_gather, g_pix, blk, 0, st, scene->dev, rec, vp, px, n, grid, (const uint32_t*)starts, (const float4*)entries, n, hot_list);
+            hipLaunchKernelGGL(k_sppm_gather_hot, g_shade, blk, 0, st, scene->dev, rec, vp, px, grid, (const uint32_t*)starts, (const float4*)entries, n, (const uint32_t*)hot_list);
             tm.end(2, st);
             if (it0 + j == n_iterations) {  // snapshot for trhip_sppm_state: the last iteration's M, ϕ and visible points
                 HIP_TRY(ctx, hipMemcpyAsync(ctx->sp_snap_M.p, px.M, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
