@@ -220,9 +220,12 @@ int trhip_film_accumulate(trhip_ctx* ctx, const trhip_sensor* sensor, uint32_t s
  * "tiny_scene_prims" (0..255): scenes of at most this many primitives are committed as ONE leaf (default 16; 0 = never).
  *     Read by trhip_scene_commit; results do not depend on it except through the order coincident hits are visited in.
  * "streaming" (-1/0/1): PathIntegrator on scenes with a real BVH as a streaming wavefront: rays that exceed a fetch budget
- *     are suspended and resumed in the next round instead of holding up their launch; same result bit for bit.  -1 (default):
- *     automatic, for frames of at most 96 camera samples per primitive, where launch tails dominate; 0 never; 1 always.
- *     "stream_budget_min" (default 2048), "stream_budget_shift" (12) and "stream_list_cap" (0 = automatic) tune it.
+ *     are suspended and resumed in the next round instead of holding up their launch; same result bit for bit.  0 (default):
+ *     never — since "slab_margin_log2" removed the 10^5-fetch rays it only costs; 1 always; -1 automatic (frames of
+ *     at most 96 camera samples per primitive).  "stream_budget_min" (default 2048), "stream_budget_shift" (12) and
+ *     "stream_list_cap" (0 = automatic) tune it.
+ * "occluder_pretest" (0/1, default 1): any-hit rays test the scene's (at most 16) largest triangles first and go through the
+ *     hierarchy only when none of them stops the ray; exact (th_trace2.h, k_any_occluders).
  * "sppm_batch": SPPM iterations whose camera / photon paths share the traversal launches (default 0 = as many as fit in
  *     free HBM, at most 128); the result does not depend on it.
  * "film_block" (0/1/2): film pixels per thread of the film gather: 1, 2 x 2, 1 x 4 (default); same film bit for bit.

@@ -363,7 +363,7 @@ def test_streaming_wavefront_matches_classic_and_oracle(T, ob, ctx, traversal):
             film = integ.render(scene, ctx).copy()
             return film, integ.sample_radiance(scene).copy(), integ.stats
         finally:
-            ctx.set_option("streaming", -1)
+            ctx.set_option("streaming", 0)
             ctx.set_option("stream_budget_min", 2048)
             ctx.set_option("stream_list_cap", 0)
             ctx.set_option("overlap", 1)

@@ -114,6 +114,10 @@ def compare_all(T, ob, ctx, scene, flat, sets, oracle_rays=6000):
                 ctx.check(L.trhip_last_visit_counts(ctx._h, counts.ctypes.data_as(C.POINTER(C.c_uint64))))  # of the last trace call
                 ctx.set_option("count_visits", 0)
                 occ = flat.trace_any(rays)
+                if trav == 3:  # the any-hit pre-pass on the scene's largest triangles (k_any_occluders) on and off
+                    ctx.set_option("occluder_pretest", 0)
+                    assert np.array_equal(flat.trace_any(rays), occ), f"{name}: occluder pre-pass changes occlusion (margin 2^-{margin})"
+                    ctx.set_option("occluder_pretest", 1)
                 visits[(trav, margin)] = int(counts[0])
                 what = f"{name}: traversal {trav}, margin 2^-{margin}"
                 assert np.array_equal(got["prim"], ref_hits["prim"]), what
@@ -147,15 +151,19 @@ def test_tight_slab_changes_no_result_height_field(T, ob, ctx):
 
 
 def test_tight_slab_frames_identical(T, ctx):
-    """Whole frames (all bounces, shadow rays, both integrators' traversal calls) with and without the added clauses."""
+    """Whole frames (all bounces, shadow rays, both integrators' traversal calls) with and without the added clauses, and with and
+    without the any-hit pre-pass on the largest triangles."""
     scene = T.scenes.mesh_scene(181)
     cam = T.scenes.cornell_camera(160)
     films, rays = {}, {}
-    for margin in (0, 14):
+    for margin, pre in ((0, 0), (14, 1), (14, 0)):
         ctx.set_option("slab_margin_log2", margin)
+        ctx.set_option("occluder_pretest", pre)
         integ = T.PathIntegrator(cam, T.SeededSampler(8, seed=21), 8)
-        films[margin] = integ.render(scene, ctx).copy()
-        rays[margin] = (integ.stats.closest_rays, integ.stats.shadow_rays)
+        films[(margin, pre)] = integ.render(scene, ctx).copy()
+        rays[(margin, pre)] = (integ.stats.closest_rays, integ.stats.shadow_rays)
     ctx.set_option("slab_margin_log2", 14)
-    assert rays[0] == rays[14]
-    assert_bits_equal(films[14], films[0], "film, tight vs loose box test")
+    ctx.set_option("occluder_pretest", 1)
+    assert rays[(0, 0)] == rays[(14, 1)] == rays[(14, 0)]
+    assert_bits_equal(films[(14, 1)], films[(0, 0)], "film, tight box test + occluder pre-pass vs the reference's walk")
+    assert_bits_equal(films[(14, 0)], films[(0, 0)], "film, tight vs loose box test")

@@ -54,6 +54,7 @@ struct SegQueue {
     const uint32_t* counts;
     uint32_t cap;
     uint32_t n_dense;
+    const uint32_t* indirect;  // optional: entry -> index into the ray arrays (k_any_occluders' survivor lists); null = the entry is the index
 };
 struct SegView {  // per-block copy in LDS
     uint32_t count[kSeg];

@@ -620,6 +620,102 @@ __global__ __launch_bounds__(kBlock, FULL_ONLY ? TH_TRACE_LEAF_WAVES : 4) void k
     }
 }
 
+// ---- k_any_occluders: the scene's largest triangles first, for any-hit rays -----------------------------------------------------
+// intersect_p(bvh, ray) is a boolean — "some primitive the walk reaches accepts the ray" — so the order of the walk is free.  A
+// shadow ray of the reference has t_max = Inf (A.8): in an interior (every BASELINE scene is a mesh in a closed Cornell box) it ends
+// on a wall BEYOND the light at the latest, after walking the mesh's hierarchy all the way.  This pre-pass tests the ≤ 16 largest
+// triangles of the scene (picked at upload: the walls) with a wave-uniform loop — scalar loads, all lanes busy, like k_trace_leaf —
+// and resolves the ray as occluded when one of them accepts it AND the reference's own box test (bounds.jl:180-200, the loose one)
+// passes on that triangle's leaf box.  The second clause makes the shortcut exact: every ancestor box contains the leaf box, the
+// slab products are monotonic in the box planes (x - o and its product with 1/d round monotonically), so every clause of the test
+// that passes on the leaf box passes on each ancestor: the reference's walk does reach that leaf (or returns true before).  Rays
+// with a zero direction component (0 · Inf = NaN breaks the monotonicity argument) and rays no large triangle stops go on to
+// k_trace3 through per-segment survivor lists (SegQueue::indirect).  S-mesh any-hit 134 -> see DESIGN.md §4.
+struct OccluderSet {
+    const uint32_t* slots;  // ordered primitive slots of the occluders
+    const float* boxes;     // their leaf node's bounds, 6 floats each
+    uint32_t n;
+};
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock, 5) void k_any_occluders(DeviceScene sc, OccluderSet oc, SegQueue q, const float4* __restrict__ ro, const float4* __restrict__ rd,
+                                                             const float* __restrict__ tmax_or_null, TraceOut out, uint32_t* __restrict__ surv, uint32_t* __restrict__ surv_counts,
+                                                             uint32_t surv_cap, Counters* ctr) {
+    __shared__ SegView sv;
+    seg_load(q, sv);
+    const uint32_t total = sv.prefix[kSeg];
+    uint32_t nn = 0, np = 0;
+    unsigned long long resolved = 0;
+    for (uint32_t flat = blockIdx.x * kBlock + threadIdx.x; flat < total; flat += gridDim.x * kBlock) {
+        uint32_t seg, lb;
+        seg_locate(sv, flat & ~63u, seg, lb);
+        const uint32_t local = lb + (flat & 63u);
+        const bool valid = local < sv.count[seg];
+        const uint32_t idx = valid ? seg_phys(q, seg, local) : 0u;
+        float4 o4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), d4 = make_float4(0.0f, 0.0f, 1.0f, 0.0f);
+        if (valid) {
+            o4 = ro[idx];
+            d4 = rd[idx];
+        }
+        const f3 o = mk3(o4.x, o4.y, o4.z), d = mk3(d4.x, d4.y, d4.z);
+        const float t_max = (valid && tmax_or_null) ? tmax_or_null[idx] : kInf;
+        const f3 inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+        const RayShear shear = ray_shear(d);
+        bool live = valid && d.x != 0.0f && d.y != 0.0f && d.z != 0.0f;  // still looking for an occluder
+        bool found = false;
+#pragma unroll 1
+        for (uint32_t k = 0; k < oc.n; ++k) {
+            if (__ballot(live) == 0ull) break;
+            const uint32_t slot = uniform_load(oc.slots, k);
+            const float4 p0 = uniform_load(sc.prims, 3 * slot), p1 = uniform_load(sc.prims, 3 * slot + 1), p2 = uniform_load(sc.prims, 3 * slot + 2);
+            const float b0 = uniform_load(oc.boxes, 6 * k), b1 = uniform_load(oc.boxes, 6 * k + 1), b2 = uniform_load(oc.boxes, 6 * k + 2), b3 = uniform_load(oc.boxes, 6 * k + 3),
+                        b4 = uniform_load(oc.boxes, 6 * k + 4), b5 = uniform_load(oc.boxes, 6 * k + 5);
+            if (live) {
+                if (COUNT) np++;
+                TriTest tt;
+                if (tri_intersect_sheared<false>(mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z), o, shear, t_max, &tt)) {
+                    if (COUNT) nn++;
+                    float tmin;
+                    if (slab_test2(b0, b1, b2, b3, b4, b5, o, inv_d, 0.0f, false, d.x < 0.0f, d.y < 0.0f, d.z < 0.0f, tmin) && tmin < t_max) {
+                        found = true;
+                        live = false;
+                    }
+                }
+            }
+        }
+        if (valid && found) {
+            resolved++;
+            if (out.L) {
+                const uint32_t poison = __float_as_uint(d4.w);
+                if (poison) {
+                    const uint32_t slot = __float_as_uint(o4.w);
+                    float4 l = out.L[slot];
+                    const float nanv = __builtin_nanf("");
+                    if (poison & 1u) l.x += nanv;
+                    if (poison & 2u) l.y += nanv;
+                    if (poison & 4u) l.z += nanv;
+                    out.L[slot] = l;
+                }
+            } else {
+                out.occluded[idx] = 1;
+            }
+        }
+        const bool survive = valid && !found;
+        const uint32_t j = wave_compact(survive, &surv_counts[seg * kCtrStride]);  // the wave's entries all belong to `seg`
+        if (survive && j < surv_cap) surv[seg * surv_cap + j] = idx;
+    }
+    if (ctr) {
+        resolved = wave_sum(resolved);
+        if (lane_id() == 0 && resolved) atomicAdd(&ctr->shadow_total, resolved);
+        if (COUNT) {
+            const unsigned long long sn = wave_sum(nn), spr = wave_sum(np);
+            if (lane_id() == 0) {
+                atomicAdd(&ctr->nodes_shadow, sn);
+                atomicAdd(&ctr->prims_shadow, spr);
+            }
+        }
+    }
+}
+
 // ---- k_trace3: k_trace2 with the work of a wave re-grouped ("while-while") ------------------------------------------------------
 // Measured on the 1 M-triangle scene, k_trace2 keeps 11.6 of 64 lanes busy per VALU instruction: in every step the lanes at an
 // interior node, the lanes at a leaf and the lanes popping run one after the other.  Here a wave alternates between two
@@ -688,6 +784,7 @@ __global__ __launch_bounds__(kBlock, ANY ? TH_TRACE3_WAVES_ANY : TH_TRACE3_WAVES
                     const uint32_t rank = (uint32_t)__popcll(idle & lt_mask);
                     if (rank < avail) {
                         idx = seg_phys(q, wseg, pool_next + rank);
+                        if (q.indirect) idx = q.indirect[idx];
                         const float4 o4 = ro[idx], d4 = rd[idx];
                         o = mk3(o4.x, o4.y, o4.z);
                         const f3 d = mk3(d4.x, d4.y, d4.z);

@@ -56,6 +56,7 @@ struct trhip_ctx {
                            // -1 = automatic: the device builder above 16 Mi primitives.  Measured: commit 0.72 -> 0.13 s (1 M triangles), 8.0 -> 1.5 s
                            // (10 M); the LBVH costs 25-35 % more node visits per ray (frame +4 % at 1 M / 64 spp, +37 % at 10 M / 16 spp)
     bool film_transpose = false;     // film pass on pixel-group-major copies of p_film / L (option "film_transpose"; launch_film)
+    bool occluder_pretest = true;    // any-hit rays test the scene's largest triangles before the walk (option "occluder_pretest")
     bool leaf_kernel = true;         // one-leaf scenes run k_trace_leaf instead of k_trace2 (option "leaf_kernel", for A/B)
     int slab_margin_log2 = 14;       // k_trace2 / k_trace3 add the slab clauses the reference's box test lost, on boxes grown by 2^-this x the ray's reach
                                      // (th_trace2.h, slab_test2); 0 = the reference's loose test alone (its exact visit set)
@@ -65,14 +66,14 @@ struct trhip_ctx {
     bool overlap = true;  // two-stream overlap of shadow rays (depth d) with closest-hit rays (depth d+1)
     int traversal = 3;  // 1 = literal accel/bvh.jl loop, 2 = children-in-parent nodes + per-lane ray replacement, 3 = 2 with leaves postponed (while-while)
     // workspace (grown on demand, reused across calls)
-    DevBuf q[2][3], sq[3], hits, Lbuf, pfilm, counters, sensor, table, film, scratch[4], overflow, wh_L, wh_parent, wh_coef, wh_pdf, wh_flags, occl, film_Lt;
+    DevBuf q[2][3], sq[3], hits, Lbuf, pfilm, counters, sensor, table, film, scratch[4], overflow, wh_L, wh_parent, wh_coef, wh_pdf, wh_flags, occl, film_Lt, surv_list, surv_counts;
     uint64_t last_L_count = 0;  // float4 entries valid in Lbuf
     // SPPM state (th_sppm.h): per film pixel, kept after trhip_render_sppm for trhip_sppm_state
     DevBuf sp_vp[7], sp_Ld, sp_tau, sp_radius, sp_N, sp_phi, sp_M, sp_counts, sp_starts, sp_entries, sp_grid, sp_ldist, sp_snap_M, sp_snap_phi, sp_snap_p, sp_snap_beta;
     DevBuf sp_terms, sp_rec[3], sp_rec_valid;
     // streaming wavefront (render_stream_impl)
     DevBuf st_terms, st_tags[2], st_frozen, st_counts, st_list[2][2][7];  // [closest|any][ping-pong][o, d, b, trav, st, depth, stack]
-    int streaming = -1;            // PathIntegrator on scenes with a real hierarchy: suspend / resume stragglers.  1 = always, 0 = never (classic
+    int streaming = 0;             // PathIntegrator on scenes with a real hierarchy: suspend / resume stragglers.  1 = always, 0 = never (classic
                                    // per-depth launches), -1 = automatic: when the frame has at most 96 camera samples per primitive, which is where the
                                    // traversal tails dominate (measured, 1 M triangles: 16 spp 1170 -> 716 ms, 64 spp 1700 -> 1443, 128 spp 2288 vs
                                    // 2412, 256 spp 3742 vs 3823; 10 M triangles, depth 16: 32 spp 6075 -> 2465 ms, 128 spp 8364 -> 4913)
@@ -104,6 +105,8 @@ struct trhip_scene {
     DevBuf d_nodes, d_prims, d_nrm, d_spheres, d_materials, d_lights, d_wnodes;
     DeviceScene dev{};
     WideScene wide{};
+    DevBuf d_occ_slots, d_occ_boxes;
+    uint32_t n_occluders = 0;     // the scene's largest triangles, tested first by any-hit rays (th_trace2.h, k_any_occluders)
     bool partial_spheres = false;  // some sphere is clipped (z range or ϕ_max): traversal kernels with the general sphere test
     bool wide_ok = false;
 };
@@ -413,6 +416,43 @@ int upload_scene(trhip_scene* s) {
             s->wide_ok = ok;
         }
     }
+    // ---- largest triangles: the any-hit pre-pass (th_trace2.h, k_any_occluders) ----
+    s->n_occluders = 0;
+    if (s->wide_ok && s->wide.root_cnt == 0) {
+        const float* rb = &s->bvh.bounds[0];
+        const double ex = (double)rb[3] - rb[0], ey = (double)rb[4] - rb[1], ez = (double)rb[5] - rb[2];
+        const double face = std::max(ex * ey, std::max(ex * ez, ey * ez));
+        std::vector<std::pair<double, uint32_t>> big;  // (area, ordered slot)
+        for (uint32_t k = 0; k < n_prims; ++k) {
+            const HostPrim& p = s->prims[s->bvh.order[k]];
+            if (p.kind != 0 || (p.meta & PRIM_DEGENERATE)) continue;
+            const double ax = (double)p.v[3] - p.v[0], ay = (double)p.v[4] - p.v[1], az = (double)p.v[5] - p.v[2];
+            const double bx = (double)p.v[6] - p.v[0], by = (double)p.v[7] - p.v[1], bz = (double)p.v[8] - p.v[2];
+            const double cx = ay * bz - az * by, cy = az * bx - ax * bz, cz = ax * by - ay * bx;
+            const double area = 0.5 * std::sqrt(cx * cx + cy * cy + cz * cz);
+            if (area >= 0.02 * face) big.push_back({area, k});
+        }
+        if (!big.empty() && big.size() * 8 <= (size_t)n_prims) {  // a few walls around much else; not a scene that consists of large triangles
+            std::sort(big.begin(), big.end(), [](const auto& a, const auto& b) { return a.first > b.first || (a.first == b.first && a.second < b.second); });
+            if (big.size() > 16) big.resize(16);
+            std::vector<uint32_t> leaf_of(n_prims, 0xffffffffu);
+            for (uint32_t i = 0; i < n_nodes; ++i)
+                if ((s->bvh.flags[i] & 3u) == 3u)
+                    for (uint32_t k = s->bvh.a[i]; k < s->bvh.a[i] + (s->bvh.flags[i] >> 2) && k < n_prims; ++k) leaf_of[k] = i;
+            std::vector<uint32_t> slots;
+            std::vector<float> boxes;
+            for (const auto& b : big) {
+                if (leaf_of[b.second] == 0xffffffffu) continue;
+                slots.push_back(b.second);
+                for (int a = 0; a < 6; ++a) boxes.push_back(s->bvh.bounds[6 * (size_t)leaf_of[b.second] + a]);
+            }
+            if (!slots.empty()) {
+                if (int rc = upload(ctx, s->d_occ_slots, slots.data(), slots.size() * sizeof(uint32_t))) return rc;
+                if (int rc = upload(ctx, s->d_occ_boxes, boxes.data(), boxes.size() * sizeof(float))) return rc;
+                s->n_occluders = (uint32_t)slots.size();
+            }
+        }
+    }
     s->committed = true;
     return 0;
 }
@@ -514,6 +554,23 @@ void launch_trace(trhip_ctx* ctx, hipStream_t st, const trhip_scene* sc, bool an
     if (v2 && ctx->traversal == 3 && sc->wide.root_cnt == 0) {  // k_trace3: leaves postponed and tested together ("while-while"); a single-leaf scene
                                                                    // has nothing to postpone and runs k_trace2 (65 vs 73 ms on S-cornell)
         uint2* ov = (uint2*)(overflow_slab ? overflow_slab : ctx->overflow.p);
+        if (any && sc->n_occluders && ctx->occluder_pretest && ctx->pipelines <= 1 && !q.indirect) {
+            // the largest triangles first (k_any_occluders); what they do not stop goes through per-segment survivor lists
+            const uint32_t scap = q.counts ? q.cap : q.n_dense;
+            const size_t entries = (size_t)scap * (q.counts ? kSeg : 1);
+            if (ensure(ctx, ctx->surv_list, entries * sizeof(uint32_t)) == 0 && ensure(ctx, ctx->surv_counts, (size_t)kSeg * kCtrStride * sizeof(uint32_t)) == 0) {
+                uint32_t* sl = (uint32_t*)ctx->surv_list.p;
+                uint32_t* scn = (uint32_t*)ctx->surv_counts.p;
+                (void)hipMemsetAsync(scn, 0, (size_t)kSeg * kCtrStride * sizeof(uint32_t), st);
+                const OccluderSet oc{(const uint32_t*)sc->d_occ_slots.p, (const float*)sc->d_occ_boxes.p, sc->n_occluders};
+                const dim3 pgrid(ctx->num_cu * 8);
+                if (cnt)
+                    hipLaunchKernelGGL((k_any_occluders<true>), pgrid, block, 0, st, sc->dev, oc, q, ro, rd, tmax, out, sl, scn, scap, ctr);
+                else
+                    hipLaunchKernelGGL((k_any_occluders<false>), pgrid, block, 0, st, sc->dev, oc, q, ro, rd, tmax, out, sl, scn, scap, ctr);
+                q = SegQueue{scn, scap, 0u, sl};
+            }
+        }
         if (any) {
             if (cnt)
                 { if (full_only) hipLaunchKernelGGL((k_trace3<true, true, true>), grid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, work_cursors, ov, ctr); else hipLaunchKernelGGL((k_trace3<true, true, false>), grid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, work_cursors, ov, ctr); }
@@ -1533,6 +1590,8 @@ void trhip_shutdown(trhip_ctx* ctx) {
     release(ctx->wh_flags);
     release(ctx->occl);
     release(ctx->film_Lt);
+    release(ctx->surv_list);
+    release(ctx->surv_counts);
     for (auto& b : ctx->sp_vp) release(b);
     release(ctx->st_terms);
     release(ctx->st_tags[0]);
@@ -1574,6 +1633,8 @@ int trhip_set_option(trhip_ctx* ctx, const char* name, int64_t value) {
         ctx->bvh_builder = value < 0 ? -1 : (value != 0 ? 1 : 0);
     else if (!std::strcmp(name, "film_transpose"))
         ctx->film_transpose = value != 0;
+    else if (!std::strcmp(name, "occluder_pretest"))
+        ctx->occluder_pretest = value != 0;
     else if (!std::strcmp(name, "leaf_kernel"))
         ctx->leaf_kernel = value != 0;
     else if (!std::strcmp(name, "slab_margin_log2"))
@@ -1617,6 +1678,8 @@ void trhip_scene_free(trhip_scene* s) {
     release(s->d_materials);
     release(s->d_lights);
     release(s->d_wnodes);
+    release(s->d_occ_slots);
+    release(s->d_occ_boxes);
     delete s;
 }
 int trhip_scene_add_material(trhip_scene* s, int kind, const float* params, int n_params, uint32_t* id_out) {
