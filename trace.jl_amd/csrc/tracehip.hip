@@ -446,7 +446,7 @@ int upload_scene(trhip_scene* s) {
                 slots.push_back(b.second);
                 for (int a = 0; a < 6; ++a) boxes.push_back(s->bvh.bounds[6 * (size_t)leaf_of[b.second] + a]);
             }
-            if (!slots.empty()) {
+            if (slots.size() >= 6) {  // an enclosure (three quads or more); a lone floor stops few shadow rays and the pre-pass only costs (S-caustic)
                 if (int rc = upload(ctx, s->d_occ_slots, slots.data(), slots.size() * sizeof(uint32_t))) return rc;
                 if (int rc = upload(ctx, s->d_occ_boxes, boxes.data(), boxes.size() * sizeof(float))) return rc;
                 s->n_occluders = (uint32_t)slots.size();
