@@ -6,6 +6,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <future>
+#include <thread>
 #include <vector>
 
 namespace th {
@@ -61,7 +63,11 @@ class BVHBuilder {
         out_.a.reserve((size_t)n * 2);
         out_.flags.reserve((size_t)n * 2);
         out_.order.reserve(n);
-        if (n) recurse(0, n, 1);
+        // the top levels fan out into tasks (each subtree works on its own slice of idx_ and writes its own fragment, spliced in
+        // depth-first order afterwards): the tree is the one the serial recursion builds, about cores / 3 times sooner
+        int par = 0;
+        for (unsigned t = std::max(1u, std::thread::hardware_concurrency()); t > 1 && par < 6; t >>= 1) ++par;
+        if (n) recurse(0, n, 1, out_, n >= (1u << 16) ? par : 0);
         return std::move(out_);
     }
 
@@ -74,20 +80,31 @@ class BVHBuilder {
     std::vector<float> cen_;
     FlatBVH out_;
 
-    uint32_t emit_node(const HostAABB& b) {
-        const uint32_t id = (uint32_t)out_.a.size();
-        out_.bounds.insert(out_.bounds.end(), {b.mn[0], b.mn[1], b.mn[2], b.mx[0], b.mx[1], b.mx[2]});
-        out_.a.push_back(0);
-        out_.flags.push_back(0);
+    static uint32_t emit_node(FlatBVH& out, const HostAABB& b) {
+        const uint32_t id = (uint32_t)out.a.size();
+        out.bounds.insert(out.bounds.end(), {b.mn[0], b.mn[1], b.mn[2], b.mx[0], b.mx[1], b.mx[2]});
+        out.a.push_back(0);
+        out.flags.push_back(0);
         return id;
     }
-    void make_leaf(uint32_t node, uint32_t lo, uint32_t hi) {
-        out_.a[node] = (uint32_t)out_.order.size();
-        out_.flags[node] = ((hi - lo) << 2) | 3u;
-        for (uint32_t i = lo; i < hi; ++i) out_.order.push_back(idx_[i]);
+    void make_leaf(FlatBVH& out, uint32_t node, uint32_t lo, uint32_t hi) {
+        out.a[node] = (uint32_t)out.order.size();
+        out.flags[node] = ((hi - lo) << 2) | 3u;
+        for (uint32_t i = lo; i < hi; ++i) out.order.push_back(idx_[i]);
     }
-    void recurse(uint32_t lo, uint32_t hi, uint32_t depth) {
-        out_.max_depth = std::max(out_.max_depth, depth);
+    // append a subtree built on its own (node and slot indices relative to the fragment) behind what `out` holds
+    static void splice(FlatBVH& out, const FlatBVH& frag) {
+        const uint32_t noff = (uint32_t)out.a.size(), ooff = (uint32_t)out.order.size();
+        out.bounds.insert(out.bounds.end(), frag.bounds.begin(), frag.bounds.end());
+        out.flags.insert(out.flags.end(), frag.flags.begin(), frag.flags.end());
+        out.order.insert(out.order.end(), frag.order.begin(), frag.order.end());
+        out.a.reserve(out.a.size() + frag.a.size());
+        for (size_t i = 0; i < frag.a.size(); ++i) out.a.push_back(frag.a[i] + ((frag.flags[i] & 3u) == 3u ? ooff : noff));
+        out.max_depth = std::max(out.max_depth, frag.max_depth);
+    }
+    // `out` receives the subtree over idx_[lo, hi) in depth-first order; par > 0: the two children are built concurrently
+    void recurse(uint32_t lo, uint32_t hi, uint32_t depth, FlatBVH& out, int par) {
+        out.max_depth = std::max(out.max_depth, depth);
         HostAABB b, cb;
         b.reset();
         cb.reset();
@@ -95,12 +112,12 @@ class BVHBuilder {
             b.grow(pb_[idx_[i]]);
             cb.grow_point(&cen_[3 * (size_t)idx_[i]]);
         }
-        const uint32_t node = emit_node(b);
+        const uint32_t node = emit_node(out, b);
         const uint32_t n = hi - lo;
         // A hierarchy over a handful of primitives only adds divergence: a wavefront that walks one leaf tests the same
         // primitive in every lane.  Scenes of ≤ tiny_ primitives (option tiny_scene_prims, default 16) become a single leaf (the leaf-size hint is a hint).
         if (n == 1 || (depth == 1 && n <= tiny_)) {
-            make_leaf(node, lo, hi);
+            make_leaf(out, node, lo, hi);
             return;
         }
         // choose the split: binned SAH over the three axes
@@ -148,13 +165,13 @@ class BVHBuilder {
             }
         }
         if (best_axis < 0) {  // all centroids coincide: the reference makes a leaf too (bvh.jl:113-118)
-            make_leaf(node, lo, hi);
+            make_leaf(out, node, lo, hi);
             return;
         }
         if ((int)n <= max_leaf_) {
             const float leaf_cost = (float)n * b.half_area();
             if (best_cost + 0.125f * b.half_area() >= leaf_cost) {
-                make_leaf(node, lo, hi);
+                make_leaf(out, node, lo, hi);
                 return;
             }
         }
@@ -175,10 +192,20 @@ class BVHBuilder {
             std::nth_element(first, idx_.data() + mid, last,
                              [&](uint32_t x, uint32_t y) { return cen_[3 * (size_t)x + best_axis] < cen_[3 * (size_t)y + best_axis]; });
         }
-        out_.flags[node] = (uint32_t)best_axis;
-        recurse(lo, mid, depth + 1);
-        out_.a[node] = (uint32_t)out_.a.size();  // second child follows the whole first subtree
-        recurse(mid, hi, depth + 1);
+        out.flags[node] = (uint32_t)best_axis;
+        if (par > 0 && n >= (1u << 14)) {
+            FlatBVH left, right;
+            auto task = std::async(std::launch::async, [&] { recurse(lo, mid, depth + 1, left, par - 1); });
+            recurse(mid, hi, depth + 1, right, par - 1);
+            task.get();
+            splice(out, left);
+            out.a[node] = (uint32_t)out.a.size();  // second child follows the whole first subtree
+            splice(out, right);
+            return;
+        }
+        recurse(lo, mid, depth + 1, out, 0);
+        out.a[node] = (uint32_t)out.a.size();  // second child follows the whole first subtree
+        recurse(mid, hi, depth + 1, out, 0);
     }
 };
 

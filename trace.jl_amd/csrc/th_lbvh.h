@@ -3,7 +3,7 @@
 // The reference builds its BVH on the host with a (quirky) SAH (accel/bvh.jl:55-206); the results of traversal do not depend on
 // the topology except for exact-t ties (A.6), so any BVH2 over the same primitives in the same flat layout is a valid
 // BVHAccel for this library, and the oracle walks whichever one the library built (trhip_scene_get_bvh).  The binned-SAH host
-// builder (th_bvh.h) needs ~0.8 s per million primitives on one core; this one needs milliseconds:
+// builder (th_bvh.h) needs ~0.3 s per million primitives (its top levels run as parallel tasks); this one needs milliseconds:
 //   centroid bounds -> 63-bit Morton keys -> radix sort (hipCUB) -> Karras' parallel hierarchy (one thread per internal
 //   node) -> bottom-up bounds (second arrival at a node continues) -> depth-first numbering in closed form
 //   (dfs(node) = 2 * first_leaf(node) + number of left-child edges on its root path), which yields the reference layout
