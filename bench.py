@@ -242,7 +242,10 @@ def main():
             "film": 16 * sv.camera_samples + 16 * h * w,
             "raygen": 80 * sv.camera_samples,
         }
-        dominant = max(agg["ms"], key=lambda k: agg["ms"][k])
+        # the shadow rays of depth d run on a second, low-priority stream beside the closest-hit rays of depth d+1: their HIP-event
+        # time is wall time under contention, not the kernel's own — they are never the dominant kernel of these workloads (run
+        # alone: 27 ms on S-cornell, 39 ms on S-mesh) and are left out of the choice
+        dominant = max((k for k in agg["ms"] if k != "trace_any"), key=lambda k: agg["ms"][k])
         dom_ms = agg["ms"][dominant] / max(1, agg["launches"][dominant])
         dom_bytes = per_step[dominant] * args.steps / max(1, agg["launches"][dominant])
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
@@ -252,6 +255,7 @@ def main():
                     "visits_per_ray": {"closest_nodes": round(sv.nodes_visited / max(1, sv.closest_rays), 2), "closest_prims": round(sv.prims_tested / max(1, sv.closest_rays), 2),
                                        "shadow_nodes": round(sv.nodes_visited_shadow / max(1, sv.shadow_rays), 2), "shadow_prims": round(sv.prims_tested_shadow / max(1, sv.shadow_rays), 2)},
                     "kernel_ms_per_step": {k: round(v / args.steps, 3) for k, v in agg["ms"].items()},
+                    "kernel_ms_note": "HIP-event time per kernel class; trace_any runs on a second stream beside trace_closest of the next depth, so the two overlap and their sum exceeds the wall time",
                     "kernel_GBps": {k: round(per_step[k] / (agg["ms"][k] / args.steps * 1e-3) / 1e9, 1) if agg["ms"][k] > 0 else None for k in per_step}}
         if world == 1 and not args.no_traffic:
             roofline["traffic"] = measure_traffic(args, dominant)

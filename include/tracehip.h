@@ -209,6 +209,8 @@ int trhip_film_accumulate(trhip_ctx* ctx, const trhip_sensor* sensor, uint32_t s
  * "traversal" (1/2/3): 1 = literal accel/bvh.jl loop, 2 = children-in-parent nodes with per-lane ray replacement,
  *     3 = 2 with the leaves of a wave postponed and tested together (default).  Same results bit for bit.
  * "overlap" (0/1): shadow rays of depth d on a second stream beside the closest-hit pass of depth d+1 (default 1).
+ *     "stream2_priority" (-1/0/1): that stream's priority: lowest (default: the closest-hit rays are the critical path), the
+ *     default level, highest; read when the streams are created (first render of a context).
  * "pipelines" (1..8): wavefront batches in flight at once (default 1).
  * "bvh_builder" (-1/0/1): how trhip_scene_commit builds the BVH: 0 = binned SAH on the host, 1 = linear BVH on the device
  *     (Morton keys, radix sort, Karras hierarchy; ~6x faster to build, 25-35 % more node visits per ray), -1 (default) = the

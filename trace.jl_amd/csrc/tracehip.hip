@@ -57,6 +57,7 @@ struct trhip_ctx {
                            // (10 M); the LBVH costs 25-35 % more node visits per ray (frame +4 % at 1 M / 64 spp, +37 % at 10 M / 16 spp)
     bool film_transpose = false;     // film pass on pixel-group-major copies of p_film / L (option "film_transpose"; launch_film)
     bool occluder_pretest = true;    // any-hit rays test the scene's largest triangles before the walk (option "occluder_pretest")
+    int stream2_priority = -1;       // shadow-ray stream: 1 highest priority, -1 lowest, 0 the default level (option "stream2_priority", read when the streams are created)
     bool leaf_kernel = true;         // one-leaf scenes run k_trace_leaf instead of k_trace2 (option "leaf_kernel", for A/B)
     int slab_margin_log2 = 14;       // k_trace2 / k_trace3 add the slab clauses the reference's box test lost, on boxes grown by 2^-this x the ray's reach
                                      // (th_trace2.h, slab_test2); 0 = the reference's loose test alone (its exact visit set)
@@ -1133,8 +1134,15 @@ int render_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sensor* se
     for (int pi = 0; pi < NP; ++pi) {
         Pipe& pp = ctx->pipes[pi];
         if (!pp.st) {
+            // the shadow-ray stream gets its own priority level: streams of one level can share a hardware queue (then any(d) and
+            // closest(d+1) run one after the other: measured in the first context of a process), streams of different levels cannot
+            int prio_lo = 0, prio_hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
             HIP_TRY(ctx, hipStreamCreate(&pp.st));
-            HIP_TRY(ctx, hipStreamCreate(&pp.st2));
+            if (ctx->stream2_priority && prio_hi != prio_lo)
+                HIP_TRY(ctx, hipStreamCreateWithPriority(&pp.st2, hipStreamDefault, ctx->stream2_priority > 0 ? prio_hi : prio_lo));
+            else
+                HIP_TRY(ctx, hipStreamCreate(&pp.st2));
             HIP_TRY(ctx, hipEventCreateWithFlags(&pp.ev_shade, hipEventDisableTiming));
             HIP_TRY(ctx, hipEventCreateWithFlags(&pp.ev_any, hipEventDisableTiming));
             HIP_TRY(ctx, hipEventCreateWithFlags(&pp.ev_done, hipEventDisableTiming));
@@ -1635,6 +1643,8 @@ int trhip_set_option(trhip_ctx* ctx, const char* name, int64_t value) {
         ctx->film_transpose = value != 0;
     else if (!std::strcmp(name, "occluder_pretest"))
         ctx->occluder_pretest = value != 0;
+    else if (!std::strcmp(name, "stream2_priority"))
+        ctx->stream2_priority = (int)value;
     else if (!std::strcmp(name, "leaf_kernel"))
         ctx->leaf_kernel = value != 0;
     else if (!std::strcmp(name, "slab_margin_log2"))
