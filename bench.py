@@ -257,6 +257,13 @@ def main():
                     "kernel_ms_per_step": {k: round(v / args.steps, 3) for k, v in agg["ms"].items()},
                     "kernel_ms_note": "HIP-event time per kernel class; trace_any runs on a second stream beside trace_closest of the next depth, so the two overlap and their sum exceeds the wall time",
                     "kernel_GBps": {k: round(per_step[k] / (agg["ms"][k] / args.steps * 1e-3) / 1e9, 1) if agg["ms"][k] > 0 else None for k in per_step}}
+        if dominant.startswith("trace"):
+            # the compulsory-traffic lower bound beside the algorithmic figure — every ray in and its hit out, the scene once
+            bvh = flat.bvh()
+            rays_per_launch = (sv.closest_rays if dominant == "trace_closest" else sv.shadow_rays) / max(1, agg["launches"][dominant] // max(1, args.steps))
+            compulsory = rays_per_launch * (32 + (16 if dominant == "trace_closest" else 1)) + 32 * int(bvh[1].size) + 48 * int(bvh[3].size)
+            roofline["compulsory_bytes_per_launch"] = int(compulsory)
+            roofline["achieved_compulsory"] = round(compulsory / (dom_ms * 1e-3) / 1e9, 2) if dom_ms > 0 else 0.0
         if world == 1 and not args.no_traffic:
             roofline["traffic"] = measure_traffic(args, dominant)
             roofline["traffic_note"] = "bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (rocprofv3 --pmc, separate child runs of this command with --steps 1; gfx950 correction)"
