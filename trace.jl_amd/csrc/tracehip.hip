@@ -436,6 +436,28 @@ int upload_scene(trhip_scene* s) {
         if (!big.empty() && big.size() * 8 <= (size_t)n_prims) {  // a few walls around much else; not a scene that consists of large triangles
             std::sort(big.begin(), big.end(), [](const auto& a, const auto& b) { return a.first > b.first || (a.first == b.first && a.second < b.second); });
             if (big.size() > 16) big.resize(16);
+            // test order: a shadow ray runs from the surface THROUGH the light (t_max = Inf) — what stops it at the latest is what the light
+            // sees, so the triangles subtending the largest solid angle at the lights come first (Van Oosterom & Strackee)
+            auto solid_angle = [&](uint32_t k, const float* lp) {
+                const HostPrim& p = s->prims[s->bvh.order[k]];
+                double r[3][3], len[3];
+                for (int v = 0; v < 3; ++v) {
+                    for (int c = 0; c < 3; ++c) r[v][c] = (double)p.v[3 * v + c] - lp[c];
+                    len[v] = std::sqrt(r[v][0] * r[v][0] + r[v][1] * r[v][1] + r[v][2] * r[v][2]);
+                }
+                const double det = r[0][0] * (r[1][1] * r[2][2] - r[1][2] * r[2][1]) - r[0][1] * (r[1][0] * r[2][2] - r[1][2] * r[2][0]) + r[0][2] * (r[1][0] * r[2][1] - r[1][1] * r[2][0]);
+                auto dot3 = [&](int a, int b) { return r[a][0] * r[b][0] + r[a][1] * r[b][1] + r[a][2] * r[b][2]; };
+                const double den = len[0] * len[1] * len[2] + dot3(0, 1) * len[2] + dot3(0, 2) * len[1] + dot3(1, 2) * len[0];
+                return 2.0 * std::fabs(std::atan2(det, den));
+            };
+            if (!s->lights.empty()) {
+                for (auto& b : big) {
+                    double w = 0.0;
+                    for (const LightRec& l : s->lights) w += solid_angle(b.second, l.position);
+                    b.first = w;
+                }
+                std::stable_sort(big.begin(), big.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
+            }
             std::vector<uint32_t> leaf_of(n_prims, 0xffffffffu);
             for (uint32_t i = 0; i < n_nodes; ++i)
                 if ((s->bvh.flags[i] & 3u) == 3u)
