@@ -86,7 +86,10 @@ def rand_rays(rng, n, lo, hi, tri):
     v = tri[k, rng.integers(0, 3, m)]
     o = (lo + (hi - lo) * rng.random((m, 3), dtype=np.float32)).astype(np.float32)
     parts.append(make_rays(o, (v - o).astype(np.float32)))
-    return np.concatenate(parts)
+    rays = np.concatenate(parts)
+    finite = rng.random(rays.shape[0]) < 0.3  # the kernel-level entry points take a t_max per ray: a third of the rays get a finite one
+    rays[finite, 3] = (rng.random(int(finite.sum()), dtype=np.float32) * np.float32(1.5)).astype(np.float32)
+    return rays
 
 
 def main():
