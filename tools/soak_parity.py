@@ -97,6 +97,7 @@ def main():
     ap.add_argument("--scenes", type=int, default=24)
     ap.add_argument("--rays", type=int, default=400000)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--frames", type=int, default=0, help="also render each scene at this resolution (4 spp, depth 6) with traversal 1 and 3 and compare the films")
     a = ap.parse_args()
     ctx = T.default_context()
     bad_total = 0
@@ -119,6 +120,16 @@ def main():
                 bad += int((h[f].view(np.uint32) != h1[f].view(np.uint32)).sum())
             bad += int((o != o1).sum())
         ctx.set_option("traversal", 3)
+        if a.frames:  # whole frames too: every bounce and shadow ray of a small render, literal walk against all shortcuts
+            cam = T.scenes.cornell_camera(a.frames)
+            films = []
+            for trav in (1, 3):
+                ctx.set_option("traversal", trav)
+                films.append(T.PathIntegrator(cam, T.SeededSampler(4, seed=100 + k), 6).render(scene, ctx).copy())
+            fa, fb = films[0].view(np.uint32), films[1].view(np.uint32)
+            nan = np.isnan(films[0]) & np.isnan(films[1])
+            bad += int(((fa != fb) & ~nan).sum())
+            ctx.set_option("traversal", 3)
         rays_total += rays.shape[0]
         bad_total += bad
         print(f"scene {k:3d}: {flat.bvh()[3].size:7d} primitives, {rays.shape[0]} rays, hit {float((h1['prim'] >= 0).mean()):.3f}, occluded {float(o1.mean()):.3f}, mismatches {bad}", flush=True)
