@@ -72,7 +72,10 @@ class BVHBuilder {
     }
 
    private:
-    static constexpr int kBins = 16;
+#ifndef TH_BVH_BINS
+#define TH_BVH_BINS 16
+#endif
+    static constexpr int kBins = TH_BVH_BINS;
     const std::vector<HostAABB>& pb_;
     int max_leaf_;
     uint32_t tiny_;
