@@ -609,7 +609,10 @@ __global__ __launch_bounds__(kBlock) void k_shade_photon(DeviceScene sc, PathQue
 // visible point registers in (:306-317) walk the bucket of photon hits with that hash and take those within the radius.
 // A caustic puts thousands of photons into the radius of a few thousand pixels (and a handful into the rest): pixels with
 // more than kHotCandidates candidates are deferred to k_sppm_gather_hot, where a whole wave shares one pixel's buckets.
-constexpr uint32_t kHotCandidates = 192;
+#ifndef TH_SPPM_HOT
+#define TH_SPPM_HOT 192
+#endif
+constexpr uint32_t kHotCandidates = TH_SPPM_HOT;
 struct GatherSum {
     f3 phi;
     uint32_t M;
@@ -695,24 +698,80 @@ __global__ __launch_bounds__(kBlock) void k_sppm_gather(DeviceScene sc, PhotonRe
 // One wave per hot pixel: the lanes stride through each bucket, ϕ and M are reduced across the wave.
 __global__ __launch_bounds__(kBlock) void k_sppm_gather_hot(DeviceScene sc, PhotonRecords rec, VisiblePoints vp, PixelStats px, GridInfo* gp, const uint32_t* __restrict__ starts,
                                                             const float4* __restrict__ hit_sorted, uint32_t hash_size, const uint32_t* __restrict__ hot_list) {
+    // One wave per hot pixel.  The distance test runs over a bucket with all 64 lanes; the photons that pass (about one in eight) are
+    // not shaded where they are found — a handful of lanes would run the BSDF while the rest wait — but parked in a per-wave ring
+    // and shaded 64 at a time (the trick of k_shade_path).
+    __shared__ uint32_t s_ring[kBlock / 64][128];
     const GridInfo& g = *gp;
     const uint32_t n_hot = g.n_hot;
+    const uint32_t lane = lane_id(), wv = threadIdx.x >> 6;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6, n_waves = (gridDim.x * kBlock) >> 6;
     for (uint32_t w = wave; w < n_hot; w += n_waves) {
         const uint32_t i = hot_list[w];
         const float4 p4 = vp.p_mat[i];
         const float rad = px.radius[i];
+        const f3 vpp = mk3(p4.x, p4.y, p4.z);
         uint32_t lo[3], hi[3];
         to_grid(g, mk3(p4.x - rad, p4.y - rad, p4.z - rad), lo);
         to_grid(g, mk3(p4.x + rad, p4.y + rad, p4.z + rad), hi);
-        GatherSum s = gather_pixel(sc, rec, vp, i, p4, rad, lo, hi, starts, hit_sorted, hash_size, lane_id(), 64u);
+        const float4 wo4 = vp.wo[i], ng4 = vp.ng[i], ns4 = vp.ns[i], ss4 = vp.ss[i], ts4 = vp.ts[i];
+        Shading vs;
+        vs.p = vpp;
+        vs.wo = mk3(wo4.x, wo4.y, wo4.z);
+        vs.ng = mk3(ng4.x, ng4.y, ng4.z);
+        vs.ns = mk3(ns4.x, ns4.y, ns4.z);
+        vs.ss = mk3(ss4.x, ss4.y, ss4.z);
+        vs.ts = mk3(ts4.x, ts4.y, ts4.z);
+        const LobeSet& vb = sc.materials[__float_as_uint(p4.w)].set[1];
+        GatherSum s{splat3(0.0f), 0u};
+        uint32_t ring_head = 0, ring_cnt = 0;  // wave-uniform
+        auto shade = [&](uint32_t n) {         // the first n parked photons, one per lane
+            if (lane < n) {
+                const uint32_t r = s_ring[wv][(ring_head + lane) & 127u];
+                const float4 w4 = rec.wi[r], b4 = rec.beta[r];
+                s.phi = s.phi + mk3(b4.x, b4.y, b4.z) * bsdf_f(vb, vs, vs.wo, mk3(w4.x, w4.y, w4.z), BSDF_ALL);
+                s.M++;
+            }
+        };
+        for (uint32_t z = lo[2]; z <= hi[2]; ++z)
+            for (uint32_t y = lo[1]; y <= hi[1]; ++y)
+                for (uint32_t x = lo[0]; x <= hi[0]; ++x) {
+                    const uint32_t h = grid_hash(x, y, z, hash_size);
+                    const uint32_t e0 = starts[h], e1 = starts[h + 1];
+                    for (uint32_t eb = e0; eb < e1; eb += 64u) {  // wave-uniform trip count
+                        const uint32_t e = eb + lane;
+                        bool acc = false;
+                        uint32_t r = 0;
+                        if (e < e1) {
+                            const float4 hp = hit_sorted[e];
+                            r = __float_as_uint(hp.w);
+                            const f3 dv = vpp - mk3(hp.x, hp.y, hp.z);  // distance_squared(vp.p, p)
+                            acc = !(dot(dv, dv) > rad * rad);
+                        }
+                        const unsigned long long m = __ballot(acc);
+                        if (m) {
+                            if (acc) s_ring[wv][(ring_head + ring_cnt + (uint32_t)__popcll(m & lt_mask)) & 127u] = r;
+                            ring_cnt += (uint32_t)__popcll(m);
+                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                            if (ring_cnt >= 64u) {
+                                shade(64u);
+                                ring_head = (ring_head + 64u) & 127u;
+                                ring_cnt -= 64u;
+                                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                            }
+                        }
+                    }
+                }
+        if (ring_cnt) shade(ring_cnt);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         for (int off = 32; off > 0; off >>= 1) {
             s.phi.x += __shfl_down(s.phi.x, off);
             s.phi.y += __shfl_down(s.phi.y, off);
             s.phi.z += __shfl_down(s.phi.z, off);
             s.M += __shfl_down(s.M, off);
         }
-        if (lane_id() == 0 && s.M) {
+        if (lane == 0 && s.M) {
             px.phi[3 * i + 0] = s.phi.x;
             px.phi[3 * i + 1] = s.phi.y;
             px.phi[3 * i + 2] = s.phi.z;
