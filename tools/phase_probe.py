@@ -1,0 +1,36 @@
+#!/usr/bin/env python
+"""Where k_trace3<closest> spends its wave cycles, and with how many lanes.  Needs the DIAGNOSTIC build:
+
+    hipcc <__graft_entry__.HIPCC_FLAGS> -DTH_DIAG_PHASES -o _diag/libtracehip_phases.so trace.jl_amd/csrc/tracehip.hip
+    TRHIP_LIB=$PWD/_diag/libtracehip_phases.so python tools/phase_probe.py --workload mesh_1m --spp 64
+
+Phases: refill (idle lanes take new rays), pop (stack pops of lanes whose node is done), node (interior step: one 64-byte node,
+two boxes), leaf (primitive tests).  cycles = wave cycles inside the phase summed over all waves; lanes = lanes with work at entry."""
+import argparse, ctypes as C, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as g
+import bench
+T = g.load_package()
+ap = argparse.ArgumentParser()
+ap.add_argument("--workload", default="mesh_1m")
+ap.add_argument("--spp", type=int, default=64)
+a = ap.parse_args()
+L = T.lib()
+fn = L.trhip_debug_phases
+fn.restype = C.c_int
+fn.argtypes = [C.POINTER(C.c_uint64), C.c_int]
+scene, cam, desc = bench.build_workload(T, a.workload, 1024)
+ctx = T.default_context()
+out = np.zeros(12, np.uint64)
+integ = T.PathIntegrator(cam, T.SeededSampler(a.spp, seed=1), 8)
+integ.render(scene, ctx)
+fn(out.ctypes.data_as(C.POINTER(C.c_uint64)), 1)
+integ.render(scene, ctx)
+assert fn(out.ctypes.data_as(C.POINTER(C.c_uint64)), 1) == 0
+tot = float(sum(out[0::3]))
+print(f"{a.workload}, {a.spp} spp: closest-hit {integ.stats.ms_trace_closest:.1f} ms, {integ.stats.closest_rays} rays")
+for k, name in enumerate(("refill", "pop", "node", "leaf")):
+    cyc, lan, cnt = float(out[3 * k]), float(out[3 * k + 1]), float(out[3 * k + 2])
+    print(f"  {name:7s} {100 * cyc / tot:5.1f} % of the instrumented wave cycles, {cnt:.3e} entries, {cyc / max(cnt, 1):7.1f} cycles each, {lan / max(cnt, 1):5.1f} lanes with work")

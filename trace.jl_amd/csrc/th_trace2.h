@@ -725,8 +725,25 @@ __global__ __launch_bounds__(kBlock, 5) void k_any_occluders(DeviceScene sc, Occ
 #ifndef TH_TRACE3_LEAF_WAIT
 #define TH_TRACE3_LEAF_WAIT 32  // measured (128 spp, S-blob / S-mesh frame ms): 20: 694 / 2250, 32: 654 / 2207, 40: 659 / 2202, 48: 696 / 2265
 #endif
+#ifndef TH_TRACE3_POP_MIN
+#define TH_TRACE3_POP_MIN 1
+#endif
 #ifndef TH_TRACE3_MAX_A
 #define TH_TRACE3_MAX_A 8
+#endif
+#ifdef TH_DIAG_PHASES
+// DIAGNOSTIC build (tools/phase_probe.py): wave cycles and active lanes per phase of k_trace3, summed over the waves of all launches
+__device__ unsigned long long g_phase[16];
+#define TH_PHASE_BEGIN() const unsigned long long ph_t0 = __builtin_readcyclecounter()
+#define TH_PHASE_END(slot, lanes)                                                   \
+    do {                                                                            \
+        ph_cyc[slot] += __builtin_readcyclecounter() - ph_t0;                       \
+        ph_lan[slot] += (unsigned long long)(lanes);                                \
+        ph_cnt[slot] += 1ull;                                                       \
+    } while (0)
+#else
+#define TH_PHASE_BEGIN()
+#define TH_PHASE_END(slot, lanes)
 #endif
 template <bool ANY, bool COUNT, bool FULL_ONLY>
 __global__ __launch_bounds__(kBlock, ANY ? TH_TRACE3_WAVES_ANY : TH_TRACE3_WAVES_CLOSEST) void k_trace3(DeviceScene sc, WideScene ws, SegQueue q, const float4* __restrict__ ro, const float4* __restrict__ rd, const float* __restrict__ tmax_or_null,
@@ -754,6 +771,9 @@ __global__ __launch_bounds__(kBlock, ANY ? TH_TRACE3_WAVES_ANY : TH_TRACE3_WAVES
     float t_max = 0.0f, slot_w = 0.0f, flag_w = 0.0f;
     bool found = false;
     uint32_t nn = 0, np = 0;
+#ifdef TH_DIAG_PHASES
+    unsigned long long ph_cyc[4] = {0, 0, 0, 0}, ph_lan[4] = {0, 0, 0, 0}, ph_cnt[4] = {0, 0, 0, 0};  // refill, pop, node, leaf
+#endif
 #ifdef TH_DIAG_RAY_VISITS
     uint32_t rn = 0;  // DIAGNOSTIC build only: interior fetches of the current ray, delivered in hits[].x (tools/visit_probe.py)
 #endif
@@ -763,6 +783,7 @@ __global__ __launch_bounds__(kBlock, ANY ? TH_TRACE3_WAVES_ANY : TH_TRACE3_WAVES
         const unsigned long long idle = __ballot(!active);
         const uint32_t n_idle = (uint32_t)__popcll(idle);
         if (n_idle == 64u || (!exhausted && n_idle >= (uint32_t)TH_TRACE_REFILL)) {
+            TH_PHASE_BEGIN();
             if (!exhausted) {
                 if (pool_next >= pool_end) {
                     uint32_t base = 0;
@@ -817,6 +838,7 @@ __global__ __launch_bounds__(kBlock, ANY ? TH_TRACE3_WAVES_ANY : TH_TRACE3_WAVES
                 }
                 pool_next += min(n_idle, avail);
             }
+            TH_PHASE_END(0, n_idle);
             if (__ballot(active) == 0ull) {
                 if (exhausted) break;
                 continue;
@@ -826,7 +848,14 @@ __global__ __launch_bounds__(kBlock, ANY ? TH_TRACE3_WAVES_ANY : TH_TRACE3_WAVES
 #pragma unroll 1
         for (int it = 0; it < TH_TRACE3_MAX_A; ++it) {
             bool finished = false;
-            if (active && cur == kRefNone) {  // pop the next entry whose tx_min is still below t_max (bvh.jl:247-250 with the deferred clause)
+#ifdef TH_DIAG_PHASES
+            const unsigned long long ph_pop_m = __ballot(active && cur == kRefNone);
+            const unsigned long long ph_t_pop = __builtin_readcyclecounter();
+#endif
+            // lanes whose node is done pop their stack — together: the pop section runs only when TH_TRACE3_POP_MIN lanes wait for it (or
+            // nobody can take an interior step), instead of in every round for the handful of lanes that happen to need it
+            const bool pop_now = (uint32_t)__popcll(__ballot(active && cur == kRefNone)) >= (uint32_t)TH_TRACE3_POP_MIN || __ballot(active && cur != kRefNone && cur_cnt == 0) == 0ull;
+            if (pop_now && active && cur == kRefNone) {  // pop the next entry whose tx_min is still below t_max (bvh.jl:247-250 with the deferred clause)
                 finished = true;
                 while (sp > 0) {
                     sp--;
@@ -883,6 +912,16 @@ __global__ __launch_bounds__(kBlock, ANY ? TH_TRACE3_WAVES_ANY : TH_TRACE3_WAVES
 #endif
                 }
             }
+#ifdef TH_DIAG_PHASES
+            {
+                const unsigned long long now = __builtin_readcyclecounter();
+                ph_cyc[1] += now - ph_t_pop;
+                ph_lan[1] += (unsigned long long)__popcll(ph_pop_m);
+                ph_cnt[1] += 1ull;
+            }
+            const unsigned long long ph_node_m = __ballot(active && cur != kRefNone && cur_cnt == 0);
+            const unsigned long long ph_t_node = __builtin_readcyclecounter();
+#endif
             if (active && cur != kRefNone && cur_cnt == 0) {  // interior: one 64-byte burst, both child boxes
                 const float4 a0 = ws.wnodes[4 * (size_t)cur], a1 = ws.wnodes[4 * (size_t)cur + 1], a2 = ws.wnodes[4 * (size_t)cur + 2], a3 = ws.wnodes[4 * (size_t)cur + 3];
                 if (COUNT) nn += 2;
@@ -900,10 +939,12 @@ __global__ __launch_bounds__(kBlock, ANY ? TH_TRACE3_WAVES_ANY : TH_TRACE3_WAVES
                 const float tn = neg ? trh : tlh, tf = neg ? tlh : trh;
                 const uint32_t nenc = neg ? renc : lenc, fenc = neg ? lenc : renc;
                 const bool go_n = tn < t_max, go_f = tf < t_max;
-                // The far child waits on the stack whenever its box is hit at all, NOT only when tx_min < t_max now: t_max is not
-                // monotonic in the reference — a sphere entered from inside returns t1 without looking at t_max (sphere.jl:143-147)
-                // and raises it — so the clause has to be evaluated when the entry is popped, as bvh.jl:226 does at visit time.
-                if (go_n & (tf < kInf)) {
+                // The far child waits on the stack; its `tx_min < t_max` clause is evaluated when the entry is popped, as bvh.jl:226 does at
+                // visit time.  A child that fails the clause NOW fails it then too — unless t_max can go up in between: t_max is not
+                // monotonic in the reference (a sphere entered from inside returns t1 without looking at t_max, sphere.jl:143-147).  Any-hit rays,
+                // whose t_max never changes, skip the dead entries.  (Doing the same for closest-hit rays that start outside every sphere's
+                // bound was measured: no gain — dead entries are not what the pop phase costs.)
+                if (go_n & (ANY ? go_f : (tf < kInf))) {
                     if (sp < kLds) {
                         s_ref[sp][tid] = fenc;
                         s_tmin[sp][tid] = tf;
@@ -917,11 +958,20 @@ __global__ __launch_bounds__(kBlock, ANY ? TH_TRACE3_WAVES_ANY : TH_TRACE3_WAVES
                 cur = any_child ? (nxt & 0x00ffffffu) : kRefNone;
                 cur_cnt = any_child ? (nxt >> 24) : 0u;
             }
+#ifdef TH_DIAG_PHASES
+            ph_cyc[2] += __builtin_readcyclecounter() - ph_t_node;
+            ph_lan[2] += (unsigned long long)__popcll(ph_node_m);
+            ph_cnt[2] += 1ull;
+#endif
             // lanes that can go on without touching a leaf; when few are left, everybody's leaves are tested together
             const uint32_t n_desc = (uint32_t)__popcll(__ballot(active && cur_cnt == 0));
             if (n_desc <= (uint32_t)TH_TRACE3_LEAF_WAIT) break;
         }
         // ---- phase B: leaves, primitives in slot order, later equal-t hit wins (bvh.jl:229-237, triangle_mesh.jl:211-214) ----------
+#ifdef TH_DIAG_PHASES
+        const unsigned long long ph_leaf_m = __ballot(active && cur != kRefNone && cur_cnt > 0);
+        const unsigned long long ph_t_leaf = __builtin_readcyclecounter();
+#endif
         if (active && cur != kRefNone && cur_cnt > 0) {
             bool hit_any = false;
             for (uint32_t k = 0; k < cur_cnt; ++k) {
@@ -969,7 +1019,20 @@ __global__ __launch_bounds__(kBlock, ANY ? TH_TRACE3_WAVES_ANY : TH_TRACE3_WAVES
                 sp = 0;
             }
         }
+#ifdef TH_DIAG_PHASES
+        ph_cyc[3] += __builtin_readcyclecounter() - ph_t_leaf;
+        ph_lan[3] += (unsigned long long)__popcll(ph_leaf_m);
+        ph_cnt[3] += 1ull;
+#endif
     }
+#ifdef TH_DIAG_PHASES
+    if (!ANY && lane == 0)
+        for (int k4 = 0; k4 < 4; ++k4) {
+            atomicAdd(&g_phase[3 * k4], ph_cyc[k4]);
+            atomicAdd(&g_phase[3 * k4 + 1], ph_lan[k4]);
+            atomicAdd(&g_phase[3 * k4 + 2], ph_cnt[k4]);
+        }
+#endif
     if (ctr) {
         if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(ANY ? &ctr->shadow_total : &ctr->closest_total, (unsigned long long)seg_total(sv));
         if (COUNT) {

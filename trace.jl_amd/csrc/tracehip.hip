@@ -2034,6 +2034,18 @@ int trhip_trace_any_device(trhip_ctx* ctx, const trhip_scene* sc, const void* d_
     if (!ctx || !sc || !d_rays || !d_occ) return fail(ctx, TRHIP_ERR_INVALID, "null argument");
     return api_trace(ctx, sc, true, d_rays, true, n, d_occ, repeat, avg_ms);
 }
+#ifdef TH_DIAG_PHASES
+extern "C" int trhip_debug_phases(uint64_t* out12, int reset) {  // DIAGNOSTIC build only (tools/phase_probe.py)
+    unsigned long long h[16];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase), sizeof h) != hipSuccess) return -1;
+    for (int i = 0; i < 12; ++i) out12[i] = h[i];
+    if (reset) {
+        std::memset(h, 0, sizeof h);
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase), h, sizeof h) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 // visit counters of the last *_device trace call (when "count_visits" is on): nodes, prims for closest then shadow
 int trhip_last_visit_counts(trhip_ctx* ctx, uint64_t* out4) {
     if (!ctx || !out4 || !ctx->counters.p) return fail(ctx, TRHIP_ERR_INVALID, "no counters");
