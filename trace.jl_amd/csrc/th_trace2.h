@@ -773,6 +773,7 @@ __global__ __launch_bounds__(kBlock, ANY ? TH_TRACE3_WAVES_ANY : TH_TRACE3_WAVES
     uint32_t nn = 0, np = 0;
 #ifdef TH_DIAG_PHASES
     unsigned long long ph_cyc[4] = {0, 0, 0, 0}, ph_lan[4] = {0, 0, 0, 0}, ph_cnt[4] = {0, 0, 0, 0};  // refill, pop, node, leaf
+    unsigned long long ph_load = 0;  // of the leaf cycles: until the primitive's three records have arrived
 #endif
 #ifdef TH_DIAG_RAY_VISITS
     uint32_t rn = 0;  // DIAGNOSTIC build only: interior fetches of the current ray, delivered in hits[].x (tools/visit_probe.py)
@@ -978,6 +979,10 @@ __global__ __launch_bounds__(kBlock, ANY ? TH_TRACE3_WAVES_ANY : TH_TRACE3_WAVES
                 const uint32_t slot = cur + k;
                 const float4 p0 = sc.prims[3 * slot];
                 const float4 p1 = sc.prims[3 * slot + 1], p2 = sc.prims[3 * slot + 2];
+#ifdef TH_DIAG_PHASES
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                ph_load += __builtin_readcyclecounter() - ph_t_leaf;
+#endif
                 const uint32_t meta = __float_as_uint(p0.w);
                 if (COUNT) np++;
                 if (meta & PRIM_SPHERE) {
@@ -1026,6 +1031,12 @@ __global__ __launch_bounds__(kBlock, ANY ? TH_TRACE3_WAVES_ANY : TH_TRACE3_WAVES
 #endif
     }
 #ifdef TH_DIAG_PHASES
+    {
+        float f = (float)ph_load;  // a lane's view of the wave's clock; the float rounding does not matter here
+        for (int off = 32; off > 0; off >>= 1) f = fmaxf(f, __shfl_xor(f, off));
+        ph_load = (unsigned long long)f;
+    }
+    if (!ANY && lane == 0) atomicAdd(&g_phase[12], ph_load);
     if (!ANY && lane == 0)
         for (int k4 = 0; k4 < 4; ++k4) {
             atomicAdd(&g_phase[3 * k4], ph_cyc[k4]);

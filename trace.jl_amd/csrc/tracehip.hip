@@ -2038,7 +2038,7 @@ int trhip_trace_any_device(trhip_ctx* ctx, const trhip_scene* sc, const void* d_
 extern "C" int trhip_debug_phases(uint64_t* out12, int reset) {  // DIAGNOSTIC build only (tools/phase_probe.py)
     unsigned long long h[16];
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase), sizeof h) != hipSuccess) return -1;
-    for (int i = 0; i < 12; ++i) out12[i] = h[i];
+    for (int i = 0; i < 13; ++i) out12[i] = h[i];
     if (reset) {
         std::memset(h, 0, sizeof h);
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase), h, sizeof h) != hipSuccess) return -1;
