@@ -41,6 +41,22 @@ def test_ray_bounds_intersection(ob):
     assert ob.lib().orc_bounds_intersect_p(ob.fp(b_neg), ob.fp(r1)) == 0
 
 
+def test_bounds_intersect_p_keeps_the_larger_xy_exit(ob):
+    """bounds.jl:190 reads `ty_max > tx_max && (tx_max = ty_max)`: the LARGER of the x and y exits survives, so the earlier one never
+    bounds the z entry and a box wholly behind the ray in x (or y) still passes.  Derived by hand from the lines 180-200; the
+    restatement must keep it (it decides which boxes a walk visits, and the GPU kernels' added clauses are defined against it)."""
+    r = ray((0, 0, 0), (1, 1e-3, 1))                       # nearly in the x-z plane, heading +x +z
+    behind_x = np.array([-3, -1, 1, -2, 1, 2], np.float32)  # x in [-3, -2]: entirely behind the origin; y range holds the ray, z ahead
+    # tx in [-3, -2], ty in [-1000, 1000], tz in [1, 2]: x-y overlap passes, tx_max becomes 1000, z overlaps [max(-2,-1000), 1000] -> "hit"
+    assert ob.lib().orc_bounds_intersect_p(ob.fp(behind_x), ob.fp(r)) == 1
+    # the same box seen by a ray whose y interval ends early is rejected: there ty_max < tx_max keeps tx_max
+    r2 = ray((0, 5, 0), (1, 1, 1))                          # ty in [-6, -4]
+    assert ob.lib().orc_bounds_intersect_p(ob.fp(behind_x), ob.fp(r2)) == 0
+    # a box behind the ray in z is rejected as it should be (the z exit is taken with `<`)
+    behind_z = np.array([1, -1, -3, 2, 1, -2], np.float32)
+    assert ob.lib().orc_bounds_intersect_p(ob.fp(behind_z), ob.fp(r)) == 0
+
+
 # ---- test_intersection.jl:22-87 --------------------------------------------------------------------------------------------------
 def test_ray_sphere_intersection(T, ob):
     sc = ob.OracleScene()
@@ -70,6 +86,22 @@ def test_ray_sphere_intersection(T, ob):
     # translated sphere
     hit, t, g, hp = prim_intersect(ob, sc, 1, ray((0, 0, 0), (0, 1, 0)))
     assert hit and hit == hp and approx(t, 1) and approx(g[0:3], (0, 1, 0)) and approx(g[3:6], (0, -1, 0))
+
+
+def test_sphere_hit_from_inside_ignores_t_max(T, ob):
+    """sphere.jl:137-147: `t0 > t_max || t1 < 0` rejects, then `t0 < 0 && (t0 = t1)` — the exit point is returned without a second look at
+    t_max.  A ray that starts inside the sphere with t_max = 0.5 is told it hit at t = 1: the caller then RAISES its t_max
+    (primitive.jl:12-20).  Derived from the lines; the traversal kernels' stack handling depends on it."""
+    sc = ob.OracleScene()
+    sc.add_sphere(T.Transformation(), False, 1.0, -1.0, 1.0, 360.0)
+    r = ray((0, 0, 0), (0, 0, 1))
+    r[3] = 0.5
+    hit, t, g, hp = prim_intersect(ob, sc, 0, r)
+    assert hit and hp and approx(t, 1) and approx(g[0:3], (0, 0, 1))
+    r_out = ray((0, 0, -3), (0, 0, 1))   # from outside the test is the usual one: nearer root beyond t_max -> no hit
+    r_out[3] = 1.5
+    hit, *_ = prim_intersect(ob, sc, 0, r_out)
+    assert not hit
 
 
 # ---- runtests.jl:34-41 ----------------------------------------------------------------------------------------------------------------

@@ -942,7 +942,7 @@ __global__ __launch_bounds__(kBlock, ANY ? TH_TRACE3_WAVES_ANY : TH_TRACE3_WAVES
                 const bool go_n = tn < t_max, go_f = tf < t_max;
                 // The far child waits on the stack; its `tx_min < t_max` clause is evaluated when the entry is popped, as bvh.jl:226 does at
                 // visit time.  A child that fails the clause NOW fails it then too — unless t_max can go up in between: t_max is not
-                // monotonic in the reference (a sphere entered from inside returns t1 without looking at t_max, sphere.jl:143-147).  Any-hit rays,
+                // monotonic in the reference (a sphere entered from inside returns t1 without looking at t_max, sphere.jl:137-138).  Any-hit rays,
                 // whose t_max never changes, skip the dead entries.  (Doing the same for closest-hit rays that start outside every sphere's
                 // bound was measured: no gain — dead entries are not what the pop phase costs.)
                 if (go_n & (ANY ? go_f : (tf < kInf))) {
