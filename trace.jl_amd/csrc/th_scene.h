@@ -68,8 +68,6 @@ struct LightRec {  // lights/point.jl:1-24, lights/spot.jl:1-19
     float pad;
 };
 
-constexpr int kLdsMaterials = 16, kLdsLights = 8;  // tables of at most this size are staged in LDS by the shading kernel
-
 struct DeviceScene {
     const float4* nodes;
     const float4* prims;

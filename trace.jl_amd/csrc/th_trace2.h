@@ -423,9 +423,6 @@ __global__ __launch_bounds__(kBlock, TH_TRACE2_MIN_WAVES) void k_trace2(DeviceSc
                         const uint2 e = overflow[(size_t)(sp - kStack2Lds) * gthreads + gtid];
                         enc = e.x;
                         tm = __uint_as_float(e.y);
-#ifdef TH_DIAG_OVERFLOW_POPS
-                        if (COUNT) np += 1000u;  // DIAGNOSTIC: pops served by the global slab, reported through prims_tested / 1e3
-#endif
                     } else {
                         continue;  // beyond 64 levels the reference throws (bvh.jl:222); entries were dropped
                     }
