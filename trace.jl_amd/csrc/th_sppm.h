@@ -655,18 +655,32 @@ TH_D GatherSum gather_pixel(const DeviceScene& sc, const PhotonRecords& rec, con
 // One thread per pixel; also counts the registrations (the reference's list nodes) for trhip_sppm_state.
 __global__ __launch_bounds__(kBlock) void k_sppm_gather(DeviceScene sc, PhotonRecords rec, VisiblePoints vp, PixelStats px, uint32_t n, GridInfo* gp, const uint32_t* __restrict__ starts,
                                                         const float4* __restrict__ hit_sorted, uint32_t hash_size, uint32_t* __restrict__ hot_list) {
+    // A wave takes 64 pixels.  Every lane walks the buckets of ITS pixel one candidate per round (a cursor over cells and entries);
+    // the (pixel, photon) pairs that pass the distance test are parked in a per-wave ring and evaluated 64 at a time — frame and
+    // material of the pair's pixel are fetched by whichever lane gets the pair — and summed per pixel in LDS.  (One thread per pixel
+    // evaluating its own pairs in place ran the BSDF with 13 of 64 lanes.)  Pixels with more than kHotCandidates candidates go to
+    // k_sppm_gather_hot as before.  Also counts the registrations (the reference's list nodes) for trhip_sppm_state.
+    __shared__ uint32_t s_ring[kBlock / 64][128];   // photon record of a parked pair
+    __shared__ uint32_t s_src[kBlock / 64][128];    // … and the lane whose pixel it belongs to
+    __shared__ float s_phi[kBlock / 64][64][3];
+    __shared__ uint32_t s_m[kBlock / 64][64];
     const GridInfo& g = *gp;
     if (!g.valid) return;
+    const uint32_t lane = lane_id(), wv = threadIdx.x >> 6;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
     unsigned long long n_reg = 0;
     const uint32_t total = (n + 63u) & ~63u;
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < total; i += gridDim.x * kBlock) {
-        bool hot = false;
+        const uint32_t base = i - lane;  // the wave's first pixel
+        bool hot = false, walk = false;
+        float4 p4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        float rad = 0.0f;
+        uint32_t lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
         if (i < n) {
             const float4 b = vp.beta[i];
             if (!(b.x == 0.0f && b.y == 0.0f && b.z == 0.0f)) {
-                const float4 p4 = vp.p_mat[i];
-                const float rad = px.radius[i];
-                uint32_t lo[3], hi[3];
+                p4 = vp.p_mat[i];
+                rad = px.radius[i];
                 to_grid(g, mk3(p4.x - rad, p4.y - rad, p4.z - rad), lo);
                 to_grid(g, mk3(p4.x + rad, p4.y + rad, p4.z + rad), hi);
                 uint32_t candidates = 0;
@@ -678,24 +692,102 @@ __global__ __launch_bounds__(kBlock) void k_sppm_gather(DeviceScene sc, PhotonRe
                             candidates += starts[h + 1] - starts[h];
                         }
                 hot = candidates > kHotCandidates;
-                if (!hot && candidates) {
-                    const GatherSum s = gather_pixel(sc, rec, vp, i, p4, rad, lo, hi, starts, hit_sorted, hash_size, 0u, 1u);
-                    if (s.M) {  // ϕ and M are zero between iterations (_update_pixels! clears them)
-                        px.phi[3 * i + 0] = s.phi.x;
-                        px.phi[3 * i + 1] = s.phi.y;
-                        px.phi[3 * i + 2] = s.phi.z;
-                        px.M[i] = s.M;
-                    }
-                }
+                walk = !hot && candidates > 0;
             }
         }
         const uint32_t k = wave_compact(hot, &gp->n_hot);
         if (hot) hot_list[k] = i;
+        if (__ballot(walk) == 0ull) continue;
+        s_phi[wv][lane][0] = s_phi[wv][lane][1] = s_phi[wv][lane][2] = 0.0f;
+        s_m[wv][lane] = 0u;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const f3 vpp = mk3(p4.x, p4.y, p4.z);
+        // cursor: cell (cx, cy, cz), entries [e, e1) of its bucket
+        uint32_t cx = lo[0], cy = lo[1], cz = lo[2], e = 0, e1 = 0;
+        bool more = walk;
+        if (more) {
+            const uint32_t h = grid_hash(cx, cy, cz, hash_size);
+            e = starts[h];
+            e1 = starts[h + 1];
+        }
+        uint32_t ring_head = 0, ring_cnt = 0;  // wave-uniform
+        auto shade = [&](uint32_t cnt) {        // the first cnt parked pairs, one per lane
+            if (lane < cnt) {
+                const uint32_t r = s_ring[wv][(ring_head + lane) & 127u], src = s_src[wv][(ring_head + lane) & 127u], j = base + src;
+                const float4 q4 = vp.p_mat[j], wo4 = vp.wo[j], ng4 = vp.ng[j], ns4 = vp.ns[j], ss4 = vp.ss[j], ts4 = vp.ts[j];
+                Shading vs;
+                vs.p = mk3(q4.x, q4.y, q4.z);
+                vs.wo = mk3(wo4.x, wo4.y, wo4.z);
+                vs.ng = mk3(ng4.x, ng4.y, ng4.z);
+                vs.ns = mk3(ns4.x, ns4.y, ns4.z);
+                vs.ss = mk3(ss4.x, ss4.y, ss4.z);
+                vs.ts = mk3(ts4.x, ts4.y, ts4.z);
+                const float4 w4 = rec.wi[r], b4 = rec.beta[r];
+                const LobeSet& vb = sc.materials[__float_as_uint(q4.w)].set[1];
+                const f3 c = mk3(b4.x, b4.y, b4.z) * bsdf_f(vb, vs, vs.wo, mk3(w4.x, w4.y, w4.z), BSDF_ALL);
+                atomicAdd(&s_phi[wv][src][0], c.x);
+                atomicAdd(&s_phi[wv][src][1], c.y);
+                atomicAdd(&s_phi[wv][src][2], c.z);
+                atomicAdd(&s_m[wv][src], 1u);
+            }
+        };
+        while (__ballot(more) != 0ull) {
+            bool acc = false;
+            uint32_t r = 0;
+            if (more) {
+                // skip empty buckets / advance to the next cell
+                while (e >= e1) {
+                    if (++cx > hi[0]) {
+                        cx = lo[0];
+                        if (++cy > hi[1]) {
+                            cy = lo[1];
+                            if (++cz > hi[2]) {
+                                more = false;
+                                break;
+                            }
+                        }
+                    }
+                    const uint32_t h = grid_hash(cx, cy, cz, hash_size);
+                    e = starts[h];
+                    e1 = starts[h + 1];
+                }
+                if (more) {
+                    const float4 hp = hit_sorted[e++];
+                    r = __float_as_uint(hp.w);
+                    const f3 dv = vpp - mk3(hp.x, hp.y, hp.z);  // distance_squared(vp.p, p)
+                    acc = !(dot(dv, dv) > rad * rad);
+                }
+            }
+            const unsigned long long m = __ballot(acc);
+            if (m) {
+                if (acc) {
+                    const uint32_t at = (ring_head + ring_cnt + (uint32_t)__popcll(m & lt_mask)) & 127u;
+                    s_ring[wv][at] = r;
+                    s_src[wv][at] = lane;
+                }
+                ring_cnt += (uint32_t)__popcll(m);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                if (ring_cnt >= 64u) {
+                    shade(64u);
+                    ring_head = (ring_head + 64u) & 127u;
+                    ring_cnt -= 64u;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                }
+            }
+        }
+        if (ring_cnt) shade(ring_cnt);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (walk && s_m[wv][lane]) {  // ϕ and M are zero between iterations (_update_pixels! clears them)
+            px.phi[3 * i + 0] = s_phi[wv][lane][0];
+            px.phi[3 * i + 1] = s_phi[wv][lane][1];
+            px.phi[3 * i + 2] = s_phi[wv][lane][2];
+            px.M[i] = s_m[wv][lane];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
     n_reg = wave_sum(n_reg);
     if (lane_id() == 0 && n_reg) atomicAdd(&gp->registrations, n_reg);
 }
-// One wave per hot pixel: the lanes stride through each bucket, ϕ and M are reduced across the wave.
 __global__ __launch_bounds__(kBlock) void k_sppm_gather_hot(DeviceScene sc, PhotonRecords rec, VisiblePoints vp, PixelStats px, GridInfo* gp, const uint32_t* __restrict__ starts,
                                                             const float4* __restrict__ hit_sorted, uint32_t hash_size, const uint32_t* __restrict__ hot_list) {
     // One wave per hot pixel.  The distance test runs over a bucket with all 64 lanes; the photons that pass (about one in eight) are
