@@ -110,3 +110,21 @@ def test_path_first_vertex_is_kd_over_pi_cos_li(T, ob):
     want = np.float64(kd) / np.pi * cos * np.float64(inten) / d2
     assert np.allclose(L[hit], want[:, None], rtol=5e-6, atol=0)
     assert np.all(L[~hit] == 0)
+
+
+def test_bsdf_sample_f_picks_a_lobe_and_divides_the_pdf(T, ob):
+    """BSDF.sample_f (bsdf.jl:107-175) on a two-lobe BSDF: GlassMaterial without multiple lobes adds SpecularReflection(Kr,
+    FresnelDielectric(1, η)) and SpecularTransmission(Kt, 1, η) (material.jl:75-116).  component = ceil(u₁ · 2): u₁ = 0.25 samples the
+    reflection lobe, u₁ = 0.75 the transmission lobe; a specular lobe's pdf (1) is divided by the 2 matching components and f comes
+    from the chosen lobe alone.  At normal incidence Fr = ((η - 1) / (η + 1))² = 0.04 for η = 1.5; f_r = Fr · Kr / |cosθ|,
+    f_t = (1 - Fr) · Kt / |cosθ| (no η² factor: `T isa Radiance` is always false, A.11)."""
+    glass = T.GlassMaterial(T.ConstantTexture(T.RGBSpectrum(0.9)), T.ConstantTexture(T.RGBSpectrum(0.8)), T.ConstantTexture(0.0), T.ConstantTexture(0.0),
+                            T.ConstantTexture(1.5), True)
+    scene = one_triangle_scene(T, [], glass)
+    osc = ob.OracleScene.from_scene(scene)
+    r = osc.bsdf_query(0, False, 1, 31, [frame_z(), frame_z()], [[0, 0, 1, 0.25, 0.5, 0], [0, 0, 1, 0.75, 0.5, 0]])
+    assert np.allclose(r[0, :3], [0, 0, 1], atol=1e-7) and np.allclose(r[0, 3:6], 0.04 * 0.9, rtol=2e-6) and r[0, 6] == 0.5 and int(r[0, 7]) == (1 | 16)
+    assert np.allclose(r[1, :3], [0, 0, -1], atol=1e-7) and np.allclose(r[1, 3:6], 0.96 * 0.8, rtol=2e-6) and r[1, 6] == 0.5 and int(r[1, 7]) == (2 | 16)
+    # restricted to reflection there is one matching component: the pdf is not divided, whatever u₁
+    q = osc.bsdf_query(0, False, 1, 1 | 16, [frame_z()], [[0, 0, 1, 0.75, 0.5, 0]])[0]
+    assert np.allclose(q[:3], [0, 0, 1], atol=1e-7) and q[6] == 1.0 and np.allclose(q[3:6], 0.04 * 0.9, rtol=2e-6)
