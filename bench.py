@@ -1,11 +1,15 @@
 #!/usr/bin/env python
 """bench.py — the reference's headline metric on MI355X: Mray/s (all bounces, closest-hit + shadow rays) at 1024x1024,
-depth 8 (BASELINE.json), PathIntegrator on the synthetic Cornell box (configs[1]) by default.
+depth 8 (BASELINE.json), PathIntegrator on the north star's 1 M-triangle synthetic scene (S-mesh) by default.
 
-    python bench.py --gpus N --steps K --warmup W [--workload cornell|shadows|blob_870k|mesh_1m|mesh_10m|caustic|caustic_sppm] [--spp S]
+    python bench.py --gpus N --steps K --warmup W [--workload mesh_1m|blob_870k|cornell|shadows|mesh_10m|caustic|caustic_sppm]
+                    [--spp S] [--res R] [--depth D] [--scaling weak|strong]
 
-One "step" = one full render of the workload on every rank (weak scaling: each of the N ranks renders `spp` samples per
-pixel with its own sample-index range) followed, for N > 1, by the RCCL sum-reduce of the film accumulators to rank 0.
+One "step" = one full render of the workload.  N > 1 (one process per GPU, torch.distributed.run): the frame is sharded by
+global sample index and the film accumulators are sum-reduced to rank 0 by trhip_film_reduce (RCCL inside libtracehip.so).
+`--scaling weak` (default): every rank renders `spp` samples per pixel (per-GPU work fixed); `strong`: the `spp` samples of
+ONE frame are split over the ranks (BASELINE configs[4] = `--workload mesh_10m --res 4096 --spp 1024 --depth 16 --scaling strong`).
+For N > 1 the line also carries the other mode, measured right after, as `"strong_scaling"` / `"weak_scaling"`.
 Inputs (scene, BVH) are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
@@ -20,6 +24,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+KERNEL_CLASSES = ("raygen", "trace_closest", "shade", "trace_any", "film")
+TRAVERSAL_KERNEL = {1: "k_trace_closest", 2: "k_trace2", 3: "k_trace3", 4: "k_trace8", 5: "k_trace_leaf"}
+TRAVERSAL_KERNEL_ANY = {1: "k_trace_any", 2: "k_trace2", 3: "k_trace3", 4: "k_trace8", 5: "k_trace_leaf"}
 
 
 def build_workload(T, name: str, res: int):
@@ -31,25 +38,41 @@ def build_workload(T, name: str, res: int):
         return T.scenes.shadows_scene(), T.scenes.shadows_camera(res), "docs/src/shadows.md scene: 4 spheres + 4 triangles, PointLight"
     if name in T.scenes.MESH_N:
         n = T.scenes.MESH_N[name]
-        return T.scenes.mesh_scene(n), T.scenes.cornell_camera(res), f"S-mesh: Cornell box + {2 * n * n} triangle height field"
+        return T.scenes.mesh_scene(n), T.scenes.cornell_camera(res), f"S-mesh: Cornell box (10 wall triangles, mirror + glass sphere) + {2 * n * n} triangle height field"
     if name == "blob_870k":
         return T.scenes.blob_scene(270), T.scenes.cornell_camera(res), "S-blob: Cornell walls + a closed bumpy object of ~870 k triangles (stand-in for configs[2], Dragon in Cornell box)"
     if name == "caustic":
-        return T.scenes.caustic_scene(), T.scenes.caustic_camera(res), "S-caustic: procedural glass goblet (~88k triangles) on a plastic floor, SpotLight (docs/code/caustic_glass.jl)"
+        return T.scenes.caustic_scene(caustic_model()), T.scenes.caustic_camera(res), "S-caustic: docs/code/caustic_glass.jl (caustic-glass.ply, 88 064 triangles, on a plastic floor, SpotLight)"
     raise SystemExit(f"unknown workload {name}")
 
 
-def traversal_bytes(rays, nodes, prims, hit_bytes):
-    """per ray 32 B ray load + hit store (16 B closest / 1 B any) + 32 B per node visited + 48 B per primitive tested."""
-    return 32 * rays + hit_bytes * rays + 32 * nodes + 48 * prims
+def caustic_model() -> str:
+    """The reference's own mesh asset (tests/golden/caustic-glass.ply, placed there by make_caustic_ply.py); the procedural goblet if absent."""
+    p = os.path.join(ROOT, "tests", "golden", "caustic-glass.ply")
+    return p if os.path.exists(p) else ""
 
 
-KERNEL_OF = {"trace_closest": "k_trace", "trace_any": "k_trace", "shade": "k_shade_path", "film": "k_film_gather", "raygen": "k_raygen"}
+def kernel_bytes(st, film_px: int):
+    """Algorithmic bytes per kernel class for one frame, from the records the kernels touch:
+    traversal: per ray 32 B (o, d) in + 16 B hit out (any-hit: 16 B contribution in, 16 B radiance read-modify-write counted once)
+        + node_bytes per counted node + 48 B per primitive fetched; a one-leaf scene (traversal 5) reads its primitives through
+        scalar loads: ray + hit only.
+    shade: per path vertex 64 B (o, d, beta, hit) + 48 B vertices + 48 B normals read, 48 B next ray + 48 B shadow ray written = 256 B;
+    raygen: 48 B (o, d, beta) written per camera sample; film: 24 B (radiance + film position) per camera sample + 16 B per film pixel."""
+    nb = int(st.node_bytes)
+    leaf = int(st.traversal) == 5
+    return {
+        "trace_closest": st.closest_rays * 48 + (0 if leaf else st.nodes_visited * nb + st.prims_tested * 48),
+        "trace_any": st.shadow_rays * 64 + (0 if leaf else st.nodes_visited_shadow * nb + st.prims_tested_shadow * 48),
+        "shade": st.closest_rays * 256,
+        "film": st.camera_samples * 24 + film_px * 16,
+        "raygen": st.camera_samples * 48,
+    }
 
 
-def measure_traffic(args, dominant: str):
+def measure_traffic(args, kernel_prefix: str, want_any: bool):
     """HBM-side bytes per launch of the dominant kernel: FETCH_SIZE and WRITE_SIZE from two separate `rocprofv3 --pmc` child
-    runs of this same command (one step, no baseline), corrected as MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE
+    runs of this same command (one step, no baselines), corrected as MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE
     tallies 128-byte requests at 64 B: doubled; both counters are in KiB).  None when rocprofv3 is unavailable or fails."""
     import csv
     import glob
@@ -59,21 +82,21 @@ def measure_traffic(args, dominant: str):
     exe = shutil.which("rocprofv3")
     if exe is None:
         return None
-    want_any = dominant == "trace_any"
     totals = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         out = tempfile.mkdtemp(prefix="trhip_pmc_", dir="/tmp")
         cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "1", "--warmup", "0",
-               "--workload", args.workload, "--res", str(args.res), "--spp", str(args.spp), "--depth", str(args.depth), "--seed", str(args.seed), "--no-cpu-baseline", "--no-traffic"]
+               "--workload", args.workload, "--res", str(args.res), "--spp", str(args.spp), "--depth", str(args.depth), "--seed", str(args.seed), "--traversal", str(args.traversal),
+               "--no-cpu-baseline", "--no-traffic", "--no-micro", "--no-visits"]
         try:
-            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600, check=True)
+            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900, check=True)
             files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
             kb, n = 0.0, 0
             for r in csv.DictReader(open(files[0])):
                 name = r["Kernel_Name"]
-                if KERNEL_OF[dominant] not in name or r["Counter_Name"] != counter:
+                if kernel_prefix not in name or r["Counter_Name"] != counter:
                     continue
-                if dominant.startswith("trace") and (("<true" in name) != want_any):
+                if "k_trace" in kernel_prefix and kernel_prefix not in ("k_trace_closest", "k_trace_any") and (("<true" in name) != want_any):
                     continue
                 kb += float(r["Counter_Value"])
                 n += 1
@@ -87,20 +110,67 @@ def measure_traffic(args, dominant: str):
     return int(2.0 * totals["FETCH_SIZE"] + totals["WRITE_SIZE"])
 
 
-def run_sppm(args, T, ctx, graft):
-    """BASELINE.json configs[3]: docs/code/caustic_glass.jl with SPPMIntegrator (procedural goblet: the reference's PLY does not
-    travel), 1024x1024, 100 iterations, depth 8.  A step = one whole SPPMIntegrator call; rays = camera + shadow + photon rays."""
+def micro_benchmark(args, T, ctx, flat, osc):
+    """BASELINE.md §2 leg 3 / SURVEY.md §8d: 2^24 incoherent rays (origins uniform in the scene bound, directions uniform on the
+    sphere, t_max = Inf, seed 0x5EED0002) against the same BVH: closest-hit and any-hit kernels alone on device-resident rays, and
+    the CPU restatement (all host cores) on a 2^21-ray subset of the same set."""
+    import ctypes as C
+    import numpy as np
     import torch
-    scene, cam = T.scenes.caustic_scene(), T.scenes.caustic_camera(args.res)
+    n = 1 << args.micro_log2
+    bnd = flat.bvh()[0][0]
+    rays = T.scenes.incoherent_rays(n, bnd[:3], bnd[3:])
+    d_rays = torch.from_numpy(rays).cuda()
+    d_hits = torch.empty((n, 4), dtype=torch.float32, device="cuda")
+    d_occ = torch.empty(n, dtype=torch.uint8, device="cuda")
+    L = T.lib()
+    out = {"rays": n, "set": "incoherent: uniform origins in the scene bound, uniform directions, t_max = Inf, seed 0x5EED0002"}
+    ms = C.c_double()
+    for name, fn, buf in (("closest", L.trhip_trace_closest_device, d_hits), ("any", L.trhip_trace_any_device, d_occ)):
+        ctx.check(fn(ctx._h, flat._h, C.c_void_p(d_rays.data_ptr()), n, C.c_void_p(buf.data_ptr()), 1, C.byref(ms)))  # warm-up
+        ctx.check(fn(ctx._h, flat._h, C.c_void_p(d_rays.data_ptr()), n, C.c_void_p(buf.data_ptr()), 3, C.byref(ms)))
+        out[f"gpu_{name}_Mray_s"] = round(n / (ms.value * 1e-3) / 1e6, 1)
+        out[f"gpu_{name}_ms"] = round(ms.value, 3)
+    if osc is not None:
+        m = min(n, 1 << 21)
+        sub = rays[:m]
+        t1 = time.perf_counter()
+        t, prim, _, counts = osc.trace_closest(sub)
+        dt = time.perf_counter() - t1
+        out["cpu_closest_Mray_s"] = round(m / dt / 1e6, 3)
+        out["cpu_nodes_per_ray"] = round(float(counts[0]) / m, 1)
+        out["cpu_prims_per_ray"] = round(float(counts[1]) / m, 2)
+        t1 = time.perf_counter()
+        occ, _ = osc.trace_any(sub)
+        out["cpu_any_Mray_s"] = round(m / (time.perf_counter() - t1) / 1e6, 3)
+        out["cpu_rays"] = m
+        hits = d_hits[:m].cpu().numpy()
+        out["gpu_equals_cpu_on_subset"] = bool(np.array_equal(hits[:, 1].view(np.int32), prim) and np.array_equal(hits[:, 0].view(np.uint32), t.view(np.uint32))
+                                               and np.array_equal(d_occ[:m].cpu().numpy(), occ))
+    return out
+
+
+def run_sppm(args, T, ctx, graft, rank, world, comm_ok):
+    """BASELINE.json configs[3]: docs/code/caustic_glass.jl with SPPMIntegrator, 1024x1024, 100 iterations, depth 8.  A step = one whole
+    SPPMIntegrator call; rays = camera + shadow + photon rays.  N > 1: the photon pass is sharded inside the library (strong scaling)."""
+    import torch
+    import torch.distributed as dist
+    scene, cam = T.scenes.caustic_scene(caustic_model()), T.scenes.caustic_camera(args.res)
     t0 = time.time()
     flat = scene.flatten(ctx)
     t_build = time.time() - t0
     integ = T.SPPMIntegrator(cam, args.radius, args.depth, args.iterations, -1, seed=args.seed)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
     for _ in range(args.warmup):
         integ.render(scene, ctx)
-    torch.cuda.synchronize()
+    sync()
     t_start = time.perf_counter()
-    rays, ms, launches = 0, {k: 0.0 for k in ("raygen", "trace_closest", "shade", "trace_any", "film")}, {}
+    rays, ms, launches = 0, {k: 0.0 for k in KERNEL_CLASSES}, {}
     for _ in range(args.steps):
         integ.render(scene, ctx)
         st = integ.stats
@@ -108,38 +178,59 @@ def run_sppm(args, T, ctx, graft):
         for k in ms:
             ms[k] += getattr(st, "ms_" + k)
             launches[k] = launches.get(k, 0) + getattr(st, "launches_" + k)
-    torch.cuda.synchronize()
+    sync()
     elapsed = time.perf_counter() - t_start
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    cnt = torch.tensor([float(rays)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+    elapsed, rays = float(tmax.item()), float(cnt.item())
+    if rank != 0:
+        return None
     ctx.set_option("count_visits", 1)
-    integ.render(scene, ctx)
+    if world == 1:
+        integ.render(scene, ctx)
     sv = integ.stats
     ctx.set_option("count_visits", 0)
-    dom_bytes = traversal_bytes(sv.closest_rays, sv.nodes_visited, sv.prims_tested, 16) * args.steps / max(1, launches["trace_closest"])
+    kb = kernel_bytes(sv, 0)
+    dom_bytes = kb["trace_closest"] * (args.steps if world == 1 else 0) / max(1, launches["trace_closest"])
     dom_ms = ms["trace_closest"] / max(1, launches["trace_closest"])
-    achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
-    roofline = {"bound": "hbm", "kernel": "k_trace3<closest>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+    achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    kname = TRAVERSAL_KERNEL.get(int(sv.traversal), "k_trace")
+    roofline = {"bound": "hbm", "kernel": kname + "<closest>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                 "avg_launch_ms": round(dom_ms, 4), "launches": launches["trace_closest"], "algorithmic_bytes_per_launch": int(dom_bytes),
-                "visits_per_ray": {"closest_nodes": round(sv.nodes_visited / max(1, sv.closest_rays), 2), "closest_prims": round(sv.prims_tested / max(1, sv.closest_rays), 2)},
+                "visits_per_ray": {"closest_nodes": round(sv.nodes_visited / max(1, sv.closest_rays), 2), "closest_prims": round(sv.prims_tested / max(1, sv.closest_rays), 2),
+                                   "node_bytes": int(sv.node_bytes)},
                 "kernel_ms_per_step": {"raygen+photon_gen": round(ms["raygen"] / args.steps, 2), "trace_closest": round(ms["trace_closest"] / args.steps, 2),
                                        "shade+grid+gather+update": round(ms["shade"] / args.steps, 2), "trace_any": round(ms["trace_any"] / args.steps, 2), "image": round(ms["film"] / args.steps, 3)}}
+    if world == 1 and not args.no_traffic:
+        roofline["traffic"] = measure_traffic(args, kname, False)
+        if roofline["traffic"]:
+            roofline["achieved_counters"] = round(roofline["traffic"] / (dom_ms * 1e-3) / 1e9, 2)
+            roofline["frac_counters"] = round(roofline["achieved_counters"] / HBM_PEAK_GBS, 5)
     cpu = None
-    if not args.no_cpu_baseline:  # the oracle, single-threaded (its photon pass is sequential), on a bounded number of iterations
+    if world == 1 and not args.no_cpu_baseline:  # the oracle with its photon loop threaded like sppm.jl:334, on a bounded number of iterations
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         graft.build_oracle()
         import oracle_bridge as ob
         osc = ob.OracleScene.from_scene(scene, bvh=flat.bvh())
+        threads = ob.lib().orc_num_threads()
         n_it = max(1, min(args.iterations, 2))
         t1 = time.perf_counter()
-        r = osc.sppm(cam, args.radius, args.depth, n_it, -1, seed=args.seed)
+        r = osc.sppm(cam, args.radius, args.depth, n_it, -1, seed=args.seed, threads=threads)
         dt = time.perf_counter() - t1
-        cpu = {"value": round((r["stats"].closest_rays + r["stats"].shadow_rays) / dt / 1e6, 3), "unit": "Mray/s", "cores": 1, "kind": "port",
+        cpu = {"value": round((r["stats"].closest_rays + r["stats"].shadow_rays) / dt / 1e6, 3), "unit": "Mray/s", "cores": threads, "kind": "port",
                "sample": f"{n_it} of {args.iterations} iterations of the same configuration ({dt:.1f} s)"}
     info = integ.state()["info"]
-    result = {"metric": "Mray/s (all bounces)", "value": round(rays / elapsed / 1e6, 2), "unit": "Mray/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-              "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 (f64 pixel update)", "data": "synthetic",
-              "config": {"workload": f"caustic_sppm: S-caustic (procedural goblet, {flat.bvh()[3].size} primitives, SpotLight), SPPMIntegrator, {args.res}x{args.res}, "
-                                     f"{args.iterations} iterations, {info['photons_per_iteration']} photons per iteration, max depth {args.depth}, radius {args.radius}, seed {args.seed:#x}",
-                         "rays_per_step": int(rays / args.steps), "ms_per_iteration": round(elapsed / args.steps / args.iterations * 1e3, 3), "bvh_build_upload_s": round(t_build, 3)},
+    result = {"metric": "Mray/s (all bounces)", "value": round(rays / elapsed / 1e6, 2), "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+              "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
+              "dtype": "f32 (f64 pixel update)", "data": "synthetic",
+              "config": {"workload": f"caustic_sppm: docs/code/caustic_glass.jl ({'caustic-glass.ply' if caustic_model() else 'procedural goblet'}, {flat.bvh()[3].size} primitives, SpotLight), "
+                                     f"SPPMIntegrator, {args.res}x{args.res}, {args.iterations} iterations, {info['photons_per_iteration']} photons per iteration, max depth {args.depth}, "
+                                     f"radius {args.radius}, seed {args.seed:#x}",
+                         "rays_per_step": int(rays / args.steps), "ms_per_iteration": round(elapsed / args.steps / args.iterations * 1e3, 3), "bvh_build_upload_s": round(t_build, 3),
+                         "parallelism": f"photon indices sharded x{world}, one RCCL all-reduce of phi / M per iteration ({'libtracehip' if comm_ok else 'unavailable'})" if world > 1 else "single GPU"},
               "roofline": roofline, "cpu_baseline": cpu}
     print(json.dumps(result), flush=True)
     return result
@@ -150,14 +241,19 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="cornell")
+    ap.add_argument("--workload", default="mesh_1m")
     ap.add_argument("--res", type=int, default=1024)
     ap.add_argument("--spp", type=int, default=256)
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED0001)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--traversal", type=int, default=0, help="traversal kernel (0 = the library's default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-spp", type=int, default=0, help="spp of the bounded CPU-baseline sample (0 = auto)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child runs that fill roofline.traffic")
+    ap.add_argument("--no-micro", action="store_true", help="skip the 2^24-incoherent-ray traversal micro-benchmark")
+    ap.add_argument("--no-visits", action="store_true", help="skip the untimed instrumented pass (visit counts; no roofline then)")
+    ap.add_argument("--micro-log2", type=int, default=24)
     ap.add_argument("--iterations", type=int, default=100, help="caustic_sppm: SPPM iterations per step")
     ap.add_argument("--radius", type=float, default=0.075, help="caustic_sppm: initial search radius")
     args = ap.parse_args()
@@ -165,9 +261,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+    if world != args.gpus and world == 1 and args.gpus > 1:
+        raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
     import torch
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
@@ -175,105 +270,164 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     import __graft_entry__ as graft
-    if rank == 0 or not os.path.exists(os.path.join(ROOT, "trace.jl_amd", "libtracehip.so")):
-        graft.build_library()
+    if rank == 0:
+        graft.build_library()  # only rank 0 builds (the others wait at the barrier): no write race on the shared object
     if world > 1:
         dist.barrier()
     T = graft.load_package()
     ctx = T.Context(local_rank)
+    if args.traversal:
+        ctx.set_option("traversal", args.traversal)
+
+    # ---- the job's communicator, inside the library (include/tracehip.h "multi-GPU"): rank 0 makes the RCCL id, torch.distributed carries it ----
+    comm_ok = False
+    if world > 1:
+        idbuf = torch.zeros(T._ffi.UNIQUE_ID_BYTES, dtype=torch.uint8, device="cuda")
+        try:
+            if rank == 0:
+                idbuf.copy_(torch.frombuffer(bytearray(T._ffi.comm_unique_id()), dtype=torch.uint8))
+            dist.broadcast(idbuf, src=0)
+            ctx.comm_init(bytes(idbuf.cpu().numpy().tobytes()), rank, world)
+            comm_ok = True
+        except Exception as e:  # keep the bench line: fall back to torch.distributed's reduce and say so
+            sys.stderr.write(f"[bench] rank {rank}: trhip_comm_init failed ({e}); film reduce falls back to torch.distributed\n")
+        flag = torch.tensor([1 if comm_ok else 0], device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        comm_ok = bool(flag.item())
 
     if args.workload == "caustic_sppm":
-        if world != 1:
-            raise SystemExit("caustic_sppm runs on one GPU")
-        return run_sppm(args, T, ctx, graft)
+        r = run_sppm(args, T, ctx, graft, rank, world, comm_ok)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return r
     scene, cam, desc = build_workload(T, args.workload, args.res)
     t0 = time.time()
     flat = scene.flatten(ctx)  # BVH build + upload: outside the timed region
     t_build = time.time() - t0
     h, w = cam.film.size
     film = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
-    integ = T.PathIntegrator(cam, T.SeededSampler(args.spp, seed=args.seed, sample_offset=T.parallel.shard_sample_offset(rank, args.spp)), args.depth)
 
-    def step():
-        integ.render(scene, ctx, device_out=film.data_ptr())
-        if world > 1:
-            T.parallel.reduce_film(film, dst=0)  # Film pixels are additive (film.jl:161-162, 190-191)
-        return integ.stats
+    def shard(mode):
+        """(spp of this rank, first global sample index) — weak: every rank `spp`; strong: the frame's `spp` split over the ranks."""
+        if mode == "weak" or world == 1:
+            return args.spp, rank * args.spp
+        base, rem = divmod(args.spp, world)
+        return base + (1 if rank < rem else 0), rank * base + min(rank, rem)
+
+    def make_step(mode):
+        spp_r, off = shard(mode)
+        integ = T.PathIntegrator(cam, T.SeededSampler(max(1, spp_r), seed=args.seed, sample_offset=off), args.depth)
+
+        def step():
+            if spp_r > 0:
+                integ.render(scene, ctx, device_out=film.data_ptr())
+            else:
+                film.zero_()
+            if world > 1:  # Film pixels are additive (film.jl:161-162, 190-191): one sum-reduce ends the frame
+                if comm_ok:
+                    ctx.film_reduce(film.data_ptr(), h * w, 0)
+                else:
+                    T.parallel.reduce_film(film, dst=0)
+            return integ.stats
+        return step, integ
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    sync()
-    t_start = time.perf_counter()
-    agg = {"rays": 0, "samples": 0, "ms": {k: 0.0 for k in ("raygen", "trace_closest", "shade", "trace_any", "film")}, "launches": {}, "closest": 0, "shadow": 0}
-    for _ in range(args.steps):
-        st = step()
-        agg["closest"] += st.closest_rays
-        agg["shadow"] += st.shadow_rays
-        agg["samples"] += st.camera_samples
-        for k in agg["ms"]:
-            agg["ms"][k] += getattr(st, "ms_" + k)
-            agg["launches"][k] = agg["launches"].get(k, 0) + getattr(st, "launches_" + k)
-    sync()
-    elapsed = time.perf_counter() - t_start
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    counts = torch.tensor([agg["closest"] + agg["shadow"], agg["samples"]], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
-    elapsed = float(tmax.item())
-    total_rays, total_samples = float(counts[0].item()), float(counts[1].item())
+    def timed(mode, steps, warmup):
+        step, integ = make_step(mode)
+        for _ in range(warmup):
+            step()
+        sync()
+        t_start = time.perf_counter()
+        agg = {"samples": 0, "ms": {k: 0.0 for k in KERNEL_CLASSES}, "launches": {}, "closest": 0, "shadow": 0}
+        for _ in range(steps):
+            st = step()
+            agg["closest"] += st.closest_rays
+            agg["shadow"] += st.shadow_rays
+            agg["samples"] += st.camera_samples
+            for k in agg["ms"]:
+                agg["ms"][k] += getattr(st, "ms_" + k)
+                agg["launches"][k] = agg["launches"].get(k, 0) + getattr(st, "launches_" + k)
+        sync()
+        elapsed = time.perf_counter() - t_start
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        counts = torch.tensor([agg["closest"] + agg["shadow"], agg["samples"]], dtype=torch.float64, device="cuda")
+        if world > 1:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+        return float(tmax.item()), float(counts[0].item()), float(counts[1].item()), agg, integ
+
+    elapsed, total_rays, total_samples, agg, integ = timed(args.scaling, args.steps, args.warmup)
+    other = None
+    if world > 1:  # the other scaling mode, right after (fewer steps): both values in one line
+        omode = "strong" if args.scaling == "weak" else "weak"
+        osteps = max(1, min(args.steps, 5))
+        oe, orays, osamples, _, _ = timed(omode, osteps, 1)
+        other = {"scaling": omode, "value": round(orays / oe / 1e6, 2), "unit": "Mray/s", "steps": osteps, "ms_per_step": round(oe / osteps * 1e3, 3), "spp_per_gpu": shard(omode)[0],
+                 "Msample_per_s": round(osamples / oe / 1e6, 3)}
 
     result = None
     if rank == 0:
-        # ---- roofline of the dominant kernel (rank 0's launches), live HIP-event durations from the timed region ----
-        ctx.set_option("count_visits", 1)
-        integ.render(scene, ctx, device_out=film.data_ptr())  # untimed, instrumented: node / primitive visit counts
+        steps = args.steps
+        roofline = None
         sv = integ.stats
-        ctx.set_option("count_visits", 0)
-        per_step = {
-            "trace_closest": traversal_bytes(sv.closest_rays, sv.nodes_visited, sv.prims_tested, 16),
-            "trace_any": traversal_bytes(sv.shadow_rays, sv.nodes_visited_shadow, sv.prims_tested_shadow, 1),
-            "shade": 364 * sv.closest_rays,   # §8(d): ≈364 B per path vertex (ray, hit, state, geometry, material in; next ray, shadow ray, state out)
-            "film": 16 * sv.camera_samples + 16 * h * w,
-            "raygen": 80 * sv.camera_samples,
-        }
-        # the shadow rays of depth d run on a second, low-priority stream beside the closest-hit rays of depth d+1: their HIP-event
-        # time is wall time under contention, not the kernel's own — they are never the dominant kernel of these workloads (run
-        # alone: 27 ms on S-cornell, 39 ms on S-mesh) and are left out of the choice
-        dominant = max((k for k in agg["ms"] if k != "trace_any"), key=lambda k: agg["ms"][k])
-        dom_ms = agg["ms"][dominant] / max(1, agg["launches"][dominant])
-        dom_bytes = per_step[dominant] * args.steps / max(1, agg["launches"][dominant])
-        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        roofline = {"bound": "hbm", "kernel": "k_" + dominant + ("_path" if dominant == "shade" else ""), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "avg_launch_ms": round(dom_ms, 4), "launches": agg["launches"][dominant],
-                    "algorithmic_bytes_per_launch": int(dom_bytes),
-                    "visits_per_ray": {"closest_nodes": round(sv.nodes_visited / max(1, sv.closest_rays), 2), "closest_prims": round(sv.prims_tested / max(1, sv.closest_rays), 2),
-                                       "shadow_nodes": round(sv.nodes_visited_shadow / max(1, sv.shadow_rays), 2), "shadow_prims": round(sv.prims_tested_shadow / max(1, sv.shadow_rays), 2)},
-                    "kernel_ms_per_step": {k: round(v / args.steps, 3) for k, v in agg["ms"].items()},
-                    "kernel_ms_note": "HIP-event time per kernel class; trace_any runs on a second stream beside trace_closest of the next depth, so the two overlap and their sum exceeds the wall time",
-                    "kernel_GBps": {k: round(per_step[k] / (agg["ms"][k] / args.steps * 1e-3) / 1e9, 1) if agg["ms"][k] > 0 else None for k in per_step}}
-        if dominant.startswith("trace"):
-            # the compulsory-traffic lower bound beside the algorithmic figure — every ray in and its hit out, the scene once
-            bvh = flat.bvh()
-            rays_per_launch = (sv.closest_rays if dominant == "trace_closest" else sv.shadow_rays) / max(1, agg["launches"][dominant] // max(1, args.steps))
-            compulsory = rays_per_launch * (32 + (16 if dominant == "trace_closest" else 1)) + 32 * int(bvh[1].size) + 48 * int(bvh[3].size)
-            roofline["compulsory_bytes_per_launch"] = int(compulsory)
-            roofline["achieved_compulsory"] = round(compulsory / (dom_ms * 1e-3) / 1e9, 2) if dom_ms > 0 else 0.0
-        if world == 1 and not args.no_traffic:
-            roofline["traffic"] = measure_traffic(args, dominant)
-            roofline["traffic_note"] = "bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (rocprofv3 --pmc, separate child runs of this command with --steps 1; gfx950 correction)"
+        if not args.no_visits:
+            # ---- roofline of the dominant kernel (rank 0's launches): live HIP-event durations from the timed region, bytes from an
+            #      untimed instrumented pass of the same frame (node / primitive visit counts) ----
+            ctx.set_option("count_visits", 1)
+            integ.render(scene, ctx, device_out=film.data_ptr())
+            sv = integ.stats
+            ctx.set_option("count_visits", 0)
+            per_step = kernel_bytes(sv, h * w)
+            # the shadow rays of depth d run on a second, low-priority stream beside the closest-hit rays of depth d+1: their HIP-event
+            # time is wall time under contention, not the kernel's own — never the dominant kernel of these workloads; left out of the choice
+            dominant = max((k for k in agg["ms"] if k != "trace_any"), key=lambda k: agg["ms"][k])
+            dom_ms = agg["ms"][dominant] / max(1, agg["launches"][dominant])
+            dom_bytes = per_step[dominant] * steps / max(1, agg["launches"][dominant])
+            achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+            kname = {"trace_closest": TRAVERSAL_KERNEL.get(int(sv.traversal), "k_trace"), "shade": "k_shade_path", "film": "k_film_gather", "raygen": "k_raygen"}[dominant]
+            gbps = {k: round(per_step[k] / (agg["ms"][k] / steps * 1e-3) / 1e9, 1) if agg["ms"][k] > 0 else None for k in per_step}
+            roofline = {"bound": "hbm", "kernel": kname + ("<closest>" if dominant == "trace_closest" else ""), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "avg_launch_ms": round(dom_ms, 4), "launches": agg["launches"][dominant],
+                        "algorithmic_bytes_per_launch": int(dom_bytes),
+                        "frac_note": "frac = ALGORITHMIC bytes (what the kernel asks the memory system for: rays, hits, every node and primitive fetch — L2 and MALL serve part of it) "
+                                     "/ launch time / HBM peak; frac_counters = bytes that left L2 (2 x FETCH_SIZE + WRITE_SIZE) / launch time / HBM peak",
+                        "visits_per_ray": {"closest_nodes": round(sv.nodes_visited / max(1, sv.closest_rays), 2), "closest_prims": round(sv.prims_tested / max(1, sv.closest_rays), 2),
+                                           "shadow_nodes": round(sv.nodes_visited_shadow / max(1, sv.shadow_rays), 2), "shadow_prims": round(sv.prims_tested_shadow / max(1, sv.shadow_rays), 2),
+                                           "node_bytes": int(sv.node_bytes), "traversal": int(sv.traversal)},
+                        "kernel_ms_per_step": {k: round(v / steps, 3) for k, v in agg["ms"].items()},
+                        "kernel_ms_note": "HIP-event time per kernel class; trace_any runs on a second stream beside trace_closest of the next depth, so the two overlap and their sum exceeds the wall time",
+                        "kernel_GBps": gbps}
+            over = [k for k, v in gbps.items() if v is not None and v > HBM_PEAK_GBS and k != "trace_any"]
+            roofline["byte_models_within_peak"] = not over
+            if over:
+                sys.stderr.write(f"[bench] byte model exceeds the HBM peak for {over}: those bytes are not being moved\n")
+            if dominant.startswith("trace"):
+                # SURVEY.md §8(d): the compulsory-traffic lower bound beside the algorithmic figure — every ray in and its hit out, the scene once
+                bvh = flat.bvh()
+                rays_per_launch = sv.closest_rays / max(1, agg["launches"][dominant] // max(1, steps))
+                compulsory = rays_per_launch * 48 + 32 * int(bvh[1].size) + 48 * int(bvh[3].size)
+                roofline["compulsory_bytes_per_launch"] = int(compulsory)
+                roofline["achieved_compulsory"] = round(compulsory / (dom_ms * 1e-3) / 1e9, 2) if dom_ms > 0 else 0.0
+            if world == 1 and not args.no_traffic:
+                roofline["traffic"] = measure_traffic(args, kname, False)
+                roofline["traffic_note"] = "bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (rocprofv3 --pmc, separate child runs of this command with --steps 1; gfx950 correction)"
+                if roofline["traffic"]:
+                    roofline["achieved_counters"] = round(roofline["traffic"] / (dom_ms * 1e-3) / 1e9, 2)
+                    roofline["frac_counters"] = round(roofline["achieved_counters"] / HBM_PEAK_GBS, 5)
         # ---- CPU baseline: the oracle (faithful restatement, OpenMP over the reference's 16x16 tiles) on a bounded sample ----
-        cpu = None
-        if world == 1 and not args.no_cpu_baseline:
+        cpu, micro = None, None
+        osc = None
+        if world == 1 and not (args.no_cpu_baseline and args.no_micro):
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             graft.build_oracle()
             import oracle_bridge as ob
             osc = ob.OracleScene.from_scene(scene, bvh=flat.bvh())
+        if world == 1 and not args.no_cpu_baseline:
             threads = ob.lib().orc_num_threads()
             cpu_spp = args.cpu_spp
             if cpu_spp <= 0:  # calibrate on one pass, then size the sample for ~15 s
@@ -287,15 +441,24 @@ def main():
             cpu = {"value": round((cst.closest_rays + cst.shadow_rays) / dt / 1e6, 3), "unit": "Mray/s", "cores": threads, "kind": "port",
                    "sample": f"same scene, {args.res}x{args.res}, depth {args.depth}, {cpu_spp} spp of {args.spp} ({cst.camera_samples} camera samples, {dt:.1f} s)",
                    "Msample_per_s": round(cst.camera_samples / dt / 1e6, 4)}
+        if world == 1 and not args.no_micro:
+            micro = micro_benchmark(args, T, ctx, flat, osc if not args.no_cpu_baseline else None)
+        spp_r = shard(args.scaling)[0]
         result = {
             "metric": "Mray/s (all bounces)", "value": round(total_rays / elapsed / 1e6, 2), "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "Msample_per_s": round(total_samples / elapsed / 1e6, 3),
-            "config": {"workload": f"{args.workload}: {desc}; {args.res}x{args.res}, {args.spp} spp per GPU, max depth {args.depth}, PathIntegrator, seed {args.seed:#x}",
+            "config": {"workload": f"{args.workload}: {desc}; {args.res}x{args.res}, {spp_r} spp per GPU" + (f" ({args.spp} per frame)" if args.scaling == "strong" and world > 1 else "")
+                                   + f", max depth {args.depth}, PathIntegrator, seed {args.seed:#x}",
                        "rays_per_step": int(total_rays / args.steps), "samples_per_step": int(total_samples / args.steps), "bvh_build_upload_s": round(t_build, 3),
-                       "parallelism": f"sample-index sharding x{world} + RCCL film sum-reduce" if world > 1 else "single GPU"},
+                       "traversal": int(sv.traversal),
+                       "parallelism": (f"sample-index sharding x{world} + film sum-reduce over RCCL ({'trhip_film_reduce' if comm_ok else 'torch.distributed fallback'})") if world > 1 else "single GPU"},
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        if micro:
+            result["traversal_micro"] = micro
+        if other:
+            result[other["scaling"] + "_scaling"] = other
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

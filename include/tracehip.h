@@ -9,7 +9,8 @@
  * Conventions: every function returns 0 on success and a negative trhip_status on failure; the message is available
  * from trhip_last_error().  Nothing throws across the boundary.  Host pointers are caller-owned and only borrowed for
  * the duration of the call.  Calls are blocking (internal HIP streams are synchronised before returning).  One
- * trhip_ctx owns one GPU; use one process per GPU (multi-GPU film reduction is done by the host over RCCL).
+ * trhip_ctx owns one GPU; use one process per GPU.  Several processes form one job through trhip_comm_init (RCCL over xGMI):
+ * trhip_film_reduce sums the per-rank film accumulators, trhip_render_sppm shards its photons (multi-GPU section below).
  * Matrices are 16 floats, row-major: m[4*row + col] (Julia's Mat4f is column-major: pass transpose / permutedims).
  * All arithmetic is IEEE Float32 without FMA contraction; transcendental functions and the sampler are the ones
  * specified in trace_detmath.h / trace_sampler.h, so results are reproducible bit-for-bit on any conforming host.
@@ -123,6 +124,9 @@ typedef struct {
     double ms_raygen, ms_trace_closest, ms_shade, ms_trace_any, ms_film;
     uint32_t launches_raygen, launches_trace_closest, launches_shade, launches_trace_any, launches_film;
     uint32_t n_batches, max_depth_reached;
+    uint32_t traversal;      /* traversal kernel that ran: 1 literal, 2, 3 binary children-in-parent walk, 4 8-wide nodes, 5 one-leaf scene */
+    uint32_t node_bytes;     /* bytes fetched per unit of nodes_visited: 32 (a node box of the binary kernels: 64-byte node = 2 boxes),
+                                96 (one 8-wide node: six 16-byte loads from one 128-byte line), 0 (one-leaf scene: scalar loads) */
 } trhip_stats;
 
 /* ---- integrators (replace `integrator(scene)`, integrators/sampler.jl:12-56) ---------------------------------------
@@ -202,12 +206,37 @@ int trhip_bsdf_query(trhip_ctx* ctx, const trhip_scene* scene, uint32_t material
 int trhip_film_accumulate(trhip_ctx* ctx, const trhip_sensor* sensor, uint32_t spp, uint64_t seed, uint32_t sample_offset, const float* sample_L,
                           float* out_xyzw);
 
+/* ---- multi-GPU: one process per GPU, RCCL over xGMI -----------------------------------------------------
+ * The scene is replicated; samples are independent.  A frame is sharded by global sample index (`sample_offset`: rank r of N
+ * renders indices [r*spp_r, (r+1)*spp_r) of every pixel) into a private film; Film pixels are additive (xyz sums and
+ * filter_weight_sum, film.jl:161-162, 190-191 — what merge_film_tile! relies on, film.jl:182-193), so ONE collective ends the frame.
+ * The reference's only parallelism is Threads.@threads over tiles (integrators/sampler.jl:24) and photons (integrators/sppm.jl:334).
+ *
+ * trhip_comm_unique_id: rank 0 creates the 128-byte RCCL id (ncclGetUniqueId) and hands it to the other processes by any means
+ *     (a file, MPI, torch.distributed's store ...).  trhip_comm_init: ncclCommInitRank on the context's GPU (collective: every
+ *     rank calls it).  n_ranks == 1 is allowed (the collectives become copies).  RCCL is dlopen'ed on first use.
+ * trhip_film_reduce: in-place ncclReduce(sum) of n_pixels x 4 floats (a device pointer, e.g. what trhip_render_path_device wrote)
+ *     onto `root`; blocking.  trhip_film_allreduce: the same with every rank receiving the sum.
+ * With a communicator, trhip_render_sppm shards the photon pass (rank r traces photon indices [r*P/N, (r+1)*P/N) of every
+ *     iteration, sppm.jl:334) and all-reduces the per-pixel ϕ and M (sppm.jl:398-399) before _update_pixels! (sppm.jl:438-459):
+ *     one exchange per iteration; every rank ends with the whole image.  The camera pass is replicated (1 path per pixel). */
+#define TRHIP_UNIQUE_ID_BYTES 128
+int trhip_comm_unique_id(uint8_t* out_id128);
+int trhip_comm_init(trhip_ctx* ctx, const uint8_t* id128, int rank, int n_ranks);
+int trhip_comm_destroy(trhip_ctx* ctx);
+int trhip_comm_rank(const trhip_ctx* ctx, int* rank, int* n_ranks); /* 0 / 1 without a communicator */
+int trhip_film_reduce(trhip_ctx* ctx, void* d_xyzw, uint64_t n_pixels, int root);
+int trhip_film_allreduce(trhip_ctx* ctx, void* d_xyzw, uint64_t n_pixels);
+
 /* ---- options ------------------------------------------------------------------------------------------------------- */
 /* "count_visits" (0/1): instrumented traversal kernels fill nodes_visited / prims_tested.
  * "batch_paths": paths in flight per wavefront batch (0 = size from free HBM, the default).
  * "timing" (0/1): per-kernel HIP-event timing in trhip_stats (default 1).
- * "traversal" (1/2/3): 1 = literal accel/bvh.jl loop, 2 = children-in-parent nodes with per-lane ray replacement,
- *     3 = 2 with the leaves of a wave postponed and tested together (default).  Same results bit for bit.
+ * "traversal" (1/2/3/4): 1 = literal accel/bvh.jl loop, 2 = children-in-parent nodes with per-lane ray replacement,
+ *     3 = 2 with the leaves of a wave postponed and tested together, 4 (default) = 8-wide nodes with quantised child boxes
+ *     walked in the binary tree's depth-first order (th_trace8.h); scenes 4 cannot take (foreign trees whose boxes do not nest,
+ *     leaves of several primitives, more than 8 spheres) and rays it cannot take (a zero direction component) run 3.
+ *     Same results bit for bit.
  * "overlap" (0/1): shadow rays of depth d on a second stream beside the closest-hit pass of depth d+1 (default 1).
  *     "stream2_priority" (-1/0/1): that stream's priority: lowest (default: the closest-hit rays are the critical path), the
  *     default level, highest; read when the streams are created (first render of a context).

@@ -698,9 +698,22 @@ void orc_detmath_f64(int fn, const double* x, uint64_t n, double* out) {
 // image: (height, width, 3) = _sppm_to_image after the last iteration.  Optional state dumps, all (height, width[, 3]):
 // Ld, tau, radius, N (double), and from the last iteration before _update_pixels!: M (int64), phi, vp_p, vp_beta.
 // info[0..5] = grid resolution xyz, grid entries, photon hits inside the grid (all iterations), photons per iteration.
+// orc_sppm_ex: threads = OpenMP threads for the camera pass (tiles) and the photon pass (photons), as the reference's
+// Threads.@threads (sppm.jl:184, 334) — ϕ then depends on the order of the atomic adds, like the reference's; [photon_begin,
+// photon_end) + exchange(user, phi3, M, n_pixels): this process's photon slice and the per-iteration sum over processes.
+typedef void (*orc_exchange_fn)(void* user, float* phi3, int64_t* M, uint64_t n_pixels);
+int orc_sppm_ex(void* sp, const orc_sensor* sn, float initial_radius, int max_depth, int64_t n_iterations, int64_t photons_per_iteration, uint64_t seed, int threads,
+                int64_t photon_begin, int64_t photon_end, orc_exchange_fn exchange, void* exchange_user, float* image, float* out_Ld, float* out_tau, float* out_radius, double* out_N,
+                int64_t* out_M, float* out_phi, float* out_vp_p, float* out_vp_beta, int64_t* info, orc_stats* stats);
 int orc_sppm(void* sp, const orc_sensor* sn, float initial_radius, int max_depth, int64_t n_iterations, int64_t photons_per_iteration, uint64_t seed, float* image,
              float* out_Ld, float* out_tau, float* out_radius, double* out_N, int64_t* out_M, float* out_phi, float* out_vp_p, float* out_vp_beta, int64_t* info,
              orc_stats* stats) {
+    return orc_sppm_ex(sp, sn, initial_radius, max_depth, n_iterations, photons_per_iteration, seed, 1, 0, -1, nullptr, nullptr, image, out_Ld, out_tau, out_radius, out_N, out_M, out_phi,
+                       out_vp_p, out_vp_beta, info, stats);
+}
+int orc_sppm_ex(void* sp, const orc_sensor* sn, float initial_radius, int max_depth, int64_t n_iterations, int64_t photons_per_iteration, uint64_t seed, int threads,
+                int64_t photon_begin, int64_t photon_end, orc_exchange_fn exchange, void* exchange_user, float* image, float* out_Ld, float* out_tau, float* out_radius, double* out_N,
+                int64_t* out_M, float* out_phi, float* out_vp_p, float* out_vp_beta, int64_t* info, orc_stats* stats) {
     OrcScene* s = (OrcScene*)sp;
     if (!s->committed) {
         g_err = "scene not committed";
@@ -714,6 +727,11 @@ int orc_sppm(void* sp, const orc_sensor* sn, float initial_radius, int max_depth
     prm.n_iterations = n_iterations;
     prm.photons_per_iteration = photons_per_iteration;
     prm.seed = seed;
+    prm.threads = threads > 0 ? threads : 1;
+    prm.photon_begin = photon_begin;
+    prm.photon_end = photon_end;
+    prm.exchange = exchange;
+    prm.exchange_user = exchange_user;
     SPPMState st;
     if (!sppm_render(s->scene, cam, film, prm, st, image)) {
         g_err = "SPPM needs a film whose crop starts at pixel (1, 1) (sppm.jl:203 indexes pixels[y, x] with raster coordinates)";
@@ -739,10 +757,10 @@ int orc_sppm(void* sp, const orc_sensor* sn, float initial_radius, int max_depth
     }
     if (stats) {
         stats->camera_samples = (uint64_t)n * (uint64_t)n_iterations;
-        stats->closest_rays = counters().closest;
-        stats->shadow_rays = counters().shadow;
-        stats->nodes_visited = counters().nodes;
-        stats->prims_tested = counters().prims;
+        stats->closest_rays = st.totals.closest;
+        stats->shadow_rays = st.totals.shadow;
+        stats->nodes_visited = st.totals.nodes;
+        stats->prims_tested = st.totals.prims;
     }
     return 0;
 }

@@ -178,6 +178,15 @@ struct SPPMParams {
     int64_t n_iterations = 1;
     int64_t photons_per_iteration = -1;  // <= 0: area(crop_bounds) (sppm.jl:121-124, the non-inclusive area of bounds.jl:87-90)
     uint64_t seed = 0;
+    // How the reference spreads the work (Threads.@threads over tiles, sppm.jl:184, and over photons, sppm.jl:334, with
+    // Threads.Atomic adds for ϕ and M, :398-399).  threads == 1 (the parity tests): the sequential order.
+    int threads = 1;
+    // Multi-process jobs (tests/test_sharding_gloo.py): this process traces photon indices [photon_begin, photon_end) of every
+    // iteration (photon_end < 0: all) and `exchange`, if set, is called between the photon pass and _update_pixels! with the
+    // per-pixel ϕ (3 floats each) and M to be summed over the processes in place.
+    int64_t photon_begin = 0, photon_end = -1;
+    void (*exchange)(void* user, float* phi3, int64_t* M, uint64_t n_pixels) = nullptr;
+    void* exchange_user = nullptr;
 };
 struct SPPMState {
     int width = 0, height = 0;     // inclusive sides of crop_bounds
@@ -191,6 +200,7 @@ struct SPPMState {
     int64_t grid_res[3] = {1, 1, 1};
     bool grid_valid = false;
     uint64_t photon_hits = 0, grid_entries = 0;
+    Counters totals;  // rays / visits of all threads
     SPPMPixel& at(int x1, int y1) { return pixels[(size_t)(y1 - 1) * width + (size_t)(x1 - 1)]; }  // pixels[y, x], 1-based
 };
 
@@ -201,6 +211,10 @@ inline void sppm_camera_pass(Scene& scene, const PerspectiveCamera& cam, const F
     const V2 extent{pb.p_max.x - pb.p_min.x, pb.p_max.y - pb.p_min.y};
     const long long width = (long long)std::floor((extent.x + tile_size) / tile_size), height = (long long)std::floor((extent.y + tile_size) / tile_size);
     const long long total_tiles = width * height - 1;
+#pragma omp parallel num_threads(prm.threads > 0 ? prm.threads : 1)
+    {
+    counters() = Counters{};
+#pragma omp for schedule(dynamic, 1)
     for (long long k = 0; k <= total_tiles; ++k) {
         const float tx = (float)(k % width), ty = (float)(k / width);
         SeededSampler smp(1, prm.seed, (uint32_t)(iteration - 1));  // deepcopy(sampler): UniformSampler(1)
@@ -259,6 +273,11 @@ inline void sppm_camera_pass(Scene& scene, const PerspectiveCamera& cam, const F
                     depth += 1;
                 }
             }
+    }
+#pragma omp critical(orc_sppm_totals)
+    {
+        st.totals.closest += counters().closest, st.totals.shadow += counters().shadow, st.totals.nodes += counters().nodes, st.totals.prims += counters().prims;
+    }
     }
 }
 
@@ -320,7 +339,13 @@ inline void sppm_populate_grid(SPPMState& st, SPPMGrid& grid, uint64_t n_pixels)
 inline void sppm_trace_photons(Scene& scene, const SPPMParams& prm, SPPMState& st, const SPPMGrid& grid, const Distribution1D& light_distr, int64_t iteration,
                                uint64_t n_pixels) {
     const uint64_t halton_base = (uint64_t)(iteration - 1) * (uint64_t)st.photons_per_iteration;
-    for (int64_t photon_index = 0; photon_index < st.photons_per_iteration; ++photon_index) {
+    const int64_t p_begin = prm.photon_end < 0 ? 0 : prm.photon_begin, p_end = prm.photon_end < 0 ? st.photons_per_iteration : (prm.photon_end < st.photons_per_iteration ? prm.photon_end : st.photons_per_iteration);
+    uint64_t hits_total = 0;
+#pragma omp parallel num_threads(prm.threads > 0 ? prm.threads : 1) reduction(+ : hits_total)
+    {
+    counters() = Counters{};
+#pragma omp for schedule(dynamic, 64)
+    for (int64_t photon_index = p_begin; photon_index < p_end; ++photon_index) {
         const uint64_t hi = halton_base + (uint64_t)photon_index;
         int64_t dim = 0;
         const float light_sample = radical_inverse(dim, hi);
@@ -342,15 +367,19 @@ inline void sppm_trace_photons(Scene& scene, const SPPMParams& prm, SPPMState& s
             if (depth > 1 && st.grid_valid) {
                 const GridPoint gp = to_grid(si.p, st.grid_bounds, st.grid_res);
                 if (gp.in_bounds) {
-                    st.photon_hits++;
+                    hits_total++;
                     const uint64_t h = grid_hash(gp.g[0], gp.g[1], gp.g[2], n_pixels);
                     for (int64_t node = grid.head[(size_t)h]; node >= 0; node = grid.next[(size_t)node]) {
                         SPPMPixel& px = st.pixels[grid.node_pixel[(size_t)node]];
                         if (distance_squared(px.vp.p, si.p) > px.radius * px.radius) continue;
                         const RGB phi = beta * px.vp.bsdf.f(px.vp.wo, -photon_ray.d);  // β is the emission weight: never updated (A.13)
-                        px.phi[0] += phi.x;
+#pragma omp atomic
+                        px.phi[0] += phi.x;  // Threads.Atomic{Float32} adds, sppm.jl:398
+#pragma omp atomic
                         px.phi[1] += phi.y;
+#pragma omp atomic
                         px.phi[2] += phi.z;
+#pragma omp atomic
                         px.M += 1;
                     }
                 }
@@ -373,6 +402,12 @@ inline void sppm_trace_photons(Scene& scene, const SPPMParams& prm, SPPMState& s
             depth += 1;
         }
     }
+#pragma omp critical(orc_sppm_totals)
+    {
+        st.totals.closest += counters().closest, st.totals.shadow += counters().shadow, st.totals.nodes += counters().nodes, st.totals.prims += counters().prims;
+    }
+    }
+    st.photon_hits += hits_total;
 }
 
 // sppm.jl:438-459
@@ -423,11 +458,27 @@ inline bool sppm_render(Scene& scene, const PerspectiveCamera& cam, const Film& 
     const float gamma = 2.0f / 3.0f;
     const Distribution1D light_distr = compute_light_power_distribution(scene);
     SPPMGrid grid;
-    counters() = Counters{};
+    st.totals = Counters{};
+    std::vector<float> x_phi;
+    std::vector<int64_t> x_M;
     for (int64_t it = 1; it <= prm.n_iterations; ++it) {
         sppm_camera_pass(scene, cam, film, prm, st, it);
         sppm_populate_grid(st, grid, n_pixels);
         if (!scene.lights.empty()) sppm_trace_photons(scene, prm, st, grid, light_distr, it, n_pixels);
+        if (prm.exchange) {  // multi-process job: ϕ and M summed over the processes before _update_pixels!
+            const size_t n = st.pixels.size();
+            x_phi.resize(3 * n);
+            x_M.resize(n);
+            for (size_t i = 0; i < n; ++i) {
+                for (int c = 0; c < 3; ++c) x_phi[3 * i + c] = st.pixels[i].phi[c];
+                x_M[i] = st.pixels[i].M;
+            }
+            prm.exchange(prm.exchange_user, x_phi.data(), x_M.data(), (uint64_t)n);
+            for (size_t i = 0; i < n; ++i) {
+                for (int c = 0; c < 3; ++c) st.pixels[i].phi[c] = x_phi[3 * i + c];
+                st.pixels[i].M = x_M[i];
+            }
+        }
         if (it == prm.n_iterations) {
             const size_t n = st.pixels.size();
             st.last_M.resize(n);

@@ -32,6 +32,10 @@ class OrcStats(C.Structure):
 _lib = None
 
 
+# exchange(user, phi3, M, n_pixels): sum the per-pixel ϕ / M of a sharded SPPM photon pass over the processes, in place
+EXCHANGE_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int64), C.c_uint64)
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -62,6 +66,8 @@ def lib():
             "orc_render": (C.c_int, [_VP, C.POINTER(OrcSensor), C.c_int, C.c_int64, C.c_int, C.c_uint64, C.c_uint32, C.c_int, _F, _F, C.POINTER(OrcStats)]),
             "orc_sppm": (C.c_int, [_VP, C.POINTER(OrcSensor), C.c_float, C.c_int, C.c_int64, C.c_int64, C.c_uint64, _F, _F, _F, _F, C.POINTER(C.c_double),
                                    C.POINTER(C.c_int64), _F, _F, _F, C.POINTER(C.c_int64), C.POINTER(OrcStats)]),
+            "orc_sppm_ex": (C.c_int, [_VP, C.POINTER(OrcSensor), C.c_float, C.c_int, C.c_int64, C.c_int64, C.c_uint64, C.c_int, C.c_int64, C.c_int64, EXCHANGE_FN, _VP, _F, _F, _F, _F,
+                                      C.POINTER(C.c_double), C.POINTER(C.c_int64), _F, _F, _F, C.POINTER(C.c_int64), C.POINTER(OrcStats)]),
             "orc_radical_inverse": (C.c_float, [C.c_int64, C.c_uint64]),
             "orc_grid_hash": (C.c_uint64, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64]),
             "orc_distribution1d": (C.c_float, [_F, C.c_int, _F]),
@@ -296,9 +302,12 @@ class OracleScene:
             raise RuntimeError(lib().orc_last_error().decode())
         return xyzw, L, st
 
-    def sppm(self, cam, initial_radius: float, max_depth: int, n_iterations: int, photons_per_iteration: int = -1, seed: int = 0, sensor=None):
+    def sppm(self, cam, initial_radius: float, max_depth: int, n_iterations: int, photons_per_iteration: int = -1, seed: int = 0, sensor=None, threads: int = 1,
+             photon_range=None, exchange=None):
         """SPPMIntegrator (oracle/orc_sppm.h).  Returns a dict: image (h, w, 3), Ld, tau, radius, N, and the last
-        iteration's M / phi / vp_p / vp_beta (before _update_pixels!), info, stats."""
+        iteration's M / phi / vp_p / vp_beta (before _update_pixels!), info, stats.
+        threads: OpenMP threads over tiles / photons like Threads.@threads (sppm.jl:184, 334); photon_range = (begin, end): the photon
+        indices this process traces in every iteration; exchange(phi (n, 3) float32, M (n,) int64): sums them over the processes in place."""
         sn = sensor or make_sensor(cam)
         h, w = cam.film.size
         out = {"image": np.empty((h, w, 3), np.float32), "Ld": np.empty((h, w, 3), np.float32), "tau": np.empty((h, w, 3), np.float32),
@@ -307,7 +316,13 @@ class OracleScene:
         info = np.zeros(6, np.int64)
         st = OrcStats()
         i64 = C.POINTER(C.c_int64)
-        rc = lib().orc_sppm(self.h, C.byref(sn), float(initial_radius), max_depth, n_iterations, photons_per_iteration, seed, fp(out["image"]), fp(out["Ld"]), fp(out["tau"]),
+        cb = EXCHANGE_FN()
+        if exchange is not None:
+            def _cb(_user, phi_p, m_p, n):
+                exchange(np.ctypeslib.as_array(phi_p, shape=(int(n), 3)), np.ctypeslib.as_array(m_p, shape=(int(n),)))
+            cb = EXCHANGE_FN(_cb)
+        pb, pe = (0, -1) if photon_range is None else (int(photon_range[0]), int(photon_range[1]))
+        rc = lib().orc_sppm_ex(self.h, C.byref(sn), float(initial_radius), max_depth, n_iterations, photons_per_iteration, seed, int(threads), pb, pe, cb, None, fp(out["image"]), fp(out["Ld"]), fp(out["tau"]),
                             fp(out["radius"]), out["N"].ctypes.data_as(C.POINTER(C.c_double)), out["M"].ctypes.data_as(i64), fp(out["phi"]), fp(out["vp_p"]), fp(out["vp_beta"]),
                             info.ctypes.data_as(i64), C.byref(st))
         if rc:

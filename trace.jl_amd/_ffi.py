@@ -58,10 +58,24 @@ class Stats(C.Structure):
         ("launches_film", C.c_uint32),
         ("n_batches", C.c_uint32),
         ("max_depth_reached", C.c_uint32),
+        ("traversal", C.c_uint32),
+        ("node_bytes", C.c_uint32),
     ]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+UNIQUE_ID_BYTES = 128  # TRHIP_UNIQUE_ID_BYTES
+
+
+def comm_unique_id() -> bytes:
+    """ncclGetUniqueId through the library: rank 0 calls this and hands the 128 bytes to the other processes."""
+    buf = (C.c_uint8 * UNIQUE_ID_BYTES)()
+    rc = lib().trhip_comm_unique_id(buf)
+    if rc:
+        raise TraceHipError(f"trhip_comm_unique_id failed ({rc}): {lib().trhip_last_error(None).decode()}")
+    return bytes(buf)
 
 
 HIT_DTYPE = np.dtype([("t", np.float32), ("prim", np.int32), ("b1", np.float32), ("b2", np.float32)])
@@ -107,6 +121,12 @@ SIGNATURES = {
     "trhip_bsdf_query": (C.c_int, [_VP, _VP, C.c_uint32, C.c_int, C.c_int, C.c_int, _F, _F, C.c_uint64, _F]),
     "trhip_film_accumulate": (C.c_int, [_VP, C.POINTER(Sensor), C.c_uint32, C.c_uint64, C.c_uint32, _F, _F]),
     "trhip_set_option": (C.c_int, [_VP, C.c_char_p, C.c_int64]),
+    "trhip_comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
+    "trhip_comm_init": (C.c_int, [_VP, C.POINTER(C.c_uint8), C.c_int, C.c_int]),
+    "trhip_comm_destroy": (C.c_int, [_VP]),
+    "trhip_comm_rank": (C.c_int, [_VP, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "trhip_film_reduce": (C.c_int, [_VP, _VP, C.c_uint64, C.c_int]),
+    "trhip_film_allreduce": (C.c_int, [_VP, _VP, C.c_uint64]),
     "trhip_detmath_f32": (C.c_int, [C.c_int, _F, _F, C.c_uint64, _F]),
 }
 
@@ -169,6 +189,26 @@ class Context:
 
     def set_option(self, name: str, value: int):
         self.check(lib().trhip_set_option(self._h, name.encode(), int(value)))
+
+    # ---- multi-GPU job (include/tracehip.h "multi-GPU"): one process per GPU, RCCL behind the C ABI -------------------
+    def comm_init(self, unique_id: bytes, rank: int, n_ranks: int):
+        buf = (C.c_uint8 * UNIQUE_ID_BYTES).from_buffer_copy(bytes(unique_id))
+        self.check(lib().trhip_comm_init(self._h, buf, int(rank), int(n_ranks)))
+
+    def comm_destroy(self):
+        self.check(lib().trhip_comm_destroy(self._h))
+
+    def comm_rank(self):
+        r, n = C.c_int(), C.c_int()
+        self.check(lib().trhip_comm_rank(self._h, C.byref(r), C.byref(n)))
+        return r.value, n.value
+
+    def film_reduce(self, device_ptr: int, n_pixels: int, root: int = 0):
+        """In-place sum of the (H, W, 4) film accumulators of all ranks onto `root` (ncclReduce inside the library)."""
+        self.check(lib().trhip_film_reduce(self._h, C.c_void_p(int(device_ptr)), int(n_pixels), int(root)))
+
+    def film_allreduce(self, device_ptr: int, n_pixels: int):
+        self.check(lib().trhip_film_allreduce(self._h, C.c_void_p(int(device_ptr)), int(n_pixels)))
 
     def close(self):
         if self._h:

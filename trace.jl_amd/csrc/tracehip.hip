@@ -17,6 +17,7 @@
 #include "th_whitted.h"
 #include "th_sppm.h"
 #include "th_lbvh.h"
+#include "th_comm.h"
 
 using namespace th;
 
@@ -84,6 +85,7 @@ struct trhip_ctx {
     uint64_t sppm_batch = 0;  // SPPM iterations per wavefront batch (0 = from free HBM, at most 128)
     uint32_t sp_pixels = 0;
     int64_t sp_photons = 0;
+    Comm comm;  // multi-GPU job this context belongs to (trhip_comm_init); n_ranks == 1 without one
 };
 
 struct HostPrim {
@@ -110,6 +112,8 @@ struct trhip_scene {
     uint32_t n_occluders = 0;     // the scene's largest triangles, tested first by any-hit rays (th_trace2.h, k_any_occluders)
     bool partial_spheres = false;  // some sphere is clipped (z range or ϕ_max): traversal kernels with the general sphere test
     bool wide_ok = false;
+    bool w8_ok = false;            // the 8-wide view exists (th_trace8.h)
+    bool literal_only = false;     // a caller-supplied BVH whose boxes do not nest (trhip_scene_set_bvh): literal kernels only
 };
 
 namespace {
@@ -359,7 +363,7 @@ int upload_scene(trhip_scene* s) {
     s->wide_ok = false;
     std::memset(&s->wide, 0, sizeof s->wide);
     s->wide.root_ref = kRefNone;
-    if (n_nodes > 0 && n_prims < (1u << 24)) {
+    if (n_nodes > 0 && n_prims < (1u << 24) && !s->literal_only) {
         std::vector<uint32_t> widx(n_nodes, 0);
         uint32_t n_int = 0;
         for (uint32_t i = 0; i < n_nodes; ++i)
@@ -564,6 +568,26 @@ WideScene wide_view(const trhip_ctx* ctx, const trhip_scene* sc) {
     WideScene w = sc->wide;
     w.tight_scale = ctx->slab_margin_log2 > 0 ? std::ldexp(1.0f, -ctx->slab_margin_log2) : 0.0f;
     return w;
+}
+
+// which kernel launch_trace picks for this scene, and the bytes one unit of the visit counters stands for (trhip_stats)
+void traversal_info(const trhip_ctx* ctx, const trhip_scene* sc, uint32_t* trav, uint32_t* node_bytes) {
+    uint32_t t = 1, nb = 32;
+    if (ctx->traversal >= 2 && sc->wide_ok) {
+        if (sc->wide.root_cnt > 0 && ctx->leaf_kernel && ctx->debug_trace_budget == 0) {
+            t = 5;
+            nb = 0;
+        } else if (sc->wide.root_cnt > 0) {
+            t = 2;
+        } else if (ctx->traversal >= 4 && sc->w8_ok) {
+            t = 4;
+            nb = 96;
+        } else {
+            t = ctx->traversal >= 3 ? 3 : 2;
+        }
+    }
+    *trav = t;
+    *node_bytes = nb;
 }
 
 // One traversal launch over a queue (count in HBM at count_ptr, or n_max when count_ptr is null).
@@ -1058,6 +1082,7 @@ int render_stream_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sen
         stats->ms_film = tm.total(4, &stats->launches_film);
         stats->n_batches = 1;
         stats->max_depth_reached = (uint32_t)max_depth;
+        traversal_info(ctx, scene, &stats->traversal, &stats->node_bytes);
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
@@ -1113,6 +1138,7 @@ int render_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sensor* se
             stats->prims_tested_shadow = h.prims_shadow;
             stats->ms_total = ms;
             stats->max_depth_reached = (uint32_t)max_depth;
+        traversal_info(ctx, scene, &stats->traversal, &stats->node_bytes);
         }
         return 0;
     }
@@ -1278,6 +1304,7 @@ int render_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sensor* se
         stats->ms_film = tm.total(4, &stats->launches_film);
         stats->n_batches = n_batches;
         stats->max_depth_reached = (uint32_t)max_depth;
+        traversal_info(ctx, scene, &stats->traversal, &stats->node_bytes);
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
@@ -1551,6 +1578,7 @@ int render_sppm_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
         stats->ms_film = tm.total(4, &stats->launches_film);
         stats->n_batches = n_batches;
         stats->max_depth_reached = (uint32_t)max_depth;
+        traversal_info(ctx, scene, &stats->traversal, &stats->node_bytes);
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
@@ -1562,7 +1590,7 @@ int render_sppm_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
 // ---- C ABI ------------------------------------------------------------------------------------------------------------------------
 extern "C" {
 
-int trhip_version(void) { return 1000; }
+int trhip_version(void) { return 2000; }
 
 int trhip_init(trhip_ctx** out, int device_id) {
     if (!out) return fail(nullptr, TRHIP_ERR_INVALID, "ctx out pointer is null");
@@ -1587,6 +1615,7 @@ int trhip_init(trhip_ctx** out, int device_id) {
 void trhip_shutdown(trhip_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    if (ctx->comm.comm) (void)rccl_api()->CommDestroy(ctx->comm.comm);
     for (auto& a : ctx->q)
         for (auto& b : a) release(b);
     for (auto& b : ctx->sq) release(b);
@@ -1641,6 +1670,73 @@ void trhip_shutdown(trhip_ctx* ctx) {
 }
 const char* trhip_last_error(const trhip_ctx* ctx) { return ctx ? ctx->err.c_str() : g_init_error.c_str(); }
 
+// ---- multi-GPU: RCCL over xGMI, one process per GPU (th_comm.h) ---------------------------------------------------------------------
+#define NCCL_TRY(ctx, expr)                                                                                                  \
+    do {                                                                                                                     \
+        ncclResult_t r_ = (expr);                                                                                            \
+        if (r_ != ncclSuccess) return fail(ctx, TRHIP_ERR_HIP, "%s failed: %s", #expr, rccl_api()->GetErrorString ? rccl_api()->GetErrorString(r_) : "RCCL error"); \
+    } while (0)
+
+int trhip_comm_unique_id(uint8_t* out_id128) {
+    if (!out_id128) return fail(nullptr, TRHIP_ERR_INVALID, "null argument");
+    static_assert(sizeof(ncclUniqueId) == TRHIP_UNIQUE_ID_BYTES, "ncclUniqueId size");
+    RcclApi* api = rccl_api();
+    if (!api->error.empty()) return fail(nullptr, TRHIP_ERR_UNSUPPORTED, "%s", api->error.c_str());
+    ncclUniqueId id;
+    NCCL_TRY(nullptr, api->GetUniqueId(&id));
+    std::memcpy(out_id128, &id, sizeof id);
+    return 0;
+}
+int trhip_comm_init(trhip_ctx* ctx, const uint8_t* id128, int rank, int n_ranks) {
+    if (!ctx || !id128) return fail(ctx, TRHIP_ERR_INVALID, "null argument");
+    if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(ctx, TRHIP_ERR_INVALID, "rank %d of %d", rank, n_ranks);
+    if (ctx->comm.comm) return fail(ctx, TRHIP_ERR_INVALID, "the context already has a communicator (trhip_comm_destroy first)");
+    RcclApi* api = rccl_api();
+    if (!api->error.empty()) return fail(ctx, TRHIP_ERR_UNSUPPORTED, "%s", api->error.c_str());
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof id);
+    NCCL_TRY(ctx, api->CommInitRank(&ctx->comm.comm, n_ranks, id, rank));
+    ctx->comm.rank = rank;
+    ctx->comm.n_ranks = n_ranks;
+    return 0;
+}
+int trhip_comm_destroy(trhip_ctx* ctx) {
+    if (!ctx) return fail(ctx, TRHIP_ERR_INVALID, "null argument");
+    if (ctx->comm.comm) {
+        (void)hipSetDevice(ctx->device);
+        NCCL_TRY(ctx, rccl_api()->CommDestroy(ctx->comm.comm));
+    }
+    ctx->comm = Comm{};
+    return 0;
+}
+int trhip_comm_rank(const trhip_ctx* ctx, int* rank, int* n_ranks) {
+    if (!ctx) return TRHIP_ERR_INVALID;
+    if (rank) *rank = ctx->comm.rank;
+    if (n_ranks) *n_ranks = ctx->comm.n_ranks;
+    return 0;
+}
+static int film_collective(trhip_ctx* ctx, void* d_xyzw, uint64_t n_pixels, int root, bool all) {
+    if (!ctx || !d_xyzw) return fail(ctx, TRHIP_ERR_INVALID, "null argument");
+    if (!ctx->comm.comm) {
+        if (ctx->comm.n_ranks == 1) return 0;  // a single-process job: the film already is the sum
+        return fail(ctx, TRHIP_ERR_INVALID, "no communicator: call trhip_comm_init first");
+    }
+    if (!all && (root < 0 || root >= ctx->comm.n_ranks)) return fail(ctx, TRHIP_ERR_INVALID, "root %d of %d ranks", root, ctx->comm.n_ranks);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    RcclApi* api = rccl_api();
+    // Film.pixels are additive: xyz sums and filter_weight_sum (film.jl:161-162, 190-191) — the sum over ranks is what
+    // merge_film_tile! (film.jl:182-193) would have produced from all tiles of all samples, up to Float32 summation order
+    if (all)
+        NCCL_TRY(ctx, api->AllReduce(d_xyzw, d_xyzw, (size_t)n_pixels * 4, ncclFloat32, ncclSum, ctx->comm.comm, ctx->stream));
+    else
+        NCCL_TRY(ctx, api->Reduce(d_xyzw, d_xyzw, (size_t)n_pixels * 4, ncclFloat32, ncclSum, root, ctx->comm.comm, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+int trhip_film_reduce(trhip_ctx* ctx, void* d_xyzw, uint64_t n_pixels, int root) { return film_collective(ctx, d_xyzw, n_pixels, root, false); }
+int trhip_film_allreduce(trhip_ctx* ctx, void* d_xyzw, uint64_t n_pixels) { return film_collective(ctx, d_xyzw, n_pixels, 0, true); }
+
 int trhip_set_option(trhip_ctx* ctx, const char* name, int64_t value) {
     if (!ctx || !name) return fail(ctx, TRHIP_ERR_INVALID, "null argument");
     if (!std::strcmp(name, "count_visits"))
@@ -1683,7 +1779,7 @@ int trhip_set_option(trhip_ctx* ctx, const char* name, int64_t value) {
     } else if (!std::strcmp(name, "overlap"))
         ctx->overlap = value != 0;
     else if (!std::strcmp(name, "traversal")) {
-        if (value < 1 || value > 3) return fail(ctx, TRHIP_ERR_INVALID, "traversal must be 1, 2 or 3");
+        if (value < 1 || value > 4) return fail(ctx, TRHIP_ERR_INVALID, "traversal must be 1, 2, 3 or 4");
         ctx->traversal = (int)value;
     } else if (!std::strcmp(name, "batch_paths")) {
         if (value < 0) return fail(ctx, TRHIP_ERR_INVALID, "batch_paths must be >= 0 (0 = auto)");
@@ -1861,6 +1957,7 @@ int trhip_scene_commit(trhip_scene* s, int max_node_primitives) {
     }
     if (s->bvh.max_depth > (uint32_t)(kStackLds + kStackSpill))
         return fail(s->ctx, TRHIP_ERR_UNSUPPORTED, "BVH depth %u exceeds the 64-entry traversal stack (bvh.jl:222)", s->bvh.max_depth);
+    s->literal_only = false;
     return upload_scene(s);
 }
 int trhip_scene_bvh_size(const trhip_scene* s, uint32_t* n_nodes, uint32_t* n_prims) {
@@ -1879,19 +1976,63 @@ int trhip_scene_get_bvh(const trhip_scene* s, float* bounds, uint32_t* a, uint32
 }
 int trhip_scene_set_bvh(trhip_scene* s, const float* bounds, const uint32_t* a, const uint32_t* flags, uint32_t n_nodes, const uint32_t* order, uint32_t n_prims) {
     if (!s || !bounds || !a || !flags || !order) return fail(s ? s->ctx : nullptr, TRHIP_ERR_INVALID, "null argument");
+    if (n_nodes == 0) return fail(s->ctx, TRHIP_ERR_INVALID, "empty node array");
     for (uint32_t i = 0; i < n_prims; ++i)
         if (order[i] >= s->prims.size()) return fail(s->ctx, TRHIP_ERR_INVALID, "prim_order[%u] = %u out of range", i, order[i]);
-    for (uint32_t i = 0; i < n_nodes; ++i) {
+    // The array must be ONE tree in the reference's depth-first layout (bvh.jl:187-206): the subtree of node i is the index range
+    // [i, end): first child i + 1 .. a[i] - 1, second child a[i] .. end - 1.  Anything else (a[i] <= i + 1 closes a cycle: the
+    // traversal kernels would never end) is rejected here; so is a tree deeper than the 64-entry stack, where the reference
+    // throws a BoundsError (bvh.jl:222).
+    struct Span {
+        uint32_t node, end, depth;
+    };
+    std::vector<Span> todo;
+    todo.push_back({0u, n_nodes, 1u});
+    uint32_t max_depth = 0;
+    bool nested = true;  // every child box inside its parent's, every primitive's bound inside its leaf box
+    auto inside = [&](const float* in, const float* out) {
+        return in[0] >= out[0] && in[1] >= out[1] && in[2] >= out[2] && in[3] <= out[3] && in[4] <= out[4] && in[5] <= out[5];
+    };
+    while (!todo.empty()) {
+        const Span sp = todo.back();
+        todo.pop_back();
+        const uint32_t i = sp.node;
+        max_depth = std::max(max_depth, sp.depth);
         if ((flags[i] & 3u) == 3u) {
-            if ((uint64_t)a[i] + (flags[i] >> 2) > n_prims) return fail(s->ctx, TRHIP_ERR_INVALID, "leaf %u references primitives outside the list", i);
-        } else if (a[i] >= n_nodes || i + 1 >= n_nodes)
-            return fail(s->ctx, TRHIP_ERR_INVALID, "interior node %u has a child outside the array", i);
+            if (sp.end != i + 1) return fail(s->ctx, TRHIP_ERR_INVALID, "leaf %u is followed by nodes that belong to no subtree (not a depth-first layout)", i);
+            const uint32_t cnt = flags[i] >> 2;
+            if ((uint64_t)a[i] + cnt > n_prims) return fail(s->ctx, TRHIP_ERR_INVALID, "leaf %u references primitives outside the list", i);
+            for (uint32_t k = a[i]; k < a[i] + cnt && nested; ++k) {
+                const HostPrim& p = s->prims[order[k]];
+                HostAABB pb;
+                if (p.kind == 1) {
+                    pb = s->sphere_bounds[p.sphere_id];
+                } else {
+                    pb.reset();
+                    for (int j = 0; j < 3; ++j) pb.grow_point(&p.v[3 * j]);
+                }
+                const float pbox[6] = {pb.mn[0], pb.mn[1], pb.mn[2], pb.mx[0], pb.mx[1], pb.mx[2]};
+                nested = inside(pbox, &bounds[6 * (size_t)i]);
+            }
+            continue;
+        }
+        if (a[i] <= i + 1 || a[i] >= sp.end)
+            return fail(s->ctx, TRHIP_ERR_INVALID, "interior node %u: second child %u outside (%u, %u) — not the depth-first layout of bvh.jl:187-206", i, a[i], i + 1, sp.end);
+        if ((flags[i] & 3u) > 2u) return fail(s->ctx, TRHIP_ERR_INVALID, "interior node %u: split axis %u", i, flags[i] & 3u);
+        nested = nested && inside(&bounds[6 * (size_t)(i + 1)], &bounds[6 * (size_t)i]) && inside(&bounds[6 * (size_t)a[i]], &bounds[6 * (size_t)i]);
+        todo.push_back({a[i], sp.end, sp.depth + 1});
+        todo.push_back({i + 1, a[i], sp.depth + 1});
     }
+    if (max_depth > (uint32_t)(kStackLds + kStackSpill))
+        return fail(s->ctx, TRHIP_ERR_UNSUPPORTED, "BVH depth %u exceeds the 64-entry traversal stack (bvh.jl:222 throws a BoundsError there)", max_depth);
     s->bvh.bounds.assign(bounds, bounds + 6 * (size_t)n_nodes);
     s->bvh.a.assign(a, a + n_nodes);
     s->bvh.flags.assign(flags, flags + n_nodes);
     s->bvh.order.assign(order, order + n_prims);
-    s->bvh.max_depth = 0;
+    s->bvh.max_depth = max_depth;
+    // The default kernels' shortcuts (tight slab clauses, largest-triangle pre-pass, wide nodes: th_trace2.h, th_trace8.h) are exact
+    // only when boxes nest; a foreign tree that does not is walked by the literal kernels (the reference's loop, op for op).
+    s->literal_only = !nested;
     HIP_TRY(s->ctx, hipSetDevice(s->ctx->device));
     return upload_scene(s);
 }
