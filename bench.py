@@ -87,7 +87,7 @@ def measure_traffic(args, kernel_prefix: str, want_any: bool):
         out = tempfile.mkdtemp(prefix="trhip_pmc_", dir="/tmp")
         cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "1", "--warmup", "0",
                "--workload", args.workload, "--res", str(args.res), "--spp", str(args.spp), "--depth", str(args.depth), "--seed", str(args.seed), "--traversal", str(args.traversal),
-               "--no-cpu-baseline", "--no-traffic", "--no-micro", "--no-visits"]
+               "--no-cpu-baseline", "--no-traffic", "--no-micro", "--no-visits"] + [a for kv in args.opt for a in ("--opt", kv)]
         try:
             subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900, check=True)
             files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
@@ -256,6 +256,7 @@ def main():
     ap.add_argument("--micro-log2", type=int, default=24)
     ap.add_argument("--iterations", type=int, default=100, help="caustic_sppm: SPPM iterations per step")
     ap.add_argument("--radius", type=float, default=0.075, help="caustic_sppm: initial search radius")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="library option (trhip_set_option) set before the scene is committed; repeatable")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -278,17 +279,16 @@ def main():
     ctx = T.Context(local_rank)
     if args.traversal:
         ctx.set_option("traversal", args.traversal)
+    for kv in args.opt:
+        name, _, value = kv.partition("=")
+        ctx.set_option(name, int(value))
 
     # ---- the job's communicator, inside the library (include/tracehip.h "multi-GPU"): rank 0 makes the RCCL id, torch.distributed carries it ----
     comm_ok = False
     if world > 1:
-        idbuf = torch.zeros(T._ffi.UNIQUE_ID_BYTES, dtype=torch.uint8, device="cuda")
         try:
-            if rank == 0:
-                idbuf.copy_(torch.frombuffer(bytearray(T._ffi.comm_unique_id()), dtype=torch.uint8))
-            dist.broadcast(idbuf, src=0)
-            ctx.comm_init(bytes(idbuf.cpu().numpy().tobytes()), rank, world)
-            comm_ok = True
+            job = T.parallel.Job(ctx, rank, world)
+            comm_ok = job.ok
         except Exception as e:  # keep the bench line: fall back to torch.distributed's reduce and say so
             sys.stderr.write(f"[bench] rank {rank}: trhip_comm_init failed ({e}); film reduce falls back to torch.distributed\n")
         flag = torch.tensor([1 if comm_ok else 0], device="cuda")
@@ -311,9 +311,8 @@ def main():
     def shard(mode):
         """(spp of this rank, first global sample index) — weak: every rank `spp`; strong: the frame's `spp` split over the ranks."""
         if mode == "weak" or world == 1:
-            return args.spp, rank * args.spp
-        base, rem = divmod(args.spp, world)
-        return base + (1 if rank < rem else 0), rank * base + min(rank, rem)
+            return args.spp, T.parallel.shard_sample_offset(rank, args.spp)
+        return T.parallel.shard_samples(args.spp, rank, world)
 
     def make_step(mode):
         spp_r, off = shard(mode)

@@ -233,10 +233,13 @@ int trhip_film_allreduce(trhip_ctx* ctx, void* d_xyzw, uint64_t n_pixels);
  * "batch_paths": paths in flight per wavefront batch (0 = size from free HBM, the default).
  * "timing" (0/1): per-kernel HIP-event timing in trhip_stats (default 1).
  * "traversal" (1/2/3/4): 1 = literal accel/bvh.jl loop, 2 = children-in-parent nodes with per-lane ray replacement,
- *     3 = 2 with the leaves of a wave postponed and tested together, 4 (default) = 8-wide nodes with quantised child boxes
- *     walked in the binary tree's depth-first order (th_trace8.h); scenes 4 cannot take (foreign trees whose boxes do not nest,
- *     leaves of several primitives, more than 8 spheres) and rays it cannot take (a zero direction component) run 3.
- *     Same results bit for bit.
+ *     3 (default) = 2 with the leaves of a wave postponed and tested together, 4 = 8-wide nodes with quantised child boxes walked
+ *     in the binary tree's depth-first order (th_trace8.h; measured on par with 3); scenes 4 cannot take (foreign
+ *     trees whose boxes do not nest, leaves of several primitives, more than 8 spheres, spheres not committed as a chain — see
+ *     "compose_spheres") and rays it cannot take (a zero direction component) run 3.  Same results bit for bit.
+ * "compose_spheres" (-1/0/1): how trhip_scene_commit places up to 8 spheres of a scene that also has triangles: 1 = as a chain of
+ *     single-sphere leaves above the triangles' subtree (what traversal 4 needs), 0 = inside one SAH tree, -1 (default) = 1 when
+ *     "traversal" is 4 at commit time.  Either tree is a valid BVHAccel: results differ only in exact-t ties.
  * "overlap" (0/1): shadow rays of depth d on a second stream beside the closest-hit pass of depth d+1 (default 1).
  *     "stream2_priority" (-1/0/1): that stream's priority: lowest (default: the closest-hit rays are the critical path), the
  *     default level, highest; read when the streams are created (first render of a context).
@@ -270,6 +273,8 @@ int trhip_set_option(trhip_ctx* ctx, const char* name, int64_t value);
  * (fn: 0 sin, 1 cos, 2 tan, 3 atan2(y, x), 4 acos, 5 log, 6 / 7 the sin / cos part of tm_sincosf); y may be NULL unless
  * fn == 3.  Needs no GPU. */
 int trhip_detmath_f32(int fn, const float* x, const float* y, uint64_t n, float* out);
+/* The same functions as the GPU kernels evaluate them (one thread per element): host and device must agree bit for bit. */
+int trhip_detmath_f32_device(trhip_ctx* ctx, int fn, const float* x, const float* y, uint64_t n, float* out);
 
 #ifdef __cplusplus
 }

@@ -11,6 +11,7 @@
 
 #ifdef _OPENMP
 #include <omp.h>
+#include <memory>
 #endif
 
 using namespace orc;
@@ -335,9 +336,9 @@ struct orc_stats {
     uint64_t camera_samples, closest_rays, shadow_rays, nodes_visited, prims_tested;
 };
 // integrator: 0 Whitted, 1 Path.  out_xyzw: height*width*4 (xyz sums + filter_weight_sum, film.pixels (y,x) order).
-// out_sample_L: optional, spp * n_sample_pixels * 3.  threads <= 1: the sequential tile order of the restatement (bitwise
-// reproducible); threads > 1 is only used by the cpu_baseline timing leg: tiles are rendered in parallel into private
-// FilmTiles (like Threads.@threads, integrators/sampler.jl:24) and merged under a lock in completion order.
+// out_sample_L: optional, spp * n_sample_pixels * 3.  threads <= 1: the sequential tile loop of the restatement; threads > 1: the
+// tiles of a tile row are rendered in parallel into private FilmTiles (like Threads.@threads, integrators/sampler.jl:24) and
+// merged in tile order — the same film and samples bit for bit, sooner.
 int orc_render(void* sp, const orc_sensor* sn, int integrator, int64_t spp, int max_depth, uint64_t seed, uint32_t sample_offset, int threads, float* out_xyzw,
                float* out_sample_L, orc_stats* stats) {
     OrcScene* s = (OrcScene*)sp;
@@ -356,17 +357,26 @@ int orc_render(void* sp, const orc_sensor* sn, int integrator, int64_t spp, int 
         const int tile_size = 16;
         const long long width = (long long)std::floor((sb.p_max.x - sb.p_min.x + tile_size) / tile_size), height = (long long)std::floor((sb.p_max.y - sb.p_min.y + tile_size) / tile_size);
         uint64_t n_samples = 0, n_closest = 0, n_shadow = 0, n_nodes = 0, n_prims = 0;
+        const int sbw = (int)(sb.p_max.x - sb.p_min.x) + 1, sbh = (int)(sb.p_max.y - sb.p_min.y) + 1;
+        const size_t n_pix = (size_t)sbw * sbh;
+        // bounded memory: bands of tile rows; the tiles of a band are rendered in parallel, then merged in k order — the film is the
+        // sequential loop's bit for bit (the reference itself merges in completion order without a lock, film.jl:182-193)
+        const long long band_rows = std::max<long long>(1, (8LL * threads + width - 1) / width);
+        std::vector<std::unique_ptr<FilmTile>> tiles((size_t)(width * band_rows));
+        for (long long row0 = 0; row0 < height; row0 += band_rows) {
+            const long long n_band = std::min(band_rows, height - row0) * width;
 #pragma omp parallel num_threads(threads) reduction(+ : n_samples, n_closest, n_shadow, n_nodes, n_prims)
         {
             Scene& local = s->scene;
             counters() = Counters{};
 #pragma omp for schedule(dynamic, 1)
-            for (long long k = 0; k < width * height; ++k) {
-                const float tx = (float)(k % width), ty = (float)(k / width);
+            for (long long kx = 0; kx < n_band; ++kx) {
+                const float tx = (float)(kx % width), ty = (float)(row0 + kx / width);
                 SeededSampler smp(spp, seed, sample_offset);
                 const V2 tb_min{sb.p_min.x + tx * tile_size, sb.p_min.y + ty * tile_size};
                 const V2 tb_max{jl_min(tb_min.x + (tile_size - 1), sb.p_max.x), jl_min(tb_min.y + (tile_size - 1), sb.p_max.y)};
-                FilmTile tile(film, Bounds2{tb_min, tb_max});
+                tiles[(size_t)kx].reset(new FilmTile(film, Bounds2{tb_min, tb_max}));
+                FilmTile& tile = *tiles[(size_t)kx];
                 for (float py = tb_min.y; py <= tb_max.y; py += 1.0f)
                     for (float px = tb_min.x; px <= tb_max.x; px += 1.0f) {
                         smp.start_pixel(V2{px, py});
@@ -375,18 +385,25 @@ int orc_render(void* sp, const orc_sensor* sn, int integrator, int64_t spp, int 
                             const Ray ray = generate_ray(cam, cs);
                             RGB l = integrator == 0 ? whitted_li(local, ray, max_depth, 1) : path_li(local, ray, smp, max_depth);
                             if (has_nan(l)) l = RGB(0.0f);
+                            if (out_sample_L) {
+                                const size_t pix = (size_t)(py - sb.p_min.y) * sbw + (size_t)(px - sb.p_min.x);
+                                float* o = out_sample_L + ((size_t)(smp.current_sample - 1) * n_pix + pix) * 3;
+                                o[0] = l.x;
+                                o[1] = l.y;
+                                o[2] = l.z;
+                            }
                             add_sample(tile, cs.film, l, 1.0f);
                             n_samples++;
                             smp.start_next_sample();
                         }
                     }
-#pragma omp critical
-                merge_film_tile(film, tile);
             }
             n_closest += counters().closest;
             n_shadow += counters().shadow;
             n_nodes += counters().nodes;
             n_prims += counters().prims;
+        }
+            for (long long kx = 0; kx < n_band; ++kx) merge_film_tile(film, *tiles[(size_t)kx]);
         }
         rs.camera_samples = n_samples;
         rs.closest_rays = n_closest;

@@ -1,0 +1,64 @@
+"""The multi-GPU entry points of the C ABI on ONE GPU (the box the tests run on has one): a 1-rank RCCL communicator created
+from a unique id exactly as an N-rank job creates it; the collectives must leave single-rank results untouched, and
+trhip_render_sppm with a communicator (its photon pass sharded 1 way, ϕ / M all-reduced every iteration) must reproduce the
+render without one.  The N = 2 semantics are covered on CPU by tests/test_sharding_gloo.py."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def comm_ctx(T):
+    ctx = T.Context(0)
+    uid = T._ffi.comm_unique_id()
+    assert len(uid) == 128 and any(uid)
+    ctx.comm_init(uid, 0, 1)
+    assert ctx.comm_rank() == (0, 1)
+    yield ctx
+    ctx.comm_destroy()
+    assert ctx.comm_rank() == (0, 1)
+    ctx.close()
+
+
+def test_film_reduce_single_rank_is_identity(T, comm_ctx):
+    import torch
+    scene, cam = T.scenes.shadows_scene(), T.scenes.shadows_camera(48)
+    h, w = cam.film.size
+    film = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+    integ = T.PathIntegrator(cam, T.SeededSampler(4, seed=9), 4)
+    integ.render(scene, comm_ctx, device_out=film.data_ptr())
+    before = film.cpu().numpy().copy()
+    comm_ctx.film_reduce(film.data_ptr(), h * w, 0)
+    assert np.array_equal(film.cpu().numpy().view(np.uint32), before.view(np.uint32))
+    comm_ctx.film_allreduce(film.data_ptr(), h * w)
+    assert np.array_equal(film.cpu().numpy().view(np.uint32), before.view(np.uint32))
+    with pytest.raises(T.TraceHipError):
+        comm_ctx.film_reduce(film.data_ptr(), h * w, 3)  # root outside the job
+    scene._flat.free()
+    scene._flat = None
+
+
+def test_comm_errors(T, ctx):
+    with pytest.raises(T.TraceHipError):
+        ctx.comm_init(bytes(128), 2, 2)  # rank outside the job
+    assert ctx.comm_rank() == (0, 1)
+    ctx.film_reduce(0x1000, 16, 0)  # no communicator, single-process job: nothing to do (the pointer is not touched)
+
+
+def test_sppm_with_communicator_equals_sppm_without(T, ctx, comm_ctx):
+    scene, cam = T.scenes.cornell_scene(), T.scenes.cornell_camera(40)
+    a = T.SPPMIntegrator(cam, 0.08, 5, 3, 20000, seed=11)
+    img_a = a.render(scene, ctx).copy()
+    st_a = a.state()
+    scene._flat.free()
+    scene._flat = None
+    b = T.SPPMIntegrator(cam, 0.08, 5, 3, 20000, seed=11)
+    img_b = b.render(scene, comm_ctx).copy()
+    st_b = b.state()
+    scene._flat.free()
+    scene._flat = None
+    assert np.array_equal(st_a["M"], st_b["M"]) and st_a["M"].sum() > 0
+    for k in ("phi", "tau", "radius", "Ld"):
+        assert np.array_equal(st_a[k].view(np.uint32), st_b[k].view(np.uint32)), k
+    assert np.array_equal(img_a.view(np.uint32), img_b.view(np.uint32))

@@ -124,12 +124,12 @@ def test_material_less_primitive_is_rejected_by_render_but_traced(T, ctx):
 
 
 def test_bench_size_properties(T, ctx):
-    """At the size of the bench (1024 x 1024, S-cornell, depth 8; 64 of the 256 spp to keep the suite short) the oracle is too
+    """At the size of the bench (1024 x 1024, S-cornell, depth 8; all 256 spp) the oracle is too
     slow to compare against; size-independent properties instead: the render is reproducible bit for bit, does not depend on
     the traversal kernel, the film-gather variant or the batch size, and the two halves of the sample range add up to the whole."""
     scene, cam = T.scenes.cornell_scene(), T.scenes.cornell_camera(1024)
 
-    def render(spp=64, offset=0, **opts):
+    def render(spp=256, offset=0, **opts):
         for k, v in opts.items():
             ctx.set_option(k, v)
         try:
@@ -144,6 +144,83 @@ def test_bench_size_properties(T, ctx):
     assert_bits_equal(render(traversal=1), a, "literal traversal kernel")
     assert_bits_equal(render(film_block=0), a, "one film pixel per thread")
     assert_bits_equal(render(batch_paths=16 * 1026 * 1026, overlap=0), a, "four batches, one stream")
-    h0, h1 = render(32, 0), render(32, 32)
+    assert_bits_equal(render(traversal=3), a, "binary children-in-parent walk (k_trace_leaf here: one-leaf scene)")
+    h0, h1 = render(128, 0), render(128, 128)
     np.testing.assert_allclose(h0 + h1, a, rtol=3e-5, atol=1e-5)
     assert np.array_equal((h0 + h1)[..., 3] > 0, a[..., 3] > 0)
+
+
+def test_device_detmath_equals_host_detmath(T, ctx):
+    """include/trace_detmath.h is shared by the oracle (g++), the library's host side and the kernels (hipcc, device): the device
+    copy must return the host copy's Float32 bit patterns — sin, cos, tan, atan2, acos, log and both parts of the fused sincos —
+    over their working ranges, the special values and the range-reduction boundaries."""
+    rng = np.random.default_rng(7)
+    wide = np.concatenate([rng.uniform(-50, 50, 200000), rng.uniform(-1e4, 1e4, 50000), rng.normal(size=50000) * 1e-3,
+                           np.arange(-64, 65) * (np.pi / 4), [0.0, -0.0, 1e-30, -1e-30, 1e-45, np.inf, -np.inf, np.nan, 1e10, -1e10]]).astype(np.float32)
+    unit = np.concatenate([rng.uniform(-1, 1, 200000), [1.0, -1.0, 0.0, -0.0, 1.0 + 1e-7, -1.0 - 1e-7, np.nan]]).astype(np.float32)
+    pos = np.concatenate([10.0 ** rng.uniform(-30, 30, 200000), [0.0, -0.0, 1.0, 1e-3, np.inf, -1.0, np.nan, 1e-45]]).astype(np.float32)
+    cases = [(0, wide, None), (1, wide, None), (2, wide, None), (6, wide, None), (7, wide, None), (4, unit, None), (5, pos, None),
+             (3, wide, np.roll(wide, 7919))]
+    for fn, x, y in cases:
+        host = T._ffi.detmath(fn, x, y)
+        dev = ctx.detmath(fn, x, y)
+        na, nb = np.isnan(host), np.isnan(dev)
+        assert np.array_equal(na, nb), f"fn {fn}: NaN pattern"
+        bad = (host.view(np.uint32) != dev.view(np.uint32)) & ~na
+        assert not bad.any(), f"fn {fn}: {int(bad.sum())} of {x.size} values differ, e.g. x = {x[bad][0]!r}: host {host[bad][0]!r} device {dev[bad][0]!r}"
+
+
+def test_set_bvh_rejects_trees_the_kernels_cannot_walk(T, ob, ctx):
+    """trhip_scene_set_bvh: a node array that is not ONE tree in the reference's depth-first layout (a child index that closes a
+    cycle would make the traversal kernels spin forever) or that is deeper than the 64-entry stack (the reference throws a
+    BoundsError there, bvh.jl:222) is an error, not a hang or a silent miss; a valid tree whose boxes do not nest is walked by
+    the literal kernels and still agrees with the oracle."""
+    scene = T.scenes.mesh_scene(8)
+    flat = scene.flatten(ctx)
+    bounds, a, flags, order = [x.copy() for x in flat.bvh()]
+    inner = np.flatnonzero((flags & 3) != 3)
+    bad = a.copy()
+    bad[inner[3]] = inner[3]  # second child = the node itself: a cycle
+    with pytest.raises(T.TraceHipError):
+        flat.set_bvh(bounds, bad, flags, order)
+    bad = a.copy()
+    bad[inner[2]] = inner[2] + 1  # second child = first child
+    with pytest.raises(T.TraceHipError):
+        flat.set_bvh(bounds, bad, flags, order)
+    # a chain deeper than 64 levels: node i = interior {leaf, rest}
+    n = 70
+    prims = scene.aggregate.primitives
+    tri = next(p for p in prims if isinstance(p, T.MeshPrimitives))
+    verts, idx = tri.mesh.vertices, tri.mesh.indices.reshape(-1, 3)[:n]
+    chain_scene = T.Scene(scene.lights, T.BVHAccel([T.create_mesh_primitives(T.ShapeCore(T.translate([0, 0, 0]), False), idx.reshape(-1), verts, tri.mesh.normals, tri.material)], 1))
+    cflat = chain_scene.flatten(ctx)
+    big = np.array([[-10, -10, -10, 10, 10, 10]], np.float32)
+    cb, ca, cf = [], [], []
+    for i in range(n - 1):
+        cb += [big[0], big[0]]
+        ca += [2 * i + 2, i]
+        cf += [0, (1 << 2) | 3]
+    cb.append(big[0])
+    ca.append(n - 1)
+    cf.append((1 << 2) | 3)
+    with pytest.raises(T.TraceHipError) as e:
+        cflat.set_bvh(np.array(cb, np.float32), np.array(ca, np.uint32), np.array(cf, np.uint32), np.arange(n, dtype=np.uint32))
+    assert "64" in str(e.value)
+    # loose boxes that do not nest (every node the whole scene, leaves too small for their triangles' neighbours): literal kernels, same hits as the oracle
+    loose = bounds.copy()
+    loose[inner] += np.float32([0.01, 0.01, 0.01, -0.01, -0.01, -0.01]) * 0  # interiors unchanged
+    leaf = np.flatnonzero((flags & 3) == 3)
+    loose[leaf[::2], :3] -= np.float32(0.05)  # every other leaf box grown beyond its parent
+    loose[leaf[::2], 3:] += np.float32(0.05)
+    flat.set_bvh(loose, a, flags, order)
+    try:
+        osc = ob.OracleScene.from_scene(scene, bvh=(loose, a, flags, order))
+        wb = osc.world_bound()
+        rays = T.scenes.incoherent_rays(20000, wb[:3], wb[3:])
+        got = flat.trace_closest(rays)
+        t_ref, prim_ref, _, _ = osc.trace_closest(rays)
+        assert np.array_equal(got["prim"], prim_ref)
+        assert_bits_equal(got["t"], t_ref, "t (foreign tree whose boxes do not nest)")
+        assert np.array_equal(flat.trace_any(rays), osc.trace_any(rays)[0])
+    finally:
+        flat.set_bvh(bounds, a, flags, order)

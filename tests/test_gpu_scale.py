@@ -19,12 +19,8 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def traversals(T, ctx):
-    """Traversal kernels of this build, fastest first; the last entry (1) is the literal accel/bvh.jl loop."""
-    try:
-        ctx.set_option("traversal", 4)
-        return (4, 3, 2, 1)
-    except T.TraceHipError:
-        return (3, 2, 1)
+    """Traversal kernels of this build; the last entry (1) is the literal accel/bvh.jl loop, the first the library's default."""
+    return (3, 4, 2, 1)
 
 
 def bits(a):
@@ -53,12 +49,13 @@ def ray_set(T, ob, n_incoherent):
         r[:, 0:3], r[:, 3], r[:, 4:7], r[:, 7] = o, tmax, d, 0.0
         return r
 
-    m = 1 << 18
+    m = 1 << 19
     # grazing: just above the height field, almost horizontal (|d_y| ~ 1e-3 .. 1e-5) — the rays the loose box test lets through thousands of boxes
     o = np.stack([rng.uniform(0, 1, m), rng.uniform(0.0, 0.16, m), rng.uniform(-3, -2, m)], 1).astype(f32)
     ang = rng.uniform(0, 2 * np.pi, m)
     d = np.stack([np.cos(ang), rng.choice([-1.0, 1.0], m) * 10.0 ** rng.uniform(-5, -3, m), np.sin(ang)], 1).astype(f32)
     parts.append(rays_from(o, d))
+    m = 1 << 18
     # finite t_max: shadow-ray-like segments that end inside the scene
     o = np.stack([rng.uniform(0, 1, m), rng.uniform(0, 1, m), rng.uniform(-3, -2, m)], 1).astype(f32)
     d = rng.normal(size=(m, 3)).astype(f32)
@@ -95,8 +92,14 @@ def ray_set(T, ob, n_incoherent):
     return rays, np.concatenate(sub)
 
 
-def check_traversals(T, ob, ctx, scene, n_incoherent, expect_prims):
-    flat = scene.flatten(ctx)
+def check_traversals(T, ob, ctx, scene, n_incoherent, expect_prims, chain):
+    """chain: commit the scene's spheres as a chain of leaves above the triangles (option compose_spheres), the tree k_trace8 walks;
+    otherwise one SAH tree over everything (the default), where traversal 4 falls back to k_trace3 when the scene has spheres."""
+    ctx.set_option("compose_spheres", 1 if chain else 0)
+    try:
+        flat = scene.flatten(ctx)
+    finally:
+        ctx.set_option("compose_spheres", -1)
     bvh = flat.bvh()
     assert bvh[3].size == expect_prims
     rays, sub = ray_set(T, ob, n_incoherent)
@@ -131,11 +134,13 @@ def check_frame(T, ob, ctx, scene, osc, res=64, spp=32, depth=16, seed=0x5EED000
     cam = T.scenes.cornell_camera(res)
     films = {}
     travs = traversals(T, ctx)
-    for trav in (travs[0], 1):
+    ran = {}
+    for trav in (3, 4, 1):
         ctx.set_option("traversal", trav)
         try:
             integ = T.PathIntegrator(cam, T.SeededSampler(spp, seed=seed), depth)
             films[trav] = (integ.render(scene, ctx).copy(), integ.sample_radiance(scene).copy())
+            ran[trav] = int(integ.stats.traversal)
         finally:
             ctx.set_option("traversal", travs[0])
     ref_xyzw, ref_L, _ = osc.render(cam, "path", spp, depth, seed=seed, threads=ob.lib().orc_num_threads(), want_samples=True)
@@ -143,20 +148,24 @@ def check_frame(T, ob, ctx, scene, osc, res=64, spp=32, depth=16, seed=0x5EED000
         assert_bits_equal(L, ref_L, f"traversal {trav}: per-sample radiance at depth {depth}")
         assert_bits_equal(xyzw, ref_xyzw, f"traversal {trav}: film")
     assert np.isfinite(ref_xyzw).all() and ref_xyzw[..., :3].max() > 0
+    return ran
 
 
-def test_mesh_1m_all_traversals_and_oracle(T, ob, ctx):
+@pytest.mark.parametrize("chain", [False, True], ids=["sah_tree", "sphere_chain"])
+def test_mesh_1m_all_traversals_and_oracle(T, ob, ctx, chain):
     """BASELINE configs[2] / the north star's "1 M-triangle synthetic scene" (and the C5 geometry at a tenth of its size)."""
     scene = T.scenes.mesh_scene(T.scenes.MESH_N["mesh_1m"])
-    _, osc = check_traversals(T, ob, ctx, scene, 1 << 21, 2 * 724 * 724 + 12)
-    check_frame(T, ob, ctx, scene, osc)
+    _, osc = check_traversals(T, ob, ctx, scene, 1 << 21, 2 * 724 * 724 + 12, chain)
+    ran = check_frame(T, ob, ctx, scene, osc)
+    assert ran[4] == (4 if chain else 3)  # trhip_stats.traversal: k_trace8 needs the chain when the scene has spheres
 
 
 def test_blob_870k_all_traversals_and_oracle(T, ob, ctx):
     """BASELINE configs[2] stand-in: a closed 874 800-triangle object in the Cornell walls (no spheres)."""
     scene = T.scenes.blob_scene(270)
-    _, osc = check_traversals(T, ob, ctx, scene, 1 << 21, 12 * 270 * 270 + 10)
-    check_frame(T, ob, ctx, scene, osc)
+    _, osc = check_traversals(T, ob, ctx, scene, 1 << 21, 12 * 270 * 270 + 10, False)
+    ran = check_frame(T, ob, ctx, scene, osc)
+    assert ran[4] == 4 and ran[3] == 3
 
 
 def sppm_pair(T, ob, ctx, scene, cam, radius, depth, iters, seed):

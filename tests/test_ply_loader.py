@@ -58,3 +58,33 @@ def test_ply_errors(T, tmp_path):
                   b"0 0 0\n1 0 0\n1 1 0\n3 0 1 2\n")
     with pytest.raises(ValueError, match="normals"):
         T.load_triangle_mesh(str(r))
+
+
+def test_reference_caustic_glass_ply(T):
+    """The reference's one mesh asset (docs/src/assets/models/caustic-glass.ply, placed under tests/golden/ by make_caustic_ply.py),
+    read by load_triangle_mesh as docs/code/caustic_glass.jl:21-24 does: 44 034 vertices with normals, 88 064 triangles, the
+    bounding box SURVEY.md §8d quotes, then moved by the script's translate(5, -1.49, -100)."""
+    import hashlib
+    import json
+    import os
+    import numpy as np
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    path = os.path.join(here, "caustic-glass.ply")
+    meta = json.load(open(path + ".json"))
+    blob = open(path, "rb").read()
+    assert len(blob) == meta["bytes"] and hashlib.sha256(blob).hexdigest() == meta["sha256"]
+    verts, normals, faces = T.api.read_ply(path)
+    assert verts.shape == (44034, 3) and normals.shape == (44034, 3) and faces.shape == (88064, 3)
+    assert faces.dtype == np.uint32 and int(faces.max()) == 44033 and int(faces.min()) == 0
+    np.testing.assert_allclose(verts.min(0), [-4.81, 1.50, 1.35], atol=0.01)
+    np.testing.assert_allclose(verts.max(0), [-2.66, 3.50, 3.50], atol=0.01)
+    np.testing.assert_allclose(np.linalg.norm(normals, axis=1), 1.0, atol=1e-3)
+    meshes, triangles = T.load_triangle_mesh(path, T.ShapeCore(T.translate([5, -1.49, -100]), False))
+    assert len(meshes) == 1 and len(triangles) == 88064
+    mesh = triangles[0].mesh
+    moved = (verts.astype(np.float32) + np.float32([5, -1.49, -100])).astype(np.float32)
+    assert np.abs(mesh.vertices - moved).max() <= 1e-5  # world-space vertices (triangle_mesh.jl:23); normals stay untransformed (:23-28)
+    assert np.array_equal(mesh.normals, normals)
+    assert np.array_equal(mesh.indices.reshape(-1, 3), faces + 1)  # 1-based (model_loader.jl:36)
+    scene = T.scenes.caustic_scene(path)
+    assert len(scene.aggregate.primitives[0].mesh.indices) // 3 == 88064 and len(scene.lights) == 1

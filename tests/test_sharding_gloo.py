@@ -45,3 +45,94 @@ def test_two_rank_film_reduce(T, ob, tmp_path):
     np.testing.assert_allclose(reduced, full, rtol=3e-5, atol=1e-6)
     # weights are sums of table values: exact up to order as well
     assert np.abs(reduced[..., 3] - full[..., 3]).max() <= 1e-4
+
+
+STRONG_WORKER = r'''
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import __graft_entry__ as graft
+T = graft.load_package()
+import oracle_bridge as ob
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group(backend="gloo")
+total_spp = 7  # ONE frame of 7 samples per pixel split over the ranks (bench.py --scaling strong): 4 + 3
+spp, off = T.parallel.shard_samples(total_spp, rank, world)
+assert (spp, off) == ((4, 0) if rank == 0 else (3, 4))
+scene, cam = T.scenes.shadows_scene(), T.scenes.shadows_camera(24)
+osc = ob.OracleScene.from_scene(scene)
+xyzw, _, _ = osc.render(cam, "path", spp, 4, seed=11, sample_offset=off)
+film = torch.from_numpy(xyzw.copy())
+T.parallel.reduce_film(film, dst=0)
+if rank == 0:
+    np.save(sys.argv[2], film.numpy())
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+SPPM_WORKER = r'''
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import __graft_entry__ as graft
+T = graft.load_package()
+import oracle_bridge as ob
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group(backend="gloo")
+scene, cam = T.scenes.cornell_scene(), T.scenes.cornell_camera(32)
+osc = ob.OracleScene.from_scene(scene)
+P = 9000
+lo, hi = T.parallel.photon_slice(P, rank, world)      # the slice trhip_render_sppm gives rank r of a communicator (tracehip.hip)
+calls = []
+def exchange(phi, M):                                  # one all-reduce of phi (3 floats) and M per pixel per iteration (SURVEY.md 8e)
+    t_phi, t_M = torch.from_numpy(phi), torch.from_numpy(M)
+    dist.all_reduce(t_phi, op=dist.ReduceOp.SUM)
+    dist.all_reduce(t_M, op=dist.ReduceOp.SUM)
+    calls.append(int(M.sum()))
+r = osc.sppm(cam, 0.08, 5, 3, P, seed=11, photon_range=(lo, hi), exchange=exchange)
+assert len(calls) == 3
+np.savez(sys.argv[2] + f".{rank}.npz", image=r["image"], M=r["M"], radius=r["radius"], N=r["N"], tau=r["tau"], Ld=r["Ld"], phi=r["phi"])
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def _run_two_ranks(tmp_path, body, out, port):
+    script = tmp_path / "worker.py"
+    script.write_text(body)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2")
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                           str(script), ROOT, str(out)], env=env, timeout=600)
+
+
+def test_two_rank_strong_scaling_frame(T, ob, tmp_path):
+    """bench.py --scaling strong: ONE frame's samples split over the ranks (uneven: 4 + 3), films sum-reduced: equals the
+    single-process frame of all 7 samples up to Float32 summation order."""
+    out = tmp_path / "film.npy"
+    _run_two_ranks(tmp_path, STRONG_WORKER, out, 29573)
+    reduced = np.load(out)
+    scene, cam = T.scenes.shadows_scene(), T.scenes.shadows_camera(24)
+    full, _, _ = ob.OracleScene.from_scene(scene).render(cam, "path", 7, 4, seed=11)
+    assert full[..., :3].max() > 0
+    np.testing.assert_allclose(reduced, full, rtol=3e-5, atol=1e-6)
+
+
+def test_two_rank_sppm_photon_sharding(T, ob, tmp_path):
+    """SPPM over two processes as trhip_render_sppm does it with a communicator: the camera pass replicated, each rank tracing its
+    slice of every iteration's photons, ONE all-reduce of ϕ and M per iteration before _update_pixels!.  Both ranks end with the same
+    pixels; M, radius and N equal the single-process run exactly (integers / functions of M), ϕ, τ and the image up to the
+    order of the Float32 adds (the reference's own atomics are unordered, sppm.jl:398-399)."""
+    out = tmp_path / "sppm"
+    _run_two_ranks(tmp_path, SPPM_WORKER, out, 29575)
+    r0, r1 = np.load(str(out) + ".0.npz"), np.load(str(out) + ".1.npz")
+    for k in r0.files:
+        assert np.array_equal(r0[k], r1[k]), f"ranks disagree on {k}"
+    scene, cam = T.scenes.cornell_scene(), T.scenes.cornell_camera(32)
+    ref = ob.OracleScene.from_scene(scene).sppm(cam, 0.08, 5, 3, 9000, seed=11)
+    assert np.array_equal(r0["M"], ref["M"]) and ref["M"].sum() > 0
+    assert np.array_equal(r0["radius"], ref["radius"]) and np.array_equal(r0["N"], ref["N"])
+    assert np.array_equal(r0["Ld"].view(np.uint32), ref["Ld"].view(np.uint32))
+    scale = np.abs(ref["phi"]).max()
+    np.testing.assert_allclose(r0["phi"], ref["phi"], rtol=2e-5, atol=2e-5 * scale)
+    np.testing.assert_allclose(r0["tau"], ref["tau"], rtol=5e-5, atol=5e-5 * np.abs(ref["tau"]).max())
+    np.testing.assert_allclose(r0["image"], ref["image"], rtol=1e-4, atol=1e-4 * np.abs(ref["image"]).max())

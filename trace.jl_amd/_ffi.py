@@ -128,6 +128,7 @@ SIGNATURES = {
     "trhip_film_reduce": (C.c_int, [_VP, _VP, C.c_uint64, C.c_int]),
     "trhip_film_allreduce": (C.c_int, [_VP, _VP, C.c_uint64]),
     "trhip_detmath_f32": (C.c_int, [C.c_int, _F, _F, C.c_uint64, _F]),
+    "trhip_detmath_f32_device": (C.c_int, [_VP, C.c_int, _F, _F, C.c_uint64, _F]),
 }
 
 _lib = None
@@ -174,6 +175,14 @@ def detmath(fn: int, x, y=None):
 
 class Context:
     """One GPU (trhip_ctx)."""
+
+    def detmath(self, fn: int, x, y=None):
+        """include/trace_detmath.h evaluated by a kernel on this GPU (trhip_detmath_f32_device)."""
+        x = f32(np.atleast_1d(x))
+        out = np.empty_like(x)
+        yy = f32(np.atleast_1d(y)) if y is not None else None
+        self.check(lib().trhip_detmath_f32_device(self._h, fn, fptr(x), fptr(yy) if yy is not None else None, x.size, fptr(out)))
+        return out
 
     def __init__(self, device: int = 0):
         self._h = _VP()

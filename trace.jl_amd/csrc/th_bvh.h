@@ -167,8 +167,18 @@ class BVHBuilder {
                 }
             }
         }
-        if (best_axis < 0) {  // all centroids coincide: the reference makes a leaf too (bvh.jl:113-118)
-            make_leaf(out, node, lo, hi);
+        if (best_axis < 0) {  // all centroids coincide: the reference makes a leaf (bvh.jl:113-118); so does this builder up to the leaf-size hint,
+                              // beyond it the set is halved by index (same boxes on both sides) so that the hint holds: with
+                              // max_node_primitives = 1 every leaf holds ONE primitive, what the 8-wide view needs (th_wide8.h)
+            if ((int)n <= max_leaf_ || depth >= 60) {
+                make_leaf(out, node, lo, hi);
+                return;
+            }
+            const uint32_t mid = lo + n / 2;
+            out.flags[node] = 0u;
+            recurse(lo, mid, depth + 1, out, 0);
+            out.a[node] = (uint32_t)out.a.size();
+            recurse(mid, hi, depth + 1, out, 0);
             return;
         }
         if ((int)n <= max_leaf_) {

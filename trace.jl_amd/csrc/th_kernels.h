@@ -55,6 +55,7 @@ struct SegQueue {
     uint32_t cap;
     uint32_t n_dense;
     const uint32_t* indirect;  // optional: entry -> index into the ray arrays (k_any_occluders' survivor lists); null = the entry is the index
+    uint32_t no_total;         // 1: the rays of this queue were already counted (k_trace8's fallback list): do not add them to the ray totals
 };
 struct SegView {  // per-block copy in LDS
     uint32_t count[kSeg];

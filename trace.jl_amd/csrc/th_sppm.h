@@ -460,12 +460,16 @@ __global__ __launch_bounds__(1024) void k_sppm_scan(const uint32_t* __restrict__
 
 // ---- photon pass (sppm.jl:320-436) ----------------------------------------------------------------------------------------------
 // Photon ray leaving the light: sample_discrete over light power, sample_le (point.jl:60-69, spot.jl:46-55), β.
-__global__ __launch_bounds__(kBlock) void k_photon_gen(DeviceScene sc, LightDistribution ld, uint32_t n_photons, uint64_t halton_base, PathQueue q, uint32_t cap, Counters* ctr) {
+// per_iter / p_lo / p_hi: a multi-GPU job (trhip_comm_init) traces photon indices [p_lo, p_hi) of every iteration on this rank
+// (Threads.@threads over photon_index, sppm.jl:334, spread over processes); the index space and the records keep the full layout.
+__global__ __launch_bounds__(kBlock) void k_photon_gen(DeviceScene sc, LightDistribution ld, uint32_t n_photons, uint64_t halton_base, PathQueue q, uint32_t cap, Counters* ctr,
+                                                       uint32_t per_iter, uint32_t p_lo, uint32_t p_hi) {
     const uint32_t total = (n_photons + 63u) & ~63u;
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < total; i += gridDim.x * kBlock) {
         bool want = false;
         float4 o4, d4, b4;
-        if (i < n_photons) {
+        const uint32_t p_in_iter = per_iter ? i % per_iter : 0u;
+        if (i < n_photons && p_in_iter >= p_lo && p_in_iter < p_hi) {
             const uint64_t hi = halton_base + i;
             const float light_sample = radical_inverse(0, hi);
             int offset = 0;  // findlast(cdf[i] ≤ u), 1-based

@@ -14,6 +14,7 @@
 #include "th_bvh.h"
 #include "th_kernels.h"
 #include "th_trace2.h"
+#include "th_trace8.h"
 #include "th_whitted.h"
 #include "th_sppm.h"
 #include "th_lbvh.h"
@@ -66,7 +67,10 @@ struct trhip_ctx {
     int film_block = 2;  // film gather: 0 = one film pixel per thread, 1 = 2 x 2 pixels per thread, 2 = TH_FILM_BX x TH_FILM_BY = 1 x 4 (default)
     bool film_tiled = false;  // LDS-staged film gather (k_film_gather_tiled): bit-identical, measured 2.7x SLOWER than k_film_gather (11 % lane use), kept as an option
     bool overlap = true;  // two-stream overlap of shadow rays (depth d) with closest-hit rays (depth d+1)
-    int traversal = 3;  // 1 = literal accel/bvh.jl loop, 2 = children-in-parent nodes + per-lane ray replacement, 3 = 2 with leaves postponed (while-while)
+    int compose_spheres = -1;  // commit: spheres as a chain of leaves above the triangles' subtree, what k_trace8 needs of a scene with spheres
+                               // (option "compose_spheres": 1 / 0 = one SAH tree over everything / -1 = when "traversal" is 4 at commit time)
+    int traversal = 3;  // 1 = literal accel/bvh.jl loop, 2 = children-in-parent nodes + per-lane ray replacement, 3 = 2 with leaves postponed (while-while),
+                        // 4 = 8-wide quantised nodes in the binary walk's order (th_trace8.h; scenes / rays it cannot take run 3)
     // workspace (grown on demand, reused across calls)
     DevBuf q[2][3], sq[3], hits, Lbuf, pfilm, counters, sensor, table, film, scratch[4], overflow, wh_L, wh_parent, wh_coef, wh_pdf, wh_flags, occl, film_Lt, surv_list, surv_counts;
     uint64_t last_L_count = 0;  // float4 entries valid in Lbuf
@@ -85,6 +89,7 @@ struct trhip_ctx {
     uint64_t sppm_batch = 0;  // SPPM iterations per wavefront batch (0 = from free HBM, at most 128)
     uint32_t sp_pixels = 0;
     int64_t sp_photons = 0;
+    DevBuf ov8[2], fb_list[2], fb_counts[2];  // k_trace8: global stack levels, fallback lists + their counters / work cursors ([closest | any])
     Comm comm;  // multi-GPU job this context belongs to (trhip_comm_init); n_ranks == 1 without one
 };
 
@@ -108,7 +113,9 @@ struct trhip_scene {
     DevBuf d_nodes, d_prims, d_nrm, d_spheres, d_materials, d_lights, d_wnodes;
     DeviceScene dev{};
     WideScene wide{};
-    DevBuf d_occ_slots, d_occ_boxes;
+    DevBuf d_occ_slots, d_occ_boxes, d_w8nodes, d_w8tris;
+    Wide8Scene w8{};              // the 8-wide view of the triangles' subtree (th_wide8.h / th_trace8.h)
+    uint32_t w8_nodes = 0, w8_depth = 0;
     uint32_t n_occluders = 0;     // the scene's largest triangles, tested first by any-hit rays (th_trace2.h, k_any_occluders)
     bool partial_spheres = false;  // some sphere is clipped (z range or ϕ_max): traversal kernels with the general sphere test
     bool wide_ok = false;
@@ -134,6 +141,12 @@ int fail(trhip_ctx* ctx, int code, const char* fmt, ...) {
     do {                                                                                                         \
         hipError_t e_ = (expr);                                                                                  \
         if (e_ != hipSuccess) return fail(ctx, TRHIP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+#define NCCL_TRY(ctx, expr)                                                                                                  \
+    do {                                                                                                                     \
+        ncclResult_t r_ = (expr);                                                                                            \
+        if (r_ != ncclSuccess) return fail(ctx, TRHIP_ERR_HIP, "%s failed: %s", #expr, rccl_api()->GetErrorString ? rccl_api()->GetErrorString(r_) : "RCCL error"); \
     } while (0)
 
 int ensure(trhip_ctx* ctx, DevBuf& b, size_t bytes) {
@@ -317,6 +330,20 @@ float det3(const float* m) {  // rows of the upper-left 3x3 of a row-major 4x4
     return m[0] * (m[5] * m[10] - m[6] * m[9]) - m[1] * (m[4] * m[10] - m[6] * m[8]) + m[2] * (m[4] * m[9] - m[5] * m[8]);
 }
 
+// does the subtree rooted at flat node `root` hold a sphere?  (depth-first layout: the subtree is a contiguous index range)
+bool has_sphere_subtree(const trhip_scene* s, uint32_t root) {
+    const uint32_t n_nodes = (uint32_t)s->bvh.a.size(), n_prims = (uint32_t)s->bvh.order.size();
+    if (root >= n_nodes) return true;
+    // end of the subtree: follow second children until a leaf
+    uint32_t end = root;
+    while ((s->bvh.flags[end] & 3u) != 3u) end = s->bvh.a[end];
+    for (uint32_t i = root; i <= end && i < n_nodes; ++i)
+        if ((s->bvh.flags[i] & 3u) == 3u)
+            for (uint32_t k = s->bvh.a[i]; k < s->bvh.a[i] + (s->bvh.flags[i] >> 2) && k < n_prims; ++k)
+                if (s->prims[s->bvh.order[k]].kind == 1) return true;
+    return false;
+}
+
 int upload_scene(trhip_scene* s) {
     trhip_ctx* ctx = s->ctx;
     const uint32_t n_nodes = (uint32_t)s->bvh.a.size(), n_prims = (uint32_t)s->bvh.order.size();
@@ -419,6 +446,48 @@ int upload_scene(trhip_scene* s) {
                 s->wide.root_cnt = 0;
             }
             s->wide_ok = ok;
+        }
+    }
+    // ---- 8-wide nodes over the triangles' subtree for k_trace8 (th_wide8.h) ----
+    s->w8_ok = false;
+    std::memset(&s->w8, 0, sizeof s->w8);
+    if (s->wide_ok && s->wide.root_cnt == 0 && n_nodes >= 3) {
+        // root of the triangles' subtree: the whole tree when the scene has no sphere; with spheres the commit composed
+        // root -> {leaf of all spheres (flat node 1), triangles (flat node 2)} (compose_bvh)
+        uint32_t sub_root = 0, n_sph = 0;
+        bool shape_ok = true;
+        if (!s->spheres.empty()) {
+            n_sph = (uint32_t)s->spheres.size();
+            sub_root = 2 * n_sph;
+            shape_ok = n_sph <= (uint32_t)kW8MaxSpheres && sub_root < n_nodes;
+            for (uint32_t i = 0; i < n_sph && shape_ok; ++i)
+                shape_ok = (s->bvh.flags[2 * i] & 3u) != 3u && (s->bvh.flags[2 * i] & 3u) == (s->bvh.flags[0] & 3u) && s->bvh.a[2 * i] == 2 * i + 2 &&
+                           s->bvh.flags[2 * i + 1] == ((1u << 2) | 3u) && s->bvh.a[2 * i + 1] == i && s->prims[s->bvh.order[i]].kind == 1;
+            shape_ok = shape_ok && !has_sphere_subtree(s, sub_root);
+        }
+        if (shape_ok) {
+            Wide8Host wh = build_wide8(s->bvh, sub_root, [&](uint32_t slot, float* v, uint32_t& meta) {
+                if (slot >= n_prims) return false;
+                const HostPrim& p = s->prims[s->bvh.order[slot]];
+                if (p.kind != 0) return false;
+                std::memcpy(v, p.v, 9 * sizeof(float));
+                meta = p.meta;
+                return true;
+            });
+            if (wh.ok) {
+                if (int rc = upload(ctx, s->d_w8nodes, wh.nodes.data(), wh.nodes.size() * sizeof(uint32_t))) return rc;
+                if (int rc = upload(ctx, s->d_w8tris, wh.tris.data(), wh.tris.size() * sizeof(float))) return rc;
+                s->w8.nodes = (const uint4*)s->d_w8nodes.p;
+                s->w8.tris = (const float4*)s->d_w8tris.p;
+                std::memcpy(s->w8.root_box, &s->bvh.bounds[0], 6 * sizeof(float));
+                std::memcpy(s->w8.tri_box, &s->bvh.bounds[6 * (size_t)sub_root], 6 * sizeof(float));
+                for (uint32_t i = 0; i < n_sph; ++i) std::memcpy(s->w8.sph_box[i], &s->bvh.bounds[6 * (size_t)(2 * i + 1)], 6 * sizeof(float));
+                s->w8.n_sph = n_sph;
+                s->w8.chain_axis = s->bvh.flags[0] & 3u;
+                s->w8_nodes = (uint32_t)(wh.nodes.size() / kW8NodeDwords);
+                s->w8_depth = wh.depth;
+                s->w8_ok = true;
+            }
         }
     }
     // ---- largest triangles: the any-hit pre-pass (th_trace2.h, k_any_occluders) ----
@@ -598,8 +667,7 @@ void launch_trace(trhip_ctx* ctx, hipStream_t st, const trhip_scene* sc, bool an
     const bool v2 = ctx->traversal >= 2 && sc->wide_ok;
     const bool cnt = ctx->count_visits;
     const bool full_only = !sc->partial_spheres;  // no clipped sphere in the scene: kernels without the Float64 atan2 path
-    if (v2 && ctx->traversal == 3 && sc->wide.root_cnt == 0) {  // k_trace3: leaves postponed and tested together ("while-while"); a single-leaf scene
-                                                                   // has nothing to postpone and runs k_trace2 (65 vs 73 ms on S-cornell)
+    if (v2 && ctx->traversal >= 3 && sc->wide.root_cnt == 0) {  // k_trace8 / k_trace3; a single-leaf scene has nothing to postpone and runs k_trace_leaf / k_trace2
         uint2* ov = (uint2*)(overflow_slab ? overflow_slab : ctx->overflow.p);
         if (any && sc->n_occluders && ctx->occluder_pretest && ctx->pipelines <= 1 && !q.indirect) {
             // the largest triangles first (k_any_occluders); what they do not stop goes through per-segment survivor lists
@@ -616,6 +684,35 @@ void launch_trace(trhip_ctx* ctx, hipStream_t st, const trhip_scene* sc, bool an
                 else
                     hipLaunchKernelGGL((k_any_occluders<false>), pgrid, block, 0, st, sc->dev, oc, q, ro, rd, tmax, out, sl, scn, scap, ctr);
                 q = SegQueue{scn, scap, 0u, sl};
+            }
+        }
+        // ---- traversal 4: 8-wide nodes (th_trace8.h); the rays it does not take come back on a fallback list that k_trace3 walks below ----
+        if (ctx->traversal >= 4 && sc->w8_ok && ctx->slab_margin_log2 > 0 && ctx->pipelines <= 1) {
+            const int w = any ? 1 : 0;
+            const uint32_t fcap = q.counts ? q.cap : q.n_dense;
+            const size_t entries = (size_t)fcap * (q.counts ? kSeg : 1);
+            const size_t ctr_words = 2 * (size_t)kSeg * kCtrStride;  // counts, then the work cursors of the fallback launch
+            const size_t ov8_bytes = (size_t)trace_grid(ctx) * kBlock * (size_t)kStack8Global * 3 * sizeof(uint32_t);
+            if (ensure(ctx, ctx->fb_list[w], entries * sizeof(uint32_t)) == 0 && ensure(ctx, ctx->fb_counts[w], ctr_words * sizeof(uint32_t)) == 0 && ensure(ctx, ctx->ov8[w], ov8_bytes) == 0) {
+                uint32_t* fcounts = (uint32_t*)ctx->fb_counts[w].p;
+                (void)hipMemsetAsync(fcounts, 0, ctr_words * sizeof(uint32_t), st);
+                Wide8Scene w8 = sc->w8;
+                w8.tight_scale = std::ldexp(1.0f, -ctx->slab_margin_log2);
+                const FallbackList fb{(uint32_t*)ctx->fb_list[w].p, fcounts, fcap};
+                uint32_t* ov8 = (uint32_t*)ctx->ov8[w].p;
+                if (any) {
+                    if (cnt)
+                        { if (full_only) hipLaunchKernelGGL((k_trace8<true, true, true>), grid, block, 0, st, sc->dev, w8, q, ro, rd, tmax, out, work_cursors, ov8, ctr, fb); else hipLaunchKernelGGL((k_trace8<true, true, false>), grid, block, 0, st, sc->dev, w8, q, ro, rd, tmax, out, work_cursors, ov8, ctr, fb); }
+                    else
+                        { if (full_only) hipLaunchKernelGGL((k_trace8<true, false, true>), grid, block, 0, st, sc->dev, w8, q, ro, rd, tmax, out, work_cursors, ov8, ctr, fb); else hipLaunchKernelGGL((k_trace8<true, false, false>), grid, block, 0, st, sc->dev, w8, q, ro, rd, tmax, out, work_cursors, ov8, ctr, fb); }
+                } else {
+                    if (cnt)
+                        { if (full_only) hipLaunchKernelGGL((k_trace8<false, true, true>), grid, block, 0, st, sc->dev, w8, q, ro, rd, tmax, out, work_cursors, ov8, ctr, fb); else hipLaunchKernelGGL((k_trace8<false, true, false>), grid, block, 0, st, sc->dev, w8, q, ro, rd, tmax, out, work_cursors, ov8, ctr, fb); }
+                    else
+                        { if (full_only) hipLaunchKernelGGL((k_trace8<false, false, true>), grid, block, 0, st, sc->dev, w8, q, ro, rd, tmax, out, work_cursors, ov8, ctr, fb); else hipLaunchKernelGGL((k_trace8<false, false, false>), grid, block, 0, st, sc->dev, w8, q, ro, rd, tmax, out, work_cursors, ov8, ctr, fb); }
+                }
+                q = SegQueue{fcounts, fcap, 0u, fb.list, 1u};
+                work_cursors = fcounts + (size_t)kSeg * kCtrStride;
             }
         }
         if (any) {
@@ -1466,6 +1563,9 @@ int render_sppm_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
     }
     const dim3 blk(kBlock), g_pix(grid_for(ctx, n, 8)), g_shade(ctx->num_cu * 8);
     const float gamma = 2.0f / 3.0f;
+    // multi-GPU job: this rank's slice of every iteration's photons (all of them without a communicator)
+    const uint64_t n_ranks = ctx->comm.comm ? (uint64_t)ctx->comm.n_ranks : 1u, my_rank = ctx->comm.comm ? (uint64_t)ctx->comm.rank : 0u;
+    const uint32_t p_lo = (uint32_t)((uint64_t)P * my_rank / n_ranks), p_hi = (uint32_t)((uint64_t)P * (my_rank + 1) / n_ranks);
     uint32_t n_batches = 0;
     for (uint32_t it0 = 1; it0 <= n_iterations; it0 += (uint32_t)B) {
         const uint32_t nb = (uint32_t)std::min<uint64_t>(B, n_iterations - it0 + 1);
@@ -1502,7 +1602,7 @@ int render_sppm_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
             HIP_TRY(ctx, hipMemsetAsync(rec.valid, 0, (size_t)NP * ndep, st));
             HIP_TRY(ctx, hipMemsetAsync(ctr, 0, offsetof(Counters, closest_total), st));
             tm.begin(0, st);
-            hipLaunchKernelGGL(k_photon_gen, dim3(grid_for(ctx, NP, 8)), blk, 0, st, scene->dev, ldist, NP, halton_base, pq[0], cap, ctr);
+            hipLaunchKernelGGL(k_photon_gen, dim3(grid_for(ctx, NP, 8)), blk, 0, st, scene->dev, ldist, NP, halton_base, pq[0], cap, ctr, (uint32_t)P, p_lo, p_hi);
             tm.end(0, st);
             cur = 0;
             for (int depth = 1; depth <= max_depth; ++depth) {
@@ -1537,6 +1637,15 @@ int render_sppm_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
             hipLaunchKernelGGL(k_sppm_gather, g_pix, blk, 0, st, scene->dev, rec, vp, px, n, grid, (const uint32_t*)starts, (const float4*)entries, n, hot_list);
             hipLaunchKernelGGL(k_sppm_gather_hot, g_shade, blk, 0, st, scene->dev, rec, vp, px, grid, (const uint32_t*)starts, (const float4*)entries, n, (const uint32_t*)hot_list);
             tm.end(2, st);
+            if (ctx->comm.comm && ctx->comm.n_ranks > 1) {
+                // the one exchange of an iteration: every rank traced its slice of the photons, ϕ and M are the sums over all of
+                // them (the reference adds them with Threads.Atomic, sppm.jl:398-399) — then _update_pixels! runs identically everywhere
+                RcclApi* api = rccl_api();
+                NCCL_TRY(ctx, api->GroupStart());
+                NCCL_TRY(ctx, api->AllReduce(px.phi, px.phi, (size_t)n * 3, ncclFloat32, ncclSum, ctx->comm.comm, st));
+                NCCL_TRY(ctx, api->AllReduce(px.M, px.M, (size_t)n, ncclUint32, ncclSum, ctx->comm.comm, st));
+                NCCL_TRY(ctx, api->GroupEnd());
+            }
             if (it0 + j == n_iterations) {  // snapshot for trhip_sppm_state: the last iteration's M, ϕ and visible points
                 HIP_TRY(ctx, hipMemcpyAsync(ctx->sp_snap_M.p, px.M, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
                 HIP_TRY(ctx, hipMemcpyAsync(ctx->sp_snap_phi.p, px.phi, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -1651,6 +1760,11 @@ void trhip_shutdown(trhip_ctx* ctx) {
     release(ctx->film_Lt);
     release(ctx->surv_list);
     release(ctx->surv_counts);
+    for (int k = 0; k < 2; ++k) {
+        release(ctx->ov8[k]);
+        release(ctx->fb_list[k]);
+        release(ctx->fb_counts[k]);
+    }
     for (auto& b : ctx->sp_vp) release(b);
     release(ctx->st_terms);
     release(ctx->st_tags[0]);
@@ -1671,11 +1785,6 @@ void trhip_shutdown(trhip_ctx* ctx) {
 const char* trhip_last_error(const trhip_ctx* ctx) { return ctx ? ctx->err.c_str() : g_init_error.c_str(); }
 
 // ---- multi-GPU: RCCL over xGMI, one process per GPU (th_comm.h) ---------------------------------------------------------------------
-#define NCCL_TRY(ctx, expr)                                                                                                  \
-    do {                                                                                                                     \
-        ncclResult_t r_ = (expr);                                                                                            \
-        if (r_ != ncclSuccess) return fail(ctx, TRHIP_ERR_HIP, "%s failed: %s", #expr, rccl_api()->GetErrorString ? rccl_api()->GetErrorString(r_) : "RCCL error"); \
-    } while (0)
 
 int trhip_comm_unique_id(uint8_t* out_id128) {
     if (!out_id128) return fail(nullptr, TRHIP_ERR_INVALID, "null argument");
@@ -1759,6 +1868,8 @@ int trhip_set_option(trhip_ctx* ctx, const char* name, int64_t value) {
         ctx->bvh_builder = value < 0 ? -1 : (value != 0 ? 1 : 0);
     else if (!std::strcmp(name, "film_transpose"))
         ctx->film_transpose = value != 0;
+    else if (!std::strcmp(name, "compose_spheres"))
+        ctx->compose_spheres = value < 0 ? -1 : (value != 0 ? 1 : 0);
     else if (!std::strcmp(name, "occluder_pretest"))
         ctx->occluder_pretest = value != 0;
     else if (!std::strcmp(name, "stream2_priority"))
@@ -1808,6 +1919,8 @@ void trhip_scene_free(trhip_scene* s) {
     release(s->d_wnodes);
     release(s->d_occ_slots);
     release(s->d_occ_boxes);
+    release(s->d_w8nodes);
+    release(s->d_w8tris);
     delete s;
 }
 int trhip_scene_add_material(trhip_scene* s, int kind, const float* params, int n_params, uint32_t* id_out) {
@@ -1939,11 +2052,25 @@ int trhip_scene_commit(trhip_scene* s, int max_node_primitives) {
             for (int j = 0; j < 3; ++j) pb[i].grow_point(&p.v[3 * j]);
         }
     }
+    // Scenes with a few spheres beside a mesh: a chain root -> {sphere 1, {sphere 2, ... {sphere k, the triangles' subtree}}}.  Any BVH2 is a valid
+    // BVHAccel (results depend on the topology only through exact-t ties); this one keeps the spheres — whose fp32
+    // quadratic accepts rays far outside their box and can raise t_max (A.18) — out of the triangles' subtree, which the 8-wide
+    // kernel then walks with conservative interior boxes (th_wide8.h).  The leaf-size hint is a hint (bvh.jl:159-165 decides by cost).
+    std::vector<uint32_t> sph_ids, tri_ids;
+    for (size_t i = 0; i < s->prims.size(); ++i) (s->prims[i].kind == 1 ? sph_ids : tri_ids).push_back((uint32_t)i);
+    const bool want_chain = s->ctx->compose_spheres > 0 || (s->ctx->compose_spheres < 0 && s->ctx->traversal >= 4);
+    const bool compose = want_chain && !sph_ids.empty() && sph_ids.size() <= (size_t)kW8MaxSpheres && tri_ids.size() >= 2 && pb.size() > s->ctx->tiny_scene_prims;
+    std::vector<HostAABB> pb_sub;
+    if (compose) {
+        pb_sub.reserve(tri_ids.size());
+        for (uint32_t id : tri_ids) pb_sub.push_back(pb[id]);
+    }
+    const std::vector<HostAABB>& pb_build = compose ? pb_sub : pb;
     bool built = false;
     const int mode = s->ctx->bvh_builder;
-    if ((mode == 1 || (mode < 0 && pb.size() > (16u << 20))) && pb.size() > s->ctx->tiny_scene_prims) {
+    if ((mode == 1 || (mode < 0 && pb_build.size() > (16u << 20))) && pb_build.size() > s->ctx->tiny_scene_prims) {
         FlatBVH dev;
-        const int rc = build_bvh_device(s->ctx, pb, dev);
+        const int rc = build_bvh_device(s->ctx, pb_build, dev);
         if (rc == 0) {
             s->bvh = std::move(dev);
             built = true;
@@ -1952,8 +2079,55 @@ int trhip_scene_commit(trhip_scene* s, int max_node_primitives) {
         }
     }
     if (!built) {
-        BVHBuilder builder(pb, max_node_primitives, s->ctx->tiny_scene_prims);
+        BVHBuilder builder(pb_build, max_node_primitives, s->ctx->tiny_scene_prims);
         s->bvh = builder.build();
+    }
+    if (compose) {
+        // flat layout (bvh.jl:187-206): chain node i at 2 i = interior {leaf of sphere i at 2 i + 1, rest at 2 i + 2}; the triangles' subtree at 2 n_sph
+        FlatBVH sub = std::move(s->bvh), out;
+        const uint32_t n_sph = (uint32_t)sph_ids.size(), n_sub = (uint32_t)sub.a.size();
+        std::vector<HostAABB> rest(n_sph + 1);
+        std::memcpy(rest[n_sph].mn, &sub.bounds[0], 3 * sizeof(float));
+        std::memcpy(rest[n_sph].mx, &sub.bounds[3], 3 * sizeof(float));
+        for (uint32_t i = n_sph; i-- > 0;) {
+            rest[i] = rest[i + 1];
+            rest[i].grow(pb[sph_ids[i]]);
+        }
+        // one split axis for every chain node (it only decides whether a ray meets the sphere leaves before or after the triangles): where the
+        // spheres' centre and the triangles' lie furthest apart
+        HostAABB sall;
+        sall.reset();
+        for (uint32_t id : sph_ids) sall.grow(pb[id]);
+        uint32_t axis = 0;
+        float best = -1.0f;
+        for (int a = 0; a < 3; ++a) {
+            const float dc = std::fabs((0.5f * sall.mn[a] + 0.5f * sall.mx[a]) - (0.5f * rest[n_sph].mn[a] + 0.5f * rest[n_sph].mx[a]));
+            if (dc > best) {
+                best = dc;
+                axis = (uint32_t)a;
+            }
+        }
+        for (uint32_t i = 0; i < n_sph; ++i) {
+            const HostAABB& sbx = pb[sph_ids[i]];
+            out.bounds.insert(out.bounds.end(), {rest[i].mn[0], rest[i].mn[1], rest[i].mn[2], rest[i].mx[0], rest[i].mx[1], rest[i].mx[2]});
+            out.a.push_back(2 * i + 2);
+            out.flags.push_back(axis);
+            out.bounds.insert(out.bounds.end(), {sbx.mn[0], sbx.mn[1], sbx.mn[2], sbx.mx[0], sbx.mx[1], sbx.mx[2]});
+            out.a.push_back(i);
+            out.flags.push_back((1u << 2) | 3u);
+        }
+        out.bounds.insert(out.bounds.end(), sub.bounds.begin(), sub.bounds.end());
+        out.a.reserve(n_sub + 2 * n_sph);
+        out.flags.reserve(n_sub + 2 * n_sph);
+        for (uint32_t i = 0; i < n_sub; ++i) {
+            out.a.push_back(sub.a[i] + ((sub.flags[i] & 3u) == 3u ? n_sph : 2 * n_sph));
+            out.flags.push_back(sub.flags[i]);
+        }
+        out.order = sph_ids;
+        out.order.reserve(pb.size());
+        for (uint32_t k : sub.order) out.order.push_back(tri_ids[k]);
+        out.max_depth = sub.max_depth + n_sph;
+        s->bvh = std::move(out);
     }
     if (s->bvh.max_depth > (uint32_t)(kStackLds + kStackSpill))
         return fail(s->ctx, TRHIP_ERR_UNSUPPORTED, "BVH depth %u exceeds the 64-entry traversal stack (bvh.jl:222)", s->bvh.max_depth);
@@ -2268,6 +2442,41 @@ int trhip_film_accumulate(trhip_ctx* ctx, const trhip_sensor* sn, uint32_t spp, 
 // Host utility: the deterministic elementary functions of include/trace_detmath.h for hosts that cannot include a C
 // header (the Python mirror needs tan() for perspective(), transformations.jl:128).  fn: 0 sin 1 cos 2 tan 3 atan2(y,x)
 // 4 acos 5 log.  This is specification math evaluated on the host, not a fallback of any device path.
+namespace {
+TH_HD float detmath_eval(int fn, float x, float y) {
+    switch (fn) {
+    case 0: return tm_sinf(x);
+    case 1: return tm_cosf(x);
+    case 2: return tm_tanf(x);
+    case 3: return tm_atan2f(y, x);
+    case 4: return tm_acosf(x);
+    case 5: return tm_logf(x);
+    default: {  // 6 / 7: tm_sincosf, sin part / cos part
+        float sn, cs;
+        tm_sincosf(x, &sn, &cs);
+        return fn == 6 ? sn : cs;
+    }
+    }
+}
+__global__ void k_detmath(int fn, const float* __restrict__ x, const float* __restrict__ y, uint64_t n, float* __restrict__ out) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) out[i] = detmath_eval(fn, x[i], y ? y[i] : 0.0f);
+}
+}  // namespace
+// The same functions evaluated BY THE KERNELS' COMPILER on the GPU: the parity contract needs device == host bit for bit
+// (tests/test_gpu_edge_cases.py compares this with trhip_detmath_f32).
+extern "C" int trhip_detmath_f32_device(trhip_ctx* ctx, int fn, const float* x, const float* y, uint64_t n, float* out) {
+    if (!ctx || !x || !out || (fn == 3 && !y) || fn < 0 || fn > 7) return fail(ctx, TRHIP_ERR_INVALID, "bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (int rc = upload(ctx, ctx->scratch[0], x, n * sizeof(float))) return rc;
+    if (y)
+        if (int rc = upload(ctx, ctx->scratch[1], y, n * sizeof(float))) return rc;
+    if (int rc = ensure(ctx, ctx->scratch[2], n * sizeof(float))) return rc;
+    if (n) hipLaunchKernelGGL(k_detmath, dim3(grid_for(ctx, n, 4)), dim3(kBlock), 0, ctx->stream, fn, (const float*)ctx->scratch[0].p, y ? (const float*)ctx->scratch[1].p : nullptr, n, (float*)ctx->scratch[2].p);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (n) HIP_TRY(ctx, hipMemcpy(out, ctx->scratch[2].p, n * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
 extern "C" int trhip_detmath_f32(int fn, const float* x, const float* y, uint64_t n, float* out) {
     if (!x || !out || (fn == 3 && !y)) return TRHIP_ERR_INVALID;
     for (uint64_t i = 0; i < n; ++i) {
