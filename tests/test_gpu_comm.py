@@ -59,6 +59,11 @@ def test_sppm_with_communicator_equals_sppm_without(T, ctx, comm_ctx):
     scene._flat.free()
     scene._flat = None
     assert np.array_equal(st_a["M"], st_b["M"]) and st_a["M"].sum() > 0
-    for k in ("phi", "tau", "radius", "Ld"):
+    for k in ("radius", "Ld"):
         assert np.array_equal(st_a[k].view(np.uint32), st_b[k].view(np.uint32)), k
-    assert np.array_equal(img_a.view(np.uint32), img_b.view(np.uint32))
+    assert np.array_equal(st_a["N"], st_b["N"])
+    # ϕ / τ / image: Float32 sums whose order is not fixed from run to run (the photon hits of a grid cell are binned with atomics,
+    # like the reference's own Threads.Atomic adds, sppm.jl:398-399): the tolerance of tests/test_gpu_sppm.py
+    np.testing.assert_allclose(st_b["phi"], st_a["phi"], rtol=2e-5, atol=2e-5 * np.abs(st_a["phi"]).max())
+    np.testing.assert_allclose(st_b["tau"], st_a["tau"], rtol=5e-5, atol=5e-5 * np.abs(st_a["tau"]).max())
+    np.testing.assert_allclose(img_b, img_a, rtol=1e-4, atol=1e-4 * np.abs(img_a).max())
