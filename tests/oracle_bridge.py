@@ -229,7 +229,7 @@ class OracleScene:
                 mat_ids[id(m)] = s.add_material(kind, params)
             return mat_ids[id(m)]
 
-        prims = scene.aggregate.primitives
+        prims = T.api.splice_nested(scene.aggregate.primitives)
         i = 0
         while i < len(prims):
             p = prims[i]

@@ -224,3 +224,27 @@ def test_set_bvh_rejects_trees_the_kernels_cannot_walk(T, ob, ctx):
         assert np.array_equal(flat.trace_any(rays), osc.trace_any(rays)[0])
     finally:
         flat.set_bvh(bounds, a, flags, order)
+
+
+def test_nested_bvh_as_primitive(T, ob, ctx):
+    """test/test_intersection.jl:129-156: eight unit spheres at (i, i, 0), i = 0:3:21; BVHAccel(1:4) is a PRIMITIVE of the BVHAccel that
+    also holds spheres 5:8.  Expected (Appendix B): the ray o = (-2, 0, 0), d = (1, 0, 0) hits at t = 1, the ray o = (0, 18, 0),
+    d = (1, 0, 0) at t = 17.  The host splices nested aggregates (one BVH over the flat list)."""
+    matte = T.MatteMaterial(T.ConstantTexture(T.RGBSpectrum(0.5)), T.ConstantTexture(0.0))
+    spheres = [T.GeometricPrimitive(T.Sphere(T.ShapeCore(T.translate([float(i), float(i), 0.0]), False), 1.0, 360.0), matte) for i in range(0, 22, 3)]
+    inner = T.BVHAccel(spheres[:4], 1)
+    outer = T.BVHAccel([inner] + spheres[4:], 1)
+    scene = T.Scene([], outer)
+    ctx.set_option("tiny_scene_prims", 0)
+    try:
+        flat = scene.flatten(ctx)
+    finally:
+        ctx.set_option("tiny_scene_prims", 16)
+    bounds = flat.bvh()[0]
+    assert np.allclose(bounds[0], [-1, -1, -1, 22, 22, 1])
+    rays = np.float32([[-2, 0, 0, np.inf, 1, 0, 0, 0], [0, 18, 0, np.inf, 1, 0, 0, 0], [0, 50, 0, np.inf, 1, 0, 0, 0]])
+    hits = flat.trace_closest(rays)
+    assert hits["t"][0] == 1.0 and hits["t"][1] == 17.0 and hits["prim"][2] == -1
+    osc = ob.OracleScene.from_scene(scene, bvh=flat.bvh())
+    t, prim, _, _ = osc.trace_closest(rays)
+    assert np.array_equal(hits["prim"], prim) and np.array_equal(hits["t"].view(np.uint32), t.view(np.uint32))

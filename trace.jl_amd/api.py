@@ -501,6 +501,19 @@ def UniformSampler(samples_per_pixel: int) -> SeededSampler:
 
 
 # ---- flattening ---------------------------------------------------------------------------------------------------------------------
+def splice_nested(prims):
+    """A BVHAccel may itself be a primitive of another (accel/bvh.jl:50-53, test/test_intersection.jl:137-138): its primitives are
+    spliced in place — the library builds ONE BVH over the flat list (any BVH over the same primitives gives the same hits except
+    exact-t ties)."""
+    out = []
+    for p in prims:
+        if isinstance(p, BVHAccel):
+            out += splice_nested(p.primitives)
+        else:
+            out.append(p)
+    return out
+
+
 class FlatScene:
     """Walk Scene -> BVHAccel -> GeometricPrimitive -> shape/material and push everything through the C ABI."""
 
@@ -522,7 +535,7 @@ class FlatScene:
                 mat_ids[id(m)] = out.value
             return mat_ids[id(m)]
 
-        prims = scene.aggregate.primitives
+        prims = splice_nested(scene.aggregate.primitives)
         self.n_prims = len(prims)
         i = 0
         while i < len(prims):

@@ -2,7 +2,9 @@
 #
 # STATUS: written against include/tracehip.h, NEVER EXECUTED — the build image has no Julia runtime (SURVEY.md F5).
 # The tested host over the same C ABI is the Python mirror (trace.jl_amd/api.py); this file is the reference-side
-# binding a maintainer would add (INTEGRATION.md).  Scene scripts stay unchanged: they build Trace.Scene / Trace.Film /
+# binding a maintainer would add (INTEGRATION.md).  What it sends across the boundary — the exact call sequence and argument
+# layout of flatten() / sensor() / render!() — is written down in tests/golden/julia_shim_calls.json and REPLAYED through ctypes by
+# tests/test_gpu_julia_replay.py against the Python host's film, so the marshalling below is pinned even though Julia is absent.  Scene scripts stay unchanged: they build Trace.Scene / Trace.Film /
 # Trace.PerspectiveCamera with Trace.jl's own constructors (so every load-bearing matrix bug is the reference's own) and
 # call `integrator(scene)`; the methods below replace the CPU render loops of src/integrators/sampler.jl:12-56.
 module TraceHIP
@@ -45,7 +47,9 @@ mutable struct TrhipStats
     launches::NTuple{5,UInt32}
     n_batches::UInt32
     max_depth_reached::UInt32
-    TrhipStats() = new(0, 0, 0, 0, 0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, (0, 0, 0, 0, 0), 0, 0)
+    traversal::UInt32
+    node_bytes::UInt32
+    TrhipStats() = new(0, 0, 0, 0, 0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, (0, 0, 0, 0, 0), 0, 0, 0, 0)
 end
 
 struct TraceHIPError <: Exception
@@ -97,8 +101,25 @@ function flatten(scene::Trace.Scene)
         end
     end
     bvh = scene.aggregate::Trace.BVHAccel
-    # NOTE: bvh.primitives is already the reference builder's ordering; any order gives the same image except exact-t ties.
-    for p in bvh.primitives
+    # Every GeometricPrimitive under the aggregate, in order; a BVHAccel may itself be a primitive of another
+    # (primitive.jl / accel/bvh.jl:50-53, test/test_intersection.jl:137-138): its primitives are spliced in place.  Any order gives the
+    # same image except exact-t ties: the library builds its own BVH over the flat list (trhip_scene_commit).
+    prims = Trace.GeometricPrimitive[]
+    function collect_prims!(list)
+        for p in list
+            if p isa Trace.BVHAccel
+                collect_prims!(p.primitives)
+            elseif p isa Trace.GeometricPrimitive
+                push!(prims, p)
+            else
+                error("TraceHIP: unsupported primitive $(typeof(p))")
+            end
+        end
+    end
+    collect_prims!(bvh.primitives)
+    i = 1
+    while i <= length(prims)
+        p = prims[i]
         shape = p.shape
         if shape isa Trace.Sphere
             o2w = shape.core.object_to_world
@@ -106,15 +127,31 @@ function flatten(scene::Trace.Scene)
                 (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Cint, Float32, Float32, Float32, Float32, Float32, Float32, UInt32, Ptr{UInt32}),
                 s, rowmajor_vec(o2w.m), rowmajor_vec(o2w.inv_m), shape.core.reverse_orientation, shape.radius, shape.z_min, shape.z_max,
                 shape.θ_min, shape.θ_max, shape.ϕ_max, material_id(p.material), C_NULL))
+            i += 1
         elseif shape isa Trace.Triangle
+            # ONE call per run of consecutive triangles of the same TriangleMesh (create_triangle_mesh returns them in order,
+            # triangle_mesh.jl:45-58): the mesh's vertex / normal arrays cross the boundary once, with the run's index triples and
+            # per-triangle materials — what trace.jl_amd/api.py does for the same object graph.
             mesh = shape.mesh
-            verts = reinterpret(Float32, mesh.vertices) |> collect           # already world space (triangle_mesh.jl:23)
-            idx = UInt32[mesh.indices[shape.i+j] for j in 0:2]                # 1-based
-            nrm = mesh.normals === nothing ? C_NULL : collect(reinterpret(Float32, mesh.normals))
+            (mesh.uv === nothing && mesh.tangents === nothing) ||
+                error("TraceHIP: TriangleMesh.uv / .tangents are not carried across the C ABI (no scene of the reference sets them)")
             flip = shape.core.reverse_orientation ⊻ shape.core.transform_swaps_handedness
+            j = i
+            idx = UInt32[]
+            mats = UInt32[]
+            while j <= length(prims) && prims[j].shape isa Trace.Triangle && prims[j].shape.mesh === mesh &&
+                  (prims[j].shape.core.reverse_orientation ⊻ prims[j].shape.core.transform_swaps_handedness) == flip
+                t = prims[j].shape
+                append!(idx, (mesh.indices[t.i], mesh.indices[t.i+1], mesh.indices[t.i+2]))   # 1-based, as the ABI wants them
+                push!(mats, material_id(prims[j].material))
+                j += 1
+            end
+            verts = collect(reinterpret(Float32, mesh.vertices))          # already world space (triangle_mesh.jl:23)
+            nrm = mesh.normals === nothing ? C_NULL : collect(reinterpret(Float32, mesh.normals))
             check(ccall((:trhip_scene_add_triangles, LIB), Cint,
                 (Ptr{Cvoid}, Ptr{Float32}, UInt32, Ptr{UInt32}, UInt32, Ptr{Float32}, Ptr{UInt32}, Cint, Ptr{UInt32}),
-                s, verts, mesh.n_vertices, idx, 1, nrm, UInt32[material_id(p.material)], flip, C_NULL))
+                s, verts, mesh.n_vertices, idx, length(mats), nrm, mats, flip, C_NULL))
+            i = j
         else
             error("TraceHIP: unsupported shape $(typeof(shape))")
         end
@@ -161,6 +198,45 @@ struct PathIntegrator <: Trace.SamplerIntegrator
     max_depth::Int64
 end
 
+# ---- multi-GPU jobs (include/tracehip.h "multi-GPU"): one Julia process per GPU ----------------------------------------------
+# RANK / WORLD_SIZE / LOCAL_RANK in the environment (any launcher); rank 0 writes the 128-byte RCCL id to TRACEHIP_ID_FILE, the
+# others read it: trhip_comm_init.  Then every rank renders its share of the samples (`sample_offset`) and trhip_film_reduce sums
+# the film accumulators onto rank 0, which alone writes the image; SPPM shards its photons inside trhip_render_sppm.
+const JOB = Ref{Tuple{Int,Int}}((0, 1))
+function init_job!(; rank = parse(Int, get(ENV, "RANK", "0")), world = parse(Int, get(ENV, "WORLD_SIZE", "1")), id_file = get(ENV, "TRACEHIP_ID_FILE", ""))
+    world <= 1 && return JOB[]
+    isempty(id_file) && error("TraceHIP: set TRACEHIP_ID_FILE to a path all ranks can reach")
+    id = Vector{UInt8}(undef, 128)
+    if rank == 0
+        check(ccall((:trhip_comm_unique_id, LIB), Cint, (Ptr{UInt8},), id))
+        write(id_file * ".tmp", id)
+        mv(id_file * ".tmp", id_file; force = true)
+    else
+        while !isfile(id_file)
+            sleep(0.05)
+        end
+        id = read(id_file)
+    end
+    check(ccall((:trhip_comm_init, LIB), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Cint, Cint), context(), id, rank, world))
+    JOB[] = (rank, world)
+end
+# the `spp` samples of one frame split over the ranks: (spp of this rank, first global sample index)
+function shard_samples(spp::Integer)
+    rank, world = JOB[]
+    base, rem = divrem(spp, world)
+    (base + (rank < rem ? 1 : 0), rank * base + min(rank, rem))
+end
+
+function write_film!(film, out, h, w; clear_splat = false)
+    @inbounds for y in 1:h, x in 1:w            # film.pixels is (y, x); out is row-major over (y, x)
+        k = 4 * ((y - 1) * w + (x - 1))
+        px = film.pixels[y, x]
+        px.xyz = Point3f(out[k+1], out[k+2], out[k+3])
+        px.filter_weight_sum = out[k+4]
+        clear_splat && (px.splat_xyz = Point3f(0f0))
+    end
+end
+
 function render!(entry::Symbol, i, scene::Trace.Scene)
     film = Trace.get_film(i.camera)
     s = flatten(scene)
@@ -169,17 +245,28 @@ function render!(entry::Symbol, i, scene::Trace.Scene)
     out = Vector{Float32}(undef, 4 * h * w)
     stats = TrhipStats()
     seed, offset = seed_of(i.sampler)
-    rc = ccall((entry, LIB), Cint,
-        (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{TrhipSensor}, UInt32, Cint, UInt64, UInt32, Ptr{Float32}, Ptr{TrhipStats}),
-        context(), s, sn, i.sampler.samples_per_pixel, i.max_depth, seed, offset, out, Ref(stats))
+    rank, world = JOB[]
+    spp, first = world > 1 ? shard_samples(i.sampler.samples_per_pixel) : (i.sampler.samples_per_pixel, 0)
+    if world > 1
+        # device-resident film, summed over the ranks by the library (ncclReduce), then copied out on rank 0
+        d_film = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:hipMalloc, "libamdhip64"), Cint, (Ptr{Ptr{Cvoid}}, Csize_t), d_film, sizeof(out)))
+        rc = ccall((Symbol(entry, :_device), LIB), Cint,
+            (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{TrhipSensor}, UInt32, Cint, UInt64, UInt32, Ptr{Cvoid}, Ptr{TrhipStats}),
+            context(), s, sn, max(spp, 1), i.max_depth, seed, offset + first, d_film[], Ref(stats))
+        rc == 0 && spp == 0 && ccall((:hipMemset, "libamdhip64"), Cint, (Ptr{Cvoid}, Cint, Csize_t), d_film[], 0, sizeof(out))
+        rc == 0 && (rc = ccall((:trhip_film_reduce, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, UInt64, Cint), context(), d_film[], h * w, 0))
+        rc == 0 && rank == 0 && ccall((:hipMemcpy, "libamdhip64"), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Cint), out, d_film[], sizeof(out), 2)
+        ccall((:hipFree, "libamdhip64"), Cint, (Ptr{Cvoid},), d_film[])
+    else
+        rc = ccall((entry, LIB), Cint,
+            (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{TrhipSensor}, UInt32, Cint, UInt64, UInt32, Ptr{Float32}, Ptr{TrhipStats}),
+            context(), s, sn, spp, i.max_depth, seed, offset, out, Ref(stats))
+    end
     ccall((:trhip_scene_free, LIB), Cvoid, (Ptr{Cvoid},), s)
     check(rc)
-    @inbounds for y in 1:h, x in 1:w            # film.pixels is (y, x); out is row-major over (y, x)
-        k = 4 * ((y - 1) * w + (x - 1))
-        px = film.pixels[y, x]
-        px.xyz = Point3f(out[k+1], out[k+2], out[k+3])
-        px.filter_weight_sum = out[k+4]
-    end
+    rank == 0 || return nothing
+    write_film!(film, out, h, w)
     Trace.save(film)
 end
 
@@ -199,13 +286,8 @@ function render_sppm!(i::Trace.SPPMIntegrator, scene::Trace.Scene; seed::Integer
         context(), s, sn, i.initial_search_radius, i.max_depth, i.n_iterations, i.photons_per_iteration, UInt64(seed), out, Ref(stats))
     ccall((:trhip_scene_free, LIB), Cvoid, (Ptr{Cvoid},), s)
     check(rc)
-    @inbounds for y in 1:h, x in 1:w
-        k = 4 * ((y - 1) * w + (x - 1))
-        px = film.pixels[y, x]
-        px.xyz = Point3f(out[k+1], out[k+2], out[k+3])
-        px.filter_weight_sum = out[k+4]          # 1 after set_image!
-        px.splat_xyz = Point3f(0f0)
-    end
+    JOB[][1] == 0 || return nothing                 # with a communicator every rank holds the whole image; rank 0 writes it
+    write_film!(film, out, h, w; clear_splat = true)  # filter_weight_sum = 1 after set_image!
     Trace.save(film)
 end
 # Opt-in replacement of the CPU loop for SPPMIntegrator (shadows integrators/sppm.jl:132):
