@@ -23,24 +23,14 @@ class DryReplay(jr.ShimReplay):
     def __init__(self, T):
         self.T = T
         self.ccalls = jr.parse_ccalls()
-        self.ctx = None
+        import ctypes as C
+        self.ctx = C.c_void_p(1)
         self.log = []
         self._keep = []
         self._next_material = 0
 
     def call(self, fn, *args, which=0):
-        import ctypes as C
-        import numpy as np
-        desc = []
-        for a in args:
-            if isinstance(a, np.ndarray):
-                desc.append(f"{a.dtype}{list(a.shape)}")
-            elif a is None:
-                desc.append("C_NULL")
-            elif isinstance(a, (int, float)) and not isinstance(a, bool):
-                desc.append(repr(a) if not isinstance(a, float) else repr(float(np.float32(a))))
-            else:
-                desc.append("ref")
+        desc = [jr.describe(a) for a in args]
         self.log.append([fn] + desc)
         if fn == "trhip_scene_add_material":
             args[-1]._obj.value = self._next_material

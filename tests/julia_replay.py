@@ -135,6 +135,21 @@ def spot_fields(T, l):
     return float(T._ffi.detmath(1, deg2rad(l.total_width))[0]), float(T._ffi.detmath(1, deg2rad(l.falloff_start))[0])
 
 
+def describe(a):
+    """How an argument appears in the call log / manifest: array dtype and shape, scalars by value, handles and references by kind."""
+    if isinstance(a, np.ndarray):
+        return f"{a.dtype}{list(a.shape)}"
+    if a is None:
+        return "C_NULL"
+    if isinstance(a, C.c_void_p):
+        return "handle"
+    if isinstance(a, (C.Structure, C._SimpleCData)) or hasattr(a, "_obj"):
+        return "ref"
+    if isinstance(a, float):
+        return repr(float(np.float32(a)))
+    return repr(a)
+
+
 class ShimReplay:
     """TraceHIP.flatten / sensor / render! for a trace_jl_amd scene, call for call, through the shim's own ccall signatures."""
 
@@ -150,21 +165,13 @@ class ShimReplay:
         ret, argtypes = ctypes_sig(self.ccalls[fn][which])
         f = getattr(self.lib, fn)
         f.restype, f.argtypes = ret, argtypes
-        conv, desc = [], []
+        conv, desc = [], [describe(a) for a in args]
         for a in args:
             if isinstance(a, np.ndarray):
                 self._keep.append(a)
                 conv.append(a.ctypes.data_as(C.c_void_p))
-                desc.append(f"{a.dtype}{list(a.shape)}")
-            elif a is None:
-                conv.append(None)
-                desc.append("C_NULL")
-            elif isinstance(a, (C.Structure, C._SimpleCData)) or hasattr(a, "_obj"):
-                conv.append(a)
-                desc.append("ref")
             else:
                 conv.append(a)
-                desc.append(repr(a) if not isinstance(a, float) else repr(float(np.float32(a))))
         self.log.append([fn] + desc)
         rc = f(*conv)
         if ret is C.c_int and rc != 0:
