@@ -93,8 +93,9 @@ def ray_set(T, ob, n_incoherent):
 
 
 def check_traversals(T, ob, ctx, scene, n_incoherent, expect_prims, chain):
-    """chain: commit the scene's spheres as a chain of leaves above the triangles (option compose_spheres), the tree k_trace8 walks;
-    otherwise one SAH tree over everything (the default), where traversal 4 falls back to k_trace3 when the scene has spheres."""
+    """chain: commit the scene the way traversal 4 needs it (option compose_spheres = 1: spheres as a chain of leaves above the triangles,
+    one primitive per leaf); otherwise the default tree (one SAH tree over everything, triangles with coincident centroids sharing a
+    leaf), where traversal 4 falls back to k_trace3."""
     ctx.set_option("compose_spheres", 1 if chain else 0)
     try:
         flat = scene.flatten(ctx)
@@ -163,7 +164,7 @@ def test_mesh_1m_all_traversals_and_oracle(T, ob, ctx, chain):
 def test_blob_870k_all_traversals_and_oracle(T, ob, ctx):
     """BASELINE configs[2] stand-in: a closed 874 800-triangle object in the Cornell walls (no spheres)."""
     scene = T.scenes.blob_scene(270)
-    _, osc = check_traversals(T, ob, ctx, scene, 1 << 21, 12 * 270 * 270 + 10, False)
+    _, osc = check_traversals(T, ob, ctx, scene, 1 << 21, 12 * 270 * 270 + 10, True)  # commit for traversal 4: one primitive per leaf
     ran = check_frame(T, ob, ctx, scene, osc)
     assert ran[4] == 4 and ran[3] == 3
 

@@ -48,8 +48,11 @@ struct FlatBVH {
 
 class BVHBuilder {
    public:
-    BVHBuilder(const std::vector<HostAABB>& prim_bounds, int max_node_prims, uint32_t tiny_scene = 16)
-        : pb_(prim_bounds), max_leaf_(std::max(1, std::min(255, max_node_prims))), tiny_(std::min(255u, tiny_scene)) {}
+    // split_coincident: primitives whose centroids coincide (the two triangles of an axis-aligned quad) are still split down to the
+    // leaf-size hint — one primitive per leaf for BVHAccel(prims, 1), what the 8-wide view needs (th_wide8.h); otherwise they share
+    // a leaf like in the reference (bvh.jl:113-118), which the binary kernels walk faster (fewer nodes)
+    BVHBuilder(const std::vector<HostAABB>& prim_bounds, int max_node_prims, uint32_t tiny_scene = 16, bool split_coincident = false)
+        : pb_(prim_bounds), max_leaf_(std::max(1, std::min(255, max_node_prims))), tiny_(std::min(255u, tiny_scene)), split_coincident_(split_coincident) {}
 
     FlatBVH build() {
         const uint32_t n = (uint32_t)pb_.size();
@@ -79,6 +82,7 @@ class BVHBuilder {
     const std::vector<HostAABB>& pb_;
     int max_leaf_;
     uint32_t tiny_;
+    bool split_coincident_;
     std::vector<uint32_t> idx_;
     std::vector<float> cen_;
     FlatBVH out_;
@@ -170,7 +174,7 @@ class BVHBuilder {
         if (best_axis < 0) {  // all centroids coincide: the reference makes a leaf (bvh.jl:113-118); so does this builder up to the leaf-size hint,
                               // beyond it the set is halved by index (same boxes on both sides) so that the hint holds: with
                               // max_node_primitives = 1 every leaf holds ONE primitive, what the 8-wide view needs (th_wide8.h)
-            if ((int)n <= max_leaf_ || depth >= 60) {
+            if (!split_coincident_ || (int)n <= max_leaf_ || depth >= 60 || n > 255u) {
                 make_leaf(out, node, lo, hi);
                 return;
             }

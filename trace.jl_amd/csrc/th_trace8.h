@@ -235,10 +235,13 @@ __global__ __launch_bounds__(kBlock, ANY ? TH_TRACE8_WAVES_ANY : TH_TRACE8_WAVES
             bool to_fallback = false;
             if (!exhausted && n_idle) {
                 if (pool_next >= pool_end) {
-                    uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(&work[wseg * kCtrStride], (uint32_t)kChunk);
-                    base = __builtin_amdgcn_readfirstlane(base);
+                    // an empty segment, or one whose cursor already ran past its count, needs no atomic: the waves that arrive when the queue is
+                    // drained (all of them, at the end of every launch) would otherwise queue 32 returning atomics each on the same 32 words
                     const uint32_t cnt = __builtin_amdgcn_readfirstlane(sv.count[wseg]);
+                    uint32_t base = cnt;
+                    if (lane == 0 && cnt != 0u && __hip_atomic_load(&work[wseg * kCtrStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < cnt)
+                        base = atomicAdd(&work[wseg * kCtrStride], (uint32_t)kChunk);
+                    base = __builtin_amdgcn_readfirstlane(base);
                     if (base < cnt) {
                         pool_next = base;
                         pool_end = min(base + (uint32_t)kChunk, cnt);

@@ -2079,7 +2079,7 @@ int trhip_scene_commit(trhip_scene* s, int max_node_primitives) {
         }
     }
     if (!built) {
-        BVHBuilder builder(pb_build, max_node_primitives, s->ctx->tiny_scene_prims);
+        BVHBuilder builder(pb_build, max_node_primitives, s->ctx->tiny_scene_prims, want_chain);  // traversal 4 wants one primitive per leaf
         s->bvh = builder.build();
     }
     if (compose) {
