@@ -169,6 +169,50 @@ def test_blob_870k_all_traversals_and_oracle(T, ob, ctx):
     assert ran[4] == 4 and ran[3] == 3
 
 
+def test_mesh_10m_c5_geometry(T, ob, ctx):
+    """BASELINE configs[4]'s geometry and frame size on one GPU: the 10 488 200-triangle height field (+ Cornell box, 2 spheres), closest-hit
+    and any-hit results of the default kernel against the literal accel/bvh.jl loop on 2^20 + mixed rays and against the oracle on a
+    subsample; then a 4096 x 4096 frame at depth 16 (one sample per pixel: the oracle cannot render it, the literal kernel can) must be
+    the same film bit for bit with either kernel, and the two halves of a 2-sample frame must add up to it (sample-index sharding)."""
+    n = T.scenes.MESH_N["mesh_10m"]
+    scene = T.scenes.mesh_scene(n)
+    flat = scene.flatten(ctx)
+    bvh = flat.bvh()
+    assert bvh[3].size == 2 * n * n + 12
+    rays, sub = ray_set(T, ob, 1 << 19)
+    sub = sub[::4]
+    got = {}
+    for trav in (3, 1):
+        ctx.set_option("traversal", trav)
+        try:
+            got[trav] = (flat.trace_closest(rays), flat.trace_any(rays))
+        finally:
+            ctx.set_option("traversal", 3)
+    assert np.array_equal(got[3][0]["prim"], got[1][0]["prim"])
+    for f in ("t", "b1", "b2"):
+        assert_bits_equal(got[3][0][f], got[1][0][f], f"10 M triangles, closest-hit {f}")
+    assert np.array_equal(got[3][1], got[1][1])
+    osc = ob.OracleScene.from_scene(scene, bvh=bvh)
+    t, prim, _, _ = osc.trace_closest(rays[sub])
+    assert np.array_equal(got[1][0]["prim"][sub], prim)
+    assert_bits_equal(got[1][0]["t"][sub], t, "10 M triangles, t vs oracle")
+    assert np.array_equal(got[1][1][sub], osc.trace_any(rays[sub])[0])
+    del osc
+    cam = T.scenes.cornell_camera(4096)
+    films = {}
+    for trav in (3, 1):
+        ctx.set_option("traversal", trav)
+        try:
+            films[trav] = T.PathIntegrator(cam, T.SeededSampler(1, seed=0x5EED0001), 16).render(scene, ctx).copy()
+        finally:
+            ctx.set_option("traversal", 3)
+    assert films[3].shape == (4096, 4096, 4) and np.isfinite(films[3]).all() and films[3][..., 3].min() > 0
+    assert_bits_equal(films[3], films[1], "4096 x 4096, depth 16: default kernel vs the literal loop")
+    second = T.PathIntegrator(cam, T.SeededSampler(1, seed=0x5EED0001, sample_offset=1), 16).render(scene, ctx).copy()
+    both = T.PathIntegrator(cam, T.SeededSampler(2, seed=0x5EED0001), 16).render(scene, ctx)
+    np.testing.assert_allclose(films[3] + second, both, rtol=3e-5, atol=1e-5)
+
+
 def sppm_pair(T, ob, ctx, scene, cam, radius, depth, iters, seed):
     from test_gpu_sppm import check_pair, run_pair
     _, xyzw, got, ref = run_pair(T, ob, ctx, scene, cam, radius, depth, iters, -1, seed)
