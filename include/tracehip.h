@@ -266,6 +266,9 @@ int trhip_film_allreduce(trhip_ctx* ctx, void* d_xyzw, uint64_t n_pixels);
  * "film_tiled" (0/1): LDS-staged film gather (default 0: measured slower).
  * "film_transpose" (0/1): film pass on pixel-group-major copies of the per-sample radiance / film positions (default 0: no gain).
  * "leaf_kernel" (0/1): one-leaf scenes (tiny_scene_prims) run the dedicated uniform-walk kernel instead of traversal 2 (default 1).
+ * "band_tile_rows": PathIntegrator frames whose per-sample buffers (24 B per camera sample) do not fit in HBM are rendered in bands of
+ *     whole 16-row tile rows into the same film — bit-identical to one band (tiles reach a film pixel in the reference's order either
+ *     way); this option forces bands of N tile rows (tests; 0 = automatic).  trhip_last_sample_radiance needs a one-band frame.
  * "debug_trace_budget": DIAGNOSTIC ONLY, traversal abandons rays after this many node fetches (results wrong). */
 int trhip_set_option(trhip_ctx* ctx, const char* name, int64_t value);
 

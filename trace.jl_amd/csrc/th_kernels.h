@@ -129,13 +129,13 @@ struct SlotInfo {
     uint32_t sample;  // sample index within this render call
 };
 TH_D SlotInfo slot_info(const DeviceSensor& se, uint32_t slot) {
-    const uint32_t npix = (uint32_t)(se.sb_w * se.sb_h);
+    const uint32_t npix = (uint32_t)(se.sb_w * se.band_rows);  // slots, like the radiance buffer, cover the band being rendered (the whole frame normally)
     SlotInfo r;
     r.sample = slot / npix;
     r.pix = slot - r.sample * npix;
     const uint32_t y = r.pix / (uint32_t)se.sb_w;
     r.px = se.sb_min[0] + (int)(r.pix - y * (uint32_t)se.sb_w);
-    r.py = se.sb_min[1] + (int)y;
+    r.py = se.band_y0 + (int)y;
     return r;
 }
 
@@ -651,14 +651,14 @@ __global__ __launch_bounds__(kBlock) void k_film_positions(const DeviceSensor* _
     for (uint64_t slot = (uint64_t)blockIdx.x * kBlock + threadIdx.x; slot < n; slot += (uint64_t)gridDim.x * kBlock) {
         const SlotInfo si = slot_info(se, (uint32_t)slot);
         const uint64_t key = ts_stream_key(seed, si.px, si.py, sample_offset + si.sample);
-        pfilm[film_index(layout, (uint32_t)(se.sb_w * se.sb_h), spp, si.sample, si.pix)] = make_float2((float)si.px + ts_uniform(key, TS_DIM_FILM_X), (float)si.py + ts_uniform(key, TS_DIM_FILM_Y));
+        pfilm[film_index(layout, (uint32_t)(se.sb_w * se.band_rows), spp, si.sample, si.pix)] = make_float2((float)si.px + ts_uniform(key, TS_DIM_FILM_X), (float)si.py + ts_uniform(key, TS_DIM_FILM_Y));
     }
 }
 __global__ __launch_bounds__(kBlock) void k_film_gather(const DeviceSensor* __restrict__ sep, const float* __restrict__ table, const float4* __restrict__ L,
                                                         const float2* __restrict__ pfilm, uint32_t spp, uint32_t layout, float4* __restrict__ out) {
     const DeviceSensor& se = *sep;
     const uint32_t npx = (uint32_t)(se.film_w * se.film_h);
-    const uint32_t npix = (uint32_t)(se.sb_w * se.sb_h);
+    const uint32_t npix = (uint32_t)(se.sb_w * se.band_rows);
     const float rx = se.filter_radius[0], ry = se.filter_radius[1];
     const float inv_rx = 1.0f / rx, inv_ry = 1.0f / ry;
     for (uint32_t idx = blockIdx.x * kBlock + threadIdx.x; idx < npx; idx += gridDim.x * kBlock) {
@@ -673,8 +673,13 @@ __global__ __launch_bounds__(kBlock) void k_film_gather(const DeviceSensor* __re
         sy_hi = min(sy_hi, se.sb_max[1]);
         f3 xyz = splat3(0.0f);
         float wsum = 0.0f;
+        if (se.accumulate) {  // a later band of the frame: its tiles are added, in k order, onto the tiles of the bands before
+            const float4 prev = out[idx];
+            xyz = mk3(prev.x, prev.y, prev.z);
+            wsum = prev.w;
+        }
         if (sx_lo <= sx_hi && sy_lo <= sy_hi) {
-            const int ty_lo = (sy_lo - se.sb_min[1]) >> 4, ty_hi = (sy_hi - se.sb_min[1]) >> 4;
+            const int ty_lo = max((sy_lo - se.sb_min[1]) >> 4, se.band_ty0), ty_hi = min((sy_hi - se.sb_min[1]) >> 4, se.band_ty1);
             const int tx_lo = (sx_lo - se.sb_min[0]) >> 4, tx_hi = (sx_hi - se.sb_min[0]) >> 4;
             for (int ty = ty_lo; ty <= ty_hi; ++ty)
                 for (int tx = tx_lo; tx <= tx_hi; ++tx) {
@@ -690,7 +695,7 @@ __global__ __launch_bounds__(kBlock) void k_film_gather(const DeviceSensor* __re
                     const int x0 = max(sx_lo, (int)tbx0), x1 = min(sx_hi, (int)tbx1);
                     for (int sy = y0; sy <= y1; ++sy)
                         for (int sx = x0; sx <= x1; ++sx) {
-                            const uint32_t pix = (uint32_t)(sy - se.sb_min[1]) * (uint32_t)se.sb_w + (uint32_t)(sx - se.sb_min[0]);
+                            const uint32_t pix = (uint32_t)(sy - se.band_y0) * (uint32_t)se.sb_w + (uint32_t)(sx - se.sb_min[0]);
                             for (uint32_t s = 0; s < spp; ++s) {
                                 const float2 pf = pfilm[film_index(layout, npix, spp, s, pix)];  // camera_sample.film, from k_film_positions
                                 const float dpx = pf.x - 0.5f, dpy = pf.y - 0.5f;
@@ -744,7 +749,7 @@ __global__ __launch_bounds__(kBlock) void k_film_gather_block(const DeviceSensor
     __shared__ float s_table[256];
     for (uint32_t t = threadIdx.x; t < 256u; t += kBlock) s_table[t] = table[t];
     __syncthreads();
-    const uint32_t npix = (uint32_t)(se.sb_w * se.sb_h);
+    const uint32_t npix = (uint32_t)(se.sb_w * se.band_rows);
     const float rx = se.filter_radius[0], ry = se.filter_radius[1];
     const float inv_rx = 1.0f / rx, inv_ry = 1.0f / ry;
     const uint32_t nbx = ((uint32_t)se.film_w + BX - 1) / BX, nby = ((uint32_t)se.film_h + BY - 1) / BY;
@@ -762,9 +767,14 @@ __global__ __launch_bounds__(kBlock) void k_film_gather_block(const DeviceSensor
             for (int i = 0; i < BX; ++i) {
                 xyz[j][i] = splat3(0.0f);
                 wsum[j][i] = 0.0f;
+                if (se.accumulate && fx0 + i < se.film_w && fy0 + j < se.film_h) {  // a later band: add onto the tiles of the bands before (k order)
+                    const float4 prev = out[(size_t)(fy0 + j) * (size_t)se.film_w + (size_t)(fx0 + i)];
+                    xyz[j][i] = mk3(prev.x, prev.y, prev.z);
+                    wsum[j][i] = prev.w;
+                }
             }
         if (sx_lo <= sx_hi && sy_lo <= sy_hi) {
-            const int ty_lo = (sy_lo - se.sb_min[1]) >> 4, ty_hi = (sy_hi - se.sb_min[1]) >> 4;
+            const int ty_lo = max((sy_lo - se.sb_min[1]) >> 4, se.band_ty0), ty_hi = min((sy_hi - se.sb_min[1]) >> 4, se.band_ty1);
             const int tx_lo = (sx_lo - se.sb_min[0]) >> 4, tx_hi = (sx_hi - se.sb_min[0]) >> 4;
             for (int ty = ty_lo; ty <= ty_hi; ++ty)
                 for (int tx = tx_lo; tx <= tx_hi; ++tx) {
@@ -791,7 +801,7 @@ __global__ __launch_bounds__(kBlock) void k_film_gather_block(const DeviceSensor
                     const int x0 = max(sx_lo, (int)tbx0), x1 = min(sx_hi, (int)tbx1);
                     for (int sy = y0; sy <= y1; ++sy)
                         for (int sx = x0; sx <= x1; ++sx) {
-                            const uint32_t pix = (uint32_t)(sy - se.sb_min[1]) * (uint32_t)se.sb_w + (uint32_t)(sx - se.sb_min[0]);
+                            const uint32_t pix = (uint32_t)(sy - se.band_y0) * (uint32_t)se.sb_w + (uint32_t)(sx - se.sb_min[0]);
                             // kFilmUnroll samples per trip: their p_film and L loads are issued together (the gather is a chain of
                             // dependent trips otherwise), then they are splatted one after the other, in sample order
                             auto splat = [&](float2 pf, float4 l4) {

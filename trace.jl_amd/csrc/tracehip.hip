@@ -63,6 +63,7 @@ struct trhip_ctx {
     bool leaf_kernel = true;         // one-leaf scenes run k_trace_leaf instead of k_trace2 (option "leaf_kernel", for A/B)
     int slab_margin_log2 = 14;       // k_trace2 / k_trace3 add the slab clauses the reference's box test lost, on boxes grown by 2^-this x the ray's reach
                                      // (th_trace2.h, slab_test2); 0 = the reference's loose test alone (its exact visit set)
+    int band_tile_rows = 0;          // DIAGNOSTIC / tests: render frames in bands of this many tile rows (0 = one band unless the samples do not fit in HBM)
     uint32_t tiny_scene_prims = 16;  // scenes of at most this many primitives get a single-leaf BVH (th_bvh.h); 0 = always build the hierarchy
     int film_block = 2;  // film gather: 0 = one film pixel per thread, 1 = 2 x 2 pixels per thread, 2 = TH_FILM_BX x TH_FILM_BY = 1 x 4 (default)
     bool film_tiled = false;  // LDS-staged film gather (k_film_gather_tiled): bit-identical, measured 2.7x SLOWER than k_film_gather (11 % lane use), kept as an option
@@ -575,6 +576,11 @@ void derive_sensor(const trhip_sensor* sn, DeviceSensor& d) {
     d.film_h = (int)std::fabs(sn->crop_max[1] - (sn->crop_min[1] - 1.0f));
     d.tiles_x = (int)std::floor(((float)(d.sb_max[0] - d.sb_min[0]) + 16.0f) / 16.0f);
     d.tiles_y = (int)std::floor(((float)(d.sb_max[1] - d.sb_min[1]) + 16.0f) / 16.0f);
+    d.band_y0 = d.sb_min[1];  // one band: the whole frame
+    d.band_rows = d.sb_h;
+    d.band_ty0 = 0;
+    d.band_ty1 = d.tiles_y - 1;
+    d.accumulate = 0;
 }
 
 // Film accumulation: positions, then the LDS-tiled gather (falls back to the per-pixel gather when a 16x16 film tile is reached
@@ -587,17 +593,18 @@ void launch_film(trhip_ctx* ctx, hipStream_t st, const DeviceSensor& ds, const D
                  float4* d_film) {
     // pixel-group-major inputs for the gather (th_kernels.h, film_index): p_film is written that way, L is re-laid into a second buffer
     // (the frame's radiance, 16 B per sample, once more); without room for it the gather reads the sample-major arrays as before
-    const uint32_t npix = (uint32_t)(ds.sb_w * ds.sb_h);
+    const uint32_t npix = (uint32_t)(ds.sb_w * ds.band_rows);
     const uint64_t padded = (uint64_t)((npix + 63u) / 64u) * 64u * spp;
     uint32_t layout = 0;
-    if (ctx->film_transpose && spp > 1 && total_slots == (uint64_t)npix * spp && ensure(ctx, ctx->pfilm, padded * sizeof(float2)) == 0 && ensure(ctx, ctx->film_Lt, padded * sizeof(float4)) == 0) {
+    const bool whole = ds.band_rows == ds.sb_h;
+    if (whole && ctx->film_transpose && spp > 1 && total_slots == (uint64_t)npix * spp && ensure(ctx, ctx->pfilm, padded * sizeof(float2)) == 0 && ensure(ctx, ctx->film_Lt, padded * sizeof(float4)) == 0) {
         layout = 1;
         hipLaunchKernelGGL(k_film_transpose, dim3(grid_for(ctx, padded, 8)), dim3(kBlock), 0, st, L, npix, spp, (float4*)ctx->film_Lt.p);
         L = (const float4*)ctx->film_Lt.p;
     }
     hipLaunchKernelGGL(k_film_positions, dim3(grid_for(ctx, total_slots, 8)), dim3(kBlock), 0, st, dsp, total_slots, seed, sample_offset, (float2*)ctx->pfilm.p, layout, spp);
     const float rmax = std::fmax(ds.filter_radius[0], ds.filter_radius[1]);
-    if (ctx->film_tiled && rmax <= 6.0f) {  // reach of a pixel = 2r + 3 sample pixels <= 16: at most 2 x 2 sample tiles
+    if (whole && ctx->film_tiled && rmax <= 6.0f) {  // reach of a pixel = 2r + 3 sample pixels <= 16: at most 2 x 2 sample tiles
         const uint32_t budget = 24 * 1024 / 20;  // staged {p_film, L} elements in 24 KiB of LDS: ~6 blocks per CU
         const uint32_t nc_max = 16 + 2 * (uint32_t)std::ceil(rmax) + 4;
         uint32_t cols, ns;
@@ -1188,8 +1195,10 @@ int render_stream_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sen
     return 0;
 }
 
-int render_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sensor* sensor, int integrator, uint32_t spp, int max_depth, uint64_t seed,
-                uint32_t sample_offset, void* out, bool out_is_device, trhip_stats* stats) {
+// One band of a frame (band == nullptr: the whole frame, the normal case).  A band is a range of whole tile rows; its DeviceSensor carries
+// the range and whether the film gather starts from zero or adds onto the bands before (th_scene.h).
+int render_impl_band(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sensor* sensor, int integrator, uint32_t spp, int max_depth, uint64_t seed, uint32_t sample_offset, void* out,
+                     bool out_is_device, trhip_stats* stats, const DeviceSensor* band) {
     if (!ctx || !scene || !sensor || !out) return fail(ctx, TRHIP_ERR_INVALID, "null argument");
     if (!scene->committed) return fail(ctx, TRHIP_ERR_INVALID, "scene not committed");
     if (integrator != 0 && integrator != 1) return fail(ctx, TRHIP_ERR_INVALID, "unknown integrator %d", integrator);
@@ -1201,11 +1210,14 @@ int render_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sensor* se
     if (spp == 0 || max_depth < 1 || max_depth > kMaxDepth) return fail(ctx, TRHIP_ERR_INVALID, "spp must be >= 1 and max_depth in 1..%d", kMaxDepth);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     DeviceSensor ds;
-    derive_sensor(sensor, ds);
+    if (band)
+        ds = *band;
+    else
+        derive_sensor(sensor, ds);
     if (ds.film_w <= 0 || ds.film_h <= 0 || ds.sb_w <= 0 || ds.sb_h <= 0) return fail(ctx, TRHIP_ERR_INVALID, "empty film");
-    const uint64_t npix = (uint64_t)ds.sb_w * ds.sb_h;
+    const uint64_t npix = (uint64_t)ds.sb_w * ds.band_rows;
     const uint64_t total_slots = npix * spp;
-    if (total_slots >= (1ull << 32)) return fail(ctx, TRHIP_ERR_UNSUPPORTED, "more than 2^32 camera samples in one call: split spp over calls/ranks");
+    if (total_slots >= (1ull << 32)) return fail(ctx, TRHIP_ERR_UNSUPPORTED, "more than 2^32 camera samples in one band of a frame");
     if (integrator == 0) {
         if (int rc = upload(ctx, ctx->sensor, &ds, sizeof ds)) return rc;
         if (int rc = upload(ctx, ctx->table, sensor->filter_table, 256 * sizeof(float))) return rc;
@@ -1239,7 +1251,7 @@ int render_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sensor* se
         }
         return 0;
     }
-    if ((ctx->streaming == 1 || (ctx->streaming < 0 && total_slots <= 96ull * scene->prims.size())) && ctx->traversal >= 2 && scene->wide_ok && scene->wide.root_cnt == 0 && scene->wide.root_ref != kRefNone && ctx->batch_paths == 0 && ctx->pipelines <= 1) {
+    if (!band && (ctx->streaming == 1 || (ctx->streaming < 0 && total_slots <= 96ull * scene->prims.size())) && ctx->traversal >= 2 && scene->wide_ok && scene->wide.root_cnt == 0 && scene->wide.root_ref != kRefNone && ctx->batch_paths == 0 && ctx->pipelines <= 1) {
         bool declined = false;
         const int rc = render_stream_impl(ctx, scene, sensor, ds, spp, max_depth, seed, sample_offset, out, out_is_device, stats, &declined);
         if (!declined) return rc;
@@ -1406,6 +1418,85 @@ int render_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sensor* se
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     (void)hipEventDestroy(ev_start);
+    return 0;
+}
+
+// A frame: one band when its per-sample buffers (radiance 16 B + film position 8 B per camera sample) fit in HBM next to the queues — every
+// BASELINE configuration up to 1024^2 x 256 spp does — otherwise bands of whole tile rows, rendered one after the other into the same film.
+// The film is the sequential tile loop's bit for bit either way: a film pixel receives its tiles in k order (integrators/sampler.jl:24-52,
+// film.jl:182-193), and bands are ranges of k.  (4096^2 x 1024 spp, BASELINE configs[4], is 412 GB of samples: 3 bands on one MI355X.)
+int render_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sensor* sensor, int integrator, uint32_t spp, int max_depth, uint64_t seed, uint32_t sample_offset, void* out,
+                bool out_is_device, trhip_stats* stats) {
+    if (!ctx || !scene || !sensor || !out) return fail(ctx, TRHIP_ERR_INVALID, "null argument");
+    DeviceSensor ds;
+    derive_sensor(sensor, ds);
+    int rows_per_band = ds.tiles_y;  // in tile rows
+    if (integrator == 1 && ds.sb_w > 0 && ds.sb_h > 0 && spp > 0) {
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        if (ctx->band_tile_rows > 0) {
+            rows_per_band = std::min<int>(ds.tiles_y, ctx->band_tile_rows);
+        } else {
+            size_t free_b = 0, total_b = 0;
+            HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
+            size_t held = ctx->Lbuf.bytes + ctx->pfilm.bytes;
+            for (auto& pp : ctx->pipes) {
+                held += pp.hits.bytes;
+                for (auto& a : pp.q)
+                    for (auto& b : a) held += b.bytes;
+                for (auto& b : pp.sq) held += b.bytes;
+            }
+            // half of what is free for the per-sample buffers, the rest for the wavefront queues (164 B per path in flight); 32-bit slot indices
+            const double budget = std::min(0.5 * (double)(free_b + held), 4.0e9 * 24.0);
+            const double row_bytes = (double)ds.sb_w * 16.0 * (double)spp * 24.0;
+            rows_per_band = (int)std::max(1.0, std::min((double)ds.tiles_y, std::floor(budget / row_bytes)));
+            while (rows_per_band > 1 && (uint64_t)ds.sb_w * 16ull * (uint64_t)rows_per_band * spp >= (1ull << 32)) --rows_per_band;
+        }
+    }
+    if (rows_per_band >= ds.tiles_y) return render_impl_band(ctx, scene, sensor, integrator, spp, max_depth, seed, sample_offset, out, out_is_device, stats, nullptr);
+    const size_t film_bytes = (size_t)ds.film_w * ds.film_h * sizeof(float4);
+    void* d_film = out;
+    if (!out_is_device) {
+        if (int rc = ensure(ctx, ctx->film, film_bytes)) return rc;
+        d_film = ctx->film.p;
+    }
+    trhip_stats sum;
+    std::memset(&sum, 0, sizeof sum);
+    uint32_t n_bands = 0;
+    for (int t0 = 0; t0 < ds.tiles_y; t0 += rows_per_band, ++n_bands) {
+        DeviceSensor b = ds;
+        b.band_ty0 = t0;
+        b.band_ty1 = std::min(ds.tiles_y, t0 + rows_per_band) - 1;
+        b.band_y0 = ds.sb_min[1] + 16 * t0;
+        b.band_rows = std::min(ds.sb_max[1], ds.sb_min[1] + 16 * b.band_ty1 + 15) - b.band_y0 + 1;
+        b.accumulate = t0 > 0 ? 1 : 0;
+        trhip_stats st;
+        if (int rc = render_impl_band(ctx, scene, sensor, integrator, spp, max_depth, seed, sample_offset, d_film, true, &st, &b)) return rc;
+        sum.camera_samples += st.camera_samples;
+        sum.closest_rays += st.closest_rays;
+        sum.shadow_rays += st.shadow_rays;
+        sum.nodes_visited += st.nodes_visited;
+        sum.prims_tested += st.prims_tested;
+        sum.nodes_visited_shadow += st.nodes_visited_shadow;
+        sum.prims_tested_shadow += st.prims_tested_shadow;
+        sum.ms_total += st.ms_total;
+        sum.ms_raygen += st.ms_raygen;
+        sum.ms_trace_closest += st.ms_trace_closest;
+        sum.ms_shade += st.ms_shade;
+        sum.ms_trace_any += st.ms_trace_any;
+        sum.ms_film += st.ms_film;
+        sum.launches_raygen += st.launches_raygen;
+        sum.launches_trace_closest += st.launches_trace_closest;
+        sum.launches_shade += st.launches_shade;
+        sum.launches_trace_any += st.launches_trace_any;
+        sum.launches_film += st.launches_film;
+        sum.n_batches += st.n_batches;
+        sum.max_depth_reached = st.max_depth_reached;
+        sum.traversal = st.traversal;
+        sum.node_bytes = st.node_bytes;
+    }
+    ctx->last_L_count = 0;  // trhip_last_sample_radiance describes whole frames only
+    if (!out_is_device) HIP_TRY(ctx, hipMemcpy(out, d_film, film_bytes, hipMemcpyDeviceToHost));
+    if (stats) *stats = sum;
     return 0;
 }
 
@@ -1868,6 +1959,8 @@ int trhip_set_option(trhip_ctx* ctx, const char* name, int64_t value) {
         ctx->bvh_builder = value < 0 ? -1 : (value != 0 ? 1 : 0);
     else if (!std::strcmp(name, "film_transpose"))
         ctx->film_transpose = value != 0;
+    else if (!std::strcmp(name, "band_tile_rows"))
+        ctx->band_tile_rows = (int)std::max<int64_t>(0, value);
     else if (!std::strcmp(name, "compose_spheres"))
         ctx->compose_spheres = value < 0 ? -1 : (value != 0 ? 1 : 0);
     else if (!std::strcmp(name, "occluder_pretest"))
