@@ -186,6 +186,21 @@ __global__ __launch_bounds__(kBlock) void k_raygen(const DeviceSensor* __restric
     }
 }
 
+// L[slot] += NaN on the channels a shading vertex noted in `poison` (ShadeStream::poison): NaN + x = NaN, so when the note is applied is immaterial
+__global__ __launch_bounds__(kBlock) void k_apply_poison(float4* __restrict__ L, const uint8_t* __restrict__ poison, uint64_t n) {
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
+        const uint32_t p = poison[i];
+        if (p) {
+            float4 l = L[i];
+            const float nanv = __builtin_nanf("");
+            if (p & 1u) l.x += nanv;
+            if (p & 2u) l.y += nanv;
+            if (p & 4u) l.z += nanv;
+            L[i] = l;
+        }
+    }
+}
+
 // ---- traversal ------------------------------------------------------------------------------------------------------------------
 struct Hit {
     float t;
@@ -414,6 +429,8 @@ struct ShadeStream {
     const uint32_t* tags_in;
     uint32_t* tags_out;
     uint32_t term_stride;
+    uint8_t* poison;  // classic wavefront: where a vertex notes "L += β · 0 with a non-finite β" (bit c = channel c) instead of touching L, which the
+                      // shadow rays of the depth before may still be adding to on the other stream; k_apply_poison folds the notes in at the end
 };
 struct ShadeOut {  // what one vertex emits: a shadow ray and / or the continuation of the path
     bool want_shadow, want_next;
@@ -485,7 +502,9 @@ TH_D void shade_vertex(const DeviceScene& sc, const PathQueue& qin, const float4
             }
         }
     }
-    if (!direct_added && poison) {  // L += β · 0 with a non-finite β
+    if (!direct_added && poison && ss.poison) {
+        ss.poison[slot] |= (uint8_t)poison;  // one vertex per sample and launch, launches in order: a plain read-modify-write of the sample's own byte
+    } else if (!direct_added && poison) {  // L += β · 0 with a non-finite β
         float4 l = L[slot];
         const float nanv = __builtin_nanf("");
         if (poison & 1u) l.x += nanv;

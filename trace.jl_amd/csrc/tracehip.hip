@@ -37,8 +37,8 @@ constexpr int kMaxPipes = 8;
 // different pipelines so that the long single-ray tail of one batch's traversal launch overlaps the bulk of another's.
 struct Pipe {
     hipStream_t st = nullptr, st2 = nullptr;
-    hipEvent_t ev_shade = nullptr, ev_any = nullptr, ev_done = nullptr;
-    DevBuf q[2][3], sq[3], hits, counters, overflow[2];
+    hipEvent_t ev_shade = nullptr, ev_any = nullptr, ev_any2 = nullptr, ev_done = nullptr;
+    DevBuf q[2][3], sq[3], sq2[3], hits, counters, overflow[2];  // sq / sq2: the shadow queues of odd / even depths (any(d) may still run while shade(d+1) fills the other)
 };
 
 struct trhip_ctx {
@@ -90,6 +90,7 @@ struct trhip_ctx {
     uint64_t sppm_batch = 0;  // SPPM iterations per wavefront batch (0 = from free HBM, at most 128)
     uint32_t sp_pixels = 0;
     int64_t sp_photons = 0;
+    DevBuf poison;  // one byte per camera sample of the band: ShadeStream::poison
     DevBuf ov8[2], fb_list[2], fb_counts[2];  // k_trace8: global stack levels, fallback lists + their counters / work cursors ([closest | any])
     Comm comm;  // multi-GPU job this context belongs to (trhip_comm_init); n_ranks == 1 without one
 };
@@ -1156,6 +1157,7 @@ int render_stream_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sen
     HIP_TRY(ctx, hipEventRecord(pp.ev_done, ps));
     HIP_TRY(ctx, hipStreamWaitEvent(st, pp.ev_done, 0));
     tm.begin(4, st);
+    if (ctx->overlap) hipLaunchKernelGGL(k_apply_poison, dim3(grid_for(ctx, total_slots, 8)), dim3(kBlock), 0, st, L, (const uint8_t*)ctx->poison.p, total_slots);
     launch_film(ctx, st, ds, dsp, L, total_slots, spp, seed, sample_offset, (float4*)d_film);
     tm.end(4, st);
     HIP_TRY(ctx, hipEventRecord(e1, st));
@@ -1269,7 +1271,7 @@ int render_impl_band(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
             for (auto& b : pp.sq) held += b.bytes;
         }
         const double avail = 0.85 * (double)(free_b + held) - (double)total_slots * (sizeof(float4) + sizeof(float2)) - 2.5e9;
-        batch_paths = avail > 0 ? (uint64_t)(avail / 164.0) : npix;
+        batch_paths = avail > 0 ? (uint64_t)(avail / 212.0) : npix;  // per path in flight: 2 x 3 queue float4 + 2 x 3 shadow float4 + 1 hit float4 + counters
     }
     uint64_t spp_batch = std::max<uint64_t>(1, batch_paths / npix);
     spp_batch = std::min<uint64_t>(spp_batch, spp);
@@ -1309,11 +1311,16 @@ int render_impl_band(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
                 if (int rc = ensure(ctx, pp.q[k][j], Pphys * sizeof(float4))) return rc;
         for (int j = 0; j < 3; ++j)
             if (int rc = ensure(ctx, pp.sq[j], Pphys * sizeof(float4))) return rc;
+        if (ctx->overlap)
+            for (int j = 0; j < 3; ++j)
+                if (int rc = ensure(ctx, pp.sq2[j], Pphys * sizeof(float4))) return rc;
+        if (!pp.ev_any2) HIP_TRY(ctx, hipEventCreateWithFlags(&pp.ev_any2, hipEventDisableTiming));
         if (int rc = ensure(ctx, pp.hits, Pphys * sizeof(float4))) return rc;
         if (int rc = ensure(ctx, pp.counters, sizeof(Counters))) return rc;
         for (int k = 0; k < 2; ++k)
             if (int rc = ensure(ctx, pp.overflow[k], slab_bytes)) return rc;
     }
+    if (int rc = ensure(ctx, ctx->poison, total_slots)) return rc;
     if (int rc = ensure(ctx, ctx->Lbuf, total_slots * sizeof(float4))) return rc;
     if (int rc = ensure(ctx, ctx->pfilm, total_slots * sizeof(float2))) return rc;
     const size_t film_bytes = (size_t)ds.film_w * ds.film_h * sizeof(float4);
@@ -1333,6 +1340,7 @@ int render_impl_band(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
     HIP_TRY(ctx, hipEventCreateWithFlags(&ev_start, hipEventDisableTiming));
     HIP_TRY(ctx, hipEventRecord(e0, st));
     HIP_TRY(ctx, hipMemsetAsync(L, 0, total_slots * sizeof(float4), st));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->poison.p, 0, total_slots, st));
     HIP_TRY(ctx, hipEventRecord(ev_start, st));
     const int g_shade = ctx->num_cu * 8;
     const uint32_t bary_mode = (ctx->traversal >= 2 && scene->wide_ok) ? 1u : 0u;  // k_trace2 hands the barycentrics to the shading kernel
@@ -1350,7 +1358,14 @@ int render_impl_band(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
         Counters* ctr = (Counters*)pp.counters.p;
         PathQueue pq[2];
         for (int k = 0; k < 2; ++k) pq[k] = PathQueue{(float4*)pp.q[k][0].p, (float4*)pp.q[k][1].p, (float4*)pp.q[k][2].p};
-        ShadowQueue sq{(float4*)pp.sq[0].p, (float4*)pp.sq[1].p, (float4*)pp.sq[2].p};
+        // Two shadow queues, by parity of the depth: the shadow rays of depth d (low-priority stream, starved while the closest-hit rays of
+        // depth d + 1 run) may go on while shade(d + 1) fills the other queue; shade(d + 2) waits for them.  They add into L, shade(d + 1)
+        // only NOTES a non-finite beta in ctx->poison (k_apply_poison) — no two writers of one L entry at a time.  (One queue made every
+        // shade launch wait for the shadow rays of the depth before: 2-6 ms each, 26 ms of the 436 ms S-mesh frame.)
+        const bool two = ps2 != ps;
+        const ShadowQueue sqs[2] = {ShadowQueue{(float4*)pp.sq[0].p, (float4*)pp.sq[1].p, (float4*)pp.sq[2].p},
+                                    two ? ShadowQueue{(float4*)pp.sq2[0].p, (float4*)pp.sq2[1].p, (float4*)pp.sq2[2].p} : ShadowQueue{(float4*)pp.sq[0].p, (float4*)pp.sq[1].p, (float4*)pp.sq[2].p}};
+        hipEvent_t ev_anys[2] = {pp.ev_any, pp.ev_any2};
         float4* hits = (float4*)pp.hits.p;
         HIP_TRY(ctx, hipMemsetAsync(ctr, 0, offsetof(Counters, closest_total), ps));  // queue sizes + work cursors of this batch
         tm.begin(0, ps);
@@ -1358,31 +1373,37 @@ int render_impl_band(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
         tm.end(0, ps);
         int cur = 0;
         for (int depth = 1; depth <= max_depth; ++depth) {
+            const ShadowQueue& sq = sqs[depth & 1];
             tm.begin(1, ps);
             launch_trace(ctx, ps, scene, false, SegQueue{ctr->n_queue[depth - 1], cap, 0u}, pq[cur].o, pq[cur].d, nullptr, TraceOut{hits, nullptr, nullptr, nullptr, bary_mode}, ctr->work_closest[depth - 1], ctr,
                          pp.overflow[0].p);
             tm.end(1, ps);
-            if (ps2 != ps && depth > 1) HIP_TRY(ctx, hipStreamWaitEvent(ps, pp.ev_any, 0));  // shade(d) reuses the shadow queue and touches L
+            if (two && depth > 2) HIP_TRY(ctx, hipStreamWaitEvent(ps, ev_anys[depth & 1], 0));  // shade(d) refills the queue the shadow rays of depth d - 2 read
             tm.begin(2, ps);
-            hipLaunchKernelGGL(k_shade_path<false>, dim3(g_shade), dim3(kBlock), 0, ps, scene->dev, dsp, pq[cur], pq[cur ^ 1], sq, cap, hits, L, ctr, depth - 1, depth, max_depth, bary_mode, ShadeStream{nullptr, nullptr, 0u});
+            hipLaunchKernelGGL(k_shade_path<false>, dim3(g_shade), dim3(kBlock), 0, ps, scene->dev, dsp, pq[cur], pq[cur ^ 1], sq, cap, hits, L, ctr, depth - 1, depth, max_depth, bary_mode,
+                               ShadeStream{nullptr, nullptr, 0u, two ? (uint8_t*)ctx->poison.p : nullptr});
             tm.end(2, ps);
-            if (ps2 != ps) {
+            if (two) {
                 HIP_TRY(ctx, hipEventRecord(pp.ev_shade, ps));
                 HIP_TRY(ctx, hipStreamWaitEvent(ps2, pp.ev_shade, 0));
             }
             tm.begin(3, ps2);
             launch_trace(ctx, ps2, scene, true, SegQueue{ctr->n_shadow[depth - 1], cap, 0u}, sq.o, sq.d, nullptr, TraceOut{nullptr, L, sq.c, nullptr}, ctr->work_shadow[depth - 1], ctr, pp.overflow[1].p);
             tm.end(3, ps2);
-            if (ps2 != ps) HIP_TRY(ctx, hipEventRecord(pp.ev_any, ps2));
+            if (two) HIP_TRY(ctx, hipEventRecord(ev_anys[depth & 1], ps2));
             cur ^= 1;
         }
-        if (ps2 != ps) HIP_TRY(ctx, hipStreamWaitEvent(ps, pp.ev_any, 0));  // the pipeline's next batch (or the film gather) needs every shadow ray resolved
+        if (two) {  // the pipeline's next batch (or the film gather) needs every shadow ray resolved
+            HIP_TRY(ctx, hipStreamWaitEvent(ps, pp.ev_any, 0));
+            if (max_depth >= 2) HIP_TRY(ctx, hipStreamWaitEvent(ps, pp.ev_any2, 0));
+        }
     }
     for (int pi = 0; pi < NP; ++pi) {
         HIP_TRY(ctx, hipEventRecord(ctx->pipes[pi].ev_done, ctx->pipes[pi].st));
         HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->pipes[pi].ev_done, 0));
     }
     tm.begin(4, st);
+    if (ctx->overlap) hipLaunchKernelGGL(k_apply_poison, dim3(grid_for(ctx, total_slots, 8)), dim3(kBlock), 0, st, L, (const uint8_t*)ctx->poison.p, total_slots);
     launch_film(ctx, st, ds, dsp, L, total_slots, spp, seed, sample_offset, (float4*)d_film);
     tm.end(4, st);
     HIP_TRY(ctx, hipEventRecord(e1, st));
@@ -1832,6 +1853,8 @@ void trhip_shutdown(trhip_ctx* ctx) {
         for (auto& a : pp.q)
             for (auto& b : a) release(b);
         for (auto& b : pp.sq) release(b);
+        for (auto& b : pp.sq2) release(b);
+        if (pp.ev_any2) (void)hipEventDestroy(pp.ev_any2);
         release(pp.hits);
         release(pp.counters);
         release(pp.overflow[0]);
@@ -1851,6 +1874,7 @@ void trhip_shutdown(trhip_ctx* ctx) {
     release(ctx->film_Lt);
     release(ctx->surv_list);
     release(ctx->surv_counts);
+    release(ctx->poison);
     for (int k = 0; k < 2; ++k) {
         release(ctx->ov8[k]);
         release(ctx->fb_list[k]);
