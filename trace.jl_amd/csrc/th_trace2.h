@@ -728,6 +728,9 @@ __global__ __launch_bounds__(kBlock, 5) void k_any_occluders(DeviceScene sc, Occ
 #ifndef TH_TRACE3_MAX_A
 #define TH_TRACE3_MAX_A 8
 #endif
+#ifndef TH_TRACE3_INLINE_POP
+#define TH_TRACE3_INLINE_POP 1
+#endif
 #ifdef TH_DIAG_PHASES
 // DIAGNOSTIC build (tools/phase_probe.py): wave cycles and active lanes per phase of k_trace3, summed over the waves of all launches
 __device__ unsigned long long g_phase[16];
@@ -925,6 +928,23 @@ __global__ __launch_bounds__(kBlock, ANY ? TH_TRACE3_WAVES_ANY : TH_TRACE3_WAVES
 #endif
             if (active && cur != kRefNone && cur_cnt == 0) {  // interior: one 64-byte burst, both child boxes
                 const float4 a0 = ws.wnodes[4 * (size_t)cur], a1 = ws.wnodes[4 * (size_t)cur + 1], a2 = ws.wnodes[4 * (size_t)cur + 2], a3 = ws.wnodes[4 * (size_t)cur + 3];
+#if TH_TRACE3_INLINE_POP
+                // the stack top, read while the node is on its way: when neither child is entered the lane continues with it in this same
+                // step instead of idling through a pop section of its own at the next round (that section ran for ~9 of 64 lanes and took a
+                // fifth of the kernel's cycles); a dead top (tx_min >= t_max) is dropped and the pop section goes on from there, as before
+                uint32_t top_enc = kRefNone;
+                float top_tm = kInf;
+                if (sp > 0) {
+                    if (sp - 1 < kLds) {
+                        top_enc = s_ref[sp - 1][tid];
+                        top_tm = s_tmin[sp - 1][tid];
+                    } else if (sp - 1 < kStack2Total) {
+                        const uint2 e = overflow[(size_t)(sp - 1 - kLds) * gthreads + gtid];
+                        top_enc = e.x;
+                        top_tm = __uint_as_float(e.y);
+                    }
+                }
+#endif
                 if (COUNT) nn += 2;
 #ifdef TH_DIAG_RAY_VISITS
                 rn++;
@@ -958,6 +978,15 @@ __global__ __launch_bounds__(kBlock, ANY ? TH_TRACE3_WAVES_ANY : TH_TRACE3_WAVES
                 const bool any_child = go_n | go_f;
                 cur = any_child ? (nxt & 0x00ffffffu) : kRefNone;
                 cur_cnt = any_child ? (nxt >> 24) : 0u;
+#if TH_TRACE3_INLINE_POP
+                if (!any_child && sp > 0) {  // nothing was pushed in this step: the top read above is still the top
+                    sp--;
+                    if (top_tm < t_max && sp < kStack2Total) {
+                        cur = top_enc & 0x00ffffffu;
+                        cur_cnt = top_enc >> 24;
+                    }
+                }
+#endif
             }
 #ifdef TH_DIAG_PHASES
             ph_cyc[2] += __builtin_readcyclecounter() - ph_t_node;
@@ -975,6 +1004,21 @@ __global__ __launch_bounds__(kBlock, ANY ? TH_TRACE3_WAVES_ANY : TH_TRACE3_WAVES
 #endif
         if (active && cur != kRefNone && cur_cnt > 0) {
             bool hit_any = false;
+#if TH_TRACE3_INLINE_POP
+            // the stack top, read while the primitives are on their way: the leaf's lanes pop it at the end of this phase, together
+            uint32_t top_enc = kRefNone;
+            float top_tm = kInf;
+            if (sp > 0) {
+                if (sp - 1 < kLds) {
+                    top_enc = s_ref[sp - 1][tid];
+                    top_tm = s_tmin[sp - 1][tid];
+                } else if (sp - 1 < kStack2Total) {
+                    const uint2 e = overflow[(size_t)(sp - 1 - kLds) * gthreads + gtid];
+                    top_enc = e.x;
+                    top_tm = __uint_as_float(e.y);
+                }
+            }
+#endif
             for (uint32_t k = 0; k < cur_cnt; ++k) {
                 const uint32_t slot = cur + k;
                 const float4 p0 = sc.prims[3 * slot];
@@ -1023,6 +1067,15 @@ __global__ __launch_bounds__(kBlock, ANY ? TH_TRACE3_WAVES_ANY : TH_TRACE3_WAVES
                 found = true;
                 sp = 0;
             }
+#if TH_TRACE3_INLINE_POP
+            else if (sp > 0) {  // the next stack entry, against the t_max the leaf left (bvh.jl:226 at pop time); a dead one is dropped, phase A goes on from there
+                sp--;
+                if (top_tm < t_max && sp < kStack2Total) {
+                    cur = top_enc & 0x00ffffffu;
+                    cur_cnt = top_enc >> 24;
+                }
+            }
+#endif
         }
 #ifdef TH_DIAG_PHASES
         ph_cyc[3] += __builtin_readcyclecounter() - ph_t_leaf;
