@@ -44,7 +44,8 @@ def rand_scene(rng, k):
     if k % 2 == 0:
         hv, hi, hn = T.scenes.heightfield_mesh(int(rng.integers(20, 90)), seed=int(rng.integers(1, 1 << 30)))
         prims.append(T.create_mesh_primitives(core, hi, hv, hn, white))
-    for _ in range(int(rng.integers(0, 40))):
+    n_sph = int(rng.integers(0, 40)) if k % 4 < 2 else int(rng.integers(0, 7))  # half of the scenes have few enough spheres for the 8-wide kernel (<= 8)
+    for _ in range(n_sph):
         p = rng.random(3) * 0.9 + [0.05, 0.05, -2.95]
         r = float(0.003 + 0.1 * rng.random() ** 2)
         if rng.random() < 0.3:  # clipped
@@ -97,6 +98,7 @@ def main():
     ap.add_argument("--scenes", type=int, default=24)
     ap.add_argument("--rays", type=int, default=400000)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--wide", action="store_true", help="commit the scenes the way traversal 4 needs them (compose_spheres = 1) and compare the 8-wide kernel too")
     ap.add_argument("--frames", type=int, default=0, help="also render each scene at this resolution (4 spp, depth 6) with traversal 1 and 3 and compare the films")
     a = ap.parse_args()
     ctx = T.default_context()
@@ -106,13 +108,14 @@ def main():
         rng = np.random.default_rng(a.seed * 1000 + k)
         scene, tri = rand_scene(rng, k)
         ctx.set_option("bvh_builder", 1 if k % 5 == 4 else 0)
+        ctx.set_option("compose_spheres", 1 if a.wide else -1)
         flat = scene.flatten(ctx)
         bnd = flat.bvh()[0][0]
         rays = rand_rays(rng, a.rays, bnd[:3].copy(), bnd[3:].copy(), tri)
         ctx.set_option("traversal", 1)
         h1, o1 = flat.trace_closest(rays), flat.trace_any(rays)
         bad = 0
-        for trav in (3, 2):
+        for trav in ((3, 2, 4) if a.wide else (3, 2)):
             ctx.set_option("traversal", trav)
             h, o = flat.trace_closest(rays), flat.trace_any(rays)
             bad += int((h["prim"] != h1["prim"]).sum())
@@ -123,19 +126,20 @@ def main():
         if a.frames:  # whole frames too: every bounce and shadow ray of a small render, literal walk against all shortcuts
             cam = T.scenes.cornell_camera(a.frames)
             films = []
-            for trav in (1, 3):
+            for trav in ((1, 3, 4) if a.wide else (1, 3)):
                 ctx.set_option("traversal", trav)
                 films.append(T.PathIntegrator(cam, T.SeededSampler(4, seed=100 + k), 6).render(scene, ctx).copy())
-            fa, fb = films[0].view(np.uint32), films[1].view(np.uint32)
-            nan = np.isnan(films[0]) & np.isnan(films[1])
-            bad += int(((fa != fb) & ~nan).sum())
+            for other in films[1:]:
+                fa, fb = films[0].view(np.uint32), other.view(np.uint32)
+                nan = np.isnan(films[0]) & np.isnan(other)
+                bad += int(((fa != fb) & ~nan).sum())
             ctx.set_option("traversal", 3)
         rays_total += rays.shape[0]
         bad_total += bad
         print(f"scene {k:3d}: {flat.bvh()[3].size:7d} primitives, {rays.shape[0]} rays, hit {float((h1['prim'] >= 0).mean()):.3f}, occluded {float(o1.mean()):.3f}, mismatches {bad}", flush=True)
         flat.free()
         scene._flat = None
-    print(f"total: {a.scenes} scenes, {rays_total} rays x (closest + any) x (traversal 3, 2) against traversal 1: {bad_total} mismatches")
+    print(f"total: {a.scenes} scenes, {rays_total} rays x (closest + any) x (traversal {'3, 2, 4' if a.wide else '3, 2'}) against traversal 1: {bad_total} mismatches")
     sys.exit(1 if bad_total else 0)
 
 

@@ -1394,8 +1394,8 @@ int render_impl_band(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
             cur ^= 1;
         }
         if (two) {  // the pipeline's next batch (or the film gather) needs every shadow ray resolved
-            HIP_TRY(ctx, hipStreamWaitEvent(ps, pp.ev_any, 0));
-            if (max_depth >= 2) HIP_TRY(ctx, hipStreamWaitEvent(ps, pp.ev_any2, 0));
+            HIP_TRY(ctx, hipStreamWaitEvent(ps, ev_anys[max_depth & 1], 0));                       // the last depth's shadow rays
+            if (max_depth >= 2) HIP_TRY(ctx, hipStreamWaitEvent(ps, ev_anys[(max_depth - 1) & 1], 0));  // and the depth's before
         }
     }
     for (int pi = 0; pi < NP; ++pi) {
