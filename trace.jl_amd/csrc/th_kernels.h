@@ -393,8 +393,9 @@ __global__ __launch_bounds__(kBlock) void k_trace_any(DeviceScene sc, SegQueue q
 template <bool TRI_ONLY = false>
 TH_D bool rebuild_shading(const DeviceScene& sc, int prim, f3 o, f3 d, Shading& sh, uint32_t& material, const float4* bary = nullptr, f3* fast_r = nullptr) {
     // all six 16-byte loads are issued up front (independent of the sphere / normals flags) so that their latencies overlap
-    const float4 p0 = sc.prims[3 * prim], p1 = sc.prims[3 * prim + 1], p2 = sc.prims[3 * prim + 2];
-    const float4 na = sc.tri_nrm[3 * prim], nb = sc.tri_nrm[3 * prim + 1], nc = sc.tri_nrm[3 * prim + 2];
+    const float4* rec = sc.shade + 8 * (size_t)prim;  // one 128-byte line: vertices and normals of the slot
+    const float4 p0 = rec[0], p1 = rec[1], p2 = rec[2];
+    const float4 na = rec[3], nb = rec[4], nc = rec[5];
     const uint32_t meta = __float_as_uint(p0.w);
     material = meta & PRIM_MATERIAL_MASK;
     if (fast_r) *fast_r = mk3(na.w, nb.w, nc.w);  // PRIM_FAST: the single Lambert lobe's reflectance
@@ -584,7 +585,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TH_SHADE
         if (local < sv.count[seg_in]) {
             const int prim = __float_as_int(hits[i].y);
             if (prim >= 0) {
-                cls = (__float_as_uint(sc.prims[3 * prim].w) & PRIM_FAST) ? 1 : 2;  // flag set at upload: no material fetch to classify
+                cls = (__float_as_uint(sc.shade[8 * (size_t)prim].w) & PRIM_FAST) ? 1 : 2;  // flag set at upload: no material fetch to classify
             }
         }
         ShadeOut e;

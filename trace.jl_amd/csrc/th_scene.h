@@ -8,6 +8,7 @@
 //                                  triangle: v0 v1 v2 (world space); v0.w = as_float(meta), meta = material | flags << 24
 //                                  sphere:   {as_float(sphere index), 0, 0, as_float(meta)}, unused, unused
 //   tri_nrm    float4[3*n_prims]   vertex normals of slot k (zeros when the mesh has none / slot is a sphere)
+//   shade      float4[8*n_prims]   prims and tri_nrm of slot k side by side, 128-byte aligned: what rebuild_shading reads
 //   spheres    SphereRec[n_spheres]
 //   materials  MaterialRec[n_materials]: the ≤2 BxDF lobes each material adds, for allow_multiple_lobes = false / true
 //   lights     LightRec[n_lights]
@@ -72,6 +73,8 @@ struct DeviceScene {
     const float4* nodes;
     const float4* prims;
     const float4* tri_nrm;
+    const float4* shade;  // the shading kernels' view of slot k: {v0 | meta, v1, v2, n0 | r, n1 | g, n2 | b, -, -} in ONE 128-byte line (prims + tri_nrm
+                          // interleaved): a path vertex gathers one line instead of ~2.75
     const SphereRec* spheres;
     const MaterialRec* materials;
     const LightRec* lights;

@@ -112,7 +112,7 @@ struct trhip_scene {
     std::vector<LightRec> lights;
     FlatBVH bvh;
     bool committed = false;
-    DevBuf d_nodes, d_prims, d_nrm, d_spheres, d_materials, d_lights, d_wnodes;
+    DevBuf d_nodes, d_prims, d_nrm, d_shade, d_spheres, d_materials, d_lights, d_wnodes;
     DeviceScene dev{};
     WideScene wide{};
     DevBuf d_occ_slots, d_occ_boxes, d_w8nodes, d_w8tris;
@@ -374,12 +374,22 @@ int upload_scene(trhip_scene* s) {
     if (int rc = upload(ctx, s->d_nodes, nodes.data(), nodes.size() * sizeof(float4))) return rc;
     if (int rc = upload(ctx, s->d_prims, prims.data(), prims.size() * sizeof(float4))) return rc;
     if (int rc = upload(ctx, s->d_nrm, nrm.data(), nrm.size() * sizeof(float4))) return rc;
+    {  // the shading kernels' interleaved view (th_scene.h): one 128-byte line per slot
+        std::vector<float4> rec((size_t)n_prims * 8, make_float4(0, 0, 0, 0));
+        for (uint32_t k = 0; k < n_prims; ++k)
+            for (int j = 0; j < 3; ++j) {
+                rec[8 * (size_t)k + j] = prims[3 * (size_t)k + j];
+                rec[8 * (size_t)k + 3 + j] = nrm[3 * (size_t)k + j];
+            }
+        if (int rc = upload(ctx, s->d_shade, rec.data(), rec.size() * sizeof(float4))) return rc;
+    }
     if (int rc = upload(ctx, s->d_spheres, s->spheres.data(), s->spheres.size() * sizeof(SphereRec))) return rc;
     if (int rc = upload(ctx, s->d_materials, s->materials.data(), s->materials.size() * sizeof(MaterialRec))) return rc;
     if (int rc = upload(ctx, s->d_lights, s->lights.data(), s->lights.size() * sizeof(LightRec))) return rc;
     s->dev.nodes = (const float4*)s->d_nodes.p;
     s->dev.prims = (const float4*)s->d_prims.p;
     s->dev.tri_nrm = (const float4*)s->d_nrm.p;
+    s->dev.shade = (const float4*)s->d_shade.p;
     s->dev.spheres = (const SphereRec*)s->d_spheres.p;
     s->dev.materials = (const MaterialRec*)s->d_materials.p;
     s->dev.lights = (const LightRec*)s->d_lights.p;
@@ -2030,6 +2040,7 @@ void trhip_scene_free(trhip_scene* s) {
     release(s->d_nodes);
     release(s->d_prims);
     release(s->d_nrm);
+    release(s->d_shade);
     release(s->d_spheres);
     release(s->d_materials);
     release(s->d_lights);
