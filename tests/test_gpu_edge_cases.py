@@ -56,7 +56,7 @@ def test_cropped_film(T, ob, ctx):
     assert got.shape == ref.shape == (21, 20, 4)
     assert_bits_equal(integ.sample_radiance(scene), ref_L, "per-sample radiance (cropped film)")
     assert_bits_equal(got, ref, "cropped film")
-    for mode in (0, 1):
+    for mode in (0, 1, 3):  # 3 = splat descriptors; the default is 2
         ctx.set_option("film_block", mode)
         try:
             assert_bits_equal(T.PathIntegrator(cam, T.SeededSampler(3, seed=8), 4).render(scene, ctx), ref, f"cropped film, film_block {mode}")
@@ -143,6 +143,7 @@ def test_bench_size_properties(T, ctx):
     assert_bits_equal(render(), a, "second run")
     assert_bits_equal(render(traversal=1), a, "literal traversal kernel")
     assert_bits_equal(render(film_block=0), a, "one film pixel per thread")
+    assert_bits_equal(render(film_block=3), a, "film gather from splat descriptors")
     assert_bits_equal(render(batch_paths=16 * 1026 * 1026, overlap=0), a, "four batches, one stream")
     assert_bits_equal(render(traversal=3), a, "binary children-in-parent walk (k_trace_leaf here: one-leaf scene)")
     h0, h1 = render(128, 0), render(128, 128)
@@ -260,7 +261,7 @@ def test_banded_frame_equals_whole_frame(T, ob, ctx, rows):
     osc = ob.OracleScene.from_scene(scene, bvh=scene.flatten(ctx).bvh())
     ref, _, st_ref = osc.render(cam, "path", 3, 5, seed=12, threads=ob.lib().orc_num_threads())
     assert_bits_equal(whole, ref, "one band vs oracle")
-    for film_block in (2, 0, 1):
+    for film_block in (2, 3, 0, 1):
         ctx.set_option("band_tile_rows", rows)
         ctx.set_option("film_block", film_block)
         try:

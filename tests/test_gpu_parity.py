@@ -272,7 +272,7 @@ def test_film_accumulate_matches_oracle_tile_order(T, ob, ctx):
     finally:
         ctx.set_option("film_tiled", 0)
     assert_bits_equal(out2, ref_xyzw, "film accumulate, LDS-tiled gather")
-    for mode in (0, 1, 2):  # one film pixel per thread, 2 x 2 blocks, 1 x 4 blocks (the default; odd film sizes: 37 x 29)
+    for mode in (0, 1, 2, 3):  # one film pixel per thread, 2 x 2 blocks, 1 x 4 blocks (the default), 1 x 4 from splat descriptors (odd film sizes: 37 x 29)
         ctx.set_option("film_block", mode)
         try:
             out3 = np.empty_like(ref_xyzw)

@@ -889,6 +889,151 @@ __global__ __launch_bounds__(kBlock) void k_film_gather_block(const DeviceSensor
     }
 }
 
+// ---- film gather from per-sample splat descriptors (film_block = 3, the default) ---------------------------------------------------
+// k_film_gather_block spends ~300 VALU instructions per (sample, thread): every thread that a sample can reach recomputes the sample's
+// pixel range (ceil / floor, film.jl:145-146) and, per pixel, the filter-table index (|x - dp| / r * 16, ceil for x, floor for y, clamp,
+// film.jl:149-153).  All of that depends on the sample alone, so k_film_descriptors computes it ONCE per sample — with the same Float32
+// operations — into 16 bytes: the first pixel column / row of the unclamped range (int16 each), the number of columns / rows (<= 8: filter
+// radius <= 3), and one 4-bit table index per column and per row.  The gather then reads {descriptor, radiance} and, per film pixel, does
+// two compares, two bit-field extracts, one LDS lookup and the three multiply-adds of add_sample! (film.jl:161-162) — in the same order
+// (tile k, sample pixel, sample): the film is bit-identical to k_film_gather's.
+struct SplatDesc {   // uint4
+    uint32_t origin;  // int16 p0x | int16 p0y << 16  = ceil(dp - r), unclamped (film.jl:145)
+    uint32_t count;   // nx | ny << 8               = floor(dp + r) + 1 - p0 + 1 (film.jl:146: the extra column / row of A.9 included)
+    uint32_t ox;      // 4 bits per column: clamp(ceil(|x - dpx| / rx * 16), 1, 16) - 1
+    uint32_t oy;      // 4 bits per row:    clamp(floor(|y - dpy| / ry * 16), 1, 16) - 1
+};
+__global__ __launch_bounds__(kBlock) void k_film_descriptors(const DeviceSensor* __restrict__ sep, uint64_t n, uint64_t seed, uint32_t sample_offset, uint4* __restrict__ desc) {
+    const DeviceSensor& se = *sep;
+    const float rx = se.filter_radius[0], ry = se.filter_radius[1];
+    const float inv_rx = 1.0f / rx, inv_ry = 1.0f / ry;
+    for (uint64_t slot = (uint64_t)blockIdx.x * kBlock + threadIdx.x; slot < n; slot += (uint64_t)gridDim.x * kBlock) {
+        const SlotInfo si = slot_info(se, (uint32_t)slot);
+        const uint64_t key = ts_stream_key(seed, si.px, si.py, sample_offset + si.sample);
+        const float pfx = (float)si.px + ts_uniform(key, TS_DIM_FILM_X), pfy = (float)si.py + ts_uniform(key, TS_DIM_FILM_Y);  // camera_sample.film
+        const float dpx = pfx - 0.5f, dpy = pfy - 0.5f;
+        const float p0x = __builtin_ceilf(dpx - rx), p0y = __builtin_ceilf(dpy - ry);
+        const float p1x = __builtin_floorf(dpx + rx) + 1.0f, p1y = __builtin_floorf(dpy + ry) + 1.0f;
+        const int nx = (int)(p1x - p0x) + 1, ny = (int)(p1y - p0y) + 1;
+        uint32_t oxw = 0, oyw = 0;
+        for (int c = 0; c < 8; ++c) {
+            const float X = p0x + (float)c, Y = p0y + (float)c;
+            oxw |= (uint32_t)((int)jclamp(__builtin_ceilf(fabs_((X - dpx) * inv_rx * 16.0f)), 1.0f, 16.0f) - 1) << (4 * c);   // ceil for x …
+            oyw |= (uint32_t)((int)jclamp(__builtin_floorf(fabs_((Y - dpy) * inv_ry * 16.0f)), 1.0f, 16.0f) - 1) << (4 * c);  // … floor for y (A.9)
+        }
+        desc[slot] = make_uint4(((uint32_t)(int)p0x & 0xffffu) | ((uint32_t)(int)p0y << 16), (uint32_t)nx | ((uint32_t)ny << 8), oxw, oyw);
+    }
+}
+template <int BY>
+__global__ __launch_bounds__(kBlock) void k_film_gather_desc(const DeviceSensor* __restrict__ sep, const float* __restrict__ table, const float4* __restrict__ L,
+                                                             const uint4* __restrict__ desc, uint32_t spp, float4* __restrict__ out) {
+    const DeviceSensor& se = *sep;
+    __shared__ float s_table[256];
+    for (uint32_t t = threadIdx.x; t < 256u; t += kBlock) s_table[t] = table[t];
+    __syncthreads();
+    const uint32_t npix = (uint32_t)(se.sb_w * se.band_rows);
+    const float rx = se.filter_radius[0], ry = se.filter_radius[1];
+    const uint32_t nbx = (uint32_t)se.film_w, nby = ((uint32_t)se.film_h + BY - 1) / BY;
+    for (uint32_t bidx = blockIdx.x * kBlock + threadIdx.x; bidx < nbx * nby; bidx += gridDim.x * kBlock) {
+        const int fy0 = (int)(bidx / nbx) * BY, fx0 = (int)(bidx - (bidx / nbx) * nbx);
+        const float X = se.crop_min[0] + (float)fx0;
+        const int Xi = (int)X;
+        float Y[BY];
+        int Yi[BY];
+        for (int j = 0; j < BY; ++j) {
+            Y[j] = se.crop_min[1] + (float)(fy0 + j);
+            Yi[j] = (int)Y[j];
+        }
+        // union of the pixels' reaches (k_film_gather: sx in (X - 1.5 - r, X + r + 0.5])
+        const int sx_lo = max((int)__builtin_floorf(X - 1.5f - rx), se.sb_min[0]), sx_hi = min((int)__builtin_ceilf(X + rx + 0.5f), se.sb_max[0]);
+        const int sy_lo = max((int)__builtin_floorf(Y[0] - 1.5f - ry), se.sb_min[1]), sy_hi = min((int)__builtin_ceilf(Y[BY - 1] + ry + 0.5f), se.sb_max[1]);
+        f3 xyz[BY];
+        float wsum[BY];
+        for (int j = 0; j < BY; ++j) {
+            xyz[j] = splat3(0.0f);
+            wsum[j] = 0.0f;
+            if (se.accumulate && fy0 + j < se.film_h) {  // a later band: add onto the tiles of the bands before (k order)
+                const float4 prev = out[(size_t)(fy0 + j) * (size_t)se.film_w + (size_t)fx0];
+                xyz[j] = mk3(prev.x, prev.y, prev.z);
+                wsum[j] = prev.w;
+            }
+        }
+        if (sx_lo <= sx_hi && sy_lo <= sy_hi) {
+            const int ty_lo = max((sy_lo - se.sb_min[1]) >> 4, se.band_ty0), ty_hi = min((sy_hi - se.sb_min[1]) >> 4, se.band_ty1);
+            const int tx_lo = (sx_lo - se.sb_min[0]) >> 4, tx_hi = (sx_hi - se.sb_min[0]) >> 4;
+            for (int ty = ty_lo; ty <= ty_hi; ++ty)
+                for (int tx = tx_lo; tx <= tx_hi; ++tx) {
+                    float bx0, by0, bx1, by1;
+                    film_tile_bounds(se, ty, tx, rx, ry, bx0, by0, bx1, by1);
+                    const float tbx0 = (float)se.sb_min[0] + (float)tx * 16.0f, tby0 = (float)se.sb_min[1] + (float)ty * 16.0f;
+                    const float tbx1 = jmin(tbx0 + 15.0f, (float)se.sb_max[0]), tby1 = jmin(tby0 + 15.0f, (float)se.sb_max[1]);
+                    // merge_film_tile! touches the pixel (film.jl:182-193); add_sample! clamps its range to the tile's film bounds and to 1 (film.jl:147-148)
+                    const bool in_x = !(X < bx0 || X > bx1), ok_x = in_x && !(X < 1.0f);
+                    bool in_tile[BY], ok_y[BY];
+                    bool any_in = false;
+                    for (int j = 0; j < BY; ++j) {
+                        const bool in_y = !(Y[j] < by0 || Y[j] > by1);
+                        in_tile[j] = in_x && in_y;
+                        ok_y[j] = in_y && !(Y[j] < 1.0f);
+                        any_in = any_in || in_tile[j];
+                    }
+                    if (!any_in) continue;
+                    f3 csum[BY];
+                    float fws[BY];
+                    for (int j = 0; j < BY; ++j) {
+                        csum[j] = splat3(0.0f);
+                        fws[j] = 0.0f;
+                    }
+                    const int y0 = max(sy_lo, (int)tby0), y1 = min(sy_hi, (int)tby1);
+                    const int x0 = max(sx_lo, (int)tbx0), x1 = min(sx_hi, (int)tbx1);
+                    for (int sy = y0; sy <= y1; ++sy)
+                        for (int sx = x0; sx <= x1; ++sx) {
+                            const uint32_t pix = (uint32_t)(sy - se.band_y0) * (uint32_t)se.sb_w + (uint32_t)(sx - se.sb_min[0]);
+                            auto splat = [&](uint4 d, float4 l4) {
+                                const int cx = Xi - (int)(short)(d.x & 0xffffu);
+                                if (!(ok_x && (uint32_t)cx < (d.y & 0xffu))) return;
+                                f3 l = mk3(l4.x, l4.y, l4.z);
+                                if (has_nan(l)) l = splat3(0.0f);  // integrators/sampler.jl:46
+                                const uint32_t oxi = (d.z >> (4 * cx)) & 15u;
+                                const int p0y = (int)(short)(d.x >> 16);
+                                const uint32_t ny = (d.y >> 8) & 0xffu;
+                                for (int j = 0; j < BY; ++j) {
+                                    const int cy = Yi[j] - p0y;
+                                    if (ok_y[j] && (uint32_t)cy < ny) {
+                                        const float w = s_table[((d.w >> (4 * cy)) & 15u) * 16u + oxi];
+                                        csum[j] = csum[j] + l * w;   // contrib_sum += l * sample_weight (1) * w
+                                        fws[j] += w;
+                                    }
+                                }
+                            };
+                            constexpr uint32_t kU = 4;
+                            uint32_t s = 0;
+                            for (; s + kU <= spp; s += kU) {
+                                uint4 dv[kU];
+                                float4 lv[kU];
+#pragma unroll
+                                for (uint32_t u = 0; u < kU; ++u) {
+                                    const size_t at = (size_t)(s + u) * npix + pix;
+                                    dv[u] = desc[at];
+                                    lv[u] = L[at];
+                                }
+#pragma unroll
+                                for (uint32_t u = 0; u < kU; ++u) splat(dv[u], lv[u]);
+                            }
+                            for (; s < spp; ++s) splat(desc[(size_t)s * npix + pix], L[(size_t)s * npix + pix]);
+                        }
+                    for (int j = 0; j < BY; ++j)
+                        if (in_tile[j]) {
+                            xyz[j] = xyz[j] + rgb_to_xyz(csum[j]);
+                            wsum[j] += fws[j];
+                        }
+                }
+        }
+        for (int j = 0; j < BY; ++j)
+            if (fy0 + j < se.film_h) out[(size_t)(fy0 + j) * (size_t)se.film_w + (size_t)fx0] = make_float4(xyz[j].x, xyz[j].y, xyz[j].z, wsum[j]);
+    }
+}
+
 // k_film_gather with the samples staged through LDS: one block = a 16x16 film tile; for every sample row (ascending) the
 // block stages `cols` sample columns x `ns` samples {p_film, L} once (instead of each of the ~16 film pixels a sample
 // reaches re-reading them from HBM/MALL), then the film pixels in reach accumulate from LDS.  The summation order per film

@@ -65,7 +65,9 @@ struct trhip_ctx {
                                      // (th_trace2.h, slab_test2); 0 = the reference's loose test alone (its exact visit set)
     int band_tile_rows = 0;          // DIAGNOSTIC / tests: render frames in bands of this many tile rows (0 = one band unless the samples do not fit in HBM)
     uint32_t tiny_scene_prims = 16;  // scenes of at most this many primitives get a single-leaf BVH (th_bvh.h); 0 = always build the hierarchy
-    int film_block = 2;  // film gather: 0 = one film pixel per thread, 1 = 2 x 2 pixels per thread, 2 = TH_FILM_BX x TH_FILM_BY = 1 x 4 (default)
+    int film_block = 2;  // film gather: 0 = one film pixel per thread, 1 = 2 x 2 pixels per thread, 2 (default) = TH_FILM_BX x TH_FILM_BY = 1 x 4, all three recomputing a
+                         // sample's pixel range and table indices per thread; 3 = 1 x 4 from per-sample splat descriptors (k_film_descriptors): measured SLOWER
+                         // (1024^2, 256 spp: 29.0 ms against 24.3 ms: the 16-byte descriptor doubles the gather's loads and the arithmetic it saves was hidden)
     bool film_tiled = false;  // LDS-staged film gather (k_film_gather_tiled): bit-identical, measured 2.7x SLOWER than k_film_gather (11 % lane use), kept as an option
     bool overlap = true;  // two-stream overlap of shadow rays (depth d) with closest-hit rays (depth d+1)
     int compose_spheres = -1;  // commit: spheres as a chain of leaves above the triangles' subtree, what k_trace8 needs of a scene with spheres
@@ -90,6 +92,7 @@ struct trhip_ctx {
     uint64_t sppm_batch = 0;  // SPPM iterations per wavefront batch (0 = from free HBM, at most 128)
     uint32_t sp_pixels = 0;
     int64_t sp_photons = 0;
+    DevBuf fdesc;   // film_block 3: one SplatDesc (16 B) per camera sample of the band (th_kernels.h, k_film_descriptors)
     DevBuf poison;  // one byte per camera sample of the band: ShadeStream::poison
     DevBuf ov8[2], fb_list[2], fb_counts[2];  // k_trace8: global stack levels, fallback lists + their counters / work cursors ([closest | any])
     Comm comm;  // multi-GPU job this context belongs to (trhip_comm_init); n_ranks == 1 without one
@@ -600,8 +603,24 @@ void derive_sensor(const trhip_sensor* sn, DeviceSensor& d) {
 #define TH_FILM_BX 1  // film_block = 2; measured at 1024^2, 256 spp, 4 samples in flight per thread: 1x1 67 ms, 2x2 40, 1x4 32, 1x6 47, 1x8 42, 2x4 39
 #define TH_FILM_BY 4
 #endif
+// film_block = 3: the gather reads one 16-byte splat descriptor per sample (k_film_descriptors) instead of recomputing the sample's pixel range
+// and table indices in every thread it reaches; needs a filter radius <= 3 (<= 8 columns / rows per sample)
+bool film_uses_desc(const trhip_ctx* ctx, const DeviceSensor& ds) {
+    return ctx->film_block == 3 && !ctx->film_tiled && !ctx->film_transpose && std::fmax(ds.filter_radius[0], ds.filter_radius[1]) <= 3.0f && ds.film_w < 32000 && ds.film_h < 32000;
+}
+// the per-sample buffer the film pass needs next to the radiance: descriptors (16 B) or film positions (8 B)
+int ensure_film_samples(trhip_ctx* ctx, const DeviceSensor& ds, uint64_t total_slots) {
+    if (film_uses_desc(ctx, ds)) return ensure(ctx, ctx->fdesc, total_slots * sizeof(uint4));
+    return ensure(ctx, ctx->pfilm, total_slots * sizeof(float2));
+}
 void launch_film(trhip_ctx* ctx, hipStream_t st, const DeviceSensor& ds, const DeviceSensor* dsp, const float4* L, uint64_t total_slots, uint32_t spp, uint64_t seed, uint32_t sample_offset,
                  float4* d_film) {
+    if (film_uses_desc(ctx, ds) && ctx->fdesc.bytes >= total_slots * sizeof(uint4)) {
+        hipLaunchKernelGGL(k_film_descriptors, dim3(grid_for(ctx, total_slots, 8)), dim3(kBlock), 0, st, dsp, total_slots, seed, sample_offset, (uint4*)ctx->fdesc.p);
+        const uint64_t nthreads = (uint64_t)ds.film_w * ((ds.film_h + 3) / 4);
+        hipLaunchKernelGGL((k_film_gather_desc<4>), dim3(grid_for(ctx, nthreads, 8)), dim3(kBlock), 0, st, dsp, (const float*)ctx->table.p, L, (const uint4*)ctx->fdesc.p, spp, d_film);
+        return;
+    }
     // pixel-group-major inputs for the gather (th_kernels.h, film_index): p_film is written that way, L is re-laid into a second buffer
     // (the frame's radiance, 16 B per sample, once more); without room for it the gather reads the sample-major arrays as before
     const uint32_t npix = (uint32_t)(ds.sb_w * ds.band_rows);
@@ -1065,7 +1084,7 @@ int render_stream_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sen
     for (int k = 0; k < 2; ++k)
         if (int rc = ensure(ctx, pp.overflow[k], slab_bytes)) return rc;
     if (int rc = ensure(ctx, ctx->Lbuf, total_slots * sizeof(float4))) return rc;
-    if (int rc = ensure(ctx, ctx->pfilm, total_slots * sizeof(float2))) return rc;
+    if (int rc = ensure_film_samples(ctx, ds, total_slots)) return rc;
     if (int rc = ensure(ctx, ctx->st_terms, terms_bytes)) return rc;
     for (int k = 0; k < 2; ++k)
         if (int rc = ensure(ctx, ctx->st_tags[k], Pphys * sizeof(uint32_t))) return rc;
@@ -1234,7 +1253,7 @@ int render_impl_band(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
         if (int rc = upload(ctx, ctx->sensor, &ds, sizeof ds)) return rc;
         if (int rc = upload(ctx, ctx->table, sensor->filter_table, 256 * sizeof(float))) return rc;
         if (int rc = ensure(ctx, ctx->Lbuf, total_slots * sizeof(float4))) return rc;
-        if (int rc = ensure(ctx, ctx->pfilm, total_slots * sizeof(float2))) return rc;
+        if (int rc = ensure_film_samples(ctx, ds, total_slots)) return rc;
         if (int rc = ensure(ctx, ctx->counters, sizeof(Counters))) return rc;
         const size_t fb = (size_t)ds.film_w * ds.film_h * sizeof(float4);
         void* df = out;
@@ -1332,7 +1351,7 @@ int render_impl_band(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
     }
     if (int rc = ensure(ctx, ctx->poison, total_slots)) return rc;
     if (int rc = ensure(ctx, ctx->Lbuf, total_slots * sizeof(float4))) return rc;
-    if (int rc = ensure(ctx, ctx->pfilm, total_slots * sizeof(float2))) return rc;
+    if (int rc = ensure_film_samples(ctx, ds, total_slots)) return rc;
     const size_t film_bytes = (size_t)ds.film_w * ds.film_h * sizeof(float4);
     void* d_film = out;
     if (!out_is_device) {
@@ -1478,7 +1497,7 @@ int render_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sensor* se
             }
             // half of what is free for the per-sample buffers, the rest for the wavefront queues (164 B per path in flight); 32-bit slot indices
             const double budget = std::min(0.5 * (double)(free_b + held), 4.0e9 * 24.0);
-            const double row_bytes = (double)ds.sb_w * 16.0 * (double)spp * 24.0;
+            const double row_bytes = (double)ds.sb_w * 16.0 * (double)spp * (film_uses_desc(ctx, ds) ? 33.0 : 25.0);  // radiance + descriptor / film position + poison byte
             rows_per_band = (int)std::max(1.0, std::min((double)ds.tiles_y, std::floor(budget / row_bytes)));
             while (rows_per_band > 1 && (uint64_t)ds.sb_w * 16ull * (uint64_t)rows_per_band * spp >= (1ull << 32)) --rows_per_band;
         }
@@ -1859,6 +1878,7 @@ void trhip_shutdown(trhip_ctx* ctx) {
     release(ctx->film);
     release(ctx->overflow);
     release(ctx->pfilm);
+    release(ctx->fdesc);
     for (auto& pp : ctx->pipes) {
         for (auto& a : pp.q)
             for (auto& b : a) release(b);
@@ -2008,7 +2028,7 @@ int trhip_set_option(trhip_ctx* ctx, const char* name, int64_t value) {
     else if (!std::strcmp(name, "tiny_scene_prims"))
         ctx->tiny_scene_prims = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(255, value));
     else if (!std::strcmp(name, "film_block"))
-        ctx->film_block = (int)std::max<int64_t>(0, std::min<int64_t>(2, value));
+        ctx->film_block = (int)std::max<int64_t>(0, std::min<int64_t>(3, value));
     else if (!std::strcmp(name, "film_tiled"))
         ctx->film_tiled = value != 0;
     else if (!std::strcmp(name, "pipelines")) {
@@ -2555,7 +2575,7 @@ int trhip_film_accumulate(trhip_ctx* ctx, const trhip_sensor* sn, uint32_t spp, 
     if (int rc = ensure(ctx, ctx->Lbuf, n * sizeof(float4))) return rc;
     const size_t film_bytes = (size_t)ds.film_w * ds.film_h * sizeof(float4);
     if (int rc = ensure(ctx, ctx->film, film_bytes)) return rc;
-    if (int rc = ensure(ctx, ctx->pfilm, n * sizeof(float2))) return rc;
+    if (int rc = ensure_film_samples(ctx, ds, n)) return rc;
     if (n) hipLaunchKernelGGL(k_import_L, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const float*)ctx->scratch[0].p, n, (float4*)ctx->Lbuf.p);
     launch_film(ctx, ctx->stream, ds, (const DeviceSensor*)ctx->sensor.p, (const float4*)ctx->Lbuf.p, n, spp, seed, sample_offset, (float4*)ctx->film.p);
     HIP_TRY(ctx, hipGetLastError());
