@@ -216,8 +216,14 @@ struct Shading {  // what BSDF(si) (bsdf.jl:41-50) and the integrators read from
     f3 ts;        // ns × ss (not re-normalised, A.11)
 };
 // triangle_mesh.jl:219-243 + 125-141 + 160-185 + surface_interaction.jl:51-88
-TH_D Shading shade_triangle(f3 v0, f3 v1, f3 v2, bool has_normals, f3 n0, f3 n1, f3 n2, bool flip, f3 bary, f3 ray_d) {
-    Shading s;
+// The two quantities of a triangle's interaction that depend on nothing but its vertices: the geometric normal (:230) and the
+// normalised ∂p∂u.  k_shade_constants evaluates this once per slot at commit (same code, same device: same bits) and leaves the
+// results in the slot's shading record; shade_triangle then takes them from there (`pre`) instead of redoing two cross / normalise
+// chains per path vertex.
+struct TriConstants {
+    f3 n, ss;
+};
+TH_D TriConstants triangle_constants(f3 v0, f3 v1, f3 v2) {
     // ∂p with the default uvs (0,0) (1,0) (1,1)  (:79-83, :125-141)
     const float du13x = 0.0f - 1.0f, du13y = 0.0f - 1.0f, du23x = 1.0f - 1.0f, du23y = 0.0f - 1.0f;
     const f3 dp13 = v0 - v2, dp23 = v1 - v2;
@@ -230,14 +236,23 @@ TH_D Shading shade_triangle(f3 v0, f3 v1, f3 v2, bool has_normals, f3 n0, f3 n1,
         const float inv_det = 1.0f / det;
         dpdu = (du23y * dp13 - du13y * dp23) * inv_det;
     }
+    TriConstants c;
+    c.n = normalize(cross(dp13, dp23));  // :230 overrides the constructor's normal
+    c.ss = normalize(dpdu);
+    return c;
+}
+TH_D Shading shade_triangle(f3 v0, f3 v1, f3 v2, bool has_normals, f3 n0, f3 n1, f3 n2, bool flip, f3 bary, f3 ray_d, const TriConstants* pre = nullptr) {
+    Shading s;
+    const TriConstants tc = pre ? *pre : triangle_constants(v0, v1, v2);
     s.p = bary.x * v0 + bary.y * v1 + bary.z * v2;  // sum_mul(barycentric, vs) :222
     s.wo = -ray_d;
-    f3 n = normalize(cross(dp13, dp23));  // :230 overrides the constructor's normal
+    f3 n = tc.n;
     f3 shn = n;
-    f3 sh_dpdu = dpdu;
+    bool ss_is_unit = true;  // s.ss below is normalize(∂p∂u): tc.ss itself unless the shading normals replace ∂p∂u
+    f3 sh_dpdu = tc.ss;
     if (has_normals) {
         const f3 nsn = normalize(bary.x * n0 + bary.y * n1 + bary.z * n2);
-        f3 ss = normalize(dpdu);
+        f3 ss = tc.ss;
         f3 ts = cross(nsn, ss);
         if (dot(ts, ts) > 0.0f) {
             ts = normalize(ts);
@@ -250,6 +265,7 @@ TH_D Shading shade_triangle(f3 v0, f3 v1, f3 v2, bool has_normals, f3 n0, f3 n1,
         if (flip) shn = shn * -1.0f;
         n = face_forward(n, shn);
         sh_dpdu = ss;
+        ss_is_unit = false;
         n = face_forward(n, shn);  // :234-237
     } else if (flip) {
         n = -n;
@@ -257,7 +273,7 @@ TH_D Shading shade_triangle(f3 v0, f3 v1, f3 v2, bool has_normals, f3 n0, f3 n1,
     }
     s.ng = n;
     s.ns = shn;
-    s.ss = normalize(sh_dpdu);
+    s.ss = ss_is_unit ? sh_dpdu : normalize(sh_dpdu);
     s.ts = cross(s.ns, s.ss);
     return s;
 }

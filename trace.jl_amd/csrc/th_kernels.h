@@ -392,10 +392,13 @@ __global__ __launch_bounds__(kBlock) void k_trace_any(DeviceScene sc, SegQueue q
 // barycentrics ARE the accepted candidate's.
 template <bool TRI_ONLY = false>
 TH_D bool rebuild_shading(const DeviceScene& sc, int prim, f3 o, f3 d, Shading& sh, uint32_t& material, const float4* bary = nullptr, f3* fast_r = nullptr) {
-    // all six 16-byte loads are issued up front (independent of the sphere / normals flags) so that their latencies overlap
+    // all six 16-byte loads are issued up front (independent of the sphere / normals flags) so that their latencies overlap.  (Fetching them
+    // in k_shade_path while it classifies the entry — two dependent trips instead of three — was measured: 24 more live registers, 368
+    // instead of 208 bytes of scratch, S-mesh shading 92 -> 163 ms; fetching only the ray and the throughput there: 92 -> 107 ms.)
     const float4* rec = sc.shade + 8 * (size_t)prim;  // one 128-byte line: vertices and normals of the slot
     const float4 p0 = rec[0], p1 = rec[1], p2 = rec[2];
     const float4 na = rec[3], nb = rec[4], nc = rec[5];
+    const float4 cn = rec[6], cs = rec[7];  // the triangle's geometric normal and unit ∂p∂u (k_shade_constants)
     const uint32_t meta = __float_as_uint(p0.w);
     material = meta & PRIM_MATERIAL_MASK;
     if (fast_r) *fast_r = mk3(na.w, nb.w, nc.w);  // PRIM_FAST: the single Lambert lobe's reflectance
@@ -413,8 +416,20 @@ TH_D bool rebuild_shading(const DeviceScene& sc, int prim, f3 o, f3 d, Shading& 
     else if (!tri_intersect<true>(v0, v1, v2, o, d, kInf, &tt))
         return false;
     const bool has_n = (meta & PRIM_HAS_NORMALS) != 0;
-    sh = shade_triangle(v0, v1, v2, has_n, mk3(na.x, na.y, na.z), mk3(nb.x, nb.y, nb.z), mk3(nc.x, nc.y, nc.z), (meta & PRIM_FLIP) != 0, tt.bary, d);
+    const TriConstants tc{mk3(cn.x, cn.y, cn.z), mk3(cs.x, cs.y, cs.z)};
+    sh = shade_triangle(v0, v1, v2, has_n, mk3(na.x, na.y, na.z), mk3(nb.x, nb.y, nb.z), mk3(nc.x, nc.y, nc.z), (meta & PRIM_FLIP) != 0, tt.bary, d, &tc);
     return true;
+}
+// Commit time: records 6 / 7 of every triangle slot's shading line (th_scene.h) = triangle_constants of its vertices.
+__global__ __launch_bounds__(kBlock) void k_shade_constants(float4* __restrict__ shade, uint32_t n_prims) {
+    for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < n_prims; k += gridDim.x * kBlock) {
+        float4* rec = shade + 8 * (size_t)k;
+        const float4 p0 = rec[0], p1 = rec[1], p2 = rec[2];
+        if (__float_as_uint(p0.w) & PRIM_SPHERE) continue;
+        const TriConstants tc = triangle_constants(mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z));
+        rec[6] = make_float4(tc.n.x, tc.n.y, tc.n.z, 0.0f);
+        rec[7] = make_float4(tc.ss.x, tc.ss.y, tc.ss.z, 0.0f);
+    }
 }
 
 // One PathIntegrator vertex (DESIGN.md "PathIntegrator"; sppm.jl:208-266 without the visible-point early-out, β on the
@@ -545,6 +560,9 @@ TH_D void shade_vertex(const DeviceScene& sc, const PathQueue& qin, const float4
 // multi-lobe materials) run several times as many instructions.  Mixed in one wave they serialise (S-cornell: 108 ms against
 // 58 ms for the same box without its two spheres), so every wave shades its FAST entries at once and parks the indices of the
 // others in an LDS ring; whenever 64 are parked they are shaded together by the general code, with all lanes busy.
+// (Two launches instead — the FAST entries, then the others from an index list in HBM, each with a register allocation of its
+// own — were measured: S-mesh frame 405 -> 415 ms, S-cornell 162 -> 173 ms; the list traffic and the second launch's tail cost
+// more than the 144 bytes of scratch the FAST code gets rid of.)
 template <bool STREAM>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TH_SHADE_WAVES))) void k_shade_path(DeviceScene sc, const DeviceSensor* __restrict__ sep, PathQueue qin, PathQueue qout, ShadowQueue sq, uint32_t cap,
                                                        const float4* __restrict__ hits, float4* __restrict__ L, Counters* ctr, int row, int depth_fixed, int max_depth, uint32_t hits_have_bary,

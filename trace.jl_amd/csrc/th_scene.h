@@ -73,7 +73,7 @@ struct DeviceScene {
     const float4* nodes;
     const float4* prims;
     const float4* tri_nrm;
-    const float4* shade;  // the shading kernels' view of slot k: {v0 | meta, v1, v2, n0 | r, n1 | g, n2 | b, -, -} in ONE 128-byte line (prims + tri_nrm
+    const float4* shade;  // the shading kernels' view of slot k: {v0 | meta, v1, v2, n0 | r, n1 | g, n2 | b, geometric normal, unit dpdu (k_shade_constants)} in ONE 128-byte line (prims + tri_nrm
                           // interleaved): a path vertex gathers one line instead of ~2.75
     const SphereRec* spheres;
     const MaterialRec* materials;

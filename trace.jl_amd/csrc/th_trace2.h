@@ -723,13 +723,19 @@ __global__ __launch_bounds__(kBlock, 5) void k_any_occluders(DeviceScene sc, Occ
 #define TH_TRACE3_LEAF_WAIT 32  // measured (128 spp, S-blob / S-mesh frame ms): 20: 694 / 2250, 32: 654 / 2207, 40: 659 / 2202, 48: 696 / 2265
 #endif
 #ifndef TH_TRACE3_POP_MIN
-#define TH_TRACE3_POP_MIN 1
+#define TH_TRACE3_POP_MIN 8  // with the in-step pops: 1 -> 8 measured -1 % (S-mesh 411.2 -> 407.4 ms), 12 / 16 the same
 #endif
 #ifndef TH_TRACE3_MAX_A
 #define TH_TRACE3_MAX_A 8
 #endif
 #ifndef TH_TRACE3_INLINE_POP
 #define TH_TRACE3_INLINE_POP 1
+#endif
+#ifndef TH_TRACE3_LEAF_BURST
+#define TH_TRACE3_LEAF_BURST 1
+#endif
+#ifndef TH_TRACE3_LEAF_PREFETCH
+#define TH_TRACE3_LEAF_PREFETCH 0
 #endif
 #ifdef TH_DIAG_PHASES
 // DIAGNOSTIC build (tools/phase_probe.py): wave cycles and active lanes per phase of k_trace3, summed over the waves of all launches
@@ -771,6 +777,9 @@ __global__ __launch_bounds__(kBlock, ANY ? TH_TRACE3_WAVES_ANY : TH_TRACE3_WAVES
     float t_max = 0.0f, slot_w = 0.0f, flag_w = 0.0f;
     bool found = false;
     uint32_t nn = 0, np = 0;
+#if TH_TRACE3_LEAF_PREFETCH
+    uint32_t pf0 = 0, pf1 = 0;  // landing registers of the leaf prefetch, never read
+#endif
 #ifdef TH_DIAG_PHASES
     unsigned long long ph_cyc[4] = {0, 0, 0, 0}, ph_lan[4] = {0, 0, 0, 0}, ph_cnt[4] = {0, 0, 0, 0};  // refill, pop, node, leaf
     unsigned long long ph_load = 0;  // of the leaf cycles: until the primitive's three records have arrived
@@ -987,6 +996,15 @@ __global__ __launch_bounds__(kBlock, ANY ? TH_TRACE3_WAVES_ANY : TH_TRACE3_WAVES
                     }
                 }
 #endif
+#if TH_TRACE3_LEAF_PREFETCH
+                // the lane now waits for phase B with a leaf in hand: touch its first primitive's record (48 bytes, possibly across two lines)
+                // so that phase B finds it in the cache.  The loaded words are never read; the asm hides the loads from the compiler, hence
+                // the explicit wait in front: every load the compiler tracks is then older than these two and its counting stays right.
+                if (cur != kRefNone && cur_cnt > 0) {
+                    const float4* rec = sc.prims + 3 * (size_t)cur;
+                    asm volatile("s_waitcnt vmcnt(0)\n\tglobal_load_dword %0, %2, off\n\tglobal_load_dword %1, %2, off offset:44" : "+v"(pf0), "+v"(pf1) : "v"(rec) : "memory");
+                }
+#endif
             }
 #ifdef TH_DIAG_PHASES
             ph_cyc[2] += __builtin_readcyclecounter() - ph_t_node;
@@ -1023,6 +1041,11 @@ __global__ __launch_bounds__(kBlock, ANY ? TH_TRACE3_WAVES_ANY : TH_TRACE3_WAVES
                 const uint32_t slot = cur + k;
                 const float4 p0 = sc.prims[3 * slot];
                 const float4 p1 = sc.prims[3 * slot + 1], p2 = sc.prims[3 * slot + 2];
+#if TH_TRACE3_LEAF_BURST
+                // all three records in one burst: left alone, the compiler sinks the loads of p1 / p2 below the sphere / degenerate test on
+                // p0.w — a second dependent round trip per primitive
+                asm volatile("" ::"v"(p1.x), "v"(p1.y), "v"(p1.z), "v"(p2.x), "v"(p2.y), "v"(p2.z));
+#endif
 #ifdef TH_DIAG_PHASES
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 ph_load += __builtin_readcyclecounter() - ph_t_leaf;

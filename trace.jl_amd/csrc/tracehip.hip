@@ -385,6 +385,10 @@ int upload_scene(trhip_scene* s) {
                 rec[8 * (size_t)k + 3 + j] = nrm[3 * (size_t)k + j];
             }
         if (int rc = upload(ctx, s->d_shade, rec.data(), rec.size() * sizeof(float4))) return rc;
+        // records 6 / 7: what a triangle's interaction derives from its vertices alone, computed by the code the shading kernels would run
+        hipLaunchKernelGGL(k_shade_constants, dim3(std::max(1u, std::min((n_prims + kBlock - 1) / kBlock, 4096u))), dim3(kBlock), 0, ctx->stream, (float4*)s->d_shade.p, n_prims);
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
     if (int rc = upload(ctx, s->d_spheres, s->spheres.data(), s->spheres.size() * sizeof(SphereRec))) return rc;
     if (int rc = upload(ctx, s->d_materials, s->materials.data(), s->materials.size() * sizeof(MaterialRec))) return rc;
