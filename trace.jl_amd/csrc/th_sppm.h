@@ -328,12 +328,32 @@ __global__ __launch_bounds__(kBlock) void k_sppm_grid_bounds(VisiblePoints vp, c
         mx[a] = wave_max(mx[a]);
     }
     mr = wave_max(mr);
-    if (lane_id() == 0 && mr > 0.0f) {
+    // one set of atomics per block (seven words shared by the whole grid: one set per wave was 80 µs of the launch's 97)
+    __shared__ float s_red[kBlock / 64][7];
+    const uint32_t wv = threadIdx.x >> 6;
+    if (lane_id() == 0) {
         for (int a = 0; a < 3; ++a) {
-            atomicMin(&g->enc_min[a], enc_f32(mn[a]));
-            atomicMax(&g->enc_max[a], enc_f32(mx[a]));
+            s_red[wv][a] = mn[a];
+            s_red[wv][3 + a] = mx[a];
         }
-        atomicMax(&g->enc_max_radius, enc_f32(mr));
+        s_red[wv][6] = mr;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (uint32_t w = 1; w < kBlock / 64; ++w) {
+            for (int a = 0; a < 3; ++a) {
+                s_red[0][a] = fminf(s_red[0][a], s_red[w][a]);
+                s_red[0][3 + a] = fmaxf(s_red[0][3 + a], s_red[w][3 + a]);
+            }
+            s_red[0][6] = fmaxf(s_red[0][6], s_red[w][6]);
+        }
+        if (s_red[0][6] > 0.0f) {
+            for (int a = 0; a < 3; ++a) {
+                atomicMin(&g->enc_min[a], enc_f32(s_red[0][a]));
+                atomicMax(&g->enc_max[a], enc_f32(s_red[0][3 + a]));
+            }
+            atomicMax(&g->enc_max_radius, enc_f32(s_red[0][6]));
+        }
     }
 }
 // grid resolution (:293-302)
@@ -374,7 +394,6 @@ __global__ __launch_bounds__(kBlock) void k_sppm_hit_bin(const float4* __restric
     const GridInfo& g = *gp;
     if (!g.valid) return;
     const uint32_t total = n_photons * n_depths;
-    unsigned long long n_hits = 0;
     for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < total; k += gridDim.x * kBlock) {
         const uint32_t d = k / n_photons, i = k - d * n_photons;
         const uint32_t r = d * n_batch_photons + first_photon + i;
@@ -384,17 +403,12 @@ __global__ __launch_bounds__(kBlock) void k_sppm_hit_bin(const float4* __restric
         if (!to_grid(g, mk3(hp.x, hp.y, hp.z), gi)) continue;  // `in_bounds` (:370-373)
         const uint32_t h = grid_hash(gi[0], gi[1], gi[2], hash_size);
         if (pass == 0) {
-            n_hits++;
-            atomicAdd(&counts[h], 1u);
+            atomicAdd(&counts[h], 1u);  // the call's hit total is kept by k_sppm_scan (a counter per wave here was 8 192 atomics on one word: 90 µs of the launch's 130)
         } else {
             // the position travels with the record index: the gather rejects most candidates on the distance alone, without a second,
             // dependent fetch through the index
             hit_sorted[starts[h] + atomicSub(&counts[h], 1u) - 1u] = make_float4(hp.x, hp.y, hp.z, __uint_as_float(r));
         }
-    }
-    if (pass == 0) {
-        n_hits = wave_sum(n_hits);
-        if (lane_id() == 0 && n_hits) atomicAdd(&gp->photon_hits, n_hits);
     }
 }
 // Exclusive prefix sums of the bucket sizes in three launches: tiles of kScanTile counts (local prefix + tile total), the
@@ -455,6 +469,7 @@ __global__ __launch_bounds__(1024) void k_sppm_scan(const uint32_t* __restrict__
     if (t == 1023) {
         starts[n] = part[1023];
         g->total = part[1023];
+        g->photon_hits += part[1023];  // in-bounds photon hits, all iterations of the call
     }
 }
 
@@ -546,56 +561,62 @@ struct PhotonRecords {
 
 // One photon bounce: record the hit at depth > 1 (:366-391 happens in k_sppm_deposit), then sample the next direction and play
 // Russian roulette (:393-418).
+// Consecutive photons (Halton indices) land anywhere: taken 64 at a time in queue order, a wave mixes glass, plastic and matte hits and
+// runs each material's lobe code for a third of its lanes (PMC: 21 of 64 lanes per VALU instruction).  So a wave only CLASSIFIES its
+// entries as they come (material index mod kPhotonRings, from the hit slot's record) and parks their indices in per-class rings in
+// LDS; a class is shaded whenever 64 of its entries wait, all lanes in the same lobe code (the trick of k_shade_path).  Every photon
+// is processed by exactly the code it was processed by before — a photon's record slot and Halton dimensions depend on nothing
+// but its index and depth — so the results do not change.
+constexpr int kPhotonRings = 4;
 __global__ __launch_bounds__(kBlock) void k_shade_photon(DeviceScene sc, PathQueue qin, PathQueue qout, uint32_t cap, const float4* __restrict__ hits, PhotonRecords rec,
                                                          uint32_t n_batch_photons, Counters* ctr, int depth, int max_depth, uint64_t halton_base) {
     __shared__ SegView sv;
+    __shared__ uint32_t s_ring[kBlock / 64][kPhotonRings][128];
     const SegQueue qv{ctr->n_queue[depth - 1], cap, 0u};
     seg_load(qv, sv);
     const uint32_t total = sv.prefix[kSeg];
-    for (uint32_t flat = blockIdx.x * kBlock + threadIdx.x; flat < total; flat += gridDim.x * kBlock) {
-        uint32_t seg_in, lb;
-        seg_locate(sv, flat & ~63u, seg_in, lb);
-        const uint32_t local = lb + (flat & 63u);
-        const bool valid = local < sv.count[seg_in];
-        const uint32_t i = seg_in * cap + local;
-        const uint32_t seg_out = (flat >> 6) % kSeg;
+    const uint32_t lane = lane_id(), wv = threadIdx.x >> 6;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const uint32_t seg_out = ((blockIdx.x * kBlock + threadIdx.x) >> 6) % kSeg;  // every wave-iteration of a wave feeds the same output segment (k_shade_path)
+    uint32_t ring_head[kPhotonRings], ring_cnt[kPhotonRings];  // wave-uniform
+    for (int c = 0; c < kPhotonRings; ++c) ring_head[c] = ring_cnt[c] = 0u;
+    // one photon-path vertex for queue entry i (a real hit), if `on`; called by the whole wave
+    auto vertex = [&](bool on, uint32_t i) {
         bool want_next = false;
-        float4 no4, nd4, nb4;
-        if (valid) {
+        float4 no4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), nd4 = no4, nb4 = no4;
+        if (on) {
             const float4 h4 = hits[i];
             const int prim = __float_as_int(h4.y);
-            if (prim >= 0) {
-                const float4 o4 = qin.o[i], d4 = qin.d[i], b4 = qin.beta[i];
-                const uint32_t photon = __float_as_uint(o4.w);
-                const f3 o = mk3(o4.x, o4.y, o4.z), d = mk3(d4.x, d4.y, d4.z);
-                const f3 beta = mk3(b4.x, b4.y, b4.z);
-                Shading sh;
-                uint32_t material;
-                if (rebuild_shading(sc, prim, o, d, sh, material) && material != PRIM_NO_MATERIAL) {
-                    const f3 wi_photon = -d;
-                    if (depth > 1) {
-                        const size_t r = (size_t)(depth - 2) * n_batch_photons + photon;
-                        rec.p[r] = make_float4(sh.p.x, sh.p.y, sh.p.z, 0.0f);
-                        rec.wi[r] = make_float4(wi_photon.x, wi_photon.y, wi_photon.z, 0.0f);
-                        rec.beta[r] = b4;
-                        rec.valid[r] = 1;
-                    }
-                    const LobeSet& bsdf = sc.materials[material].set[1];  // compute_scattering!(…, true, Importance): the mode changes nothing (A.11)
-                    const uint64_t hidx = halton_base + photon;
-                    const int dim = 6 + 3 * (depth - 1);
-                    const f2 u{radical_inverse(dim, hidx), radical_inverse(dim + 1, hidx)};
-                    const BsdfSample bs = bsdf_sample_f(bsdf, sh, wi_photon, u, BSDF_ALL);
-                    if (!(is_black(bs.f) || bs.pdf == 0.0f) && depth < max_depth) {
-                        const f3 beta_new = beta * bs.f * fabs_(dot(bs.wi, sh.ns)) / bs.pdf;
-                        const float q = jmax(0.0f, 1.0f - to_Y(beta_new) / to_Y(beta));
-                        if (!(radical_inverse(dim + 2, hidx) < q)) {
-                            const f3 org = sh.p + 1e-6f * bs.wi;
-                            const f3 nd = check_direction(bs.wi);
-                            no4 = make_float4(org.x, org.y, org.z, __uint_as_float(photon));
-                            nd4 = make_float4(nd.x, nd.y, nd.z, 0.0f);
-                            nb4 = b4;
-                            want_next = true;
-                        }
+            const float4 o4 = qin.o[i], d4 = qin.d[i], b4 = qin.beta[i];
+            const uint32_t photon = __float_as_uint(o4.w);
+            const f3 o = mk3(o4.x, o4.y, o4.z), d = mk3(d4.x, d4.y, d4.z);
+            const f3 beta = mk3(b4.x, b4.y, b4.z);
+            Shading sh;
+            uint32_t material;
+            if (rebuild_shading(sc, prim, o, d, sh, material) && material != PRIM_NO_MATERIAL) {
+                const f3 wi_photon = -d;
+                if (depth > 1) {
+                    const size_t r = (size_t)(depth - 2) * n_batch_photons + photon;
+                    rec.p[r] = make_float4(sh.p.x, sh.p.y, sh.p.z, 0.0f);
+                    rec.wi[r] = make_float4(wi_photon.x, wi_photon.y, wi_photon.z, 0.0f);
+                    rec.beta[r] = b4;
+                    rec.valid[r] = 1;
+                }
+                const LobeSet& bsdf = sc.materials[material].set[1];  // compute_scattering!(…, true, Importance): the mode changes nothing (A.11)
+                const uint64_t hidx = halton_base + photon;
+                const int dim = 6 + 3 * (depth - 1);
+                const f2 u{radical_inverse(dim, hidx), radical_inverse(dim + 1, hidx)};
+                const BsdfSample bs = bsdf_sample_f(bsdf, sh, wi_photon, u, BSDF_ALL);
+                if (!(is_black(bs.f) || bs.pdf == 0.0f) && depth < max_depth) {
+                    const f3 beta_new = beta * bs.f * fabs_(dot(bs.wi, sh.ns)) / bs.pdf;
+                    const float q = jmax(0.0f, 1.0f - to_Y(beta_new) / to_Y(beta));
+                    if (!(radical_inverse(dim + 2, hidx) < q)) {
+                        const f3 org = sh.p + 1e-6f * bs.wi;
+                        const f3 nd = check_direction(bs.wi);
+                        no4 = make_float4(org.x, org.y, org.z, __uint_as_float(photon));
+                        nd4 = make_float4(nd.x, nd.y, nd.z, 0.0f);
+                        nb4 = b4;
+                        want_next = true;
                     }
                 }
             }
@@ -606,7 +627,35 @@ __global__ __launch_bounds__(kBlock) void k_shade_photon(DeviceScene sc, PathQue
             qout.d[ni] = nd4;
             qout.beta[ni] = nb4;
         }
+    };
+    for (uint32_t flat = blockIdx.x * kBlock + threadIdx.x; flat < total; flat += gridDim.x * kBlock) {
+        uint32_t seg_in, lb;
+        seg_locate(sv, flat & ~63u, seg_in, lb);
+        const uint32_t local = lb + (flat & 63u);
+        const uint32_t i = seg_in * cap + local;
+        int cls = -1;  // -1: nothing to do (padding, miss)
+        if (local < sv.count[seg_in]) {
+            const int prim = __float_as_int(hits[i].y);
+            if (prim >= 0) cls = (int)((__float_as_uint(sc.shade[8 * (size_t)prim].w) & PRIM_MATERIAL_MASK) % (uint32_t)kPhotonRings);
+        }
+#pragma unroll
+        for (int c = 0; c < kPhotonRings; ++c) {
+            const unsigned long long m = __ballot(cls == c);
+            if (m == 0ull) continue;
+            if (cls == c) s_ring[wv][c][(ring_head[c] + ring_cnt[c] + (uint32_t)__popcll(m & lt_mask)) & 127u] = i;
+            ring_cnt[c] += (uint32_t)__popcll(m);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (ring_cnt[c] >= 64u) {
+                vertex(true, s_ring[wv][c][(ring_head[c] + lane) & 127u]);
+                ring_head[c] = (ring_head[c] + 64u) & 127u;
+                ring_cnt[c] -= 64u;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            }
+        }
     }
+#pragma unroll
+    for (int c = 0; c < kPhotonRings; ++c)
+        if (ring_cnt[c]) vertex(lane < ring_cnt[c], s_ring[wv][c][(ring_head[c] + lane) & 127u]);  // the last, partial batches
 }
 
 // `pixel.ϕ += β · f_vp(wo_vp, wi)`, `pixel.M += 1` (sppm.jl:374-391) for one iteration, gathered per pixel: for every cell the
@@ -658,7 +707,7 @@ TH_D GatherSum gather_pixel(const DeviceScene& sc, const PhotonRecords& rec, con
 }
 // One thread per pixel; also counts the registrations (the reference's list nodes) for trhip_sppm_state.
 __global__ __launch_bounds__(kBlock) void k_sppm_gather(DeviceScene sc, PhotonRecords rec, VisiblePoints vp, PixelStats px, uint32_t n, GridInfo* gp, const uint32_t* __restrict__ starts,
-                                                        const float4* __restrict__ hit_sorted, uint32_t hash_size, uint32_t* __restrict__ hot_list) {
+                                                        const float4* __restrict__ hit_sorted, uint32_t hash_size, uint32_t* __restrict__ hot_list, uint32_t count_registrations) {
     // A wave takes 64 pixels.  Every lane walks the buckets of ITS pixel one candidate per round (a cursor over cells and entries);
     // the (pixel, photon) pairs that pass the distance test are parked in a per-wave ring and evaluated 64 at a time — frame and
     // material of the pair's pixel are fetched by whichever lane gets the pair — and summed per pixel in LDS.  (One thread per pixel
@@ -789,8 +838,10 @@ __global__ __launch_bounds__(kBlock) void k_sppm_gather(DeviceScene sc, PhotonRe
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
-    n_reg = wave_sum(n_reg);
-    if (lane_id() == 0 && n_reg) atomicAdd(&gp->registrations, n_reg);
+    if (count_registrations) {  // trhip_sppm_state reports the last iteration's: only that launch pays for 8 192 atomics on one word (90 µs)
+        n_reg = wave_sum(n_reg);
+        if (lane_id() == 0 && n_reg) atomicAdd(&gp->registrations, n_reg);
+    }
 }
 __global__ __launch_bounds__(kBlock) void k_sppm_gather_hot(DeviceScene sc, PhotonRecords rec, VisiblePoints vp, PixelStats px, GridInfo* gp, const uint32_t* __restrict__ starts,
                                                             const float4* __restrict__ hit_sorted, uint32_t hash_size, const uint32_t* __restrict__ hot_list) {
