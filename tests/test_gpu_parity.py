@@ -227,12 +227,13 @@ def test_render_batches_and_sample_offset(T, ob, ctx, shadows):
     finally:
         ctx.set_option("batch_paths", 0)
     assert_bits_equal(a, b, "batched film")
-    ctx.set_option("overlap", 0)  # single-stream schedule
-    try:
-        c = T.PathIntegrator(cam, T.SeededSampler(4, seed=9), 4).render(scene).copy()
-    finally:
-        ctx.set_option("overlap", 1)
-    assert_bits_equal(a, c, "film without the two-stream overlap")
+    for overlap in (0, 1):  # single-stream schedule / shadow rays on a second stream (the default, -1, picks one per scene)
+        ctx.set_option("overlap", overlap)
+        try:
+            c = T.PathIntegrator(cam, T.SeededSampler(4, seed=9), 4).render(scene).copy()
+        finally:
+            ctx.set_option("overlap", -1)
+        assert_bits_equal(a, c, f"film with overlap = {overlap}")
     ctx.set_option("pipelines", 4)  # four batches in flight on separate stream pairs
     ctx.set_option("batch_paths", 4 * 34 * 34)
     try:
@@ -369,11 +370,11 @@ def test_streaming_wavefront_matches_classic_and_oracle(T, ob, ctx, traversal):
             ctx.set_option("streaming", 0)
             ctx.set_option("stream_budget_min", 2048)
             ctx.set_option("stream_list_cap", 0)
-            ctx.set_option("overlap", 1)
+            ctx.set_option("overlap", -1)
 
     classic, classic_L, st0 = render(streaming=0)
     assert_bits_equal(classic, ref, "classic film")
-    for opts in ({"streaming": 1}, {"streaming": 1, "stream_budget_min": 1}, {"streaming": 1, "stream_budget_min": 7}, {"streaming": 1, "stream_budget_min": 3, "stream_list_cap": 64},
+    for opts in ({"streaming": 0, "overlap": 1}, {"streaming": 0, "overlap": 0}, {"streaming": 1}, {"streaming": 1, "stream_budget_min": 1}, {"streaming": 1, "stream_budget_min": 7}, {"streaming": 1, "stream_budget_min": 3, "stream_list_cap": 64},
                  {"streaming": 1, "stream_budget_min": 2, "overlap": 0}):
         film, L, st = render(**opts)
         assert_bits_equal(L, classic_L, f"per-sample radiance, {opts}")

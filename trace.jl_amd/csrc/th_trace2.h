@@ -633,34 +633,38 @@ struct OccluderSet {
     const float* boxes;     // their leaf node's bounds, 6 floats each
     uint32_t n;
 };
+// Two stages.  Ordered by the solid angle they subtend at the lights, the first two or three occluders stop most rays (2.3 tests per
+// ray on the S-mesh scene) — but a wave that walks the whole list for the last of its 64 rays runs all the tests with a handful of
+// lanes.  Stage A therefore tests only the first TH_OCC_STAGE_A occluders on the rays as they come; the rays still looking are parked in
+// a per-wave ring in LDS and, 64 at a time, go through the rest of the list in stage B with all lanes busy at its start.
+#ifndef TH_OCC_STAGE_A
+#define TH_OCC_STAGE_A 3
+#endif
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock, 5) void k_any_occluders(DeviceScene sc, OccluderSet oc, SegQueue q, const float4* __restrict__ ro, const float4* __restrict__ rd,
                                                              const float* __restrict__ tmax_or_null, TraceOut out, uint32_t* __restrict__ surv, uint32_t* __restrict__ surv_counts,
                                                              uint32_t surv_cap, Counters* ctr) {
     __shared__ SegView sv;
+    __shared__ uint32_t s_ring[kBlock / 64][128];
     seg_load(q, sv);
     const uint32_t total = sv.prefix[kSeg];
+    const uint32_t lane = lane_id(), wv = threadIdx.x >> 6;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    // the survivors of a wave go to one list: chunk c of the flat work space is taken by wave c mod (waves of the grid, a multiple of kSeg),
+    // so list s receives the survivors of every kSeg-th chunk: at most total / kSeg + 64 <= surv_cap entries
+    const uint32_t seg_out = q.counts ? ((blockIdx.x * kBlock + threadIdx.x) >> 6) % kSeg : 0u;  // a dense queue (kernel-level API) has one list
+    const uint32_t n_a = min(oc.n, (uint32_t)TH_OCC_STAGE_A);
     uint32_t nn = 0, np = 0;
-    unsigned long long resolved = 0;
-    for (uint32_t flat = blockIdx.x * kBlock + threadIdx.x; flat < total; flat += gridDim.x * kBlock) {
-        uint32_t seg, lb;
-        seg_locate(sv, flat & ~63u, seg, lb);
-        const uint32_t local = lb + (flat & 63u);
-        const bool valid = local < sv.count[seg];
-        const uint32_t idx = valid ? seg_phys(q, seg, local) : 0u;
-        float4 o4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), d4 = make_float4(0.0f, 0.0f, 1.0f, 0.0f);
-        if (valid) {
-            o4 = ro[idx];
-            d4 = rd[idx];
-        }
+    uint32_t ring_head = 0, ring_cnt = 0;  // wave-uniform
+    // occluders [k0, k1) on this lane's ray (if `on`); writes the result of a ray that is stopped; returns "stopped"
+    auto run = [&](bool on, uint32_t idx, float4 o4, float4 d4, uint32_t k0, uint32_t k1, bool& live) {
         const f3 o = mk3(o4.x, o4.y, o4.z), d = mk3(d4.x, d4.y, d4.z);
-        const float t_max = (valid && tmax_or_null) ? tmax_or_null[idx] : kInf;
+        const float t_max = (on && tmax_or_null) ? tmax_or_null[idx] : kInf;
         const f3 inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
         const RayShear shear = ray_shear(d);
-        bool live = valid && d.x != 0.0f && d.y != 0.0f && d.z != 0.0f;  // still looking for an occluder
         bool found = false;
 #pragma unroll 1
-        for (uint32_t k = 0; k < oc.n; ++k) {
+        for (uint32_t k = k0; k < k1; ++k) {
             if (__ballot(live) == 0ull) break;
             const uint32_t slot = uniform_load(oc.slots, k);
             const float4 p0 = uniform_load(sc.prims, 3 * slot), p1 = uniform_load(sc.prims, 3 * slot + 1), p2 = uniform_load(sc.prims, 3 * slot + 2);
@@ -679,8 +683,7 @@ __global__ __launch_bounds__(kBlock, 5) void k_any_occluders(DeviceScene sc, Occ
                 }
             }
         }
-        if (valid && found) {
-            resolved++;
+        if (on && found) {
             if (out.L) {
                 const uint32_t poison = __float_as_uint(d4.w);
                 if (poison) {
@@ -696,13 +699,58 @@ __global__ __launch_bounds__(kBlock, 5) void k_any_occluders(DeviceScene sc, Occ
                 out.occluded[idx] = 1;
             }
         }
-        const bool survive = valid && !found;
-        const uint32_t j = wave_compact(survive, &surv_counts[seg * kCtrStride]);  // the wave's entries all belong to `seg`
-        if (survive && j < surv_cap) surv[seg * surv_cap + j] = idx;
+        return found;
+    };
+    auto survivors = [&](bool survive, uint32_t idx) {  // called by the whole wave
+        const uint32_t j = wave_compact(survive, &surv_counts[seg_out * kCtrStride]);
+        if (survive && j < surv_cap) surv[seg_out * surv_cap + j] = idx;
+    };
+    auto stage_b = [&](uint32_t cnt) {  // the first cnt parked rays through the rest of the list
+        const bool on = lane < cnt;
+        const uint32_t idx = on ? s_ring[wv][(ring_head + lane) & 127u] : 0u;
+        float4 o4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), d4 = make_float4(0.0f, 0.0f, 1.0f, 0.0f);
+        if (on) {
+            o4 = ro[idx];
+            d4 = rd[idx];
+        }
+        bool live = on;
+        const bool found = run(on, idx, o4, d4, n_a, oc.n, live);
+        survivors(on && !found, idx);
+    };
+    for (uint32_t flat = blockIdx.x * kBlock + threadIdx.x; flat < total; flat += gridDim.x * kBlock) {
+        uint32_t seg, lb;
+        seg_locate(sv, flat & ~63u, seg, lb);
+        const uint32_t local = lb + (flat & 63u);
+        const bool valid = local < sv.count[seg];
+        const uint32_t idx = valid ? seg_phys(q, seg, local) : 0u;
+        float4 o4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), d4 = make_float4(0.0f, 0.0f, 1.0f, 0.0f);
+        if (valid) {
+            o4 = ro[idx];
+            d4 = rd[idx];
+        }
+        const bool testable = valid && d4.x != 0.0f && d4.y != 0.0f && d4.z != 0.0f;  // a zero component: straight to k_trace3 (see above)
+        bool live = testable;
+        const bool found = run(valid, idx, o4, d4, 0u, n_a, live);
+        const bool park = testable && !found && n_a < oc.n;
+        survivors(valid && !found && !park, idx);
+        const unsigned long long m = __ballot(park);
+        if (m) {
+            if (park) s_ring[wv][(ring_head + ring_cnt + (uint32_t)__popcll(m & lt_mask)) & 127u] = idx;
+            ring_cnt += (uint32_t)__popcll(m);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (ring_cnt >= 64u) {
+                stage_b(64u);
+                ring_head = (ring_head + 64u) & 127u;
+                ring_cnt -= 64u;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            }
+        }
     }
+    if (ring_cnt) stage_b(ring_cnt);
     if (ctr) {
-        resolved = wave_sum(resolved);
-        if (lane_id() == 0 && resolved) atomicAdd(&ctr->shadow_total, resolved);
+        // every ray of the queue is counted here, once (the survivors' launch is told not to: SegQueue::no_total); a count of the resolved
+        // rays per wave was 8 192 atomics on one word at the end of every launch
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctr->shadow_total, (unsigned long long)seg_total(sv));
         if (COUNT) {
             const unsigned long long sn = wave_sum(nn), spr = wave_sum(np);
             if (lane_id() == 0) {

@@ -395,7 +395,7 @@ __global__ __launch_bounds__(kBlock, ANY ? TH_TRACE8_WAVES_ANY : TH_TRACE8_WAVES
         }
     }
     if (ctr) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(ANY ? &ctr->shadow_total : &ctr->closest_total, (unsigned long long)seg_total(sv));
+        if (blockIdx.x == 0 && threadIdx.x == 0 && !q.no_total) atomicAdd(ANY ? &ctr->shadow_total : &ctr->closest_total, (unsigned long long)seg_total(sv));
         if (COUNT) {
             const unsigned long long sn = wave_sum(nn), spr = wave_sum(np);
             if (lane_id() == 0) {

@@ -69,7 +69,9 @@ struct trhip_ctx {
                          // sample's pixel range and table indices per thread; 3 = 1 x 4 from per-sample splat descriptors (k_film_descriptors): measured SLOWER
                          // (1024^2, 256 spp: 29.0 ms against 24.3 ms: the 16-byte descriptor doubles the gather's loads and the arithmetic it saves was hidden)
     bool film_tiled = false;  // LDS-staged film gather (k_film_gather_tiled): bit-identical, measured 2.7x SLOWER than k_film_gather (11 % lane use), kept as an option
-    bool overlap = true;  // two-stream overlap of shadow rays (depth d) with closest-hit rays (depth d+1)
+    int overlap = -1;  // shadow rays of depth d on a second stream beside the closest-hit rays of depth d+1: 1 on, 0 off, -1 (default) on for one-leaf scenes only —
+                       // measured at 256 spp after the two-stage occluder pre-pass: S-cornell 165 (on) vs 174 ms (off), S-mesh 399 vs 393, 10 M triangles 485 vs 480
+    bool overlap_on(const trhip_scene* sc) const;
     int compose_spheres = -1;  // commit: spheres as a chain of leaves above the triangles' subtree, what k_trace8 needs of a scene with spheres
                                // (option "compose_spheres": 1 / 0 = one SAH tree over everything / -1 = when "traversal" is 4 at commit time)
     int traversal = 3;  // 1 = literal accel/bvh.jl loop, 2 = children-in-parent nodes + per-lane ray replacement, 3 = 2 with leaves postponed (while-while),
@@ -127,6 +129,8 @@ struct trhip_scene {
     bool w8_ok = false;            // the 8-wide view exists (th_trace8.h)
     bool literal_only = false;     // a caller-supplied BVH whose boxes do not nest (trhip_scene_set_bvh): literal kernels only
 };
+
+bool trhip_ctx::overlap_on(const trhip_scene* sc) const { return overlap < 0 ? sc->wide.root_cnt > 0 || !sc->wide_ok : overlap != 0; }
 
 namespace {
 
@@ -724,7 +728,7 @@ void launch_trace(trhip_ctx* ctx, hipStream_t st, const trhip_scene* sc, bool an
                     hipLaunchKernelGGL((k_any_occluders<true>), pgrid, block, 0, st, sc->dev, oc, q, ro, rd, tmax, out, sl, scn, scap, ctr);
                 else
                     hipLaunchKernelGGL((k_any_occluders<false>), pgrid, block, 0, st, sc->dev, oc, q, ro, rd, tmax, out, sl, scn, scap, ctr);
-                q = SegQueue{scn, scap, 0u, sl};
+                q = SegQueue{scn, scap, 0u, sl, 1u};
             }
         }
         // ---- traversal 4: 8-wide nodes (th_trace8.h); the rays it does not take come back on a fallback list that k_trace3 walks below ----
@@ -1111,7 +1115,7 @@ int render_stream_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sen
         return SuspendList{(float4*)b[0].p, (float4*)b[1].p, (float4*)b[2].p, (float4*)b[3].p, (uint4*)b[4].p, (uint32_t*)b[5].p, (uint2*)b[6].p, list_cap};
     };
     uint32_t* lc = (uint32_t*)ctx->st_counts.p;  // [0..1] closest list counts (ping-pong), [2] closest cursor, [4..5] any counts, [6] any cursor
-    hipStream_t st = ctx->stream, ps = pp.st, ps2 = ctx->overlap ? pp.st2 : pp.st;
+    hipStream_t st = ctx->stream, ps = pp.st, ps2 = ctx->overlap_on(scene) ? pp.st2 : pp.st;
     const DeviceSensor* dsp = (const DeviceSensor*)ctx->sensor.p;
     float4* L = (float4*)ctx->Lbuf.p;
     float4* terms = (float4*)ctx->st_terms.p;
@@ -1190,7 +1194,7 @@ int render_stream_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sen
     HIP_TRY(ctx, hipEventRecord(pp.ev_done, ps));
     HIP_TRY(ctx, hipStreamWaitEvent(st, pp.ev_done, 0));
     tm.begin(4, st);
-    if (ctx->overlap) hipLaunchKernelGGL(k_apply_poison, dim3(grid_for(ctx, total_slots, 8)), dim3(kBlock), 0, st, L, (const uint8_t*)ctx->poison.p, total_slots);
+    if (ctx->overlap_on(scene)) hipLaunchKernelGGL(k_apply_poison, dim3(grid_for(ctx, total_slots, 8)), dim3(kBlock), 0, st, L, (const uint8_t*)ctx->poison.p, total_slots);
     launch_film(ctx, st, ds, dsp, L, total_slots, spp, seed, sample_offset, (float4*)d_film);
     tm.end(4, st);
     HIP_TRY(ctx, hipEventRecord(e1, st));
@@ -1344,7 +1348,7 @@ int render_impl_band(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
                 if (int rc = ensure(ctx, pp.q[k][j], Pphys * sizeof(float4))) return rc;
         for (int j = 0; j < 3; ++j)
             if (int rc = ensure(ctx, pp.sq[j], Pphys * sizeof(float4))) return rc;
-        if (ctx->overlap)
+        if (ctx->overlap_on(scene))
             for (int j = 0; j < 3; ++j)
                 if (int rc = ensure(ctx, pp.sq2[j], Pphys * sizeof(float4))) return rc;
         if (!pp.ev_any2) HIP_TRY(ctx, hipEventCreateWithFlags(&pp.ev_any2, hipEventDisableTiming));
@@ -1387,7 +1391,7 @@ int render_impl_band(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
         n_batches++;
         const uint64_t nb = std::min<uint64_t>(spp_batch, spp - s0) * npix;
         // Within a batch, shadow rays of depth d (any-hit + accumulate) and closest-hit rays of depth d+1 are independent: two streams.
-        hipStream_t ps = pp.st, ps2 = ctx->overlap ? pp.st2 : pp.st;
+        hipStream_t ps = pp.st, ps2 = ctx->overlap_on(scene) ? pp.st2 : pp.st;
         Counters* ctr = (Counters*)pp.counters.p;
         PathQueue pq[2];
         for (int k = 0; k < 2; ++k) pq[k] = PathQueue{(float4*)pp.q[k][0].p, (float4*)pp.q[k][1].p, (float4*)pp.q[k][2].p};
@@ -1436,7 +1440,7 @@ int render_impl_band(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
         HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->pipes[pi].ev_done, 0));
     }
     tm.begin(4, st);
-    if (ctx->overlap) hipLaunchKernelGGL(k_apply_poison, dim3(grid_for(ctx, total_slots, 8)), dim3(kBlock), 0, st, L, (const uint8_t*)ctx->poison.p, total_slots);
+    if (ctx->overlap_on(scene)) hipLaunchKernelGGL(k_apply_poison, dim3(grid_for(ctx, total_slots, 8)), dim3(kBlock), 0, st, L, (const uint8_t*)ctx->poison.p, total_slots);
     launch_film(ctx, st, ds, dsp, L, total_slots, spp, seed, sample_offset, (float4*)d_film);
     tm.end(4, st);
     HIP_TRY(ctx, hipEventRecord(e1, st));
@@ -2039,7 +2043,7 @@ int trhip_set_option(trhip_ctx* ctx, const char* name, int64_t value) {
         if (value < 1 || value > kMaxPipes) return fail(ctx, TRHIP_ERR_INVALID, "pipelines must be in 1..%d", kMaxPipes);
         ctx->pipelines = (int)value;
     } else if (!std::strcmp(name, "overlap"))
-        ctx->overlap = value != 0;
+        ctx->overlap = value < 0 ? -1 : (value != 0 ? 1 : 0);
     else if (!std::strcmp(name, "traversal")) {
         if (value < 1 || value > 4) return fail(ctx, TRHIP_ERR_INVALID, "traversal must be 1, 2, 3 or 4");
         ctx->traversal = (int)value;
