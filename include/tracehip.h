@@ -240,8 +240,7 @@ int trhip_film_allreduce(trhip_ctx* ctx, void* d_xyzw, uint64_t n_pixels);
  * "compose_spheres" (-1/0/1): how trhip_scene_commit places up to 8 spheres of a scene that also has triangles: 1 = as a chain of
  *     single-sphere leaves above the triangles' subtree (what traversal 4 needs), 0 = inside one SAH tree, -1 (default) = 1 when
  *     "traversal" is 4 at commit time.  Either tree is a valid BVHAccel: results differ only in exact-t ties.
- * "overlap" (-1/0/1): shadow rays of depth d on a second stream beside the closest-hit pass of depth d+1; -1 (default) = for one-leaf
- *     scenes only (there it gains 5 %; beside a hierarchy walk it loses 1 %).
+ * "overlap" (0/1): shadow rays of depth d on a second stream beside the closest-hit pass of depth d+1 (default 0: no gain any more).
  *     "stream2_priority" (-1/0/1): that stream's priority: lowest (default: the closest-hit rays are the critical path), the
  *     default level, highest; read when the streams are created (first render of a context).
  * "pipelines" (1..8): wavefront batches in flight at once (default 1).

@@ -56,6 +56,7 @@ struct WideScene {            // device view of the v2 node array
     uint32_t root_ref, root_cnt;  // root_cnt > 0: the root is a leaf with that many primitives starting at root_ref
     uint32_t n_wnodes;
     float tight_scale;        // slab_test2's margin as a fraction of the ray's reach (2^-14); 0: the reference's loose test alone
+    const uint32_t* leaf_order;  // one-leaf scenes: the order in which any-hit rays test the leaf's primitives (k_any_leaf); null = slot order
 };
 
 // The t_max-independent part of bounds.jl:186-206; returns false when the box is certainly missed, otherwise tx_min (to be
@@ -612,6 +613,153 @@ __global__ __launch_bounds__(kBlock, FULL_ONLY ? TH_TRACE_LEAF_WAVES : 4) void k
             if (lane_id() == 0) {
                 atomicAdd(ANY ? &ctr->nodes_shadow : &ctr->nodes_closest, sn);
                 atomicAdd(ANY ? &ctr->prims_shadow : &ctr->prims_closest, spr);
+            }
+        }
+    }
+}
+
+// ---- k_any_leaf: any-hit rays of a one-leaf scene ------------------------------------------------------------------------------------
+// intersect_p is a boolean, so the order in which the leaf's primitives are tried is free: `ws.leaf_order` lists them by the solid angle
+// they subtend at the lights (a shadow ray runs from the surface through the light, t_max = Inf: what the light sees stops it).  And, as in
+// k_any_occluders below, a wave that walks the whole leaf for the last of its 64 rays runs most tests with a handful of lanes: stage A
+// tries the first TH_LEAF_STAGE_A primitives on the rays as they come, the rays still looking are parked in a per-wave ring in LDS and
+// go through the rest of the leaf 64 at a time (stage B).  S-cornell any-hit: 27 -> see DESIGN.md §4.
+#ifndef TH_LEAF_STAGE_A
+#define TH_LEAF_STAGE_A 3
+#endif
+template <bool COUNT, bool FULL_ONLY>
+__global__ __launch_bounds__(kBlock, FULL_ONLY ? TH_TRACE_LEAF_WAVES : 4) void k_any_leaf(DeviceScene sc, WideScene ws, SegQueue q, const float4* __restrict__ ro, const float4* __restrict__ rd,
+                                                                          const float* __restrict__ tmax_or_null, TraceOut out, Counters* ctr) {
+    __shared__ SegView sv;
+    __shared__ uint32_t s_ring[kBlock / 64][128];
+    seg_load(q, sv);
+    const uint32_t total = sv.prefix[kSeg];
+    const uint32_t first = ws.root_ref, cnt = ws.root_cnt;
+    const uint32_t lane = lane_id(), wv = threadIdx.x >> 6;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const uint32_t n_a = min(cnt, (uint32_t)TH_LEAF_STAGE_A);
+    uint32_t nn = 0, np = 0;
+    uint32_t ring_head = 0, ring_cnt = 0;  // wave-uniform
+    // primitives order[k0 .. k1) on this lane's ray while it is `live`; returns "accepted by one of them"
+    auto run = [&](uint32_t idx, f3 o, f3 d, uint32_t k0, uint32_t k1, bool& live) {
+        const float t_max = (live && tmax_or_null) ? tmax_or_null[idx] : kInf;
+        const RayShear shear = ray_shear(d);
+        bool found = false;
+#pragma unroll 1
+        for (uint32_t k = k0; k < k1; ++k) {
+            if (__ballot(live) == 0ull) break;
+            const uint32_t slot = first + (ws.leaf_order ? uniform_load(ws.leaf_order, k) : k);  // wave-uniform: scalar loads
+            const float4 p0 = uniform_load(sc.prims, 3 * slot);
+            const uint32_t meta = __float_as_uint(p0.w);
+            if (meta & PRIM_SPHERE) {
+                const SphereRec sr = uniform_load(sc.spheres, __float_as_uint(p0.x));
+                if (live) {
+                    if (COUNT) np++;
+                    SphereHit sh;
+                    if (sphere_intersect<false, FULL_ONLY>(sr, o, d, t_max, sh)) {
+                        found = true;
+                        live = false;
+                    }
+                }
+            } else if (!(meta & PRIM_DEGENERATE)) {
+                const float4 p1 = uniform_load(sc.prims, 3 * slot + 1), p2 = uniform_load(sc.prims, 3 * slot + 2);
+                if (live) {
+                    if (COUNT) np++;
+                    TriTest tt;
+                    if (tri_intersect_sheared<false>(mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z), o, shear, t_max, &tt)) {
+                        found = true;
+                        live = false;
+                    }
+                }
+            } else if (COUNT && live) {
+                np++;  // k_trace2 counts the degenerate triangle it skips
+            }
+        }
+        return found;
+    };
+    auto deliver = [&](bool on, uint32_t idx, float4 o4, float4 d4, bool found) {
+        if (!on) return;
+        if (out.L) {
+            const uint32_t slot = __float_as_uint(o4.w);
+            if (!found) {
+                const float4 c = out.contrib[idx];
+                float4 l = out.L[slot];
+                l.x += c.x;
+                l.y += c.y;
+                l.z += c.z;
+                out.L[slot] = l;
+            } else {
+                const uint32_t poison = __float_as_uint(d4.w);
+                if (poison) {
+                    float4 l = out.L[slot];
+                    const float nanv = __builtin_nanf("");
+                    if (poison & 1u) l.x += nanv;
+                    if (poison & 2u) l.y += nanv;
+                    if (poison & 4u) l.z += nanv;
+                    out.L[slot] = l;
+                }
+            }
+        } else {
+            out.occluded[idx] = found ? 1 : 0;
+        }
+    };
+    auto stage_b = [&](uint32_t n) {  // the first n parked rays through the rest of the leaf
+        const bool on = lane < n;
+        const uint32_t idx = on ? s_ring[wv][(ring_head + lane) & 127u] : 0u;
+        float4 o4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), d4 = make_float4(0.0f, 0.0f, 1.0f, 0.0f);
+        if (on) {
+            o4 = ro[idx];
+            d4 = rd[idx];
+        }
+        bool live = on;
+        const bool found = run(idx, mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z), n_a, cnt, live);
+        deliver(on, idx, o4, d4, found);
+    };
+    for (uint32_t flat = blockIdx.x * kBlock + threadIdx.x; flat < total; flat += gridDim.x * kBlock) {
+        uint32_t seg, lb;
+        seg_locate(sv, flat & ~63u, seg, lb);
+        const uint32_t local = lb + (flat & 63u);
+        const bool valid = local < sv.count[seg];
+        const uint32_t idx = valid ? seg_phys(q, seg, local) : 0u;
+        float4 o4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), d4 = make_float4(0.0f, 0.0f, 1.0f, 0.0f);
+        if (valid) {
+            o4 = ro[idx];
+            d4 = rd[idx];
+        }
+        const f3 o = mk3(o4.x, o4.y, o4.z), d = mk3(d4.x, d4.y, d4.z);
+        bool live = false;  // still has primitives to test
+        if (valid) {
+            const float t_max = tmax_or_null ? tmax_or_null[idx] : kInf;
+            const f3 inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+            float tmin;
+            if (COUNT) nn++;
+            live = slab_test2(ws.root_box[0], ws.root_box[1], ws.root_box[2], ws.root_box[3], ws.root_box[4], ws.root_box[5], o, inv_d, 0.0f, false, d.x < 0.0f, d.y < 0.0f, d.z < 0.0f, tmin) &&
+                   tmin < t_max;
+        }
+        const bool found = run(idx, o, d, 0u, n_a, live);
+        const bool park = live && n_a < cnt;  // passed the root box, not stopped yet, primitives left
+        deliver(valid && !park, idx, o4, d4, found);
+        const unsigned long long m = __ballot(park);
+        if (m) {
+            if (park) s_ring[wv][(ring_head + ring_cnt + (uint32_t)__popcll(m & lt_mask)) & 127u] = idx;
+            ring_cnt += (uint32_t)__popcll(m);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (ring_cnt >= 64u) {
+                stage_b(64u);
+                ring_head = (ring_head + 64u) & 127u;
+                ring_cnt -= 64u;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            }
+        }
+    }
+    if (ring_cnt) stage_b(ring_cnt);
+    if (ctr) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctr->shadow_total, (unsigned long long)seg_total(sv));
+        if (COUNT) {
+            const unsigned long long sn = wave_sum(nn), spr = wave_sum(np);
+            if (lane_id() == 0) {
+                atomicAdd(&ctr->nodes_shadow, sn);
+                atomicAdd(&ctr->prims_shadow, spr);
             }
         }
     }

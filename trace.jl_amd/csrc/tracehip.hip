@@ -69,9 +69,9 @@ struct trhip_ctx {
                          // sample's pixel range and table indices per thread; 3 = 1 x 4 from per-sample splat descriptors (k_film_descriptors): measured SLOWER
                          // (1024^2, 256 spp: 29.0 ms against 24.3 ms: the 16-byte descriptor doubles the gather's loads and the arithmetic it saves was hidden)
     bool film_tiled = false;  // LDS-staged film gather (k_film_gather_tiled): bit-identical, measured 2.7x SLOWER than k_film_gather (11 % lane use), kept as an option
-    int overlap = -1;  // shadow rays of depth d on a second stream beside the closest-hit rays of depth d+1: 1 on, 0 off, -1 (default) on for one-leaf scenes only —
-                       // measured at 256 spp after the two-stage occluder pre-pass: S-cornell 165 (on) vs 174 ms (off), S-mesh 399 vs 393, 10 M triangles 485 vs 480
-    bool overlap_on(const trhip_scene* sc) const;
+    bool overlap = false;  // shadow rays of depth d on a second stream beside the closest-hit rays of depth d+1 (option "overlap").  Off since the two-stage
+                           // any-hit kernels (k_any_occluders, k_any_leaf) halved the shadow rays' cost: 256 spp, on / off: S-cornell 158.2 / 157.9 ms, S-mesh 399 / 393,
+                           // 10 M triangles 485 / 480 (it was worth 5 ms of S-cornell's 172 before)
     int compose_spheres = -1;  // commit: spheres as a chain of leaves above the triangles' subtree, what k_trace8 needs of a scene with spheres
                                // (option "compose_spheres": 1 / 0 = one SAH tree over everything / -1 = when "traversal" is 4 at commit time)
     int traversal = 3;  // 1 = literal accel/bvh.jl loop, 2 = children-in-parent nodes + per-lane ray replacement, 3 = 2 with leaves postponed (while-while),
@@ -120,7 +120,7 @@ struct trhip_scene {
     DevBuf d_nodes, d_prims, d_nrm, d_shade, d_spheres, d_materials, d_lights, d_wnodes;
     DeviceScene dev{};
     WideScene wide{};
-    DevBuf d_occ_slots, d_occ_boxes, d_w8nodes, d_w8tris;
+    DevBuf d_occ_slots, d_occ_boxes, d_w8nodes, d_w8tris, d_leaf_order;
     Wide8Scene w8{};              // the 8-wide view of the triangles' subtree (th_wide8.h / th_trace8.h)
     uint32_t w8_nodes = 0, w8_depth = 0;
     uint32_t n_occluders = 0;     // the scene's largest triangles, tested first by any-hit rays (th_trace2.h, k_any_occluders)
@@ -129,8 +129,6 @@ struct trhip_scene {
     bool w8_ok = false;            // the 8-wide view exists (th_trace8.h)
     bool literal_only = false;     // a caller-supplied BVH whose boxes do not nest (trhip_scene_set_bvh): literal kernels only
 };
-
-bool trhip_ctx::overlap_on(const trhip_scene* sc) const { return overlap < 0 ? sc->wide.root_cnt > 0 || !sc->wide_ok : overlap != 0; }
 
 namespace {
 
@@ -513,6 +511,48 @@ int upload_scene(trhip_scene* s) {
             }
         }
     }
+    // ---- one-leaf scenes: the order in which any-hit rays try the leaf's primitives (th_trace2.h, k_any_leaf) ----
+    // A shadow ray runs from the surface THROUGH the light (t_max = Inf): what stops it at the latest is what the light sees, so the
+    // primitives subtending the largest solid angle at the lights come first (triangles: Van Oosterom & Strackee; spheres: the cap of
+    // their bounding sphere).  Any order gives the same boolean.
+    s->wide.leaf_order = nullptr;
+    if (s->wide_ok && s->wide.root_cnt > 1 && !s->lights.empty()) {
+        const uint32_t first = s->wide.root_ref, cnt = s->wide.root_cnt;
+        std::vector<std::pair<double, uint32_t>> ord;
+        for (uint32_t k = 0; k < cnt; ++k) {
+            const HostPrim& p = s->prims[s->bvh.order[first + k]];
+            double w = 0.0;
+            for (const LightRec& l : s->lights) {
+                const float* lp = l.position;
+                if (p.kind == 1) {
+                    const HostAABB& b = s->sphere_bounds[p.sphere_id];
+                    double c[3], r = 0.0, d2 = 0.0;
+                    for (int a = 0; a < 3; ++a) {
+                        c[a] = 0.5 * ((double)b.mn[a] + b.mx[a]);
+                        r = std::max(r, 0.5 * ((double)b.mx[a] - b.mn[a]));
+                        d2 += (c[a] - lp[a]) * (c[a] - lp[a]);
+                    }
+                    w += d2 <= r * r ? 4.0 * 3.14159265358979 : 2.0 * 3.14159265358979 * (1.0 - std::sqrt(std::max(0.0, 1.0 - r * r / d2)));
+                } else {
+                    double r[3][3], len[3];
+                    for (int v = 0; v < 3; ++v) {
+                        for (int c = 0; c < 3; ++c) r[v][c] = (double)p.v[3 * v + c] - lp[c];
+                        len[v] = std::sqrt(r[v][0] * r[v][0] + r[v][1] * r[v][1] + r[v][2] * r[v][2]);
+                    }
+                    const double det = r[0][0] * (r[1][1] * r[2][2] - r[1][2] * r[2][1]) - r[0][1] * (r[1][0] * r[2][2] - r[1][2] * r[2][0]) + r[0][2] * (r[1][0] * r[2][1] - r[1][1] * r[2][0]);
+                    auto dot3 = [&](int a, int b) { return r[a][0] * r[b][0] + r[a][1] * r[b][1] + r[a][2] * r[b][2]; };
+                    const double den = len[0] * len[1] * len[2] + dot3(0, 1) * len[2] + dot3(0, 2) * len[1] + dot3(1, 2) * len[0];
+                    w += 2.0 * std::fabs(std::atan2(det, den));
+                }
+            }
+            ord.push_back({w, k});
+        }
+        std::stable_sort(ord.begin(), ord.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
+        std::vector<uint32_t> order(cnt);
+        for (uint32_t k = 0; k < cnt; ++k) order[k] = ord[k].second;
+        if (int rc = upload(ctx, s->d_leaf_order, order.data(), order.size() * sizeof(uint32_t))) return rc;
+        s->wide.leaf_order = (const uint32_t*)s->d_leaf_order.p;
+    }
     // ---- largest triangles: the any-hit pre-pass (th_trace2.h, k_any_occluders) ----
     s->n_occluders = 0;
     if (s->wide_ok && s->wide.root_cnt == 0) {
@@ -778,9 +818,9 @@ void launch_trace(trhip_ctx* ctx, hipStream_t st, const trhip_scene* sc, bool an
             const dim3 lgrid(ctx->num_cu * 8);
             if (any) {
                 if (cnt)
-                    { if (full_only) hipLaunchKernelGGL((k_trace_leaf<true, true, true>), lgrid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, ctr); else hipLaunchKernelGGL((k_trace_leaf<true, true, false>), lgrid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, ctr); }
+                    { if (full_only) hipLaunchKernelGGL((k_any_leaf<true, true>), lgrid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, ctr); else hipLaunchKernelGGL((k_any_leaf<true, false>), lgrid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, ctr); }
                 else
-                    { if (full_only) hipLaunchKernelGGL((k_trace_leaf<true, false, true>), lgrid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, ctr); else hipLaunchKernelGGL((k_trace_leaf<true, false, false>), lgrid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, ctr); }
+                    { if (full_only) hipLaunchKernelGGL((k_any_leaf<false, true>), lgrid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, ctr); else hipLaunchKernelGGL((k_any_leaf<false, false>), lgrid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, ctr); }
             } else {
                 if (cnt)
                     { if (full_only) hipLaunchKernelGGL((k_trace_leaf<false, true, true>), lgrid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, ctr); else hipLaunchKernelGGL((k_trace_leaf<false, true, false>), lgrid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, ctr); }
@@ -1115,7 +1155,7 @@ int render_stream_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sen
         return SuspendList{(float4*)b[0].p, (float4*)b[1].p, (float4*)b[2].p, (float4*)b[3].p, (uint4*)b[4].p, (uint32_t*)b[5].p, (uint2*)b[6].p, list_cap};
     };
     uint32_t* lc = (uint32_t*)ctx->st_counts.p;  // [0..1] closest list counts (ping-pong), [2] closest cursor, [4..5] any counts, [6] any cursor
-    hipStream_t st = ctx->stream, ps = pp.st, ps2 = ctx->overlap_on(scene) ? pp.st2 : pp.st;
+    hipStream_t st = ctx->stream, ps = pp.st, ps2 = ctx->overlap ? pp.st2 : pp.st;
     const DeviceSensor* dsp = (const DeviceSensor*)ctx->sensor.p;
     float4* L = (float4*)ctx->Lbuf.p;
     float4* terms = (float4*)ctx->st_terms.p;
@@ -1194,7 +1234,7 @@ int render_stream_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sen
     HIP_TRY(ctx, hipEventRecord(pp.ev_done, ps));
     HIP_TRY(ctx, hipStreamWaitEvent(st, pp.ev_done, 0));
     tm.begin(4, st);
-    if (ctx->overlap_on(scene)) hipLaunchKernelGGL(k_apply_poison, dim3(grid_for(ctx, total_slots, 8)), dim3(kBlock), 0, st, L, (const uint8_t*)ctx->poison.p, total_slots);
+    if (ctx->overlap) hipLaunchKernelGGL(k_apply_poison, dim3(grid_for(ctx, total_slots, 8)), dim3(kBlock), 0, st, L, (const uint8_t*)ctx->poison.p, total_slots);
     launch_film(ctx, st, ds, dsp, L, total_slots, spp, seed, sample_offset, (float4*)d_film);
     tm.end(4, st);
     HIP_TRY(ctx, hipEventRecord(e1, st));
@@ -1348,7 +1388,7 @@ int render_impl_band(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
                 if (int rc = ensure(ctx, pp.q[k][j], Pphys * sizeof(float4))) return rc;
         for (int j = 0; j < 3; ++j)
             if (int rc = ensure(ctx, pp.sq[j], Pphys * sizeof(float4))) return rc;
-        if (ctx->overlap_on(scene))
+        if (ctx->overlap)
             for (int j = 0; j < 3; ++j)
                 if (int rc = ensure(ctx, pp.sq2[j], Pphys * sizeof(float4))) return rc;
         if (!pp.ev_any2) HIP_TRY(ctx, hipEventCreateWithFlags(&pp.ev_any2, hipEventDisableTiming));
@@ -1391,7 +1431,7 @@ int render_impl_band(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
         n_batches++;
         const uint64_t nb = std::min<uint64_t>(spp_batch, spp - s0) * npix;
         // Within a batch, shadow rays of depth d (any-hit + accumulate) and closest-hit rays of depth d+1 are independent: two streams.
-        hipStream_t ps = pp.st, ps2 = ctx->overlap_on(scene) ? pp.st2 : pp.st;
+        hipStream_t ps = pp.st, ps2 = ctx->overlap ? pp.st2 : pp.st;
         Counters* ctr = (Counters*)pp.counters.p;
         PathQueue pq[2];
         for (int k = 0; k < 2; ++k) pq[k] = PathQueue{(float4*)pp.q[k][0].p, (float4*)pp.q[k][1].p, (float4*)pp.q[k][2].p};
@@ -1440,7 +1480,7 @@ int render_impl_band(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
         HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->pipes[pi].ev_done, 0));
     }
     tm.begin(4, st);
-    if (ctx->overlap_on(scene)) hipLaunchKernelGGL(k_apply_poison, dim3(grid_for(ctx, total_slots, 8)), dim3(kBlock), 0, st, L, (const uint8_t*)ctx->poison.p, total_slots);
+    if (ctx->overlap) hipLaunchKernelGGL(k_apply_poison, dim3(grid_for(ctx, total_slots, 8)), dim3(kBlock), 0, st, L, (const uint8_t*)ctx->poison.p, total_slots);
     launch_film(ctx, st, ds, dsp, L, total_slots, spp, seed, sample_offset, (float4*)d_film);
     tm.end(4, st);
     HIP_TRY(ctx, hipEventRecord(e1, st));
@@ -2043,7 +2083,7 @@ int trhip_set_option(trhip_ctx* ctx, const char* name, int64_t value) {
         if (value < 1 || value > kMaxPipes) return fail(ctx, TRHIP_ERR_INVALID, "pipelines must be in 1..%d", kMaxPipes);
         ctx->pipelines = (int)value;
     } else if (!std::strcmp(name, "overlap"))
-        ctx->overlap = value < 0 ? -1 : (value != 0 ? 1 : 0);
+        ctx->overlap = value != 0;
     else if (!std::strcmp(name, "traversal")) {
         if (value < 1 || value > 4) return fail(ctx, TRHIP_ERR_INVALID, "traversal must be 1, 2, 3 or 4");
         ctx->traversal = (int)value;
@@ -2069,6 +2109,7 @@ void trhip_scene_free(trhip_scene* s) {
     release(s->d_prims);
     release(s->d_nrm);
     release(s->d_shade);
+    release(s->d_leaf_order);
     release(s->d_spheres);
     release(s->d_materials);
     release(s->d_lights);
