@@ -232,11 +232,12 @@ int trhip_film_allreduce(trhip_ctx* ctx, void* d_xyzw, uint64_t n_pixels);
 /* "count_visits" (0/1): instrumented traversal kernels fill nodes_visited / prims_tested.
  * "batch_paths": paths in flight per wavefront batch (0 = size from free HBM, the default).
  * "timing" (0/1): per-kernel HIP-event timing in trhip_stats (default 1).
- * "traversal" (1/2/3/4): 1 = literal accel/bvh.jl loop, 2 = children-in-parent nodes with per-lane ray replacement,
+ * "traversal" (1/2/3/4/6): 1 = literal accel/bvh.jl loop, 2 = children-in-parent nodes with per-lane ray replacement,
  *     3 (default) = 2 with the leaves of a wave postponed and tested together, 4 = 8-wide nodes with quantised child boxes walked
  *     in the binary tree's depth-first order (th_trace8.h; measured on par with 3); scenes 4 cannot take (foreign
  *     trees whose boxes do not nest, leaves of several primitives, more than 8 spheres, spheres not committed as a chain — see
- *     "compose_spheres") and rays it cannot take (a zero direction component) run 3.  Same results bit for bit.
+ *     "compose_spheres") and rays it cannot take (a zero direction component) run 3; 6 = 3 with two rays per lane (th_trace4.h: better
+ *     lane use, no fewer instructions: measured slower).  Same results bit for bit.
  * "compose_spheres" (-1/0/1): how trhip_scene_commit places up to 8 spheres of a scene that also has triangles: 1 = as a chain of
  *     single-sphere leaves above the triangles' subtree (what traversal 4 needs), 0 = inside one SAH tree, -1 (default) = 1 when
  *     "traversal" is 4 at commit time.  Either tree is a valid BVHAccel: results differ only in exact-t ties.

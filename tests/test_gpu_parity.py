@@ -8,7 +8,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=[4, 2, 3, 1], ids=["trace8", "trace2", "trace3", "trace1"])
+@pytest.fixture(autouse=True, params=[4, 6, 2, 3, 1], ids=["trace8", "trace4x2", "trace2", "trace3", "trace1"])
 def traversal(request, ctx):
     """Every parity test runs with all traversal kernels: 4 = k_trace8 (8-wide quantised nodes in the binary walk's order; the
     default), 2 = k_trace2 (children-in-parent nodes, per-lane ray replacement), 3 = k_trace3 (the same with leaves postponed
@@ -335,7 +335,7 @@ def test_partial_spheres_and_transforms(T, ob, ctx):
         osc2 = ob.OracleScene.from_scene(scene2, bvh=flat2.bvh())
         t2, prim2, _, _ = osc2.trace_closest(rays)
         occ2, _ = osc2.trace_any(rays)
-        for trav in (4, 3, 2, 1):
+        for trav in (6, 4, 3, 2, 1):
             ctx.set_option("traversal", trav)
             h2 = flat2.trace_closest(rays)
             assert np.array_equal(h2["prim"], prim2), trav

@@ -20,7 +20,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 def traversals(T, ctx):
     """Traversal kernels of this build; the last entry (1) is the literal accel/bvh.jl loop, the first the library's default."""
-    return (3, 4, 2, 1)
+    return (3, 6, 4, 2, 1)
 
 
 def bits(a):
@@ -136,7 +136,7 @@ def check_frame(T, ob, ctx, scene, osc, res=64, spp=32, depth=16, seed=0x5EED000
     films = {}
     travs = traversals(T, ctx)
     ran = {}
-    for trav in (3, 4, 1):
+    for trav in (3, 6, 4, 1):
         ctx.set_option("traversal", trav)
         try:
             integ = T.PathIntegrator(cam, T.SeededSampler(spp, seed=seed), depth)

@@ -15,6 +15,7 @@
 #include "th_kernels.h"
 #include "th_trace2.h"
 #include "th_trace8.h"
+#include "th_trace4.h"
 #include "th_whitted.h"
 #include "th_sppm.h"
 #include "th_lbvh.h"
@@ -75,7 +76,7 @@ struct trhip_ctx {
     int compose_spheres = -1;  // commit: spheres as a chain of leaves above the triangles' subtree, what k_trace8 needs of a scene with spheres
                                // (option "compose_spheres": 1 / 0 = one SAH tree over everything / -1 = when "traversal" is 4 at commit time)
     int traversal = 3;  // 1 = literal accel/bvh.jl loop, 2 = children-in-parent nodes + per-lane ray replacement, 3 = 2 with leaves postponed (while-while),
-                        // 4 = 8-wide quantised nodes in the binary walk's order (th_trace8.h; scenes / rays it cannot take run 3)
+                        // 4 = 8-wide quantised nodes in the binary walk's order (th_trace8.h; scenes / rays it cannot take run 3), 6 = 3 with two rays per lane (th_trace4.h)
     // workspace (grown on demand, reused across calls)
     DevBuf q[2][3], sq[3], hits, Lbuf, pfilm, counters, sensor, table, film, scratch[4], overflow, wh_L, wh_parent, wh_coef, wh_pdf, wh_flags, occl, film_Lt, surv_list, surv_counts;
     uint64_t last_L_count = 0;  // float4 entries valid in Lbuf
@@ -714,7 +715,7 @@ int trace_grid(const trhip_ctx* ctx) { return ctx->num_cu * TH_TRACE_BLOCKS_PER_
 // k_trace2 keeps stack levels 16..63 of every resident thread in a global slab laid out [level][thread].
 int ensure_overflow(trhip_ctx* ctx) {
     const size_t threads = (size_t)trace_grid(ctx) * kBlock;
-    return ensure(ctx, ctx->overflow, threads * (size_t)(kStack2Total - kStackMinLds) * sizeof(uint2));
+    return ensure(ctx, ctx->overflow, threads * (size_t)kStackSlabLevels * sizeof(uint2));
 }
 
 // the scene's children-in-parent view with the context's slab margin (option "slab_margin_log2")
@@ -733,9 +734,11 @@ void traversal_info(const trhip_ctx* ctx, const trhip_scene* sc, uint32_t* trav,
             nb = 0;
         } else if (sc->wide.root_cnt > 0) {
             t = 2;
-        } else if (ctx->traversal >= 4 && sc->w8_ok) {
+        } else if (ctx->traversal == 4 && sc->w8_ok) {
             t = 4;
             nb = 96;
+        } else if (ctx->traversal == 6) {
+            t = 6;
         } else {
             t = ctx->traversal >= 3 ? 3 : 2;
         }
@@ -772,7 +775,7 @@ void launch_trace(trhip_ctx* ctx, hipStream_t st, const trhip_scene* sc, bool an
             }
         }
         // ---- traversal 4: 8-wide nodes (th_trace8.h); the rays it does not take come back on a fallback list that k_trace3 walks below ----
-        if (ctx->traversal >= 4 && sc->w8_ok && ctx->slab_margin_log2 > 0 && ctx->pipelines <= 1) {
+        if (ctx->traversal == 4 && sc->w8_ok && ctx->slab_margin_log2 > 0 && ctx->pipelines <= 1) {
             const int w = any ? 1 : 0;
             const uint32_t fcap = q.counts ? q.cap : q.n_dense;
             const size_t entries = (size_t)fcap * (q.counts ? kSeg : 1);
@@ -799,6 +802,20 @@ void launch_trace(trhip_ctx* ctx, hipStream_t st, const trhip_scene* sc, bool an
                 q = SegQueue{fcounts, fcap, 0u, fb.list, 1u};
                 work_cursors = fcounts + (size_t)kSeg * kCtrStride;
             }
+        }
+        if (ctx->traversal == 6) {  // two rays per lane (th_trace4.h)
+            if (any) {
+                if (cnt)
+                    { if (full_only) hipLaunchKernelGGL((k_trace4<true, true, true>), grid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, work_cursors, ov, ctr); else hipLaunchKernelGGL((k_trace4<true, true, false>), grid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, work_cursors, ov, ctr); }
+                else
+                    { if (full_only) hipLaunchKernelGGL((k_trace4<true, false, true>), grid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, work_cursors, ov, ctr); else hipLaunchKernelGGL((k_trace4<true, false, false>), grid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, work_cursors, ov, ctr); }
+            } else {
+                if (cnt)
+                    { if (full_only) hipLaunchKernelGGL((k_trace4<false, true, true>), grid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, work_cursors, ov, ctr); else hipLaunchKernelGGL((k_trace4<false, true, false>), grid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, work_cursors, ov, ctr); }
+                else
+                    { if (full_only) hipLaunchKernelGGL((k_trace4<false, false, true>), grid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, work_cursors, ov, ctr); else hipLaunchKernelGGL((k_trace4<false, false, false>), grid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, work_cursors, ov, ctr); }
+            }
+            return;
         }
         if (any) {
             if (cnt)
@@ -1128,7 +1145,7 @@ int render_stream_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sen
         if (int rc = ensure(ctx, pp.sq[j], Pphys * sizeof(float4))) return rc;
     if (int rc = ensure(ctx, pp.hits, Pphys * sizeof(float4))) return rc;
     if (int rc = ensure(ctx, pp.counters, sizeof(Counters))) return rc;
-    const size_t slab_bytes = (size_t)trace_grid(ctx) * kBlock * (size_t)(kStack2Total - kStackMinLds) * sizeof(uint2);
+    const size_t slab_bytes = (size_t)trace_grid(ctx) * kBlock * (size_t)kStackSlabLevels * sizeof(uint2);
     for (int k = 0; k < 2; ++k)
         if (int rc = ensure(ctx, pp.overflow[k], slab_bytes)) return rc;
     if (int rc = ensure(ctx, ctx->Lbuf, total_slots * sizeof(float4))) return rc;
@@ -1366,7 +1383,7 @@ int render_impl_band(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
     const uint64_t Pphys = (uint64_t)cap * kSeg;
     if (int rc = upload(ctx, ctx->sensor, &ds, sizeof ds)) return rc;
     if (int rc = upload(ctx, ctx->table, sensor->filter_table, 256 * sizeof(float))) return rc;
-    const size_t slab_bytes = (size_t)trace_grid(ctx) * kBlock * (size_t)(kStack2Total - kStackMinLds) * sizeof(uint2);
+    const size_t slab_bytes = (size_t)trace_grid(ctx) * kBlock * (size_t)kStackSlabLevels * sizeof(uint2);
     for (int pi = 0; pi < NP; ++pi) {
         Pipe& pp = ctx->pipes[pi];
         if (!pp.st) {
@@ -1675,7 +1692,7 @@ int render_sppm_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
         if (int rc = ensure(ctx, pp.sq[j], Pphys * sizeof(float4))) return rc;
     if (int rc = ensure(ctx, pp.hits, Pphys * sizeof(float4))) return rc;
     if (int rc = ensure(ctx, pp.counters, sizeof(Counters))) return rc;
-    const size_t slab_bytes = (size_t)trace_grid(ctx) * kBlock * (size_t)(kStack2Total - kStackMinLds) * sizeof(uint2);
+    const size_t slab_bytes = (size_t)trace_grid(ctx) * kBlock * (size_t)kStackSlabLevels * sizeof(uint2);
     if (int rc = ensure(ctx, pp.overflow[0], slab_bytes)) return rc;
     for (auto& b : ctx->sp_vp)
         if (int rc = ensure(ctx, b, (size_t)B * n * sizeof(float4))) return rc;
@@ -2085,7 +2102,7 @@ int trhip_set_option(trhip_ctx* ctx, const char* name, int64_t value) {
     } else if (!std::strcmp(name, "overlap"))
         ctx->overlap = value != 0;
     else if (!std::strcmp(name, "traversal")) {
-        if (value < 1 || value > 4) return fail(ctx, TRHIP_ERR_INVALID, "traversal must be 1, 2, 3 or 4");
+        if (value < 1 || value > 6 || value == 5) return fail(ctx, TRHIP_ERR_INVALID, "traversal must be 1, 2, 3, 4 or 6");
         ctx->traversal = (int)value;
     } else if (!std::strcmp(name, "batch_paths")) {
         if (value < 0) return fail(ctx, TRHIP_ERR_INVALID, "batch_paths must be >= 0 (0 = auto)");
@@ -2255,7 +2272,7 @@ int trhip_scene_commit(trhip_scene* s, int max_node_primitives) {
     // kernel then walks with conservative interior boxes (th_wide8.h).  The leaf-size hint is a hint (bvh.jl:159-165 decides by cost).
     std::vector<uint32_t> sph_ids, tri_ids;
     for (size_t i = 0; i < s->prims.size(); ++i) (s->prims[i].kind == 1 ? sph_ids : tri_ids).push_back((uint32_t)i);
-    const bool want_chain = s->ctx->compose_spheres > 0 || (s->ctx->compose_spheres < 0 && s->ctx->traversal >= 4);
+    const bool want_chain = s->ctx->compose_spheres > 0 || (s->ctx->compose_spheres < 0 && s->ctx->traversal == 4);
     const bool compose = want_chain && !sph_ids.empty() && sph_ids.size() <= (size_t)kW8MaxSpheres && tri_ids.size() >= 2 && pb.size() > s->ctx->tiny_scene_prims;
     std::vector<HostAABB> pb_sub;
     if (compose) {
