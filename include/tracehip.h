@@ -118,8 +118,8 @@ typedef struct {
     uint64_t shadow_rays;    /* any-hit (shadow) rays traced, all bounces */
     uint64_t nodes_visited;  /* filled only when instrumentation is on (trhip_set_option "count_visits") */
     uint64_t prims_tested;
-    uint64_t nodes_visited_shadow;
-    uint64_t prims_tested_shadow;
+    uint64_t nodes_visited_shadow; /* any-hit rays: box and primitive RECORDS fetched — a record one scalar fetch brings to all 64 rays of */
+    uint64_t prims_tested_shadow;  /* a wave (the any-hit pre-pass kernels of th_trace2.h) counts once                                   */
     double ms_total;         /* wall time of the render call's device work (HIP events) */
     double ms_raygen, ms_trace_closest, ms_shade, ms_trace_any, ms_film;
     uint32_t launches_raygen, launches_trace_closest, launches_shade, launches_trace_any, launches_film;

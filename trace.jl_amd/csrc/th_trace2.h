@@ -651,10 +651,10 @@ __global__ __launch_bounds__(kBlock, FULL_ONLY ? TH_TRACE_LEAF_WAVES : 4) void k
             const uint32_t slot = first + (ws.leaf_order ? uniform_load(ws.leaf_order, k) : k);  // wave-uniform: scalar loads
             const float4 p0 = uniform_load(sc.prims, 3 * slot);
             const uint32_t meta = __float_as_uint(p0.w);
+            if (COUNT && lane == 0) np++;  // primitive records FETCHED: one scalar fetch serves the wave's 64 rays (what the byte model of bench.py counts)
             if (meta & PRIM_SPHERE) {
                 const SphereRec sr = uniform_load(sc.spheres, __float_as_uint(p0.x));
                 if (live) {
-                    if (COUNT) np++;
                     SphereHit sh;
                     if (sphere_intersect<false, FULL_ONLY>(sr, o, d, t_max, sh)) {
                         found = true;
@@ -664,15 +664,12 @@ __global__ __launch_bounds__(kBlock, FULL_ONLY ? TH_TRACE_LEAF_WAVES : 4) void k
             } else if (!(meta & PRIM_DEGENERATE)) {
                 const float4 p1 = uniform_load(sc.prims, 3 * slot + 1), p2 = uniform_load(sc.prims, 3 * slot + 2);
                 if (live) {
-                    if (COUNT) np++;
                     TriTest tt;
                     if (tri_intersect_sheared<false>(mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z), o, shear, t_max, &tt)) {
                         found = true;
                         live = false;
                     }
                 }
-            } else if (COUNT && live) {
-                np++;  // k_trace2 counts the degenerate triangle it skips
             }
         }
         return found;
@@ -818,11 +815,13 @@ __global__ __launch_bounds__(kBlock, 5) void k_any_occluders(DeviceScene sc, Occ
             const float4 p0 = uniform_load(sc.prims, 3 * slot), p1 = uniform_load(sc.prims, 3 * slot + 1), p2 = uniform_load(sc.prims, 3 * slot + 2);
             const float b0 = uniform_load(oc.boxes, 6 * k), b1 = uniform_load(oc.boxes, 6 * k + 1), b2 = uniform_load(oc.boxes, 6 * k + 2), b3 = uniform_load(oc.boxes, 6 * k + 3),
                         b4 = uniform_load(oc.boxes, 6 * k + 4), b5 = uniform_load(oc.boxes, 6 * k + 5);
+            if (COUNT && lane == 0) {  // records FETCHED: one scalar fetch of the triangle and of its leaf box serves the wave's 64 rays
+                np++;
+                nn++;
+            }
             if (live) {
-                if (COUNT) np++;
                 TriTest tt;
                 if (tri_intersect_sheared<false>(mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z), o, shear, t_max, &tt)) {
-                    if (COUNT) nn++;
                     float tmin;
                     if (slab_test2(b0, b1, b2, b3, b4, b5, o, inv_d, 0.0f, false, d.x < 0.0f, d.y < 0.0f, d.z < 0.0f, tmin) && tmin < t_max) {
                         found = true;
