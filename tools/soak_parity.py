@@ -115,7 +115,7 @@ def main():
         ctx.set_option("traversal", 1)
         h1, o1 = flat.trace_closest(rays), flat.trace_any(rays)
         bad = 0
-        for trav in ((3, 2, 4) if a.wide else (3, 2)):
+        for trav in ((3, 2, 6, 4) if a.wide else (3, 2, 6)):
             ctx.set_option("traversal", trav)
             h, o = flat.trace_closest(rays), flat.trace_any(rays)
             bad += int((h["prim"] != h1["prim"]).sum())
@@ -126,7 +126,7 @@ def main():
         if a.frames:  # whole frames too: every bounce and shadow ray of a small render, literal walk against all shortcuts
             cam = T.scenes.cornell_camera(a.frames)
             films = []
-            for trav in ((1, 3, 4) if a.wide else (1, 3)):
+            for trav in ((1, 3, 6, 4) if a.wide else (1, 3, 6)):
                 ctx.set_option("traversal", trav)
                 films.append(T.PathIntegrator(cam, T.SeededSampler(4, seed=100 + k), 6).render(scene, ctx).copy())
             for other in films[1:]:
@@ -139,7 +139,7 @@ def main():
         print(f"scene {k:3d}: {flat.bvh()[3].size:7d} primitives, {rays.shape[0]} rays, hit {float((h1['prim'] >= 0).mean()):.3f}, occluded {float(o1.mean()):.3f}, mismatches {bad}", flush=True)
         flat.free()
         scene._flat = None
-    print(f"total: {a.scenes} scenes, {rays_total} rays x (closest + any) x (traversal {'3, 2, 4' if a.wide else '3, 2'}) against traversal 1: {bad_total} mismatches")
+    print(f"total: {a.scenes} scenes, {rays_total} rays x (closest + any) x (traversal {'3, 2, 6, 4' if a.wide else '3, 2, 6'}) against traversal 1: {bad_total} mismatches")
     sys.exit(1 if bad_total else 0)
 
 
