@@ -56,43 +56,43 @@ TH_HD RayShear ray_shear(f3 d) {
     r.sz = denom;
     return r;
 }
-template <bool WANT_HIT>
+template <bool WANT_HIT, bool SELECTS = true>
 TH_D bool tri_intersect_sheared(f3 v0, f3 v1, f3 v2, f3 o, const RayShear& rs, float t_max, TriTest* out);
 template <bool WANT_HIT>
-TH_D bool tri_intersect(f3 v0, f3 v1, f3 v2, f3 o, f3 d, float t_max, TriTest* out) {
+TH_D bool tri_intersect(f3 v0, f3 v1, f3 v2, f3 o, f3 d, float t_max, TriTest* out) {  // the shading kernels' entry (hit geometry rebuilt from one primitive)
     if (tri_degenerate(v0, v1, v2)) return false;
-    return tri_intersect_sheared<WANT_HIT>(v0, v1, v2, o, ray_shear(d), t_max, out);
+    return tri_intersect_sheared<WANT_HIT, false>(v0, v1, v2, o, ray_shear(d), t_max, out);
 }
 // The test proper, for a triangle already known not to be degenerate (PRIM_DEGENERATE is set at scene commit).
-template <bool WANT_HIT>
+// SELECTS: the permutation by 18 selects instead of a three-way branch — a wave of a traversal kernel mixes rays of all three dominant axes
+// and ran the branch three times with a third of its lanes each (S-cornell closest-hit 50.8 -> 49.6 ms, S-blob 188.6 -> 186.4); in the shading
+// kernels, where the test is a cold path, the selects cost registers (S-mesh shading 60 -> 66 ms): they keep the branch.
+template <bool WANT_HIT, bool SELECTS>
 TH_D bool tri_intersect_sheared(f3 v0, f3 v1, f3 v2, f3 o, const RayShear& rs, float t_max, TriTest* out) {
     const int kz = rs.kz;
-    // permute so that kz is last: (kx, ky, kz) = (kz+1, kz+2, kz) mod 3
-    f3 a0, a1, a2;
+    // permute so that kz is last: (kx, ky, kz) = (kz+1, kz+2, kz) mod 3; vertices[i][kz] - ray.o[kz] (:116-117) is the same subtraction as the
+    // translated vertex's kz component
     const f3 p0 = v0 - o, p1 = v1 - o, p2 = v2 - o;
-    float dz0, dz1, dz2;  // vertices[i][kz] - ray.o[kz] (recomputed exactly as :116-117 do)
-    if (kz == 0) {
+    f3 a0, a1, a2;
+    if (SELECTS) {
+        const bool k0 = kz == 0, k1 = kz == 1;
+        a0 = mk3(k0 ? p0.y : (k1 ? p0.z : p0.x), k0 ? p0.z : (k1 ? p0.x : p0.y), k0 ? p0.x : (k1 ? p0.y : p0.z));
+        a1 = mk3(k0 ? p1.y : (k1 ? p1.z : p1.x), k0 ? p1.z : (k1 ? p1.x : p1.y), k0 ? p1.x : (k1 ? p1.y : p1.z));
+        a2 = mk3(k0 ? p2.y : (k1 ? p2.z : p2.x), k0 ? p2.z : (k1 ? p2.x : p2.y), k0 ? p2.x : (k1 ? p2.y : p2.z));
+    } else if (kz == 0) {
         a0 = mk3(p0.y, p0.z, p0.x);
         a1 = mk3(p1.y, p1.z, p1.x);
         a2 = mk3(p2.y, p2.z, p2.x);
-        dz0 = v0.x - o.x;
-        dz1 = v1.x - o.x;
-        dz2 = v2.x - o.x;
     } else if (kz == 1) {
         a0 = mk3(p0.z, p0.x, p0.y);
         a1 = mk3(p1.z, p1.x, p1.y);
         a2 = mk3(p2.z, p2.x, p2.y);
-        dz0 = v0.y - o.y;
-        dz1 = v1.y - o.y;
-        dz2 = v2.y - o.y;
     } else {
         a0 = p0;
         a1 = p1;
         a2 = p2;
-        dz0 = v0.z - o.z;
-        dz1 = v1.z - o.z;
-        dz2 = v2.z - o.z;
     }
+    const float dz0 = a0.z, dz1 = a1.z, dz2 = a2.z;
     const float sx = rs.sx, sy = rs.sy, sz = rs.sz;
     const float x0 = a0.x + sx * dz0, y0 = a0.y + sy * dz0, z0 = a0.z + 0.0f;
     const float x1 = a1.x + sx * dz1, y1 = a1.y + sy * dz1, z1 = a1.z + 0.0f;
