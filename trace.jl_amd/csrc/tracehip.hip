@@ -1755,6 +1755,7 @@ int render_sppm_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
     HIP_TRY(ctx, hipEventCreate(&e1));
     HIP_TRY(ctx, hipEventRecord(e0, st));
     // pixels = [SPPMPixel(radius = initial_search_radius) …] (:136-139)
+    HIP_TRY(ctx, hipMemsetAsync(counts, 0, (size_t)n * sizeof(uint32_t), st));  // once per call: every iteration leaves them at zero again
     HIP_TRY(ctx, hipMemsetAsync(px.Ld, 0, (size_t)n * sizeof(float4), st));
     HIP_TRY(ctx, hipMemsetAsync(px.tau, 0, (size_t)n * sizeof(float4), st));
     HIP_TRY(ctx, hipMemsetAsync(px.N, 0, (size_t)n * sizeof(double), st));
@@ -1826,7 +1827,7 @@ int render_sppm_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
         for (uint32_t j = 0; j < nb; ++j) {
             const VisiblePoints vp = vp_slice(j);
             tm.begin(2, st);
-            HIP_TRY(ctx, hipMemsetAsync(counts, 0, (size_t)n * sizeof(uint32_t), st));
+            // (the bucket counters are zero here: k_sppm_hit_bin's fill pass counts every bucket back down to 0)
             hipLaunchKernelGGL(k_sppm_grid_reset, dim3(1), blk, 0, st, grid);
             hipLaunchKernelGGL(k_sppm_grid_bounds, dim3(ctx->num_cu), blk, 0, st, vp, (const float*)px.radius, n, grid);  // few waves: 7 same-address atomics each
             hipLaunchKernelGGL(k_sppm_grid_setup, dim3(1), dim3(64), 0, st, grid);
