@@ -759,7 +759,9 @@ void launch_trace(trhip_ctx* ctx, hipStream_t st, const trhip_scene* sc, bool an
         uint2* ov = (uint2*)(overflow_slab ? overflow_slab : ctx->overflow.p);
         if (any && sc->n_occluders && ctx->occluder_pretest && ctx->pipelines <= 1 && !q.indirect) {
             // the largest triangles first (k_any_occluders); what they do not stop goes through per-segment survivor lists
-            const uint32_t scap = q.counts ? q.cap : q.n_dense;
+            // a survivor list takes the rays of every kSeg-th 64-ray chunk of the padded work space (k_any_occluders): at most (sum of the segment
+            // counts + kSeg * (kSegGran - 1)) / kSeg + 64 <= the queue's per-segment capacity + 319 entries, whatever the caller's slack
+            const uint32_t scap = (q.counts ? q.cap : q.n_dense) + 1024u;
             const size_t entries = (size_t)scap * (q.counts ? kSeg : 1);
             if (ensure(ctx, ctx->surv_list, entries * sizeof(uint32_t)) == 0 && ensure(ctx, ctx->surv_counts, (size_t)kSeg * kCtrStride * sizeof(uint32_t)) == 0) {
                 uint32_t* sl = (uint32_t*)ctx->surv_list.p;
