@@ -29,9 +29,11 @@ constexpr int kStack2Lds = TH_STACK2_LDS;  // stack levels per lane kept in LDS
 constexpr int kStack2Total = 64;
 // k_trace3 occupancy: waves per SIMD asked of the compiler and stack levels kept in LDS (levels x 2 KB per block of 256 lanes).
 // Measured on the S-mesh frame (ms): closest-hit 4 waves / 16 levels 360, 5 / 12 (spills ~10 of its 106 VGPRs) 330, 6 / 10 397;
-// any-hit (93 VGPRs) 4 / 16: 170, 5 / 12: 155, 6 / 10: 144.
+// any-hit (93 VGPRs) 4 / 16: 170, 5 / 12: 155, 6 / 10: 144.  End of round 2: the closest-hit variant has come down to 85 VGPRs (hits
+// stored at once, the triangle permutation by selects, …), five short of six waves: 6 / 12 (80 VGPRs + 20 B scratch) 271 ms against
+// 5 / 12 282 ms, 6 / 10 272, 7 / 8 284.
 #ifndef TH_TRACE3_WAVES_CLOSEST
-#define TH_TRACE3_WAVES_CLOSEST 5
+#define TH_TRACE3_WAVES_CLOSEST 6
 #endif
 #ifndef TH_TRACE3_LDS_CLOSEST
 #define TH_TRACE3_LDS_CLOSEST 12
@@ -946,8 +948,10 @@ __device__ unsigned long long g_phase[16];
 #define TH_PHASE_BEGIN()
 #define TH_PHASE_END(slot, lanes)
 #endif
-template <bool ANY, bool COUNT, bool FULL_ONLY>
-__global__ __launch_bounds__(kBlock, ANY ? TH_TRACE3_WAVES_ANY : TH_TRACE3_WAVES_CLOSEST) void k_trace3(DeviceScene sc, WideScene ws, SegQueue q, const float4* __restrict__ ro, const float4* __restrict__ rd, const float* __restrict__ tmax_or_null,
+// BIG (closest-hit only): scenes whose nodes and primitives exceed the last-level cache (10.5 M triangles: 1.2 GB) run one wave per SIMD
+// fewer — there the sixth wave's extra streams cost more in misses than they hide (365 vs 374 ms; the 1 M-triangle scene: 282 vs 271 ms)
+template <bool ANY, bool COUNT, bool FULL_ONLY, bool BIG = false>
+__global__ __launch_bounds__(kBlock, ANY ? TH_TRACE3_WAVES_ANY : (BIG ? TH_TRACE3_WAVES_CLOSEST - 1 : TH_TRACE3_WAVES_CLOSEST)) void k_trace3(DeviceScene sc, WideScene ws, SegQueue q, const float4* __restrict__ ro, const float4* __restrict__ rd, const float* __restrict__ tmax_or_null,
                                                    TraceOut out, uint32_t* __restrict__ work, uint2* __restrict__ overflow, Counters* ctr) {
     constexpr int kLds = ANY ? TH_TRACE3_LDS_ANY : TH_TRACE3_LDS_CLOSEST;
     __shared__ uint32_t s_ref[kLds][kBlock];

@@ -825,8 +825,12 @@ void launch_trace(trhip_ctx* ctx, hipStream_t st, const trhip_scene* sc, bool an
             else
                 { if (full_only) hipLaunchKernelGGL((k_trace3<true, false, true>), grid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, work_cursors, ov, ctr); else hipLaunchKernelGGL((k_trace3<true, false, false>), grid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, work_cursors, ov, ctr); }
         } else {
+            // scenes larger than the last-level cache (256 MB of MALL): one wave per SIMD fewer (k_trace3's BIG variant)
+            const bool big = (size_t)sc->wide.n_wnodes * 64u + (size_t)sc->dev.n_prims * 48u > ((size_t)256 << 20);
             if (cnt)
                 { if (full_only) hipLaunchKernelGGL((k_trace3<false, true, true>), grid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, work_cursors, ov, ctr); else hipLaunchKernelGGL((k_trace3<false, true, false>), grid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, work_cursors, ov, ctr); }
+            else if (big)
+                { if (full_only) hipLaunchKernelGGL((k_trace3<false, false, true, true>), grid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, work_cursors, ov, ctr); else hipLaunchKernelGGL((k_trace3<false, false, false, true>), grid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, work_cursors, ov, ctr); }
             else
                 { if (full_only) hipLaunchKernelGGL((k_trace3<false, false, true>), grid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, work_cursors, ov, ctr); else hipLaunchKernelGGL((k_trace3<false, false, false>), grid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, work_cursors, ov, ctr); }
         }
