@@ -172,7 +172,10 @@ TH_D void add_nan_where(float4* L, uint32_t slot, uint32_t poison) {  // L += β
 // visible points of the batch; what the reference adds to pixel.Ld at this depth goes to the term slot
 // ((it_local * max_depth + depth - 1) * n_pix + pixel) of a zeroed buffer — written by at most one path, so the `+=` of the
 // shadow kernel is race-free — and k_sppm_fold_ld adds the terms to Ld in the reference's order afterwards.
-__global__ __launch_bounds__(kBlock) void k_shade_sppm(DeviceScene sc, PathQueue qin, PathQueue qout, ShadowQueue sq, uint32_t cap, const float4* __restrict__ hits, VisiblePoints vp,
+#ifndef TH_SHADE_SPPM_WAVES
+#define TH_SHADE_SPPM_WAVES 3  // 180 VGPRs unconstrained (2 waves per SIMD); capped at 3: C4 shading section 162.9 -> 159.3 ms, at 4 (spills) 162.2
+#endif
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TH_SHADE_SPPM_WAVES))) void k_shade_sppm(DeviceScene sc, PathQueue qin, PathQueue qout, ShadowQueue sq, uint32_t cap, const float4* __restrict__ hits, VisiblePoints vp,
                                                        float4* __restrict__ Ld, Counters* ctr, int depth, int max_depth, uint64_t seed, uint32_t it0, uint32_t n_pix, uint32_t width) {
     __shared__ SegView sv;
     const SegQueue qv{ctr->n_queue[depth - 1], cap, 0u};
@@ -568,7 +571,10 @@ struct PhotonRecords {
 // is processed by exactly the code it was processed by before — a photon's record slot and Halton dimensions depend on nothing
 // but its index and depth — so the results do not change.
 constexpr int kPhotonRings = 4;
-__global__ __launch_bounds__(kBlock) void k_shade_photon(DeviceScene sc, PathQueue qin, PathQueue qout, uint32_t cap, const float4* __restrict__ hits, PhotonRecords rec,
+#ifndef TH_SHADE_PHOTON_WAVES
+#define TH_SHADE_PHOTON_WAVES 4
+#endif
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TH_SHADE_PHOTON_WAVES))) void k_shade_photon(DeviceScene sc, PathQueue qin, PathQueue qout, uint32_t cap, const float4* __restrict__ hits, PhotonRecords rec,
                                                          uint32_t n_batch_photons, Counters* ctr, int depth, int max_depth, uint64_t halton_base) {
     __shared__ SegView sv;
     __shared__ uint32_t s_ring[kBlock / 64][kPhotonRings][128];
@@ -706,7 +712,13 @@ TH_D GatherSum gather_pixel(const DeviceScene& sc, const PhotonRecords& rec, con
     return s;
 }
 // One thread per pixel; also counts the registrations (the reference's list nodes) for trhip_sppm_state.
-__global__ __launch_bounds__(kBlock) void k_sppm_gather(DeviceScene sc, PhotonRecords rec, VisiblePoints vp, PixelStats px, uint32_t n, GridInfo* gp, const uint32_t* __restrict__ starts,
+#ifndef TH_SPPM_GATHER_WAVES
+#define TH_SPPM_GATHER_WAVES 4
+#endif
+#ifndef TH_SPPM_HOT_WAVES
+#define TH_SPPM_HOT_WAVES 4  // 144 VGPRs unconstrained (3 waves); capped at 4: C4 shading section 160.4 -> 156.4 ms
+#endif
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TH_SPPM_GATHER_WAVES))) void k_sppm_gather(DeviceScene sc, PhotonRecords rec, VisiblePoints vp, PixelStats px, uint32_t n, GridInfo* gp, const uint32_t* __restrict__ starts,
                                                         const float4* __restrict__ hit_sorted, uint32_t hash_size, uint32_t* __restrict__ hot_list, uint32_t count_registrations) {
     // A wave takes 64 pixels.  Every lane walks the buckets of ITS pixel one candidate per round (a cursor over cells and entries);
     // the (pixel, photon) pairs that pass the distance test are parked in a per-wave ring and evaluated 64 at a time — frame and
@@ -843,7 +855,7 @@ __global__ __launch_bounds__(kBlock) void k_sppm_gather(DeviceScene sc, PhotonRe
         if (lane_id() == 0 && n_reg) atomicAdd(&gp->registrations, n_reg);
     }
 }
-__global__ __launch_bounds__(kBlock) void k_sppm_gather_hot(DeviceScene sc, PhotonRecords rec, VisiblePoints vp, PixelStats px, GridInfo* gp, const uint32_t* __restrict__ starts,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TH_SPPM_HOT_WAVES))) void k_sppm_gather_hot(DeviceScene sc, PhotonRecords rec, VisiblePoints vp, PixelStats px, GridInfo* gp, const uint32_t* __restrict__ starts,
                                                             const float4* __restrict__ hit_sorted, uint32_t hash_size, const uint32_t* __restrict__ hot_list) {
     // One wave per hot pixel.  The distance test runs over a bucket with all 64 lanes; the photons that pass (about one in eight) are
     // not shaded where they are found — a handful of lanes would run the BSDF while the rest wait — but parked in a per-wave ring
