@@ -962,7 +962,6 @@ __global__ __launch_bounds__(kBlock, ANY ? TH_TRACE3_WAVES_ANY : (BIG ? TH_TRACE
     const uint32_t gthreads = gridDim.x * kBlock;
     const uint32_t gtid = blockIdx.x * kBlock + tid;
     const uint32_t lane = lane_id();
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
     bool active = false, exhausted = false;
     uint32_t wseg = __builtin_amdgcn_readfirstlane((gtid >> 6) % kSeg), dry = 0, pool_next = 0, pool_end = 0;  // wave-uniform: scalar registers
@@ -1014,7 +1013,7 @@ __global__ __launch_bounds__(kBlock, ANY ? TH_TRACE3_WAVES_ANY : (BIG ? TH_TRACE
                 }
                 const uint32_t avail = pool_end - pool_next;
                 if (avail && !active) {
-                    const uint32_t rank = (uint32_t)__popcll(idle & lt_mask);
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));  // idle lanes below this one (no mask kept in registers)
                     if (rank < avail) {
                         idx = seg_phys(q, wseg, pool_next + rank);
                         if (q.indirect) idx = q.indirect[idx];
