@@ -130,8 +130,11 @@ def transform32(t) -> np.ndarray:
     return np.concatenate([np.asarray(t.m, np.float32).reshape(-1), np.asarray(t.inv_m, np.float32).reshape(-1)])
 
 
-def make_sensor(cam, screen_window=(-1.0, -1.0, 1.0, 1.0), fov=90.0, crop=(0.0, 0.0, 1.0, 1.0)) -> OrcSensor:
-    """Raw constructor arguments: the oracle re-derives film geometry / matrices with its own restated constructors."""
+def make_sensor(cam, screen_window=(-1.0, -1.0, 1.0, 1.0), fov=90.0, crop=None) -> OrcSensor:
+    """Raw constructor arguments: the oracle re-derives film geometry / matrices with its own restated constructors.
+    crop: the Film's fractional crop window (default: the one the film was built with)."""
+    if crop is None:
+        crop = getattr(cam.film, "crop_window", (0.0, 0.0, 1.0, 1.0))
     s = OrcSensor()
     s.camera_to_world[:] = np.asarray(cam.camera_to_world.m, np.float32).reshape(-1).tolist()
     s.camera_to_world_inv[:] = np.asarray(cam.camera_to_world.inv_m, np.float32).reshape(-1).tolist()

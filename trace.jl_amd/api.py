@@ -364,6 +364,7 @@ class Film:  # film.jl:7-62
         res = self.resolution
         cmin = np.asarray(crop_bounds.p_min, dtype=np.float32)
         cmax = np.asarray(crop_bounds.p_max, dtype=np.float32)
+        self.crop_window = (float(cmin[0]), float(cmin[1]), float(cmax[0]), float(cmax[1]))  # the constructor's fractional window (kept for hosts / tests)
         self.crop_bounds = Bounds2(np.ceil(res * cmin) + f32(1.0), np.ceil(res * cmax))  # :41-44
         self.filter = filter
         self.diagonal = f32(diagonal) * f32(0.001)
