@@ -644,10 +644,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TH_SHADE
             const int prim = __float_as_int(hits[i].y);
             if (prim >= 0) cls = (int)((__float_as_uint(sc.shade[8 * (size_t)prim].w) & PRIM_MATERIAL_MASK) % (uint32_t)kPhotonRings);
         }
-#pragma unroll
-        for (int c = 0; c < kPhotonRings; ++c) {
+        auto park = [&](auto cc) {  // class cc (a compile-time constant: the ring counters stay in registers)
+            constexpr int c = decltype(cc)::value;
             const unsigned long long m = __ballot(cls == c);
-            if (m == 0ull) continue;
+            if (m == 0ull) return;
             if (cls == c) s_ring[wv][c][(ring_head[c] + ring_cnt[c] + (uint32_t)__popcll(m & lt_mask)) & 127u] = i;
             ring_cnt[c] += (uint32_t)__popcll(m);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -657,11 +657,21 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TH_SHADE
                 ring_cnt[c] -= 64u;
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             }
-        }
+        };
+        static_assert(kPhotonRings == 4, "one call per class");
+        park(std::integral_constant<int, 0>{});
+        park(std::integral_constant<int, 1>{});
+        park(std::integral_constant<int, 2>{});
+        park(std::integral_constant<int, 3>{});
     }
-#pragma unroll
-    for (int c = 0; c < kPhotonRings; ++c)
-        if (ring_cnt[c]) vertex(lane < ring_cnt[c], s_ring[wv][c][(ring_head[c] + lane) & 127u]);  // the last, partial batches
+    auto flush = [&](auto cc) {  // the last, partial batches
+        constexpr int c = decltype(cc)::value;
+        if (ring_cnt[c]) vertex(lane < ring_cnt[c], s_ring[wv][c][(ring_head[c] + lane) & 127u]);
+    };
+    flush(std::integral_constant<int, 0>{});
+    flush(std::integral_constant<int, 1>{});
+    flush(std::integral_constant<int, 2>{});
+    flush(std::integral_constant<int, 3>{});
 }
 
 // `pixel.ϕ += β · f_vp(wo_vp, wi)`, `pixel.M += 1` (sppm.jl:374-391) for one iteration, gathered per pixel: for every cell the

@@ -162,12 +162,10 @@ __global__ __launch_bounds__(kBlock, TH_TRACE4_WAVES) void k_trace4(DeviceScene 
         const uint32_t n_idle = (uint32_t)__popcll(__ballot(!R0.active)) + (uint32_t)__popcll(__ballot(!R1.active));
         if (n_idle == 128u || (!exhausted && n_idle >= (uint32_t)TH_TRACE4_REFILL)) {
             if (!exhausted) {
-#pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    Ray4& R = r ? R1 : R0;
+                auto refill_slot = [&](Ray4& R) {
                     const unsigned long long idle = __ballot(!R.active);
                     const uint32_t ni = (uint32_t)__popcll(idle);
-                    if (ni == 0u) continue;
+                    if (ni == 0u) return;
                     if (pool_next >= pool_end && !exhausted) {
                         for (int tries = 0; tries < kSeg && pool_next >= pool_end && !exhausted; ++tries) {
                             const uint32_t cnt = __builtin_amdgcn_readfirstlane(sv.count[wseg]);
@@ -196,7 +194,9 @@ __global__ __launch_bounds__(kBlock, TH_TRACE4_WAVES) void k_trace4(DeviceScene 
                         }
                     }
                     pool_next += min(ni, avail);
-                }
+                };
+                refill_slot(R0);
+                refill_slot(R1);
             }
             if (__ballot(R0.active || R1.active) == 0ull) {
                 if (exhausted) break;
