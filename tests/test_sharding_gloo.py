@@ -82,7 +82,7 @@ dist.init_process_group(backend="gloo")
 scene, cam = T.scenes.cornell_scene(), T.scenes.cornell_camera(32)
 osc = ob.OracleScene.from_scene(scene)
 P = 9000
-lo, hi = T.parallel.photon_slice(P, rank, world)      # the slice trhip_render_sppm gives rank r of a communicator (tracehip.hip)
+lo, hi = T.parallel.photon_slice(P, rank, world)      # the slice trhip_render_sppm gives rank r of a communicator (tu_sppm.hip)
 calls = []
 def exchange(phi, M):                                  # one all-reduce of phi (3 floats) and M per pixel per iteration (SURVEY.md 8e)
     t_phi, t_M = torch.from_numpy(phi), torch.from_numpy(M)

@@ -1,8 +1,8 @@
 #!/usr/bin/env python
 """Where k_trace3<closest> spends its wave cycles, and with how many lanes.  Needs the DIAGNOSTIC build:
 
-    hipcc <__graft_entry__.HIPCC_FLAGS> -DTH_DIAG_PHASES -o _diag/libtracehip_phases.so trace.jl_amd/csrc/tracehip.hip
-    TRHIP_LIB=$PWD/_diag/libtracehip_phases.so python tools/phase_probe.py --workload mesh_1m --spp 64
+    python -c "import __graft_entry__ as g; g.build_library(extra_flags=['-DTH_DIAG_PHASES'], out_name='libtracehip_phases.so')"
+    TRHIP_LIB=$PWD/trace.jl_amd/libtracehip_phases.so python tools/phase_probe.py --workload mesh_1m --spp 64
 
 Phases: refill (idle lanes take new rays), pop (stack pops of lanes whose node is done), node (interior step: one 64-byte node,
 two boxes), leaf (primitive tests).  cycles = wave cycles inside the phase summed over all waves; lanes = lanes with work at entry."""

@@ -1,8 +1,8 @@
 #!/usr/bin/env python
 """Which rays are the traversal tail?  Needs a DIAGNOSTIC build of the library (per-ray interior-fetch counts in hits[].x):
 
-    hipcc <flags of __graft_entry__.HIPCC_FLAGS> -DTH_DIAG_RAY_VISITS -o /tmp/libtracehip_diag.so trace.jl_amd/csrc/tracehip.hip
-    TRHIP_LIB=/tmp/libtracehip_diag.so python tools/visit_probe.py --workload mesh_1m
+    python -c "import __graft_entry__ as g; g.build_library(extra_flags=['-DTH_DIAG_RAY_VISITS'], out_name='libtracehip_diag.so')"
+    TRHIP_LIB=$PWD/trace.jl_amd/libtracehip_diag.so python tools/visit_probe.py --workload mesh_1m
 
 Traces the bounce ray set of tools/trace_bench.py (cosine-distributed directions leaving the primary hit points) with
 k_trace3 and prints the distribution of node fetches per ray and the worst rays (origin, direction, fetches, hit primitive).

@@ -1,0 +1,250 @@
+// th_host.h — what the translation units of libtracehip.so share on the host side: the context and scene objects behind the opaque
+// handles of include/tracehip.h, error / buffer helpers, and the functions one unit calls in another.  Units (each compiled on its own
+// and linked into the one shared object): tu_api.hip (context, options, communicator), tu_scene.hip (scene flattening, commit, upload),
+// tu_lbvh.hip (BVH build on the device), tu_trace.hip / tu_trace3.hip / tu_trace8.hip (traversal launches and entry points),
+// tu_path.hip (PathIntegrator frames, film), tu_whitted.hip, tu_sppm.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#pragma GCC visibility push(default)
+#include "../../include/tracehip.h"
+#pragma GCC visibility pop
+#include "th_bvh.h"
+#include "th_kernels.h"
+#include "th_trace2.h"
+#include "th_trace8.h"
+#include "th_trace4.h"
+#include "th_comm.h"
+
+using namespace th;
+
+// ---- context ------------------------------------------------------------------------------------------------------------------
+extern thread_local std::string g_init_error;  // tu_api.hip: the message of a failed trhip_init
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+constexpr int kMaxPipes = 8;
+// One wavefront pipeline: its own queues, counters and stream pair.  Several batches of one frame run concurrently on
+// different pipelines so that the long single-ray tail of one batch's traversal launch overlaps the bulk of another's.
+struct Pipe {
+    hipStream_t st = nullptr, st2 = nullptr;
+    hipEvent_t ev_shade = nullptr, ev_any = nullptr, ev_any2 = nullptr, ev_done = nullptr;
+    DevBuf q[2][3], sq[3], sq2[3], hits, counters, overflow[2];  // sq / sq2: the shadow queues of odd / even depths (any(d) may still run while shade(d+1) fills the other)
+};
+
+struct trhip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;  // shadow rays of depth d overlap with the closest-hit rays of depth d+1
+    std::string err;
+    int num_cu = 256;
+    // options
+    bool count_visits = false;
+    bool timing = true;
+    uint64_t batch_paths = 0;  // 0 = as many whole sample passes as fit in free HBM (fewer launches, fewer traversal tails)
+    int pipelines = 1;    // concurrent wavefront batches (each on its own stream pair); measured: no gain, every batch pays every tail
+    Pipe pipes[kMaxPipes];
+    uint32_t debug_trace_budget = 0;  // DIAGNOSTIC: k_trace2 abandons rays after this many node fetches (results wrong; measures bulk vs tail)
+    int bvh_builder = -1;  // BVHAccel construction: 0 = binned SAH on the host (th_bvh.h), 1 = linear BVH on the device (th_lbvh.h),
+                           // -1 = automatic: the device builder above 16 Mi primitives.  Measured: commit 0.72 -> 0.13 s (1 M triangles), 8.0 -> 1.5 s
+                           // (10 M); the LBVH costs 25-35 % more node visits per ray (frame +4 % at 1 M / 64 spp, +37 % at 10 M / 16 spp)
+    bool film_transpose = false;     // film pass on pixel-group-major copies of p_film / L (option "film_transpose"; launch_film)
+    bool occluder_pretest = true;    // any-hit rays test the scene's largest triangles before the walk (option "occluder_pretest")
+    int stream2_priority = -1;       // shadow-ray stream: 1 highest priority, -1 lowest, 0 the default level (option "stream2_priority", read when the streams are created)
+    bool leaf_kernel = true;         // one-leaf scenes run k_trace_leaf instead of k_trace2 (option "leaf_kernel", for A/B)
+    int slab_margin_log2 = 14;       // k_trace2 / k_trace3 add the slab clauses the reference's box test lost, on boxes grown by 2^-this x the ray's reach
+                                     // (th_trace2.h, slab_test2); 0 = the reference's loose test alone (its exact visit set)
+    int band_tile_rows = 0;          // DIAGNOSTIC / tests: render frames in bands of this many tile rows (0 = one band unless the samples do not fit in HBM)
+    uint32_t tiny_scene_prims = 16;  // scenes of at most this many primitives get a single-leaf BVH (th_bvh.h); 0 = always build the hierarchy
+    int film_block = 2;  // film gather: 0 = one film pixel per thread, 1 = 2 x 2 pixels per thread, 2 (default) = TH_FILM_BX x TH_FILM_BY = 1 x 4, all three recomputing a
+                         // sample's pixel range and table indices per thread; 3 = 1 x 4 from per-sample splat descriptors (k_film_descriptors): measured SLOWER
+                         // (1024^2, 256 spp: 29.0 ms against 24.3 ms: the 16-byte descriptor doubles the gather's loads and the arithmetic it saves was hidden)
+    bool film_tiled = false;  // LDS-staged film gather (k_film_gather_tiled): bit-identical, measured 2.7x SLOWER than k_film_gather (11 % lane use), kept as an option
+    bool overlap = false;  // shadow rays of depth d on a second stream beside the closest-hit rays of depth d+1 (option "overlap").  Off since the two-stage
+                           // any-hit kernels (k_any_occluders, k_any_leaf) halved the shadow rays' cost: 256 spp, on / off: S-cornell 158.2 / 157.9 ms, S-mesh 399 / 393,
+                           // 10 M triangles 485 / 480 (it was worth 5 ms of S-cornell's 172 before)
+    int compose_spheres = -1;  // commit: spheres as a chain of leaves above the triangles' subtree, what k_trace8 needs of a scene with spheres
+                               // (option "compose_spheres": 1 / 0 = one SAH tree over everything / -1 = when "traversal" is 4 at commit time)
+    int traversal = 3;  // 1 = literal accel/bvh.jl loop, 2 = children-in-parent nodes + per-lane ray replacement, 3 = 2 with leaves postponed (while-while),
+                        // 4 = 8-wide quantised nodes in the binary walk's order (th_trace8.h; scenes / rays it cannot take run 3), 6 = 3 with two rays per lane (th_trace4.h)
+    // workspace (grown on demand, reused across calls)
+    DevBuf q[2][3], sq[3], hits, Lbuf, pfilm, counters, sensor, table, film, scratch[4], overflow, wh_L, wh_parent, wh_coef, wh_pdf, wh_flags, occl, film_Lt, surv_list, surv_counts;
+    uint64_t last_L_count = 0;  // float4 entries valid in Lbuf
+    // SPPM state (th_sppm.h): per film pixel, kept after trhip_render_sppm for trhip_sppm_state
+    DevBuf sp_vp[7], sp_Ld, sp_tau, sp_radius, sp_N, sp_phi, sp_M, sp_counts, sp_starts, sp_entries, sp_grid, sp_ldist, sp_snap_M, sp_snap_phi, sp_snap_p, sp_snap_beta;
+    DevBuf sp_terms, sp_rec[3], sp_rec_valid;
+    // streaming wavefront (render_stream_impl)
+    DevBuf st_terms, st_tags[2], st_frozen, st_counts, st_list[2][2][7];  // [closest|any][ping-pong][o, d, b, trav, st, depth, stack]
+    int streaming = 0;             // PathIntegrator on scenes with a real hierarchy: suspend / resume stragglers.  1 = always, 0 = never (classic
+                                   // per-depth launches), -1 = automatic: when the frame has at most 96 camera samples per primitive, which is where the
+                                   // traversal tails dominate (measured, 1 M triangles: 16 spp 1170 -> 716 ms, 64 spp 1700 -> 1443, 128 spp 2288 vs
+                                   // 2412, 256 spp 3742 vs 3823; 10 M triangles, depth 16: 32 spp 6075 -> 2465 ms, 128 spp 8364 -> 4913)
+    uint32_t stream_budget_shift = 12;  // budget = max(stream_budget_min, fresh rays of the round >> shift)
+    uint32_t stream_list_cap = 0;       // suspended-ray list capacity (0 = max(65536, paths / 128)); tests shrink it
+    uint32_t stream_budget_min = 2048;  // interior fetches before a ray may be suspended (tests lower it to force suspensions)
+    uint64_t sppm_batch = 0;  // SPPM iterations per wavefront batch (0 = from free HBM, at most 128)
+    uint32_t sp_pixels = 0;
+    int64_t sp_photons = 0;
+    DevBuf fdesc;   // film_block 3: one SplatDesc (16 B) per camera sample of the band (th_kernels.h, k_film_descriptors)
+    DevBuf poison;  // one byte per camera sample of the band: ShadeStream::poison
+    DevBuf ov8[2], fb_list[2], fb_counts[2];  // k_trace8: global stack levels, fallback lists + their counters / work cursors ([closest | any])
+    Comm comm;  // multi-GPU job this context belongs to (trhip_comm_init); n_ranks == 1 without one
+};
+
+struct HostPrim {
+    uint32_t kind;       // 0 triangle, 1 sphere
+    float v[9];          // triangle vertices (world)
+    float n[9];          // vertex normals
+    uint32_t meta;       // material | flags
+    uint32_t sphere_id;  // for spheres
+};
+
+struct trhip_scene {
+    trhip_ctx* ctx = nullptr;
+    std::vector<MaterialRec> materials;
+    std::vector<HostPrim> prims;  // caller order
+    std::vector<SphereRec> spheres;
+    std::vector<HostAABB> sphere_bounds;
+    std::vector<LightRec> lights;
+    FlatBVH bvh;
+    bool committed = false;
+    DevBuf d_nodes, d_prims, d_nrm, d_shade, d_spheres, d_materials, d_lights, d_wnodes;
+    DeviceScene dev{};
+    WideScene wide{};
+    DevBuf d_occ_slots, d_occ_boxes, d_w8nodes, d_w8tris, d_leaf_order;
+    Wide8Scene w8{};              // the 8-wide view of the triangles' subtree (th_wide8.h / th_trace8.h)
+    uint32_t w8_nodes = 0, w8_depth = 0;
+    uint32_t n_occluders = 0;     // the scene's largest triangles, tested first by any-hit rays (th_trace2.h, k_any_occluders)
+    bool partial_spheres = false;  // some sphere is clipped (z range or ϕ_max): traversal kernels with the general sphere test
+    bool wide_ok = false;
+    bool w8_ok = false;            // the 8-wide view exists (th_trace8.h)
+    bool literal_only = false;     // a caller-supplied BVH whose boxes do not nest (trhip_scene_set_bvh): literal kernels only
+};
+
+inline int fail(trhip_ctx* ctx, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx)
+        ctx->err = buf;
+    else
+        g_init_error = buf;
+    return code;
+}
+#define HIP_TRY(ctx, expr)                                                                                       \
+    do {                                                                                                         \
+        hipError_t e_ = (expr);                                                                                  \
+        if (e_ != hipSuccess) return fail(ctx, TRHIP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+#define NCCL_TRY(ctx, expr)                                                                                                  \
+    do {                                                                                                                     \
+        ncclResult_t r_ = (expr);                                                                                            \
+        if (r_ != ncclSuccess) return fail(ctx, TRHIP_ERR_HIP, "%s failed: %s", #expr, rccl_api()->GetErrorString ? rccl_api()->GetErrorString(r_) : "RCCL error"); \
+    } while (0)
+
+inline int ensure(trhip_ctx* ctx, DevBuf& b, size_t bytes) {
+    if (b.bytes >= bytes && b.p) return 0;
+    if (b.p) HIP_TRY(ctx, hipFree(b.p));
+    b.p = nullptr;
+    b.bytes = 0;
+    if (bytes == 0) bytes = 16;
+    HIP_TRY(ctx, hipMalloc(&b.p, bytes));
+    b.bytes = bytes;
+    return 0;
+}
+inline void release(DevBuf& b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.bytes = 0;
+}
+inline int upload(trhip_ctx* ctx, DevBuf& b, const void* src, size_t bytes) {
+    if (int rc = ensure(ctx, b, bytes)) return rc;
+    if (bytes) HIP_TRY(ctx, hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
+    return 0;
+}
+inline int grid_for(const trhip_ctx* ctx, uint64_t n, int blocks_per_cu) {
+    const uint64_t need = (n + kBlock - 1) / kBlock;
+    const uint64_t cap = (uint64_t)ctx->num_cu * blocks_per_cu;
+    return (int)std::max<uint64_t>(1, std::min(need, cap));
+}
+
+struct Timer {
+    trhip_ctx* ctx;
+    bool on;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[5];
+    explicit Timer(trhip_ctx* c, bool enable) : ctx(c), on(enable) {}
+    ~Timer() {
+        for (auto& v : ev)
+            for (auto& p : v) {
+                (void)hipEventDestroy(p.first);
+                (void)hipEventDestroy(p.second);
+            }
+    }
+    void begin(int cls, hipStream_t st) {
+        if (!on) return;
+        hipEvent_t a, b;
+        (void)hipEventCreate(&a);
+        (void)hipEventCreate(&b);
+        (void)hipEventRecord(a, st);
+        ev[cls].push_back({a, b});
+    }
+    void end(int cls, hipStream_t st) {
+        if (!on) return;
+        (void)hipEventRecord(ev[cls].back().second, st);
+    }
+    double total(int cls, uint32_t* launches) {
+        double ms = 0;
+        for (auto& p : ev[cls]) {
+            float t = 0;
+            (void)hipEventElapsedTime(&t, p.first, p.second);
+            ms += t;
+        }
+        *launches = (uint32_t)ev[cls].size();
+        return ms;
+    }
+};
+
+// ---- functions one unit calls in another ---------------------------------------------------------------------------------------------
+// tu_scene.hip
+int upload_scene(trhip_scene* s);
+// tu_lbvh.hip
+int build_bvh_device(trhip_ctx* ctx, const std::vector<HostAABB>& pb, FlatBVH& out);
+// tu_trace.hip
+int trace_grid(const trhip_ctx* ctx);
+int ensure_overflow(trhip_ctx* ctx);
+WideScene wide_view(const trhip_ctx* ctx, const trhip_scene* sc);
+void traversal_info(const trhip_ctx* ctx, const trhip_scene* sc, uint32_t* trav, uint32_t* node_bytes);
+void launch_trace(trhip_ctx* ctx, hipStream_t st, const trhip_scene* sc, bool any, SegQueue q, const float4* ro, const float4* rd, const float* tmax, TraceOut out, uint32_t* work_cursors,
+                  Counters* ctr, void* overflow_slab = nullptr);
+void launch_trace2_stream(trhip_ctx* ctx, hipStream_t st, const trhip_scene* sc, bool any, SegQueue q, const float4* ro, const float4* rd, TraceOut out, uint32_t* work_cursors, void* overflow_slab,
+                          Counters* ctr, const StreamCtl& sx);
+// tu_trace3.hip / tu_trace8.hip: the kernel families launch_trace picks from
+void launch_trace3(trhip_ctx* ctx, hipStream_t st, const trhip_scene* sc, bool any, bool cnt, bool full_only, bool big, const SegQueue& q, const float4* ro, const float4* rd, const float* tmax,
+                   const TraceOut& out, uint32_t* work_cursors, uint2* ov, Counters* ctr);
+void launch_trace4(trhip_ctx* ctx, hipStream_t st, const trhip_scene* sc, bool any, bool cnt, bool full_only, const SegQueue& q, const float4* ro, const float4* rd, const float* tmax,
+                   const TraceOut& out, uint32_t* work_cursors, uint2* ov, Counters* ctr);
+void launch_trace8(trhip_ctx* ctx, hipStream_t st, const trhip_scene* sc, bool any, bool cnt, bool full_only, const Wide8Scene& w8, const SegQueue& q, const float4* ro, const float4* rd,
+                   const float* tmax, const TraceOut& out, uint32_t* work_cursors, uint32_t* ov8, Counters* ctr, const FallbackList& fb);
+// tu_path.hip
+void derive_sensor(const trhip_sensor* sn, DeviceSensor& d);
+bool film_uses_desc(const trhip_ctx* ctx, const DeviceSensor& ds);
+int ensure_film_samples(trhip_ctx* ctx, const DeviceSensor& ds, uint64_t total_slots);
+void launch_film(trhip_ctx* ctx, hipStream_t st, const DeviceSensor& ds, const DeviceSensor* dsp, const float4* L, uint64_t total_slots, uint32_t spp, uint64_t seed, uint32_t sample_offset,
+                 float4* d_film);
+// tu_whitted.hip
+int render_whitted_impl(trhip_ctx* ctx, const trhip_scene* scene, const DeviceSensor& ds, const trhip_sensor* sensor, uint32_t spp, int max_depth, uint64_t seed, uint32_t sample_offset,
+                        void* d_film, trhip_stats* stats, double* ms_total);

@@ -158,7 +158,7 @@ TH_D void generate_ray(const DeviceSensor& se, f2 film, f2 lens, float time_u, f
     d = normalize(d);
 }
 
-__global__ __launch_bounds__(kBlock) void k_raygen(const DeviceSensor* __restrict__ sep, uint32_t slot0, uint32_t n, uint64_t seed, uint32_t sample_offset,
+static __global__ __launch_bounds__(kBlock) void k_raygen(const DeviceSensor* __restrict__ sep, uint32_t slot0, uint32_t n, uint64_t seed, uint32_t sample_offset,
                                                    PathQueue q, uint32_t cap, Counters* ctr) {
     const DeviceSensor& se = *sep;
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(kBlock) void k_raygen(const DeviceSensor* __restric
 }
 
 // L[slot] += NaN on the channels a shading vertex noted in `poison` (ShadeStream::poison): NaN + x = NaN, so when the note is applied is immaterial
-__global__ __launch_bounds__(kBlock) void k_apply_poison(float4* __restrict__ L, const uint8_t* __restrict__ poison, uint64_t n) {
+static __global__ __launch_bounds__(kBlock) void k_apply_poison(float4* __restrict__ L, const uint8_t* __restrict__ poison, uint64_t n) {
     for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
         const uint32_t p = poison[i];
         if (p) {
@@ -421,7 +421,7 @@ TH_D bool rebuild_shading(const DeviceScene& sc, int prim, f3 o, f3 d, Shading& 
     return true;
 }
 // Commit time: records 6 / 7 of every triangle slot's shading line (th_scene.h) = triangle_constants of its vertices.
-__global__ __launch_bounds__(kBlock) void k_shade_constants(float4* __restrict__ shade, uint32_t n_prims) {
+static __global__ __launch_bounds__(kBlock) void k_shade_constants(float4* __restrict__ shade, uint32_t n_prims) {
     for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < n_prims; k += gridDim.x * kBlock) {
         float4* rec = shade + 8 * (size_t)k;
         const float4 p0 = rec[0], p1 = rec[1], p2 = rec[2];
@@ -640,7 +640,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TH_SHADE
 }
 // STREAM: per-sample radiance = its per-depth terms added in depth order, which is the order the classic wavefront (and the
 // reference's loop) adds them in.  A depth that contributed nothing holds +0, and x + 0 == x for every x this sum can take.
-__global__ __launch_bounds__(kBlock) void k_fold_terms(const float4* __restrict__ terms, uint64_t n_slots, uint32_t n_depths, float4* __restrict__ L) {
+static __global__ __launch_bounds__(kBlock) void k_fold_terms(const float4* __restrict__ terms, uint64_t n_slots, uint32_t n_depths, float4* __restrict__ L) {
     for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n_slots; i += (uint64_t)gridDim.x * kBlock) {
         float4 l = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         for (uint32_t dd = 0; dd < n_depths; ++dd) {
@@ -653,7 +653,7 @@ __global__ __launch_bounds__(kBlock) void k_fold_terms(const float4* __restrict_
     }
 }
 // depth tag 1 for every camera ray of a streaming batch
-__global__ __launch_bounds__(kBlock) void k_fill_u32(uint32_t* __restrict__ p, uint64_t n, uint32_t v) {
+static __global__ __launch_bounds__(kBlock) void k_fill_u32(uint32_t* __restrict__ p, uint64_t n, uint32_t v) {
     for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) p[i] = v;
 }
 
@@ -673,7 +673,7 @@ __global__ __launch_bounds__(kBlock) void k_fill_u32(uint32_t* __restrict__ p, u
 TH_D size_t film_index(uint32_t layout, uint32_t npix, uint32_t spp, uint32_t s, uint32_t pix) {
     return layout ? ((size_t)(pix >> 6) * spp + s) * 64u + (pix & 63u) : (size_t)s * npix + pix;
 }
-__global__ __launch_bounds__(kBlock) void k_film_transpose(const float4* __restrict__ L, uint32_t npix, uint32_t spp, float4* __restrict__ Lt) {
+static __global__ __launch_bounds__(kBlock) void k_film_transpose(const float4* __restrict__ L, uint32_t npix, uint32_t spp, float4* __restrict__ Lt) {
     const uint32_t groups = (npix + 63u) >> 6;
     const uint64_t chunks = (uint64_t)groups * spp;
     const uint32_t lane = threadIdx.x & 63u;
@@ -683,7 +683,7 @@ __global__ __launch_bounds__(kBlock) void k_film_transpose(const float4* __restr
         if (pix < npix) Lt[film_index(1u, npix, spp, s, pix)] = L[(size_t)s * npix + pix];
     }
 }
-__global__ __launch_bounds__(kBlock) void k_film_positions(const DeviceSensor* __restrict__ sep, uint64_t n, uint64_t seed, uint32_t sample_offset, float2* __restrict__ pfilm, uint32_t layout,
+static __global__ __launch_bounds__(kBlock) void k_film_positions(const DeviceSensor* __restrict__ sep, uint64_t n, uint64_t seed, uint32_t sample_offset, float2* __restrict__ pfilm, uint32_t layout,
                                                            uint32_t spp) {
     const DeviceSensor& se = *sep;
     for (uint64_t slot = (uint64_t)blockIdx.x * kBlock + threadIdx.x; slot < n; slot += (uint64_t)gridDim.x * kBlock) {
@@ -692,7 +692,7 @@ __global__ __launch_bounds__(kBlock) void k_film_positions(const DeviceSensor* _
         pfilm[film_index(layout, (uint32_t)(se.sb_w * se.band_rows), spp, si.sample, si.pix)] = make_float2((float)si.px + ts_uniform(key, TS_DIM_FILM_X), (float)si.py + ts_uniform(key, TS_DIM_FILM_Y));
     }
 }
-__global__ __launch_bounds__(kBlock) void k_film_gather(const DeviceSensor* __restrict__ sep, const float* __restrict__ table, const float4* __restrict__ L,
+static __global__ __launch_bounds__(kBlock) void k_film_gather(const DeviceSensor* __restrict__ sep, const float* __restrict__ table, const float4* __restrict__ L,
                                                         const float2* __restrict__ pfilm, uint32_t spp, uint32_t layout, float4* __restrict__ out) {
     const DeviceSensor& se = *sep;
     const uint32_t npx = (uint32_t)(se.film_w * se.film_h);
@@ -921,7 +921,7 @@ struct SplatDesc {   // uint4
     uint32_t ox;      // 4 bits per column: clamp(ceil(|x - dpx| / rx * 16), 1, 16) - 1
     uint32_t oy;      // 4 bits per row:    clamp(floor(|y - dpy| / ry * 16), 1, 16) - 1
 };
-__global__ __launch_bounds__(kBlock) void k_film_descriptors(const DeviceSensor* __restrict__ sep, uint64_t n, uint64_t seed, uint32_t sample_offset, uint4* __restrict__ desc) {
+static __global__ __launch_bounds__(kBlock) void k_film_descriptors(const DeviceSensor* __restrict__ sep, uint64_t n, uint64_t seed, uint32_t sample_offset, uint4* __restrict__ desc) {
     const DeviceSensor& se = *sep;
     const float rx = se.filter_radius[0], ry = se.filter_radius[1];
     const float inv_rx = 1.0f / rx, inv_ry = 1.0f / ry;
@@ -1058,7 +1058,7 @@ __global__ __launch_bounds__(kBlock) void k_film_gather_desc(const DeviceSensor*
 // pixel is unchanged: one accumulator per sample tile (at most 2x2 reach a pixel), inside a tile rows ascending, columns
 // ascending, samples ascending; tiles merged in k order (film.jl:182-193).  LDS layout: five planes [s][col], so the lanes
 // of a wave (different columns, same s) read consecutive banks and equal columns broadcast.
-__global__ __launch_bounds__(kBlock) void k_film_gather_tiled(const DeviceSensor* __restrict__ sep, const float* __restrict__ table, const float4* __restrict__ L,
+static __global__ __launch_bounds__(kBlock) void k_film_gather_tiled(const DeviceSensor* __restrict__ sep, const float* __restrict__ table, const float4* __restrict__ L,
                                                               const float2* __restrict__ pfilm, uint32_t spp, uint32_t layout, uint32_t cols, uint32_t ns_stage, float4* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float s_planes[];
     __shared__ float s_table[256];
@@ -1186,7 +1186,7 @@ __global__ __launch_bounds__(kBlock) void k_film_gather_tiled(const DeviceSensor
 }
 
 // save(film) up to the encoder (film.jl:204-222)
-__global__ void k_film_to_rgb(const float4* __restrict__ xyzw, uint32_t n, float scale, float* __restrict__ rgb) {
+static __global__ void k_film_to_rgb(const float4* __restrict__ xyzw, uint32_t n, float scale, float* __restrict__ rgb) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float4 p = xyzw[i];
@@ -1203,7 +1203,7 @@ __global__ void k_film_to_rgb(const float4* __restrict__ xyzw, uint32_t n, float
 }
 
 // ---- test / inspection kernels -----------------------------------------------------------------------------------------------------
-__global__ void k_hit_geometry(DeviceScene sc, const float4* __restrict__ ro, const float4* __restrict__ rd, const float4* __restrict__ hits, uint32_t n, float* __restrict__ out15) {
+static __global__ void k_hit_geometry(DeviceScene sc, const float4* __restrict__ ro, const float4* __restrict__ rd, const float4* __restrict__ hits, uint32_t n, float* __restrict__ out15) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float* g = out15 + 15 * (size_t)i;
@@ -1218,7 +1218,7 @@ __global__ void k_hit_geometry(DeviceScene sc, const float4* __restrict__ ro, co
     const float v[15] = {sh.p.x, sh.p.y, sh.p.z, sh.ng.x, sh.ng.y, sh.ng.z, sh.ns.x, sh.ns.y, sh.ns.z, sh.wo.x, sh.wo.y, sh.wo.z, sh.ss.x, sh.ss.y, sh.ss.z};
     for (int k = 0; k < 15; ++k) g[k] = v[k];
 }
-__global__ void k_prepare_rays(const float* __restrict__ rays8, uint32_t n, float4* __restrict__ ro, float4* __restrict__ rd, float* __restrict__ tmax) {
+static __global__ void k_prepare_rays(const float* __restrict__ rays8, uint32_t n, float4* __restrict__ ro, float4* __restrict__ rd, float* __restrict__ tmax) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float* r = rays8 + 8 * (size_t)i;
@@ -1227,7 +1227,7 @@ __global__ void k_prepare_rays(const float* __restrict__ rays8, uint32_t n, floa
     rd[i] = make_float4(d.x, d.y, d.z, 0.0f);
     tmax[i] = r[3];
 }
-__global__ void k_generate_rays(const DeviceSensor* __restrict__ sep, const float* __restrict__ samples5, uint32_t n, float* __restrict__ out8) {
+static __global__ void k_generate_rays(const DeviceSensor* __restrict__ sep, const float* __restrict__ samples5, uint32_t n, float* __restrict__ out8) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float* c = samples5 + 5 * (size_t)i;
@@ -1244,7 +1244,7 @@ __global__ void k_generate_rays(const DeviceSensor* __restrict__ sep, const floa
     r[6] = d.z;
     r[7] = time;
 }
-__global__ void k_bsdf_query(DeviceScene sc, uint32_t material, int multi, int mode, int flags, const float* __restrict__ frame9, const float* __restrict__ dirs6, uint32_t n,
+static __global__ void k_bsdf_query(DeviceScene sc, uint32_t material, int multi, int mode, int flags, const float* __restrict__ frame9, const float* __restrict__ dirs6, uint32_t n,
                              float* __restrict__ out8) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -1281,7 +1281,7 @@ __global__ void k_bsdf_query(DeviceScene sc, uint32_t material, int multi, int m
     }
 }
 // Per-sample radiance read-back: float4 L -> rgb with the NaN rule of integrators/sampler.jl:46
-__global__ void k_export_L(const float4* __restrict__ L, uint64_t n, float* __restrict__ out) {
+static __global__ void k_export_L(const float4* __restrict__ L, uint64_t n, float* __restrict__ out) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float4 l = L[i];
@@ -1291,7 +1291,7 @@ __global__ void k_export_L(const float4* __restrict__ L, uint64_t n, float* __re
     out[3 * i + 1] = c.y;
     out[3 * i + 2] = c.z;
 }
-__global__ void k_import_L(const float* __restrict__ in, uint64_t n, float4* __restrict__ L) {
+static __global__ void k_import_L(const float* __restrict__ in, uint64_t n, float4* __restrict__ L) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     L[i] = make_float4(in[3 * i], in[3 * i + 1], in[3 * i + 2], 0.0f);

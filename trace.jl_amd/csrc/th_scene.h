@@ -92,7 +92,7 @@ struct DeviceSensor {
     int32_t sb_w, sb_h;            // sample-pixel grid
     int32_t film_w, film_h;        // size(film.pixels) = (film_h, film_w)
     int32_t tiles_x, tiles_y;      // 16x16 sample tiles, integrators/sampler.jl:15-20
-    // A frame too large for HBM is rendered in BANDS of whole tile rows (tracehip.hip, render_impl): the wavefront and the film gather of one
+    // A frame too large for HBM is rendered in BANDS of whole tile rows (tu_path.hip, render_impl): the wavefront and the film gather of one
     // launch cover sample rows band_y0 .. band_y0 + band_rows - 1 = tile rows band_ty0 .. band_ty1; with `accumulate` the gather adds the band's
     // tiles, in k order, onto what the film pixel already holds — merge_film_tile! (film.jl:182-193) adds tile after tile the same way.
     int32_t band_y0, band_rows, band_ty0, band_ty1, accumulate;

@@ -936,7 +936,7 @@ __global__ __launch_bounds__(kBlock, 5) void k_any_occluders(DeviceScene sc, Occ
 #endif
 #ifdef TH_DIAG_PHASES
 // DIAGNOSTIC build (tools/phase_probe.py): wave cycles and active lanes per phase of k_trace3, summed over the waves of all launches
-__device__ unsigned long long g_phase[16];
+static __device__ unsigned long long g_phase[16];
 #define TH_PHASE_BEGIN() const unsigned long long ph_t0 = __builtin_readcyclecounter()
 #define TH_PHASE_END(slot, lanes)                                                   \
     do {                                                                            \

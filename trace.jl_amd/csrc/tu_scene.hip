@@ -1,0 +1,756 @@
+// tu_scene.hip — scene flattening into HBM: materials, primitives, BVHAccel commit (host SAH / device LBVH / a caller's tree), the
+// derived node arrays of the traversal kernels.
+#include "th_host.h"
+
+namespace {
+// ---- materials: the lobes each Material adds (materials/material.jl), precomputed per material ---------------------------------
+float roughness_to_alpha(float roughness) {  // microfacet.jl:82-87
+    roughness = jmax(1e-3f, roughness);
+    const float x = tm_logf(roughness);
+    return 1.62142f + 0.819955f * x + 0.1734f * (x * x) + 0.0171201f * (x * x * x) + 0.000640711f * pow4(x);
+}
+void clamp_rgb(const float* in, float* out) {  // clamp(spectrum) spectrum.jl:34-38
+    for (int i = 0; i < 3; ++i) out[i] = jclamp(in[i], 0.0f, kInf);
+}
+bool black(const float* c) { return c[0] == 0.0f && c[1] == 0.0f && c[2] == 0.0f; }
+Lobe base_lobe(int kind, int type) {
+    Lobe l;
+    std::memset(&l, 0, sizeof l);
+    l.kind = kind;
+    l.type = type;
+    l.fresnel = FRESNEL_NOOP;
+    l.eta_a = l.eta_b = l.fr_eta_i = l.fr_eta_t = 1.0f;
+    return l;
+}
+void set_rgb(float* dst, const float* src) {
+    dst[0] = src[0];
+    dst[1] = src[1];
+    dst[2] = src[2];
+}
+Lobe microfacet_lobe(int kind, int type, const float* rgb, float ax, float ay) {
+    Lobe l = base_lobe(kind, type);
+    set_rgb(l.r, rgb);
+    l.a = jmax(1e-3f, ax);  // TrowbridgeReitzDistribution ctor microfacet.jl:61-65
+    l.b = jmax(1e-3f, ay);
+    return l;
+}
+int build_material(int kind, const float* p, int n, MaterialRec& m) {
+    std::memset(&m, 0, sizeof m);
+    for (int multi = 0; multi < 2; ++multi) {
+        LobeSet& s = m.set[multi];
+        s.n = 0;
+        s.eta = 1.0f;
+        switch (kind) {
+        case TRHIP_MATTE: {  // material.jl:16-31
+            if (n != 4) return -1;
+            float r[3];
+            clamp_rgb(p, r);
+            if (black(r)) break;
+            const float sigma = jclamp(p[3], 0.0f, 90.0f);
+            if (sigma == 0.0f) {
+                Lobe l = base_lobe(LOBE_LAMBERT_R, BSDF_DIFFUSE | BSDF_REFLECTION);
+                set_rgb(l.r, r);
+                s.lobe[s.n++] = l;
+            } else {  // OrenNayar ctor microfacet.jl:12-19
+                Lobe l = base_lobe(LOBE_OREN_NAYAR, BSDF_DIFFUSE | BSDF_REFLECTION);
+                set_rgb(l.r, r);
+                const float sg = deg2rad(sigma);
+                const float s2 = sg * sg;
+                l.a = 1.0f - (s2 / (2.0f * (s2 + 0.33f)));
+                l.b = 0.45f * s2 / (s2 + 0.09f);
+                s.lobe[s.n++] = l;
+            }
+            break;
+        }
+        case TRHIP_MIRROR: {  // material.jl:39-46
+            if (n != 3) return -1;
+            float r[3];
+            clamp_rgb(p, r);
+            if (black(r)) break;
+            Lobe l = base_lobe(LOBE_SPECULAR_R, BSDF_SPECULAR | BSDF_REFLECTION);
+            set_rgb(l.r, r);
+            s.lobe[s.n++] = l;
+            break;
+        }
+        case TRHIP_GLASS: {  // material.jl:75-116
+            if (n != 10) return -1;
+            const float eta = p[8];
+            float ur = p[6], vr = p[7];
+            const bool remap = p[9] != 0.0f;
+            s.eta = eta;
+            float r[3], t[3];
+            clamp_rgb(p, r);
+            clamp_rgb(p + 3, t);
+            if (black(r) && black(t)) break;
+            const bool is_specular = ur == 0.0f && vr == 0.0f;
+            if (is_specular && multi) {
+                Lobe l = base_lobe(LOBE_FRESNEL_SPECULAR, BSDF_SPECULAR | BSDF_TRANSMISSION | BSDF_REFLECTION);
+                set_rgb(l.r, r);
+                set_rgb(l.t, t);
+                l.eta_a = 1.0f;
+                l.eta_b = eta;
+                s.lobe[s.n++] = l;
+                break;
+            }
+            if (remap) {
+                ur = roughness_to_alpha(ur);
+                vr = roughness_to_alpha(vr);
+            }
+            if (!black(r)) {
+                Lobe l = is_specular ? base_lobe(LOBE_SPECULAR_R, BSDF_SPECULAR | BSDF_REFLECTION) : microfacet_lobe(LOBE_MICROFACET_R, BSDF_REFLECTION | BSDF_GLOSSY, r, ur, vr);
+                set_rgb(l.r, r);
+                l.fresnel = FRESNEL_DIELECTRIC;
+                l.fr_eta_i = 1.0f;
+                l.fr_eta_t = eta;
+                s.lobe[s.n++] = l;
+            }
+            if (!black(t)) {
+                Lobe l = is_specular ? base_lobe(LOBE_SPECULAR_T, BSDF_SPECULAR | BSDF_TRANSMISSION) : microfacet_lobe(LOBE_MICROFACET_T, BSDF_TRANSMISSION | BSDF_GLOSSY, t, ur, vr);
+                set_rgb(l.r, t);
+                l.eta_a = 1.0f;
+                l.eta_b = eta;
+                l.fresnel = FRESNEL_DIELECTRIC;  // FresnelDielectric(η_a, η_b) specular.jl:60, microfacet.jl:275
+                l.fr_eta_i = 1.0f;
+                l.fr_eta_t = eta;
+                s.lobe[s.n++] = l;
+            }
+            break;
+        }
+        case TRHIP_PLASTIC: {  // material.jl:135-151
+            if (n != 8) return -1;
+            float kd[3], ks[3];
+            clamp_rgb(p, kd);
+            if (!black(kd)) {
+                Lobe l = base_lobe(LOBE_LAMBERT_R, BSDF_DIFFUSE | BSDF_REFLECTION);
+                set_rgb(l.r, kd);
+                s.lobe[s.n++] = l;
+            }
+            clamp_rgb(p + 3, ks);
+            if (black(ks)) break;
+            float rough = p[6];
+            if (p[7] != 0.0f) rough = roughness_to_alpha(rough);
+            Lobe l = microfacet_lobe(LOBE_MICROFACET_R, BSDF_REFLECTION | BSDF_GLOSSY, ks, rough, rough);
+            l.fresnel = FRESNEL_DIELECTRIC;
+            l.fr_eta_i = 1.5f;
+            l.fr_eta_t = 1.0f;
+            s.lobe[s.n++] = l;
+            break;
+        }
+        default: return -1;
+        }
+    }
+    return 0;
+}
+
+// world_bound(sphere) = object_to_world(object_bound) (Shape.jl:17-19, transformations.jl:141-143)
+HostAABB sphere_world_bound(const SphereRec& s) {
+    HostAABB b;
+    b.reset();
+    const float lo[3] = {-s.radius, -s.radius, s.z_min}, hi[3] = {s.radius, s.radius, s.z_max};
+    for (int c = 0; c < 8; ++c) {
+        const f3 p = xf_point(s.o2w, mk3((c & 1) ? hi[0] : lo[0], (c & 2) ? hi[1] : lo[1], (c & 4) ? hi[2] : lo[2]));
+        const float q[3] = {p.x, p.y, p.z};
+        b.grow_point(q);
+    }
+    return b;
+}
+float det3(const float* m) {  // rows of the upper-left 3x3 of a row-major 4x4
+    return m[0] * (m[5] * m[10] - m[6] * m[9]) - m[1] * (m[4] * m[10] - m[6] * m[8]) + m[2] * (m[4] * m[9] - m[5] * m[8]);
+}
+
+// does the subtree rooted at flat node `root` hold a sphere?  (depth-first layout: the subtree is a contiguous index range)
+bool has_sphere_subtree(const trhip_scene* s, uint32_t root) {
+    const uint32_t n_nodes = (uint32_t)s->bvh.a.size(), n_prims = (uint32_t)s->bvh.order.size();
+    if (root >= n_nodes) return true;
+    // end of the subtree: follow second children until a leaf
+    uint32_t end = root;
+    while ((s->bvh.flags[end] & 3u) != 3u) end = s->bvh.a[end];
+    for (uint32_t i = root; i <= end && i < n_nodes; ++i)
+        if ((s->bvh.flags[i] & 3u) == 3u)
+            for (uint32_t k = s->bvh.a[i]; k < s->bvh.a[i] + (s->bvh.flags[i] >> 2) && k < n_prims; ++k)
+                if (s->prims[s->bvh.order[k]].kind == 1) return true;
+    return false;
+}
+}  // namespace
+
+int upload_scene(trhip_scene* s) {
+    trhip_ctx* ctx = s->ctx;
+    const uint32_t n_nodes = (uint32_t)s->bvh.a.size(), n_prims = (uint32_t)s->bvh.order.size();
+    std::vector<float4> nodes((size_t)n_nodes * 2), prims((size_t)n_prims * 3), nrm((size_t)n_prims * 3);
+    for (uint32_t i = 0; i < n_nodes; ++i) {
+        const float* b = &s->bvh.bounds[6 * (size_t)i];
+        nodes[2 * (size_t)i] = make_float4(b[0], b[1], b[2], __builtin_bit_cast(float, s->bvh.a[i]));
+        nodes[2 * (size_t)i + 1] = make_float4(b[3], b[4], b[5], __builtin_bit_cast(float, s->bvh.flags[i]));
+    }
+    for (uint32_t k = 0; k < n_prims; ++k) {
+        const HostPrim& p = s->prims[s->bvh.order[k]];
+        if (p.kind == 1) {
+            prims[3 * (size_t)k] = make_float4(__builtin_bit_cast(float, p.sphere_id), 0, 0, __builtin_bit_cast(float, p.meta));
+            prims[3 * (size_t)k + 1] = prims[3 * (size_t)k + 2] = make_float4(0, 0, 0, 0);
+            nrm[3 * (size_t)k] = nrm[3 * (size_t)k + 1] = nrm[3 * (size_t)k + 2] = make_float4(0, 0, 0, 0);
+        } else {
+            prims[3 * (size_t)k] = make_float4(p.v[0], p.v[1], p.v[2], __builtin_bit_cast(float, p.meta));
+            prims[3 * (size_t)k + 1] = make_float4(p.v[3], p.v[4], p.v[5], 0);
+            prims[3 * (size_t)k + 2] = make_float4(p.v[6], p.v[7], p.v[8], 0);
+            const uint32_t mat = p.meta & PRIM_MATERIAL_MASK;
+            const bool fast = mat != PRIM_NO_MATERIAL && mat < s->materials.size() && s->materials[mat].set[1].n == 1 && s->materials[mat].set[1].lobe[0].kind == LOBE_LAMBERT_R;
+            if (fast) prims[3 * (size_t)k].w = __builtin_bit_cast(float, p.meta | PRIM_FAST);
+            for (int j = 0; j < 3; ++j) nrm[3 * (size_t)k + j] = make_float4(p.n[3 * j], p.n[3 * j + 1], p.n[3 * j + 2], fast ? s->materials[mat].set[1].lobe[0].r[j] : 0.0f);
+        }
+    }
+    if (int rc = upload(ctx, s->d_nodes, nodes.data(), nodes.size() * sizeof(float4))) return rc;
+    if (int rc = upload(ctx, s->d_prims, prims.data(), prims.size() * sizeof(float4))) return rc;
+    if (int rc = upload(ctx, s->d_nrm, nrm.data(), nrm.size() * sizeof(float4))) return rc;
+    {  // the shading kernels' interleaved view (th_scene.h): one 128-byte line per slot
+        std::vector<float4> rec((size_t)n_prims * 8, make_float4(0, 0, 0, 0));
+        for (uint32_t k = 0; k < n_prims; ++k)
+            for (int j = 0; j < 3; ++j) {
+                rec[8 * (size_t)k + j] = prims[3 * (size_t)k + j];
+                rec[8 * (size_t)k + 3 + j] = nrm[3 * (size_t)k + j];
+            }
+        if (int rc = upload(ctx, s->d_shade, rec.data(), rec.size() * sizeof(float4))) return rc;
+        // records 6 / 7: what a triangle's interaction derives from its vertices alone, computed by the code the shading kernels would run
+        hipLaunchKernelGGL(k_shade_constants, dim3(std::max(1u, std::min((n_prims + kBlock - 1) / kBlock, 4096u))), dim3(kBlock), 0, ctx->stream, (float4*)s->d_shade.p, n_prims);
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    if (int rc = upload(ctx, s->d_spheres, s->spheres.data(), s->spheres.size() * sizeof(SphereRec))) return rc;
+    if (int rc = upload(ctx, s->d_materials, s->materials.data(), s->materials.size() * sizeof(MaterialRec))) return rc;
+    if (int rc = upload(ctx, s->d_lights, s->lights.data(), s->lights.size() * sizeof(LightRec))) return rc;
+    s->dev.nodes = (const float4*)s->d_nodes.p;
+    s->dev.prims = (const float4*)s->d_prims.p;
+    s->dev.tri_nrm = (const float4*)s->d_nrm.p;
+    s->dev.shade = (const float4*)s->d_shade.p;
+    s->dev.spheres = (const SphereRec*)s->d_spheres.p;
+    s->dev.materials = (const MaterialRec*)s->d_materials.p;
+    s->dev.lights = (const LightRec*)s->d_lights.p;
+    s->dev.n_nodes = n_nodes;
+    s->dev.n_prims = n_prims;
+    s->dev.n_spheres = (uint32_t)s->spheres.size();
+    s->dev.n_materials = (uint32_t)s->materials.size();
+    s->dev.n_lights = (uint32_t)s->lights.size();
+    // ---- children-in-parent nodes for k_trace2 (th_trace2.h) ----
+    s->wide_ok = false;
+    std::memset(&s->wide, 0, sizeof s->wide);
+    s->wide.root_ref = kRefNone;
+    if (n_nodes > 0 && n_prims < (1u << 24) && !s->literal_only) {
+        std::vector<uint32_t> widx(n_nodes, 0);
+        uint32_t n_int = 0;
+        for (uint32_t i = 0; i < n_nodes; ++i)
+            if ((s->bvh.flags[i] & 3u) != 3u) widx[i] = n_int++;
+        bool ok = n_int < (1u << 24);
+        std::vector<float4> wn((size_t)n_int * 4);
+        // subtrees that hold a sphere keep the reference's loose slab test (th_trace2.h, slab_test2): the fp32 sphere quadratic
+        // (sphere.jl:120-150) accepts rays that pass the sphere at a distance far beyond the tight test's margin
+        std::vector<uint8_t> has_sphere(n_nodes, 0);
+        for (uint32_t i = n_nodes; i-- > 0;) {
+            if ((s->bvh.flags[i] & 3u) == 3u) {
+                const uint32_t first = s->bvh.a[i], cnt = s->bvh.flags[i] >> 2;
+                for (uint32_t k = first; k < first + cnt && k < n_prims; ++k) has_sphere[i] |= s->prims[s->bvh.order[k]].kind == 1;
+            } else {
+                has_sphere[i] = has_sphere[i + 1] | (s->bvh.a[i] < n_nodes ? has_sphere[s->bvh.a[i]] : 1);
+            }
+        }
+        for (uint32_t i = 0; i < n_nodes && ok; ++i) {
+            if ((s->bvh.flags[i] & 3u) == 3u) continue;
+            const uint32_t c[2] = {i + 1, s->bvh.a[i]};
+            uint32_t ref[2], cnt[2];
+            for (int k = 0; k < 2; ++k) {
+                if ((s->bvh.flags[c[k]] & 3u) == 3u) {
+                    ref[k] = s->bvh.a[c[k]];
+                    cnt[k] = s->bvh.flags[c[k]] >> 2;
+                    if (cnt[k] == 0 || cnt[k] > 255) ok = false;  // empty / oversized leaves only come from foreign BVHs: use the literal kernel
+                } else {
+                    ref[k] = widx[c[k]];
+                    cnt[k] = 0;
+                }
+            }
+            const float* l = &s->bvh.bounds[6 * (size_t)c[0]];
+            const float* r = &s->bvh.bounds[6 * (size_t)c[1]];
+            float4* w = &wn[4 * (size_t)widx[i]];
+            w[0] = make_float4(l[0], l[1], l[2], l[3]);
+            w[1] = make_float4(l[4], l[5], r[0], r[1]);
+            w[2] = make_float4(r[2], r[3], r[4], r[5]);
+            // child word = ref | count << 24 (the stack entry format); meta = split axis | "subtree holds a sphere" bits 2 (first) / 3 (second)
+            w[3] = make_float4(__builtin_bit_cast(float, ref[0] | (cnt[0] << 24)), __builtin_bit_cast(float, ref[1] | (cnt[1] << 24)),
+                               __builtin_bit_cast(float, (s->bvh.flags[i] & 3u) | ((uint32_t)has_sphere[c[0]] << 2) | ((uint32_t)has_sphere[c[1]] << 3)), 0.0f);
+        }
+        if (ok) {
+            if (int rc = upload(ctx, s->d_wnodes, wn.data(), wn.size() * sizeof(float4))) return rc;
+            s->wide.wnodes = (const float4*)s->d_wnodes.p;
+            s->wide.n_wnodes = n_int;
+            std::memcpy(s->wide.root_box, &s->bvh.bounds[0], 6 * sizeof(float));
+            if ((s->bvh.flags[0] & 3u) == 3u) {
+                s->wide.root_ref = s->bvh.a[0];
+                s->wide.root_cnt = s->bvh.flags[0] >> 2;
+                ok = s->wide.root_cnt > 0 && s->wide.root_cnt <= 255;
+            } else {
+                s->wide.root_ref = 0;
+                s->wide.root_cnt = 0;
+            }
+            s->wide_ok = ok;
+        }
+    }
+    // ---- 8-wide nodes over the triangles' subtree for k_trace8 (th_wide8.h) ----
+    s->w8_ok = false;
+    std::memset(&s->w8, 0, sizeof s->w8);
+    if (s->wide_ok && s->wide.root_cnt == 0 && n_nodes >= 3) {
+        // root of the triangles' subtree: the whole tree when the scene has no sphere; with spheres the commit composed
+        // root -> {leaf of all spheres (flat node 1), triangles (flat node 2)} (compose_bvh)
+        uint32_t sub_root = 0, n_sph = 0;
+        bool shape_ok = true;
+        if (!s->spheres.empty()) {
+            n_sph = (uint32_t)s->spheres.size();
+            sub_root = 2 * n_sph;
+            shape_ok = n_sph <= (uint32_t)kW8MaxSpheres && sub_root < n_nodes;
+            for (uint32_t i = 0; i < n_sph && shape_ok; ++i)
+                shape_ok = (s->bvh.flags[2 * i] & 3u) != 3u && (s->bvh.flags[2 * i] & 3u) == (s->bvh.flags[0] & 3u) && s->bvh.a[2 * i] == 2 * i + 2 &&
+                           s->bvh.flags[2 * i + 1] == ((1u << 2) | 3u) && s->bvh.a[2 * i + 1] == i && s->prims[s->bvh.order[i]].kind == 1;
+            shape_ok = shape_ok && !has_sphere_subtree(s, sub_root);
+        }
+        if (shape_ok) {
+            Wide8Host wh = build_wide8(s->bvh, sub_root, [&](uint32_t slot, float* v, uint32_t& meta) {
+                if (slot >= n_prims) return false;
+                const HostPrim& p = s->prims[s->bvh.order[slot]];
+                if (p.kind != 0) return false;
+                std::memcpy(v, p.v, 9 * sizeof(float));
+                meta = p.meta;
+                return true;
+            });
+            if (wh.ok) {
+                if (int rc = upload(ctx, s->d_w8nodes, wh.nodes.data(), wh.nodes.size() * sizeof(uint32_t))) return rc;
+                if (int rc = upload(ctx, s->d_w8tris, wh.tris.data(), wh.tris.size() * sizeof(float))) return rc;
+                s->w8.nodes = (const uint4*)s->d_w8nodes.p;
+                s->w8.tris = (const float4*)s->d_w8tris.p;
+                std::memcpy(s->w8.root_box, &s->bvh.bounds[0], 6 * sizeof(float));
+                std::memcpy(s->w8.tri_box, &s->bvh.bounds[6 * (size_t)sub_root], 6 * sizeof(float));
+                for (uint32_t i = 0; i < n_sph; ++i) std::memcpy(s->w8.sph_box[i], &s->bvh.bounds[6 * (size_t)(2 * i + 1)], 6 * sizeof(float));
+                s->w8.n_sph = n_sph;
+                s->w8.chain_axis = s->bvh.flags[0] & 3u;
+                s->w8_nodes = (uint32_t)(wh.nodes.size() / kW8NodeDwords);
+                s->w8_depth = wh.depth;
+                s->w8_ok = true;
+            }
+        }
+    }
+    // ---- one-leaf scenes: the order in which any-hit rays try the leaf's primitives (th_trace2.h, k_any_leaf) ----
+    // A shadow ray runs from the surface THROUGH the light (t_max = Inf): what stops it at the latest is what the light sees, so the
+    // primitives subtending the largest solid angle at the lights come first (triangles: Van Oosterom & Strackee; spheres: the cap of
+    // their bounding sphere).  Any order gives the same boolean.
+    s->wide.leaf_order = nullptr;
+    if (s->wide_ok && s->wide.root_cnt > 1 && !s->lights.empty()) {
+        const uint32_t first = s->wide.root_ref, cnt = s->wide.root_cnt;
+        std::vector<std::pair<double, uint32_t>> ord;
+        for (uint32_t k = 0; k < cnt; ++k) {
+            const HostPrim& p = s->prims[s->bvh.order[first + k]];
+            double w = 0.0;
+            for (const LightRec& l : s->lights) {
+                const float* lp = l.position;
+                if (p.kind == 1) {
+                    const HostAABB& b = s->sphere_bounds[p.sphere_id];
+                    double c[3], r = 0.0, d2 = 0.0;
+                    for (int a = 0; a < 3; ++a) {
+                        c[a] = 0.5 * ((double)b.mn[a] + b.mx[a]);
+                        r = std::max(r, 0.5 * ((double)b.mx[a] - b.mn[a]));
+                        d2 += (c[a] - lp[a]) * (c[a] - lp[a]);
+                    }
+                    w += d2 <= r * r ? 4.0 * 3.14159265358979 : 2.0 * 3.14159265358979 * (1.0 - std::sqrt(std::max(0.0, 1.0 - r * r / d2)));
+                } else {
+                    double r[3][3], len[3];
+                    for (int v = 0; v < 3; ++v) {
+                        for (int c = 0; c < 3; ++c) r[v][c] = (double)p.v[3 * v + c] - lp[c];
+                        len[v] = std::sqrt(r[v][0] * r[v][0] + r[v][1] * r[v][1] + r[v][2] * r[v][2]);
+                    }
+                    const double det = r[0][0] * (r[1][1] * r[2][2] - r[1][2] * r[2][1]) - r[0][1] * (r[1][0] * r[2][2] - r[1][2] * r[2][0]) + r[0][2] * (r[1][0] * r[2][1] - r[1][1] * r[2][0]);
+                    auto dot3 = [&](int a, int b) { return r[a][0] * r[b][0] + r[a][1] * r[b][1] + r[a][2] * r[b][2]; };
+                    const double den = len[0] * len[1] * len[2] + dot3(0, 1) * len[2] + dot3(0, 2) * len[1] + dot3(1, 2) * len[0];
+                    w += 2.0 * std::fabs(std::atan2(det, den));
+                }
+            }
+            ord.push_back({w, k});
+        }
+        std::stable_sort(ord.begin(), ord.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
+        std::vector<uint32_t> order(cnt);
+        for (uint32_t k = 0; k < cnt; ++k) order[k] = ord[k].second;
+        if (int rc = upload(ctx, s->d_leaf_order, order.data(), order.size() * sizeof(uint32_t))) return rc;
+        s->wide.leaf_order = (const uint32_t*)s->d_leaf_order.p;
+    }
+    // ---- largest triangles: the any-hit pre-pass (th_trace2.h, k_any_occluders) ----
+    s->n_occluders = 0;
+    if (s->wide_ok && s->wide.root_cnt == 0) {
+        const float* rb = &s->bvh.bounds[0];
+        const double ex = (double)rb[3] - rb[0], ey = (double)rb[4] - rb[1], ez = (double)rb[5] - rb[2];
+        const double face = std::max(ex * ey, std::max(ex * ez, ey * ez));
+        std::vector<std::pair<double, uint32_t>> big;  // (area, ordered slot)
+        for (uint32_t k = 0; k < n_prims; ++k) {
+            const HostPrim& p = s->prims[s->bvh.order[k]];
+            if (p.kind != 0 || (p.meta & PRIM_DEGENERATE)) continue;
+            const double ax = (double)p.v[3] - p.v[0], ay = (double)p.v[4] - p.v[1], az = (double)p.v[5] - p.v[2];
+            const double bx = (double)p.v[6] - p.v[0], by = (double)p.v[7] - p.v[1], bz = (double)p.v[8] - p.v[2];
+            const double cx = ay * bz - az * by, cy = az * bx - ax * bz, cz = ax * by - ay * bx;
+            const double area = 0.5 * std::sqrt(cx * cx + cy * cy + cz * cz);
+            if (area >= 0.02 * face) big.push_back({area, k});
+        }
+        if (!big.empty() && big.size() * 8 <= (size_t)n_prims) {  // a few walls around much else; not a scene that consists of large triangles
+            std::sort(big.begin(), big.end(), [](const auto& a, const auto& b) { return a.first > b.first || (a.first == b.first && a.second < b.second); });
+            if (big.size() > 16) big.resize(16);
+            // test order: a shadow ray runs from the surface THROUGH the light (t_max = Inf) — what stops it at the latest is what the light
+            // sees, so the triangles subtending the largest solid angle at the lights come first (Van Oosterom & Strackee)
+            auto solid_angle = [&](uint32_t k, const float* lp) {
+                const HostPrim& p = s->prims[s->bvh.order[k]];
+                double r[3][3], len[3];
+                for (int v = 0; v < 3; ++v) {
+                    for (int c = 0; c < 3; ++c) r[v][c] = (double)p.v[3 * v + c] - lp[c];
+                    len[v] = std::sqrt(r[v][0] * r[v][0] + r[v][1] * r[v][1] + r[v][2] * r[v][2]);
+                }
+                const double det = r[0][0] * (r[1][1] * r[2][2] - r[1][2] * r[2][1]) - r[0][1] * (r[1][0] * r[2][2] - r[1][2] * r[2][0]) + r[0][2] * (r[1][0] * r[2][1] - r[1][1] * r[2][0]);
+                auto dot3 = [&](int a, int b) { return r[a][0] * r[b][0] + r[a][1] * r[b][1] + r[a][2] * r[b][2]; };
+                const double den = len[0] * len[1] * len[2] + dot3(0, 1) * len[2] + dot3(0, 2) * len[1] + dot3(1, 2) * len[0];
+                return 2.0 * std::fabs(std::atan2(det, den));
+            };
+            if (!s->lights.empty()) {
+                for (auto& b : big) {
+                    double w = 0.0;
+                    for (const LightRec& l : s->lights) w += solid_angle(b.second, l.position);
+                    b.first = w;
+                }
+                std::stable_sort(big.begin(), big.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
+            }
+            std::vector<uint32_t> leaf_of(n_prims, 0xffffffffu);
+            for (uint32_t i = 0; i < n_nodes; ++i)
+                if ((s->bvh.flags[i] & 3u) == 3u)
+                    for (uint32_t k = s->bvh.a[i]; k < s->bvh.a[i] + (s->bvh.flags[i] >> 2) && k < n_prims; ++k) leaf_of[k] = i;
+            std::vector<uint32_t> slots;
+            std::vector<float> boxes;
+            for (const auto& b : big) {
+                if (leaf_of[b.second] == 0xffffffffu) continue;
+                slots.push_back(b.second);
+                for (int a = 0; a < 6; ++a) boxes.push_back(s->bvh.bounds[6 * (size_t)leaf_of[b.second] + a]);
+            }
+            if (slots.size() >= 6) {  // an enclosure (three quads or more); a lone floor stops few shadow rays and the pre-pass only costs (S-caustic)
+                if (int rc = upload(ctx, s->d_occ_slots, slots.data(), slots.size() * sizeof(uint32_t))) return rc;
+                if (int rc = upload(ctx, s->d_occ_boxes, boxes.data(), boxes.size() * sizeof(float))) return rc;
+                s->n_occluders = (uint32_t)slots.size();
+            }
+        }
+    }
+    s->committed = true;
+    return 0;
+}
+
+extern "C" {
+
+int trhip_scene_new(trhip_ctx* ctx, trhip_scene** out) {
+    if (!ctx || !out) return fail(ctx, TRHIP_ERR_INVALID, "null argument");
+    auto s = new trhip_scene();
+    s->ctx = ctx;
+    *out = s;
+    return 0;
+}
+void trhip_scene_free(trhip_scene* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->ctx->device);
+    release(s->d_nodes);
+    release(s->d_prims);
+    release(s->d_nrm);
+    release(s->d_shade);
+    release(s->d_leaf_order);
+    release(s->d_spheres);
+    release(s->d_materials);
+    release(s->d_lights);
+    release(s->d_wnodes);
+    release(s->d_occ_slots);
+    release(s->d_occ_boxes);
+    release(s->d_w8nodes);
+    release(s->d_w8tris);
+    delete s;
+}
+int trhip_scene_add_material(trhip_scene* s, int kind, const float* params, int n_params, uint32_t* id_out) {
+    if (!s || !params) return fail(s ? s->ctx : nullptr, TRHIP_ERR_INVALID, "null argument");
+    MaterialRec m;
+    if (build_material(kind, params, n_params, m)) return fail(s->ctx, TRHIP_ERR_INVALID, "bad material kind %d / parameter count %d", kind, n_params);
+    if (s->materials.size() >= PRIM_NO_MATERIAL) return fail(s->ctx, TRHIP_ERR_INVALID, "too many materials");
+    s->materials.push_back(m);
+    if (id_out) *id_out = (uint32_t)s->materials.size() - 1;
+    s->committed = false;
+    return 0;
+}
+int trhip_scene_add_triangles(trhip_scene* s, const float* xyz, uint32_t n_verts, const uint32_t* idx, uint32_t n_tris, const float* normals, const uint32_t* mat, int flip,
+                              uint32_t* first_out) {
+    if (!s || !xyz || !idx) return fail(s ? s->ctx : nullptr, TRHIP_ERR_INVALID, "null argument");
+    const uint32_t first = (uint32_t)s->prims.size();
+    s->prims.reserve(s->prims.size() + n_tris);
+    for (uint32_t k = 0; k < n_tris; ++k) {
+        HostPrim p;
+        std::memset(&p, 0, sizeof p);
+        p.kind = 0;
+        for (int j = 0; j < 3; ++j) {
+            const uint32_t vi = idx[3 * (size_t)k + j];
+            if (vi < 1 || vi > n_verts) return fail(s->ctx, TRHIP_ERR_INVALID, "triangle %u: index %u outside 1..%u (indices are 1-based)", k, vi, n_verts);
+            std::memcpy(&p.v[3 * j], &xyz[3 * (size_t)(vi - 1)], 3 * sizeof(float));
+            if (normals) std::memcpy(&p.n[3 * j], &normals[3 * (size_t)(vi - 1)], 3 * sizeof(float));
+        }
+        uint32_t m = mat ? mat[k] : PRIM_NO_MATERIAL;
+        if (mat && m != PRIM_NO_MATERIAL && m >= s->materials.size()) return fail(s->ctx, TRHIP_ERR_INVALID, "triangle %u: material %u not defined", k, m);
+        // is_degenerate (triangle_mesh.jl:65-68) depends on the triangle alone: evaluated here, once, in the kernels' arithmetic
+        const f3 tv0 = mk3(p.v[0], p.v[1], p.v[2]), tv1 = mk3(p.v[3], p.v[4], p.v[5]), tv2 = mk3(p.v[6], p.v[7], p.v[8]);
+        const f3 tn = cross(tv2 - tv0, tv1 - tv0);
+        const bool degenerate = dot(tn, tn) == 0.0f;
+        p.meta = (m & PRIM_MATERIAL_MASK) | (normals ? PRIM_HAS_NORMALS : 0u) | (flip ? PRIM_FLIP : 0u) | (degenerate ? PRIM_DEGENERATE : 0u);
+        s->prims.push_back(p);
+    }
+    if (first_out) *first_out = first;
+    s->committed = false;
+    return 0;
+}
+static int add_sphere_rec(trhip_scene* s, const float* o2w, const float* o2w_inv, int reverse, SphereRec r, uint32_t material, uint32_t* prim_out) {
+    if (material != PRIM_NO_MATERIAL && material >= s->materials.size()) return fail(s->ctx, TRHIP_ERR_INVALID, "material %u not defined", material);
+    std::memcpy(r.o2w, o2w, sizeof r.o2w);
+    std::memcpy(r.o2w_inv, o2w_inv, sizeof r.o2w_inv);
+    const bool swaps = det3(o2w) < 0.0f;  // transformations.jl:161-163
+    r.flip = ((reverse != 0) != swaps) ? 1u : 0u;
+    r.never_clipped = (!(r.z_min > -r.radius) && !(r.z_max < r.radius) && r.phi_max >= 2.0f * kPi) ? 1u : 0u;
+    if (!r.never_clipped) s->partial_spheres = true;
+    HostPrim p;
+    std::memset(&p, 0, sizeof p);
+    p.kind = 1;
+    p.sphere_id = (uint32_t)s->spheres.size();
+    p.meta = (material & PRIM_MATERIAL_MASK) | PRIM_SPHERE;
+    s->spheres.push_back(r);
+    s->sphere_bounds.push_back(sphere_world_bound(r));
+    if (prim_out) *prim_out = (uint32_t)s->prims.size();
+    s->prims.push_back(p);
+    s->committed = false;
+    return 0;
+}
+int trhip_scene_add_sphere(trhip_scene* s, const float* o2w, const float* o2w_inv, int reverse, float radius, float z_min, float z_max, float phi_max_deg, uint32_t material,
+                           uint32_t* prim_out) {
+    if (!s || !o2w || !o2w_inv) return fail(s ? s->ctx : nullptr, TRHIP_ERR_INVALID, "null argument");
+    SphereRec r;
+    std::memset(&r, 0, sizeof r);
+    r.radius = radius;  // Sphere ctor sphere.jl:13-26
+    r.z_min = jclamp(jmin(z_min, z_max), -radius, radius);
+    r.z_max = jclamp(jmax(z_min, z_max), -radius, radius);
+    r.theta_min = tm_acosf(jclamp(jmin(z_min, z_max) / radius, -1.0f, 1.0f));
+    r.theta_max = tm_acosf(jclamp(jmax(z_min, z_max) / radius, -1.0f, 1.0f));
+    r.phi_max = deg2rad(jclamp(phi_max_deg, 0.0f, 360.0f));
+    return add_sphere_rec(s, o2w, o2w_inv, reverse, r, material, prim_out);
+}
+int trhip_scene_add_sphere_fields(trhip_scene* s, const float* o2w, const float* o2w_inv, int reverse, float radius, float z_min, float z_max, float theta_min, float theta_max,
+                                  float phi_max_rad, uint32_t material, uint32_t* prim_out) {
+    if (!s || !o2w || !o2w_inv) return fail(s ? s->ctx : nullptr, TRHIP_ERR_INVALID, "null argument");
+    SphereRec r;
+    std::memset(&r, 0, sizeof r);
+    r.radius = radius;
+    r.z_min = z_min;
+    r.z_max = z_max;
+    r.theta_min = theta_min;
+    r.theta_max = theta_max;
+    r.phi_max = phi_max_rad;
+    return add_sphere_rec(s, o2w, o2w_inv, reverse, r, material, prim_out);
+}
+static int add_light(trhip_scene* s, int kind, const float* l2w, const float* l2w_inv, const float* I, float total_deg, float falloff_deg, bool fields = false) {
+    if (!s || !l2w || !l2w_inv || !I) return fail(s ? s->ctx : nullptr, TRHIP_ERR_INVALID, "null argument");
+    LightRec l;
+    std::memset(&l, 0, sizeof l);
+    l.kind = kind;
+    const f3 pos = xf_point(l2w, splat3(0.0f));  // light_to_world(Point3f(0)) point.jl:23, spot.jl:16
+    l.position[0] = pos.x;
+    l.position[1] = pos.y;
+    l.position[2] = pos.z;
+    std::memcpy(l.I, I, 3 * sizeof(float));
+    if (kind == 1) {
+        l.cos_total_width = fields ? total_deg : tm_cosf(deg2rad(total_deg));  // spot.jl:17
+        l.cos_falloff_start = fields ? falloff_deg : tm_cosf(deg2rad(falloff_deg));
+    }
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+            l.w2l[3 * r + c] = l2w_inv[4 * r + c];  // world_to_light = inv(light_to_world): .m = inv_m
+            l.l2w[3 * r + c] = l2w[4 * r + c];
+        }
+    s->lights.push_back(l);
+    s->committed = false;
+    return 0;
+}
+int trhip_scene_add_point_light(trhip_scene* s, const float* l2w, const float* l2w_inv, const float* I) { return add_light(s, 0, l2w, l2w_inv, I, 0, 0); }
+int trhip_scene_add_spot_light(trhip_scene* s, const float* l2w, const float* l2w_inv, const float* I, float total_deg, float falloff_deg) {
+    return add_light(s, 1, l2w, l2w_inv, I, total_deg, falloff_deg);
+}
+
+int trhip_scene_add_spot_light_fields(trhip_scene* s, const float* l2w, const float* l2w_inv, const float* I, float cos_total, float cos_falloff) {
+    return add_light(s, 1, l2w, l2w_inv, I, cos_total, cos_falloff, true);
+}
+
+int trhip_scene_commit(trhip_scene* s, int max_node_primitives) {
+    if (!s) return fail(nullptr, TRHIP_ERR_INVALID, "null scene");
+    HIP_TRY(s->ctx, hipSetDevice(s->ctx->device));
+    std::vector<HostAABB> pb(s->prims.size());
+    for (size_t i = 0; i < s->prims.size(); ++i) {
+        const HostPrim& p = s->prims[i];
+        if (p.kind == 1) {
+            pb[i] = s->sphere_bounds[p.sphere_id];
+        } else {  // world_bound(triangle) triangle_mesh.jl:97
+            pb[i].reset();
+            for (int j = 0; j < 3; ++j) pb[i].grow_point(&p.v[3 * j]);
+        }
+    }
+    // Scenes with a few spheres beside a mesh: a chain root -> {sphere 1, {sphere 2, ... {sphere k, the triangles' subtree}}}.  Any BVH2 is a valid
+    // BVHAccel (results depend on the topology only through exact-t ties); this one keeps the spheres — whose fp32
+    // quadratic accepts rays far outside their box and can raise t_max (A.18) — out of the triangles' subtree, which the 8-wide
+    // kernel then walks with conservative interior boxes (th_wide8.h).  The leaf-size hint is a hint (bvh.jl:159-165 decides by cost).
+    std::vector<uint32_t> sph_ids, tri_ids;
+    for (size_t i = 0; i < s->prims.size(); ++i) (s->prims[i].kind == 1 ? sph_ids : tri_ids).push_back((uint32_t)i);
+    const bool want_chain = s->ctx->compose_spheres > 0 || (s->ctx->compose_spheres < 0 && s->ctx->traversal == 4);
+    const bool compose = want_chain && !sph_ids.empty() && sph_ids.size() <= (size_t)kW8MaxSpheres && tri_ids.size() >= 2 && pb.size() > s->ctx->tiny_scene_prims;
+    std::vector<HostAABB> pb_sub;
+    if (compose) {
+        pb_sub.reserve(tri_ids.size());
+        for (uint32_t id : tri_ids) pb_sub.push_back(pb[id]);
+    }
+    const std::vector<HostAABB>& pb_build = compose ? pb_sub : pb;
+    bool built = false;
+    const int mode = s->ctx->bvh_builder;
+    if ((mode == 1 || (mode < 0 && pb_build.size() > (16u << 20))) && pb_build.size() > s->ctx->tiny_scene_prims) {
+        FlatBVH dev;
+        const int rc = build_bvh_device(s->ctx, pb_build, dev);
+        if (rc == 0) {
+            s->bvh = std::move(dev);
+            built = true;
+        } else if (rc != TRHIP_ERR_UNSUPPORTED) {
+            return rc;
+        }
+    }
+    if (!built) {
+        BVHBuilder builder(pb_build, max_node_primitives, s->ctx->tiny_scene_prims, want_chain);  // traversal 4 wants one primitive per leaf
+        s->bvh = builder.build();
+    }
+    if (compose) {
+        // flat layout (bvh.jl:187-206): chain node i at 2 i = interior {leaf of sphere i at 2 i + 1, rest at 2 i + 2}; the triangles' subtree at 2 n_sph
+        FlatBVH sub = std::move(s->bvh), out;
+        const uint32_t n_sph = (uint32_t)sph_ids.size(), n_sub = (uint32_t)sub.a.size();
+        std::vector<HostAABB> rest(n_sph + 1);
+        std::memcpy(rest[n_sph].mn, &sub.bounds[0], 3 * sizeof(float));
+        std::memcpy(rest[n_sph].mx, &sub.bounds[3], 3 * sizeof(float));
+        for (uint32_t i = n_sph; i-- > 0;) {
+            rest[i] = rest[i + 1];
+            rest[i].grow(pb[sph_ids[i]]);
+        }
+        // one split axis for every chain node (it only decides whether a ray meets the sphere leaves before or after the triangles): where the
+        // spheres' centre and the triangles' lie furthest apart
+        HostAABB sall;
+        sall.reset();
+        for (uint32_t id : sph_ids) sall.grow(pb[id]);
+        uint32_t axis = 0;
+        float best = -1.0f;
+        for (int a = 0; a < 3; ++a) {
+            const float dc = std::fabs((0.5f * sall.mn[a] + 0.5f * sall.mx[a]) - (0.5f * rest[n_sph].mn[a] + 0.5f * rest[n_sph].mx[a]));
+            if (dc > best) {
+                best = dc;
+                axis = (uint32_t)a;
+            }
+        }
+        for (uint32_t i = 0; i < n_sph; ++i) {
+            const HostAABB& sbx = pb[sph_ids[i]];
+            out.bounds.insert(out.bounds.end(), {rest[i].mn[0], rest[i].mn[1], rest[i].mn[2], rest[i].mx[0], rest[i].mx[1], rest[i].mx[2]});
+            out.a.push_back(2 * i + 2);
+            out.flags.push_back(axis);
+            out.bounds.insert(out.bounds.end(), {sbx.mn[0], sbx.mn[1], sbx.mn[2], sbx.mx[0], sbx.mx[1], sbx.mx[2]});
+            out.a.push_back(i);
+            out.flags.push_back((1u << 2) | 3u);
+        }
+        out.bounds.insert(out.bounds.end(), sub.bounds.begin(), sub.bounds.end());
+        out.a.reserve(n_sub + 2 * n_sph);
+        out.flags.reserve(n_sub + 2 * n_sph);
+        for (uint32_t i = 0; i < n_sub; ++i) {
+            out.a.push_back(sub.a[i] + ((sub.flags[i] & 3u) == 3u ? n_sph : 2 * n_sph));
+            out.flags.push_back(sub.flags[i]);
+        }
+        out.order = sph_ids;
+        out.order.reserve(pb.size());
+        for (uint32_t k : sub.order) out.order.push_back(tri_ids[k]);
+        out.max_depth = sub.max_depth + n_sph;
+        s->bvh = std::move(out);
+    }
+    if (s->bvh.max_depth > (uint32_t)(kStackLds + kStackSpill))
+        return fail(s->ctx, TRHIP_ERR_UNSUPPORTED, "BVH depth %u exceeds the 64-entry traversal stack (bvh.jl:222)", s->bvh.max_depth);
+    s->literal_only = false;
+    return upload_scene(s);
+}
+int trhip_scene_bvh_size(const trhip_scene* s, uint32_t* n_nodes, uint32_t* n_prims) {
+    if (!s) return TRHIP_ERR_INVALID;
+    if (n_nodes) *n_nodes = (uint32_t)s->bvh.a.size();
+    if (n_prims) *n_prims = (uint32_t)s->bvh.order.size();
+    return 0;
+}
+int trhip_scene_get_bvh(const trhip_scene* s, float* bounds, uint32_t* a, uint32_t* flags, uint32_t* order) {
+    if (!s) return TRHIP_ERR_INVALID;
+    if (bounds) std::memcpy(bounds, s->bvh.bounds.data(), s->bvh.bounds.size() * sizeof(float));
+    if (a) std::memcpy(a, s->bvh.a.data(), s->bvh.a.size() * sizeof(uint32_t));
+    if (flags) std::memcpy(flags, s->bvh.flags.data(), s->bvh.flags.size() * sizeof(uint32_t));
+    if (order) std::memcpy(order, s->bvh.order.data(), s->bvh.order.size() * sizeof(uint32_t));
+    return 0;
+}
+int trhip_scene_set_bvh(trhip_scene* s, const float* bounds, const uint32_t* a, const uint32_t* flags, uint32_t n_nodes, const uint32_t* order, uint32_t n_prims) {
+    if (!s || !bounds || !a || !flags || !order) return fail(s ? s->ctx : nullptr, TRHIP_ERR_INVALID, "null argument");
+    if (n_nodes == 0) return fail(s->ctx, TRHIP_ERR_INVALID, "empty node array");
+    for (uint32_t i = 0; i < n_prims; ++i)
+        if (order[i] >= s->prims.size()) return fail(s->ctx, TRHIP_ERR_INVALID, "prim_order[%u] = %u out of range", i, order[i]);
+    // The array must be ONE tree in the reference's depth-first layout (bvh.jl:187-206): the subtree of node i is the index range
+    // [i, end): first child i + 1 .. a[i] - 1, second child a[i] .. end - 1.  Anything else (a[i] <= i + 1 closes a cycle: the
+    // traversal kernels would never end) is rejected here; so is a tree deeper than the 64-entry stack, where the reference
+    // throws a BoundsError (bvh.jl:222).
+    struct Span {
+        uint32_t node, end, depth;
+    };
+    std::vector<Span> todo;
+    todo.push_back({0u, n_nodes, 1u});
+    uint32_t max_depth = 0;
+    bool nested = true;  // every child box inside its parent's, every primitive's bound inside its leaf box
+    auto inside = [&](const float* in, const float* out) {
+        return in[0] >= out[0] && in[1] >= out[1] && in[2] >= out[2] && in[3] <= out[3] && in[4] <= out[4] && in[5] <= out[5];
+    };
+    while (!todo.empty()) {
+        const Span sp = todo.back();
+        todo.pop_back();
+        const uint32_t i = sp.node;
+        max_depth = std::max(max_depth, sp.depth);
+        if ((flags[i] & 3u) == 3u) {
+            if (sp.end != i + 1) return fail(s->ctx, TRHIP_ERR_INVALID, "leaf %u is followed by nodes that belong to no subtree (not a depth-first layout)", i);
+            const uint32_t cnt = flags[i] >> 2;
+            if ((uint64_t)a[i] + cnt > n_prims) return fail(s->ctx, TRHIP_ERR_INVALID, "leaf %u references primitives outside the list", i);
+            for (uint32_t k = a[i]; k < a[i] + cnt && nested; ++k) {
+                const HostPrim& p = s->prims[order[k]];
+                HostAABB pb;
+                if (p.kind == 1) {
+                    pb = s->sphere_bounds[p.sphere_id];
+                } else {
+                    pb.reset();
+                    for (int j = 0; j < 3; ++j) pb.grow_point(&p.v[3 * j]);
+                }
+                const float pbox[6] = {pb.mn[0], pb.mn[1], pb.mn[2], pb.mx[0], pb.mx[1], pb.mx[2]};
+                nested = inside(pbox, &bounds[6 * (size_t)i]);
+            }
+            continue;
+        }
+        if (a[i] <= i + 1 || a[i] >= sp.end)
+            return fail(s->ctx, TRHIP_ERR_INVALID, "interior node %u: second child %u outside (%u, %u) — not the depth-first layout of bvh.jl:187-206", i, a[i], i + 1, sp.end);
+        if ((flags[i] & 3u) > 2u) return fail(s->ctx, TRHIP_ERR_INVALID, "interior node %u: split axis %u", i, flags[i] & 3u);
+        nested = nested && inside(&bounds[6 * (size_t)(i + 1)], &bounds[6 * (size_t)i]) && inside(&bounds[6 * (size_t)a[i]], &bounds[6 * (size_t)i]);
+        todo.push_back({a[i], sp.end, sp.depth + 1});
+        todo.push_back({i + 1, a[i], sp.depth + 1});
+    }
+    if (max_depth > (uint32_t)(kStackLds + kStackSpill))
+        return fail(s->ctx, TRHIP_ERR_UNSUPPORTED, "BVH depth %u exceeds the 64-entry traversal stack (bvh.jl:222 throws a BoundsError there)", max_depth);
+    s->bvh.bounds.assign(bounds, bounds + 6 * (size_t)n_nodes);
+    s->bvh.a.assign(a, a + n_nodes);
+    s->bvh.flags.assign(flags, flags + n_nodes);
+    s->bvh.order.assign(order, order + n_prims);
+    s->bvh.max_depth = max_depth;
+    // The default kernels' shortcuts (tight slab clauses, largest-triangle pre-pass, wide nodes: th_trace2.h, th_trace8.h) are exact
+    // only when boxes nest; a foreign tree that does not is walked by the literal kernels (the reference's loop, op for op).
+    s->literal_only = !nested;
+    HIP_TRY(s->ctx, hipSetDevice(s->ctx->device));
+    return upload_scene(s);
+}
+
+}  // extern "C"

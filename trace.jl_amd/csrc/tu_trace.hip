@@ -1,0 +1,255 @@
+// tu_trace.hip — which traversal kernel walks a queue (launch_trace) and the kernel-level trace entry points.  The k_trace3 / k_trace4 / k_trace8
+// families are instantiated in tu_trace3.hip / tu_trace8.hip.
+#include "th_host.h"
+
+#ifndef TH_TRACE_BLOCKS_PER_CU
+#define TH_TRACE_BLOCKS_PER_CU 6
+#endif
+int trace_grid(const trhip_ctx* ctx) { return ctx->num_cu * TH_TRACE_BLOCKS_PER_CU; }  // persistent blocks per CU (LDS stack: kStack2Lds x 256 x 8 B each)
+
+// k_trace2 keeps stack levels 16..63 of every resident thread in a global slab laid out [level][thread].
+int ensure_overflow(trhip_ctx* ctx) {
+    const size_t threads = (size_t)trace_grid(ctx) * kBlock;
+    return ensure(ctx, ctx->overflow, threads * (size_t)kStackSlabLevels * sizeof(uint2));
+}
+
+// the scene's children-in-parent view with the context's slab margin (option "slab_margin_log2")
+WideScene wide_view(const trhip_ctx* ctx, const trhip_scene* sc) {
+    WideScene w = sc->wide;
+    w.tight_scale = ctx->slab_margin_log2 > 0 ? std::ldexp(1.0f, -ctx->slab_margin_log2) : 0.0f;
+    return w;
+}
+
+// which kernel launch_trace picks for this scene, and the bytes one unit of the visit counters stands for (trhip_stats)
+void traversal_info(const trhip_ctx* ctx, const trhip_scene* sc, uint32_t* trav, uint32_t* node_bytes) {
+    uint32_t t = 1, nb = 32;
+    if (ctx->traversal >= 2 && sc->wide_ok) {
+        if (sc->wide.root_cnt > 0 && ctx->leaf_kernel && ctx->debug_trace_budget == 0) {
+            t = 5;
+            nb = 0;
+        } else if (sc->wide.root_cnt > 0) {
+            t = 2;
+        } else if (ctx->traversal == 4 && sc->w8_ok) {
+            t = 4;
+            nb = 96;
+        } else if (ctx->traversal == 6) {
+            t = 6;
+        } else {
+            t = ctx->traversal >= 3 ? 3 : 2;
+        }
+    }
+    *trav = t;
+    *node_bytes = nb;
+}
+
+// One traversal launch over a queue (count in HBM at count_ptr, or n_max when count_ptr is null).
+// ctx->traversal == 1: the literal accel/bvh.jl loop (k_trace_closest / k_trace_any); 2: k_trace2 (same results).
+void launch_trace(trhip_ctx* ctx, hipStream_t st, const trhip_scene* sc, bool any, SegQueue q, const float4* ro, const float4* rd, const float* tmax, TraceOut out, uint32_t* work_cursors,
+                  Counters* ctr, void* overflow_slab) {
+    const dim3 grid(trace_grid(ctx)), block(kBlock);
+    const bool v2 = ctx->traversal >= 2 && sc->wide_ok;
+    const bool cnt = ctx->count_visits;
+    const bool full_only = !sc->partial_spheres;  // no clipped sphere in the scene: kernels without the Float64 atan2 path
+    if (v2 && ctx->traversal >= 3 && sc->wide.root_cnt == 0) {  // k_trace8 / k_trace3; a single-leaf scene has nothing to postpone and runs k_trace_leaf / k_trace2
+        uint2* ov = (uint2*)(overflow_slab ? overflow_slab : ctx->overflow.p);
+        if (any && sc->n_occluders && ctx->occluder_pretest && ctx->pipelines <= 1 && !q.indirect) {
+            // the largest triangles first (k_any_occluders); what they do not stop goes through per-segment survivor lists
+            // a survivor list takes the rays of every kSeg-th 64-ray chunk of the padded work space (k_any_occluders): at most (sum of the segment
+            // counts + kSeg * (kSegGran - 1)) / kSeg + 64 <= the queue's per-segment capacity + 319 entries, whatever the caller's slack
+            const uint32_t scap = (q.counts ? q.cap : q.n_dense) + 1024u;
+            const size_t entries = (size_t)scap * (q.counts ? kSeg : 1);
+            if (ensure(ctx, ctx->surv_list, entries * sizeof(uint32_t)) == 0 && ensure(ctx, ctx->surv_counts, (size_t)kSeg * kCtrStride * sizeof(uint32_t)) == 0) {
+                uint32_t* sl = (uint32_t*)ctx->surv_list.p;
+                uint32_t* scn = (uint32_t*)ctx->surv_counts.p;
+                (void)hipMemsetAsync(scn, 0, (size_t)kSeg * kCtrStride * sizeof(uint32_t), st);
+                const OccluderSet oc{(const uint32_t*)sc->d_occ_slots.p, (const float*)sc->d_occ_boxes.p, sc->n_occluders};
+                const dim3 pgrid(ctx->num_cu * 8);
+                if (cnt)
+                    hipLaunchKernelGGL((k_any_occluders<true>), pgrid, block, 0, st, sc->dev, oc, q, ro, rd, tmax, out, sl, scn, scap, ctr);
+                else
+                    hipLaunchKernelGGL((k_any_occluders<false>), pgrid, block, 0, st, sc->dev, oc, q, ro, rd, tmax, out, sl, scn, scap, ctr);
+                q = SegQueue{scn, scap, 0u, sl, 1u};
+            }
+        }
+        // ---- traversal 4: 8-wide nodes (th_trace8.h); the rays it does not take come back on a fallback list that k_trace3 walks below ----
+        if (ctx->traversal == 4 && sc->w8_ok && ctx->slab_margin_log2 > 0 && ctx->pipelines <= 1) {
+            const int w = any ? 1 : 0;
+            const uint32_t fcap = q.counts ? q.cap : q.n_dense;
+            const size_t entries = (size_t)fcap * (q.counts ? kSeg : 1);
+            const size_t ctr_words = 2 * (size_t)kSeg * kCtrStride;  // counts, then the work cursors of the fallback launch
+            const size_t ov8_bytes = (size_t)trace_grid(ctx) * kBlock * (size_t)kStack8Global * 3 * sizeof(uint32_t);
+            if (ensure(ctx, ctx->fb_list[w], entries * sizeof(uint32_t)) == 0 && ensure(ctx, ctx->fb_counts[w], ctr_words * sizeof(uint32_t)) == 0 && ensure(ctx, ctx->ov8[w], ov8_bytes) == 0) {
+                uint32_t* fcounts = (uint32_t*)ctx->fb_counts[w].p;
+                (void)hipMemsetAsync(fcounts, 0, ctr_words * sizeof(uint32_t), st);
+                Wide8Scene w8 = sc->w8;
+                w8.tight_scale = std::ldexp(1.0f, -ctx->slab_margin_log2);
+                const FallbackList fb{(uint32_t*)ctx->fb_list[w].p, fcounts, fcap};
+                uint32_t* ov8 = (uint32_t*)ctx->ov8[w].p;
+                launch_trace8(ctx, st, sc, any, cnt, full_only, w8, q, ro, rd, tmax, out, work_cursors, ov8, ctr, fb);
+                q = SegQueue{fcounts, fcap, 0u, fb.list, 1u};
+                work_cursors = fcounts + (size_t)kSeg * kCtrStride;
+            }
+        }
+        if (ctx->traversal == 6) {  // two rays per lane (th_trace4.h)
+            launch_trace4(ctx, st, sc, any, cnt, full_only, q, ro, rd, tmax, out, work_cursors, ov, ctr);
+            return;
+        }
+        // scenes larger than the last-level cache (256 MB of MALL): one wave per SIMD fewer (k_trace3's BIG variant)
+        const bool big = !any && !cnt && (size_t)sc->wide.n_wnodes * 64u + (size_t)sc->dev.n_prims * 48u > ((size_t)256 << 20);
+        launch_trace3(ctx, st, sc, any, cnt, full_only, big, q, ro, rd, tmax, out, work_cursors, ov, ctr);
+        return;
+    }
+    if (v2) {
+        if (sc->wide.root_cnt > 0 && ctx->debug_trace_budget == 0 && ctx->leaf_kernel) {  // one-leaf scene: the dedicated kernel (th_trace2.h, k_trace_leaf)
+            const dim3 lgrid(ctx->num_cu * 8);
+            if (any) {
+                if (cnt)
+                    { if (full_only) hipLaunchKernelGGL((k_any_leaf<true, true>), lgrid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, ctr); else hipLaunchKernelGGL((k_any_leaf<true, false>), lgrid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, ctr); }
+                else
+                    { if (full_only) hipLaunchKernelGGL((k_any_leaf<false, true>), lgrid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, ctr); else hipLaunchKernelGGL((k_any_leaf<false, false>), lgrid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, ctr); }
+            } else {
+                if (cnt)
+                    { if (full_only) hipLaunchKernelGGL((k_trace_leaf<false, true, true>), lgrid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, ctr); else hipLaunchKernelGGL((k_trace_leaf<false, true, false>), lgrid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, ctr); }
+                else
+                    { if (full_only) hipLaunchKernelGGL((k_trace_leaf<false, false, true>), lgrid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, ctr); else hipLaunchKernelGGL((k_trace_leaf<false, false, false>), lgrid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, ctr); }
+            }
+            return;
+        }
+        uint2* ov = (uint2*)(overflow_slab ? overflow_slab : ctx->overflow.p);
+        if (any) {
+            if (cnt)
+                hipLaunchKernelGGL((k_trace2<true, true>), grid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, work_cursors, ov, ctr, ctx->debug_trace_budget);
+            else
+                hipLaunchKernelGGL((k_trace2<true, false>), grid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, work_cursors, ov, ctr, ctx->debug_trace_budget);
+        } else {
+            if (cnt)
+                hipLaunchKernelGGL((k_trace2<false, true>), grid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, work_cursors, ov, ctr, ctx->debug_trace_budget);
+            else
+                hipLaunchKernelGGL((k_trace2<false, false>), grid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, work_cursors, ov, ctr, ctx->debug_trace_budget);
+        }
+        return;
+    }
+    if (any) {
+        if (cnt)
+            hipLaunchKernelGGL(k_trace_any<true>, grid, block, 0, st, sc->dev, q, ro, rd, out.contrib, tmax, out.L, out.occluded, ctr);
+        else
+            hipLaunchKernelGGL(k_trace_any<false>, grid, block, 0, st, sc->dev, q, ro, rd, out.contrib, tmax, out.L, out.occluded, ctr);
+    } else {
+        if (cnt)
+            hipLaunchKernelGGL(k_trace_closest<true>, grid, block, 0, st, sc->dev, q, ro, rd, tmax, out.hits, ctr);
+        else
+            hipLaunchKernelGGL(k_trace_closest<false>, grid, block, 0, st, sc->dev, q, ro, rd, tmax, out.hits, ctr);
+    }
+}
+
+// the streaming wavefront's rounds (tu_path.hip, render_stream_impl): k_trace2 with the suspend / resume logic
+void launch_trace2_stream(trhip_ctx* ctx, hipStream_t st, const trhip_scene* sc, bool any, SegQueue q, const float4* ro, const float4* rd, TraceOut out, uint32_t* work_cursors, void* overflow_slab,
+                          Counters* ctr, const StreamCtl& sx) {
+    const dim3 grid(trace_grid(ctx)), block(kBlock);
+    const bool cnt = ctx->count_visits;
+    uint2* ov = (uint2*)overflow_slab;
+    if (any) {
+        if (cnt)
+            hipLaunchKernelGGL((k_trace2<true, true, true>), grid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, nullptr, out, work_cursors, ov, ctr, 0u, sx);
+        else
+            hipLaunchKernelGGL((k_trace2<true, false, true>), grid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, nullptr, out, work_cursors, ov, ctr, 0u, sx);
+    } else {
+        if (cnt)
+            hipLaunchKernelGGL((k_trace2<false, true, true>), grid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, nullptr, out, work_cursors, ov, ctr, 0u, sx);
+        else
+            hipLaunchKernelGGL((k_trace2<false, false, true>), grid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, nullptr, out, work_cursors, ov, ctr, 0u, sx);
+    }
+}
+
+extern "C" {
+
+// Shared body of the four kernel-level trace entry points: stage rays (host or device, n*8 floats) into SoA, run the
+// traversal `repeat` times, time it with HIP events on the library's stream.
+static int api_trace(trhip_ctx* ctx, const trhip_scene* sc, bool any, const void* rays, bool rays_on_device, uint64_t n, void* d_out, int repeat, double* avg_ms) {
+    if (!sc->committed) return fail(ctx, TRHIP_ERR_INVALID, "scene not committed");
+    if (n >= (1ull << 31)) return fail(ctx, TRHIP_ERR_INVALID, "too many rays in one call");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const float* d_rays = (const float*)rays;
+    if (!rays_on_device) {
+        if (int rc = upload(ctx, ctx->scratch[3], rays, n * 8 * sizeof(float))) return rc;
+        d_rays = (const float*)ctx->scratch[3].p;
+    }
+    for (int j = 0; j < 2; ++j)
+        if (int rc = ensure(ctx, ctx->scratch[j], n * sizeof(float4))) return rc;
+    if (int rc = ensure(ctx, ctx->scratch[2], n * sizeof(float))) return rc;
+    if (int rc = ensure(ctx, ctx->counters, sizeof(Counters))) return rc;
+    if (int rc = ensure_overflow(ctx)) return rc;
+    if (n) hipLaunchKernelGGL(k_prepare_rays, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_rays, (uint32_t)n, (float4*)ctx->scratch[0].p, (float4*)ctx->scratch[1].p,
+                              (float*)ctx->scratch[2].p);
+    Counters* ctr = (Counters*)ctx->counters.p;
+    HIP_TRY(ctx, hipMemsetAsync(ctr, 0, sizeof(Counters), ctx->stream));
+    hipEvent_t e0, e1;
+    HIP_TRY(ctx, hipEventCreate(&e0));
+    HIP_TRY(ctx, hipEventCreate(&e1));
+    repeat = std::max(1, std::min(repeat, kMaxDepth + 1));
+    TraceOut out{any ? nullptr : (float4*)d_out, nullptr, nullptr, any ? (uint8_t*)d_out : nullptr};
+    HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
+    if (n)
+        for (int r = 0; r < repeat; ++r)  // every repetition uses its own (zeroed) work cursor
+            launch_trace(ctx, ctx->stream, sc, any, SegQueue{nullptr, (uint32_t)n, (uint32_t)n}, (const float4*)ctx->scratch[0].p, (const float4*)ctx->scratch[1].p, (const float*)ctx->scratch[2].p,
+                         out, any ? ctr->work_shadow[r] : ctr->work_closest[r], ctr);
+    HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    if (avg_ms) *avg_ms = ms / repeat;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return 0;
+}
+int trhip_trace_closest(trhip_ctx* ctx, const trhip_scene* sc, const float* rays, uint64_t n, trhip_hit* out) {
+    if (!ctx || !sc || !rays || !out) return fail(ctx, TRHIP_ERR_INVALID, "null argument");
+    static_assert(sizeof(trhip_hit) == sizeof(float4), "trhip_hit layout");
+    if (int rc = ensure(ctx, ctx->hits, n * sizeof(float4))) return rc;
+    if (int rc = api_trace(ctx, sc, false, rays, false, n, ctx->hits.p, 1, nullptr)) return rc;
+    HIP_TRY(ctx, hipMemcpy(out, ctx->hits.p, n * sizeof(float4), hipMemcpyDeviceToHost));
+    return 0;
+}
+int trhip_trace_any(trhip_ctx* ctx, const trhip_scene* sc, const float* rays, uint64_t n, uint8_t* occluded) {
+    if (!ctx || !sc || !rays || !occluded) return fail(ctx, TRHIP_ERR_INVALID, "null argument");
+    if (int rc = ensure(ctx, ctx->hits, n)) return rc;
+    if (int rc = api_trace(ctx, sc, true, rays, false, n, ctx->hits.p, 1, nullptr)) return rc;
+    HIP_TRY(ctx, hipMemcpy(occluded, ctx->hits.p, n, hipMemcpyDeviceToHost));
+    return 0;
+}
+// d_rays: n*8 floats on the device (same layout as the host entry points); d_hits: n trhip_hit / d_occ: n bytes
+int trhip_trace_closest_device(trhip_ctx* ctx, const trhip_scene* sc, const void* d_rays, uint64_t n, void* d_hits, int repeat, double* avg_ms) {
+    if (!ctx || !sc || !d_rays || !d_hits) return fail(ctx, TRHIP_ERR_INVALID, "null argument");
+    return api_trace(ctx, sc, false, d_rays, true, n, d_hits, repeat, avg_ms);
+}
+int trhip_trace_any_device(trhip_ctx* ctx, const trhip_scene* sc, const void* d_rays, uint64_t n, void* d_occ, int repeat, double* avg_ms) {
+    if (!ctx || !sc || !d_rays || !d_occ) return fail(ctx, TRHIP_ERR_INVALID, "null argument");
+    return api_trace(ctx, sc, true, d_rays, true, n, d_occ, repeat, avg_ms);
+}
+// visit counters of the last *_device trace call (when "count_visits" is on): nodes, prims for closest then shadow
+int trhip_last_visit_counts(trhip_ctx* ctx, uint64_t* out4) {
+    if (!ctx || !out4 || !ctx->counters.p) return fail(ctx, TRHIP_ERR_INVALID, "no counters");
+    Counters h;
+    HIP_TRY(ctx, hipMemcpy(&h, ctx->counters.p, sizeof h, hipMemcpyDeviceToHost));
+    out4[0] = h.nodes_closest;
+    out4[1] = h.prims_closest;
+    out4[2] = h.nodes_shadow;
+    out4[3] = h.prims_shadow;
+    return 0;
+}
+
+int trhip_hit_geometry(trhip_ctx* ctx, const trhip_scene* sc, const float* rays, uint64_t n, float* out15) {
+    if (!ctx || !sc || !rays || !out15) return fail(ctx, TRHIP_ERR_INVALID, "null argument");
+    if (int rc = ensure(ctx, ctx->hits, n * sizeof(float4))) return rc;
+    if (int rc = ensure(ctx, ctx->film, n * 15 * sizeof(float))) return rc;
+    if (int rc = api_trace(ctx, sc, false, rays, false, n, ctx->hits.p, 1, nullptr)) return rc;
+    if (n) hipLaunchKernelGGL(k_hit_geometry, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, sc->dev, (const float4*)ctx->scratch[0].p, (const float4*)ctx->scratch[1].p,
+                              (const float4*)ctx->hits.p, (uint32_t)n, (float*)ctx->film.p);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(out15, ctx->film.p, n * 15 * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+}  // extern "C"
