@@ -41,7 +41,7 @@ void trhip_shutdown(trhip_ctx* ctx);
 /* ctx may be NULL to read the message of a failed trhip_init. */
 const char* trhip_last_error(const trhip_ctx* ctx);
 /* ABI version of this header: major*1000 + minor. */
-int trhip_version(void);
+int trhip_version(void);  /* 3000 */
 
 /* ---- scene flattening (replaces the Scene / BVHAccel / GeometricPrimitive object graph) --------------------------- */
 /* Scene(lights, aggregate)  Trace.jl:176-187 */
@@ -127,6 +127,16 @@ typedef struct {
     uint32_t traversal;      /* traversal kernel that ran: 1 literal, 2, 3 binary children-in-parent walk, 4 8-wide nodes, 5 one-leaf scene */
     uint32_t node_bytes;     /* bytes fetched per unit of nodes_visited: 32 (a node box of the binary kernels: 64-byte node = 2 boxes),
                                 96 (one 8-wide node: six 16-byte loads from one 128-byte line), 0 (one-leaf scene: scalar loads) */
+    /* ---- since ABI 3000 ---- */
+    uint64_t replicated_rays; /* of closest_rays + shadow_rays: rays that EVERY rank of a multi-GPU job traces identically (the camera pass of
+                                 trhip_render_sppm, which only shards its photons); a job's ray total counts them once */
+    uint64_t fallback_rays;   /* closest-hit rays the order-free walk (traversal 7) flagged — a second candidate within the tie margin, a box it
+                                 could not decide, an origin inside a sphere — and handed to the reference-order walk (k_trace3) */
+    double ms_sub[4];         /* parts of ms_shade.  trhip_render_sppm: [0] photon gather (k_sppm_gather + k_sppm_gather_hot), [1] camera / photon
+                                 shading, [2] grid bounds + hit binning + scans, [3] pixel update + fold.  Path / Whitted: zeros */
+    uint32_t launches_sub[4];
+    uint64_t count_sub[4];    /* trhip_render_sppm with "count_visits": [0] (pixel, photon) candidates distance-tested by the gather, [1] pairs accepted
+                                 (BSDF evaluated), [2] photon hits binned, [3] visible points; otherwise zeros */
 } trhip_stats;
 
 /* ---- integrators (replace `integrator(scene)`, integrators/sampler.jl:12-56) ---------------------------------------

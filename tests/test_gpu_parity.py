@@ -380,6 +380,30 @@ def test_streaming_wavefront_matches_classic_and_oracle(T, ob, ctx, traversal):
         assert_bits_equal(L, classic_L, f"per-sample radiance, {opts}")
         assert_bits_equal(film, ref, f"film, {opts}")
         assert st.closest_rays == st0.closest_rays and st.shadow_rays == st0.shadow_rays, opts
+    # streaming + the two-stream mode on a FRESH context (no classic frame has sized the poison notes of the two-stream classic path: the
+    # streaming path must not read them), and again after a classic two-stream frame left stale notes behind
+    fresh = T.Context(0)
+    try:
+        fresh.set_option("traversal", traversal)
+        scene.flatten(fresh)
+        for pre_classic in (False, True):
+            if pre_classic:
+                fresh.set_option("overlap", 1)
+                T.PathIntegrator(T.scenes.cornell_camera(40), T.SeededSampler(2, seed=5), 3).render(scene, fresh)
+            for opts in ({"streaming": 1, "overlap": 1}, {"streaming": 1, "overlap": 1, "stream_budget_min": 2}):
+                for k, v in opts.items():
+                    fresh.set_option(k, v)
+                integ = T.PathIntegrator(cam, T.SeededSampler(4, seed=21), 6)
+                film = integ.render(scene, fresh).copy()
+                assert_bits_equal(integ.sample_radiance(scene), classic_L, f"per-sample radiance, fresh context, {opts}")
+                assert_bits_equal(film, ref, f"film, fresh context, {opts}")
+                fresh.set_option("streaming", 0)
+                fresh.set_option("stream_budget_min", 2048)
+    finally:
+        if scene._flat is not None and scene._flat.ctx is fresh:  # the scene's device copy on the context about to go
+            scene._flat.free()
+            scene._flat = None
+        fresh.close()
 
 
 def test_render_closed_mesh_scene(T, ob, ctx):

@@ -60,6 +60,11 @@ class Stats(C.Structure):
         ("max_depth_reached", C.c_uint32),
         ("traversal", C.c_uint32),
         ("node_bytes", C.c_uint32),
+        ("replicated_rays", C.c_uint64),
+        ("fallback_rays", C.c_uint64),
+        ("ms_sub", C.c_double * 4),
+        ("launches_sub", C.c_uint32 * 4),
+        ("count_sub", C.c_uint64 * 4),
     ]
 
     def as_dict(self):

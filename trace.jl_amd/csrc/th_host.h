@@ -83,7 +83,7 @@ struct trhip_ctx {
     uint64_t last_L_count = 0;  // float4 entries valid in Lbuf
     // SPPM state (th_sppm.h): per film pixel, kept after trhip_render_sppm for trhip_sppm_state
     DevBuf sp_vp[7], sp_Ld, sp_tau, sp_radius, sp_N, sp_phi, sp_M, sp_counts, sp_starts, sp_entries, sp_grid, sp_ldist, sp_snap_M, sp_snap_phi, sp_snap_p, sp_snap_beta;
-    DevBuf sp_terms, sp_rec[3], sp_rec_valid;
+    DevBuf sp_terms, sp_rec[3], sp_rec_valid, sp_raysnap;  // sp_raysnap: {closest_total, shadow_total} after every batch's camera pass and photon pass
     // streaming wavefront (render_stream_impl)
     DevBuf st_terms, st_tags[2], st_frozen, st_counts, st_list[2][2][7];  // [closest|any][ping-pong][o, d, b, trav, st, depth, stack]
     int streaming = 0;             // PathIntegrator on scenes with a real hierarchy: suspend / resume stragglers.  1 = always, 0 = never (classic
@@ -185,7 +185,7 @@ inline int grid_for(const trhip_ctx* ctx, uint64_t n, int blocks_per_cu) {
 struct Timer {
     trhip_ctx* ctx;
     bool on;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[5];
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[8];  // 0 raygen, 1 closest, 2 shade, 3 any, 4 film; 5-7: sub-classes of an integrator (tu_sppm.hip)
     explicit Timer(trhip_ctx* c, bool enable) : ctx(c), on(enable) {}
     ~Timer() {
         for (auto& v : ev)

@@ -6,7 +6,7 @@ thread_local std::string g_init_error;
 
 extern "C" {
 
-int trhip_version(void) { return 2000; }
+int trhip_version(void) { return 3000; }
 
 int trhip_init(trhip_ctx** out, int device_id) {
     if (!out) return fail(nullptr, TRHIP_ERR_INVALID, "ctx out pointer is null");
@@ -87,7 +87,7 @@ void trhip_shutdown(trhip_ctx* ctx) {
             for (auto& c : b) release(c);
     for (DevBuf* b : {&ctx->sp_Ld, &ctx->sp_tau, &ctx->sp_radius, &ctx->sp_N, &ctx->sp_phi, &ctx->sp_M, &ctx->sp_counts, &ctx->sp_starts, &ctx->sp_entries, &ctx->sp_grid, &ctx->sp_ldist,
                       &ctx->sp_snap_M, &ctx->sp_snap_phi, &ctx->sp_snap_p, &ctx->sp_snap_beta, &ctx->sp_terms, &ctx->sp_rec[0], &ctx->sp_rec[1], &ctx->sp_rec[2],
-                      &ctx->sp_rec_valid})
+                      &ctx->sp_rec_valid, &ctx->sp_raysnap})
         release(*b);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
@@ -138,10 +138,10 @@ int trhip_comm_rank(const trhip_ctx* ctx, int* rank, int* n_ranks) {
 }
 static int film_collective(trhip_ctx* ctx, void* d_xyzw, uint64_t n_pixels, int root, bool all) {
     if (!ctx || !d_xyzw) return fail(ctx, TRHIP_ERR_INVALID, "null argument");
-    if (!ctx->comm.comm) {
-        if (ctx->comm.n_ranks == 1) return 0;  // a single-process job: the film already is the sum
-        return fail(ctx, TRHIP_ERR_INVALID, "no communicator: call trhip_comm_init first");
-    }
+    // Without a communicator the context is a single-process job and its film already is the sum: a no-op, by design (hosts call the
+    // reduce unconditionally).  A host that runs SEVERAL processes must check trhip_comm_rank's n_ranks against its own world size before it
+    // trusts the film — parallel.Job.reduce_film and bench.py do; the library cannot know about processes that never called trhip_comm_init.
+    if (!ctx->comm.comm) return 0;
     if (!all && (root < 0 || root >= ctx->comm.n_ranks)) return fail(ctx, TRHIP_ERR_INVALID, "root %d of %d ranks", root, ctx->comm.n_ranks);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     RcclApi* api = rccl_api();

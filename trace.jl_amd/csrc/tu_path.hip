@@ -244,7 +244,8 @@ int render_stream_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sen
     HIP_TRY(ctx, hipEventRecord(pp.ev_done, ps));
     HIP_TRY(ctx, hipStreamWaitEvent(st, pp.ev_done, 0));
     tm.begin(4, st);
-    if (ctx->overlap) hipLaunchKernelGGL(k_apply_poison, dim3(grid_for(ctx, total_slots, 8)), dim3(kBlock), 0, st, L, (const uint8_t*)ctx->poison.p, total_slots);
+    // (no k_apply_poison here: the streaming shade kernel writes its terms — NaN included — straight into the per-depth slots and never notes
+    //  poison; ctx->poison belongs to the classic path's two-stream mode alone)
     launch_film(ctx, st, ds, dsp, L, total_slots, spp, seed, sample_offset, (float4*)d_film);
     tm.end(4, st);
     HIP_TRY(ctx, hipEventRecord(e1, st));

@@ -162,6 +162,10 @@ int render_sppm_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
     const uint64_t n_ranks = ctx->comm.comm ? (uint64_t)ctx->comm.n_ranks : 1u, my_rank = ctx->comm.comm ? (uint64_t)ctx->comm.rank : 0u;
     const uint32_t p_lo = (uint32_t)((uint64_t)P * my_rank / n_ranks), p_hi = (uint32_t)((uint64_t)P * (my_rank + 1) / n_ranks);
     uint32_t n_batches = 0;
+    // ray totals after every batch's camera pass and photon pass: what of closest_rays + shadow_rays every rank of a multi-GPU job repeats
+    const uint32_t max_batches = (uint32_t)((n_iterations + B - 1) / B);
+    if (int rc = ensure(ctx, ctx->sp_raysnap, (size_t)max_batches * 4 * sizeof(unsigned long long))) return rc;
+    unsigned long long* raysnap = (unsigned long long*)ctx->sp_raysnap.p;
     for (uint32_t it0 = 1; it0 <= n_iterations; it0 += (uint32_t)B) {
         const uint32_t nb = (uint32_t)std::min<uint64_t>(B, n_iterations - it0 + 1);
         n_batches++;
@@ -187,9 +191,10 @@ int render_sppm_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
             tm.end(3, st);
             cur ^= 1;
         }
-        tm.begin(2, st);
+        tm.begin(7, st);
         hipLaunchKernelGGL(k_sppm_fold_ld, g_pix, blk, 0, st, n, nb, (uint32_t)max_depth, (const float4*)terms, px.Ld);
-        tm.end(2, st);
+        tm.end(7, st);
+        HIP_TRY(ctx, hipMemcpyAsync(raysnap + 4 * (size_t)(n_batches - 1), &ctr->closest_total, 2 * sizeof(unsigned long long), hipMemcpyDeviceToDevice, st));
         // ---- photon paths of the same iterations (:320-365, 393-418): Halton indices (it0 - 1) * P .. (it0 - 1 + nb) * P - 1 ----
         const uint32_t NP = nb * (uint32_t)P;
         if (n_lights) {
@@ -211,10 +216,11 @@ int render_sppm_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
                 cur ^= 1;
             }
         }
+        HIP_TRY(ctx, hipMemcpyAsync(raysnap + 4 * (size_t)(n_batches - 1) + 2, &ctr->closest_total, 2 * sizeof(unsigned long long), hipMemcpyDeviceToDevice, st));
         // ---- per iteration, in order: grid (:272-318), photon contributions (:366-391), _update_pixels! (:438-459) ----
         for (uint32_t j = 0; j < nb; ++j) {
             const VisiblePoints vp = vp_slice(j);
-            tm.begin(2, st);
+            tm.begin(6, st);
             // (the bucket counters are zero here: k_sppm_hit_bin's fill pass counts every bucket back down to 0)
             hipLaunchKernelGGL(k_sppm_grid_reset, dim3(1), blk, 0, st, grid);
             hipLaunchKernelGGL(k_sppm_grid_bounds, dim3(ctx->num_cu), blk, 0, st, vp, (const float*)px.radius, n, grid);  // few waves: 7 same-address atomics each
@@ -229,9 +235,11 @@ int render_sppm_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
             if (n_lights)
                 hipLaunchKernelGGL(k_sppm_hit_bin, g_rec, blk, 0, st, (const float4*)rec.p, (const uint8_t*)rec.valid, NP, j * (uint32_t)P, (uint32_t)P, (uint32_t)(max_depth - 1), n, grid, counts,
                                    (const uint32_t*)starts, entries, 1);
+            tm.end(6, st);
+            tm.begin(5, st);
             hipLaunchKernelGGL(k_sppm_gather, g_pix, blk, 0, st, scene->dev, rec, vp, px, n, grid, (const uint32_t*)starts, (const float4*)entries, n, hot_list, it0 + j == n_iterations ? 1u : 0u);
             hipLaunchKernelGGL(k_sppm_gather_hot, g_shade, blk, 0, st, scene->dev, rec, vp, px, grid, (const uint32_t*)starts, (const float4*)entries, n, (const uint32_t*)hot_list);
-            tm.end(2, st);
+            tm.end(5, st);
             if (ctx->comm.comm && ctx->comm.n_ranks > 1) {
                 // the one exchange of an iteration: every rank traced its slice of the photons, ϕ and M are the sums over all of
                 // them (the reference adds them with Threads.Atomic, sppm.jl:398-399) — then _update_pixels! runs identically everywhere
@@ -247,9 +255,9 @@ int render_sppm_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
                 HIP_TRY(ctx, hipMemcpyAsync(ctx->sp_snap_p.p, vp.p_mat, (size_t)n * sizeof(float4), hipMemcpyDeviceToDevice, st));
                 HIP_TRY(ctx, hipMemcpyAsync(ctx->sp_snap_beta.p, vp.beta, (size_t)n * sizeof(float4), hipMemcpyDeviceToDevice, st));
             }
-            tm.begin(2, st);
+            tm.begin(7, st);
             hipLaunchKernelGGL(k_sppm_update, g_pix, blk, 0, st, n, gamma, px, vp);
-            tm.end(2, st);
+            tm.end(7, st);
         }
     }
     tm.begin(4, st);
@@ -277,12 +285,26 @@ int render_sppm_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
         stats->ms_total = ms;
         stats->ms_raygen = tm.total(0, &stats->launches_raygen);
         stats->ms_trace_closest = tm.total(1, &stats->launches_trace_closest);
-        stats->ms_shade = tm.total(2, &stats->launches_shade);
+        stats->ms_sub[0] = tm.total(5, &stats->launches_sub[0]);  // photon gather
+        stats->ms_sub[1] = tm.total(2, &stats->launches_sub[1]);  // camera / photon shading
+        stats->ms_sub[2] = tm.total(6, &stats->launches_sub[2]);  // grid bounds, hit binning, scans
+        stats->ms_sub[3] = tm.total(7, &stats->launches_sub[3]);  // Ld fold, pixel update
+        stats->ms_shade = stats->ms_sub[0] + stats->ms_sub[1] + stats->ms_sub[2] + stats->ms_sub[3];
+        stats->launches_shade = stats->launches_sub[0] + stats->launches_sub[1] + stats->launches_sub[2] + stats->launches_sub[3];
         stats->ms_trace_any = tm.total(3, &stats->launches_trace_any);
         stats->ms_film = tm.total(4, &stats->launches_film);
         stats->n_batches = n_batches;
         stats->max_depth_reached = (uint32_t)max_depth;
         traversal_info(ctx, scene, &stats->traversal, &stats->node_bytes);
+        // the camera pass (closest-hit + shadow rays) is traced by every rank of a job; only the photons are sharded
+        std::vector<unsigned long long> snap((size_t)n_batches * 4);
+        HIP_TRY(ctx, hipMemcpy(snap.data(), raysnap, snap.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        unsigned long long prev_c = 0, prev_s = 0;
+        for (uint32_t b = 0; b < n_batches; ++b) {
+            stats->replicated_rays += (snap[4 * b] - prev_c) + (snap[4 * b + 1] - prev_s);
+            prev_c = snap[4 * b + 2];
+            prev_s = snap[4 * b + 3];
+        }
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);

@@ -20,6 +20,10 @@ WideScene wide_view(const trhip_ctx* ctx, const trhip_scene* sc) {
     return w;
 }
 
+// k_trace8 takes the launch (traversal 4) only with the tight slab clauses on and a single pipeline; otherwise k_trace3 walks the 32-byte boxes.
+// One place for the rule: launch_trace and the byte model of trhip_stats (traversal_info) must agree.
+static bool uses_trace8(const trhip_ctx* ctx, const trhip_scene* sc) { return ctx->traversal == 4 && sc->w8_ok && ctx->slab_margin_log2 > 0 && ctx->pipelines <= 1; }
+
 // which kernel launch_trace picks for this scene, and the bytes one unit of the visit counters stands for (trhip_stats)
 void traversal_info(const trhip_ctx* ctx, const trhip_scene* sc, uint32_t* trav, uint32_t* node_bytes) {
     uint32_t t = 1, nb = 32;
@@ -29,7 +33,7 @@ void traversal_info(const trhip_ctx* ctx, const trhip_scene* sc, uint32_t* trav,
             nb = 0;
         } else if (sc->wide.root_cnt > 0) {
             t = 2;
-        } else if (ctx->traversal == 4 && sc->w8_ok) {
+        } else if (uses_trace8(ctx, sc)) {
             t = 4;
             nb = 96;
         } else if (ctx->traversal == 6) {
@@ -72,7 +76,7 @@ void launch_trace(trhip_ctx* ctx, hipStream_t st, const trhip_scene* sc, bool an
             }
         }
         // ---- traversal 4: 8-wide nodes (th_trace8.h); the rays it does not take come back on a fallback list that k_trace3 walks below ----
-        if (ctx->traversal == 4 && sc->w8_ok && ctx->slab_margin_log2 > 0 && ctx->pipelines <= 1) {
+        if (uses_trace8(ctx, sc)) {
             const int w = any ? 1 : 0;
             const uint32_t fcap = q.counts ? q.cap : q.n_dense;
             const size_t entries = (size_t)fcap * (q.counts ? kSeg : 1);

@@ -49,7 +49,12 @@ mutable struct TrhipStats
     max_depth_reached::UInt32
     traversal::UInt32
     node_bytes::UInt32
-    TrhipStats() = new(0, 0, 0, 0, 0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, (0, 0, 0, 0, 0), 0, 0, 0, 0)
+    replicated_rays::UInt64
+    fallback_rays::UInt64
+    ms_sub::NTuple{4,Float64}
+    launches_sub::NTuple{4,UInt32}
+    count_sub::NTuple{4,UInt64}
+    TrhipStats() = new(0, 0, 0, 0, 0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, (0, 0, 0, 0, 0), 0, 0, 0, 0, 0, 0, (0.0, 0.0, 0.0, 0.0), (0, 0, 0, 0), (0, 0, 0, 0))
 end
 
 struct TraceHIPError <: Exception
@@ -203,22 +208,36 @@ end
 # others read it: trhip_comm_init.  Then every rank renders its share of the samples (`sample_offset`) and trhip_film_reduce sums
 # the film accumulators onto rank 0, which alone writes the image; SPPM shards its photons inside trhip_render_sppm.
 const JOB = Ref{Tuple{Int,Int}}((0, 1))
+const JOB_ID_PATH = Ref{String}("")
+# what tells this job's id file from an earlier job's at the same path (an id of another job makes ncclCommInitRank hang)
+job_nonce() = get(ENV, "TRACEHIP_JOB_ID", haskey(ENV, "MASTER_PORT") ? string(get(ENV, "TORCHELASTIC_RUN_ID", "run"), "-", ENV["MASTER_PORT"]) : string("ppid", ccall(:getppid, Cint, ())))
 function init_job!(; rank = parse(Int, get(ENV, "RANK", "0")), world = parse(Int, get(ENV, "WORLD_SIZE", "1")), id_file = get(ENV, "TRACEHIP_ID_FILE", ""))
     world <= 1 && return JOB[]
     isempty(id_file) && error("TraceHIP: set TRACEHIP_ID_FILE to a path all ranks can reach")
+    path = string(id_file, ".", job_nonce())
     id = Vector{UInt8}(undef, 128)
     if rank == 0
+        isfile(path) && rm(path)                      # a stale file of a crashed job with the same nonce
         check(ccall((:trhip_comm_unique_id, LIB), Cint, (Ptr{UInt8},), id))
-        write(id_file * ".tmp", id)
-        mv(id_file * ".tmp", id_file; force = true)
+        tmp = string(path, ".tmp", getpid())
+        write(tmp, id)
+        mv(tmp, path; force = true)
+        JOB_ID_PATH[] = path
     else
-        while !isfile(id_file)
+        while !(isfile(path) && filesize(path) == 128)
             sleep(0.05)
         end
-        id = read(id_file)
+        id = read(path)
     end
     check(ccall((:trhip_comm_init, LIB), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Cint, Cint), context(), id, rank, world))
     JOB[] = (rank, world)
+end
+# end of the job: the communicator goes, rank 0 removes the id file (every rank has read it: trhip_comm_init returned everywhere)
+function close_job!()
+    JOB[][2] > 1 && ccall((:trhip_comm_destroy, LIB), Cint, (Ptr{Cvoid},), context())
+    isempty(JOB_ID_PATH[]) || rm(JOB_ID_PATH[]; force = true)
+    JOB_ID_PATH[] = ""
+    JOB[] = (0, 1)
 end
 # the `spp` samples of one frame split over the ranks: (spp of this rank, first global sample index)
 function shard_samples(spp::Integer)
@@ -255,7 +274,11 @@ function render!(entry::Symbol, i, scene::Trace.Scene)
             (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{TrhipSensor}, UInt32, Cint, UInt64, UInt32, Ptr{Cvoid}, Ptr{TrhipStats}),
             context(), s, sn, max(spp, 1), i.max_depth, seed, offset + first, d_film[], Ref(stats))
         rc == 0 && spp == 0 && ccall((:hipMemset, "libamdhip64"), Cint, (Ptr{Cvoid}, Cint, Csize_t), d_film[], 0, sizeof(out))
-        rc == 0 && (rc = ccall((:trhip_film_reduce, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, UInt64, Cint), context(), d_film[], h * w, 0))
+        # a rank whose render failed still ENTERS the collective (the others would block in it for ever) — with a film of NaNs (0xff bytes), so
+        # that the sum on rank 0 is NaN everywhere and rank 0 fails too instead of writing an image that misses this rank's samples
+        rc == 0 || ccall((:hipMemset, "libamdhip64"), Cint, (Ptr{Cvoid}, Cint, Csize_t), d_film[], 0xff, sizeof(out))
+        rc_red = ccall((:trhip_film_reduce, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, UInt64, Cint), context(), d_film[], h * w, 0)
+        rc == 0 && (rc = rc_red)
         rc == 0 && rank == 0 && ccall((:hipMemcpy, "libamdhip64"), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Cint), out, d_film[], sizeof(out), 2)
         ccall((:hipFree, "libamdhip64"), Cint, (Ptr{Cvoid},), d_film[])
     else
@@ -266,6 +289,7 @@ function render!(entry::Symbol, i, scene::Trace.Scene)
     ccall((:trhip_scene_free, LIB), Cvoid, (Ptr{Cvoid},), s)
     check(rc)
     rank == 0 || return nothing
+    world > 1 && isnan(out[4]) && error("TraceHIP: a rank of the job failed to render its samples (the reduced film is NaN)")
     write_film!(film, out, h, w)
     Trace.save(film)
 end

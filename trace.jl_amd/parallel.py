@@ -53,28 +53,50 @@ class Job:
         self.rank = int(os.environ.get("RANK", "0")) if rank is None else int(rank)
         self.world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else int(world)
         self.ok = False
+        self._id_path = None
         if self.world <= 1:
             return
         uid = self._exchange_id(id_file, timeout_s)
         ctx.comm_init(uid, self.rank, self.world)
         self.ok = True
 
+    @staticmethod
+    def job_nonce() -> str:
+        """What tells this job's id file from an earlier job's at the same path: TRACEHIP_JOB_ID, else the launcher's rendezvous
+        (TORCHELASTIC_RUN_ID + MASTER_PORT), else the launcher's pid (the ranks of one node share their parent)."""
+        env = os.environ
+        if env.get("TRACEHIP_JOB_ID"):
+            return env["TRACEHIP_JOB_ID"]
+        if env.get("MASTER_PORT"):
+            return f"{env.get('TORCHELASTIC_RUN_ID', 'run')}-{env['MASTER_PORT']}"
+        return f"ppid{os.getppid()}"
+
     def _exchange_id(self, id_file, timeout_s) -> bytes:
         if id_file:
+            # the file is per job (nonce in its name), written atomically, and removed by rank 0 in close(): a second job at the same
+            # path never reads the first one's id (ncclCommInitRank with two different ids hangs)
+            path = self._id_path = f"{id_file}.{self.job_nonce()}"
             if self.rank == 0:
+                if os.path.exists(path):
+                    os.unlink(path)  # a stale file of a crashed job with the same nonce
                 uid = _ffi.comm_unique_id()
-                tmp = id_file + ".tmp"
+                tmp = path + f".tmp{os.getpid()}"
                 with open(tmp, "wb") as f:
                     f.write(uid)
-                os.replace(tmp, id_file)
+                os.replace(tmp, path)
                 return uid
             t0 = time.time()
-            while not os.path.exists(id_file):
+            while True:
+                try:
+                    with open(path, "rb") as f:
+                        uid = f.read()
+                    if len(uid) == _ffi.UNIQUE_ID_BYTES:
+                        return uid
+                except FileNotFoundError:
+                    pass
                 if time.time() - t0 > timeout_s:
-                    raise _ffi.TraceHipError(f"no RCCL id at {id_file} after {timeout_s} s")
+                    raise _ffi.TraceHipError(f"no RCCL id at {path} after {timeout_s} s")
                 time.sleep(0.05)
-            with open(id_file, "rb") as f:
-                return f.read()
         import torch
         import torch.distributed as dist
         if not (dist.is_available() and dist.is_initialized()):
@@ -87,11 +109,18 @@ class Job:
         return bytes(buf.cpu().numpy().tobytes())
 
     def reduce_film(self, device_ptr: int, n_pixels: int, root: int = 0):
-        """In-place sum of the ranks' film accumulators onto `root` (trhip_film_reduce)."""
+        """In-place sum of the ranks' film accumulators onto `root` (trhip_film_reduce).  A job of several processes whose communicator
+        is missing fails here: trhip_film_reduce on a context without one is a no-op (the film of a single process IS the sum)."""
         if self.world > 1:
+            _, n = self.ctx.comm_rank()
+            if not self.ok or n != self.world:
+                raise _ffi.TraceHipError(f"film reduce of a {self.world}-process job, but the library's communicator has {n} rank(s)")
             self.ctx.film_reduce(device_ptr, n_pixels, root)
 
     def close(self):
         if self.ok:
-            self.ctx.comm_destroy()
+            self.ctx.comm_destroy()  # every rank has read the id by now (ncclCommInitRank returned everywhere)
             self.ok = False
+        if self.rank == 0 and self._id_path and os.path.exists(self._id_path):
+            os.unlink(self._id_path)
+            self._id_path = None
