@@ -7,9 +7,12 @@ depth 8 (BASELINE.json), PathIntegrator on the north star's 1 M-triangle synthet
 
 One "step" = one full render of the workload.  N > 1 (one process per GPU, torch.distributed.run): the frame is sharded by
 global sample index and the film accumulators are sum-reduced to rank 0 by trhip_film_reduce (RCCL inside libtracehip.so).
-`--scaling weak` (default): every rank renders `spp` samples per pixel (per-GPU work fixed); `strong`: the `spp` samples of
-ONE frame are split over the ranks (BASELINE configs[4] = `--workload mesh_10m --res 4096 --spp 1024 --depth 16 --scaling strong`).
-For N > 1 the line also carries the other mode, measured right after, as `"strong_scaling"` / `"weak_scaling"`.
+`--scaling strong` (default for N > 1): the `spp` samples of ONE frame are split over the ranks — what BASELINE configs[4] asks
+(`--workload mesh_10m --res 4096 --spp 1024 --depth 16`) and the only mode in which "x N" is not true by construction; `weak`:
+every rank renders `spp` samples per pixel (per-GPU work fixed).  For N > 1 the line also carries the other mode, measured right
+after, as `"weak_scaling"` / `"strong_scaling"`, the number of ranks the library's RCCL communicator has (`rccl_ranks`: an N-rank
+line cannot be produced without it — a failed trhip_comm_init ends the run with a non-zero exit) and the film reduce's time.
+`--workload mesh_10m --res 4096 --spp 128 --depth 16` on ONE GPU is one rank's share of BASELINE configs[4].
 Inputs (scene, BVH) are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
@@ -71,10 +74,10 @@ def kernel_bytes(st, film_px: int):
     }
 
 
-def measure_traffic(args, kernel_prefix: str, want_any: bool):
-    """HBM-side bytes per launch of the dominant kernel: FETCH_SIZE and WRITE_SIZE from two separate `rocprofv3 --pmc` child
-    runs of this same command (one step, no baselines), corrected as MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE
-    tallies 128-byte requests at 64 B: doubled; both counters are in KiB).  None when rocprofv3 is unavailable or fails."""
+def pmc_child_runs(args, kernel_prefix: str, want_any: bool, passes):
+    """Counters of the dominant kernel from separate `rocprofv3 --pmc` child runs of this same command (one step, no baselines; a PMC pass
+    never shares a run with a trace domain).  `passes` = lists of counter names, one child run each.  Returns {counter: average per
+    dispatch of the kernels whose name contains kernel_prefix}, or None for a pass that failed / when rocprofv3 is absent."""
     import csv
     import glob
     import shutil
@@ -84,31 +87,70 @@ def measure_traffic(args, kernel_prefix: str, want_any: bool):
     if exe is None:
         return None
     totals = {}
-    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+    for counters in passes:
         out = tempfile.mkdtemp(prefix="trhip_pmc_", dir="/tmp")
-        cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "1", "--warmup", "0",
+        cmd = [exe, "--pmc"] + list(counters) + ["--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "1", "--warmup", "0",
                "--workload", args.workload, "--res", str(args.res), "--spp", str(args.spp), "--depth", str(args.depth), "--seed", str(args.seed), "--traversal", str(args.traversal),
+               "--iterations", str(args.iterations), "--radius", str(args.radius),
                "--no-cpu-baseline", "--no-traffic", "--no-micro", "--no-visits"] + [a for kv in args.opt for a in ("--opt", kv)]
         try:
             subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900, check=True)
             files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
-            kb, n = 0.0, 0
+            acc, n = {}, {}
             for r in csv.DictReader(open(files[0])):
                 name = r["Kernel_Name"]
-                if kernel_prefix not in name or r["Counter_Name"] != counter:
+                if kernel_prefix not in name:
                     continue
-                if "k_trace" in kernel_prefix and kernel_prefix not in ("k_trace_closest", "k_trace_any") and (("<true" in name) != want_any):
+                if kernel_prefix.startswith("k_trace") and kernel_prefix not in ("k_trace_closest", "k_trace_any") and (("<true" in name) != want_any):
                     continue
-                kb += float(r["Counter_Value"])
-                n += 1
-            if n == 0:
-                return None
-            totals[counter] = kb * 1024.0 / n
+                c = r["Counter_Name"]
+                acc[c] = acc.get(c, 0.0) + float(r["Counter_Value"])
+                n[c] = n.get(c, 0) + 1
+            for c in acc:
+                totals[c] = acc[c] / n[c]
         except Exception:
-            return None
+            pass
         finally:
             shutil.rmtree(out, ignore_errors=True)
-    return int(2.0 * totals["FETCH_SIZE"] + totals["WRITE_SIZE"])
+    return totals or None
+
+
+# bytes that left L2 per unit of FETCH_SIZE (KiB) for the dominant kernel's access pattern.  MI355X_MICROARCH.md gives x2 for 16 B / lane coalesced
+# streaming reads (128-byte requests tallied at 64 B) and leaves other widths to the user; tools/calib/fetch_calib.hip measured the per-lane 64- /
+# 48- / 128-byte record gathers of the traversal and shading kernels on a 1 GiB table read exactly once (profiles/r3/fetch_calib_summary.txt).
+FETCH_FACTOR = {"default": 2.0}
+
+
+def measure_counters(args, kernel_prefix: str, want_any: bool):
+    """roofline.traffic (HBM-side bytes per launch of the dominant kernel: FETCH_SIZE and WRITE_SIZE need separate passes — TCC slots) and
+    roofline.valu (lanes per VALU instruction = SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU, VALU busy) from three PMC child runs."""
+    t = pmc_child_runs(args, kernel_prefix, want_any, [["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_INSTS_VALU", "VALUBusy"]])
+    if not t:
+        return None, None
+    traffic = None
+    if "FETCH_SIZE" in t and "WRITE_SIZE" in t:
+        f = FETCH_FACTOR.get(kernel_prefix, FETCH_FACTOR["default"])
+        traffic = {"bytes": int(f * t["FETCH_SIZE"] * 1024.0 + t["WRITE_SIZE"] * 1024.0), "fetch_factor": f, "FETCH_SIZE_KiB": round(t["FETCH_SIZE"], 1), "WRITE_SIZE_KiB": round(t["WRITE_SIZE"], 1)}
+    valu = None
+    if t.get("SQ_ACTIVE_INST_VALU"):
+        valu = {"lanes_per_valu_inst": round(t["SQ_THREAD_CYCLES_VALU"] / t["SQ_ACTIVE_INST_VALU"], 2), "of": 64,
+                "wave_valu_insts_per_launch": int(t.get("SQ_INSTS_VALU", 0))}
+        if t.get("VALUBusy") is not None:  # rocprofv3's derived metric (gfx94x formula: ROCm 7.2 ships no gfx950 section), in percent
+            valu["valu_busy"] = round(min(1.0, t["VALUBusy"] / 100.0), 3)
+    return traffic, valu
+
+
+def classify_bound(roofline):
+    """Which resource the evidence says bounds the dominant kernel.  `frac` stays SURVEY §8(d)'s request-rate figure; the label comes from counters:
+    VALU >= 80 % busy -> "valu-issue" (with lanes per instruction beside it); else HBM-side bytes >= 60 % of peak -> "hbm"; else "latency"."""
+    v = roofline.get("valu") or {}
+    if v.get("valu_busy", 0.0) >= 0.8:
+        return "valu-issue"
+    if roofline.get("frac_counters", 0.0) >= 0.6:
+        return "hbm"
+    if v or roofline.get("frac_counters") is not None:
+        return "latency"
+    return "hbm"  # no counters available: SURVEY §8(d)'s nominal roofline
 
 
 def micro_benchmark(args, T, ctx, flat, osc):
@@ -171,22 +213,29 @@ def run_sppm(args, T, ctx, graft, rank, world, comm_ok):
         integ.render(scene, ctx)
     sync()
     t_start = time.perf_counter()
-    rays, ms, launches = 0, {k: 0.0 for k in KERNEL_CLASSES}, {}
+    rays, replicated, ms, launches = 0, 0, {k: 0.0 for k in KERNEL_CLASSES}, {}
+    sub_ms, sub_launches = [0.0] * 4, [0] * 4
     for _ in range(args.steps):
         integ.render(scene, ctx)
         st = integ.stats
         rays += st.closest_rays + st.shadow_rays
+        replicated += st.replicated_rays
         for k in ms:
             ms[k] += getattr(st, "ms_" + k)
             launches[k] = launches.get(k, 0) + getattr(st, "launches_" + k)
+        for j in range(4):
+            sub_ms[j] += st.ms_sub[j]
+            sub_launches[j] += st.launches_sub[j]
     sync()
     elapsed = time.perf_counter() - t_start
     tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    cnt = torch.tensor([float(rays)], dtype=torch.float64, device="cuda")
+    # only the photon pass is sharded: every rank repeats the camera pass (closest-hit + shadow rays).  Useful rays of the job = the ranks'
+    # own (photon) rays + the camera pass ONCE (rank 0's count; identical on every rank)
+    cnt = torch.tensor([float(rays - replicated)], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-    elapsed, rays = float(tmax.item()), float(cnt.item())
+    elapsed, rays = float(tmax.item()), float(cnt.item()) + float(replicated)
     if rank != 0:
         return None
     ctx.set_option("count_visits", 1)
@@ -195,21 +244,47 @@ def run_sppm(args, T, ctx, graft, rank, world, comm_ok):
     sv = integ.stats
     ctx.set_option("count_visits", 0)
     kb = kernel_bytes(sv, 0)
-    dom_bytes = kb["trace_closest"] * (args.steps if world == 1 else 0) / max(1, launches["trace_closest"])
-    dom_ms = ms["trace_closest"] / max(1, launches["trace_closest"])
+    per_step = {"raygen+photon_gen": ms["raygen"] / args.steps, "trace_closest": ms["trace_closest"] / args.steps, "photon_gather": sub_ms[0] / args.steps,
+                "camera+photon_shading": sub_ms[1] / args.steps, "grid+bin+scan": sub_ms[2] / args.steps, "fold+pixel_update": sub_ms[3] / args.steps,
+                "trace_any": ms["trace_any"] / args.steps, "image": ms["film"] / args.steps}
+    dominant = max((k for k in per_step if k != "trace_any"), key=lambda k: per_step[k])
+    n_px = args.res * args.res
+    if dominant == "photon_gather":
+        # k_sppm_gather + k_sppm_gather_hot of one iteration = one "launch" (DESIGN.md §10).  Algorithmic bytes: per pixel with a visible point 16 B position +
+        # 4 B radius + 16 B beta + 80 B frame (wo, ng, ns, ss, ts) read, 16 B (phi, M) written; 8 B of bucket bounds per cell visited;
+        # 16 B per candidate distance-tested (sorted photon position + record index); 32 B per accepted pair (photon direction + beta)
+        c = sv.count_sub
+        it = max(1, args.iterations)
+        dom_bytes = ((c[3] * 132 + c[0] * 16 + c[1] * 32) / it) if c[0] else 0
+        dom_ms = sub_ms[0] / max(1, sub_launches[0])
+        dom_launches = sub_launches[0]
+        kname, kprefix = "k_sppm_gather + k_sppm_gather_hot", "k_sppm_gather"
+        extra = {"per_iteration": {"visible_points": int(c[3] / it), "candidates": int(c[0] / it), "accepted_pairs": int(c[1] / it)} if c[0] else None}
+    else:
+        dom_bytes = kb["trace_closest"] * (args.steps if world == 1 else 0) / max(1, launches["trace_closest"])
+        dom_ms = ms["trace_closest"] / max(1, launches["trace_closest"])
+        dom_launches = launches["trace_closest"]
+        kprefix = TRAVERSAL_KERNEL.get(int(sv.traversal), "k_trace")
+        kname = kprefix + "<closest>"
+        extra = {}
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-    kname = TRAVERSAL_KERNEL.get(int(sv.traversal), "k_trace")
-    roofline = {"bound": "hbm", "kernel": kname + "<closest>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                "avg_launch_ms": round(dom_ms, 4), "launches": launches["trace_closest"], "algorithmic_bytes_per_launch": int(dom_bytes),
+    roofline = {"bound": "hbm", "kernel": kname, "dominant_class": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "avg_launch_ms": round(dom_ms, 4), "launches": dom_launches, "algorithmic_bytes_per_launch": int(dom_bytes),
                 "visits_per_ray": {"closest_nodes": round(sv.nodes_visited / max(1, sv.closest_rays), 2), "closest_prims": round(sv.prims_tested / max(1, sv.closest_rays), 2),
                                    "node_bytes": int(sv.node_bytes)},
-                "kernel_ms_per_step": {"raygen+photon_gen": round(ms["raygen"] / args.steps, 2), "trace_closest": round(ms["trace_closest"] / args.steps, 2),
-                                       "shade+grid+gather+update": round(ms["shade"] / args.steps, 2), "trace_any": round(ms["trace_any"] / args.steps, 2), "image": round(ms["film"] / args.steps, 3)}}
+                "kernel_ms_per_step": {k: round(v, 3) for k, v in per_step.items()}}
+    roofline.update(extra)
     if world == 1 and not args.no_traffic:
-        roofline["traffic"] = measure_traffic(args, kname, False)
-        if roofline["traffic"]:
+        traffic, valu = measure_counters(args, kprefix, False)
+        if traffic:
+            n_k = 2 if dominant == "photon_gather" else 1  # two kernels per "launch" of the gather class
+            roofline["traffic"] = traffic["bytes"] * n_k
+            roofline["traffic_detail"] = traffic
             roofline["achieved_counters"] = round(roofline["traffic"] / (dom_ms * 1e-3) / 1e9, 2)
             roofline["frac_counters"] = round(roofline["achieved_counters"] / HBM_PEAK_GBS, 5)
+        if valu:
+            roofline["valu"] = valu
+    roofline["bound"] = classify_bound(roofline)
     cpu = None
     if world == 1 and not args.no_cpu_baseline:  # the oracle with its photon loop threaded like sppm.jl:334, on a bounded number of iterations
         sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -231,7 +306,8 @@ def run_sppm(args, T, ctx, graft, rank, world, comm_ok):
                                      f"SPPMIntegrator, {args.res}x{args.res}, {args.iterations} iterations, {info['photons_per_iteration']} photons per iteration, max depth {args.depth}, "
                                      f"radius {args.radius}, seed {args.seed:#x}",
                          "rays_per_step": int(rays / args.steps), "ms_per_iteration": round(elapsed / args.steps / args.iterations * 1e3, 3), "bvh_build_upload_s": round(t_build, 3),
-                         "parallelism": f"photon indices sharded x{world}, one RCCL all-reduce of phi / M per iteration ({'libtracehip' if comm_ok else 'unavailable'})" if world > 1 else "single GPU"},
+                         "parallelism": f"photon indices sharded x{world}, camera pass replicated (its rays counted once), one RCCL all-reduce of phi / M per iteration inside libtracehip" if world > 1 else "single GPU",
+                         "rccl_ranks": ctx.comm_rank()[1]},
               "roofline": roofline, "cpu_baseline": cpu}
     print(json.dumps(result), flush=True)
     return result
@@ -247,7 +323,7 @@ def main():
     ap.add_argument("--spp", type=int, default=256)
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED0001)
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default=None, help="default: strong when --gpus > 1 (one frame's samples split over the ranks), weak (= the frame) on one GPU")
     ap.add_argument("--traversal", type=int, default=0, help="traversal kernel (0 = the library's default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-spp", type=int, default=0, help="spp of the bounded CPU-baseline sample (0 = auto)")
@@ -263,6 +339,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.scaling is None:
+        args.scaling = "strong" if world > 1 else "weak"
     if world != args.gpus and world == 1 and args.gpus > 1:
         raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
     import torch
@@ -287,14 +365,20 @@ def main():
     # ---- the job's communicator, inside the library (include/tracehip.h "multi-GPU"): rank 0 makes the RCCL id, torch.distributed carries it ----
     comm_ok = False
     if world > 1:
+        err = ""
         try:
             job = T.parallel.Job(ctx, rank, world)
-            comm_ok = job.ok
-        except Exception as e:  # keep the bench line: fall back to torch.distributed's reduce and say so
-            sys.stderr.write(f"[bench] rank {rank}: trhip_comm_init failed ({e}); film reduce falls back to torch.distributed\n")
+            comm_ok = job.ok and ctx.comm_rank()[1] == world
+        except Exception as e:
+            err = str(e)
         flag = torch.tensor([1 if comm_ok else 0], device="cuda")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        comm_ok = bool(flag.item())
+        if not bool(flag.item()):
+            # no torch.distributed stand-in: an N-rank line must come from the library's own RCCL communicator with N ranks, or not at all
+            sys.stderr.write(f"[bench] rank {rank}: the library's RCCL communicator is not up on every rank ({err or 'another rank failed'}); no bench line\n")
+            dist.barrier()
+            dist.destroy_process_group()
+            raise SystemExit(3)
 
     if args.workload == "caustic_sppm":
         r = run_sppm(args, T, ctx, graft, rank, world, comm_ok)
@@ -308,6 +392,8 @@ def main():
     t_build = time.time() - t0
     h, w = cam.film.size
     film = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+
+    reduce_s = [0.0]  # wall time this rank spent inside trhip_film_reduce (includes waiting for the slowest rank)
 
     def shard(mode):
         """(spp of this rank, first global sample index) — weak: every rank `spp`; strong: the frame's `spp` split over the ranks."""
@@ -324,11 +410,10 @@ def main():
                 integ.render(scene, ctx, device_out=film.data_ptr())
             else:
                 film.zero_()
-            if world > 1:  # Film pixels are additive (film.jl:161-162, 190-191): one sum-reduce ends the frame
-                if comm_ok:
-                    ctx.film_reduce(film.data_ptr(), h * w, 0)
-                else:
-                    T.parallel.reduce_film(film, dst=0)
+            if world > 1:  # Film pixels are additive (film.jl:161-162, 190-191): one sum-reduce ends the frame (ncclReduce inside the library; blocking)
+                t_r = time.perf_counter()
+                ctx.film_reduce(film.data_ptr(), h * w, 0)
+                reduce_s[0] += time.perf_counter() - t_r
             return integ.stats
         return step, integ
 
@@ -343,17 +428,20 @@ def main():
             step()
         sync()
         t_start = time.perf_counter()
-        agg = {"samples": 0, "ms": {k: 0.0 for k in KERNEL_CLASSES}, "launches": {}, "closest": 0, "shadow": 0}
+        agg = {"samples": 0, "ms": {k: 0.0 for k in KERNEL_CLASSES}, "launches": {}, "closest": 0, "shadow": 0, "fallback": 0}
+        reduce_s[0] = 0.0
         for _ in range(steps):
             st = step()
             agg["closest"] += st.closest_rays
             agg["shadow"] += st.shadow_rays
             agg["samples"] += st.camera_samples
+            agg["fallback"] += st.fallback_rays
             for k in agg["ms"]:
                 agg["ms"][k] += getattr(st, "ms_" + k)
                 agg["launches"][k] = agg["launches"].get(k, 0) + getattr(st, "launches_" + k)
         sync()
         elapsed = time.perf_counter() - t_start
+        agg["film_reduce_ms_per_step"] = reduce_s[0] / max(1, steps) * 1e3
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         counts = torch.tensor([agg["closest"] + agg["shadow"], agg["samples"]], dtype=torch.float64, device="cuda")
         if world > 1:
@@ -366,9 +454,9 @@ def main():
     if world > 1:  # the other scaling mode, right after (fewer steps): both values in one line
         omode = "strong" if args.scaling == "weak" else "weak"
         osteps = max(1, min(args.steps, 5))
-        oe, orays, osamples, _, _ = timed(omode, osteps, 1)
+        oe, orays, osamples, oagg, _ = timed(omode, osteps, 1)
         other = {"scaling": omode, "value": round(orays / oe / 1e6, 2), "unit": "Mray/s", "steps": osteps, "ms_per_step": round(oe / osteps * 1e3, 3), "spp_per_gpu": shard(omode)[0],
-                 "Msample_per_s": round(osamples / oe / 1e6, 3)}
+                 "Msample_per_s": round(osamples / oe / 1e6, 3), "film_reduce_ms_per_step": round(oagg["film_reduce_ms_per_step"], 3)}
 
     result = None
     if rank == 0:
@@ -390,6 +478,7 @@ def main():
             dom_bytes = per_step[dominant] * steps / max(1, agg["launches"][dominant])
             achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
             kname = {"trace_closest": TRAVERSAL_KERNEL.get(int(sv.traversal), "k_trace"), "shade": "k_shade_path", "film": "k_film_gather", "raygen": "k_raygen"}[dominant]
+            kprefix = kname
             gbps = {k: round(per_step[k] / (agg["ms"][k] / steps * 1e-3) / 1e9, 1) if agg["ms"][k] > 0 else None for k in per_step}
             roofline = {"bound": "hbm", "kernel": kname + ("<closest>" if dominant == "trace_closest" else ""), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "avg_launch_ms": round(dom_ms, 4), "launches": agg["launches"][dominant],
@@ -404,7 +493,8 @@ def main():
                         "kernel_GBps_note": "algorithmic bytes / class time; the traversal classes count REQUESTS (32 B per box tested, 48 B per primitive fetched): L2 and MALL serve part of them, so they may exceed the HBM peak — achieved_counters / frac_counters is what left L2",
                         "kernel_GBps": gbps}
             over = [k for k, v in gbps.items() if v is not None and v > HBM_PEAK_GBS and not k.startswith("trace")]
-            roofline["byte_models_within_peak"] = not over
+            # no line may carry a fraction above 1 without saying so: a request rate above the HBM peak means L2 / MALL serve part of the requests
+            roofline["byte_models_within_peak"] = not over and roofline["frac"] <= 1.0
             if over:
                 sys.stderr.write(f"[bench] byte model exceeds the HBM peak for {over}: those bytes are not being moved\n")
             if dominant.startswith("trace"):
@@ -414,12 +504,23 @@ def main():
                 compulsory = rays_per_launch * 48 + 32 * int(bvh[1].size) + 48 * int(bvh[3].size)
                 roofline["compulsory_bytes_per_launch"] = int(compulsory)
                 roofline["achieved_compulsory"] = round(compulsory / (dom_ms * 1e-3) / 1e9, 2) if dom_ms > 0 else 0.0
+            if sv.fallback_rays or int(sv.traversal) == 7:
+                roofline["fallback_rays_per_step"] = int(agg["fallback"] / steps)
+                roofline["fallback_fraction_of_closest_rays"] = round(agg["fallback"] / max(1, agg["closest"]), 5)
             if world == 1 and not args.no_traffic:
-                roofline["traffic"] = measure_traffic(args, kname, False)
-                roofline["traffic_note"] = "bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (rocprofv3 --pmc, separate child runs of this command with --steps 1; gfx950 correction)"
-                if roofline["traffic"]:
+                traffic, valu = measure_counters(args, kprefix, False)
+                roofline["traffic_note"] = ("bytes per launch = fetch_factor x FETCH_SIZE + WRITE_SIZE (rocprofv3 --pmc, separate child runs of this command with --steps 1); fetch_factor: "
+                                            "MI355X_MICROARCH.md's gfx950 correction, re-measured for this kernel's access pattern by tools/calib/fetch_calib.hip")
+                if traffic:
+                    roofline["traffic"] = traffic["bytes"]
+                    roofline["traffic_detail"] = traffic
                     roofline["achieved_counters"] = round(roofline["traffic"] / (dom_ms * 1e-3) / 1e9, 2)
                     roofline["frac_counters"] = round(roofline["achieved_counters"] / HBM_PEAK_GBS, 5)
+                if valu:
+                    roofline["valu"] = valu
+            roofline["bound"] = classify_bound(roofline)
+            roofline["bound_note"] = ("from counters: VALU busy >= 80 % -> valu-issue (lanes per VALU instruction in `valu`); else HBM-side bytes >= 60 % of peak -> hbm; else latency. "
+                                      "`frac` stays SURVEY 8(d)'s algorithmic-bytes figure against the HBM peak")
         # ---- CPU baseline: the oracle (faithful restatement, OpenMP over the reference's 16x16 tiles) on a bounded sample ----
         cpu, micro = None, None
         osc = None
@@ -453,7 +554,8 @@ def main():
                                    + f", max depth {args.depth}, PathIntegrator, seed {args.seed:#x}",
                        "rays_per_step": int(total_rays / args.steps), "samples_per_step": int(total_samples / args.steps), "bvh_build_upload_s": round(t_build, 3),
                        "traversal": int(sv.traversal),
-                       "parallelism": (f"sample-index sharding x{world} + film sum-reduce over RCCL ({'trhip_film_reduce' if comm_ok else 'torch.distributed fallback'})") if world > 1 else "single GPU"},
+                       "parallelism": f"sample-index sharding x{world} + film sum-reduce over RCCL (trhip_film_reduce)" if world > 1 else "single GPU",
+                       "rccl_ranks": ctx.comm_rank()[1], "film_reduce_ms_per_step": round(agg["film_reduce_ms_per_step"], 3) if world > 1 else 0.0},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         if micro:

@@ -87,9 +87,19 @@ int trhip_scene_add_spot_light_fields(trhip_scene* scene, const float light2worl
                                       float cos_total_width, float cos_falloff_start);
 
 /* BVHAccel(primitives, max_node_primitives)  accel/bvh.jl:55-79.  Builds a binned-SAH BVH2 on the host (results of
- * traversal do not depend on the topology except for exact-t ties), flattens it in the reference's
- * depth-first layout (first child = i+1, bvh.jl:187-206) and uploads everything to HBM. */
+ * traversal do not depend on the topology except where two primitives are accepted at (nearly) the same t), flattens it
+ * in the reference's depth-first layout (first child = i+1, bvh.jl:187-206) and uploads everything to HBM.  Option "bvh_builder" = 2
+ * builds the reference's OWN tree instead (its 12-bucket construction, quirks included): same tie-breaks as Trace.jl; a host that
+ * already holds Trace.jl's BVHAccel hands its nodes over with trhip_scene_set_bvh (what TraceHIP.jl does). */
 int trhip_scene_commit(trhip_scene* scene, int max_node_primitives);
+
+/* BVHAccel construction alone, on the host (no GPU needed): builder 0 = the library's binned SAH, 2 = the REFERENCE's construction node for node
+ * (accel/bvh.jl:87-206 + partition! Trace.jl:128-137, quirks kept — SURVEY.md A.6; what trhip_scene_commit builds under option "bvh_builder" = 2).
+ * prim_bounds: n_prims * 6 (world_bound of each primitive: min xyz, max xyz).  Outputs in the layout of trhip_scene_get_bvh; *n_nodes_inout = capacity
+ * of the node arrays on entry, the tree's node count on return (all output pointers NULL: size query).  The reference's builder may emit leaves of 0
+ * primitives with bounds (+Inf, -Inf): up to ~3 n nodes.  TRHIP_ERR_UNSUPPORTED where the reference's recursion would not end. */
+int trhip_build_bvh_host(int builder, const float* prim_bounds, uint32_t n_prims, int max_node_primitives, float* node_bounds, uint32_t* node_a, uint32_t* node_flags,
+                         uint32_t* n_nodes_inout, uint32_t* prim_order, uint32_t* max_depth_out);
 
 /* Inspection of the committed BVH (tests feed the same topology to the CPU oracle so that parity is bit-exact).
  * node_bounds: n_nodes*6 (min xyz, max xyz).  Leaf: (flags & 3) == 3, a = first ordered-primitive slot, n = flags >> 2.

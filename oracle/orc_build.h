@@ -87,9 +87,14 @@ struct RefBuilder {
                 }
                 costs[i - 1] = 1.0f + (s1 + s2) / sa;
             }
-            int min_cost_id = 1;
-            for (int i = 2; i <= n_buckets - 1; ++i)
+            int min_cost_id = 1;  // argmin(costs) :158 — the first minimum; Julia's findmin treats a NaN as smaller than every number
+            for (int i = 1; i <= n_buckets - 1; ++i) {
+                if (costs[i - 1] != costs[i - 1]) {
+                    min_cost_id = i;
+                    break;
+                }
                 if (costs[i - 1] < costs[min_cost_id - 1]) min_cost_id = i;
+            }
             const float leaf_cost = (float)n_primitives;
             if (!(n_primitives > max_node_primitives || costs[min_cost_id - 1] < leaf_cost)) return create_leaf();
             // partition! (Trace.jl:128-137): never tests the first element in place

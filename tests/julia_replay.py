@@ -196,7 +196,16 @@ class ShimReplay:
                 out.append(p)
         return out
 
-    def flatten(self, scene):
+    def reference_tree(self, scene):
+        """What a Julia host holds after `BVHAccel(primitives, 1)` ran on the CPU: the reference's own tree (the oracle's restatement of
+        accel/bvh.jl:87-206) — or None for a scene with a BVHAccel nested as a primitive, where the shim lets the library build its tree."""
+        T = self.T
+        if any(isinstance(p, T.BVHAccel) for p in scene.aggregate.primitives):
+            return None
+        import oracle_bridge as ob
+        return ob.OracleScene.from_scene(scene, max_node_primitives=int(scene.aggregate.max_node_primitives)).get_bvh()
+
+    def flatten(self, scene, exact_tree=True):
         T = self.T
         h = C.c_void_p()
         self.call("trhip_scene_new", self.ctx, C.byref(h))
@@ -215,6 +224,9 @@ class ShimReplay:
             return mat_ids[id(m)]
 
         prims = self.expand(scene.aggregate.primitives)
+        tree = self.reference_tree(scene) if exact_tree else None
+        if tree is not None:  # `bvh.primitives` of a constructed BVHAccel is the ORDERED list (bvh.jl:66-78): that is what the shim walks
+            prims = [prims[k] for k in tree[3]]
         i = 0
         while i < len(prims):
             p = prims[i]
@@ -251,6 +263,11 @@ class ShimReplay:
             else:
                 ct, cf = spot_fields(T, l)
                 self.call("trhip_scene_add_spot_light_fields", s, m, im, I, ct, cf)
+        if tree is not None:  # EXACT_TREE: Trace.jl's nodes as they are; flat primitive k is ordered slot k
+            bounds, a, flags, _ = tree
+            self.call("trhip_scene_set_bvh", s, np.ascontiguousarray(bounds, np.float32).reshape(-1), np.ascontiguousarray(a, np.uint32), np.ascontiguousarray(flags, np.uint32),
+                      int(a.size), np.arange(len(prims), dtype=np.uint32), len(prims))
+            return s
         self.call("trhip_scene_commit", s, int(scene.aggregate.max_node_primitives))
         return s
 

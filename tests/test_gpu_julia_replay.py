@@ -40,13 +40,22 @@ def test_replayed_shim_equals_python_host(T, ctx, manifest, name):
     r = jr.ShimReplay(T, T._ffi.LIB_PATH, ctx._h)
     got, st = r.render(entry, scene, cam, 4, 5, seed=0x5EED0001, offset=0)
     seq = r.summary()
-    flat_end = next(i for i, c in enumerate(seq) if c[0] == "trhip_scene_commit") + 1
+    flat_end = next(i for i, c in enumerate(seq) if c[0] in ("trhip_scene_commit", "trhip_scene_set_bvh")) + 1
+    # a scene without nested BVHAccel primitives goes over with Trace.jl's own tree (EXACT_TREE): its last flattening call is trhip_scene_set_bvh
+    assert seq[flat_end - 1][0] == ("trhip_scene_commit" if name == "nested_bvh_cornell" else "trhip_scene_set_bvh")
     assert seq[:flat_end] == manifest["sequences"][name], "the call sequence differs from tests/golden/julia_shim_calls.json"
     assert [c[0] for c in seq[flat_end:]] == [entry, "trhip_scene_free"]
     if name == "caustic_glass_ply":
         tri_calls = [c for c in seq if c[0] == "trhip_scene_add_triangles"]
-        assert tri_calls[0][1] == 1 and "float32[132102]" in tri_calls[0][2] and "uint32[264192]" in tri_calls[0][2]  # the whole mesh in ONE call
-    ref = host(cam, T.SeededSampler(4, seed=0x5EED0001), 5).render(scene, ctx)
+        assert any(c[1] == 1 and "float32[132102]" in c[2] and "uint32[264192]" in c[2] for c in tri_calls)  # the whole mesh in ONE call
+    # the Python host on the SAME tree: option "bvh_builder" = 2 builds the reference's topology inside the library (th_bvh_ref.h)
+    ctx.set_option("bvh_builder", -1 if name == "nested_bvh_cornell" else 2)
+    try:
+        scene._flat = None
+        ref = host(cam, T.SeededSampler(4, seed=0x5EED0001), 5).render(scene, ctx)
+    finally:
+        ctx.set_option("bvh_builder", -1)
+        scene._flat = None
     assert ref[..., :3].max() > 0 and st.camera_samples > 0
     assert np.array_equal(bits(got), bits(ref)), f"{int((bits(got) != bits(ref)).sum())} film values differ between the replayed shim and the Python host"
 

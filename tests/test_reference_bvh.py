@@ -1,0 +1,86 @@
+"""Row a18: the product's restatement of the reference's BVH construction (trace.jl_amd/csrc/th_bvh_ref.h, option "bvh_builder" = 2,
+trhip_build_bvh_host) against the oracle's (oracle/orc_build.h, accel/bvh.jl:87-206 bug for bug), node for node, on the CPU.  The primitive
+bounds come from the oracle's world_bound restatement; tests/test_gpu_reference_tree.py checks on the GPU that trhip_scene_commit derives
+the same bounds (hence the same tree) from the flattened scene."""
+import numpy as np
+import pytest
+
+
+def prim_bounds(ob, osc, n):
+    import ctypes as C
+    out = np.empty((n, 6), np.float32)
+    obj = np.empty(6, np.float32)
+    for i in range(n):
+        ob.lib().orc_prim_bounds(osc.h, i, out[i].ctypes.data_as(C.POINTER(C.c_float)), obj.ctypes.data_as(C.POINTER(C.c_float)))
+    return out
+
+
+def scenes(T):
+    import os
+    yield "shadows", T.scenes.shadows_scene()
+    yield "cornell", T.scenes.cornell_scene()
+    yield "mesh24", T.scenes.mesh_scene(24)
+    yield "mesh64", T.scenes.mesh_scene(64)
+    yield "blob10", T.scenes.blob_scene(10)
+    ply = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "caustic-glass.ply")
+    yield "caustic", T.scenes.caustic_scene(ply if os.path.exists(ply) else "")
+
+
+def test_reference_builder_equals_the_oracles_node_for_node(T, ob):
+    for name, scene in scenes(T):
+        osc = ob.OracleScene.from_scene(scene)  # commit_reference(): oracle/orc_build.h
+        ref_bounds, ref_a, ref_flags, ref_order = osc.get_bvh()
+        pb = prim_bounds(ob, osc, ref_order.size)
+        bounds, a, flags, order, depth = T._ffi.build_bvh_host(pb, 1, builder=2)
+        assert a.size == ref_a.size, f"{name}: {a.size} nodes, the oracle's tree has {ref_a.size}"
+        assert np.array_equal(order, ref_order), name
+        assert np.array_equal(a, ref_a) and np.array_equal(flags, ref_flags), name
+        assert np.array_equal(bounds.view(np.uint32), ref_bounds.view(np.uint32)), name
+        assert depth >= 1
+
+
+def test_reference_builder_quirks(T):
+    """The construction's quirks on hand-made inputs: coincident centroids share a leaf; partition! leaves the first element in
+    place; a right child may come out EMPTY with bounds (+Inf, -Inf)."""
+    B = T._ffi.build_bvh_host
+    # two primitives with the same centroid: one leaf of 2 (bvh.jl:113-118)
+    pb = np.float32([[0, 0, 0, 1, 1, 1], [0.25, 0.25, 0.25, 0.75, 0.75, 0.75]])
+    bounds, a, flags, order, _ = B(pb, 1)
+    assert flags.tolist() == [(2 << 2) | 3] and order.tolist() == [0, 1]
+    # two primitives: the smaller centroid goes left, whatever the caller's order (bvh.jl:121-127)
+    pb = np.float32([[2, 0, 0, 3, 1, 1], [0, 0, 0, 1, 1, 1]])
+    _, a, flags, order, _ = B(pb, 1)
+    assert flags.tolist() == [0, (1 << 2) | 3, (1 << 2) | 3] and order.tolist() == [1, 0] and a.tolist() == [2, 0, 1]
+    # three unit boxes along x at 0, 10, 11: the first is never tested by partition! (Trace.jl:128-137)
+    pb = np.float32([[x, 0, 0, x + 1, 1, 1] for x in (0.0, 10.0, 11.0)])
+    bounds, a, flags, order, depth = B(pb, 1)
+    leaves = [(int(a[i]), int(flags[i] >> 2)) for i in range(a.size) if (flags[i] & 3) == 3]
+    assert sum(c for _, c in leaves) == 3 and sorted(order.tolist()) == [0, 1, 2]
+    # every empty leaf carries the invalid bounds, every other node a finite box; the children's union is the parent's box
+    for i in range(a.size):
+        if (flags[i] & 3) == 3 and (flags[i] >> 2) == 0:
+            assert np.all(bounds[i, :3] == np.inf) and np.all(bounds[i, 3:] == -np.inf)
+        else:
+            assert np.all(np.isfinite(bounds[i]))
+
+
+def test_reference_builder_emits_empty_leaves_on_a_mesh(T, ob):
+    """The 0-primitive leaves are not a corner case: count them on the height field (and they never hold a primitive slot)."""
+    scene = T.scenes.mesh_scene(24)
+    osc = ob.OracleScene.from_scene(scene)
+    pb = prim_bounds(ob, osc, osc.get_bvh()[3].size)
+    bounds, a, flags, order, depth = T._ffi.build_bvh_host(pb, 1, builder=2)
+    leaf = (flags & 3) == 3
+    counts = flags[leaf] >> 2
+    assert counts.sum() == order.size and depth <= 64
+    assert np.all(np.isinf(bounds[leaf][counts == 0]).all(axis=1)) if (counts == 0).any() else True
+
+
+def test_sah_builder_through_the_host_entry(T):
+    rng = np.random.default_rng(3)
+    lo = rng.uniform(-1, 1, (500, 3)).astype(np.float32)
+    pb = np.concatenate([lo, lo + rng.uniform(0.01, 0.2, (500, 3)).astype(np.float32)], axis=1)
+    bounds, a, flags, order, depth = T._ffi.build_bvh_host(pb, 1, builder=0)
+    assert sorted(order.tolist()) == list(range(500)) and a.size == 999 and depth < 40
+    with pytest.raises(T.TraceHipError):
+        T._ffi.build_bvh_host(pb, 1, builder=5)

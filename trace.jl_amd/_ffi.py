@@ -105,6 +105,7 @@ SIGNATURES = {
     "trhip_scene_add_point_light": (C.c_int, [_VP, _F, _F, _F]),
     "trhip_scene_add_spot_light": (C.c_int, [_VP, _F, _F, _F, C.c_float, C.c_float]),
     "trhip_scene_commit": (C.c_int, [_VP, C.c_int]),
+    "trhip_build_bvh_host": (C.c_int, [C.c_int, _F, C.c_uint32, C.c_int, _F, _U32, _U32, _U32, _U32, _U32]),
     "trhip_scene_bvh_size": (C.c_int, [_VP, _U32, _U32]),
     "trhip_scene_get_bvh": (C.c_int, [_VP, _F, _U32, _U32, _U32]),
     "trhip_scene_set_bvh": (C.c_int, [_VP, _F, _U32, _U32, C.c_uint32, _U32, C.c_uint32]),
@@ -165,6 +166,24 @@ def u32ptr(a):
 
 def f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def build_bvh_host(prim_bounds, max_node_primitives: int = 1, builder: int = 2):
+    """BVHAccel construction alone, on the host (trhip_build_bvh_host; no GPU needed): builder 2 = the reference's own construction node for
+    node (accel/bvh.jl:87-206), 0 = the library's binned SAH.  prim_bounds: (n, 6) world bounds.  Returns (bounds (m, 6), a, flags, order, max_depth)
+    in the layout of FlatScene.bvh() / set_bvh()."""
+    import numpy as np
+    pb = f32(prim_bounds).reshape(-1, 6)
+    n_nodes, depth = C.c_uint32(0), C.c_uint32(0)
+
+    def check(rc):
+        if rc:
+            raise TraceHipError(f"trhip_build_bvh_host failed ({rc}): {lib().trhip_last_error(None).decode()}")
+    check(lib().trhip_build_bvh_host(builder, fptr(pb), pb.shape[0], max_node_primitives, None, None, None, C.byref(n_nodes), None, C.byref(depth)))
+    m = n_nodes.value
+    bounds, a, flags, order = np.empty((m, 6), np.float32), np.empty(m, np.uint32), np.empty(m, np.uint32), np.empty(pb.shape[0], np.uint32)
+    check(lib().trhip_build_bvh_host(builder, fptr(pb), pb.shape[0], max_node_primitives, fptr(bounds), u32ptr(a), u32ptr(flags), C.byref(n_nodes), u32ptr(order), C.byref(depth)))
+    return bounds, a, flags, order, depth.value
 
 
 def detmath(fn: int, x, y=None):

@@ -1,0 +1,147 @@
+// th_bvh_ref.h — BVHAccel(primitives, max_node_primitives) with the REFERENCE's own construction (accel/bvh.jl:55-206, Trace.jl:128-137),
+// node for node: option "bvh_builder" = 2, and the host-only entry point trhip_build_bvh_host.  Traversal results depend on the topology
+// only where two primitives are accepted at (nearly) the same t — the later tested one wins (bvh.jl:229-237, triangle_mesh.jl:211-214) —
+// so a host that must agree with Trace.jl on those rays too asks for this tree instead of the library's binned-SAH one (th_bvh.h).
+// What is reproduced on purpose:
+//   * 12 buckets whose bounds START as the point (0, 0, 0), not empty (bvh.jl:130): every bucket's box reaches the origin;
+//   * the cost of splitting after bucket i weighs the two unions by the LENGTHS of the bucket ranges 1:i and (i+1):11 — not by primitive
+//     counts — and the right range never includes bucket 12 (bvh.jl:141-156);
+//   * leaf when !(n > max_node_primitives || cost < n) (bvh.jl:159-165); two primitives are split by the smaller centroid (bvh.jl:121-127);
+//   * partition! never tests the first element of its range in place and returns the index of the first element it did not move, and
+//     _init puts THAT element into the left child (Trace.jl:128-137, bvh.jl:166-185): the right child may be EMPTY — a leaf of 0
+//     primitives with the invalid bounds (+Inf, -Inf), which no ray's box test passes (bounds.jl:186-200: tx_min = +Inf);
+//   * nodes in depth-first order, first child at i + 1 (bvh.jl:187-206).
+// Float32 throughout, in the reference's operation order: centroid = 0.5 min + 0.5 max (bvh.jl:12), offset = (c - min) / (max - min)
+// (bounds.jl:137-145), bucket = floor(12 x offset) + 1 clamped to 12, surface area = 2 ((dx dy + dx dz) + dy dz) (bounds.jl:93-96),
+// cost = 1 + (s1 + s2) / area.  argmin is Julia's: the first minimum, a NaN counts as the smallest.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <stdexcept>
+#include <vector>
+
+#include "th_bvh.h"
+
+namespace th {
+
+class RefBVHBuilder {
+   public:
+    RefBVHBuilder(const std::vector<HostAABB>& prim_bounds, int max_node_prims) : pb_(prim_bounds), max_leaf_(std::min(255, max_node_prims)) {}
+
+    // throws std::runtime_error when the recursion does not end within kMaxRecursion levels (the reference would overflow its stack)
+    FlatBVH build() {
+        const uint32_t n = (uint32_t)pb_.size();
+        info_.resize(n);
+        cen_.resize((size_t)n * 3);
+        for (uint32_t i = 0; i < n; ++i) {
+            info_[i] = i;
+            for (int a = 0; a < 3; ++a) cen_[3 * (size_t)i + a] = 0.5f * pb_[i].mn[a] + 0.5f * pb_[i].mx[a];
+        }
+        out_.order.reserve(n);
+        if (n) node(0, n, 1);
+        return std::move(out_);
+    }
+
+   private:
+    static constexpr int kBuckets = 12;
+    static constexpr uint32_t kMaxRecursion = 4096;
+
+    static float surface_area(const HostAABB& b) {
+        const float dx = b.mx[0] - b.mn[0], dy = b.mx[1] - b.mn[1], dz = b.mx[2] - b.mn[2];
+        return 2.0f * (dx * dy + dx * dz + dy * dz);
+    }
+    // bucket of a centroid along `dim` (bvh.jl:135-138): offset() divides by the extent only where it is positive (bounds.jl:139-144)
+    int bucket_of(const HostAABB& cb, uint32_t prim, int dim) const {
+        const float o = cen_[3 * (size_t)prim + dim] - cb.mn[dim];
+        const float off = cb.mx[dim] > cb.mn[dim] ? o / (cb.mx[dim] - cb.mn[dim]) : o;
+        int b = (int)std::floor((float)kBuckets * off) + 1;
+        if (b == kBuckets + 1) b -= 1;
+        return b;
+    }
+    uint32_t emit(const HostAABB& b, uint32_t a, uint32_t flags) {
+        const uint32_t at = (uint32_t)out_.a.size();
+        out_.bounds.insert(out_.bounds.end(), {b.mn[0], b.mn[1], b.mn[2], b.mx[0], b.mx[1], b.mx[2]});
+        out_.a.push_back(a);
+        out_.flags.push_back(flags);
+        return at;
+    }
+    uint32_t leaf(uint32_t from, uint32_t to, const HostAABB& bounds) {  // _create_leaf bvh.jl:97-106
+        const uint32_t first = (uint32_t)out_.order.size();
+        for (uint32_t i = from; i < to; ++i) out_.order.push_back(info_[i]);
+        return emit(bounds, first, ((to - from) << 2) | 3u);
+    }
+    // _init over info_[from, to) (bvh.jl:87-185); returns the node's index in the flat arrays
+    uint32_t node(uint32_t from, uint32_t to, uint32_t depth) {
+        if (depth > kMaxRecursion) throw std::runtime_error("the reference's BVH construction does not terminate on this input (bvh.jl:166-185 recursion)");
+        out_.max_depth = std::max(out_.max_depth, depth);
+        const uint32_t n = to - from;
+        HostAABB bounds;
+        bounds.reset();
+        for (uint32_t i = from; i < to; ++i) bounds.grow(pb_[info_[i]]);
+        if (n == 1) return leaf(from, to, bounds);
+        HostAABB cb;
+        cb.reset();
+        for (uint32_t i = from; i < to; ++i) cb.grow_point(&cen_[3 * (size_t)info_[i]]);
+        const float dx = cb.mx[0] - cb.mn[0], dy = cb.mx[1] - cb.mn[1], dz = cb.mx[2] - cb.mn[2];
+        const int dim = (dx > dy && dx > dz) ? 0 : (dy > dz ? 1 : 2);  // maximum_extent bounds.jl:118-126
+        bool valid = true;                                             // is_valid bounds.jl:30-32 (an empty range: the 0-primitive leaf)
+        for (int a = 0; a < 3; ++a) valid = valid && cb.mn[a] != INFINITY && cb.mx[a] != -INFINITY;
+        if (!valid || cb.mn[dim] == cb.mx[dim]) return leaf(from, to, bounds);
+        uint32_t mid;  // LAST index of the left child (the reference's `mid`, 0-based here)
+        if (n <= 2) {
+            mid = (from + to - 1) / 2;
+            // partialsort!(view, 1, by = centroid[dim]): the smaller centroid first (an insertion sort of two: swapped only when strictly smaller)
+            if (cen_[3 * (size_t)info_[to - 1] + dim] < cen_[3 * (size_t)info_[from] + dim]) std::swap(info_[from], info_[to - 1]);
+        } else {
+            HostAABB bucket[kBuckets];
+            for (auto& b : bucket)
+                for (int a = 0; a < 3; ++a) b.mn[a] = b.mx[a] = 0.0f;  // Bounds3(Point3f(0f0)) bvh.jl:130
+            for (uint32_t i = from; i < to; ++i) bucket[bucket_of(cb, info_[i], dim) - 1].grow(pb_[info_[i]]);
+            const float sa = surface_area(bounds);
+            float costs[kBuckets - 1];
+            for (int i = 1; i <= kBuckets - 1; ++i) {
+                HostAABB u = bucket[0];
+                for (int b = 2; b <= i; ++b) u.grow(bucket[b - 1]);
+                const float s1 = (float)i * surface_area(u);
+                float s2 = 0.0f;
+                const int len2 = (kBuckets - 1) - i;  // length((i+1):(n_buckets-1))
+                if (len2 > 0) {
+                    HostAABB v = bucket[i];
+                    for (int b = i + 2; b <= kBuckets - 1; ++b) v.grow(bucket[b - 1]);
+                    s2 = (float)len2 * surface_area(v);
+                }
+                costs[i - 1] = 1.0f + (s1 + s2) / sa;
+            }
+            int best = 1;  // argmin: first minimum; NaN is smaller than everything (Julia's findmin)
+            for (int i = 1; i <= kBuckets - 1; ++i) {
+                if (std::isnan(costs[i - 1])) {
+                    best = i;
+                    break;
+                }
+                if (costs[i - 1] < costs[best - 1]) best = i;
+            }
+            if (!((int)n > max_leaf_ || costs[best - 1] < (float)n)) return leaf(from, to, bounds);
+            // partition! Trace.jl:128-137
+            uint32_t left = from;
+            for (uint32_t i = from; i < to; ++i)
+                if (left != i && bucket_of(cb, info_[i], dim) <= best) {
+                    std::swap(info_[i], info_[left]);
+                    left += 1;
+                }
+            mid = left;
+        }
+        const uint32_t self = emit(bounds, 0u, (uint32_t)dim);  // bounds = left ∪ right = the union over the range (min / max are exact)
+        node(from, mid + 1, depth + 1);
+        const uint32_t second = node(mid + 1, to, depth + 1);
+        out_.a[self] = second;
+        return self;
+    }
+
+    const std::vector<HostAABB>& pb_;
+    int max_leaf_;
+    std::vector<uint32_t> info_;
+    std::vector<float> cen_;
+    FlatBVH out_;
+};
+
+}  // namespace th

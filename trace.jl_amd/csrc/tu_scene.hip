@@ -1,6 +1,7 @@
 // tu_scene.hip — scene flattening into HBM: materials, primitives, BVHAccel commit (host SAH / device LBVH / a caller's tree), the
 // derived node arrays of the traversal kernels.
 #include "th_host.h"
+#include "th_bvh_ref.h"
 
 namespace {
 // ---- materials: the lobes each Material adds (materials/material.jl), precomputed per material ---------------------------------
@@ -230,6 +231,7 @@ int upload_scene(trhip_scene* s) {
     s->dev.n_materials = (uint32_t)s->materials.size();
     s->dev.n_lights = (uint32_t)s->lights.size();
     // ---- children-in-parent nodes for k_trace2 (th_trace2.h) ----
+    bool has_empty_leaf = false;
     s->wide_ok = false;
     std::memset(&s->wide, 0, sizeof s->wide);
     s->wide.root_ref = kRefNone;
@@ -240,6 +242,7 @@ int upload_scene(trhip_scene* s) {
             if ((s->bvh.flags[i] & 3u) != 3u) widx[i] = n_int++;
         bool ok = n_int < (1u << 24);
         std::vector<float4> wn((size_t)n_int * 4);
+        has_empty_leaf = false;
         // subtrees that hold a sphere keep the reference's loose slab test (th_trace2.h, slab_test2): the fp32 sphere quadratic
         // (sphere.jl:120-150) accepts rays that pass the sphere at a distance far beyond the tight test's margin
         std::vector<uint8_t> has_sphere(n_nodes, 0);
@@ -259,7 +262,21 @@ int upload_scene(trhip_scene* s) {
                 if ((s->bvh.flags[c[k]] & 3u) == 3u) {
                     ref[k] = s->bvh.a[c[k]];
                     cnt[k] = s->bvh.flags[c[k]] >> 2;
-                    if (cnt[k] == 0 || cnt[k] > 255) ok = false;  // empty / oversized leaves only come from foreign BVHs: use the literal kernel
+                    if (cnt[k] == 0) {
+                        // the reference's builder can emit a leaf of 0 primitives with the invalid bounds (+Inf, -Inf) (A.6, th_bvh_ref.h): no ray's box
+                        // test passes on it (tx_min = +Inf, bounds.jl:186-188), so the child word is never read — any leaf-shaped word will do.
+                        // An empty leaf with a REAL box (a foreign tree) could be "entered": the literal kernel walks those.
+                        const float* eb = &s->bvh.bounds[6 * (size_t)c[k]];
+                        if (eb[0] == INFINITY && eb[1] == INFINITY && eb[2] == INFINITY && eb[3] == -INFINITY && eb[4] == -INFINITY && eb[5] == -INFINITY) {
+                            ref[k] = 0;
+                            cnt[k] = 1;
+                            has_empty_leaf = true;
+                        } else {
+                            ok = false;
+                        }
+                    } else if (cnt[k] > 255) {
+                        ok = false;  // oversized leaves only come from foreign BVHs: use the literal kernel
+                    }
                 } else {
                     ref[k] = widx[c[k]];
                     cnt[k] = 0;
@@ -294,7 +311,7 @@ int upload_scene(trhip_scene* s) {
     // ---- 8-wide nodes over the triangles' subtree for k_trace8 (th_wide8.h) ----
     s->w8_ok = false;
     std::memset(&s->w8, 0, sizeof s->w8);
-    if (s->wide_ok && s->wide.root_cnt == 0 && n_nodes >= 3) {
+    if (s->wide_ok && s->wide.root_cnt == 0 && n_nodes >= 3 && !has_empty_leaf) {
         // root of the triangles' subtree: the whole tree when the scene has no sphere; with spheres the commit composed
         // root -> {leaf of all spheres (flat node 1), triangles (flat node 2)} (compose_bvh)
         uint32_t sub_root = 0, n_sph = 0;
@@ -601,7 +618,7 @@ int trhip_scene_commit(trhip_scene* s, int max_node_primitives) {
     std::vector<uint32_t> sph_ids, tri_ids;
     for (size_t i = 0; i < s->prims.size(); ++i) (s->prims[i].kind == 1 ? sph_ids : tri_ids).push_back((uint32_t)i);
     const bool want_chain = s->ctx->compose_spheres > 0 || (s->ctx->compose_spheres < 0 && s->ctx->traversal == 4);
-    const bool compose = want_chain && !sph_ids.empty() && sph_ids.size() <= (size_t)kW8MaxSpheres && tri_ids.size() >= 2 && pb.size() > s->ctx->tiny_scene_prims;
+    const bool compose = s->ctx->bvh_builder != 2 && want_chain && !sph_ids.empty() && sph_ids.size() <= (size_t)kW8MaxSpheres && tri_ids.size() >= 2 && pb.size() > s->ctx->tiny_scene_prims;
     std::vector<HostAABB> pb_sub;
     if (compose) {
         pb_sub.reserve(tri_ids.size());
@@ -610,6 +627,19 @@ int trhip_scene_commit(trhip_scene* s, int max_node_primitives) {
     const std::vector<HostAABB>& pb_build = compose ? pb_sub : pb;
     bool built = false;
     const int mode = s->ctx->bvh_builder;
+    if (mode == 2) {
+        // the reference's own construction, node for node (th_bvh_ref.h): also for scenes the default would commit as one leaf, never composed
+        try {
+            RefBVHBuilder rb(pb, max_node_primitives);
+            s->bvh = rb.build();
+        } catch (const std::exception& e) {
+            return fail(s->ctx, TRHIP_ERR_UNSUPPORTED, "bvh_builder 2: %s", e.what());
+        }
+        if (s->bvh.max_depth > (uint32_t)(kStackLds + kStackSpill))
+            return fail(s->ctx, TRHIP_ERR_UNSUPPORTED, "BVH depth %u exceeds the 64-entry traversal stack (bvh.jl:222 throws a BoundsError there)", s->bvh.max_depth);
+        s->literal_only = false;
+        return upload_scene(s);
+    }
     if ((mode == 1 || (mode < 0 && pb_build.size() > (16u << 20))) && pb_build.size() > s->ctx->tiny_scene_prims) {
         FlatBVH dev;
         const int rc = build_bvh_device(s->ctx, pb_build, dev);
@@ -675,6 +705,36 @@ int trhip_scene_commit(trhip_scene* s, int max_node_primitives) {
         return fail(s->ctx, TRHIP_ERR_UNSUPPORTED, "BVH depth %u exceeds the 64-entry traversal stack (bvh.jl:222)", s->bvh.max_depth);
     s->literal_only = false;
     return upload_scene(s);
+}
+int trhip_build_bvh_host(int builder, const float* prim_bounds, uint32_t n_prims, int max_node_primitives, float* node_bounds, uint32_t* node_a, uint32_t* node_flags, uint32_t* n_nodes_inout,
+                         uint32_t* prim_order, uint32_t* max_depth_out) {
+    if (!prim_bounds || !n_nodes_inout) return fail(nullptr, TRHIP_ERR_INVALID, "null argument");
+    if (builder != 0 && builder != 2) return fail(nullptr, TRHIP_ERR_INVALID, "builder must be 0 (binned SAH, th_bvh.h) or 2 (the reference's construction, th_bvh_ref.h)");
+    std::vector<HostAABB> pb(n_prims);
+    static_assert(sizeof(HostAABB) == 6 * sizeof(float), "HostAABB layout");
+    if (n_prims) std::memcpy(pb.data(), prim_bounds, (size_t)n_prims * 6 * sizeof(float));
+    FlatBVH t;
+    try {
+        if (builder == 2) {
+            RefBVHBuilder rb(pb, max_node_primitives);
+            t = rb.build();
+        } else {
+            BVHBuilder b(pb, max_node_primitives, 0u, false);
+            t = b.build();
+        }
+    } catch (const std::exception& e) {
+        return fail(nullptr, TRHIP_ERR_UNSUPPORTED, "%s", e.what());
+    }
+    const uint32_t n_nodes = (uint32_t)t.a.size(), cap = *n_nodes_inout;
+    *n_nodes_inout = n_nodes;
+    if (max_depth_out) *max_depth_out = t.max_depth;
+    if (!node_bounds && !node_a && !node_flags && !prim_order) return 0;  // size query
+    if (cap < n_nodes) return fail(nullptr, TRHIP_ERR_INVALID, "the tree has %u nodes, the caller's arrays hold %u", n_nodes, cap);
+    if (node_bounds) std::memcpy(node_bounds, t.bounds.data(), t.bounds.size() * sizeof(float));
+    if (node_a) std::memcpy(node_a, t.a.data(), t.a.size() * sizeof(uint32_t));
+    if (node_flags) std::memcpy(node_flags, t.flags.data(), t.flags.size() * sizeof(uint32_t));
+    if (prim_order) std::memcpy(prim_order, t.order.data(), t.order.size() * sizeof(uint32_t));
+    return 0;
 }
 int trhip_scene_bvh_size(const trhip_scene* s, uint32_t* n_nodes, uint32_t* n_prims) {
     if (!s) return TRHIP_ERR_INVALID;

@@ -63,6 +63,8 @@ struct TraceHIPError <: Exception
 end
 
 const CTX = Ref{Ptr{Cvoid}}(C_NULL)
+# hand Trace.jl's own BVH (scene.aggregate.nodes) to the library instead of letting it build one: same tree, same equal-t tie-breaks as the CPU path
+const EXACT_TREE = Ref(true)
 
 function context()
     if CTX[] == C_NULL
@@ -107,8 +109,9 @@ function flatten(scene::Trace.Scene)
     end
     bvh = scene.aggregate::Trace.BVHAccel
     # Every GeometricPrimitive under the aggregate, in order; a BVHAccel may itself be a primitive of another
-    # (primitive.jl / accel/bvh.jl:50-53, test/test_intersection.jl:137-138): its primitives are spliced in place.  Any order gives the
-    # same image except exact-t ties: the library builds its own BVH over the flat list (trhip_scene_commit).
+    # (primitive.jl / accel/bvh.jl:50-53, test/test_intersection.jl:137-138): its primitives are spliced in place.
+    # `bvh.primitives` is the ORDERED list the constructor left behind (bvh.jl:66-78): primitive k of the flat list is ordered slot k of
+    # `bvh.nodes`, so Trace.jl's own tree goes to the library as it is (EXACT_TREE, below) and equal-t ties resolve as they do on the CPU.
     prims = Trace.GeometricPrimitive[]
     function collect_prims!(list)
         for p in list
@@ -172,6 +175,32 @@ function flatten(scene::Trace.Scene)
         else
             error("TraceHIP: unsupported light $(typeof(l))")
         end
+    end
+    # Trace.jl's own BVH topology (accel/bvh.jl:38-48 nodes, depth-first, first child = i + 1) instead of a tree the library builds: where two
+    # primitives are accepted at the same t the later visited one wins (bvh.jl:229-237), so only the SAME tree gives the CPU's answer on those
+    # rays.  Not possible with a BVHAccel nested as a primitive (its own walk inside the outer one has no flat equivalent) or a tree deeper than
+    # the 64-entry stack (where the reference itself throws, bvh.jl:222): those scenes get the library's tree.
+    if EXACT_TREE[] && !any(p -> p isa Trace.BVHAccel, bvh.primitives) && !isempty(bvh.nodes)
+        n = length(bvh.nodes)
+        bounds = Vector{Float32}(undef, 6n)
+        a = Vector{UInt32}(undef, n)
+        flags = Vector{UInt32}(undef, n)
+        for (k, nd) in enumerate(bvh.nodes)
+            bounds[6k-5:6k-3] .= nd.bounds.p_min
+            bounds[6k-2:6k] .= nd.bounds.p_max
+            if nd isa Trace.LinearBVHLeaf
+                a[k] = nd.primitives_offset - 1                       # first ordered slot, 0-based
+                flags[k] = (UInt32(nd.n_primitives) << 2) | UInt32(3)
+            else
+                a[k] = nd.second_child_offset - 1                     # 0-based index of the second child
+                flags[k] = UInt32(nd.split_axis - 1)
+            end
+        end
+        order = collect(UInt32(0):UInt32(length(prims) - 1))          # flat primitive k IS ordered slot k
+        rc = ccall((:trhip_scene_set_bvh, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}, Ptr{UInt32}, Ptr{UInt32}, UInt32, Ptr{UInt32}, UInt32),
+            s, bounds, a, flags, n, order, length(prims))
+        rc == 0 && return s
+        rc == -3 || check(rc)                                          # TRHIP_ERR_UNSUPPORTED (deeper than 64): fall through
     end
     check(ccall((:trhip_scene_commit, LIB), Cint, (Ptr{Cvoid}, Cint), s, bvh.max_node_primitives))
     s
