@@ -28,8 +28,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 KERNEL_CLASSES = ("raygen", "trace_closest", "shade", "trace_any", "film")
-TRAVERSAL_KERNEL = {1: "k_trace_closest", 2: "k_trace2", 3: "k_trace3", 4: "k_trace8", 5: "k_trace_leaf"}
-TRAVERSAL_KERNEL_ANY = {1: "k_trace_any", 2: "k_trace2", 3: "k_trace3", 4: "k_trace8", 5: "k_trace_leaf"}
+TRAVERSAL_KERNEL = {1: "k_trace_closest", 2: "k_trace2", 3: "k_trace3", 4: "k_trace8", 5: "k_trace_leaf", 6: "k_trace4", 7: "k_trace7"}
+TRAVERSAL_KERNEL_ANY = {1: "k_trace_any", 2: "k_trace2", 3: "k_trace3", 4: "k_trace8", 5: "k_trace_leaf", 6: "k_trace4", 7: "k_trace3"}
 
 
 def build_workload(T, name: str, res: int):

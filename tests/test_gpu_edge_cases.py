@@ -56,12 +56,12 @@ def test_cropped_film(T, ob, ctx):
     assert got.shape == ref.shape == (21, 20, 4)
     assert_bits_equal(integ.sample_radiance(scene), ref_L, "per-sample radiance (cropped film)")
     assert_bits_equal(got, ref, "cropped film")
-    for mode in (0, 1, 3):  # 3 = splat descriptors; the default is 2
+    for mode in (0, 1, 2, 3, 4, 9):  # 3 = splat descriptors; the default is 6 (4 x 4 pixels per thread from packed descriptors)
         ctx.set_option("film_block", mode)
         try:
             assert_bits_equal(T.PathIntegrator(cam, T.SeededSampler(3, seed=8), 4).render(scene, ctx), ref, f"cropped film, film_block {mode}")
         finally:
-            ctx.set_option("film_block", 2)
+            ctx.set_option("film_block", 6)
 
 
 def test_degenerate_triangles_and_single_leaf_threshold(T, ob, ctx):
@@ -135,7 +135,7 @@ def test_bench_size_properties(T, ctx):
         try:
             return T.PathIntegrator(cam, T.SeededSampler(spp, seed=0x5EED0001, sample_offset=offset), 8).render(scene, ctx).copy()
         finally:
-            for k, v in {"traversal": 3, "film_block": 2, "batch_paths": 0, "overlap": 0}.items():
+            for k, v in {"traversal": 3, "film_block": 6, "batch_paths": 0, "overlap": 0}.items():
                 ctx.set_option(k, v)
 
     a = render()
@@ -144,6 +144,7 @@ def test_bench_size_properties(T, ctx):
     assert_bits_equal(render(traversal=1), a, "literal traversal kernel")
     assert_bits_equal(render(film_block=0), a, "one film pixel per thread")
     assert_bits_equal(render(film_block=3), a, "film gather from splat descriptors")
+    assert_bits_equal(render(film_block=2), a, "1 x 4 blocks recomputing the ranges (round 2's default)")
     assert_bits_equal(render(batch_paths=16 * 1026 * 1026, overlap=0), a, "four batches, one stream")
     assert_bits_equal(render(traversal=3), a, "binary children-in-parent walk (k_trace_leaf here: one-leaf scene)")
     h0, h1 = render(128, 0), render(128, 128)
@@ -261,7 +262,7 @@ def test_banded_frame_equals_whole_frame(T, ob, ctx, rows):
     osc = ob.OracleScene.from_scene(scene, bvh=scene.flatten(ctx).bvh())
     ref, _, st_ref = osc.render(cam, "path", 3, 5, seed=12, threads=ob.lib().orc_num_threads())
     assert_bits_equal(whole, ref, "one band vs oracle")
-    for film_block in (2, 3, 0, 1):
+    for film_block in (6, 2, 3, 0, 1, 5):
         ctx.set_option("band_tile_rows", rows)
         ctx.set_option("film_block", film_block)
         try:
@@ -269,6 +270,6 @@ def test_banded_frame_equals_whole_frame(T, ob, ctx, rows):
             banded = integ.render(scene, ctx).copy()
         finally:
             ctx.set_option("band_tile_rows", 0)
-            ctx.set_option("film_block", 2)
+            ctx.set_option("film_block", 6)
         assert_bits_equal(banded, whole, f"bands of {rows} tile rows, film_block {film_block}")
         assert integ.stats.camera_samples == 102 * 102 * 3 and integ.stats.closest_rays == st_ref.closest_rays and integ.stats.launches_film == -(-7 // rows)

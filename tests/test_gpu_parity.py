@@ -8,7 +8,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=[4, 6, 2, 3, 1], ids=["trace8", "trace4x2", "trace2", "trace3", "trace1"])
+@pytest.fixture(autouse=True, params=[4, 6, 7, 2, 3, 1], ids=["trace8", "trace4x2", "trace7", "trace2", "trace3", "trace1"])
 def traversal(request, ctx):
     """Every parity test runs with all traversal kernels: 4 = k_trace8 (8-wide quantised nodes in the binary walk's order; the
     default), 2 = k_trace2 (children-in-parent nodes, per-lane ray replacement), 3 = k_trace3 (the same with leaves postponed
@@ -273,14 +273,52 @@ def test_film_accumulate_matches_oracle_tile_order(T, ob, ctx):
     finally:
         ctx.set_option("film_tiled", 0)
     assert_bits_equal(out2, ref_xyzw, "film accumulate, LDS-tiled gather")
-    for mode in (0, 1, 2, 3):  # one film pixel per thread, 2 x 2 blocks, 1 x 4 blocks (the default), 1 x 4 from splat descriptors (odd film sizes: 37 x 29)
-        ctx.set_option("film_block", mode)
+    for mode in (0, 1, 2, 3, 6):  # one film pixel per thread, 2 x 2 blocks, 1 x 4 blocks, 1 x 4 from splat descriptors (odd film sizes: 37 x 29); 6: this filter is too wide for
+        ctx.set_option("film_block", mode)  # the packed descriptor, the library must fall back to the 1 x 4 block gather
         try:
             out3 = np.empty_like(ref_xyzw)
             ctx.check(T.lib().trhip_film_accumulate(ctx._h, C.byref(sn), spp, 5, 0, T._ffi.fptr(ref_L), T._ffi.fptr(out3)))
         finally:
-            ctx.set_option("film_block", 2)
+            ctx.set_option("film_block", 6)
         assert_bits_equal(out3, ref_xyzw, f"film accumulate, film_block={mode}")
+
+
+def test_film_gather_from_packed_descriptors(T, ob, ctx):
+    """The default film pass for filter radii <= 1 (every scene of the reference): the sample's pixel range and filter-table indices ride as 30 bits in the
+    .w lane of its radiance record (k_film_pack_w) and a thread owns BX x BY film pixels (k_film_gather_packed).  Every block shape, odd film sizes, a crop
+    window, radii 1, 0.5 and anisotropic, NaN samples — against the oracle's add_sample! / merge_film_tile! loop and against the per-pixel gather."""
+    import ctypes as C
+    scene = T.scenes.shadows_scene()
+    osc = ob.OracleScene.from_scene(scene)
+    for res, crop, radius, spp in (([37, 29], ([0.0, 0.0], [1.0, 1.0]), [1.0, 1.0], 3), ([64, 48], ([0.0, 0.0], [1.0, 1.0]), [1.0, 1.0], 5), ([53, 41], ([0.2, 0.1], [0.9, 0.8]), [1.0, 0.5], 2),
+                                   ([33, 70], ([0.0, 0.0], [1.0, 1.0]), [0.6, 0.95], 4)):
+        flt = T.LanczosSincFilter(radius, 3.0)
+        film = T.Film(res, T.Bounds2(crop[0], crop[1]), flt, 1.0, 1.0, "")
+        cam = T.PerspectiveCamera(T.look_at([0, 15, 50], [0, 0, -2], [0, 1, 0]), T.Bounds2([-1.0, -1.0], [1.0, 1.0]), 0.0, 1.0, 0.0, 1e6, 90.0, film)
+        ref_xyzw, ref_L, _ = osc.render(cam, "path", spp, 3, seed=5, want_samples=True)
+        sn = cam.sensor()
+        outs = {}
+        for mode in (0, 4, 5, 6, 7, 8, 9):
+            ctx.set_option("film_block", mode)
+            try:
+                out = np.empty_like(ref_xyzw)
+                ctx.check(T.lib().trhip_film_accumulate(ctx._h, C.byref(sn), spp, 5, 0, T._ffi.fptr(ref_L), T._ffi.fptr(out)))
+            finally:
+                ctx.set_option("film_block", 6)
+            assert_bits_equal(out, ref_xyzw, f"film {res}, radius {radius}, film_block={mode}")
+        # NaN samples are zeroed (integrators/sampler.jl:46): every variant against the one-pixel-per-thread gather
+        bad_L = ref_L.copy()
+        bad_L.reshape(-1, 3)[::97, 1] = np.nan
+        for mode in (0, 6, 4, 9):
+            ctx.set_option("film_block", mode)
+            try:
+                out = np.empty_like(ref_xyzw)
+                ctx.check(T.lib().trhip_film_accumulate(ctx._h, C.byref(sn), spp, 5, 0, T._ffi.fptr(bad_L), T._ffi.fptr(out)))
+            finally:
+                ctx.set_option("film_block", 6)
+            outs[mode] = out
+        for mode in (6, 4, 9):
+            assert_bits_equal(outs[mode], outs[0], f"NaN samples, film_block={mode}")
 
 
 def test_film_to_rgb(T, ob, ctx, shadows):
@@ -335,7 +373,7 @@ def test_partial_spheres_and_transforms(T, ob, ctx):
         osc2 = ob.OracleScene.from_scene(scene2, bvh=flat2.bvh())
         t2, prim2, _, _ = osc2.trace_closest(rays)
         occ2, _ = osc2.trace_any(rays)
-        for trav in (6, 4, 3, 2, 1):
+        for trav in (7, 6, 4, 3, 2, 1):
             ctx.set_option("traversal", trav)
             h2 = flat2.trace_closest(rays)
             assert np.array_equal(h2["prim"], prim2), trav

@@ -10,7 +10,7 @@ ap.add_argument("--spp", type=int, default=64)
 a = ap.parse_args()
 scene, cam = T.scenes.cornell_scene(), T.scenes.cornell_camera(1024)
 ctx = T.default_context()
-for mode in (0, 1, 2):
+for mode in (2, 3, 4, 5, 6, 7, 8, 9):
     ctx.set_option("film_block", mode)
     integ = T.PathIntegrator(cam, T.SeededSampler(a.spp, seed=1), 8)
     integ.render(scene, ctx)

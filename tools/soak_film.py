@@ -41,7 +41,8 @@ def main():
         res = [int(rng.integers(9, 90)), int(rng.integers(9, 90))]
         lo = rng.uniform(0.0, 0.4, 2) if k % 3 == 1 else np.zeros(2)
         hi = rng.uniform(0.6, 1.0, 2) if k % 3 == 1 else np.ones(2)
-        flt = T.LanczosSincFilter([float(rng.uniform(0.5, 3.5)), float(rng.uniform(0.5, 3.5))], float(rng.uniform(1.0, 4.0)))
+        rmax = 1.0 if k % 2 == 0 else 3.5  # half of the cases inside the packed descriptor's range (radius <= 1: the default path), half beyond it
+        flt = T.LanczosSincFilter([float(rng.uniform(0.3, rmax)), float(rng.uniform(0.3, rmax))], float(rng.uniform(1.0, 4.0)))
         film = T.Film(res, T.Bounds2([float(lo[0]), float(lo[1])], [float(hi[0]), float(hi[1])]), flt, 1.0, float(rng.uniform(0.5, 2.0)), "")
         cam = T.PerspectiveCamera(T.look_at([0, 15, 50], [0, 0, -2], [0, 1, 0]), T.Bounds2([-1.0, -1.0], [1.0, 1.0]), 0.0, 1.0, 0.0, 1e6, 90.0, film)
         spp = int(rng.integers(1, 6))
@@ -54,7 +55,8 @@ def main():
             ref_xyzw = None
         sn = cam.sensor()
         outs = {}
-        for name, opts in (("default", {}), ("block0", {"film_block": 0}), ("block1", {"film_block": 1}), ("block3", {"film_block": 3}), ("tiled", {"film_tiled": 1})):
+        for name, opts in (("default", {}), ("block0", {"film_block": 0}), ("block1", {"film_block": 1}), ("block2", {"film_block": 2}), ("block3", {"film_block": 3}), ("packed1x4", {"film_block": 4}),
+                           ("packed2x4", {"film_block": 5}), ("packed2x2", {"film_block": 7}), ("packed4x2", {"film_block": 8}), ("packed8x4", {"film_block": 9}), ("tiled", {"film_tiled": 1})):
             for o, v in opts.items():
                 ctx.set_option(o, v)
             try:
@@ -63,7 +65,7 @@ def main():
                 outs[name] = out
             finally:
                 for o in opts:
-                    ctx.set_option(o, {"film_block": 2, "film_tiled": 0}[o])
+                    ctx.set_option(o, {"film_block": 6, "film_tiled": 0}[o])
         msgs = []
         base = ref_xyzw if ref_xyzw is not None else outs["default"]
         for name, out in outs.items():
@@ -72,7 +74,7 @@ def main():
         bad += 1 if msgs else 0
         print(f"case {k:3d}: film {res[0]} x {res[1]}, crop {'yes' if k % 3 == 1 else 'no '}, radius ({flt.radius[0]:.2f}, {flt.radius[1]:.2f}), {spp} spp, "
               f"{'vs oracle' if ref_xyzw is not None else 'NaN samples, variants vs default'}: {'equal' if not msgs else 'MISMATCH ' + ', '.join(msgs)}", flush=True)
-    print(f"total: {a.cases} cases x 5 gather variants, {bad} with a mismatch")
+    print(f"total: {a.cases} cases x 11 gather variants, {bad} with a mismatch")
     sys.exit(1 if bad else 0)
 
 

@@ -115,7 +115,7 @@ def main():
         ctx.set_option("traversal", 1)
         h1, o1 = flat.trace_closest(rays), flat.trace_any(rays)
         bad = 0
-        for trav in ((3, 2, 6, 4) if a.wide else (3, 2, 6)):
+        for trav in ((3, 7, 2, 6, 4) if a.wide else (3, 7, 2, 6)):
             ctx.set_option("traversal", trav)
             h, o = flat.trace_closest(rays), flat.trace_any(rays)
             bad += int((h["prim"] != h1["prim"]).sum())
@@ -126,7 +126,7 @@ def main():
         if a.frames:  # whole frames too: every bounce and shadow ray of a small render, literal walk against all shortcuts
             cam = T.scenes.cornell_camera(a.frames)
             films = []
-            for trav in ((1, 3, 6, 4) if a.wide else (1, 3, 6)):
+            for trav in ((1, 3, 7, 6, 4) if a.wide else (1, 3, 7, 6)):
                 ctx.set_option("traversal", trav)
                 films.append(T.PathIntegrator(cam, T.SeededSampler(4, seed=100 + k), 6).render(scene, ctx).copy())
             for other in films[1:]:

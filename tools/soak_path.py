@@ -39,7 +39,7 @@ def main():
         ref_p, ref_L, st = osc.render(cam, "path", 4, 6, seed=500 + k, want_samples=True)
         ref_w, _, _ = osc.render(cam, "whitted", 2, 5, seed=500 + k)
         msgs = []
-        for trav in (3, 6, 2, 1):
+        for trav in (3, 7, 6, 2, 1):
             ctx.set_option("traversal", trav)
             try:
                 integ = T.PathIntegrator(cam, T.SeededSampler(4, seed=500 + k), 6)

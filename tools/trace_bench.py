@@ -114,7 +114,7 @@ def main():
                     ref[key] = res
                 node_bytes = 64 if trav == 2 else 32
                 # trav 2 counts node BOXES tested (2 per 64-byte fetch); trav 1 counts 32-byte nodes fetched
-                fetch_bytes = nodes * 96 if trav == 4 else ((nodes // 2) * 64 if trav in (2, 3) else nodes * 32)
+                fetch_bytes = nodes * 96 if trav == 4 else ((nodes // 2) * 64 if trav in (2, 3, 6, 7) else nodes * 32)
                 alg = 32 * nr + (16 if kind == "closest" else 1) * nr + fetch_bytes + 48 * prims
                 print(json.dumps({"rays": name, "n": nr, "kernel": kind, "traversal": trav, "ms": round(ms.value, 3), "Mray_s": round(nr / ms.value / 1e3, 1),
                                   "nodes_per_ray": round(nodes / nr, 2), "prims_per_ray": round(prims / nr, 2), "alg_GBps": round(alg / ms.value / 1e6, 1),

@@ -22,6 +22,7 @@
 #include "th_trace2.h"
 #include "th_trace8.h"
 #include "th_trace4.h"
+#include "th_trace7.h"
 #include "th_comm.h"
 
 using namespace th;
@@ -68,7 +69,9 @@ struct trhip_ctx {
                                      // (th_trace2.h, slab_test2); 0 = the reference's loose test alone (its exact visit set)
     int band_tile_rows = 0;          // DIAGNOSTIC / tests: render frames in bands of this many tile rows (0 = one band unless the samples do not fit in HBM)
     uint32_t tiny_scene_prims = 16;  // scenes of at most this many primitives get a single-leaf BVH (th_bvh.h); 0 = always build the hierarchy
-    int film_block = 2;  // film gather: 0 = one film pixel per thread, 1 = 2 x 2 pixels per thread, 2 (default) = TH_FILM_BX x TH_FILM_BY = 1 x 4, all three recomputing a
+    int film_block = 6;  // film gather: >= 4 (filter radius <= 1; wider filters run 2): from a 32-bit splat descriptor in the radiance record's .w lane, a thread owning
+                         // 4: 1 x 4, 5: 2 x 4, 6 (default): 4 x 4, 7: 2 x 2, 8: 4 x 2, 9: 8 x 4 film pixels (th_kernels.h, k_film_gather_packed);
+                         // 0 = one film pixel per thread, 1 = 2 x 2 pixels per thread, 2 = TH_FILM_BX x TH_FILM_BY = 1 x 4, all three recomputing a
                          // sample's pixel range and table indices per thread; 3 = 1 x 4 from per-sample splat descriptors (k_film_descriptors): measured SLOWER
                          // (1024^2, 256 spp: 29.0 ms against 24.3 ms: the 16-byte descriptor doubles the gather's loads and the arithmetic it saves was hidden)
     bool film_tiled = false;  // LDS-staged film gather (k_film_gather_tiled): bit-identical, measured 2.7x SLOWER than k_film_gather (11 % lane use), kept as an option
@@ -78,7 +81,8 @@ struct trhip_ctx {
     int compose_spheres = -1;  // commit: spheres as a chain of leaves above the triangles' subtree, what k_trace8 needs of a scene with spheres
                                // (option "compose_spheres": 1 / 0 = one SAH tree over everything / -1 = when "traversal" is 4 at commit time)
     int traversal = 3;  // 1 = literal accel/bvh.jl loop, 2 = children-in-parent nodes + per-lane ray replacement, 3 = 2 with leaves postponed (while-while),
-                        // 4 = 8-wide quantised nodes in the binary walk's order (th_trace8.h; scenes / rays it cannot take run 3), 6 = 3 with two rays per lane (th_trace4.h)
+                        // 4 = 8-wide quantised nodes in the binary walk's order (th_trace8.h; scenes / rays it cannot take run 3), 6 = 3 with two rays per lane (th_trace4.h),
+                        // 7 = closest-hit rays front to back with tie detection, flagged rays re-traced by 3 (th_trace7.h); any-hit rays as 3
     // workspace (grown on demand, reused across calls)
     DevBuf q[2][3], sq[3], hits, Lbuf, pfilm, counters, sensor, table, film, scratch[4], overflow, wh_L, wh_parent, wh_coef, wh_pdf, wh_flags, occl, film_Lt, surv_list, surv_counts;
     uint64_t last_L_count = 0;  // float4 entries valid in Lbuf
@@ -238,11 +242,14 @@ void launch_trace3(trhip_ctx* ctx, hipStream_t st, const trhip_scene* sc, bool a
                    const TraceOut& out, uint32_t* work_cursors, uint2* ov, Counters* ctr);
 void launch_trace4(trhip_ctx* ctx, hipStream_t st, const trhip_scene* sc, bool any, bool cnt, bool full_only, const SegQueue& q, const float4* ro, const float4* rd, const float* tmax,
                    const TraceOut& out, uint32_t* work_cursors, uint2* ov, Counters* ctr);
+void launch_trace7(trhip_ctx* ctx, hipStream_t st, const trhip_scene* sc, bool cnt, bool full_only, bool big, const SegQueue& q, const float4* ro, const float4* rd, const float* tmax,
+                   const TraceOut& out, uint32_t* work_cursors, uint2* ov, Counters* ctr, const FallbackList& fb);
 void launch_trace8(trhip_ctx* ctx, hipStream_t st, const trhip_scene* sc, bool any, bool cnt, bool full_only, const Wide8Scene& w8, const SegQueue& q, const float4* ro, const float4* rd,
                    const float* tmax, const TraceOut& out, uint32_t* work_cursors, uint32_t* ov8, Counters* ctr, const FallbackList& fb);
 // tu_path.hip
 void derive_sensor(const trhip_sensor* sn, DeviceSensor& d);
 bool film_uses_desc(const trhip_ctx* ctx, const DeviceSensor& ds);
+bool film_uses_packed(const trhip_ctx* ctx, const DeviceSensor& ds);
 int ensure_film_samples(trhip_ctx* ctx, const DeviceSensor& ds, uint64_t total_slots);
 void launch_film(trhip_ctx* ctx, hipStream_t st, const DeviceSensor& ds, const DeviceSensor* dsp, const float4* L, uint64_t total_slots, uint32_t spp, uint64_t seed, uint32_t sample_offset,
                  float4* d_film);

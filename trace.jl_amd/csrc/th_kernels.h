@@ -47,6 +47,7 @@ struct Counters {  // device-resident
     uint32_t work_shadow[kMaxDepth + 2][kSeg * kCtrStride];
     // per render call
     unsigned long long closest_total, shadow_total, nodes_closest, prims_closest, nodes_shadow, prims_shadow;
+    unsigned long long fallback_total;  // closest-hit rays k_trace7 handed to the reference-order walk (th_trace7.h)
 };
 // How a kernel sees a queue: kSeg segments of `cap` physical entries with fill counts in HBM, or (counts == nullptr) one
 // dense array of n_dense entries (kernel-level API entry points).
@@ -1049,6 +1050,208 @@ __global__ __launch_bounds__(kBlock) void k_film_gather_desc(const DeviceSensor*
         }
         for (int j = 0; j < BY; ++j)
             if (fy0 + j < se.film_h) out[(size_t)(fy0 + j) * (size_t)se.film_w + (size_t)fx0] = make_float4(xyz[j].x, xyz[j].y, xyz[j].z, wsum[j]);
+    }
+}
+
+// ---- film gather from a 32-bit splat descriptor carried in the radiance record itself (film_block >= 4, the default for filter radii <= 1) --------------
+// Counters of round 2 (profiles/r2): k_film_gather_block<1,4> moves 139 GB per 1024^2 x 256 spp frame (2 x FETCH_SIZE, coalesced 16 B / lane loads) in 24 ms:
+// 5.8 TB/s — it is bound by HBM, by RE-READS: every sample (16 B radiance + 8 B film position) is fetched by each of the ~10 threads whose pixels it can
+// reach, at re-read distances no cache covers, for 6.5 GB of distinct data.  Two levers, both taken here:
+//   * bytes per sample 24 -> 16: what a film pixel needs of camera_sample.film is the sample's pixel range and filter-table indices (film.jl:145-153) — for
+//     a radius <= 1 that is <= 4 columns x 4 rows: 1 + 1 bits of range origin (p0 - sample pixel in {-1, 0}), 2 + 2 bits of range length, 3 x 4 + 3 x 4 bits
+//     of table indices = 30 bits, which ride in the unused .w lane of the sample's float4 radiance record (k_film_pack_w; the integrators only ever
+//     read-modify-write whole records, so the lane survives).  A range of 4 columns or rows (p_film exactly on a half: ~1e-4 of the samples at 1024^2)
+//     does not fit: marked, and the gather recomputes that sample's descriptor from the sampler.  No film-position buffer, no pass that writes one.
+//   * a thread owns BX x BY film pixels with BX > 1: a 4 x 4 block re-reads 49 sample pixels for 16 film pixels (3.1x) instead of 28 for 4 (7x); what made
+//     large blocks slower before — ~300 VALU instructions per (sample, thread) recomputing ceil / floor ranges and table indices for every pixel — is gone:
+//     decode, two unsigned compares and a bit-field extract per column / row, one LDS lookup and the multiply-adds of add_sample! per pixel.
+// Per film pixel nothing changes: tiles in k order, sample pixels in Bounds2 order, samples in order, one csum per tile (film.jl:134-193); the arithmetic of
+// the descriptor is k_film_descriptors' (bit-identical to the reference's per-pixel computation: tests/test_gpu_parity.py, tools/soak_film.py).
+constexpr uint32_t kFilmPackException = 0xffffffffu;  // nx or ny = 4 (or a radius this encoding does not cover): recompute from the sampler
+TH_D uint4 film_splat_desc(const DeviceSensor& se, int px, int py, uint64_t key) {  // the SplatDesc of one camera sample (k_film_descriptors' arithmetic)
+    const float rx = se.filter_radius[0], ry = se.filter_radius[1];
+    const float inv_rx = 1.0f / rx, inv_ry = 1.0f / ry;
+    const float pfx = (float)px + ts_uniform(key, TS_DIM_FILM_X), pfy = (float)py + ts_uniform(key, TS_DIM_FILM_Y);  // camera_sample.film
+    const float dpx = pfx - 0.5f, dpy = pfy - 0.5f;
+    const float p0x = __builtin_ceilf(dpx - rx), p0y = __builtin_ceilf(dpy - ry);
+    const float p1x = __builtin_floorf(dpx + rx) + 1.0f, p1y = __builtin_floorf(dpy + ry) + 1.0f;
+    const int nx = (int)(p1x - p0x) + 1, ny = (int)(p1y - p0y) + 1;
+    uint32_t oxw = 0, oyw = 0;
+    for (int c = 0; c < 8; ++c) {
+        const float X = p0x + (float)c, Y = p0y + (float)c;
+        oxw |= (uint32_t)((int)jclamp(__builtin_ceilf(fabs_((X - dpx) * inv_rx * 16.0f)), 1.0f, 16.0f) - 1) << (4 * c);   // ceil for x …
+        oyw |= (uint32_t)((int)jclamp(__builtin_floorf(fabs_((Y - dpy) * inv_ry * 16.0f)), 1.0f, 16.0f) - 1) << (4 * c);  // … floor for y (A.9)
+    }
+    return make_uint4(((uint32_t)(int)p0x & 0xffffu) | ((uint32_t)(int)p0y << 16), (uint32_t)nx | ((uint32_t)ny << 8), oxw, oyw);
+}
+// 32-bit form: bit 0 / 1 = px - p0x / py - p0y (0 or 1), bits 2-3 / 4-5 = nx - 1 / ny - 1 (0..2), bits 6-17 = table index of columns 0..2, bits 18-29 = rows 0..2
+TH_D uint32_t film_pack_desc(uint4 d, int px, int py) {
+    const int p0x = (int)(short)(d.x & 0xffffu), p0y = (int)(short)(d.x >> 16);
+    const uint32_t nx = d.y & 0xffu, ny = (d.y >> 8) & 0xffu;
+    const int ox = px - p0x, oy = py - p0y;
+    if (ox < 0 || ox > 1 || oy < 0 || oy > 1 || nx < 1u || nx > 3u || ny < 1u || ny > 3u) return kFilmPackException;
+    return (uint32_t)ox | ((uint32_t)oy << 1) | ((nx - 1u) << 2) | ((ny - 1u) << 4) | ((d.z & 0xfffu) << 6) | ((d.w & 0xfffu) << 18);
+}
+// writes the descriptor into L[slot].w; the other lanes of the record are not touched (4-byte stores)
+static __global__ __launch_bounds__(kBlock) void k_film_pack_w(const DeviceSensor* __restrict__ sep, uint64_t n, uint64_t seed, uint32_t sample_offset, float4* __restrict__ L) {
+    const DeviceSensor& se = *sep;
+    for (uint64_t slot = (uint64_t)blockIdx.x * kBlock + threadIdx.x; slot < n; slot += (uint64_t)gridDim.x * kBlock) {
+        const SlotInfo si = slot_info(se, (uint32_t)slot);
+        const uint64_t key = ts_stream_key(seed, si.px, si.py, sample_offset + si.sample);
+        reinterpret_cast<uint32_t*>(L + slot)[3] = film_pack_desc(film_splat_desc(se, si.px, si.py, key), si.px, si.py);
+    }
+}
+#ifndef TH_FILM_PACKED_UNROLL
+#define TH_FILM_PACKED_UNROLL 8
+#endif
+template <int BX, int BY>
+__global__ __launch_bounds__(kBlock) void k_film_gather_packed(const DeviceSensor* __restrict__ sep, const float* __restrict__ table, const float4* __restrict__ L, uint32_t spp, uint64_t seed,
+                                                               uint32_t sample_offset, float4* __restrict__ out) {
+    const DeviceSensor& se = *sep;
+    __shared__ float s_table[256];
+    for (uint32_t t = threadIdx.x; t < 256u; t += kBlock) s_table[t] = table[t];
+    __syncthreads();
+    const uint32_t npix = (uint32_t)(se.sb_w * se.band_rows);
+    const float rx = se.filter_radius[0], ry = se.filter_radius[1];
+    const uint32_t nbx = ((uint32_t)se.film_w + BX - 1) / BX, nby = ((uint32_t)se.film_h + BY - 1) / BY;
+    for (uint32_t bidx = blockIdx.x * kBlock + threadIdx.x; bidx < nbx * nby; bidx += gridDim.x * kBlock) {
+        const int fy0 = (int)(bidx / nbx) * BY, fx0 = (int)(bidx - (bidx / nbx) * nbx) * BX;
+        float X[BX], Y[BY];
+        int Xi[BX], Yi[BY];
+        for (int i = 0; i < BX; ++i) {
+            X[i] = se.crop_min[0] + (float)(fx0 + i);
+            Xi[i] = (int)X[i];
+        }
+        for (int j = 0; j < BY; ++j) {
+            Y[j] = se.crop_min[1] + (float)(fy0 + j);
+            Yi[j] = (int)Y[j];
+        }
+        // union of the pixels' reaches (k_film_gather: sx in (X - 1.5 - r, X + r + 0.5])
+        const int sx_lo = max((int)__builtin_floorf(X[0] - 1.5f - rx), se.sb_min[0]), sx_hi = min((int)__builtin_ceilf(X[BX - 1] + rx + 0.5f), se.sb_max[0]);
+        const int sy_lo = max((int)__builtin_floorf(Y[0] - 1.5f - ry), se.sb_min[1]), sy_hi = min((int)__builtin_ceilf(Y[BY - 1] + ry + 0.5f), se.sb_max[1]);
+        f3 xyz[BY][BX];
+        float wsum[BY][BX];
+        for (int j = 0; j < BY; ++j)
+            for (int i = 0; i < BX; ++i) {
+                xyz[j][i] = splat3(0.0f);
+                wsum[j][i] = 0.0f;
+                if (se.accumulate && fx0 + i < se.film_w && fy0 + j < se.film_h) {  // a later band: add onto the tiles of the bands before (k order)
+                    const float4 prev = out[(size_t)(fy0 + j) * (size_t)se.film_w + (size_t)(fx0 + i)];
+                    xyz[j][i] = mk3(prev.x, prev.y, prev.z);
+                    wsum[j][i] = prev.w;
+                }
+            }
+        if (sx_lo <= sx_hi && sy_lo <= sy_hi) {
+            const int ty_lo = max((sy_lo - se.sb_min[1]) >> 4, se.band_ty0), ty_hi = min((sy_hi - se.sb_min[1]) >> 4, se.band_ty1);
+            const int tx_lo = (sx_lo - se.sb_min[0]) >> 4, tx_hi = (sx_hi - se.sb_min[0]) >> 4;
+            for (int ty = ty_lo; ty <= ty_hi; ++ty)
+                for (int tx = tx_lo; tx <= tx_hi; ++tx) {
+                    float bx0, by0, bx1, by1;
+                    film_tile_bounds(se, ty, tx, rx, ry, bx0, by0, bx1, by1);
+                    const float tbx0 = (float)se.sb_min[0] + (float)tx * 16.0f, tby0 = (float)se.sb_min[1] + (float)ty * 16.0f;
+                    const float tbx1 = jmin(tbx0 + 15.0f, (float)se.sb_max[0]), tby1 = jmin(tby0 + 15.0f, (float)se.sb_max[1]);
+                    // merge_film_tile! touches the pixel (film.jl:182-193); add_sample! clamps its range to the tile's film bounds and to 1 (film.jl:147-148)
+                    bool in_x[BX], ok_x[BX], in_y[BY], ok_y[BY];
+                    bool any_x = false, any_y = false;
+                    for (int i = 0; i < BX; ++i) {
+                        in_x[i] = !(X[i] < bx0 || X[i] > bx1);
+                        ok_x[i] = in_x[i] && !(X[i] < 1.0f);
+                        any_x = any_x || in_x[i];
+                    }
+                    for (int j = 0; j < BY; ++j) {
+                        in_y[j] = !(Y[j] < by0 || Y[j] > by1);
+                        ok_y[j] = in_y[j] && !(Y[j] < 1.0f);
+                        any_y = any_y || in_y[j];
+                    }
+                    if (!(any_x && any_y)) continue;
+                    f3 csum[BY][BX];
+                    float fws[BY][BX];
+                    for (int j = 0; j < BY; ++j)
+                        for (int i = 0; i < BX; ++i) {
+                            csum[j][i] = splat3(0.0f);
+                            fws[j][i] = 0.0f;
+                        }
+                    const int y0 = max(sy_lo, (int)tby0), y1 = min(sy_hi, (int)tby1);
+                    const int x0 = max(sx_lo, (int)tbx0), x1 = min(sx_hi, (int)tbx1);
+                    for (int sy = y0; sy <= y1; ++sy)
+                        for (int sx = x0; sx <= x1; ++sx) {
+                            const uint32_t pix = (uint32_t)(sy - se.band_y0) * (uint32_t)se.sb_w + (uint32_t)(sx - se.sb_min[0]);
+                            // offsets of the block's pixels from the sample pixel: the descriptor's range is relative to it
+                            int rxi[BX], ryi[BY];
+                            for (int i = 0; i < BX; ++i) rxi[i] = Xi[i] - sx;
+                            for (int j = 0; j < BY; ++j) ryi[j] = Yi[j] - sy;
+                            auto splat = [&](float4 l4, uint32_t s) {
+                                uint32_t d = __float_as_uint(l4.w);
+                                int p0x, p0y;  // relative to (sx, sy)
+                                uint32_t nx, ny, oxw, oyw;
+                                if (d == kFilmPackException) {  // a 4-wide range: this sample's full descriptor, from the sampler
+                                    const uint64_t key = ts_stream_key(seed, sx, sy, sample_offset + s);
+                                    const uint4 fd = film_splat_desc(se, sx, sy, key);
+                                    p0x = (int)(short)(fd.x & 0xffffu) - sx;
+                                    p0y = (int)(short)(fd.x >> 16) - sy;
+                                    nx = fd.y & 0xffu;
+                                    ny = (fd.y >> 8) & 0xffu;
+                                    oxw = fd.z;
+                                    oyw = fd.w;
+                                } else {
+                                    p0x = -(int)(d & 1u);
+                                    p0y = -(int)((d >> 1) & 1u);
+                                    nx = ((d >> 2) & 3u) + 1u;
+                                    ny = ((d >> 4) & 3u) + 1u;
+                                    oxw = (d >> 6) & 0xfffu;
+                                    oyw = (d >> 18) & 0xfffu;
+                                }
+                                uint32_t cx[BX], cy[BY];
+                                bool vx[BX], vy[BY];
+                                bool anyx = false, anyy = false;
+                                for (int i = 0; i < BX; ++i) {
+                                    cx[i] = (uint32_t)(rxi[i] - p0x);
+                                    vx[i] = ok_x[i] && cx[i] < nx;
+                                    anyx = anyx || vx[i];
+                                }
+                                for (int j = 0; j < BY; ++j) {
+                                    cy[j] = (uint32_t)(ryi[j] - p0y);
+                                    vy[j] = ok_y[j] && cy[j] < ny;
+                                    anyy = anyy || vy[j];
+                                }
+                                if (!(anyx && anyy)) return;
+                                f3 l = mk3(l4.x, l4.y, l4.z);
+                                if (has_nan(l)) l = splat3(0.0f);  // integrators/sampler.jl:46
+                                uint32_t oxi[BX];
+                                for (int i = 0; i < BX; ++i) oxi[i] = (oxw >> (4u * (cx[i] & 7u))) & 15u;
+                                for (int j = 0; j < BY; ++j)
+                                    if (vy[j]) {
+                                        const uint32_t row = ((oyw >> (4u * (cy[j] & 7u))) & 15u) * 16u;
+                                        for (int i = 0; i < BX; ++i)
+                                            if (vx[i]) {
+                                                const float w = s_table[row + oxi[i]];
+                                                csum[j][i] = csum[j][i] + l * w;  // contrib_sum += l * sample_weight (1) * w
+                                                fws[j][i] += w;
+                                            }
+                                    }
+                            };
+                            constexpr uint32_t kU = TH_FILM_PACKED_UNROLL;
+                            uint32_t s = 0;
+                            for (; s + kU <= spp; s += kU) {
+                                float4 lv[kU];
+#pragma unroll
+                                for (uint32_t u = 0; u < kU; ++u) lv[u] = L[(size_t)(s + u) * npix + pix];
+#pragma unroll
+                                for (uint32_t u = 0; u < kU; ++u) splat(lv[u], s + u);
+                            }
+                            for (; s < spp; ++s) splat(L[(size_t)s * npix + pix], s);
+                        }
+                    for (int j = 0; j < BY; ++j)
+                        for (int i = 0; i < BX; ++i)
+                            if (in_x[i] && in_y[j]) {
+                                xyz[j][i] = xyz[j][i] + rgb_to_xyz(csum[j][i]);
+                                wsum[j][i] += fws[j][i];
+                            }
+                }
+        }
+        for (int j = 0; j < BY; ++j)
+            for (int i = 0; i < BX; ++i)
+                if (fx0 + i < se.film_w && fy0 + j < se.film_h) out[(size_t)(fy0 + j) * (size_t)se.film_w + (size_t)(fx0 + i)] = make_float4(xyz[j][i].x, xyz[j][i].y, xyz[j][i].z, wsum[j][i]);
     }
 }
 

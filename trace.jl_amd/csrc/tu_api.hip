@@ -194,7 +194,7 @@ int trhip_set_option(trhip_ctx* ctx, const char* name, int64_t value) {
     else if (!std::strcmp(name, "tiny_scene_prims"))
         ctx->tiny_scene_prims = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(255, value));
     else if (!std::strcmp(name, "film_block"))
-        ctx->film_block = (int)std::max<int64_t>(0, std::min<int64_t>(3, value));
+        ctx->film_block = (int)std::max<int64_t>(0, std::min<int64_t>(9, value));
     else if (!std::strcmp(name, "film_tiled"))
         ctx->film_tiled = value != 0;
     else if (!std::strcmp(name, "pipelines")) {
@@ -203,7 +203,7 @@ int trhip_set_option(trhip_ctx* ctx, const char* name, int64_t value) {
     } else if (!std::strcmp(name, "overlap"))
         ctx->overlap = value != 0;
     else if (!std::strcmp(name, "traversal")) {
-        if (value < 1 || value > 6 || value == 5) return fail(ctx, TRHIP_ERR_INVALID, "traversal must be 1, 2, 3, 4 or 6");
+        if (value < 1 || value > 7 || value == 5) return fail(ctx, TRHIP_ERR_INVALID, "traversal must be 1, 2, 3, 4, 6 or 7");
         ctx->traversal = (int)value;
     } else if (!std::strcmp(name, "batch_paths")) {
         if (value < 0) return fail(ctx, TRHIP_ERR_INVALID, "batch_paths must be >= 0 (0 = auto)");

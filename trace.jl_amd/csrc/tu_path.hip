@@ -42,13 +42,35 @@ void derive_sensor(const trhip_sensor* sn, DeviceSensor& d) {
 bool film_uses_desc(const trhip_ctx* ctx, const DeviceSensor& ds) {
     return ctx->film_block == 3 && !ctx->film_tiled && !ctx->film_transpose && std::fmax(ds.filter_radius[0], ds.filter_radius[1]) <= 3.0f && ds.film_w < 32000 && ds.film_h < 32000;
 }
-// the per-sample buffer the film pass needs next to the radiance: descriptors (16 B) or film positions (8 B)
+// film_block >= 4: the gather reads a 32-bit descriptor from the .w lane of the radiance records (k_film_pack_w / k_film_gather_packed); needs a filter radius <= 1
+// (<= 4 columns / rows per sample) — every scene of the reference uses LanczosSincFilter(Point2f(1f0), 3f0)
+bool film_uses_packed(const trhip_ctx* ctx, const DeviceSensor& ds) {
+    return ctx->film_block >= 4 && !ctx->film_tiled && !ctx->film_transpose && std::fmax(ds.filter_radius[0], ds.filter_radius[1]) <= 1.0f && ds.filter_radius[0] > 0.0f && ds.filter_radius[1] > 0.0f;
+}
+// the per-sample buffer the film pass needs next to the radiance: nothing (packed), descriptors (16 B) or film positions (8 B)
 int ensure_film_samples(trhip_ctx* ctx, const DeviceSensor& ds, uint64_t total_slots) {
+    if (film_uses_packed(ctx, ds)) return 0;
     if (film_uses_desc(ctx, ds)) return ensure(ctx, ctx->fdesc, total_slots * sizeof(uint4));
     return ensure(ctx, ctx->pfilm, total_slots * sizeof(float2));
 }
 void launch_film(trhip_ctx* ctx, hipStream_t st, const DeviceSensor& ds, const DeviceSensor* dsp, const float4* L, uint64_t total_slots, uint32_t spp, uint64_t seed, uint32_t sample_offset,
                  float4* d_film) {
+    if (film_uses_packed(ctx, ds)) {
+        hipLaunchKernelGGL(k_film_pack_w, dim3(grid_for(ctx, total_slots, 8)), dim3(kBlock), 0, st, dsp, total_slots, seed, sample_offset, const_cast<float4*>(L));
+        const float* tb = (const float*)ctx->table.p;
+        auto threads = [&](int bx, int by) { return (uint64_t)((ds.film_w + bx - 1) / bx) * (uint64_t)((ds.film_h + by - 1) / by); };
+#define TH_FILM_PACKED(BXV, BYV) hipLaunchKernelGGL((k_film_gather_packed<BXV, BYV>), dim3(grid_for(ctx, threads(BXV, BYV), 8)), dim3(kBlock), 0, st, dsp, tb, L, spp, seed, sample_offset, d_film)
+        switch (ctx->film_block) {
+        case 4: TH_FILM_PACKED(1, 4); break;
+        case 5: TH_FILM_PACKED(2, 4); break;
+        case 7: TH_FILM_PACKED(2, 2); break;
+        case 8: TH_FILM_PACKED(4, 2); break;
+        case 9: TH_FILM_PACKED(8, 4); break;
+        default: TH_FILM_PACKED(4, 4); break;  // 6
+        }
+#undef TH_FILM_PACKED
+        return;
+    }
     if (film_uses_desc(ctx, ds) && ctx->fdesc.bytes >= total_slots * sizeof(uint4)) {
         hipLaunchKernelGGL(k_film_descriptors, dim3(grid_for(ctx, total_slots, 8)), dim3(kBlock), 0, st, dsp, total_slots, seed, sample_offset, (uint4*)ctx->fdesc.p);
         const uint64_t nthreads = (uint64_t)ds.film_w * ((ds.film_h + 3) / 4);
@@ -83,9 +105,10 @@ void launch_film(trhip_ctx* ctx, hipStream_t st, const DeviceSensor& ds, const D
         hipLaunchKernelGGL(k_film_gather_tiled, grid, dim3(kBlock), (size_t)cols * ns * 20 + 16, st, dsp, (const float*)ctx->table.p, L, (const float2*)ctx->pfilm.p, spp, layout, cols, ns, d_film);
     } else {
         const uint64_t npx = (uint64_t)ds.film_w * ds.film_h;
-        if (ctx->film_block == 1)
+        const int fblock = ctx->film_block >= 4 ? 2 : ctx->film_block;  // a filter too wide for the packed descriptor: the 1 x 4 block gather
+        if (fblock == 1)
             hipLaunchKernelGGL((k_film_gather_block<2, 2>), dim3(grid_for(ctx, (npx + 3) / 4, 8)), dim3(kBlock), 0, st, dsp, (const float*)ctx->table.p, L, (const float2*)ctx->pfilm.p, spp, layout, d_film);
-        else if (ctx->film_block == 2)
+        else if (fblock == 2)
             hipLaunchKernelGGL((k_film_gather_block<TH_FILM_BX, TH_FILM_BY>), dim3(grid_for(ctx, (npx + TH_FILM_BX * TH_FILM_BY - 1) / (TH_FILM_BX * TH_FILM_BY), 8)), dim3(kBlock), 0, st, dsp, (const float*)ctx->table.p, L, (const float2*)ctx->pfilm.p, spp, layout, d_film);
         else
             hipLaunchKernelGGL(k_film_gather, dim3(grid_for(ctx, npx, 8)), dim3(kBlock), 0, st, dsp, (const float*)ctx->table.p, L, (const float2*)ctx->pfilm.p, spp, layout, d_film);
@@ -266,6 +289,7 @@ int render_stream_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sen
         stats->prims_tested = h.prims_closest;
         stats->nodes_visited_shadow = h.nodes_shadow;
         stats->prims_tested_shadow = h.prims_shadow;
+        stats->fallback_rays = h.fallback_total;
         float ms = 0;
         (void)hipEventElapsedTime(&ms, e0, e1);
         stats->ms_total = ms;
@@ -335,6 +359,7 @@ int render_impl_band(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
             stats->prims_tested = h.prims_closest;
             stats->nodes_visited_shadow = h.nodes_shadow;
             stats->prims_tested_shadow = h.prims_shadow;
+            stats->fallback_rays = h.fallback_total;
             stats->ms_total = ms;
             stats->max_depth_reached = (uint32_t)max_depth;
         traversal_info(ctx, scene, &stats->traversal, &stats->node_bytes);
@@ -511,6 +536,7 @@ int render_impl_band(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
             stats->prims_tested += h.prims_closest;
             stats->nodes_visited_shadow += h.nodes_shadow;
             stats->prims_tested_shadow += h.prims_shadow;
+            stats->fallback_rays += h.fallback_total;
         }
         float ms = 0;
         (void)hipEventElapsedTime(&ms, e0, e1);
@@ -556,7 +582,7 @@ int render_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sensor* se
             }
             // half of what is free for the per-sample buffers, the rest for the wavefront queues (164 B per path in flight); 32-bit slot indices
             const double budget = std::min(0.5 * (double)(free_b + held), 4.0e9 * 24.0);
-            const double row_bytes = (double)ds.sb_w * 16.0 * (double)spp * (film_uses_desc(ctx, ds) ? 33.0 : 25.0);  // radiance + descriptor / film position + poison byte
+            const double row_bytes = (double)ds.sb_w * 16.0 * (double)spp * (film_uses_packed(ctx, ds) ? 17.0 : film_uses_desc(ctx, ds) ? 33.0 : 25.0);  // radiance (+ descriptor / film position) + poison byte
             rows_per_band = (int)std::max(1.0, std::min((double)ds.tiles_y, std::floor(budget / row_bytes)));
             while (rows_per_band > 1 && (uint64_t)ds.sb_w * 16ull * (uint64_t)rows_per_band * spp >= (1ull << 32)) --rows_per_band;
         }
@@ -587,6 +613,7 @@ int render_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sensor* se
         sum.prims_tested += st.prims_tested;
         sum.nodes_visited_shadow += st.nodes_visited_shadow;
         sum.prims_tested_shadow += st.prims_tested_shadow;
+        sum.fallback_rays += st.fallback_rays;
         sum.ms_total += st.ms_total;
         sum.ms_raygen += st.ms_raygen;
         sum.ms_trace_closest += st.ms_trace_closest;

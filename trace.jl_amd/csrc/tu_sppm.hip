@@ -280,6 +280,7 @@ int render_sppm_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
         stats->prims_tested = h.prims_closest;
         stats->nodes_visited_shadow = h.nodes_shadow;
         stats->prims_tested_shadow = h.prims_shadow;
+        stats->fallback_rays = h.fallback_total;
         float ms = 0;
         (void)hipEventElapsedTime(&ms, e0, e1);
         stats->ms_total = ms;

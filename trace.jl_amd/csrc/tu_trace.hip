@@ -24,6 +24,9 @@ WideScene wide_view(const trhip_ctx* ctx, const trhip_scene* sc) {
 // One place for the rule: launch_trace and the byte model of trhip_stats (traversal_info) must agree.
 static bool uses_trace8(const trhip_ctx* ctx, const trhip_scene* sc) { return ctx->traversal == 4 && sc->w8_ok && ctx->slab_margin_log2 > 0 && ctx->pipelines <= 1; }
 
+// k_trace7 (traversal 7) takes the closest-hit launches of scenes with a hierarchy when the tight slab clauses are on (its margins derive from them)
+static bool uses_trace7(const trhip_ctx* ctx, const trhip_scene* sc) { return ctx->traversal == 7 && sc->wide_ok && sc->wide.root_cnt == 0 && ctx->slab_margin_log2 > 0 && ctx->pipelines <= 1; }
+
 // which kernel launch_trace picks for this scene, and the bytes one unit of the visit counters stands for (trhip_stats)
 void traversal_info(const trhip_ctx* ctx, const trhip_scene* sc, uint32_t* trav, uint32_t* node_bytes) {
     uint32_t t = 1, nb = 32;
@@ -38,6 +41,8 @@ void traversal_info(const trhip_ctx* ctx, const trhip_scene* sc, uint32_t* trav,
             nb = 96;
         } else if (ctx->traversal == 6) {
             t = 6;
+        } else if (uses_trace7(ctx, sc)) {
+            t = 7;
         } else {
             t = ctx->traversal >= 3 ? 3 : 2;
         }
@@ -91,6 +96,21 @@ void launch_trace(trhip_ctx* ctx, hipStream_t st, const trhip_scene* sc, bool an
                 uint32_t* ov8 = (uint32_t*)ctx->ov8[w].p;
                 launch_trace8(ctx, st, sc, any, cnt, full_only, w8, q, ro, rd, tmax, out, work_cursors, ov8, ctr, fb);
                 q = SegQueue{fcounts, fcap, 0u, fb.list, 1u};
+                work_cursors = fcounts + (size_t)kSeg * kCtrStride;
+            }
+        }
+        // ---- traversal 7: closest-hit rays front to back (th_trace7.h); the rays whose answer depends on the visiting order come back on ONE fallback list
+        //      (segment 0 of a SegQueue whose other segments are empty) that k_trace3 walks below ----
+        if (!any && uses_trace7(ctx, sc) && !q.indirect) {
+            const uint64_t total = q.counts ? (uint64_t)q.cap * kSeg : q.n_dense;
+            const size_t ctr_words = 2 * (size_t)kSeg * kCtrStride;  // counts, then the work cursors of the fallback launch
+            if (total < (1ull << 32) && ensure(ctx, ctx->fb_list[0], (size_t)total * sizeof(uint32_t)) == 0 && ensure(ctx, ctx->fb_counts[0], ctr_words * sizeof(uint32_t)) == 0) {
+                uint32_t* fcounts = (uint32_t*)ctx->fb_counts[0].p;
+                (void)hipMemsetAsync(fcounts, 0, ctr_words * sizeof(uint32_t), st);
+                const FallbackList fb{(uint32_t*)ctx->fb_list[0].p, fcounts, (uint32_t)total};
+                const bool big7 = !cnt && (size_t)sc->wide.n_wnodes * 64u + (size_t)sc->dev.n_prims * 48u > ((size_t)256 << 20);
+                launch_trace7(ctx, st, sc, cnt, full_only, big7, q, ro, rd, tmax, out, work_cursors, ov, ctr, fb);
+                q = SegQueue{fcounts, (uint32_t)total, 0u, fb.list, 1u};
                 work_cursors = fcounts + (size_t)kSeg * kCtrStride;
             }
         }
