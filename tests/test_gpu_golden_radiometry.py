@@ -9,9 +9,11 @@ save(), reduced to the fixture's 128 x 128 block means (tests/golden/make_golden
 
 Tolerances (8-bit units), and why: SPPM is consistent, not unbiased — a pixel's estimate blurs the flux over its current search radius, which shrinks
 with the iteration count — so blocks crossed by a caustic or shadow EDGE differ between two iteration counts by tens of units, while flat regions agree to
-the photon noise of a 64-pixel mean (~ 1 unit at 100 iterations).  Hence: the MEDIAN block difference <= 1.5, 90 % of the blocks within 6, 99 % within 24;
-per-channel means of the whole picture within 1.5; fraction of exactly black pixels within 1 %; named flat regions (wall, direct-lit floor, sphere
-interiors, the mirror sphere's black reflection, the empty right margin) within 4.  Measured when the test was written: see DESIGN.md §5 / profiles/r3.
+the photon noise of a 64-pixel mean (~ 1 unit at 100 iterations).  Hence: the MEDIAN block difference <= 0.5, 90 % of the blocks within 2, 99 % within 8;
+per-channel means of the whole picture within 0.3; fraction of exactly black pixels within 0.2 %; named flat regions (wall, direct-lit floor, sphere
+interiors, the mirror sphere's black reflection, the empty right margin) within 3.  Measured when the test was written (profiles/r3/r3b_golden_radiometry.txt):
+median 0.08, p90 0.61, p99 2.2, max 14.0 (a caustic edge); channel means 96.90 / 94.94 / 99.20 against the picture's 96.89 / 94.94 / 99.19; black fraction
+0.33336 against 0.33356 — the bounds leave a factor ~4 for another seed / iteration count.
 A wrong BSDF constant, light falloff, film weight, colour matrix, clamp or flip moves these numbers by tens of units."""
 import os
 
@@ -54,14 +56,14 @@ def test_gpu_sppm_render_matches_the_reference_png_statistically(T, ctx):
              "channel_mean": img.reshape(-1, 3).mean(0).round(3).tolist(), "ref_channel_mean": fx["channel_mean"].round(3).tolist(),
              "black_fraction": float((img.astype(np.uint32).sum(-1) == 0).mean()), "ref_black_fraction": float(fx["black_fraction"]), "ms": round(st.ms_total, 1)}
     print("golden radiometry:", stats)
-    assert stats["median"] <= 1.5, stats
-    assert stats["p90"] <= 6.0, stats
-    assert stats["p99"] <= 24.0, stats
-    assert np.all(np.abs(img.reshape(-1, 3).mean(0) - fx["channel_mean"]) <= 1.5), stats
-    assert abs(stats["black_fraction"] - stats["ref_black_fraction"]) <= 0.01, stats
+    assert stats["median"] <= 0.5, stats
+    assert stats["p90"] <= 2.0, stats
+    assert stats["p99"] <= 8.0, stats
+    assert np.all(np.abs(img.reshape(-1, 3).mean(0) - fx["channel_mean"]) <= 0.3), stats
+    assert abs(stats["black_fraction"] - stats["ref_black_fraction"]) <= 0.002, stats
     for name, (rows, cols) in REGIONS.items():
         a, b = blocks[rows, cols].mean((0, 1)), ref_blocks[rows, cols].mean((0, 1))
-        assert np.all(np.abs(a - b) <= 4.0), f"{name}: {a.round(2)} vs the reference's {b.round(2)}"
+        assert np.all(np.abs(a - b) <= 3.0), f"{name}: {a.round(2)} vs the reference's {b.round(2)}"
     # the margin right of the back wall is EXACTLY black in both (no geometry, no light: Ld = tau = 0 -> 0 after the clamp)
     assert blocks[:, 118:].max() == 0.0 and ref_blocks[:, 118:].max() == 0.0
 

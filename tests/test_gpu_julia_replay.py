@@ -65,6 +65,12 @@ def test_replayed_sppm(T, ctx):
     integ = T.SPPMIntegrator(cam, 0.08, 5, 2, 20000, seed=11)
     r = jr.ShimReplay(T, T._ffi.LIB_PATH, ctx._h)
     got, _ = r.render_sppm(scene, integ)
-    ref = integ.render(scene, ctx)
+    ctx.set_option("bvh_builder", 2)  # the shim hands Trace.jl's own tree over (EXACT_TREE): the host side must walk the same one
+    try:
+        scene._flat = None
+        ref = integ.render(scene, ctx)
+    finally:
+        ctx.set_option("bvh_builder", -1)
+        scene._flat = None
     np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-4 * np.abs(ref).max())  # Float32 flux sums are not ordered from run to run
     assert np.all(got[..., 3] == 1.0)

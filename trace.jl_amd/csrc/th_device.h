@@ -613,6 +613,66 @@ TH_D f3 bsdf_f(const LobeSet& b, const Shading& s, f3 wo_w, f3 wi_w, int flags) 
     }
     return out;
 }
+// bsdf_f for MANY wi against ONE (frame, wo) — the SPPM gather evaluates a visible point's BSDF for every photon inside its radius (sppm.jl:374-391).  What
+// bsdf_f derives from (frame, wo) alone is evaluated once: wo in the local frame, wo · ng, and Λ(wo) of the microfacet lobes (three square roots and three
+// divisions of tr_lambda: a quarter of the plastic floor's BSDF).  Every operation of bsdf_f / lobe_f is kept, in its order — G = 1 / ((1 + Λ(wo)) + Λ(wi)) —
+// so the value is bsdf_f's bit for bit (tests/test_gpu_sppm.py compares the gather with the oracle's bsdf evaluation per photon).
+struct BsdfWo {
+    f3 wo;         // bsdf_to_local(s, wo_w)
+    float wo_ng;   // dot(wo_w, s.ng)
+    float lam[2];  // tr_lambda(α_x, α_y, wo) of lobe i where it is a microfacet lobe (a LobeSet holds at most two lobes)
+};
+TH_D BsdfWo bsdf_wo_terms(const LobeSet& b, const Shading& s, f3 wo_w) {
+    BsdfWo p;
+    p.wo = bsdf_to_local(s, wo_w);
+    p.wo_ng = dot(wo_w, s.ng);
+    for (int i = 0; i < 2; ++i) {
+        const bool mf = i < b.n && (b.lobe[i].kind == LOBE_MICROFACET_R || b.lobe[i].kind == LOBE_MICROFACET_T);
+        p.lam[i] = mf ? tr_lambda(b.lobe[i].a, b.lobe[i].b, p.wo) : 0.0f;
+    }
+    return p;
+}
+TH_D f3 lobe_f_wo(const Lobe& l, f3 wo, f3 wi, float lam_o) {
+    switch (l.kind) {
+    case LOBE_MICROFACET_R: {  // microfacet.jl:221-234, as lobe_f
+        const float cos_o = fabs_(cos_theta(wo)), cos_i = fabs_(cos_theta(wi));
+        f3 wh = wi + wo;
+        if (cos_i == 0.0f || cos_o == 0.0f) return splat3(0.0f);
+        if (vec_isapprox_zero(wh)) return splat3(0.0f);
+        wh = normalize(wh);
+        const f3 f = lobe_fresnel(l, dot(wi, face_forward(wh, mk3(0.0f, 0.0f, 1.0f))));
+        const float g = 1.0f / (1.0f + lam_o + tr_lambda(l.a, l.b, wi));  // tr_G
+        return lobe_r(l) * tr_D(l.a, l.b, wh) * g * f / (4.0f * cos_i * cos_o);
+    }
+    case LOBE_MICROFACET_T: {  // microfacet.jl:281-304, as lobe_f
+        if (same_hemisphere(wo, wi)) return splat3(0.0f);
+        const float cos_o = cos_theta(wo), cos_i = cos_theta(wi);
+        if (cos_o == 0.0f || cos_i == 0.0f) return splat3(0.0f);
+        const float eta = cos_theta(wo) > 0.0f ? (l.eta_b / l.eta_a) : (l.eta_a / l.eta_b);
+        f3 wh = normalize(wo + wi * eta);
+        if (wh.z < 0.0f) wh = -wh;
+        const float d_o = dot(wo, wh), d_i = dot(wi, wh);
+        if (d_o * d_i > 0.0f) return splat3(0.0f);
+        const f3 f = lobe_fresnel(l, d_o);
+        const float denom = d_o + eta * d_i;
+        const float factor = 1.0f;
+        const float dd = tr_D(l.a, l.b, wh), dg = 1.0f / (1.0f + lam_o + tr_lambda(l.a, l.b, wi));
+        return (splat3(1.0f) - f) * lobe_r(l) * fabs_(dd * dg * d_o * d_i * (eta * eta) * (factor * factor) / (cos_i * cos_o * (denom * denom)));
+    }
+    default: return lobe_f(l, wo, wi);
+    }
+}
+TH_D f3 bsdf_f_wo(const LobeSet& b, const Shading& s, const BsdfWo& pre, f3 wi_w, int flags) {
+    if (pre.wo.z == 0.0f) return splat3(0.0f);
+    const f3 wi = bsdf_to_local(s, wi_w);
+    const bool refl = (dot(wi_w, s.ng) * pre.wo_ng) > 0.0f;
+    f3 out = splat3(0.0f);
+    for (int i = 0; i < b.n; ++i) {
+        const Lobe& l = b.lobe[i];
+        if (lobe_matches(l, flags) && ((refl && (l.type & BSDF_REFLECTION) != 0) || (!refl && (l.type & BSDF_TRANSMISSION) != 0))) out = out + lobe_f_wo(l, pre.wo, wi, pre.lam[i < 2 ? i : 1]);
+    }
+    return out;
+}
 // :177-193
 TH_D float bsdf_pdf(const LobeSet& b, const Shading& s, f3 wo_w, f3 wi_w, int flags) {
     if (b.n == 0) return 0.0f;

@@ -99,6 +99,10 @@ struct GridInfo {  // device-resident
     unsigned long long photon_hits;    // in-bounds photon hits, all iterations of the call
     unsigned long long registrations;  // (visible point, cell) pairs = list nodes of the reference's grid, last iteration
     uint32_t n_hot;                    // pixels deferred to k_sppm_gather_hot
+    // option "count_visits" (trhip_stats::count_sub), summed over the iterations of the call: what the gather's byte model is made of
+    unsigned long long stat_candidates;     // (pixel, photon) pairs distance-tested
+    unsigned long long stat_accepted;       // pairs inside the radius: BSDF evaluated
+    unsigned long long stat_visible_points; // pixels with a visible point
 };
 TH_D uint32_t enc_f32(float f) {
     const uint32_t b = __float_as_uint(f);
@@ -729,7 +733,7 @@ TH_D GatherSum gather_pixel(const DeviceScene& sc, const PhotonRecords& rec, con
 #define TH_SPPM_HOT_WAVES 4  // 144 VGPRs unconstrained (3 waves); capped at 4: C4 shading section 160.4 -> 156.4 ms
 #endif
 static __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TH_SPPM_GATHER_WAVES))) void k_sppm_gather(DeviceScene sc, PhotonRecords rec, VisiblePoints vp, PixelStats px, uint32_t n, GridInfo* gp, const uint32_t* __restrict__ starts,
-                                                        const float4* __restrict__ hit_sorted, uint32_t hash_size, uint32_t* __restrict__ hot_list, uint32_t count_registrations) {
+                                                        const float4* __restrict__ hit_sorted, uint32_t hash_size, uint32_t* __restrict__ hot_list, uint32_t count_registrations, uint32_t count_stats) {
     // A wave takes 64 pixels.  Every lane walks the buckets of ITS pixel one candidate per round (a cursor over cells and entries);
     // the (pixel, photon) pairs that pass the distance test are parked in a per-wave ring and evaluated 64 at a time — frame and
     // material of the pair's pixel are fetched by whichever lane gets the pair — and summed per pixel in LDS.  (One thread per pixel
@@ -739,14 +743,17 @@ static __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(T
     __shared__ uint32_t s_src[kBlock / 64][128];    // … and the lane whose pixel it belongs to
     __shared__ float s_phi[kBlock / 64][64][3];
     __shared__ uint32_t s_m[kBlock / 64][64];
+    // the wave's 64 visible points as the BSDF needs them, staged once per batch of pixels: frame (ss, ts, ns, ng: 12 floats), what bsdf_f derives from wo
+    // alone (BsdfWo: 6 floats, th_device.h) and the material — [word][lane], so that a lane shading a parked pair reads its pixel's column from LDS instead of
+    // re-fetching six 16-byte records per pair
+    __shared__ float s_vp[kBlock / 64][19][64];
     const GridInfo& g = *gp;
     if (!g.valid) return;
     const uint32_t lane = lane_id(), wv = threadIdx.x >> 6;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    unsigned long long n_reg = 0;
+    unsigned long long n_reg = 0, n_cand = 0, n_acc = 0, n_vp = 0;
     const uint32_t total = (n + 63u) & ~63u;
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < total; i += gridDim.x * kBlock) {
-        const uint32_t base = i - lane;  // the wave's first pixel
         bool hot = false, walk = false;
         float4 p4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         float rad = 0.0f;
@@ -754,6 +761,7 @@ static __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(T
         if (i < n) {
             const float4 b = vp.beta[i];
             if (!(b.x == 0.0f && b.y == 0.0f && b.z == 0.0f)) {
+                n_vp++;
                 p4 = vp.p_mat[i];
                 rad = px.radius[i];
                 to_grid(g, mk3(p4.x - rad, p4.y - rad, p4.z - rad), lo);
@@ -768,6 +776,7 @@ static __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(T
                         }
                 hot = candidates > kHotCandidates;
                 walk = !hot && candidates > 0;
+                n_cand += candidates;  // hot pixels too: k_sppm_gather_hot tests every one of them
             }
         }
         const uint32_t k = wave_compact(hot, &gp->n_hot);
@@ -775,6 +784,25 @@ static __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(T
         if (__ballot(walk) == 0ull) continue;
         s_phi[wv][lane][0] = s_phi[wv][lane][1] = s_phi[wv][lane][2] = 0.0f;
         s_m[wv][lane] = 0u;
+        if (walk) {  // this lane's visible point, for whichever lane shades one of its pairs
+            const float4 wo4 = vp.wo[i], ng4 = vp.ng[i], ns4 = vp.ns[i], ss4 = vp.ss[i], ts4 = vp.ts[i];
+            Shading vs;
+            vs.p = mk3(p4.x, p4.y, p4.z);
+            vs.wo = mk3(wo4.x, wo4.y, wo4.z);
+            vs.ng = mk3(ng4.x, ng4.y, ng4.z);
+            vs.ns = mk3(ns4.x, ns4.y, ns4.z);
+            vs.ss = mk3(ss4.x, ss4.y, ss4.z);
+            vs.ts = mk3(ts4.x, ts4.y, ts4.z);
+            const BsdfWo pre = bsdf_wo_terms(sc.materials[__float_as_uint(p4.w)].set[1], vs, vs.wo);
+            float* col = &s_vp[wv][0][lane];
+            col[0 * 64] = vs.ss.x, col[1 * 64] = vs.ss.y, col[2 * 64] = vs.ss.z;
+            col[3 * 64] = vs.ts.x, col[4 * 64] = vs.ts.y, col[5 * 64] = vs.ts.z;
+            col[6 * 64] = vs.ns.x, col[7 * 64] = vs.ns.y, col[8 * 64] = vs.ns.z;
+            col[9 * 64] = vs.ng.x, col[10 * 64] = vs.ng.y, col[11 * 64] = vs.ng.z;
+            col[12 * 64] = pre.wo.x, col[13 * 64] = pre.wo.y, col[14 * 64] = pre.wo.z;
+            col[15 * 64] = pre.wo_ng, col[16 * 64] = pre.lam[0], col[17 * 64] = pre.lam[1];
+            col[18 * 64] = p4.w;
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         const f3 vpp = mk3(p4.x, p4.y, p4.z);
         // cursor: cell (cx, cy, cz), entries [e, e1) of its bucket
@@ -788,18 +816,22 @@ static __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(T
         uint32_t ring_head = 0, ring_cnt = 0;  // wave-uniform
         auto shade = [&](uint32_t cnt) {        // the first cnt parked pairs, one per lane
             if (lane < cnt) {
-                const uint32_t r = s_ring[wv][(ring_head + lane) & 127u], src = s_src[wv][(ring_head + lane) & 127u], j = base + src;
-                const float4 q4 = vp.p_mat[j], wo4 = vp.wo[j], ng4 = vp.ng[j], ns4 = vp.ns[j], ss4 = vp.ss[j], ts4 = vp.ts[j];
-                Shading vs;
-                vs.p = mk3(q4.x, q4.y, q4.z);
-                vs.wo = mk3(wo4.x, wo4.y, wo4.z);
-                vs.ng = mk3(ng4.x, ng4.y, ng4.z);
-                vs.ns = mk3(ns4.x, ns4.y, ns4.z);
-                vs.ss = mk3(ss4.x, ss4.y, ss4.z);
-                vs.ts = mk3(ts4.x, ts4.y, ts4.z);
+                const uint32_t r = s_ring[wv][(ring_head + lane) & 127u], src = s_src[wv][(ring_head + lane) & 127u];
                 const float4 w4 = rec.wi[r], b4 = rec.beta[r];
-                const LobeSet& vb = sc.materials[__float_as_uint(q4.w)].set[1];
-                const f3 c = mk3(b4.x, b4.y, b4.z) * bsdf_f(vb, vs, vs.wo, mk3(w4.x, w4.y, w4.z), BSDF_ALL);
+                const float* col = &s_vp[wv][0][src];
+                Shading vs;  // bsdf_f reads the frame (ss, ts, ns), ng and — through BsdfWo — wo; p is not used
+                vs.ss = mk3(col[0 * 64], col[1 * 64], col[2 * 64]);
+                vs.ts = mk3(col[3 * 64], col[4 * 64], col[5 * 64]);
+                vs.ns = mk3(col[6 * 64], col[7 * 64], col[8 * 64]);
+                vs.ng = mk3(col[9 * 64], col[10 * 64], col[11 * 64]);
+                BsdfWo pre;
+                pre.wo = mk3(col[12 * 64], col[13 * 64], col[14 * 64]);
+                pre.wo_ng = col[15 * 64];
+                pre.lam[0] = col[16 * 64];
+                pre.lam[1] = col[17 * 64];
+                const LobeSet& vb = sc.materials[__float_as_uint(col[18 * 64])].set[1];
+                const f3 c = mk3(b4.x, b4.y, b4.z) * bsdf_f_wo(vb, vs, pre, mk3(w4.x, w4.y, w4.z), BSDF_ALL);
+                n_acc++;
                 atomicAdd(&s_phi[wv][src][0], c.x);
                 atomicAdd(&s_phi[wv][src][1], c.y);
                 atomicAdd(&s_phi[wv][src][2], c.z);
@@ -864,9 +896,19 @@ static __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(T
         n_reg = wave_sum(n_reg);
         if (lane_id() == 0 && n_reg) atomicAdd(&gp->registrations, n_reg);
     }
+    if (count_stats) {  // option "count_visits": the instrumented pass of bench.py
+        n_cand = wave_sum(n_cand);
+        n_acc = wave_sum(n_acc);
+        n_vp = wave_sum(n_vp);
+        if (lane_id() == 0) {
+            if (n_cand) atomicAdd(&gp->stat_candidates, n_cand);
+            if (n_acc) atomicAdd(&gp->stat_accepted, n_acc);
+            if (n_vp) atomicAdd(&gp->stat_visible_points, n_vp);
+        }
+    }
 }
 static __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TH_SPPM_HOT_WAVES))) void k_sppm_gather_hot(DeviceScene sc, PhotonRecords rec, VisiblePoints vp, PixelStats px, GridInfo* gp, const uint32_t* __restrict__ starts,
-                                                            const float4* __restrict__ hit_sorted, uint32_t hash_size, const uint32_t* __restrict__ hot_list) {
+                                                            const float4* __restrict__ hit_sorted, uint32_t hash_size, const uint32_t* __restrict__ hot_list, uint32_t count_stats) {
     // One wave per hot pixel.  The distance test runs over a bucket with all 64 lanes; the photons that pass (about one in eight) are
     // not shaded where they are found — a handful of lanes would run the BSDF while the rest wait — but parked in a per-wave ring
     // and shaded 64 at a time (the trick of k_shade_path).
@@ -893,13 +935,14 @@ static __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(T
         vs.ss = mk3(ss4.x, ss4.y, ss4.z);
         vs.ts = mk3(ts4.x, ts4.y, ts4.z);
         const LobeSet& vb = sc.materials[__float_as_uint(p4.w)].set[1];
+        const BsdfWo pre = bsdf_wo_terms(vb, vs, vs.wo);  // once per pixel instead of once per accepted photon (th_device.h)
         GatherSum s{splat3(0.0f), 0u};
         uint32_t ring_head = 0, ring_cnt = 0;  // wave-uniform
         auto shade = [&](uint32_t n) {         // the first n parked photons, one per lane
             if (lane < n) {
                 const uint32_t r = s_ring[wv][(ring_head + lane) & 127u];
                 const float4 w4 = rec.wi[r], b4 = rec.beta[r];
-                s.phi = s.phi + mk3(b4.x, b4.y, b4.z) * bsdf_f(vb, vs, vs.wo, mk3(w4.x, w4.y, w4.z), BSDF_ALL);
+                s.phi = s.phi + mk3(b4.x, b4.y, b4.z) * bsdf_f_wo(vb, vs, pre, mk3(w4.x, w4.y, w4.z), BSDF_ALL);
                 s.M++;
             }
         };
@@ -945,6 +988,7 @@ static __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(T
             px.phi[3 * i + 1] = s.phi.y;
             px.phi[3 * i + 2] = s.phi.z;
             px.M[i] = s.M;
+            if (count_stats) atomicAdd(&gp->stat_accepted, (unsigned long long)s.M);
         }
     }
 }

@@ -237,8 +237,8 @@ int render_sppm_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
                                    (const uint32_t*)starts, entries, 1);
             tm.end(6, st);
             tm.begin(5, st);
-            hipLaunchKernelGGL(k_sppm_gather, g_pix, blk, 0, st, scene->dev, rec, vp, px, n, grid, (const uint32_t*)starts, (const float4*)entries, n, hot_list, it0 + j == n_iterations ? 1u : 0u);
-            hipLaunchKernelGGL(k_sppm_gather_hot, g_shade, blk, 0, st, scene->dev, rec, vp, px, grid, (const uint32_t*)starts, (const float4*)entries, n, (const uint32_t*)hot_list);
+            hipLaunchKernelGGL(k_sppm_gather, g_pix, blk, 0, st, scene->dev, rec, vp, px, n, grid, (const uint32_t*)starts, (const float4*)entries, n, hot_list, it0 + j == n_iterations ? 1u : 0u, ctx->count_visits ? 1u : 0u);
+            hipLaunchKernelGGL(k_sppm_gather_hot, g_shade, blk, 0, st, scene->dev, rec, vp, px, grid, (const uint32_t*)starts, (const float4*)entries, n, (const uint32_t*)hot_list, ctx->count_visits ? 1u : 0u);
             tm.end(5, st);
             if (ctx->comm.comm && ctx->comm.n_ranks > 1) {
                 // the one exchange of an iteration: every rank traced its slice of the photons, ϕ and M are the sums over all of
@@ -297,6 +297,12 @@ int render_sppm_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
         stats->n_batches = n_batches;
         stats->max_depth_reached = (uint32_t)max_depth;
         traversal_info(ctx, scene, &stats->traversal, &stats->node_bytes);
+        if (ctx->count_visits) {
+            stats->count_sub[0] = gi.stat_candidates;
+            stats->count_sub[1] = gi.stat_accepted;
+            stats->count_sub[2] = gi.photon_hits;
+            stats->count_sub[3] = gi.stat_visible_points;
+        }
         // the camera pass (closest-hit + shadow rays) is traced by every rank of a job; only the photons are sharded
         std::vector<unsigned long long> snap((size_t)n_batches * 4);
         HIP_TRY(ctx, hipMemcpy(snap.data(), raysnap, snap.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
