@@ -59,6 +59,7 @@ struct WideScene {            // device view of the v2 node array
     uint32_t n_wnodes;
     float tight_scale;        // slab_test2's margin as a fraction of the ray's reach (2^-14); 0: the reference's loose test alone
     const uint32_t* leaf_order;  // one-leaf scenes: the order in which any-hit rays test the leaf's primitives (k_any_leaf); null = slot order
+    uint32_t leaf_tight;      // every triangle leaf's box is exactly the union of its triangles' boxes (k_trace7's cheap interior test needs it)
 };
 
 // The t_max-independent part of bounds.jl:186-206; returns false when the box is certainly missed, otherwise tx_min (to be

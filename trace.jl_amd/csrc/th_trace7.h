@@ -22,6 +22,12 @@
 // sign become min / max of the two products (the same two floats: rounding is monotonic), and the two clauses the reference lost are ANDed on
 // the box grown by the margin, as in slab_test2 (th_trace2.h): ~35 VALU instructions per box instead of ~55.
 //
+// CHEAP (the default when every leaf box is the exact union of its triangles' boxes — any tree built by this library): bounds.jl:186-200 is monotonic in the box —
+// a box that passes keeps passing when it grows (every plane product moves the right way, rounding is monotonic) — so "all ancestors pass" is implied by "the
+// LEAF's box passes".  Interior boxes then only have to be CONSERVATIVE: they get a plain slab test in fma form on the box grown by m (18 VALU instructions),
+// which never rejects a box that holds an acceptable hit; the reference's exact test runs once per leaf reached, on the box recomputed from the leaf's
+// vertices (min / max are exact).  Subtrees that hold a sphere keep the exact test on every box (their leaves' boxes come from the sphere records).
+//
 // gap = 4 m, cull margin = 5 m with m = 2^-14 x (largest coordinate offset between the ray origin and the scene bound) x max |1 / d|: the slack
 // of the box entry against a hit inside the box (<= m, the tight clauses' margin) plus the rounding of `t_max * det` and `ts * (1 / det)`.
 // A candidate culled by a box (entry > t_best + 5 m) has t > t_best + 4 m >= t_w + gap: nothing inside the gap is ever skipped.
@@ -68,6 +74,18 @@ TH_D float slab_entry7(float bx0, float by0, float bz0, float bx1, float by1, fl
     return hit ? t_in : kInf;
 }
 
+// CHEAP interior boxes: the standard slab test, one fma per plane (t = plane / d - o / d), on the box grown by m; conservative for every box that holds a hit
+// the primitive tests accept (th_trace2.h, slab_test2's argument) — nothing else is asked of it.
+TH_D float slab_entry_cheap(float bx0, float by0, float bz0, float bx1, float by1, float bz1, f3 inv_d, f3 noid, float m) {
+    const float x0 = __fmaf_rn(bx0, inv_d.x, noid.x), x1 = __fmaf_rn(bx1, inv_d.x, noid.x);
+    const float y0 = __fmaf_rn(by0, inv_d.y, noid.y), y1 = __fmaf_rn(by1, inv_d.y, noid.y);
+    const float z0 = __fmaf_rn(bz0, inv_d.z, noid.z), z1 = __fmaf_rn(bz1, inv_d.z, noid.z);
+    const float t_in = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+    const float t_out = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+    const bool hit = (t_in <= t_out + (m + m)) & (t_out >= -m);  // a NaN (the empty leaf's box) fails both
+    return hit ? t_in : kInf;
+}
+
 // sphere.jl:125-158 up to the roots, as sphere_intersect (th_device.h); 0 = no candidate inside t_lim, 1 = candidate at t, 2 = the ray must be re-traced
 // in the reference's order (origin inside the sphere: t_max is ignored, A.18; a clipped sphere; the limb, where the quadratic accepts rays outside the box)
 template <bool FULL_ONLY>
@@ -94,7 +112,7 @@ TH_D int sphere_candidate7(const SphereRec& s, f3 o, f3 d, float t_lim, float& t
     return 1;
 }
 
-template <bool COUNT, bool FULL_ONLY, bool BIG>
+template <bool COUNT, bool FULL_ONLY, bool BIG, bool CHEAP>
 __global__ __launch_bounds__(kBlock, BIG ? TH_TRACE7_WAVES - 1 : TH_TRACE7_WAVES) void k_trace7(DeviceScene sc, WideScene ws, SegQueue q, const float4* __restrict__ ro, const float4* __restrict__ rd,
                                                                                                const float* __restrict__ tmax_or_null, TraceOut out, uint32_t* __restrict__ work,
                                                                                                uint2* __restrict__ overflow, Counters* ctr, FallbackList fb) {
@@ -113,6 +131,8 @@ __global__ __launch_bounds__(kBlock, BIG ? TH_TRACE7_WAVES - 1 : TH_TRACE7_WAVES
     uint32_t idx = 0, fb_idx = 0, cur = kRefNone, cur_cnt = 0;
     int sp = 0;
     f3 o = splat3(0.0f), inv_d = splat3(0.0f);
+    f3 noid = splat3(0.0f);  // CHEAP: -o / d per axis
+    bool cur_exact = true;   // CHEAP: the node in `cur` was reached through the reference's exact box tests (a sphere's path); a triangle leaf reached otherwise tests its own box first
     RayShear shear{0, 0.0f, 0.0f, 0.0f};
     float m = 0.0f;         // the margin in t units
     float t_best = kInf;    // smallest candidate t so far (the hit record in out.hits belongs to it)
@@ -167,6 +187,8 @@ __global__ __launch_bounds__(kBlock, BIG ? TH_TRACE7_WAVES - 1 : TH_TRACE7_WAVES
                         const float em = slab_margin(ws.root_box, ws.tight_scale, o);
                         m = em * fmaxf(fmaxf(fabsf(inv_d.x), fabsf(inv_d.y)), fabsf(inv_d.z));
                         shear = ray_shear(d);
+                        if (CHEAP) noid = mk3(-(o.x * inv_d.x), -(o.y * inv_d.y), -(o.z * inv_d.z));
+                        cur_exact = true;
                         t_own = tmax_or_null ? tmax_or_null[idx] : kInf;
                         t_best = t_second = kInf;
                         t_cull = t_own + 5.0f * m;
@@ -226,6 +248,7 @@ __global__ __launch_bounds__(kBlock, BIG ? TH_TRACE7_WAVES - 1 : TH_TRACE7_WAVES
                     if (tin <= t_cull) {
                         cur = enc & 0x00ffffffu;
                         cur_cnt = enc >> 24;
+                        if (CHEAP) cur_exact = tin == -kInf;
                         finished = false;
                         break;
                     }
@@ -258,8 +281,18 @@ __global__ __launch_bounds__(kBlock, BIG ? TH_TRACE7_WAVES - 1 : TH_TRACE7_WAVES
                 }
                 if (COUNT) nn += 2;
                 const uint32_t lenc = __float_as_uint(a3.x), renc = __float_as_uint(a3.y), meta = __float_as_uint(a3.z);
-                float tl = slab_entry7(a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, o, inv_d, m, !(meta & 4u));
-                float tr = slab_entry7(a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, o, inv_d, m, !(meta & 8u));
+                float tl, tr;
+                if (CHEAP) {
+                    tl = slab_entry_cheap(a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, inv_d, noid, m);
+                    tr = slab_entry_cheap(a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, inv_d, noid, m);
+                    if (meta & 12u) {  // a child on a sphere's path (rare): the reference's exact test, no tight clauses
+                        if (meta & 4u) tl = slab_entry7(a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, o, inv_d, m, false);
+                        if (meta & 8u) tr = slab_entry7(a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, o, inv_d, m, false);
+                    }
+                } else {
+                    tl = slab_entry7(a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, o, inv_d, m, !(meta & 4u));
+                    tr = slab_entry7(a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, o, inv_d, m, !(meta & 8u));
+                }
                 // A subtree that holds a sphere is never culled by distance: the Float32 quadratic accepts rays that pass OUTSIDE the sphere's box (by up to
                 // 1e-3 |o - c|), and bounds.jl:190's loose test can pass such a box with an entry far beyond the sphere's t — the reference reaches that leaf
                 // or not depending on its order.  Entered whenever the reference's t_max-free clauses pass (entry -Inf), those rays get flagged at the leaf.
@@ -282,11 +315,13 @@ __global__ __launch_bounds__(kBlock, BIG ? TH_TRACE7_WAVES - 1 : TH_TRACE7_WAVES
                 }
                 cur = go_n ? (nenc & 0x00ffffffu) : kRefNone;
                 cur_cnt = go_n ? (nenc >> 24) : 0u;
+                if (CHEAP) cur_exact = tn == -kInf;
                 if (!go_n && sp > 0) {  // nothing was pushed: the top read above is still the top
                     sp--;
                     if (top_tin <= t_cull) {
                         cur = top_enc & 0x00ffffffu;
                         cur_cnt = top_enc >> 24;
+                        if (CHEAP) cur_exact = top_tin == -kInf;
                     }
                 }
             }
@@ -307,7 +342,31 @@ __global__ __launch_bounds__(kBlock, BIG ? TH_TRACE7_WAVES - 1 : TH_TRACE7_WAVES
                     top_tin = __uint_as_float(e.y);
                 }
             }
-            for (uint32_t k = 0; k < cur_cnt; ++k) {
+            bool enter = true;
+            if (CHEAP && !cur_exact) {
+                // the reference enters this leaf iff ITS box test passes (bounds.jl:186-198; the ancestors then pass too: header) — on the leaf's box, which is the
+                // union of its triangles' boxes (verified at upload: WideScene::leaf_tight).  A leaf of several triangles reads them twice (the second time from L1).
+                float bx0 = kInf, by0 = kInf, bz0 = kInf, bx1 = -kInf, by1 = -kInf, bz1 = -kInf;
+                bool has_sphere = false;
+                for (uint32_t k = 0; k < cur_cnt; ++k) {
+                    const uint32_t slot = cur + k;
+                    const float4 p0 = sc.prims[3 * slot];
+                    const float4 p1 = sc.prims[3 * slot + 1], p2 = sc.prims[3 * slot + 2];
+                    asm volatile("" ::"v"(p1.x), "v"(p1.y), "v"(p1.z), "v"(p2.x), "v"(p2.y), "v"(p2.z));
+                    has_sphere = has_sphere || (__float_as_uint(p0.w) & PRIM_SPHERE) != 0u;
+                    bx0 = fminf(bx0, fminf(fminf(p0.x, p1.x), p2.x));
+                    by0 = fminf(by0, fminf(fminf(p0.y, p1.y), p2.y));
+                    bz0 = fminf(bz0, fminf(fminf(p0.z, p1.z), p2.z));
+                    bx1 = fmaxf(bx1, fmaxf(fmaxf(p0.x, p1.x), p2.x));
+                    by1 = fmaxf(by1, fmaxf(fmaxf(p0.y, p1.y), p2.y));
+                    bz1 = fmaxf(bz1, fmaxf(fmaxf(p0.z, p1.z), p2.z));
+                }
+                if (has_sphere)
+                    flagged = true;  // cannot happen (a sphere's leaf is reached through exact tests); never decide such a leaf from a triangle's box
+                else
+                    enter = slab_entry7(bx0, by0, bz0, bx1, by1, bz1, o, inv_d, m, false) < kInf;
+            }
+            for (uint32_t k = 0; enter && k < cur_cnt; ++k) {
                 const uint32_t slot = cur + k;
                 const float4 p0 = sc.prims[3 * slot];
                 const float4 p1 = sc.prims[3 * slot + 1], p2 = sc.prims[3 * slot + 2];
@@ -355,6 +414,7 @@ __global__ __launch_bounds__(kBlock, BIG ? TH_TRACE7_WAVES - 1 : TH_TRACE7_WAVES
                 if (top_tin <= t_cull) {
                     cur = top_enc & 0x00ffffffu;
                     cur_cnt = top_enc >> 24;
+                    if (CHEAP) cur_exact = top_tin == -kInf;
                 }
             }
         }

@@ -284,6 +284,11 @@ int upload_scene(trhip_scene* s) {
             }
             const float* l = &s->bvh.bounds[6 * (size_t)c[0]];
             const float* r = &s->bvh.bounds[6 * (size_t)c[1]];
+            // an empty leaf's box (+Inf, -Inf) goes in as NaNs: every comparison with a NaN product is false, so the child is missed by the select form of the box
+            // test (slab_test2) AND by the min / max forms (th_trace7.h), where min(+Inf x, -Inf x) would turn the inverted box into "everything"
+            static const float kNanBox[6] = {NAN, NAN, NAN, NAN, NAN, NAN};
+            if ((s->bvh.flags[c[0]] & 3u) == 3u && (s->bvh.flags[c[0]] >> 2) == 0u) l = kNanBox;
+            if ((s->bvh.flags[c[1]] & 3u) == 3u && (s->bvh.flags[c[1]] >> 2) == 0u) r = kNanBox;
             float4* w = &wn[4 * (size_t)widx[i]];
             w[0] = make_float4(l[0], l[1], l[2], l[3]);
             w[1] = make_float4(l[4], l[5], r[0], r[1]);
@@ -292,8 +297,31 @@ int upload_scene(trhip_scene* s) {
             w[3] = make_float4(__builtin_bit_cast(float, ref[0] | (cnt[0] << 24)), __builtin_bit_cast(float, ref[1] | (cnt[1] << 24)),
                                __builtin_bit_cast(float, (s->bvh.flags[i] & 3u) | ((uint32_t)has_sphere[c[0]] << 2) | ((uint32_t)has_sphere[c[1]] << 3)), 0.0f);
         }
+        // k_trace7 re-derives a leaf's box from its triangles' vertices (min / max are exact): true for every tree built here; a caller's tree (trhip_scene_set_bvh) may
+        // carry larger leaf boxes, and then the kernel keeps the reference's test on every box instead
+        bool leaf_tight = true;
+        for (uint32_t i = 0; i < n_nodes && leaf_tight; ++i) {
+            if ((s->bvh.flags[i] & 3u) != 3u) continue;
+            const uint32_t first = s->bvh.a[i], cnt = s->bvh.flags[i] >> 2;
+            if (cnt == 0) continue;
+            HostAABB u;
+            u.reset();
+            bool sphere = false;
+            for (uint32_t k = first; k < first + cnt && k < n_prims; ++k) {
+                const HostPrim& p = s->prims[s->bvh.order[k]];
+                if (p.kind == 1) {
+                    sphere = true;
+                    break;
+                }
+                for (int j = 0; j < 3; ++j) u.grow_point(&p.v[3 * j]);
+            }
+            if (sphere) continue;  // sphere leaves are reached through exact tests anyway
+            const float* b = &s->bvh.bounds[6 * (size_t)i];
+            leaf_tight = u.mn[0] == b[0] && u.mn[1] == b[1] && u.mn[2] == b[2] && u.mx[0] == b[3] && u.mx[1] == b[4] && u.mx[2] == b[5];
+        }
         if (ok) {
             if (int rc = upload(ctx, s->d_wnodes, wn.data(), wn.size() * sizeof(float4))) return rc;
+            s->wide.leaf_tight = leaf_tight ? 1u : 0u;
             s->wide.wnodes = (const float4*)s->d_wnodes.p;
             s->wide.n_wnodes = n_int;
             std::memcpy(s->wide.root_box, &s->bvh.bounds[0], 6 * sizeof(float));
