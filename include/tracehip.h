@@ -146,7 +146,9 @@ typedef struct {
                                  shading, [2] grid bounds + hit binning + scans, [3] pixel update + fold.  Path / Whitted: zeros */
     uint32_t launches_sub[4];
     uint64_t count_sub[4];    /* trhip_render_sppm with "count_visits": [0] (pixel, photon) candidates distance-tested by the gather, [1] pairs accepted
-                                 (BSDF evaluated), [2] photon hits binned, [3] visible points; otherwise zeros */
+                                 (BSDF evaluated), [2] photon hits binned, [3] visible points.  trhip_render_path with traversal 7 and "count_visits": why rays went to
+                                 the reference-order walk — [0] zero / non-finite direction, [1] a sphere (origin inside, limb, clipped), [2] a candidate within the gap of
+                                 the ray's own t_max, [3] a second candidate within the gap of the nearest.  Otherwise zeros */
 } trhip_stats;
 
 /* ---- integrators (replace `integrator(scene)`, integrators/sampler.jl:12-56) ---------------------------------------

@@ -10,9 +10,11 @@ ap.add_argument("--spp", type=int, default=64)
 a = ap.parse_args()
 scene, cam = T.scenes.cornell_scene(), T.scenes.cornell_camera(1024)
 ctx = T.default_context()
-for mode in (2, 3, 4, 5, 6, 7, 8, 9):
+ap2 = [(m, r) for r in (1, 0) for m in (4, 5, 6, 10, 12, 13)] + [(2, 0)]
+for mode, relayout in ap2:
     ctx.set_option("film_block", mode)
+    ctx.set_option("film_relayout", relayout)
     integ = T.PathIntegrator(cam, T.SeededSampler(a.spp, seed=1), 8)
     integ.render(scene, ctx)
     integ.render(scene, ctx)
-    print("film_block", mode, "ms_film", round(integ.stats.ms_film, 3), "ms_total", round(integ.stats.ms_total, 2))
+    print("film_block", mode, "relayout", relayout, "ms_film", round(integ.stats.ms_film, 3), "ms_total", round(integ.stats.ms_total, 2))

@@ -74,6 +74,7 @@ struct trhip_ctx {
                          // 0 = one film pixel per thread, 1 = 2 x 2 pixels per thread, 2 = TH_FILM_BX x TH_FILM_BY = 1 x 4, all three recomputing a
                          // sample's pixel range and table indices per thread; 3 = 1 x 4 from per-sample splat descriptors (k_film_descriptors): measured SLOWER
                          // (1024^2, 256 spp: 29.0 ms against 24.3 ms: the 16-byte descriptor doubles the gather's loads and the arithmetic it saves was hidden)
+    bool film_relayout = true;  // packed film pass: gather from a pixel-group-major copy of the radiance records (k_film_pack_transpose) instead of the integrators' sample-major order
     bool film_tiled = false;  // LDS-staged film gather (k_film_gather_tiled): bit-identical, measured 2.7x SLOWER than k_film_gather (11 % lane use), kept as an option
     bool overlap = false;  // shadow rays of depth d on a second stream beside the closest-hit rays of depth d+1 (option "overlap").  Off since the two-stage
                            // any-hit kernels (k_any_occluders, k_any_leaf) halved the shadow rays' cost: 256 spp, on / off: S-cornell 158.2 / 157.9 ms, S-mesh 399 / 393,
@@ -102,6 +103,7 @@ struct trhip_ctx {
     uint64_t sppm_batch = 0;  // SPPM iterations per wavefront batch (0 = from free HBM, at most 128)
     uint32_t sp_pixels = 0;
     int64_t sp_photons = 0;
+    DevBuf film_side;  // packed film pass: counter + the full descriptors of the samples whose range does not fit 30 bits (th_kernels.h, FilmSideTable)
     DevBuf fdesc;   // film_block 3: one SplatDesc (16 B) per camera sample of the band (th_kernels.h, k_film_descriptors)
     DevBuf poison;  // one byte per camera sample of the band: ShadeStream::poison
     DevBuf ov8[2], fb_list[2], fb_counts[2];  // k_trace8: global stack levels, fallback lists + their counters / work cursors ([closest | any])

@@ -48,6 +48,7 @@ struct Counters {  // device-resident
     // per render call
     unsigned long long closest_total, shadow_total, nodes_closest, prims_closest, nodes_shadow, prims_shadow;
     unsigned long long fallback_total;  // closest-hit rays k_trace7 handed to the reference-order walk (th_trace7.h)
+    unsigned long long fallback_why[4]; // … by reason, counted under "count_visits" (th_trace7.h)
 };
 // How a kernel sees a queue: kSeg segments of `cap` physical entries with fill counts in HBM, or (counts == nullptr) one
 // dense array of n_dense entries (kernel-level API entry points).
@@ -1067,7 +1068,18 @@ __global__ __launch_bounds__(kBlock) void k_film_gather_desc(const DeviceSensor*
 //     decode, two unsigned compares and a bit-field extract per column / row, one LDS lookup and the multiply-adds of add_sample! per pixel.
 // Per film pixel nothing changes: tiles in k order, sample pixels in Bounds2 order, samples in order, one csum per tile (film.jl:134-193); the arithmetic of
 // the descriptor is k_film_descriptors' (bit-identical to the reference's per-pixel computation: tests/test_gpu_parity.py, tools/soak_film.py).
-constexpr uint32_t kFilmPackException = 0xffffffffu;  // nx or ny = 4 (or a radius this encoding does not cover): recompute from the sampler
+// A sample whose range is 4 wide (or otherwise outside the encoding) keeps its full 16-byte descriptor in a side table: .w = kFilmPackSide | index.  The table
+// holds total / 16 + 65536 entries (the rate is ~2.4e-4 at 1024^2); should it ever run full the word is kFilmPackOverflow and the gather recomputes that
+// sample's descriptor from the sampler — in a cold copy of the loop, so that the hash and the descriptor arithmetic are not inlined into the unrolled hot one.
+constexpr uint32_t kFilmPackSide = 0x80000000u;
+constexpr uint32_t kFilmPackOverflow = 0xffffffffu;
+constexpr uint32_t kFilmPackException = 0xffffffffu;  // what film_pack_desc returns for a descriptor that does not fit
+struct FilmSideTable {
+    uint4* desc;
+    uint32_t* count;
+    uint32_t cap;
+};
+TH_D uint32_t film_pack_word(const FilmSideTable& side, uint4 d, int px, int py);
 TH_D uint4 film_splat_desc(const DeviceSensor& se, int px, int py, uint64_t key) {  // the SplatDesc of one camera sample (k_film_descriptors' arithmetic)
     const float rx = se.filter_radius[0], ry = se.filter_radius[1];
     const float inv_rx = 1.0f / rx, inv_ry = 1.0f / ry;
@@ -1092,13 +1104,43 @@ TH_D uint32_t film_pack_desc(uint4 d, int px, int py) {
     if (ox < 0 || ox > 1 || oy < 0 || oy > 1 || nx < 1u || nx > 3u || ny < 1u || ny > 3u) return kFilmPackException;
     return (uint32_t)ox | ((uint32_t)oy << 1) | ((nx - 1u) << 2) | ((ny - 1u) << 4) | ((d.z & 0xfffu) << 6) | ((d.w & 0xfffu) << 18);
 }
+TH_D uint32_t film_pack_word(const FilmSideTable& side, uint4 d, int px, int py) {
+    const uint32_t w = film_pack_desc(d, px, py);
+    if (w != kFilmPackException) return w;
+    const uint32_t j = atomicAdd(side.count, 1u);
+    if (j >= side.cap || j >= 0x7fffffffu) return kFilmPackOverflow;
+    side.desc[j] = d;
+    return kFilmPackSide | j;
+}
 // writes the descriptor into L[slot].w; the other lanes of the record are not touched (4-byte stores)
-static __global__ __launch_bounds__(kBlock) void k_film_pack_w(const DeviceSensor* __restrict__ sep, uint64_t n, uint64_t seed, uint32_t sample_offset, float4* __restrict__ L) {
+static __global__ __launch_bounds__(kBlock) void k_film_pack_w(const DeviceSensor* __restrict__ sep, uint64_t n, uint64_t seed, uint32_t sample_offset, float4* __restrict__ L, FilmSideTable side) {
     const DeviceSensor& se = *sep;
     for (uint64_t slot = (uint64_t)blockIdx.x * kBlock + threadIdx.x; slot < n; slot += (uint64_t)gridDim.x * kBlock) {
         const SlotInfo si = slot_info(se, (uint32_t)slot);
         const uint64_t key = ts_stream_key(seed, si.px, si.py, sample_offset + si.sample);
-        reinterpret_cast<uint32_t*>(L + slot)[3] = film_pack_desc(film_splat_desc(se, si.px, si.py, key), si.px, si.py);
+        reinterpret_cast<uint32_t*>(L + slot)[3] = film_pack_word(side, film_splat_desc(se, si.px, si.py, key), si.px, si.py);
+    }
+}
+// The same, and the records re-laid pixel-group-major on the way ([group of 64 sample pixels][sample][lane], film_index layout 1): the gather walks ALL samples of a
+// sample pixel before the next pixel, which in the integrators' sample-major order is a 16 MB stride at 1024^2 — a new DRAM page and TLB entry for every 16-byte
+// load.  Re-laid, a wave's loads for consecutive samples are consecutive 1 KB chunks.  This pass reads and writes every record once (the in-place pass touches
+// every line too: same traffic), into a second buffer.
+static __global__ __launch_bounds__(kBlock) void k_film_pack_transpose(const DeviceSensor* __restrict__ sep, uint32_t npix, uint32_t spp, uint64_t seed, uint32_t sample_offset,
+                                                                const float4* __restrict__ L, float4* __restrict__ Lt, FilmSideTable side) {
+    const DeviceSensor& se = *sep;
+    const uint32_t groups = (npix + 63u) >> 6;
+    const uint64_t chunks = (uint64_t)groups * spp;
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint64_t c = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) >> 6; c < chunks; c += ((uint64_t)gridDim.x * kBlock) >> 6) {
+        const uint32_t smp = (uint32_t)(c / groups), g = (uint32_t)(c - (uint64_t)smp * groups);  // consecutive waves read consecutive chunks
+        const uint32_t pix = g * 64u + lane;
+        if (pix >= npix) continue;
+        const uint32_t slot = smp * npix + pix;
+        const SlotInfo si = slot_info(se, slot);
+        const uint64_t key = ts_stream_key(seed, si.px, si.py, sample_offset + si.sample);
+        float4 l = L[slot];
+        l.w = __uint_as_float(film_pack_word(side, film_splat_desc(se, si.px, si.py, key), si.px, si.py));
+        Lt[film_index(1u, npix, spp, smp, pix)] = l;
     }
 }
 #ifndef TH_FILM_PACKED_UNROLL
@@ -1106,12 +1148,13 @@ static __global__ __launch_bounds__(kBlock) void k_film_pack_w(const DeviceSenso
 #endif
 template <int BX, int BY>
 __global__ __launch_bounds__(kBlock) void k_film_gather_packed(const DeviceSensor* __restrict__ sep, const float* __restrict__ table, const float4* __restrict__ L, uint32_t spp, uint64_t seed,
-                                                               uint32_t sample_offset, float4* __restrict__ out) {
+                                                               uint32_t sample_offset, uint32_t layout, const uint4* __restrict__ side, float4* __restrict__ out) {
     const DeviceSensor& se = *sep;
     __shared__ float s_table[256];
     for (uint32_t t = threadIdx.x; t < 256u; t += kBlock) s_table[t] = table[t];
     __syncthreads();
     const uint32_t npix = (uint32_t)(se.sb_w * se.band_rows);
+    const size_t sstride = layout ? (size_t)64 : (size_t)npix;  // records between consecutive samples of one sample pixel (film_index)
     const float rx = se.filter_radius[0], ry = se.filter_radius[1];
     const uint32_t nbx = ((uint32_t)se.film_w + BX - 1) / BX, nby = ((uint32_t)se.film_h + BY - 1) / BY;
     for (uint32_t bidx = blockIdx.x * kBlock + threadIdx.x; bidx < nbx * nby; bidx += gridDim.x * kBlock) {
@@ -1180,13 +1223,20 @@ __global__ __launch_bounds__(kBlock) void k_film_gather_packed(const DeviceSenso
                             int rxi[BX], ryi[BY];
                             for (int i = 0; i < BX; ++i) rxi[i] = Xi[i] - sx;
                             for (int j = 0; j < BY; ++j) ryi[j] = Yi[j] - sy;
-                            auto splat = [&](float4 l4, uint32_t s) {
+                            // One sample against the block's pixels, BRANCH-FREE: every lookup is issued for every pixel (clamped indices) before any is
+                            // waited for, and a pixel outside the sample's range adds +0 — csum and fws are never -0 (they start at +0; a sum can only
+                            // reach -0 from -0), so x + 0 == x bit for bit; the products are SELECTED to 0, not multiplied by 0 (an infinite radiance times 0
+                            // would be a NaN).  The straight-line form replaced one branch per row and per pixel with exposed LDS latency behind each.
+                            auto splat = [&](float4 l4, uint32_t s, auto cold) {
                                 uint32_t d = __float_as_uint(l4.w);
                                 int p0x, p0y;  // relative to (sx, sy)
                                 uint32_t nx, ny, oxw, oyw;
-                                if (d == kFilmPackException) {  // a 4-wide range: this sample's full descriptor, from the sampler
-                                    const uint64_t key = ts_stream_key(seed, sx, sy, sample_offset + s);
-                                    const uint4 fd = film_splat_desc(se, sx, sy, key);
+                                if (d & kFilmPackSide) {  // a 4-wide range: the full descriptor from the side table (or, `cold` only, from the sampler)
+                                    uint4 fd = make_uint4(0u, 0u, 0u, 0u);
+                                    if (decltype(cold)::value && d == kFilmPackOverflow)
+                                        fd = film_splat_desc(se, sx, sy, ts_stream_key(seed, sx, sy, sample_offset + s));
+                                    else
+                                        fd = side[d & 0x7fffffffu];
                                     p0x = (int)(short)(fd.x & 0xffffu) - sx;
                                     p0y = (int)(short)(fd.x >> 16) - sy;
                                     nx = fd.y & 0xffu;
@@ -1201,45 +1251,52 @@ __global__ __launch_bounds__(kBlock) void k_film_gather_packed(const DeviceSenso
                                     oxw = (d >> 6) & 0xfffu;
                                     oyw = (d >> 18) & 0xfffu;
                                 }
-                                uint32_t cx[BX], cy[BY];
-                                bool vx[BX], vy[BY];
-                                bool anyx = false, anyy = false;
-                                for (int i = 0; i < BX; ++i) {
-                                    cx[i] = (uint32_t)(rxi[i] - p0x);
-                                    vx[i] = ok_x[i] && cx[i] < nx;
-                                    anyx = anyx || vx[i];
-                                }
-                                for (int j = 0; j < BY; ++j) {
-                                    cy[j] = (uint32_t)(ryi[j] - p0y);
-                                    vy[j] = ok_y[j] && cy[j] < ny;
-                                    anyy = anyy || vy[j];
-                                }
-                                if (!(anyx && anyy)) return;
                                 f3 l = mk3(l4.x, l4.y, l4.z);
                                 if (has_nan(l)) l = splat3(0.0f);  // integrators/sampler.jl:46
-                                uint32_t oxi[BX];
-                                for (int i = 0; i < BX; ++i) oxi[i] = (oxw >> (4u * (cx[i] & 7u))) & 15u;
+                                bool vx[BX], vy[BY];
+                                uint32_t oxi[BX], row[BY];
+                                for (int i = 0; i < BX; ++i) {
+                                    const uint32_t cx = (uint32_t)(rxi[i] - p0x);
+                                    vx[i] = ok_x[i] && cx < nx;
+                                    oxi[i] = (oxw >> (4u * (cx & 7u))) & 15u;
+                                }
+                                for (int j = 0; j < BY; ++j) {
+                                    const uint32_t cy = (uint32_t)(ryi[j] - p0y);
+                                    vy[j] = ok_y[j] && cy < ny;
+                                    row[j] = ((oyw >> (4u * (cy & 7u))) & 15u) * 16u;
+                                }
+                                float w[BY][BX];
                                 for (int j = 0; j < BY; ++j)
-                                    if (vy[j]) {
-                                        const uint32_t row = ((oyw >> (4u * (cy[j] & 7u))) & 15u) * 16u;
-                                        for (int i = 0; i < BX; ++i)
-                                            if (vx[i]) {
-                                                const float w = s_table[row + oxi[i]];
-                                                csum[j][i] = csum[j][i] + l * w;  // contrib_sum += l * sample_weight (1) * w
-                                                fws[j][i] += w;
-                                            }
+                                    for (int i = 0; i < BX; ++i) w[j][i] = s_table[row[j] + oxi[i]];
+                                for (int j = 0; j < BY; ++j)
+                                    for (int i = 0; i < BX; ++i) {
+                                        const bool v = vx[i] && vy[j];
+                                        const f3 c = l * w[j][i];  // contrib_sum += l * sample_weight (1) * w
+                                        csum[j][i] = csum[j][i] + mk3(v ? c.x : 0.0f, v ? c.y : 0.0f, v ? c.z : 0.0f);
+                                        fws[j][i] += v ? w[j][i] : 0.0f;
                                     }
                             };
                             constexpr uint32_t kU = TH_FILM_PACKED_UNROLL;
+                            const float4* sp = L + film_index(layout, npix, spp, 0u, pix);  // sample 0 of this sample pixel; the next sample is `sstride` records on
                             uint32_t s = 0;
-                            for (; s + kU <= spp; s += kU) {
+                            for (; s + kU <= spp; s += kU, sp += (size_t)kU * sstride) {
                                 float4 lv[kU];
+                                bool overflow = false;
 #pragma unroll
-                                for (uint32_t u = 0; u < kU; ++u) lv[u] = L[(size_t)(s + u) * npix + pix];
+                                for (uint32_t u = 0; u < kU; ++u) lv[u] = sp[(size_t)u * sstride];
 #pragma unroll
-                                for (uint32_t u = 0; u < kU; ++u) splat(lv[u], s + u);
+                                for (uint32_t u = 0; u < kU; ++u) overflow = overflow || __float_as_uint(lv[u].w) == kFilmPackOverflow;
+                                if (__builtin_expect(overflow, 0)) {  // never, unless the side table ran full: the cold loop below handles such a trip
+                                    break;
+                                }
+#pragma unroll
+                                for (uint32_t u = 0; u < kU; ++u) {
+                                    splat(lv[u], s + u, std::false_type{});
+                                    __builtin_amdgcn_sched_barrier(0);  // one sample after the other: interleaving the eight bodies costs registers (a wave per SIMD)
+                                }
                             }
-                            for (; s < spp; ++s) splat(L[(size_t)s * npix + pix], s);
+#pragma unroll 1
+                            for (; s < spp; ++s, sp += sstride) splat(*sp, s, std::true_type{});  // the remainder — and everything after an overflow marker
                         }
                     for (int j = 0; j < BY; ++j)
                         for (int i = 0; i < BX; ++i)

@@ -60,6 +60,7 @@ struct WideScene {            // device view of the v2 node array
     float tight_scale;        // slab_test2's margin as a fraction of the ray's reach (2^-14); 0: the reference's loose test alone
     const uint32_t* leaf_order;  // one-leaf scenes: the order in which any-hit rays test the leaf's primitives (k_any_leaf); null = slot order
     uint32_t leaf_tight;      // every triangle leaf's box is exactly the union of its triangles' boxes (k_trace7's cheap interior test needs it)
+    float sphere_lag;         // k_trace7: 64 ulp / (smallest world-space sphere radius), so that lag_s = sphere_lag x D^2 x max |1 / d|; 0 without spheres
 };
 
 // The t_max-independent part of bounds.jl:186-206; returns false when the box is certainly missed, otherwise tx_min (to be

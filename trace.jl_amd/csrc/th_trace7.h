@@ -28,9 +28,12 @@
 // which never rejects a box that holds an acceptable hit; the reference's exact test runs once per leaf reached, on the box recomputed from the leaf's
 // vertices (min / max are exact).  Subtrees that hold a sphere keep the exact test on every box (their leaves' boxes come from the sphere records).
 //
-// gap = 4 m, cull margin = 5 m with m = 2^-14 x (largest coordinate offset between the ray origin and the scene bound) x max |1 / d|: the slack
-// of the box entry against a hit inside the box (<= m, the tight clauses' margin) plus the rounding of `t_max * det` and `ts * (1 / det)`.
-// A candidate culled by a box (entry > t_best + 5 m) has t > t_best + 4 m >= t_w + gap: nothing inside the gap is ever skipped.
+// gap = 4 m, cull margin = 5 m with m = 2^-17 x D x max |1 / d|, D = the largest coordinate offset between the ray origin and the scene bound: the watertight
+// triangle test accepts rays that pass within ~40 ulps of |v - o| <= D of the triangle (translate, shear, edge functions: th_trace2.h), so a box's entry lags a hit
+// inside it by less than 40 ulps of D in the entering axis — a third of m — and the roundings of `t_max * det` and `ts * (1 / det)` are ulps of t.  A candidate culled
+// by a box (entry > t_best + 5 m) therefore has t > t_best + 4 m >= t_w + gap: nothing inside the gap is ever skipped.  (The box tests' own margin stays slab_test2's
+// 2^-14 D per axis: it only widens boxes.)  Boxes on a sphere's path are culled with `lag_s` more slack: the Float32 quadratic can report a hit up to
+// ~64 ulp x D^2 / r outside the sphere (the limb rule in sphere_candidate7 flags those rays when they are tested; the slack makes sure they ARE tested).
 #pragma once
 #include "th_trace2.h"
 #include "th_trace8.h"  // FallbackList
@@ -55,7 +58,7 @@ namespace th {
 
 // One child box: the reference's slab arithmetic and clauses (bounds.jl:186-198 without the t_max clause) AND the two tight clauses on the box grown
 // by m (slab_test2).  Returns the entry distance, +Inf when the box is missed.  No NaN can occur: rays with a zero direction component never get here.
-TH_D float slab_entry7(float bx0, float by0, float bz0, float bx1, float by1, float bz1, f3 o, f3 inv_d, float m, bool tight) {
+TH_D float slab_entry7(float bx0, float by0, float bz0, float bx1, float by1, float bz1, f3 o, f3 inv_d, f3 ma /* margin per axis, in t units: em |1 / d| */, bool tight) {
     const float x0 = (bx0 - o.x) * inv_d.x, x1 = (bx1 - o.x) * inv_d.x;
     const float y0 = (by0 - o.y) * inv_d.y, y1 = (by1 - o.y) * inv_d.y;
     const float z0 = (bz0 - o.z) * inv_d.z, z1 = (bz1 - o.z) * inv_d.z;
@@ -68,26 +71,29 @@ TH_D float slab_entry7(float bx0, float by0, float bz0, float bx1, float by1, fl
     const bool miss_z = (a > hiz) | (loz > b);               // :194
     const float t_in = fmaxf(loz, a);                        // :196
     const float t_out = fminf(hiz, b);                       // :197
-    const float exit_xy = fminf(hix, hiy);
-    const bool miss_tight = tight & ((loz > exit_xy + (m + m)) | (exit_xy < -m));
+    // the two clauses bounds.jl:190 lost, on the box grown by em per axis (slab_test2): z entry <= min(x exit, y exit), and that exit >= 0
+    const float exit_xy = fminf(hix + ma.x, hiy + ma.y);
+    const bool miss_tight = tight & ((loz - ma.z > exit_xy) | (exit_xy < 0.0f));
     const bool hit = !(miss_xy | miss_z | miss_tight) & (t_out > 0.0f);  // :198 without `t_in < t_max` (the caller's, with its margin)
     return hit ? t_in : kInf;
 }
 
 // CHEAP interior boxes: the standard slab test, one fma per plane (t = plane / d - o / d), on the box grown by m; conservative for every box that holds a hit
 // the primitive tests accept (th_trace2.h, slab_test2's argument) — nothing else is asked of it.
-TH_D float slab_entry_cheap(float bx0, float by0, float bz0, float bx1, float by1, float bz1, f3 inv_d, f3 noid, float m) {
+TH_D float slab_entry_cheap(float bx0, float by0, float bz0, float bx1, float by1, float bz1, f3 inv_d, f3 noid, f3 ma) {
     const float x0 = __fmaf_rn(bx0, inv_d.x, noid.x), x1 = __fmaf_rn(bx1, inv_d.x, noid.x);
     const float y0 = __fmaf_rn(by0, inv_d.y, noid.y), y1 = __fmaf_rn(by1, inv_d.y, noid.y);
     const float z0 = __fmaf_rn(bz0, inv_d.z, noid.z), z1 = __fmaf_rn(bz1, inv_d.z, noid.z);
-    const float t_in = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
-    const float t_out = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
-    const bool hit = (t_in <= t_out + (m + m)) & (t_out >= -m);  // a NaN (the empty leaf's box) fails both
-    return hit ? t_in : kInf;
+    // every slab grown by em in its own axis (em |1 / d_axis| in t units): a single scalar margin would inflate the other two axes of a grazing ray's boxes
+    const float t_in = fmaxf(fmaxf(fminf(x0, x1) - ma.x, fminf(y0, y1) - ma.y), fminf(z0, z1) - ma.z);
+    const float t_out = fminf(fminf(fmaxf(x0, x1) + ma.x, fmaxf(y0, y1) + ma.y), fmaxf(z0, z1) + ma.z);
+    const bool hit = (t_in <= t_out) & (t_out >= 0.0f);  // a NaN (the empty leaf's box) fails both
+    return hit ? t_in : kInf;  // the entry of the GROWN box: never later than the exact box's
 }
 
 // sphere.jl:125-158 up to the roots, as sphere_intersect (th_device.h); 0 = no candidate inside t_lim, 1 = candidate at t, 2 = the ray must be re-traced
-// in the reference's order (origin inside the sphere: t_max is ignored, A.18; a clipped sphere; the limb, where the quadratic accepts rays outside the box)
+// in the reference's order (a clipped sphere; the limb, where the quadratic accepts rays outside the box), 3 = the origin is inside the sphere: the reference
+// accepts t1 whatever t_max is, so it ends up as the answer in every visiting order iff it is the nearest candidate — the caller flags the ray otherwise
 template <bool FULL_ONLY>
 TH_D int sphere_candidate7(const SphereRec& s, f3 o, f3 d, float t_lim, float& t) {
     const f3 oo = xf_point(s.o2w_inv, o);
@@ -103,11 +109,18 @@ TH_D int sphere_candidate7(const SphereRec& s, f3 o, f3 d, float t_lim, float& t
         // answer is "miss" whatever the order, so nothing to flag
         return 0;
     }
-    if (t0 > t_lim || t1 < 0.0f) return 0;
-    if (t0 < 0.0f) return 2;
+    if (t1 < 0.0f) return 0;
     if (!FULL_ONLY && !s.never_clipped) return 2;
+    if (t0 < 0.0f) {  // the origin is inside: the reference takes t1 WITHOUT looking at t_max (sphere.jl:137-138, A.18) — a candidate that can raise t_max
+        t = t1;
+        return 3;
+    }
+    if (t0 > t_lim) return 0;
+    // the limb: b*b - 4ac carries an absolute error of a few ulps of b*b and of 4 a |o|^2; a discriminant within 64 ulps of those cannot tell a grazing hit from a
+    // near miss, and a "hit" at the point of closest approach of a near miss lies outside the sphere's box — whether the reference reaches that leaf depends on
+    // the boxes on the way.  Above the bound the ray truly pierces the sphere: the hit point is on it, inside every ancestor box.
     const float disc = b * b - 4 * a * c;
-    if (disc < 0.01f * (b * b)) return 2;  // chord shorter than a tenth of the diameter's: the limb
+    if (disc < 3.8e-6f * (b * b + 4 * a * (no * no))) return 2;
     t = t0;
     return 1;
 }
@@ -132,26 +145,39 @@ __global__ __launch_bounds__(kBlock, BIG ? TH_TRACE7_WAVES - 1 : TH_TRACE7_WAVES
     int sp = 0;
     f3 o = splat3(0.0f), inv_d = splat3(0.0f);
     f3 noid = splat3(0.0f);  // CHEAP: -o / d per axis
-    bool cur_exact = true;   // CHEAP: the node in `cur` was reached through the reference's exact box tests (a sphere's path); a triangle leaf reached otherwise tests its own box first
     RayShear shear{0, 0.0f, 0.0f, 0.0f};
-    float m = 0.0f;         // the margin in t units
+    f3 ma = splat3(0.0f);   // the box tests' margin per axis in t units: em |1 / d_axis| (em = 2^-14 D, slab_test2's)
+    float m = 0.0f;         // the tie / cull margin in t units: 2^-17 D max |1 / d| (header)
+    float lag_s = 0.0f;     // how far a box on a sphere's path can be entered behind that sphere's (limb) hit: its boxes are culled with this much more slack
     float t_best = kInf;    // smallest candidate t so far (the hit record in out.hits belongs to it)
     float t_second = kInf;  // smallest t among the other candidates seen
     float t_cull = kInf;    // min(t_best, the ray's own t_max) + 5 m: boxes entered beyond it and candidates beyond it do not matter
     float t_own = kInf;     // the ray's own t_max
+    float t_raise = kInf;   // smallest t of a sphere entered from inside (it ignores t_max): must end up as the nearest candidate, or the ray is flagged
     bool flagged = false;
     uint32_t nn = 0, np = 0;
     unsigned long long n_fb = 0;
+    // COUNT (option "count_visits"): why rays went to the fallback list — 0: zero / non-finite direction or origin, 1: a sphere (origin inside, limb, clipped),
+    // 2: a candidate within the gap of the ray's own t_max, 3: a second candidate within the gap of the nearest
+    uint32_t why = 0;
+    unsigned long long n_why[4] = {0ull, 0ull, 0ull, 0ull};
 
     while (true) {
         // ---- rays to re-trace in the reference's order: appended to the fallback list (wave-wide) ----
+        // kSeg lists of fb.cap entries, one counter each (a single counter word serialises at ~88 atomics per microsecond: 3 ms for the flagged rays of one
+        // launch); a wave starts at its own segment and moves on while a list is full — together they hold as many entries as the queue has rays
         if (__ballot(to_fb) != 0ull) {
-            const uint32_t j = wave_compact(to_fb, &fb.counts[0]);
-            if (to_fb) {
-                fb.list[j] = fb_idx;
-                n_fb++;
+            uint32_t fseg = __builtin_amdgcn_readfirstlane((gtid >> 6) % kSeg);
+            for (int tries = 0; tries < kSeg && __ballot(to_fb) != 0ull; ++tries) {
+                const uint32_t j = wave_compact(to_fb, &fb.counts[fseg * kCtrStride]);
+                if (to_fb && j < fb.cap) {
+                    fb.list[(size_t)fseg * fb.cap + j] = fb_idx;
+                    n_fb++;
+                    to_fb = false;
+                }
+                fseg = (fseg + 1) % kSeg;
             }
-            to_fb = false;
+            to_fb = false;  // (cannot be left over: the lists' total capacity is the queue's)
         }
         // ---- refill idle lanes (as k_trace3) ----
         const unsigned long long idle = __ballot(!active);
@@ -185,12 +211,14 @@ __global__ __launch_bounds__(kBlock, BIG ? TH_TRACE7_WAVES - 1 : TH_TRACE7_WAVES
                         const f3 d = mk3(d4.x, d4.y, d4.z);
                         inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
                         const float em = slab_margin(ws.root_box, ws.tight_scale, o);
-                        m = em * fmaxf(fmaxf(fabsf(inv_d.x), fabsf(inv_d.y)), fabsf(inv_d.z));
+                        ma = mk3(em * fabsf(inv_d.x), em * fabsf(inv_d.y), em * fabsf(inv_d.z));
+                        const float D = em / ws.tight_scale, inv_max = fmaxf(fmaxf(fabsf(inv_d.x), fabsf(inv_d.y)), fabsf(inv_d.z));
+                        m = 7.62939453125e-6f * D * inv_max;  // 2^-17 D max |1 / d|: 128 ulps of D against the <= 40 ulps the primitive tests' hit points can lie outside their boxes
+                        lag_s = ws.sphere_lag * (D * D) * inv_max;
                         shear = ray_shear(d);
                         if (CHEAP) noid = mk3(-(o.x * inv_d.x), -(o.y * inv_d.y), -(o.z * inv_d.z));
-                        cur_exact = true;
                         t_own = tmax_or_null ? tmax_or_null[idx] : kInf;
-                        t_best = t_second = kInf;
+                        t_best = t_second = t_raise = kInf;
                         t_cull = t_own + 5.0f * m;
                         sp = 0;
                         flagged = false;
@@ -198,17 +226,23 @@ __global__ __launch_bounds__(kBlock, BIG ? TH_TRACE7_WAVES - 1 : TH_TRACE7_WAVES
                         if (COUNT) nn++;
                         // what the argument above does not cover goes to k_trace3 at once: a zero or non-finite direction component (0 x Inf = NaN in the slab
                         // products; the reference's selects and this kernel's min / max then disagree), a non-finite origin or margin
+                        // … and rays that start far outside the scene (a camera 50 scene sizes away): every margin here scales with D, the reach of the ray's
+                        // Float32 arithmetic, and at D >> scene size the gap swallows the scene's detail — most such rays would be flagged anyway, and they are the
+                        // coherent ones k_trace3 walks fastest
+                        const float extent = fmaxf(fmaxf(ws.root_box[3] - ws.root_box[0], ws.root_box[4] - ws.root_box[1]), ws.root_box[5] - ws.root_box[2]);
                         const bool plain = d.x != 0.0f && d.y != 0.0f && d.z != 0.0f && m < kInf && m == m && fabsf(o.x) < kInf && fabsf(o.y) < kInf && fabsf(o.z) < kInf &&
-                                           fabsf(inv_d.x) < kInf && fabsf(inv_d.y) < kInf && fabsf(inv_d.z) < kInf;
+                                           fabsf(inv_d.x) < kInf && fabsf(inv_d.y) < kInf && fabsf(inv_d.z) < kInf && D <= 8.0f * extent;
+                        if (COUNT) why = 0;
                         if (!plain) {
                             to_fb = true;
                             fb_idx = idx;
                             active = false;
+                            if (COUNT) n_why[0]++;
                         } else {
                             const float t_in = ws.root_ref != kRefNone
-                                                   ? slab_entry7(ws.root_box[0], ws.root_box[1], ws.root_box[2], ws.root_box[3], ws.root_box[4], ws.root_box[5], o, inv_d, m, false)
+                                                   ? slab_entry7(ws.root_box[0], ws.root_box[1], ws.root_box[2], ws.root_box[3], ws.root_box[4], ws.root_box[5], o, inv_d, ma, false)
                                                    : kInf;
-                            if (t_in <= t_cull) {
+                            if (t_in < kInf && t_in <= t_cull) {  // (+Inf = missed; t_cull is +Inf until a candidate is found: `<=` alone would let it through)
                                 cur = ws.root_ref;
                                 cur_cnt = ws.root_cnt;
                             } else {
@@ -248,7 +282,6 @@ __global__ __launch_bounds__(kBlock, BIG ? TH_TRACE7_WAVES - 1 : TH_TRACE7_WAVES
                     if (tin <= t_cull) {
                         cur = enc & 0x00ffffffu;
                         cur_cnt = enc >> 24;
-                        if (CHEAP) cur_exact = tin == -kInf;
                         finished = false;
                         break;
                     }
@@ -257,9 +290,12 @@ __global__ __launch_bounds__(kBlock, BIG ? TH_TRACE7_WAVES - 1 : TH_TRACE7_WAVES
             if (finished) {  // the walk is over: a miss, a clean hit (stored when it was found), or a ray for the reference-order walk
                 active = false;
                 const bool found = t_best < kInf;
-                if (flagged || (found && t_second <= t_best + 4.0f * m)) {
+                const bool tie = found && t_second <= t_best + 4.0f * m;
+                const bool raised = t_raise < kInf && t_best < t_raise;  // a sphere entered from inside lost to a nearer candidate: the reference's answer depends on its order
+                if (flagged || tie || raised) {
                     to_fb = true;
                     fb_idx = idx;
+                    if (COUNT) n_why[(flagged || raised) ? (why == 2u ? 2 : 1) : 3]++;
                 } else if (!found) {
                     out.hits[idx] = make_float4(kInf, __int_as_float(-1), 0.0f, 0.0f);
                 }
@@ -283,25 +319,29 @@ __global__ __launch_bounds__(kBlock, BIG ? TH_TRACE7_WAVES - 1 : TH_TRACE7_WAVES
                 const uint32_t lenc = __float_as_uint(a3.x), renc = __float_as_uint(a3.y), meta = __float_as_uint(a3.z);
                 float tl, tr;
                 if (CHEAP) {
-                    tl = slab_entry_cheap(a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, inv_d, noid, m);
-                    tr = slab_entry_cheap(a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, inv_d, noid, m);
-                    if (meta & 12u) {  // a child on a sphere's path (rare): the reference's exact test, no tight clauses
-                        if (meta & 4u) tl = slab_entry7(a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, o, inv_d, m, false);
-                        if (meta & 8u) tr = slab_entry7(a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, o, inv_d, m, false);
-                    }
+                    // grown by 2^-17 D per axis (an eighth of the tight clauses' margin; the hits the primitive tests accept lie within 40 ulps of D of their boxes)
+                    const f3 mc = mk3(0.125f * ma.x, 0.125f * ma.y, 0.125f * ma.z);
+                    tl = slab_entry_cheap(a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, inv_d, noid, mc);
+                    tr = slab_entry_cheap(a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, inv_d, noid, mc);
                 } else {
-                    tl = slab_entry7(a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, o, inv_d, m, !(meta & 4u));
-                    tr = slab_entry7(a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, o, inv_d, m, !(meta & 8u));
+                    tl = slab_entry7(a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, o, inv_d, ma, true);
+                    tr = slab_entry7(a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, o, inv_d, ma, true);
                 }
-                // A subtree that holds a sphere is never culled by distance: the Float32 quadratic accepts rays that pass OUTSIDE the sphere's box (by up to
-                // 1e-3 |o - c|), and bounds.jl:190's loose test can pass such a box with an entry far beyond the sphere's t — the reference reaches that leaf
-                // or not depending on its order.  Entered whenever the reference's t_max-free clauses pass (entry -Inf), those rays get flagged at the leaf.
-                if ((meta & 4u) && tl < kInf) tl = -kInf;
-                if ((meta & 8u) && tr < kInf) tr = -kInf;
-                const bool l_first = tl <= tr;  // front to back by entry distance
-                const float tn = l_first ? tl : tr, tf = l_first ? tr : tl;
+                if (meta & 12u) {
+                    // a child on a sphere's path (rare): the reference's exact test without the tight clauses — a sphere's Float32 "hit" may lie outside its
+                    // box — and lag_s more slack against the cull distance (ordering and culling then see the entry that much earlier)
+                    if (meta & 4u) tl = slab_entry7(a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, o, inv_d, ma, false) - lag_s;
+                    if (meta & 8u) tr = slab_entry7(a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, o, inv_d, ma, false) - lag_s;
+                }
+                // front to back by entry distance; both entries behind the origin (the ray starts inside both boxes — every ray leaving a surface does near its
+                // own leaf): the side the ray travels towards first, i.e. the reference's rule (bvh.jl:239-246: second child first where d[split axis] < 0)
+                const uint32_t axis = meta & 3u;
+                const bool neg = (axis == 0u ? inv_d.x : (axis == 1u ? inv_d.y : inv_d.z)) < 0.0f;
+                const float cl = fmaxf(tl, 0.0f), cr = fmaxf(tr, 0.0f);
+                const bool l_first = cl == cr ? !neg : cl < cr;
+                const float tn = l_first ? tl : tr, tf = l_first ? tr : tl;  // (a missed child is +Inf: never first unless both are)
                 const uint32_t nenc = l_first ? lenc : renc, fenc = l_first ? renc : lenc;
-                const bool go_n = tn <= t_cull, go_f = tf <= t_cull;  // tn <= tf: go_f implies go_n
+                const bool go_n = (tn < kInf) & (tn <= t_cull), go_f = (tf < kInf) & (tf <= t_cull);  // +Inf = missed (t_cull is +Inf until a candidate is found); tn <= tf: go_f implies go_n
                 if (go_f) {
                     if (sp < kLds) {
                         s_ref[sp][tid] = fenc;
@@ -315,13 +355,11 @@ __global__ __launch_bounds__(kBlock, BIG ? TH_TRACE7_WAVES - 1 : TH_TRACE7_WAVES
                 }
                 cur = go_n ? (nenc & 0x00ffffffu) : kRefNone;
                 cur_cnt = go_n ? (nenc >> 24) : 0u;
-                if (CHEAP) cur_exact = tn == -kInf;
                 if (!go_n && sp > 0) {  // nothing was pushed: the top read above is still the top
                     sp--;
                     if (top_tin <= t_cull) {
                         cur = top_enc & 0x00ffffffu;
                         cur_cnt = top_enc >> 24;
-                        if (CHEAP) cur_exact = top_tin == -kInf;
                     }
                 }
             }
@@ -343,7 +381,7 @@ __global__ __launch_bounds__(kBlock, BIG ? TH_TRACE7_WAVES - 1 : TH_TRACE7_WAVES
                 }
             }
             bool enter = true;
-            if (CHEAP && !cur_exact) {
+            if (CHEAP) {
                 // the reference enters this leaf iff ITS box test passes (bounds.jl:186-198; the ancestors then pass too: header) — on the leaf's box, which is the
                 // union of its triangles' boxes (verified at upload: WideScene::leaf_tight).  A leaf of several triangles reads them twice (the second time from L1).
                 float bx0 = kInf, by0 = kInf, bz0 = kInf, bx1 = -kInf, by1 = -kInf, bz1 = -kInf;
@@ -361,10 +399,8 @@ __global__ __launch_bounds__(kBlock, BIG ? TH_TRACE7_WAVES - 1 : TH_TRACE7_WAVES
                     by1 = fmaxf(by1, fmaxf(fmaxf(p0.y, p1.y), p2.y));
                     bz1 = fmaxf(bz1, fmaxf(fmaxf(p0.z, p1.z), p2.z));
                 }
-                if (has_sphere)
-                    flagged = true;  // cannot happen (a sphere's leaf is reached through exact tests); never decide such a leaf from a triangle's box
-                else
-                    enter = slab_entry7(bx0, by0, bz0, bx1, by1, bz1, o, inv_d, m, false) < kInf;
+                // a leaf that holds a sphere was reached through the exact tests of the sphere's path (its parent carries the bit): nothing more to decide
+                if (!has_sphere) enter = slab_entry7(bx0, by0, bz0, bx1, by1, bz1, o, inv_d, ma, false) < kInf;
             }
             for (uint32_t k = 0; enter && k < cur_cnt; ++k) {
                 const uint32_t slot = cur + k;
@@ -383,7 +419,13 @@ __global__ __launch_bounds__(kBlock, BIG ? TH_TRACE7_WAVES - 1 : TH_TRACE7_WAVES
                     inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
                     shear = ray_shear(d);
                     if (r == 2) flagged = true;
-                    cand = r == 1;
+                    cand = r == 1 || r == 3;
+                    // r == 3 (origin inside): whoever is tested after it is measured against ITS t, whoever came before is overwritten — unless something nearer
+                    // exists, the answer is this sphere in every order.  Something nearer (found before or after) makes the order matter: flagged
+                    if (r == 3) {
+                        if (t_c >= t_best) flagged = true;
+                        t_raise = fminf(t_raise, t_c);
+                    }
                     rec = make_float4(t_c, __int_as_float((int)slot), 0.0f, 0.0f);
                 } else {
                     TriTest tt;
@@ -395,6 +437,7 @@ __global__ __launch_bounds__(kBlock, BIG ? TH_TRACE7_WAVES - 1 : TH_TRACE7_WAVES
                 }
                 if (cand) {
                     if (t_c > t_own - 4.0f * m) {
+                        if (COUNT) why = 2u;
                         flagged = true;  // within the gap of the ray's own t_max (or beyond it): the reference's `t_scaled > t_max * det` decides, not this walk
                     } else if (t_c < t_best) {
                         t_second = fminf(t_second, t_best);
@@ -414,7 +457,6 @@ __global__ __launch_bounds__(kBlock, BIG ? TH_TRACE7_WAVES - 1 : TH_TRACE7_WAVES
                 if (top_tin <= t_cull) {
                     cur = top_enc & 0x00ffffffu;
                     cur_cnt = top_enc >> 24;
-                    if (CHEAP) cur_exact = top_tin == -kInf;
                 }
             }
         }
@@ -428,6 +470,10 @@ __global__ __launch_bounds__(kBlock, BIG ? TH_TRACE7_WAVES - 1 : TH_TRACE7_WAVES
             if (lane_id() == 0) {
                 atomicAdd(&ctr->nodes_closest, sn);
                 atomicAdd(&ctr->prims_closest, spr);
+            }
+            for (int k = 0; k < 4; ++k) {
+                const unsigned long long w = wave_sum(n_why[k]);
+                if (lane_id() == 0 && w) atomicAdd(&ctr->fallback_why[k], w);
             }
         }
     }

@@ -45,6 +45,7 @@ void trhip_shutdown(trhip_ctx* ctx) {
     release(ctx->overflow);
     release(ctx->pfilm);
     release(ctx->fdesc);
+    release(ctx->film_side);
     for (auto& pp : ctx->pipes) {
         for (auto& a : pp.q)
             for (auto& b : a) release(b);
@@ -196,7 +197,9 @@ int trhip_set_option(trhip_ctx* ctx, const char* name, int64_t value) {
     else if (!std::strcmp(name, "tiny_scene_prims"))
         ctx->tiny_scene_prims = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(255, value));
     else if (!std::strcmp(name, "film_block"))
-        ctx->film_block = (int)std::max<int64_t>(0, std::min<int64_t>(9, value));
+        ctx->film_block = (int)std::max<int64_t>(0, std::min<int64_t>(13, value));
+    else if (!std::strcmp(name, "film_relayout"))
+        ctx->film_relayout = value != 0;
     else if (!std::strcmp(name, "film_tiled"))
         ctx->film_tiled = value != 0;
     else if (!std::strcmp(name, "pipelines")) {

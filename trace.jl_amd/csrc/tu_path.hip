@@ -56,16 +56,35 @@ int ensure_film_samples(trhip_ctx* ctx, const DeviceSensor& ds, uint64_t total_s
 void launch_film(trhip_ctx* ctx, hipStream_t st, const DeviceSensor& ds, const DeviceSensor* dsp, const float4* L, uint64_t total_slots, uint32_t spp, uint64_t seed, uint32_t sample_offset,
                  float4* d_film) {
     if (film_uses_packed(ctx, ds)) {
-        hipLaunchKernelGGL(k_film_pack_w, dim3(grid_for(ctx, total_slots, 8)), dim3(kBlock), 0, st, dsp, total_slots, seed, sample_offset, const_cast<float4*>(L));
+        // the descriptors go into the records' .w lanes — on the way into a pixel-group-major copy when there is room for one (option "film_relayout", default on)
+        const uint32_t npix_b = (uint32_t)(ds.sb_w * ds.band_rows);
+        const uint64_t padded = (uint64_t)((npix_b + 63u) / 64u) * 64u * spp;
+        uint32_t layout = 0;
+        // side table for the descriptors that do not fit 30 bits (one sample in ~4000 at 1024^2): entry 0 of film_side is the counter, the descriptors follow
+        const uint32_t side_cap = (uint32_t)std::min<uint64_t>(total_slots / 16 + 65536, 0x7ffffff0ull);
+        if (ensure(ctx, ctx->film_side, ((size_t)side_cap + 1) * sizeof(uint4)) != 0) return;
+        (void)hipMemsetAsync(ctx->film_side.p, 0, sizeof(uint4), st);
+        const FilmSideTable side{(uint4*)ctx->film_side.p + 1, (uint32_t*)ctx->film_side.p, side_cap};
+        if (ctx->film_relayout && total_slots == (uint64_t)npix_b * spp && ensure(ctx, ctx->film_Lt, padded * sizeof(float4)) == 0) {
+            layout = 1;
+            hipLaunchKernelGGL(k_film_pack_transpose, dim3(grid_for(ctx, padded, 8)), dim3(kBlock), 0, st, dsp, npix_b, spp, seed, sample_offset, L, (float4*)ctx->film_Lt.p, side);
+            L = (const float4*)ctx->film_Lt.p;
+        } else {
+            hipLaunchKernelGGL(k_film_pack_w, dim3(grid_for(ctx, total_slots, 8)), dim3(kBlock), 0, st, dsp, total_slots, seed, sample_offset, const_cast<float4*>(L), side);
+        }
         const float* tb = (const float*)ctx->table.p;
         auto threads = [&](int bx, int by) { return (uint64_t)((ds.film_w + bx - 1) / bx) * (uint64_t)((ds.film_h + by - 1) / by); };
-#define TH_FILM_PACKED(BXV, BYV) hipLaunchKernelGGL((k_film_gather_packed<BXV, BYV>), dim3(grid_for(ctx, threads(BXV, BYV), 8)), dim3(kBlock), 0, st, dsp, tb, L, spp, seed, sample_offset, d_film)
+#define TH_FILM_PACKED(BXV, BYV) hipLaunchKernelGGL((k_film_gather_packed<BXV, BYV>), dim3(grid_for(ctx, threads(BXV, BYV), 8)), dim3(kBlock), 0, st, dsp, tb, L, spp, seed, sample_offset, layout, (const uint4*)side.desc, d_film)
         switch (ctx->film_block) {
         case 4: TH_FILM_PACKED(1, 4); break;
         case 5: TH_FILM_PACKED(2, 4); break;
         case 7: TH_FILM_PACKED(2, 2); break;
         case 8: TH_FILM_PACKED(4, 2); break;
         case 9: TH_FILM_PACKED(8, 4); break;
+        case 10: TH_FILM_PACKED(1, 8); break;
+        case 11: TH_FILM_PACKED(1, 16); break;
+        case 12: TH_FILM_PACKED(1, 2); break;
+        case 13: TH_FILM_PACKED(1, 1); break;
         default: TH_FILM_PACKED(4, 4); break;  // 6
         }
 #undef TH_FILM_PACKED
@@ -537,6 +556,7 @@ int render_impl_band(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
             stats->nodes_visited_shadow += h.nodes_shadow;
             stats->prims_tested_shadow += h.prims_shadow;
             stats->fallback_rays += h.fallback_total;
+            for (int k = 0; k < 4; ++k) stats->count_sub[k] += h.fallback_why[k];
         }
         float ms = 0;
         (void)hipEventElapsedTime(&ms, e0, e1);

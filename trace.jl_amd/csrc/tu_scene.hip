@@ -322,6 +322,11 @@ int upload_scene(trhip_scene* s) {
         if (ok) {
             if (int rc = upload(ctx, s->d_wnodes, wn.data(), wn.size() * sizeof(float4))) return rc;
             s->wide.leaf_tight = leaf_tight ? 1u : 0u;
+            // the smallest sphere, in world units (half the smallest extent of its world bound): how far outside itself its Float32 quadratic can report a hit
+            float r_min = INFINITY;
+            for (const HostAABB& sb : s->sphere_bounds)
+                for (int ax = 0; ax < 3; ++ax) r_min = std::fmin(r_min, 0.5f * (sb.mx[ax] - sb.mn[ax]));
+            s->wide.sphere_lag = (s->sphere_bounds.empty() || !(r_min > 0.0f)) ? 0.0f : 3.8e-6f / r_min;
             s->wide.wnodes = (const float4*)s->d_wnodes.p;
             s->wide.n_wnodes = n_int;
             std::memcpy(s->wide.root_box, &s->bvh.bounds[0], 6 * sizeof(float));

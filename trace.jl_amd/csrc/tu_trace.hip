@@ -102,15 +102,16 @@ void launch_trace(trhip_ctx* ctx, hipStream_t st, const trhip_scene* sc, bool an
         // ---- traversal 7: closest-hit rays front to back (th_trace7.h); the rays whose answer depends on the visiting order come back on ONE fallback list
         //      (segment 0 of a SegQueue whose other segments are empty) that k_trace3 walks below ----
         if (!any && uses_trace7(ctx, sc) && !q.indirect) {
-            const uint64_t total = q.counts ? (uint64_t)q.cap * kSeg : q.n_dense;
+            // kSeg lists of `fcap` entries: together as many as the queue holds rays (a wave whose list is full moves on to the next one)
+            const uint32_t fcap = q.counts ? q.cap : (q.n_dense + kSeg - 1) / kSeg;
             const size_t ctr_words = 2 * (size_t)kSeg * kCtrStride;  // counts, then the work cursors of the fallback launch
-            if (total < (1ull << 32) && ensure(ctx, ctx->fb_list[0], (size_t)total * sizeof(uint32_t)) == 0 && ensure(ctx, ctx->fb_counts[0], ctr_words * sizeof(uint32_t)) == 0) {
+            if (ensure(ctx, ctx->fb_list[0], (size_t)fcap * kSeg * sizeof(uint32_t)) == 0 && ensure(ctx, ctx->fb_counts[0], ctr_words * sizeof(uint32_t)) == 0) {
                 uint32_t* fcounts = (uint32_t*)ctx->fb_counts[0].p;
                 (void)hipMemsetAsync(fcounts, 0, ctr_words * sizeof(uint32_t), st);
-                const FallbackList fb{(uint32_t*)ctx->fb_list[0].p, fcounts, (uint32_t)total};
+                const FallbackList fb{(uint32_t*)ctx->fb_list[0].p, fcounts, fcap};
                 const bool big7 = !cnt && (size_t)sc->wide.n_wnodes * 64u + (size_t)sc->dev.n_prims * 48u > ((size_t)256 << 20);
                 launch_trace7(ctx, st, sc, cnt, full_only, big7, q, ro, rd, tmax, out, work_cursors, ov, ctr, fb);
-                q = SegQueue{fcounts, (uint32_t)total, 0u, fb.list, 1u};
+                q = SegQueue{fcounts, fcap, 0u, fb.list, 1u};
                 work_cursors = fcounts + (size_t)kSeg * kCtrStride;
             }
         }
