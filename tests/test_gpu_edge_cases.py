@@ -61,7 +61,7 @@ def test_cropped_film(T, ob, ctx):
         try:
             assert_bits_equal(T.PathIntegrator(cam, T.SeededSampler(3, seed=8), 4).render(scene, ctx), ref, f"cropped film, film_block {mode}")
         finally:
-            ctx.set_option("film_block", 6)
+            ctx.set_option("film_block", 5)
 
 
 def test_degenerate_triangles_and_single_leaf_threshold(T, ob, ctx):
@@ -135,7 +135,7 @@ def test_bench_size_properties(T, ctx):
         try:
             return T.PathIntegrator(cam, T.SeededSampler(spp, seed=0x5EED0001, sample_offset=offset), 8).render(scene, ctx).copy()
         finally:
-            for k, v in {"traversal": 3, "film_block": 6, "batch_paths": 0, "overlap": 0}.items():
+            for k, v in {"traversal": 3, "film_block": 5, "batch_paths": 0, "overlap": 0}.items():
                 ctx.set_option(k, v)
 
     a = render()
@@ -270,6 +270,6 @@ def test_banded_frame_equals_whole_frame(T, ob, ctx, rows):
             banded = integ.render(scene, ctx).copy()
         finally:
             ctx.set_option("band_tile_rows", 0)
-            ctx.set_option("film_block", 6)
+            ctx.set_option("film_block", 5)
         assert_bits_equal(banded, whole, f"bands of {rows} tile rows, film_block {film_block}")
         assert integ.stats.camera_samples == 102 * 102 * 3 and integ.stats.closest_rays == st_ref.closest_rays and integ.stats.launches_film == -(-7 // rows)

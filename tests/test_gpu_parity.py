@@ -273,13 +273,13 @@ def test_film_accumulate_matches_oracle_tile_order(T, ob, ctx):
     finally:
         ctx.set_option("film_tiled", 0)
     assert_bits_equal(out2, ref_xyzw, "film accumulate, LDS-tiled gather")
-    for mode in (0, 1, 2, 3, 6):  # one film pixel per thread, 2 x 2 blocks, 1 x 4 blocks, 1 x 4 from splat descriptors (odd film sizes: 37 x 29); 6: this filter is too wide for
+    for mode in (0, 1, 2, 3, 5):  # one film pixel per thread, 2 x 2 blocks, 1 x 4 blocks, 1 x 4 from splat descriptors (odd film sizes: 37 x 29); 5: this filter is too wide for
         ctx.set_option("film_block", mode)  # the packed descriptor, the library must fall back to the 1 x 4 block gather
         try:
             out3 = np.empty_like(ref_xyzw)
             ctx.check(T.lib().trhip_film_accumulate(ctx._h, C.byref(sn), spp, 5, 0, T._ffi.fptr(ref_L), T._ffi.fptr(out3)))
         finally:
-            ctx.set_option("film_block", 6)
+            ctx.set_option("film_block", 5)
         assert_bits_equal(out3, ref_xyzw, f"film accumulate, film_block={mode}")
 
 
@@ -298,26 +298,28 @@ def test_film_gather_from_packed_descriptors(T, ob, ctx):
         ref_xyzw, ref_L, _ = osc.render(cam, "path", spp, 3, seed=5, want_samples=True)
         sn = cam.sensor()
         outs = {}
-        for mode in (0, 4, 5, 6, 7, 8, 9):
+        for mode, relayout in [(m, 1) for m in (0, 4, 5, 6, 7, 8, 9, 10, 12, 13)] + [(5, 0), (4, 0)]:  # relayout 0: descriptors written in place, sample-major gather
             ctx.set_option("film_block", mode)
+            ctx.set_option("film_relayout", relayout)
             try:
                 out = np.empty_like(ref_xyzw)
                 ctx.check(T.lib().trhip_film_accumulate(ctx._h, C.byref(sn), spp, 5, 0, T._ffi.fptr(ref_L), T._ffi.fptr(out)))
             finally:
-                ctx.set_option("film_block", 6)
-            assert_bits_equal(out, ref_xyzw, f"film {res}, radius {radius}, film_block={mode}")
+                ctx.set_option("film_block", 5)
+                ctx.set_option("film_relayout", 1)
+            assert_bits_equal(out, ref_xyzw, f"film {res}, radius {radius}, film_block={mode}, relayout={relayout}")
         # NaN samples are zeroed (integrators/sampler.jl:46): every variant against the one-pixel-per-thread gather
         bad_L = ref_L.copy()
         bad_L.reshape(-1, 3)[::97, 1] = np.nan
-        for mode in (0, 6, 4, 9):
+        for mode in (0, 5, 4, 9):
             ctx.set_option("film_block", mode)
             try:
                 out = np.empty_like(ref_xyzw)
                 ctx.check(T.lib().trhip_film_accumulate(ctx._h, C.byref(sn), spp, 5, 0, T._ffi.fptr(bad_L), T._ffi.fptr(out)))
             finally:
-                ctx.set_option("film_block", 6)
+                ctx.set_option("film_block", 5)
             outs[mode] = out
-        for mode in (6, 4, 9):
+        for mode in (5, 4, 9):
             assert_bits_equal(outs[mode], outs[0], f"NaN samples, film_block={mode}")
 
 

@@ -65,7 +65,7 @@ def main():
                 outs[name] = out
             finally:
                 for o in opts:
-                    ctx.set_option(o, {"film_block": 6, "film_tiled": 0}[o])
+                    ctx.set_option(o, {"film_block": 5, "film_tiled": 0}[o])
         msgs = []
         base = ref_xyzw if ref_xyzw is not None else outs["default"]
         for name, out in outs.items():

@@ -69,8 +69,9 @@ struct trhip_ctx {
                                      // (th_trace2.h, slab_test2); 0 = the reference's loose test alone (its exact visit set)
     int band_tile_rows = 0;          // DIAGNOSTIC / tests: render frames in bands of this many tile rows (0 = one band unless the samples do not fit in HBM)
     uint32_t tiny_scene_prims = 16;  // scenes of at most this many primitives get a single-leaf BVH (th_bvh.h); 0 = always build the hierarchy
-    int film_block = 6;  // film gather: >= 4 (filter radius <= 1; wider filters run 2): from a 32-bit splat descriptor in the radiance record's .w lane, a thread owning
-                         // 4: 1 x 4, 5: 2 x 4, 6 (default): 4 x 4, 7: 2 x 2, 8: 4 x 2, 9: 8 x 4 film pixels (th_kernels.h, k_film_gather_packed);
+    int film_block = 5;  // film gather: >= 4 (filter radius <= 1; wider filters run 2): from a 32-bit splat descriptor in the radiance record's .w lane, a thread owning
+                         // 4: 1 x 4, 5 (default): 2 x 4, 6: 4 x 4, 7: 2 x 2, 8: 4 x 2, 9: 8 x 4, 10: 1 x 8, 11: 1 x 16, 12: 1 x 2, 13: 1 x 1 film pixels (th_kernels.h,
+                         // k_film_gather_packed; measured at 1024^2 x 256 spp: 19.0 / 17.1 / 24.2 / 25.9 / 30.8 / 40.4 / 17.1 / - / 22.5 / 33.7 ms against 25.0 for 2);
                          // 0 = one film pixel per thread, 1 = 2 x 2 pixels per thread, 2 = TH_FILM_BX x TH_FILM_BY = 1 x 4, all three recomputing a
                          // sample's pixel range and table indices per thread; 3 = 1 x 4 from per-sample splat descriptors (k_film_descriptors): measured SLOWER
                          // (1024^2, 256 spp: 29.0 ms against 24.3 ms: the 16-byte descriptor doubles the gather's loads and the arithmetic it saves was hidden)

@@ -1223,10 +1223,9 @@ __global__ __launch_bounds__(kBlock) void k_film_gather_packed(const DeviceSenso
                             int rxi[BX], ryi[BY];
                             for (int i = 0; i < BX; ++i) rxi[i] = Xi[i] - sx;
                             for (int j = 0; j < BY; ++j) ryi[j] = Yi[j] - sy;
-                            // One sample against the block's pixels, BRANCH-FREE: every lookup is issued for every pixel (clamped indices) before any is
-                            // waited for, and a pixel outside the sample's range adds +0 — csum and fws are never -0 (they start at +0; a sum can only
-                            // reach -0 from -0), so x + 0 == x bit for bit; the products are SELECTED to 0, not multiplied by 0 (an infinite radiance times 0
-                            // would be a NaN).  The straight-line form replaced one branch per row and per pixel with exposed LDS latency behind each.
+                            // One sample against the block's pixels.  (A branch-free form — every lookup issued for every pixel, products selected to 0 — was
+                            // measured: 21.6 ms against 19.0 for 1 x 4, 29.2 against 17.1 for 2 x 4: six in ten (sample, pixel) pairs do not contribute, and the
+                            // branches skip their work for whole waves often enough.)
                             auto splat = [&](float4 l4, uint32_t s, auto cold) {
                                 uint32_t d = __float_as_uint(l4.w);
                                 int p0x, p0y;  // relative to (sx, sy)
@@ -1251,29 +1250,33 @@ __global__ __launch_bounds__(kBlock) void k_film_gather_packed(const DeviceSenso
                                     oxw = (d >> 6) & 0xfffu;
                                     oyw = (d >> 18) & 0xfffu;
                                 }
-                                f3 l = mk3(l4.x, l4.y, l4.z);
-                                if (has_nan(l)) l = splat3(0.0f);  // integrators/sampler.jl:46
+                                uint32_t cx[BX], cy[BY];
                                 bool vx[BX], vy[BY];
-                                uint32_t oxi[BX], row[BY];
+                                bool anyx = false, anyy = false;
                                 for (int i = 0; i < BX; ++i) {
-                                    const uint32_t cx = (uint32_t)(rxi[i] - p0x);
-                                    vx[i] = ok_x[i] && cx < nx;
-                                    oxi[i] = (oxw >> (4u * (cx & 7u))) & 15u;
+                                    cx[i] = (uint32_t)(rxi[i] - p0x);
+                                    vx[i] = ok_x[i] && cx[i] < nx;
+                                    anyx = anyx || vx[i];
                                 }
                                 for (int j = 0; j < BY; ++j) {
-                                    const uint32_t cy = (uint32_t)(ryi[j] - p0y);
-                                    vy[j] = ok_y[j] && cy < ny;
-                                    row[j] = ((oyw >> (4u * (cy & 7u))) & 15u) * 16u;
+                                    cy[j] = (uint32_t)(ryi[j] - p0y);
+                                    vy[j] = ok_y[j] && cy[j] < ny;
+                                    anyy = anyy || vy[j];
                                 }
-                                float w[BY][BX];
+                                if (!(anyx && anyy)) return;
+                                f3 l = mk3(l4.x, l4.y, l4.z);
+                                if (has_nan(l)) l = splat3(0.0f);  // integrators/sampler.jl:46
+                                uint32_t oxi[BX];
+                                for (int i = 0; i < BX; ++i) oxi[i] = (oxw >> (4u * (cx[i] & 7u))) & 15u;
                                 for (int j = 0; j < BY; ++j)
-                                    for (int i = 0; i < BX; ++i) w[j][i] = s_table[row[j] + oxi[i]];
-                                for (int j = 0; j < BY; ++j)
-                                    for (int i = 0; i < BX; ++i) {
-                                        const bool v = vx[i] && vy[j];
-                                        const f3 c = l * w[j][i];  // contrib_sum += l * sample_weight (1) * w
-                                        csum[j][i] = csum[j][i] + mk3(v ? c.x : 0.0f, v ? c.y : 0.0f, v ? c.z : 0.0f);
-                                        fws[j][i] += v ? w[j][i] : 0.0f;
+                                    if (vy[j]) {
+                                        const uint32_t row = ((oyw >> (4u * (cy[j] & 7u))) & 15u) * 16u;
+                                        for (int i = 0; i < BX; ++i)
+                                            if (vx[i]) {
+                                                const float w = s_table[row + oxi[i]];
+                                                csum[j][i] = csum[j][i] + l * w;  // contrib_sum += l * sample_weight (1) * w
+                                                fws[j][i] += w;
+                                            }
                                     }
                             };
                             constexpr uint32_t kU = TH_FILM_PACKED_UNROLL;
@@ -1292,7 +1295,6 @@ __global__ __launch_bounds__(kBlock) void k_film_gather_packed(const DeviceSenso
 #pragma unroll
                                 for (uint32_t u = 0; u < kU; ++u) {
                                     splat(lv[u], s + u, std::false_type{});
-                                    __builtin_amdgcn_sched_barrier(0);  // one sample after the other: interleaving the eight bodies costs registers (a wave per SIMD)
                                 }
                             }
 #pragma unroll 1

@@ -77,7 +77,6 @@ void launch_film(trhip_ctx* ctx, hipStream_t st, const DeviceSensor& ds, const D
 #define TH_FILM_PACKED(BXV, BYV) hipLaunchKernelGGL((k_film_gather_packed<BXV, BYV>), dim3(grid_for(ctx, threads(BXV, BYV), 8)), dim3(kBlock), 0, st, dsp, tb, L, spp, seed, sample_offset, layout, (const uint4*)side.desc, d_film)
         switch (ctx->film_block) {
         case 4: TH_FILM_PACKED(1, 4); break;
-        case 5: TH_FILM_PACKED(2, 4); break;
         case 7: TH_FILM_PACKED(2, 2); break;
         case 8: TH_FILM_PACKED(4, 2); break;
         case 9: TH_FILM_PACKED(8, 4); break;
@@ -85,7 +84,8 @@ void launch_film(trhip_ctx* ctx, hipStream_t st, const DeviceSensor& ds, const D
         case 11: TH_FILM_PACKED(1, 16); break;
         case 12: TH_FILM_PACKED(1, 2); break;
         case 13: TH_FILM_PACKED(1, 1); break;
-        default: TH_FILM_PACKED(4, 4); break;  // 6
+        case 6: TH_FILM_PACKED(4, 4); break;
+        default: TH_FILM_PACKED(2, 4); break;  // 5
         }
 #undef TH_FILM_PACKED
         return;
