@@ -41,7 +41,7 @@
 namespace th {
 
 #ifndef TH_TRACE7_WAVES
-#define TH_TRACE7_WAVES 6
+#define TH_TRACE7_WAVES 5  // 6 waves (80 VGPRs) spill 100 B per lane in the CHEAP variant: 4.78 ms against 4.07 per 8 M bounce rays
 #endif
 #ifndef TH_TRACE7_LDS
 #define TH_TRACE7_LDS 12
@@ -380,33 +380,8 @@ __global__ __launch_bounds__(kBlock, BIG ? TH_TRACE7_WAVES - 1 : TH_TRACE7_WAVES
                     top_tin = __uint_as_float(e.y);
                 }
             }
-            bool enter = true;
-            if (CHEAP) {
-                // the reference enters this leaf iff ITS box test passes (bounds.jl:186-198; the ancestors then pass too: header) — on the leaf's box, which is the
-                // union of its triangles' boxes (verified at upload: WideScene::leaf_tight).  A leaf of several triangles reads them twice (the second time from L1).
-                float bx0 = kInf, by0 = kInf, bz0 = kInf, bx1 = -kInf, by1 = -kInf, bz1 = -kInf;
-                bool has_sphere = false;
-                for (uint32_t k = 0; k < cur_cnt; ++k) {
-                    const uint32_t slot = cur + k;
-                    const float4 p0 = sc.prims[3 * slot];
-                    const float4 p1 = sc.prims[3 * slot + 1], p2 = sc.prims[3 * slot + 2];
-                    asm volatile("" ::"v"(p1.x), "v"(p1.y), "v"(p1.z), "v"(p2.x), "v"(p2.y), "v"(p2.z));
-                    has_sphere = has_sphere || (__float_as_uint(p0.w) & PRIM_SPHERE) != 0u;
-                    bx0 = fminf(bx0, fminf(fminf(p0.x, p1.x), p2.x));
-                    by0 = fminf(by0, fminf(fminf(p0.y, p1.y), p2.y));
-                    bz0 = fminf(bz0, fminf(fminf(p0.z, p1.z), p2.z));
-                    bx1 = fmaxf(bx1, fmaxf(fmaxf(p0.x, p1.x), p2.x));
-                    by1 = fmaxf(by1, fmaxf(fmaxf(p0.y, p1.y), p2.y));
-                    bz1 = fmaxf(bz1, fmaxf(fmaxf(p0.z, p1.z), p2.z));
-                }
-                // a leaf that holds a sphere was reached through the exact tests of the sphere's path (its parent carries the bit): nothing more to decide
-                if (!has_sphere) enter = slab_entry7(bx0, by0, bz0, bx1, by1, bz1, o, inv_d, ma, false) < kInf;
-            }
-            for (uint32_t k = 0; enter && k < cur_cnt; ++k) {
-                const uint32_t slot = cur + k;
-                const float4 p0 = sc.prims[3 * slot];
-                const float4 p1 = sc.prims[3 * slot + 1], p2 = sc.prims[3 * slot + 2];
-                asm volatile("" ::"v"(p1.x), "v"(p1.y), "v"(p1.z), "v"(p2.x), "v"(p2.y), "v"(p2.z));  // one burst (th_trace2.h "one fetch per leaf")
+            // one primitive against the ray (the candidate bookkeeping of the header)
+            auto test_prim = [&](uint32_t slot, float4 p0, float4 p1, float4 p2) {
                 const uint32_t meta = __float_as_uint(p0.w);
                 if (COUNT) np++;
                 float t_c = kInf;
@@ -447,6 +422,55 @@ __global__ __launch_bounds__(kBlock, BIG ? TH_TRACE7_WAVES - 1 : TH_TRACE7_WAVES
                     } else {
                         t_second = fminf(t_second, t_c);
                     }
+                }
+            };
+            if (CHEAP && cur_cnt <= 2u) {
+                // The reference enters this leaf iff ITS box test passes (bounds.jl:186-198; the ancestors then pass too: header) — on the leaf's box, which is the
+                // union of its triangles' boxes (verified at upload: WideScene::leaf_tight).  One or two primitives (97 % of the leaves of the trees built here): both
+                // records in one burst, the box from their vertices, then the tests from the same registers — one trip to memory per leaf, as k_trace3's.
+                const bool two = cur_cnt == 2u;
+                const uint32_t sb = two ? cur + 1u : cur;  // (cnt == 1: the second record is the first again — same line, no branch around the loads)
+                const float4 a0 = sc.prims[3 * cur], a1 = sc.prims[3 * cur + 1], a2 = sc.prims[3 * cur + 2];
+                const float4 b0 = sc.prims[3 * sb], b1 = sc.prims[3 * sb + 1], b2 = sc.prims[3 * sb + 2];
+                asm volatile("" ::"v"(a1.x), "v"(a2.x), "v"(b0.x), "v"(b1.x), "v"(b2.x));
+                const bool has_sphere = ((__float_as_uint(a0.w) | __float_as_uint(b0.w)) & PRIM_SPHERE) != 0u;
+                bool enter = true;
+                if (!has_sphere) {  // (a leaf that holds a sphere was reached through the exact tests of the sphere's path: nothing more to decide)
+                    const float bx0 = fminf(fminf(fminf(a0.x, a1.x), a2.x), fminf(fminf(b0.x, b1.x), b2.x)), bx1 = fmaxf(fmaxf(fmaxf(a0.x, a1.x), a2.x), fmaxf(fmaxf(b0.x, b1.x), b2.x));
+                    const float by0 = fminf(fminf(fminf(a0.y, a1.y), a2.y), fminf(fminf(b0.y, b1.y), b2.y)), by1 = fmaxf(fmaxf(fmaxf(a0.y, a1.y), a2.y), fmaxf(fmaxf(b0.y, b1.y), b2.y));
+                    const float bz0 = fminf(fminf(fminf(a0.z, a1.z), a2.z), fminf(fminf(b0.z, b1.z), b2.z)), bz1 = fmaxf(fmaxf(fmaxf(a0.z, a1.z), a2.z), fmaxf(fmaxf(b0.z, b1.z), b2.z));
+                    enter = slab_entry7(bx0, by0, bz0, bx1, by1, bz1, o, inv_d, ma, false) < kInf;
+                }
+                if (enter) {
+                    test_prim(cur, a0, a1, a2);
+                    if (two) test_prim(cur + 1u, b0, b1, b2);
+                }
+            } else {
+                bool enter = true;
+                if (CHEAP) {  // a leaf of three or more: read twice (the second time from L1)
+                    float bx0 = kInf, by0 = kInf, bz0 = kInf, bx1 = -kInf, by1 = -kInf, bz1 = -kInf;
+                    bool has_sphere = false;
+                    for (uint32_t k = 0; k < cur_cnt; ++k) {
+                        const uint32_t slot = cur + k;
+                        const float4 p0 = sc.prims[3 * slot];
+                        const float4 p1 = sc.prims[3 * slot + 1], p2 = sc.prims[3 * slot + 2];
+                        asm volatile("" ::"v"(p1.x), "v"(p1.y), "v"(p1.z), "v"(p2.x), "v"(p2.y), "v"(p2.z));
+                        has_sphere = has_sphere || (__float_as_uint(p0.w) & PRIM_SPHERE) != 0u;
+                        bx0 = fminf(bx0, fminf(fminf(p0.x, p1.x), p2.x));
+                        by0 = fminf(by0, fminf(fminf(p0.y, p1.y), p2.y));
+                        bz0 = fminf(bz0, fminf(fminf(p0.z, p1.z), p2.z));
+                        bx1 = fmaxf(bx1, fmaxf(fmaxf(p0.x, p1.x), p2.x));
+                        by1 = fmaxf(by1, fmaxf(fmaxf(p0.y, p1.y), p2.y));
+                        bz1 = fmaxf(bz1, fmaxf(fmaxf(p0.z, p1.z), p2.z));
+                    }
+                    if (!has_sphere) enter = slab_entry7(bx0, by0, bz0, bx1, by1, bz1, o, inv_d, ma, false) < kInf;
+                }
+                for (uint32_t k = 0; enter && k < cur_cnt; ++k) {
+                    const uint32_t slot = cur + k;
+                    const float4 p0 = sc.prims[3 * slot];
+                    const float4 p1 = sc.prims[3 * slot + 1], p2 = sc.prims[3 * slot + 2];
+                    asm volatile("" ::"v"(p1.x), "v"(p1.y), "v"(p1.z), "v"(p2.x), "v"(p2.y), "v"(p2.z));  // one burst (th_trace2.h "one fetch per leaf")
+                    test_prim(slot, p0, p1, p2);
                 }
             }
             cur = kRefNone;
