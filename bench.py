@@ -118,19 +118,33 @@ def pmc_child_runs(args, kernel_prefix: str, want_any: bool, passes):
 # bytes that left L2 per unit of FETCH_SIZE (KiB) for the dominant kernel's access pattern.  MI355X_MICROARCH.md gives x2 for 16 B / lane coalesced
 # streaming reads (128-byte requests tallied at 64 B) and leaves other widths to the user; tools/calib/fetch_calib.hip measured the per-lane 64- /
 # 48- / 128-byte record gathers of the traversal and shading kernels on a 1 GiB table read exactly once (profiles/r3/fetch_calib_summary.txt).
-FETCH_FACTOR = {"default": 2.0}
+# Measured (profiles/r3/r3a_fetch_calib_summary.txt): bytes / (FETCH_SIZE x 1024) = 2.000 for 16 B / lane streams and 128-byte records, 1.000 for 64-byte record gathers
+# (one 64-byte request each: FETCH_SIZE tallies REQUESTS at 64 B), 0.590 for 48-byte records (they straddle request boundaries).  The traversal kernels' reads are
+# 64-byte node gathers (1 510 of ~1 760 B per ray on S-mesh), 48-byte primitive records and a 32-byte ray stream: factor 1.0.  When the request-size counters
+# (TCC_EA0_RDREQ_{32B,64B,128B}) are available the bench uses their exact byte count instead of any factor.
+FETCH_FACTOR = {"default": 2.0, "k_trace3": 1.0, "k_trace2": 1.0, "k_trace7": 1.0, "k_trace4": 1.0, "k_trace_closest": 1.0, "k_sppm_gather": 1.0}
 
 
 def measure_counters(args, kernel_prefix: str, want_any: bool):
     """roofline.traffic (HBM-side bytes per launch of the dominant kernel: FETCH_SIZE and WRITE_SIZE need separate passes — TCC slots) and
     roofline.valu (lanes per VALU instruction = SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU, VALU busy) from three PMC child runs."""
-    t = pmc_child_runs(args, kernel_prefix, want_any, [["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_INSTS_VALU", "VALUBusy"]])
+    t = pmc_child_runs(args, kernel_prefix, want_any, [["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_INSTS_VALU", "VALUBusy"],
+                                                       ["TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum"]])
     if not t:
         return None, None
     traffic = None
     if "FETCH_SIZE" in t and "WRITE_SIZE" in t:
         f = FETCH_FACTOR.get(kernel_prefix, FETCH_FACTOR["default"])
         traffic = {"bytes": int(f * t["FETCH_SIZE"] * 1024.0 + t["WRITE_SIZE"] * 1024.0), "fetch_factor": f, "FETCH_SIZE_KiB": round(t["FETCH_SIZE"], 1), "WRITE_SIZE_KiB": round(t["WRITE_SIZE"], 1)}
+        n = [t.get("TCC_EA0_RDREQ_32B_sum"), t.get("TCC_EA0_RDREQ_64B_sum"), t.get("TCC_EA0_RDREQ_128B_sum")]
+        if all(v is not None for v in n) and t.get("TCC_EA0_RDREQ_sum"):
+            # the L2's memory-side read requests by size: exact read bytes whatever the access pattern (no factor).  On parts where the 64-byte counter is the total
+            # (32- and 128-byte requests counted in it too) the split does not add up to the total and the factor stays
+            split = n[0] + n[1] + n[2]
+            if 0.98 <= split / t["TCC_EA0_RDREQ_sum"] <= 1.02:
+                rd = 32.0 * n[0] + 64.0 * n[1] + 128.0 * n[2]
+                traffic.update({"bytes": int(rd + t["WRITE_SIZE"] * 1024.0), "read_requests": {"32B": int(n[0]), "64B": int(n[1]), "128B": int(n[2])}, "fetch_factor": round(rd / (t["FETCH_SIZE"] * 1024.0), 3),
+                                "source": "TCC_EA0_RDREQ_{32B,64B,128B} x size + WRITE_SIZE"})
     valu = None
     if t.get("SQ_ACTIVE_INST_VALU"):
         valu = {"lanes_per_valu_inst": round(t["SQ_THREAD_CYCLES_VALU"] / t["SQ_ACTIVE_INST_VALU"], 2), "of": 64,
@@ -532,16 +546,20 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             threads = ob.lib().orc_num_threads()
             cpu_spp = args.cpu_spp
+            cpu_cam, cpu_res = cam, args.res
+            if args.res > 1024:  # one sample pass of a 4096^2 frame is already minutes of CPU work: the bounded sample is the same scene and depth at 1024^2
+                cpu_res = 1024
+                cpu_cam = build_workload(T, args.workload, cpu_res)[1]
             if cpu_spp <= 0:  # calibrate on one pass, then size the sample for ~15 s
                 t1 = time.perf_counter()
-                osc.render(cam, "path", 1, args.depth, seed=args.seed, threads=threads)
+                osc.render(cpu_cam, "path", 1, args.depth, seed=args.seed, threads=threads)
                 one = time.perf_counter() - t1
                 cpu_spp = int(max(1, min(args.spp, round(15.0 / max(one, 1e-3)))))
             t1 = time.perf_counter()
-            _, _, cst = osc.render(cam, "path", cpu_spp, args.depth, seed=args.seed, threads=threads)
+            _, _, cst = osc.render(cpu_cam, "path", cpu_spp, args.depth, seed=args.seed, threads=threads)
             dt = time.perf_counter() - t1
             cpu = {"value": round((cst.closest_rays + cst.shadow_rays) / dt / 1e6, 3), "unit": "Mray/s", "cores": threads, "kind": "port",
-                   "sample": f"same scene, {args.res}x{args.res}, depth {args.depth}, {cpu_spp} spp of {args.spp} ({cst.camera_samples} camera samples, {dt:.1f} s)",
+                   "sample": f"same scene, {cpu_res}x{cpu_res}, depth {args.depth}, {cpu_spp} spp of {args.spp} ({cst.camera_samples} camera samples, {dt:.1f} s)",
                    "Msample_per_s": round(cst.camera_samples / dt / 1e6, 4)}
         if world == 1 and not args.no_micro:
             micro = micro_benchmark(args, T, ctx, flat, osc if not args.no_cpu_baseline else None)
