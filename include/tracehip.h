@@ -209,6 +209,10 @@ int trhip_trace_any_device(trhip_ctx* ctx, const trhip_scene* scene, const void*
 /* Visit counters of the last *_device trace call when "count_visits" is on: nodes, prims (closest) then nodes, prims (any-hit). */
 int trhip_last_visit_counts(trhip_ctx* ctx, uint64_t* out4);
 
+/* Device time (ms, HIP events: upload of the primitive bounds to the last flatten kernel) of the last BVHAccel built by the device
+ * SAH builder ("bvh_builder" = 3, accel/bvh.jl:55-206 replaced); 0 when the last commit used another builder. */
+int trhip_last_bvh_build_ms(trhip_ctx* ctx, double* ms_device);
+
 /* Geometry of a closest hit as the shading kernel rebuilds it (SurfaceInteraction, surface_interaction.jl:51-88,154-181;
  * BSDF frame materials/bsdf.jl:41-50): per ray 15 floats p(3) n(3) ns(3) wo(3) ss(3); zeros on a miss. */
 int trhip_hit_geometry(trhip_ctx* ctx, const trhip_scene* scene, const float* rays, uint64_t n, float* out_geom15);
@@ -267,9 +271,11 @@ int trhip_film_allreduce(trhip_ctx* ctx, void* d_xyzw, uint64_t n_pixels);
  *     "stream2_priority" (-1/0/1): that stream's priority: lowest (default: the closest-hit rays are the critical path), the
  *     default level, highest; read when the streams are created (first render of a context).
  * "pipelines" (1..8): wavefront batches in flight at once (default 1).
- * "bvh_builder" (-1/0/1): how trhip_scene_commit builds the BVH: 0 = binned SAH on the host, 1 = linear BVH on the device
- *     (Morton keys, radix sort, Karras hierarchy; ~6x faster to build, 25-35 % more node visits per ray), -1 (default) = the
- *     device builder above 16 Mi primitives.  Either tree is a valid BVHAccel: results differ only in exact-t ties.
+ * "bvh_builder" (-1/0/1/2/3): how trhip_scene_commit builds the BVH: 0 = binned SAH on the host, 1 = linear BVH on the device
+ *     (Morton keys, radix sort, Karras hierarchy; 25-35 % more node visits per ray), 3 = the host builder's binned SAH run on the
+ *     device (the same tree, 34 ms per million primitives instead of ~170 ms; scenes it cannot take go to the host builder),
+ *     2 = the reference's own construction node for node (see trhip_scene_commit), -1 (default) = 3 from 64 Ki primitives on,
+ *     0 below.  Every one of these trees is a valid BVHAccel: results differ only in exact-t ties.
  * "slab_margin_log2" (0..20, default 14): traversal 2 / 3 add to the reference's box test (bounds.jl:180-200) the two slab
  *     clauses it lost — it keeps the larger of the x and y exits — evaluated on boxes grown by 2^-N x the ray's reach; boxes on
  *     the path to a sphere keep the reference's test alone.  Fewer boxes visited, same results bit for bit;

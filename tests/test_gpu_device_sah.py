@@ -1,0 +1,108 @@
+"""Row f1: BVHAccel built on the device with the host builder's binned SAH (trace.jl_amd/csrc/th_sahb.h, option "bvh_builder" = 3;
+replaces accel/bvh.jl:55-206 like th_bvh.h does).  The tree must be a valid BVH2 in the reference's flat layout, must be the HOST
+builder's tree (same boxes, children, split axes; the primitives of a leaf may come in another order), and renders / traces bit for
+bit what the oracle computes walking that tree."""
+import numpy as np
+import pytest
+
+from test_gpu_parity import assert_bits_equal, camera_rays
+
+pytestmark = pytest.mark.gpu
+
+
+def check_layout(bounds, a, flags, order, pb=None):
+    n = order.size
+    assert sorted(order.tolist()) == list(range(n)), "every primitive in exactly one ordered slot"
+    leaf = (flags & 3) == 3
+    inner = np.flatnonzero(~leaf)
+    assert a.size == 2 * int(leaf.sum()) - 1
+    assert np.all(a[inner] > inner + 1) and np.all(a[inner] < a.size) and np.all(flags[inner] <= 2)
+    size = np.ones(a.size, np.int64)
+    for i in inner[::-1]:
+        size[i] = 1 + size[i + 1] + size[a[i]]
+        assert a[i] == i + 1 + size[i + 1]
+    assert size[0] == a.size
+    # leaves tile the ordered slots in depth-first order; leaf boxes are the union of their primitives' bounds
+    slots = 0
+    for i in np.flatnonzero(leaf):
+        cnt, first = int(flags[i] >> 2), int(a[i])
+        assert first == slots and cnt >= 1
+        slots += cnt
+        if pb is not None:
+            p = pb[order[first:first + cnt]]
+            assert np.array_equal(bounds[i, :3], p[:, :3].min(axis=0)) and np.array_equal(bounds[i, 3:], p[:, 3:].max(axis=0))
+    assert slots == n
+    for i in inner[::-1]:  # interior boxes are the union of the children's
+        lo = np.minimum(bounds[i + 1, :3], bounds[a[i], :3])
+        hi = np.maximum(bounds[i + 1, 3:], bounds[a[i], 3:])
+        assert np.array_equal(bounds[i, :3], lo) and np.array_equal(bounds[i, 3:], hi)
+
+
+def same_boxes(x, y):  # bit for bit, except that an atomic min / max may keep the other zero of a -0 / +0 pair
+    return np.array_equal(np.where(x == 0, np.float32(0), x).view(np.uint32), np.where(y == 0, np.float32(0), y).view(np.uint32))
+
+
+@pytest.mark.parametrize("which", ["mesh40", "blob", "mesh120_leaf4", "cornell_leaf1"])
+def test_device_sah_tree_is_the_host_builders(T, ob, ctx, which):
+    make = {"mesh40": lambda: T.scenes.mesh_scene(40), "blob": lambda: T.scenes.blob_scene(24), "mesh120_leaf4": lambda: T.scenes.mesh_scene(120),
+            "cornell_leaf1": lambda: T.scenes.cornell_scene()}[which]
+    trees = {}
+    try:
+        for builder in (0, 3):
+            ctx.set_option("bvh_builder", builder)
+            ctx.set_option("tiny_scene_prims", 4)
+            scene = make()
+            if which == "mesh120_leaf4":
+                scene.aggregate.max_node_primitives = 4
+            flat = scene.flatten(ctx)
+            trees[builder] = (scene, flat, [x.copy() for x in flat.bvh()])
+    finally:
+        ctx.set_option("bvh_builder", -1)
+        ctx.set_option("tiny_scene_prims", 16)
+    scene, flat, (bounds, a, flags, order) = trees[3]
+    hb, ha, hf, ho = trees[0][2]
+    osc = ob.OracleScene.from_scene(scene, bvh=flat.bvh(), max_node_primitives=scene.aggregate.max_node_primitives)
+    check_layout(bounds, a, flags, order)
+    assert a.size == ha.size, "node count differs from the host builder's"
+    assert np.array_equal(a, ha) and np.array_equal(flags, hf), "children / split axes / leaf sizes differ from the host builder's"
+    assert same_boxes(bounds, hb), "boxes differ from the host builder's"
+    leaf = np.flatnonzero((flags & 3) == 3)
+    for i in leaf:  # the same SET of primitives per leaf
+        s, c = int(a[i]), int(flags[i] >> 2)
+        assert sorted(order[s:s + c].tolist()) == sorted(ho[s:s + c].tolist())
+    # and the kernels on this tree against the oracle walking it
+    wb = osc.world_bound()
+    rays = np.concatenate([camera_rays(T, ob, T.scenes.cornell_camera(48)), T.scenes.incoherent_rays(20000, wb[:3] - 0.2, wb[3:] + 0.2)])
+    got = flat.trace_closest(rays)
+    t_ref, prim_ref, _, _ = osc.trace_closest(rays)
+    assert np.array_equal(got["prim"], prim_ref)
+    assert_bits_equal(got["t"], t_ref, "t (device SAH tree)")
+    assert np.array_equal(flat.trace_any(rays), osc.trace_any(rays)[0])
+    cam = T.scenes.cornell_camera(20)
+    ref, _, _ = osc.render(cam, "path", 2, 5, seed=9)
+    assert_bits_equal(T.PathIntegrator(cam, T.SeededSampler(2, seed=9), 5).render(scene, ctx), ref, "film (device SAH tree)")
+
+
+def test_device_sah_random_soups(T, ob, ctx):
+    """Random triangle soups of many sizes (around the small-phase threshold of 64 too) and leaf-size hints: valid layout, host topology."""
+    rng = np.random.default_rng(5)
+    try:
+        for n, leaf in [(17, 1), (64, 1), (65, 1), (66, 4), (129, 2), (1000, 1), (4097, 4), (20000, 1), (50000, 8)]:
+            c = rng.random((n, 1, 3), dtype=np.float32) * np.float32(4.0)
+            v = (c + (rng.random((n, 3, 3), dtype=np.float32) - np.float32(0.5)) * np.float32(0.2)).astype(np.float32)
+            pb = np.concatenate([v.min(axis=1), v.max(axis=1)], axis=1)
+            out = {}
+            for builder in (0, 3):
+                ctx.set_option("bvh_builder", builder)
+                grey = T.MatteMaterial(T.ConstantTexture(T.RGBSpectrum(0.5)), T.ConstantTexture(0.0))
+                mesh = T.create_mesh_primitives(T.ShapeCore(T.translate([0, 0, 0]), False), np.arange(1, 3 * n + 1, dtype=np.uint32), v.reshape(-1, 3), None, grey)
+                scene = T.Scene([], T.BVHAccel([mesh], leaf))
+                flat = scene.flatten(ctx)
+                out[builder] = [x.copy() for x in flat.bvh()]
+                flat.free()
+                scene._flat = None
+            bounds, a, flags, order = out[3]
+            check_layout(bounds, a, flags, order, pb)
+            assert np.array_equal(a, out[0][1]) and np.array_equal(flags, out[0][2]), f"n = {n}, leaf hint {leaf}: topology differs from the host builder's"
+    finally:
+        ctx.set_option("bvh_builder", -1)

@@ -139,7 +139,7 @@ def main():
         print(f"scene {k:3d}: {flat.bvh()[3].size:7d} primitives, {rays.shape[0]} rays, hit {float((h1['prim'] >= 0).mean()):.3f}, occluded {float(o1.mean()):.3f}, mismatches {bad}", flush=True)
         flat.free()
         scene._flat = None
-    print(f"total: {a.scenes} scenes, {rays_total} rays x (closest + any) x (traversal {'3, 2, 6, 4' if a.wide else '3, 2, 6'}) against traversal 1: {bad_total} mismatches")
+    print(f"total: {a.scenes} scenes, {rays_total} rays x (closest + any) x (traversal {'3, 7, 2, 6, 4' if a.wide else '3, 7, 2, 6'}) against traversal 1: {bad_total} mismatches")
     sys.exit(1 if bad_total else 0)
 
 

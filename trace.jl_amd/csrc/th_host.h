@@ -57,10 +57,12 @@ struct trhip_ctx {
     int pipelines = 1;    // concurrent wavefront batches (each on its own stream pair); measured: no gain, every batch pays every tail
     Pipe pipes[kMaxPipes];
     uint32_t debug_trace_budget = 0;  // DIAGNOSTIC: k_trace2 abandons rays after this many node fetches (results wrong; measures bulk vs tail)
-    int bvh_builder = -1;  // BVHAccel construction: 0 = binned SAH on the host (th_bvh.h), 1 = linear BVH on the device (th_lbvh.h), 2 = the reference's own
-                           // construction node for node (th_bvh_ref.h: the tree Trace.jl builds, hence its tie-breaks),
-                           // -1 = automatic: the device builder above 16 Mi primitives.  Measured: commit 0.72 -> 0.13 s (1 M triangles), 8.0 -> 1.5 s
-                           // (10 M); the LBVH costs 25-35 % more node visits per ray (frame +4 % at 1 M / 64 spp, +37 % at 10 M / 16 spp)
+    double bvh_device_ms = 0.0;  // device time of the last bvh_builder 3 build
+    int bvh_builder = -1;  // BVHAccel construction: 0 = binned SAH on the host (th_bvh.h), 1 = linear BVH on the device (th_lbvh.h), 3 = the host builder's
+                           // binned SAH on the device (th_sahb.h: the same tree), 2 = the reference's own construction node for node (th_bvh_ref.h:
+                           // the tree Trace.jl builds, hence its tie-breaks), -1 = automatic: builder 3 from 64 Ki primitives on, builder 0 below and
+                           // for the scenes builder 3 hands back.  Measured (r3): building the tree 34 ms (1 M triangles) / 186 ms (10 M) on the device
+                           // against ~0.17 s / ~1.5 s on the host, commit 0.39 -> 0.26 s and 3.67 -> 2.37 s; the LBVH builds a 25-35 % costlier tree
     bool film_transpose = false;     // film pass on pixel-group-major copies of p_film / L (option "film_transpose"; launch_film)
     bool occluder_pretest = true;    // any-hit rays test the scene's largest triangles before the walk (option "occluder_pretest")
     int stream2_priority = -1;       // shadow-ray stream: 1 highest priority, -1 lowest, 0 the default level (option "stream2_priority", read when the streams are created)
@@ -232,6 +234,7 @@ struct Timer {
 int upload_scene(trhip_scene* s);
 // tu_lbvh.hip
 int build_bvh_device(trhip_ctx* ctx, const std::vector<HostAABB>& pb, FlatBVH& out);
+int build_bvh_device_sah(trhip_ctx* ctx, const std::vector<HostAABB>& pb, int max_node_prims, bool split_coincident, FlatBVH& out, double* ms_device);
 // tu_trace.hip
 int trace_grid(const trhip_ctx* ctx);
 int ensure_overflow(trhip_ctx* ctx);

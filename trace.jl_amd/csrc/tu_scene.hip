@@ -660,6 +660,7 @@ int trhip_scene_commit(trhip_scene* s, int max_node_primitives) {
     const std::vector<HostAABB>& pb_build = compose ? pb_sub : pb;
     bool built = false;
     const int mode = s->ctx->bvh_builder;
+    s->ctx->bvh_device_ms = 0.0;
     if (mode == 2) {
         // the reference's own construction, node for node (th_bvh_ref.h): also for scenes the default would commit as one leaf, never composed
         try {
@@ -673,7 +674,18 @@ int trhip_scene_commit(trhip_scene* s, int max_node_primitives) {
         s->literal_only = false;
         return upload_scene(s);
     }
-    if ((mode == 1 || (mode < 0 && pb_build.size() > (16u << 20))) && pb_build.size() > s->ctx->tiny_scene_prims) {
+    if ((mode == 3 || (mode < 0 && pb_build.size() >= (64u << 10))) && pb_build.size() > s->ctx->tiny_scene_prims) {
+        // the host builder's binned SAH, on the device (th_sahb.h); scenes it hands back (TRHIP_ERR_UNSUPPORTED) go to the host builder below
+        FlatBVH dev;
+        const int rc = build_bvh_device_sah(s->ctx, pb_build, max_node_primitives, want_chain, dev, &s->ctx->bvh_device_ms);
+        if (rc == 0) {
+            s->bvh = std::move(dev);
+            built = true;
+        } else if (rc != TRHIP_ERR_UNSUPPORTED) {
+            return rc;
+        }
+    }
+    if (!built && mode == 1 && pb_build.size() > s->ctx->tiny_scene_prims) {
         FlatBVH dev;
         const int rc = build_bvh_device(s->ctx, pb_build, dev);
         if (rc == 0) {
