@@ -6,12 +6,14 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #pragma GCC visibility push(default)
@@ -186,6 +188,22 @@ inline int upload(trhip_ctx* ctx, DevBuf& b, const void* src, size_t bytes) {
     if (int rc = ensure(ctx, b, bytes)) return rc;
     if (bytes) HIP_TRY(ctx, hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
     return 0;
+}
+// f(begin, end) over [0, n) on the host's cores (scene commit's loops over millions of nodes / primitives); ranges are disjoint and contiguous
+template <class F>
+inline void parallel_for(size_t n, F&& f, size_t grain = size_t(1) << 15) {
+    const size_t want = n / std::max<size_t>(1, grain);
+    const size_t nt = std::min<size_t>({want, (size_t)std::max(1u, std::thread::hardware_concurrency()), (size_t)32});
+    if (nt <= 1) {
+        f((size_t)0, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    th.reserve(nt - 1);
+    const size_t step = (n + nt - 1) / nt;
+    for (size_t t = 1; t < nt; ++t) th.emplace_back([&f, t, step, n] { f(std::min(n, t * step), std::min(n, (t + 1) * step)); });
+    f((size_t)0, std::min(n, step));
+    for (auto& x : th) x.join();
 }
 inline int grid_for(const trhip_ctx* ctx, uint64_t n, int blocks_per_cu) {
     const uint64_t need = (n + kBlock - 1) / kBlock;

@@ -422,15 +422,24 @@ TH_D bool rebuild_shading(const DeviceScene& sc, int prim, f3 o, f3 d, Shading& 
     sh = shade_triangle(v0, v1, v2, has_n, mk3(na.x, na.y, na.z), mk3(nb.x, nb.y, nb.z), mk3(nc.x, nc.y, nc.z), (meta & PRIM_FLIP) != 0, tt.bary, d, &tc);
     return true;
 }
-// Commit time: records 6 / 7 of every triangle slot's shading line (th_scene.h) = triangle_constants of its vertices.
-static __global__ __launch_bounds__(kBlock) void k_shade_constants(float4* __restrict__ shade, uint32_t n_prims) {
+// Commit time: every slot's shading line (th_scene.h) from the two arrays the traversal kernels use — records 0-2 = prims, 3-5 = tri_nrm, 6 / 7 =
+// triangle_constants of the vertices.
+static __global__ __launch_bounds__(kBlock) void k_shade_constants(float4* __restrict__ shade, const float4* __restrict__ prims, const float4* __restrict__ nrm, uint32_t n_prims) {
     for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < n_prims; k += gridDim.x * kBlock) {
         float4* rec = shade + 8 * (size_t)k;
-        const float4 p0 = rec[0], p1 = rec[1], p2 = rec[2];
-        if (__float_as_uint(p0.w) & PRIM_SPHERE) continue;
-        const TriConstants tc = triangle_constants(mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z));
-        rec[6] = make_float4(tc.n.x, tc.n.y, tc.n.z, 0.0f);
-        rec[7] = make_float4(tc.ss.x, tc.ss.y, tc.ss.z, 0.0f);
+        const float4 p0 = prims[3 * (size_t)k], p1 = prims[3 * (size_t)k + 1], p2 = prims[3 * (size_t)k + 2];
+        rec[0] = p0;
+        rec[1] = p1;
+        rec[2] = p2;
+        for (int j = 0; j < 3; ++j) rec[3 + j] = nrm[3 * (size_t)k + j];
+        float4 c6 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), c7 = c6;
+        if (!(__float_as_uint(p0.w) & PRIM_SPHERE)) {
+            const TriConstants tc = triangle_constants(mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z));
+            c6 = make_float4(tc.n.x, tc.n.y, tc.n.z, 0.0f);
+            c7 = make_float4(tc.ss.x, tc.ss.y, tc.ss.z, 0.0f);
+        }
+        rec[6] = c6;
+        rec[7] = c7;
     }
 }
 

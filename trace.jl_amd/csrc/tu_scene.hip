@@ -3,7 +3,24 @@
 #include "th_host.h"
 #include "th_bvh_ref.h"
 
+#include <atomic>
+#include <chrono>
+#include <cstdlib>
+#include <mutex>
+
 namespace {
+// TRHIP_COMMIT_TIMING=1: where trhip_scene_commit spends its time, one line per stage on stderr
+struct CommitClock {
+    bool on = std::getenv("TRHIP_COMMIT_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void tick(const char* what) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[commit] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+        t = now;
+    }
+};
+
 // ---- materials: the lobes each Material adds (materials/material.jl), precomputed per material ---------------------------------
 float roughness_to_alpha(float roughness) {  // microfacet.jl:82-87
     roughness = jmax(1e-3f, roughness);
@@ -176,45 +193,46 @@ bool has_sphere_subtree(const trhip_scene* s, uint32_t root) {
 
 int upload_scene(trhip_scene* s) {
     trhip_ctx* ctx = s->ctx;
+    CommitClock clk;
     const uint32_t n_nodes = (uint32_t)s->bvh.a.size(), n_prims = (uint32_t)s->bvh.order.size();
     std::vector<float4> nodes((size_t)n_nodes * 2), prims((size_t)n_prims * 3), nrm((size_t)n_prims * 3);
-    for (uint32_t i = 0; i < n_nodes; ++i) {
-        const float* b = &s->bvh.bounds[6 * (size_t)i];
-        nodes[2 * (size_t)i] = make_float4(b[0], b[1], b[2], __builtin_bit_cast(float, s->bvh.a[i]));
-        nodes[2 * (size_t)i + 1] = make_float4(b[3], b[4], b[5], __builtin_bit_cast(float, s->bvh.flags[i]));
-    }
-    for (uint32_t k = 0; k < n_prims; ++k) {
-        const HostPrim& p = s->prims[s->bvh.order[k]];
-        if (p.kind == 1) {
-            prims[3 * (size_t)k] = make_float4(__builtin_bit_cast(float, p.sphere_id), 0, 0, __builtin_bit_cast(float, p.meta));
-            prims[3 * (size_t)k + 1] = prims[3 * (size_t)k + 2] = make_float4(0, 0, 0, 0);
-            nrm[3 * (size_t)k] = nrm[3 * (size_t)k + 1] = nrm[3 * (size_t)k + 2] = make_float4(0, 0, 0, 0);
-        } else {
-            prims[3 * (size_t)k] = make_float4(p.v[0], p.v[1], p.v[2], __builtin_bit_cast(float, p.meta));
-            prims[3 * (size_t)k + 1] = make_float4(p.v[3], p.v[4], p.v[5], 0);
-            prims[3 * (size_t)k + 2] = make_float4(p.v[6], p.v[7], p.v[8], 0);
-            const uint32_t mat = p.meta & PRIM_MATERIAL_MASK;
-            const bool fast = mat != PRIM_NO_MATERIAL && mat < s->materials.size() && s->materials[mat].set[1].n == 1 && s->materials[mat].set[1].lobe[0].kind == LOBE_LAMBERT_R;
-            if (fast) prims[3 * (size_t)k].w = __builtin_bit_cast(float, p.meta | PRIM_FAST);
-            for (int j = 0; j < 3; ++j) nrm[3 * (size_t)k + j] = make_float4(p.n[3 * j], p.n[3 * j + 1], p.n[3 * j + 2], fast ? s->materials[mat].set[1].lobe[0].r[j] : 0.0f);
+    parallel_for(n_nodes, [&](size_t i0, size_t i1) {
+        for (size_t i = i0; i < i1; ++i) {
+            const float* b = &s->bvh.bounds[6 * i];
+            nodes[2 * i] = make_float4(b[0], b[1], b[2], __builtin_bit_cast(float, s->bvh.a[i]));
+            nodes[2 * i + 1] = make_float4(b[3], b[4], b[5], __builtin_bit_cast(float, s->bvh.flags[i]));
         }
-    }
+    });
+    parallel_for(n_prims, [&](size_t k0, size_t k1) {
+        for (size_t k = k0; k < k1; ++k) {
+            const HostPrim& p = s->prims[s->bvh.order[k]];
+            if (p.kind == 1) {
+                prims[3 * k] = make_float4(__builtin_bit_cast(float, p.sphere_id), 0, 0, __builtin_bit_cast(float, p.meta));
+                prims[3 * k + 1] = prims[3 * k + 2] = make_float4(0, 0, 0, 0);
+                nrm[3 * k] = nrm[3 * k + 1] = nrm[3 * k + 2] = make_float4(0, 0, 0, 0);
+            } else {
+                prims[3 * k] = make_float4(p.v[0], p.v[1], p.v[2], __builtin_bit_cast(float, p.meta));
+                prims[3 * k + 1] = make_float4(p.v[3], p.v[4], p.v[5], 0);
+                prims[3 * k + 2] = make_float4(p.v[6], p.v[7], p.v[8], 0);
+                const uint32_t mat = p.meta & PRIM_MATERIAL_MASK;
+                const bool fast = mat != PRIM_NO_MATERIAL && mat < s->materials.size() && s->materials[mat].set[1].n == 1 && s->materials[mat].set[1].lobe[0].kind == LOBE_LAMBERT_R;
+                if (fast) prims[3 * k].w = __builtin_bit_cast(float, p.meta | PRIM_FAST);
+                for (int j = 0; j < 3; ++j) nrm[3 * k + j] = make_float4(p.n[3 * j], p.n[3 * j + 1], p.n[3 * j + 2], fast ? s->materials[mat].set[1].lobe[0].r[j] : 0.0f);
+            }
+        }
+    });
+    clk.tick("upload: node / prim records");
     if (int rc = upload(ctx, s->d_nodes, nodes.data(), nodes.size() * sizeof(float4))) return rc;
     if (int rc = upload(ctx, s->d_prims, prims.data(), prims.size() * sizeof(float4))) return rc;
     if (int rc = upload(ctx, s->d_nrm, nrm.data(), nrm.size() * sizeof(float4))) return rc;
-    {  // the shading kernels' interleaved view (th_scene.h): one 128-byte line per slot
-        std::vector<float4> rec((size_t)n_prims * 8, make_float4(0, 0, 0, 0));
-        for (uint32_t k = 0; k < n_prims; ++k)
-            for (int j = 0; j < 3; ++j) {
-                rec[8 * (size_t)k + j] = prims[3 * (size_t)k + j];
-                rec[8 * (size_t)k + 3 + j] = nrm[3 * (size_t)k + j];
-            }
-        if (int rc = upload(ctx, s->d_shade, rec.data(), rec.size() * sizeof(float4))) return rc;
-        // records 6 / 7: what a triangle's interaction derives from its vertices alone, computed by the code the shading kernels would run
-        hipLaunchKernelGGL(k_shade_constants, dim3(std::max(1u, std::min((n_prims + kBlock - 1) / kBlock, 4096u))), dim3(kBlock), 0, ctx->stream, (float4*)s->d_shade.p, n_prims);
+    clk.tick("upload: 3 copies");
+    {  // the shading kernels' interleaved view (th_scene.h): one 128-byte line per slot, put together on the device from the two arrays just uploaded
+        if (int rc = ensure(ctx, s->d_shade, (size_t)n_prims * 8 * sizeof(float4))) return rc;
+        hipLaunchKernelGGL(k_shade_constants, dim3(std::max(1u, std::min((n_prims + kBlock - 1) / kBlock, 4096u))), dim3(kBlock), 0, ctx->stream, (float4*)s->d_shade.p, (const float4*)s->d_prims.p, (const float4*)s->d_nrm.p, n_prims);
         HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
+    clk.tick("upload: shade records");
     if (int rc = upload(ctx, s->d_spheres, s->spheres.data(), s->spheres.size() * sizeof(SphereRec))) return rc;
     if (int rc = upload(ctx, s->d_materials, s->materials.data(), s->materials.size() * sizeof(MaterialRec))) return rc;
     if (int rc = upload(ctx, s->d_lights, s->lights.data(), s->lights.size() * sizeof(LightRec))) return rc;
@@ -246,79 +264,88 @@ int upload_scene(trhip_scene* s) {
         // subtrees that hold a sphere keep the reference's loose slab test (th_trace2.h, slab_test2): the fp32 sphere quadratic
         // (sphere.jl:120-150) accepts rays that pass the sphere at a distance far beyond the tight test's margin
         std::vector<uint8_t> has_sphere(n_nodes, 0);
-        for (uint32_t i = n_nodes; i-- > 0;) {
-            if ((s->bvh.flags[i] & 3u) == 3u) {
-                const uint32_t first = s->bvh.a[i], cnt = s->bvh.flags[i] >> 2;
-                for (uint32_t k = first; k < first + cnt && k < n_prims; ++k) has_sphere[i] |= s->prims[s->bvh.order[k]].kind == 1;
-            } else {
-                has_sphere[i] = has_sphere[i + 1] | (s->bvh.a[i] < n_nodes ? has_sphere[s->bvh.a[i]] : 1);
-            }
-        }
-        for (uint32_t i = 0; i < n_nodes && ok; ++i) {
-            if ((s->bvh.flags[i] & 3u) == 3u) continue;
-            const uint32_t c[2] = {i + 1, s->bvh.a[i]};
-            uint32_t ref[2], cnt[2];
-            for (int k = 0; k < 2; ++k) {
-                if ((s->bvh.flags[c[k]] & 3u) == 3u) {
-                    ref[k] = s->bvh.a[c[k]];
-                    cnt[k] = s->bvh.flags[c[k]] >> 2;
-                    if (cnt[k] == 0) {
-                        // the reference's builder can emit a leaf of 0 primitives with the invalid bounds (+Inf, -Inf) (A.6, th_bvh_ref.h): no ray's box
-                        // test passes on it (tx_min = +Inf, bounds.jl:186-188), so the child word is never read — any leaf-shaped word will do.
-                        // An empty leaf with a REAL box (a foreign tree) could be "entered": the literal kernel walks those.
-                        const float* eb = &s->bvh.bounds[6 * (size_t)c[k]];
-                        if (eb[0] == INFINITY && eb[1] == INFINITY && eb[2] == INFINITY && eb[3] == -INFINITY && eb[4] == -INFINITY && eb[5] == -INFINITY) {
-                            ref[k] = 0;
-                            cnt[k] = 1;
-                            has_empty_leaf = true;
-                        } else {
-                            ok = false;
-                        }
-                    } else if (cnt[k] > 255) {
-                        ok = false;  // oversized leaves only come from foreign BVHs: use the literal kernel
-                    }
+        if (!s->spheres.empty())
+            for (uint32_t i = n_nodes; i-- > 0;) {
+                if ((s->bvh.flags[i] & 3u) == 3u) {
+                    const uint32_t first = s->bvh.a[i], cnt = s->bvh.flags[i] >> 2;
+                    for (uint32_t k = first; k < first + cnt && k < n_prims; ++k) has_sphere[i] |= s->prims[s->bvh.order[k]].kind == 1;
                 } else {
-                    ref[k] = widx[c[k]];
-                    cnt[k] = 0;
+                    has_sphere[i] = has_sphere[i + 1] | (s->bvh.a[i] < n_nodes ? has_sphere[s->bvh.a[i]] : 1);
                 }
             }
-            const float* l = &s->bvh.bounds[6 * (size_t)c[0]];
-            const float* r = &s->bvh.bounds[6 * (size_t)c[1]];
-            // an empty leaf's box (+Inf, -Inf) goes in as NaNs: every comparison with a NaN product is false, so the child is missed by the select form of the box
-            // test (slab_test2) AND by the min / max forms (th_trace7.h), where min(+Inf x, -Inf x) would turn the inverted box into "everything"
+        std::atomic<bool> bad{!ok}, empty_leaf{false};
+        parallel_for(n_nodes, [&](size_t i0, size_t i1) {
             static const float kNanBox[6] = {NAN, NAN, NAN, NAN, NAN, NAN};
-            if ((s->bvh.flags[c[0]] & 3u) == 3u && (s->bvh.flags[c[0]] >> 2) == 0u) l = kNanBox;
-            if ((s->bvh.flags[c[1]] & 3u) == 3u && (s->bvh.flags[c[1]] >> 2) == 0u) r = kNanBox;
-            float4* w = &wn[4 * (size_t)widx[i]];
-            w[0] = make_float4(l[0], l[1], l[2], l[3]);
-            w[1] = make_float4(l[4], l[5], r[0], r[1]);
-            w[2] = make_float4(r[2], r[3], r[4], r[5]);
-            // child word = ref | count << 24 (the stack entry format); meta = split axis | "subtree holds a sphere" bits 2 (first) / 3 (second)
-            w[3] = make_float4(__builtin_bit_cast(float, ref[0] | (cnt[0] << 24)), __builtin_bit_cast(float, ref[1] | (cnt[1] << 24)),
-                               __builtin_bit_cast(float, (s->bvh.flags[i] & 3u) | ((uint32_t)has_sphere[c[0]] << 2) | ((uint32_t)has_sphere[c[1]] << 3)), 0.0f);
-        }
+            for (size_t i = i0; i < i1; ++i) {
+                if ((s->bvh.flags[i] & 3u) == 3u) continue;
+                const uint32_t c[2] = {(uint32_t)i + 1, s->bvh.a[i]};
+                uint32_t ref[2], cnt[2];
+                for (int k = 0; k < 2; ++k) {
+                    if ((s->bvh.flags[c[k]] & 3u) == 3u) {
+                        ref[k] = s->bvh.a[c[k]];
+                        cnt[k] = s->bvh.flags[c[k]] >> 2;
+                        if (cnt[k] == 0) {
+                            // the reference's builder can emit a leaf of 0 primitives with the invalid bounds (+Inf, -Inf) (A.6, th_bvh_ref.h): no ray's box
+                            // test passes on it (tx_min = +Inf, bounds.jl:186-188), so the child word is never read — any leaf-shaped word will do.
+                            // An empty leaf with a REAL box (a foreign tree) could be "entered": the literal kernel walks those.
+                            const float* eb = &s->bvh.bounds[6 * (size_t)c[k]];
+                            if (eb[0] == INFINITY && eb[1] == INFINITY && eb[2] == INFINITY && eb[3] == -INFINITY && eb[4] == -INFINITY && eb[5] == -INFINITY) {
+                                ref[k] = 0;
+                                cnt[k] = 1;
+                                empty_leaf = true;
+                            } else {
+                                bad = true;
+                            }
+                        } else if (cnt[k] > 255) {
+                            bad = true;  // oversized leaves only come from foreign BVHs: use the literal kernel
+                        }
+                    } else {
+                        ref[k] = widx[c[k]];
+                        cnt[k] = 0;
+                    }
+                }
+                const float* l = &s->bvh.bounds[6 * (size_t)c[0]];
+                const float* r = &s->bvh.bounds[6 * (size_t)c[1]];
+                // an empty leaf's box (+Inf, -Inf) goes in as NaNs: every comparison with a NaN product is false, so the child is missed by the select form of the box
+                // test (slab_test2) AND by the min / max forms (th_trace7.h), where min(+Inf x, -Inf x) would turn the inverted box into "everything"
+                if ((s->bvh.flags[c[0]] & 3u) == 3u && (s->bvh.flags[c[0]] >> 2) == 0u) l = kNanBox;
+                if ((s->bvh.flags[c[1]] & 3u) == 3u && (s->bvh.flags[c[1]] >> 2) == 0u) r = kNanBox;
+                float4* w = &wn[4 * (size_t)widx[i]];
+                w[0] = make_float4(l[0], l[1], l[2], l[3]);
+                w[1] = make_float4(l[4], l[5], r[0], r[1]);
+                w[2] = make_float4(r[2], r[3], r[4], r[5]);
+                // child word = ref | count << 24 (the stack entry format); meta = split axis | "subtree holds a sphere" bits 2 (first) / 3 (second)
+                w[3] = make_float4(__builtin_bit_cast(float, ref[0] | (cnt[0] << 24)), __builtin_bit_cast(float, ref[1] | (cnt[1] << 24)),
+                                   __builtin_bit_cast(float, (s->bvh.flags[i] & 3u) | ((uint32_t)has_sphere[c[0]] << 2) | ((uint32_t)has_sphere[c[1]] << 3)), 0.0f);
+            }
+        });
+        ok = !bad;
+        has_empty_leaf = empty_leaf;
         // k_trace7 re-derives a leaf's box from its triangles' vertices (min / max are exact): true for every tree built here; a caller's tree (trhip_scene_set_bvh) may
         // carry larger leaf boxes, and then the kernel keeps the reference's test on every box instead
-        bool leaf_tight = true;
-        for (uint32_t i = 0; i < n_nodes && leaf_tight; ++i) {
-            if ((s->bvh.flags[i] & 3u) != 3u) continue;
-            const uint32_t first = s->bvh.a[i], cnt = s->bvh.flags[i] >> 2;
-            if (cnt == 0) continue;
-            HostAABB u;
-            u.reset();
-            bool sphere = false;
-            for (uint32_t k = first; k < first + cnt && k < n_prims; ++k) {
-                const HostPrim& p = s->prims[s->bvh.order[k]];
-                if (p.kind == 1) {
-                    sphere = true;
-                    break;
+        std::atomic<bool> loose{false};
+        parallel_for(n_nodes, [&](size_t i0, size_t i1) {
+            for (size_t i = i0; i < i1 && !loose; ++i) {
+                if ((s->bvh.flags[i] & 3u) != 3u) continue;
+                const uint32_t first = s->bvh.a[i], cnt = s->bvh.flags[i] >> 2;
+                if (cnt == 0) continue;
+                HostAABB u;
+                u.reset();
+                bool sphere = false;
+                for (uint32_t k = first; k < first + cnt && k < n_prims; ++k) {
+                    const HostPrim& p = s->prims[s->bvh.order[k]];
+                    if (p.kind == 1) {
+                        sphere = true;
+                        break;
+                    }
+                    for (int j = 0; j < 3; ++j) u.grow_point(&p.v[3 * j]);
                 }
-                for (int j = 0; j < 3; ++j) u.grow_point(&p.v[3 * j]);
+                if (sphere) continue;  // sphere leaves are reached through exact tests anyway
+                const float* b = &s->bvh.bounds[6 * i];
+                if (!(u.mn[0] == b[0] && u.mn[1] == b[1] && u.mn[2] == b[2] && u.mx[0] == b[3] && u.mx[1] == b[4] && u.mx[2] == b[5])) loose = true;
             }
-            if (sphere) continue;  // sphere leaves are reached through exact tests anyway
-            const float* b = &s->bvh.bounds[6 * (size_t)i];
-            leaf_tight = u.mn[0] == b[0] && u.mn[1] == b[1] && u.mn[2] == b[2] && u.mx[0] == b[3] && u.mx[1] == b[4] && u.mx[2] == b[5];
-        }
+        });
+        const bool leaf_tight = !loose;
         if (ok) {
             if (int rc = upload(ctx, s->d_wnodes, wn.data(), wn.size() * sizeof(float4))) return rc;
             s->wide.leaf_tight = leaf_tight ? 1u : 0u;
@@ -341,6 +368,7 @@ int upload_scene(trhip_scene* s) {
             s->wide_ok = ok;
         }
     }
+    clk.tick("upload: wnodes");
     // ---- 8-wide nodes over the triangles' subtree for k_trace8 (th_wide8.h) ----
     s->w8_ok = false;
     std::memset(&s->w8, 0, sizeof s->w8);
@@ -383,6 +411,7 @@ int upload_scene(trhip_scene* s) {
             }
         }
     }
+    clk.tick("upload: 8-wide view");
     // ---- one-leaf scenes: the order in which any-hit rays try the leaf's primitives (th_trace2.h, k_any_leaf) ----
     // A shadow ray runs from the surface THROUGH the light (t_max = Inf): what stops it at the latest is what the light sees, so the
     // primitives subtending the largest solid angle at the lights come first (triangles: Van Oosterom & Strackee; spheres: the cap of
@@ -432,15 +461,23 @@ int upload_scene(trhip_scene* s) {
         const double ex = (double)rb[3] - rb[0], ey = (double)rb[4] - rb[1], ez = (double)rb[5] - rb[2];
         const double face = std::max(ex * ey, std::max(ex * ez, ey * ez));
         std::vector<std::pair<double, uint32_t>> big;  // (area, ordered slot)
-        for (uint32_t k = 0; k < n_prims; ++k) {
-            const HostPrim& p = s->prims[s->bvh.order[k]];
-            if (p.kind != 0 || (p.meta & PRIM_DEGENERATE)) continue;
-            const double ax = (double)p.v[3] - p.v[0], ay = (double)p.v[4] - p.v[1], az = (double)p.v[5] - p.v[2];
-            const double bx = (double)p.v[6] - p.v[0], by = (double)p.v[7] - p.v[1], bz = (double)p.v[8] - p.v[2];
-            const double cx = ay * bz - az * by, cy = az * bx - ax * bz, cz = ax * by - ay * bx;
-            const double area = 0.5 * std::sqrt(cx * cx + cy * cy + cz * cz);
-            if (area >= 0.02 * face) big.push_back({area, k});
-        }
+        std::mutex big_lock;
+        parallel_for(n_prims, [&](size_t k0, size_t k1) {
+            std::vector<std::pair<double, uint32_t>> mine;
+            for (size_t k = k0; k < k1; ++k) {
+                const HostPrim& p = s->prims[s->bvh.order[k]];
+                if (p.kind != 0 || (p.meta & PRIM_DEGENERATE)) continue;
+                const double ax = (double)p.v[3] - p.v[0], ay = (double)p.v[4] - p.v[1], az = (double)p.v[5] - p.v[2];
+                const double bx = (double)p.v[6] - p.v[0], by = (double)p.v[7] - p.v[1], bz = (double)p.v[8] - p.v[2];
+                const double cx = ay * bz - az * by, cy = az * bx - ax * bz, cz = ax * by - ay * bx;
+                const double area = 0.5 * std::sqrt(cx * cx + cy * cy + cz * cz);
+                if (area >= 0.02 * face) mine.push_back({area, (uint32_t)k});
+            }
+            if (!mine.empty()) {
+                std::lock_guard<std::mutex> g(big_lock);
+                big.insert(big.end(), mine.begin(), mine.end());
+            }
+        });
         if (!big.empty() && big.size() * 8 <= (size_t)n_prims) {  // a few walls around much else; not a scene that consists of large triangles
             std::sort(big.begin(), big.end(), [](const auto& a, const auto& b) { return a.first > b.first || (a.first == b.first && a.second < b.second); });
             if (big.size() > 16) big.resize(16);
@@ -466,16 +503,24 @@ int upload_scene(trhip_scene* s) {
                 }
                 std::stable_sort(big.begin(), big.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
             }
-            std::vector<uint32_t> leaf_of(n_prims, 0xffffffffu);
-            for (uint32_t i = 0; i < n_nodes; ++i)
-                if ((s->bvh.flags[i] & 3u) == 3u)
-                    for (uint32_t k = s->bvh.a[i]; k < s->bvh.a[i] + (s->bvh.flags[i] >> 2) && k < n_prims; ++k) leaf_of[k] = i;
+            // the leaf that holds each of the (at most 16) chosen slots
+            std::vector<std::atomic<uint32_t>> leaf_of(big.size());
+            for (auto& l : leaf_of) l = 0xffffffffu;
+            parallel_for(n_nodes, [&](size_t i0, size_t i1) {
+                for (size_t i = i0; i < i1; ++i) {
+                    if ((s->bvh.flags[i] & 3u) != 3u) continue;
+                    const uint32_t first = s->bvh.a[i], cnt = s->bvh.flags[i] >> 2;
+                    for (size_t q = 0; q < big.size(); ++q)
+                        if (big[q].second - first < cnt) leaf_of[q] = (uint32_t)i;
+                }
+            });
             std::vector<uint32_t> slots;
             std::vector<float> boxes;
-            for (const auto& b : big) {
-                if (leaf_of[b.second] == 0xffffffffu) continue;
-                slots.push_back(b.second);
-                for (int a = 0; a < 6; ++a) boxes.push_back(s->bvh.bounds[6 * (size_t)leaf_of[b.second] + a]);
+            for (size_t q = 0; q < big.size(); ++q) {
+                const uint32_t leaf = leaf_of[q];
+                if (leaf == 0xffffffffu) continue;
+                slots.push_back(big[q].second);
+                for (int a = 0; a < 6; ++a) boxes.push_back(s->bvh.bounds[6 * (size_t)leaf + a]);
             }
             if (slots.size() >= 6) {  // an enclosure (three quads or more); a lone floor stops few shadow rays and the pre-pass only costs (S-caustic)
                 if (int rc = upload(ctx, s->d_occ_slots, slots.data(), slots.size() * sizeof(uint32_t))) return rc;
@@ -484,6 +529,7 @@ int upload_scene(trhip_scene* s) {
             }
         }
     }
+    clk.tick("upload: occluders");
     s->committed = true;
     return 0;
 }
@@ -529,26 +575,49 @@ int trhip_scene_add_triangles(trhip_scene* s, const float* xyz, uint32_t n_verts
                               uint32_t* first_out) {
     if (!s || !xyz || !idx) return fail(s ? s->ctx : nullptr, TRHIP_ERR_INVALID, "null argument");
     const uint32_t first = (uint32_t)s->prims.size();
-    s->prims.reserve(s->prims.size() + n_tris);
-    for (uint32_t k = 0; k < n_tris; ++k) {
-        HostPrim p;
-        std::memset(&p, 0, sizeof p);
-        p.kind = 0;
+    // validate first (nothing is added when an index or a material is out of range), then fill the records on all cores
+    std::atomic<uint32_t> bad_tri{0xffffffffu};
+    parallel_for(n_tris, [&](size_t k0, size_t k1) {
+        for (size_t k = k0; k < k1; ++k) {
+            bool ok = true;
+            for (int j = 0; j < 3; ++j) ok = ok && idx[3 * k + j] >= 1 && idx[3 * k + j] <= n_verts;
+            if (mat && mat[k] != PRIM_NO_MATERIAL && mat[k] >= s->materials.size()) ok = false;
+            if (!ok) {
+                uint32_t cur = bad_tri.load();
+                while ((uint32_t)k < cur && !bad_tri.compare_exchange_weak(cur, (uint32_t)k)) {
+                }
+                return;
+            }
+        }
+    });
+    if (bad_tri != 0xffffffffu) {
+        const uint32_t k = bad_tri;
         for (int j = 0; j < 3; ++j) {
             const uint32_t vi = idx[3 * (size_t)k + j];
             if (vi < 1 || vi > n_verts) return fail(s->ctx, TRHIP_ERR_INVALID, "triangle %u: index %u outside 1..%u (indices are 1-based)", k, vi, n_verts);
-            std::memcpy(&p.v[3 * j], &xyz[3 * (size_t)(vi - 1)], 3 * sizeof(float));
-            if (normals) std::memcpy(&p.n[3 * j], &normals[3 * (size_t)(vi - 1)], 3 * sizeof(float));
         }
-        uint32_t m = mat ? mat[k] : PRIM_NO_MATERIAL;
-        if (mat && m != PRIM_NO_MATERIAL && m >= s->materials.size()) return fail(s->ctx, TRHIP_ERR_INVALID, "triangle %u: material %u not defined", k, m);
-        // is_degenerate (triangle_mesh.jl:65-68) depends on the triangle alone: evaluated here, once, in the kernels' arithmetic
-        const f3 tv0 = mk3(p.v[0], p.v[1], p.v[2]), tv1 = mk3(p.v[3], p.v[4], p.v[5]), tv2 = mk3(p.v[6], p.v[7], p.v[8]);
-        const f3 tn = cross(tv2 - tv0, tv1 - tv0);
-        const bool degenerate = dot(tn, tn) == 0.0f;
-        p.meta = (m & PRIM_MATERIAL_MASK) | (normals ? PRIM_HAS_NORMALS : 0u) | (flip ? PRIM_FLIP : 0u) | (degenerate ? PRIM_DEGENERATE : 0u);
-        s->prims.push_back(p);
+        return fail(s->ctx, TRHIP_ERR_INVALID, "triangle %u: material %u not defined", k, mat[k]);
     }
+    s->prims.resize((size_t)first + n_tris);
+    parallel_for(n_tris, [&](size_t k0, size_t k1) {
+        for (size_t k = k0; k < k1; ++k) {
+            HostPrim p;
+            std::memset(&p, 0, sizeof p);
+            p.kind = 0;
+            for (int j = 0; j < 3; ++j) {
+                const uint32_t vi = idx[3 * k + j];
+                std::memcpy(&p.v[3 * j], &xyz[3 * (size_t)(vi - 1)], 3 * sizeof(float));
+                if (normals) std::memcpy(&p.n[3 * j], &normals[3 * (size_t)(vi - 1)], 3 * sizeof(float));
+            }
+            const uint32_t m = mat ? mat[k] : PRIM_NO_MATERIAL;
+            // is_degenerate (triangle_mesh.jl:65-68) depends on the triangle alone: evaluated here, once, in the kernels' arithmetic
+            const f3 tv0 = mk3(p.v[0], p.v[1], p.v[2]), tv1 = mk3(p.v[3], p.v[4], p.v[5]), tv2 = mk3(p.v[6], p.v[7], p.v[8]);
+            const f3 tn = cross(tv2 - tv0, tv1 - tv0);
+            const bool degenerate = dot(tn, tn) == 0.0f;
+            p.meta = (m & PRIM_MATERIAL_MASK) | (normals ? PRIM_HAS_NORMALS : 0u) | (flip ? PRIM_FLIP : 0u) | (degenerate ? PRIM_DEGENERATE : 0u);
+            s->prims[(size_t)first + k] = p;
+        }
+    });
     if (first_out) *first_out = first;
     s->committed = false;
     return 0;
@@ -632,18 +701,22 @@ int trhip_scene_add_spot_light_fields(trhip_scene* s, const float* l2w, const fl
 }
 
 int trhip_scene_commit(trhip_scene* s, int max_node_primitives) {
+    CommitClock clk;
     if (!s) return fail(nullptr, TRHIP_ERR_INVALID, "null scene");
     HIP_TRY(s->ctx, hipSetDevice(s->ctx->device));
     std::vector<HostAABB> pb(s->prims.size());
-    for (size_t i = 0; i < s->prims.size(); ++i) {
-        const HostPrim& p = s->prims[i];
-        if (p.kind == 1) {
-            pb[i] = s->sphere_bounds[p.sphere_id];
-        } else {  // world_bound(triangle) triangle_mesh.jl:97
-            pb[i].reset();
-            for (int j = 0; j < 3; ++j) pb[i].grow_point(&p.v[3 * j]);
+    parallel_for(s->prims.size(), [&](size_t i0, size_t i1) {
+        for (size_t i = i0; i < i1; ++i) {
+            const HostPrim& p = s->prims[i];
+            if (p.kind == 1) {
+                pb[i] = s->sphere_bounds[p.sphere_id];
+            } else {  // world_bound(triangle) triangle_mesh.jl:97
+                pb[i].reset();
+                for (int j = 0; j < 3; ++j) pb[i].grow_point(&p.v[3 * j]);
+            }
         }
-    }
+    });
+    clk.tick("commit: primitive bounds");
     // Scenes with a few spheres beside a mesh: a chain root -> {sphere 1, {sphere 2, ... {sphere k, the triangles' subtree}}}.  Any BVH2 is a valid
     // BVHAccel (results depend on the topology only through exact-t ties); this one keeps the spheres — whose fp32
     // quadratic accepts rays far outside their box and can raise t_max (A.18) — out of the triangles' subtree, which the 8-wide
@@ -699,6 +772,7 @@ int trhip_scene_commit(trhip_scene* s, int max_node_primitives) {
         BVHBuilder builder(pb_build, max_node_primitives, s->ctx->tiny_scene_prims, want_chain);  // traversal 4 wants one primitive per leaf
         s->bvh = builder.build();
     }
+    clk.tick("commit: tree");
     if (compose) {
         // flat layout (bvh.jl:187-206): chain node i at 2 i = interior {leaf of sphere i at 2 i + 1, rest at 2 i + 2}; the triangles' subtree at 2 n_sph
         FlatBVH sub = std::move(s->bvh), out;
