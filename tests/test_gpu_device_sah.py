@@ -106,3 +106,42 @@ def test_device_sah_random_soups(T, ob, ctx):
             assert np.array_equal(a, out[0][1]) and np.array_equal(flags, out[0][2]), f"n = {n}, leaf hint {leaf}: topology differs from the host builder's"
     finally:
         ctx.set_option("bvh_builder", -1)
+
+
+def test_device_sah_million_triangles(T, ob, ctx):
+    """S-mesh (1 048 364 primitives, the bench scene): the device builder's tree is the host builder's, and camera / incoherent rays hit
+    what the oracle hits walking it."""
+    import bench
+    out = {}
+    try:
+        for builder in (0, 3):
+            ctx.set_option("bvh_builder", builder)
+            scene, cam, _ = bench.build_workload(T, "mesh_1m", 256)
+            flat = scene.flatten(ctx)
+            out[builder] = (scene, flat, [x.copy() for x in flat.bvh()])
+            if builder == 0:
+                flat.free()
+                scene._flat = None
+    finally:
+        ctx.set_option("bvh_builder", -1)
+    scene, flat, (bounds, a, flags, order) = out[3]
+    hb, ha, hf, ho = out[0][2]
+    assert a.size == ha.size and np.array_equal(a, ha) and np.array_equal(flags, hf)
+    assert same_boxes(bounds, hb)
+    diff = np.flatnonzero(order != ho)
+    if diff.size:  # only inside leaves of several primitives, as sets
+        leaf = np.flatnonzero((flags & 3) == 3)
+        first = a[leaf].astype(np.int64)
+        cnt = (flags[leaf] >> 2).astype(np.int64)
+        owner = np.searchsorted(first, diff, side="right") - 1
+        for j in np.unique(owner):
+            s, c = int(first[j]), int(cnt[j])
+            assert c > 1 and sorted(order[s:s + c].tolist()) == sorted(ho[s:s + c].tolist())
+    osc = ob.OracleScene.from_scene(scene, bvh=(bounds, a, flags, order))
+    wb = osc.world_bound()
+    rays = np.concatenate([camera_rays(T, ob, cam)[::4], T.scenes.incoherent_rays(60000, wb[:3] - 0.1, wb[3:] + 0.1)])
+    got = flat.trace_closest(rays)
+    t_ref, prim_ref, _, _ = osc.trace_closest(rays)
+    assert np.array_equal(got["prim"], prim_ref)
+    assert_bits_equal(got["t"], t_ref, "t (device SAH tree, 1 M triangles)")
+    assert np.array_equal(flat.trace_any(rays), osc.trace_any(rays)[0])
