@@ -94,7 +94,9 @@ def pmc_child_runs(args, kernel_prefix: str, want_any: bool, passes):
                "--iterations", str(args.iterations), "--radius", str(args.radius),
                "--no-cpu-baseline", "--no-traffic", "--no-micro", "--no-visits"] + [a for kv in args.opt for a in ("--opt", kv)]
         try:
-            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900, check=True)
+            res = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=900)
+            if res.returncode != 0:
+                raise RuntimeError(f"rc {res.returncode}: " + res.stderr.decode(errors="replace")[-600:])
             files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
             acc, n = {}, {}
             for r in csv.DictReader(open(files[0])):
@@ -108,8 +110,8 @@ def pmc_child_runs(args, kernel_prefix: str, want_any: bool, passes):
                 n[c] = n.get(c, 0) + 1
             for c in acc:
                 totals[c] = acc[c] / n[c]
-        except Exception:
-            pass
+        except Exception as e:  # the line then carries traffic / valu = null; say why on stderr
+            print(f"[bench] PMC pass {list(counters)} failed: {type(e).__name__}: {str(e)[-700:]}", file=sys.stderr, flush=True)
         finally:
             shutil.rmtree(out, ignore_errors=True)
     return totals or None

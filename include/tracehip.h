@@ -65,6 +65,16 @@ int trhip_scene_add_material(trhip_scene* scene, int kind, const float* params, 
 int trhip_scene_add_triangles(trhip_scene* scene, const float* world_xyz, uint32_t n_verts, const uint32_t* indices_1based, uint32_t n_tris,
                               const float* normals_or_null, const uint32_t* material_id_per_tri, int flip_orientation, uint32_t* first_prim_out);
 
+/* The same with the mesh's two optional per-vertex arrays (shapes/triangle_mesh.jl:1-30, create_triangle_mesh's last two arguments):
+ * tangents: n_verts x 3, untransformed like the normals, read through the indices (:76-78) — the shading tangent of a hit is their barycentric
+ *   mix (:172-176) instead of ∂p∂u; a mesh with tangents and no normals still gets shading geometry (:165);
+ * uv: the reference reads `mesh.uv[t.i + j]` (:82) — indexed by the triangle's CORNER position 3k + j in the index list, not through the indices —
+ *   so the array holds 3 x n_tris points (2 floats each), corner-major; ∂p∂u / ∂p∂v (:125-141) and interaction.uv follow from it.
+ * Either pointer may be NULL (both NULL = trhip_scene_add_triangles). */
+int trhip_scene_add_triangles_ex(trhip_scene* scene, const float* world_xyz, uint32_t n_verts, const uint32_t* indices_1based, uint32_t n_tris,
+                                 const float* normals_or_null, const float* tangents_or_null, const float* uv_corners_or_null,
+                                 const uint32_t* material_id_per_tri, int flip_orientation, uint32_t* first_prim_out);
+
 /* Sphere(core, radius, z_min, z_max, ϕ_max°) + GeometricPrimitive  (shapes/sphere.jl:1-30).  Both matrices of
  * core.object_to_world (m and inv_m, transformations.jl:1-4) are passed because the reference keeps them separately
  * (and multiplies inverses in a non-standard order, transformations.jl:20-22). */

@@ -82,8 +82,15 @@ int orc_scene_add_material(void* sp, int kind, const float* p, int n) {
 
 // create_triangle_mesh(core, n_tris, indices(1-based), n_verts, OBJECT-space vertices, normals|null) + one
 // GeometricPrimitive per triangle with material_ids[k] (or -1).  Returns the index of the first primitive.
+int orc_scene_add_triangle_mesh_ex(void* sp, const float* o2w, const float* o2w_inv, int reverse_orientation, const float* verts, uint32_t n_verts, const uint32_t* indices,
+                                   uint32_t n_tris, const float* normals, const float* tangents, const float* uv_corners, const int32_t* material_ids);
 int orc_scene_add_triangle_mesh(void* sp, const float* o2w, const float* o2w_inv, int reverse_orientation, const float* verts, uint32_t n_verts,
                                 const uint32_t* indices, uint32_t n_tris, const float* normals, const int32_t* material_ids) {
+    return orc_scene_add_triangle_mesh_ex(sp, o2w, o2w_inv, reverse_orientation, verts, n_verts, indices, n_tris, normals, nullptr, nullptr, material_ids);
+}
+// … with the mesh's optional tangents (n_verts x 3) and uvs (3 n_tris x 2, by corner position: triangle_mesh.jl:82)
+int orc_scene_add_triangle_mesh_ex(void* sp, const float* o2w, const float* o2w_inv, int reverse_orientation, const float* verts, uint32_t n_verts, const uint32_t* indices,
+                                   uint32_t n_tris, const float* normals, const float* tangents, const float* uv_corners, const int32_t* material_ids) {
     OrcScene* s = (OrcScene*)sp;
     ShapeCore core(tf_from(o2w, o2w_inv), reverse_orientation != 0);
     std::vector<V3> v(n_verts), nrm;
@@ -92,8 +99,18 @@ int orc_scene_add_triangle_mesh(void* sp, const float* o2w, const float* o2w_inv
         nrm.resize(n_verts);
         for (uint32_t i = 0; i < n_verts; ++i) nrm[i] = V3(normals[3 * i], normals[3 * i + 1], normals[3 * i + 2]);
     }
+    std::vector<V3> tan;
+    if (tangents) {
+        tan.resize(n_verts);
+        for (uint32_t i = 0; i < n_verts; ++i) tan[i] = V3(tangents[3 * i], tangents[3 * i + 1], tangents[3 * i + 2]);
+    }
+    std::vector<V2> uvs;
+    if (uv_corners) {
+        uvs.resize(3 * (size_t)n_tris);
+        for (size_t i = 0; i < uvs.size(); ++i) uvs[i] = V2{uv_corners[2 * i], uv_corners[2 * i + 1]};
+    }
     std::vector<uint32_t> idx(indices, indices + 3 * (size_t)n_tris);
-    auto mesh = std::make_shared<TriangleMesh>(core, idx, v, nrm);
+    auto mesh = std::make_shared<TriangleMesh>(core, idx, v, nrm, tan, uvs);
     const int first = (int)s->prims.size();
     for (uint32_t k = 0; k < n_tris; ++k) {
         Primitive p;

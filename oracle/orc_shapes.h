@@ -200,9 +200,12 @@ struct TriangleMesh {  // :1-30 — vertices are moved to world space at constru
     std::vector<V3> vertices;
     std::vector<uint32_t> indices;  // 1-based, as in the reference
     std::vector<V3> normals;        // empty = nothing
+    std::vector<V3> tangents;       // empty = nothing; one per vertex, not transformed either (:27)
+    std::vector<V2> uv;             // empty = nothing; read by CORNER position t.i + j, not through the indices (:82)
     ShapeCore core;                 // every Triangle of a mesh shares the ShapeCore it was created with (:45-58)
-    TriangleMesh(const ShapeCore& c, const std::vector<uint32_t>& idx, const std::vector<V3>& verts, const std::vector<V3>& nrm)
-        : indices(idx), normals(nrm), core(c) {
+    TriangleMesh(const ShapeCore& c, const std::vector<uint32_t>& idx, const std::vector<V3>& verts, const std::vector<V3>& nrm, const std::vector<V3>& tan = {},
+                 const std::vector<V2>& uvs = {})
+        : indices(idx), normals(nrm), tangents(tan), uv(uvs), core(c) {
         vertices.reserve(verts.size());
         for (const V3& v : verts) vertices.push_back(c.object_to_world.point(v));
     }
@@ -217,6 +220,18 @@ inline void tri_vertices(const Triangle& t, V3 vs[3]) {  // :70-72
 }
 inline void tri_normals(const Triangle& t, V3 ns[3]) {  // :73-75
     for (int j = 0; j < 3; ++j) ns[j] = t.mesh->normals[t.mesh->indices[t.i - 1 + j] - 1];
+}
+inline void tri_tangents(const Triangle& t, V3 ts[3]) {  // :76-78
+    for (int j = 0; j < 3; ++j) ts[j] = t.mesh->tangents[t.mesh->indices[t.i - 1 + j] - 1];
+}
+inline void tri_uvs(const Triangle& t, V2 uv[3]) {  // :79-83
+    if (t.mesh->uv.empty()) {
+        uv[0] = V2{0, 0};
+        uv[1] = V2{1, 0};
+        uv[2] = V2{1, 1};
+        return;
+    }
+    for (int j = 0; j < 3; ++j) uv[j] = t.mesh->uv[t.i - 1 + j];  // mesh.uv[t.i + j], 1-based
 }
 inline float tri_area(const Triangle& t) {  // :60-63
     V3 vs[3];
@@ -325,19 +340,30 @@ inline bool triangle_intersect(const Triangle& t, const Ray& ray, float& t_hit, 
     tri_vertices(t, vs);
     TriHit h;
     if (!tri_test(vs, ray, &h)) return false;
-    const V2 uv[3] = {V2{0, 0}, V2{1, 0}, V2{1, 1}};  // :79-83 (mesh.uv is never supplied, A.7)
+    V2 uv[3];
+    tri_uvs(t, uv);  // :215
     V3 dpdu, dpdv, dp13, dp23;
     tri_dp(vs, uv, dpdu, dpdv, dp13, dp23);
     const V3 hit_point = sum_mul(h.bary, vs);
     const V2 uv_hit = sum_mul(h.bary, uv);
     SurfaceInteraction si = make_interaction(hit_point, ray.time, -ray.d, uv_hit, dpdu, dpdv, &t.core());
     si.n = si.sh_n = normalize(cross(dp13, dp23));  // :230
-    const bool has_normals = !t.mesh->normals.empty();
-    if (has_normals) {  // _init_triangle_shading_geometry! :160-185 (tangents are never supplied)
-        V3 nrm[3];
-        tri_normals(t, nrm);
-        const V3 ns = normalize(sum_mul(h.bary, nrm));
-        V3 ss = normalize(si.dpdu);
+    const bool has_normals = !t.mesh->normals.empty(), has_tangents = !t.mesh->tangents.empty();
+    if (has_normals || has_tangents) {  // _init_triangle_shading_geometry! :160-185
+        V3 ns = si.n;  // :168
+        if (has_normals) {
+            V3 nrm[3];
+            tri_normals(t, nrm);
+            ns = normalize(sum_mul(h.bary, nrm));
+        }
+        V3 ss;
+        if (has_tangents) {  // :172-176
+            V3 tg[3];
+            tri_tangents(t, tg);
+            ss = normalize(sum_mul(h.bary, tg));
+        } else {
+            ss = normalize(si.dpdu);
+        }
         V3 ts = cross(ns, ss);
         if (dot(ts, ts) > 0) {
             ts = normalize(ts);
@@ -346,6 +372,8 @@ inline bool triangle_intersect(const Triangle& t, const Ray& ray, float& t_hit, 
             coordinate_system(ns, ss, ts);
         }
         set_shading_geometry(si, &t.core(), ss, ts, true);
+    }
+    if (has_normals) {
         si.n = face_forward(si.n, si.sh_n);  // :234-237
     } else if (t.core().flips()) {
         si.n = si.sh_n = -si.n;  // :238-240

@@ -49,6 +49,7 @@ def lib():
             "orc_scene_free": (None, [_VP]),
             "orc_scene_add_material": (C.c_int, [_VP, C.c_int, _F, C.c_int]),
             "orc_scene_add_triangle_mesh": (C.c_int, [_VP, _F, _F, C.c_int, _F, C.c_uint32, _U32, C.c_uint32, _F, _I32]),
+            "orc_scene_add_triangle_mesh_ex": (C.c_int, [_VP, _F, _F, C.c_int, _F, C.c_uint32, _U32, C.c_uint32, _F, _F, _F, _I32]),
             "orc_scene_add_sphere": (C.c_int, [_VP, _F, _F, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int]),
             "orc_scene_add_point_light": (C.c_int, [_VP, _F, _F, _F]),
             "orc_scene_add_spot_light": (C.c_int, [_VP, _F, _F, _F, C.c_float, C.c_float]),
@@ -174,15 +175,18 @@ class OracleScene:
         self.n_prims += 1
         return lib().orc_scene_add_sphere(self.h, fp(m), fp(im), int(reverse), radius, z_min, z_max, phi_max_deg, material)
 
-    def add_triangle_mesh(self, o2w, reverse, verts_obj, indices_1based, normals=None, materials=None) -> int:
+    def add_triangle_mesh(self, o2w, reverse, verts_obj, indices_1based, normals=None, materials=None, tangents=None, uv_corners=None) -> int:
         m, im = f32a(o2w.m), f32a(o2w.inv_m)
         v = f32a(verts_obj).reshape(-1, 3)
         idx = np.ascontiguousarray(indices_1based, dtype=np.uint32).reshape(-1)
         n = None if normals is None else f32a(normals).reshape(-1, 3)
         mats = None if materials is None else np.ascontiguousarray(materials, dtype=np.int32)
         self.n_prims += idx.size // 3
-        return lib().orc_scene_add_triangle_mesh(self.h, fp(m), fp(im), int(reverse), fp(v), v.shape[0], idx.ctypes.data_as(_U32), idx.size // 3,
-                                                 fp(n) if n is not None else None, mats.ctypes.data_as(_I32) if mats is not None else None)
+        tg = None if tangents is None else f32a(tangents).reshape(-1, 3)
+        uvc = None if uv_corners is None else f32a(uv_corners).reshape(-1, 2)
+        return lib().orc_scene_add_triangle_mesh_ex(self.h, fp(m), fp(im), int(reverse), fp(v), v.shape[0], idx.ctypes.data_as(_U32), idx.size // 3,
+                                                    fp(n) if n is not None else None, fp(tg) if tg is not None else None, fp(uvc) if uvc is not None else None,
+                                                    mats.ctypes.data_as(_I32) if mats is not None else None)
 
     def add_point_light(self, l2w, I):
         m, im, i = f32a(l2w.m), f32a(l2w.inv_m), f32a(I)
@@ -239,7 +243,9 @@ class OracleScene:
             if isinstance(p, T.MeshPrimitives):
                 mesh = p.mesh
                 idx = mesh.indices.reshape(-1, 3)
-                s.add_triangle_mesh(mesh.core.object_to_world, mesh.core.reverse_orientation, mesh.object_vertices, idx, mesh.normals, np.full(idx.shape[0], mid(p.material), np.int32))
+                uvc = None if getattr(mesh, "uv", None) is None else mesh.uv[:3 * mesh.n_triangles]
+                s.add_triangle_mesh(mesh.core.object_to_world, mesh.core.reverse_orientation, mesh.object_vertices, idx, mesh.normals, np.full(idx.shape[0], mid(p.material), np.int32),
+                                    getattr(mesh, "tangents", None), uvc)
                 i += 1
             elif isinstance(p.shape, T.Sphere):
                 sp = p.shape
@@ -258,10 +264,12 @@ class OracleScene:
                 # exactly only by keeping the original array, so the mirror's already-transformed vertices are passed with
                 # an identity core when the mesh core is not stored
                 verts = getattr(mesh, "object_vertices", None)
+                tg = getattr(mesh, "tangents", None)
+                uvc = None if getattr(mesh, "uv", None) is None else mesh.uv[:3 * mesh.n_triangles].reshape(-1, 3, 2)[np.array(ks)]
                 if verts is None:
-                    s.add_triangle_mesh(_identity_like(mesh.core, T), mesh.core.reverse_orientation != mesh.core.transform_swaps_handedness, mesh.vertices, idx, mesh.normals, mats)
+                    s.add_triangle_mesh(_identity_like(mesh.core, T), mesh.core.reverse_orientation != mesh.core.transform_swaps_handedness, mesh.vertices, idx, mesh.normals, mats, tg, uvc)
                 else:
-                    s.add_triangle_mesh(mesh.core.object_to_world, mesh.core.reverse_orientation, verts, idx, mesh.normals, mats)
+                    s.add_triangle_mesh(mesh.core.object_to_world, mesh.core.reverse_orientation, verts, idx, mesh.normals, mats, tg, uvc)
                 i = j
         for l in scene.lights:
             if isinstance(l, T.PointLight):

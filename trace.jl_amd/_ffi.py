@@ -99,6 +99,7 @@ SIGNATURES = {
     "trhip_scene_free": (None, [_VP]),
     "trhip_scene_add_material": (C.c_int, [_VP, C.c_int, _F, C.c_int, _U32]),
     "trhip_scene_add_triangles": (C.c_int, [_VP, _F, C.c_uint32, _U32, C.c_uint32, _F, _U32, C.c_int, _U32]),
+    "trhip_scene_add_triangles_ex": (C.c_int, [_VP, _F, C.c_uint32, _U32, C.c_uint32, _F, _F, _F, _U32, C.c_int, _U32]),
     "trhip_scene_add_sphere": (C.c_int, [_VP, _F, _F, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_uint32, _U32]),
     "trhip_scene_add_sphere_fields": (C.c_int, [_VP, _F, _F, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_uint32, _U32]),
     "trhip_scene_add_spot_light_fields": (C.c_int, [_VP, _F, _F, _F, C.c_float, C.c_float]),

@@ -243,8 +243,8 @@ class Sphere:  # shapes/sphere.jl:1-30 (clamps and angles are derived inside the
             self.z_min, self.z_max, self.phi_max_deg = f32(args[0]), f32(args[1]), f32(args[2])
 
 
-class TriangleMesh:  # shapes/triangle_mesh.jl:1-30: vertices go to world space here (:23), normals do not
-    def __init__(self, core: ShapeCore, indices, vertices, normals=None):
+class TriangleMesh:  # shapes/triangle_mesh.jl:1-30: vertices go to world space here (:23), normals and tangents do not
+    def __init__(self, core: ShapeCore, indices, vertices, normals=None, tangents=None, uv=None):
         self.core = core
         self.indices = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1)
         v = np.ascontiguousarray(vertices, dtype=np.float32).reshape(-1, 3)
@@ -252,6 +252,13 @@ class TriangleMesh:  # shapes/triangle_mesh.jl:1-30: vertices go to world space 
         self.vertices = transform_points(core.object_to_world, v)
         self.normals = None if normals is None else np.ascontiguousarray(normals, dtype=np.float32).reshape(-1, 3)
         self.n_triangles = self.indices.size // 3
+        # optional: one tangent per vertex (:11-12); (u, v)s, which the reference reads by CORNER position `mesh.uv[t.i + j]` (:82), i.e. 3 per triangle
+        self.tangents = None if tangents is None else np.ascontiguousarray(tangents, dtype=np.float32).reshape(-1, 3)
+        self.uv = None if uv is None else np.ascontiguousarray(uv, dtype=np.float32).reshape(-1, 2)
+        if self.tangents is not None and self.tangents.shape[0] != v.shape[0]:
+            raise ValueError("tangents: one per vertex")
+        if self.uv is not None and self.uv.shape[0] < 3 * self.n_triangles:
+            raise ValueError("uv: the reference indexes mesh.uv by corner position (triangle_mesh.jl:82): 3 * n_triangles entries are read")
 
 
 def transform_points(t: Transformation, v: np.ndarray) -> np.ndarray:
@@ -273,8 +280,8 @@ class Triangle:  # :32-43
     k: int  # 0-based triangle number; the reference stores i = 3k + 1
 
 
-def create_triangle_mesh(core: ShapeCore, n_triangles: int, indices, n_vertices: int, vertices, normals=None) -> List[Triangle]:  # :45-58
-    mesh = TriangleMesh(core, indices, vertices, normals)
+def create_triangle_mesh(core: ShapeCore, n_triangles: int, indices, n_vertices: int, vertices, normals=None, tangents=None, uv=None) -> List[Triangle]:  # :45-58
+    mesh = TriangleMesh(core, indices, vertices, normals, tangents, uv)
     assert mesh.n_triangles == n_triangles and mesh.vertices.shape[0] == n_vertices
     return [Triangle(mesh, k) for k in range(n_triangles)]
 
@@ -293,8 +300,8 @@ class MeshPrimitives:
     material: object = None
 
 
-def create_mesh_primitives(core: ShapeCore, indices, vertices, normals=None, material=None) -> MeshPrimitives:
-    return MeshPrimitives(TriangleMesh(core, indices, vertices, normals), material)
+def create_mesh_primitives(core: ShapeCore, indices, vertices, normals=None, material=None, tangents=None, uv=None) -> MeshPrimitives:
+    return MeshPrimitives(TriangleMesh(core, indices, vertices, normals, tangents, uv), material)
 
 
 class BVHAccel:  # accel/bvh.jl:50-79: the tree itself is built inside the library at Scene flattening
@@ -554,9 +561,7 @@ class FlatScene:
                 mats = np.full(idx.shape[0], material_id(p.material), dtype=np.uint32)
                 core = mesh.core
                 flip = int(core.reverse_orientation != core.transform_swaps_handedness)
-                nrm = mesh.normals
-                ctx.check(L.trhip_scene_add_triangles(self._h, _ffi.fptr(mesh.vertices), mesh.vertices.shape[0], _ffi.u32ptr(idx), idx.shape[0],
-                                                      _ffi.fptr(nrm) if nrm is not None else None, _ffi.u32ptr(mats), flip, None))
+                self._add_triangles(ctx, mesh, idx, mats, flip, None)
                 i += 1
             elif isinstance(p.shape, Triangle):
                 # batch consecutive triangles of the same mesh into one call (caller order is preserved)
@@ -571,9 +576,7 @@ class FlatScene:
                 mats = np.array(mats, dtype=np.uint32)
                 core = mesh.core
                 flip = int(core.reverse_orientation != core.transform_swaps_handedness)
-                nrm = mesh.normals
-                ctx.check(L.trhip_scene_add_triangles(self._h, _ffi.fptr(mesh.vertices), mesh.vertices.shape[0], _ffi.u32ptr(idx), idx.shape[0],
-                                                      _ffi.fptr(nrm) if nrm is not None else None, _ffi.u32ptr(mats), flip, None))
+                self._add_triangles(ctx, mesh, idx, mats, flip, np.array(ks))
                 i = j
             else:
                 raise TraceHipError(f"unsupported shape {type(p.shape).__name__}")
@@ -587,6 +590,21 @@ class FlatScene:
             else:
                 raise TraceHipError(f"unsupported light {type(l).__name__}")
         ctx.check(L.trhip_scene_commit(self._h, scene.aggregate.max_node_primitives))
+
+    def _add_triangles(self, ctx, mesh, idx, mats, flip, ks):
+        """One trhip_scene_add_triangles(_ex) call; ks = the triangle numbers of `idx` inside the mesh (None: all, in order) — the corner uvs follow them."""
+        L = _ffi.lib()
+        nrm, tan, uv = mesh.normals, getattr(mesh, "tangents", None), getattr(mesh, "uv", None)
+        if tan is None and uv is None:
+            ctx.check(L.trhip_scene_add_triangles(self._h, _ffi.fptr(mesh.vertices), mesh.vertices.shape[0], _ffi.u32ptr(idx), idx.shape[0],
+                                                  _ffi.fptr(nrm) if nrm is not None else None, _ffi.u32ptr(mats), flip, None))
+            return
+        if uv is not None:
+            uv = uv[:3 * mesh.n_triangles].reshape(-1, 3, 2)
+            uv = np.ascontiguousarray(uv if ks is None else uv[ks], dtype=np.float32)
+        ctx.check(L.trhip_scene_add_triangles_ex(self._h, _ffi.fptr(mesh.vertices), mesh.vertices.shape[0], _ffi.u32ptr(idx), idx.shape[0],
+                                                 _ffi.fptr(nrm) if nrm is not None else None, _ffi.fptr(tan) if tan is not None else None,
+                                                 _ffi.fptr(uv) if uv is not None else None, _ffi.u32ptr(mats), flip, None))
 
     def bvh(self):
         L = _ffi.lib()

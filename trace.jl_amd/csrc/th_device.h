@@ -223,13 +223,15 @@ struct Shading {  // what BSDF(si) (bsdf.jl:41-50) and the integrators read from
 struct TriConstants {
     f3 n, ss;
 };
-TH_D TriConstants triangle_constants(f3 v0, f3 v1, f3 v2) {
-    // ∂p with the default uvs (0,0) (1,0) (1,1)  (:79-83, :125-141)
-    const float du13x = 0.0f - 1.0f, du13y = 0.0f - 1.0f, du23x = 1.0f - 1.0f, du23y = 0.0f - 1.0f;
+// uv: the triangle's three (u, v) pairs {u0, v0, u1, v1, u2, v2} (uvs(t), :79-83), or null for the default (0,0) (1,0) (1,1)
+TH_D TriConstants triangle_constants(f3 v0, f3 v1, f3 v2, const float* uv = nullptr) {
+    // ∂p (:125-141)
+    const float u0 = uv ? uv[0] : 0.0f, w0 = uv ? uv[1] : 0.0f, u1 = uv ? uv[2] : 1.0f, w1 = uv ? uv[3] : 0.0f, u2 = uv ? uv[4] : 1.0f, w2 = uv ? uv[5] : 1.0f;
+    const float du13x = u0 - u2, du13y = w0 - w2, du23x = u1 - u2, du23y = w1 - w2;
     const f3 dp13 = v0 - v2, dp23 = v1 - v2;
     const float det = du13x * du23y - du13y * du23x;
     f3 dpdu;
-    if (det == 0.0f) {  // unreachable with the default uvs; kept for the formula's sake
+    if (det == 0.0f) {  // `det ≈ 0` (:132) is true for 0 only; unreachable with the default uvs
         f3 t2;
         coordinate_system(normalize(cross(v2 - v0, v1 - v0)), dpdu, t2);
     } else {
@@ -241,7 +243,9 @@ TH_D TriConstants triangle_constants(f3 v0, f3 v1, f3 v2) {
     c.ss = normalize(dpdu);
     return c;
 }
-TH_D Shading shade_triangle(f3 v0, f3 v1, f3 v2, bool has_normals, f3 n0, f3 n1, f3 n2, bool flip, f3 bary, f3 ray_d, const TriConstants* pre = nullptr) {
+// tg: the three vertex tangents when the mesh has them (has_tangents), else unused
+TH_D Shading shade_triangle(f3 v0, f3 v1, f3 v2, bool has_normals, f3 n0, f3 n1, f3 n2, bool flip, f3 bary, f3 ray_d, const TriConstants* pre = nullptr, bool has_tangents = false,
+                            const f3* tg = nullptr) {
     Shading s;
     const TriConstants tc = pre ? *pre : triangle_constants(v0, v1, v2);
     s.p = bary.x * v0 + bary.y * v1 + bary.z * v2;  // sum_mul(barycentric, vs) :222
@@ -250,9 +254,9 @@ TH_D Shading shade_triangle(f3 v0, f3 v1, f3 v2, bool has_normals, f3 n0, f3 n1,
     f3 shn = n;
     bool ss_is_unit = true;  // s.ss below is normalize(∂p∂u): tc.ss itself unless the shading normals replace ∂p∂u
     f3 sh_dpdu = tc.ss;
-    if (has_normals) {
-        const f3 nsn = normalize(bary.x * n0 + bary.y * n1 + bary.z * n2);
-        f3 ss = tc.ss;
+    if (has_normals || has_tangents) {  // _init_triangle_shading_geometry! (:160-185)
+        const f3 nsn = has_normals ? normalize(bary.x * n0 + bary.y * n1 + bary.z * n2) : n;
+        f3 ss = has_tangents ? normalize(bary.x * tg[0] + bary.y * tg[1] + bary.z * tg[2]) : tc.ss;
         f3 ts = cross(nsn, ss);
         if (dot(ts, ts) > 0.0f) {
             ts = normalize(ts);
@@ -266,7 +270,12 @@ TH_D Shading shade_triangle(f3 v0, f3 v1, f3 v2, bool has_normals, f3 n0, f3 n1,
         n = face_forward(n, shn);
         sh_dpdu = ss;
         ss_is_unit = false;
-        n = face_forward(n, shn);  // :234-237
+        if (has_normals) {
+            n = face_forward(n, shn);  // :234-237
+        } else if (flip) {             // :238-239 (a mesh with tangents only)
+            n = -n;
+            shn = n;
+        }
     } else if (flip) {
         n = -n;
         shn = n;

@@ -119,6 +119,9 @@ struct HostPrim {
     uint32_t kind;       // 0 triangle, 1 sphere
     float v[9];          // triangle vertices (world)
     float n[9];          // vertex normals
+    float tg[9];         // vertex tangents (PRIM_HAS_TANGENTS)
+    float uv[6];         // corner uvs (has_uv)
+    uint32_t has_uv;
     uint32_t meta;       // material | flags
     uint32_t sphere_id;  // for spheres
 };
@@ -132,7 +135,7 @@ struct trhip_scene {
     std::vector<LightRec> lights;
     FlatBVH bvh;
     bool committed = false;
-    DevBuf d_nodes, d_prims, d_nrm, d_shade, d_spheres, d_materials, d_lights, d_wnodes;
+    DevBuf d_nodes, d_prims, d_nrm, d_tan, d_shade, d_spheres, d_materials, d_lights, d_wnodes;
     DeviceScene dev{};
     WideScene wide{};
     DevBuf d_occ_slots, d_occ_boxes, d_w8nodes, d_w8tris, d_leaf_order;

@@ -419,12 +419,19 @@ TH_D bool rebuild_shading(const DeviceScene& sc, int prim, f3 o, f3 d, Shading& 
         return false;
     const bool has_n = (meta & PRIM_HAS_NORMALS) != 0;
     const TriConstants tc{mk3(cn.x, cn.y, cn.z), mk3(cs.x, cs.y, cs.z)};
+    if (sc.tri_tan && (meta & PRIM_HAS_TANGENTS)) {  // a mesh with vertex tangents (no scene of the reference has one): its own call, so that the common one keeps its registers
+        const float4 ta = sc.tri_tan[3 * (size_t)prim], tb = sc.tri_tan[3 * (size_t)prim + 1], tcn = sc.tri_tan[3 * (size_t)prim + 2];
+        const f3 tg[3] = {mk3(ta.x, ta.y, ta.z), mk3(tb.x, tb.y, tb.z), mk3(tcn.x, tcn.y, tcn.z)};
+        sh = shade_triangle(v0, v1, v2, has_n, mk3(na.x, na.y, na.z), mk3(nb.x, nb.y, nb.z), mk3(nc.x, nc.y, nc.z), (meta & PRIM_FLIP) != 0, tt.bary, d, &tc, true, tg);
+        return true;
+    }
     sh = shade_triangle(v0, v1, v2, has_n, mk3(na.x, na.y, na.z), mk3(nb.x, nb.y, nb.z), mk3(nc.x, nc.y, nc.z), (meta & PRIM_FLIP) != 0, tt.bary, d, &tc);
     return true;
 }
 // Commit time: every slot's shading line (th_scene.h) from the two arrays the traversal kernels use — records 0-2 = prims, 3-5 = tri_nrm, 6 / 7 =
 // triangle_constants of the vertices.
-static __global__ __launch_bounds__(kBlock) void k_shade_constants(float4* __restrict__ shade, const float4* __restrict__ prims, const float4* __restrict__ nrm, uint32_t n_prims) {
+// uv: 2 float4 per slot {u0, v0, u1, v1}, {u2, v2, has_uv, 0} for scenes where some mesh carries (u, v)s, else null
+static __global__ __launch_bounds__(kBlock) void k_shade_constants(float4* __restrict__ shade, const float4* __restrict__ prims, const float4* __restrict__ nrm, const float4* __restrict__ uv, uint32_t n_prims) {
     for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < n_prims; k += gridDim.x * kBlock) {
         float4* rec = shade + 8 * (size_t)k;
         const float4 p0 = prims[3 * (size_t)k], p1 = prims[3 * (size_t)k + 1], p2 = prims[3 * (size_t)k + 2];
@@ -434,7 +441,14 @@ static __global__ __launch_bounds__(kBlock) void k_shade_constants(float4* __res
         for (int j = 0; j < 3; ++j) rec[3 + j] = nrm[3 * (size_t)k + j];
         float4 c6 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), c7 = c6;
         if (!(__float_as_uint(p0.w) & PRIM_SPHERE)) {
-            const TriConstants tc = triangle_constants(mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z));
+            float uvs[6];
+            bool has_uv = false;
+            if (uv) {
+                const float4 a = uv[2 * (size_t)k], b = uv[2 * (size_t)k + 1];
+                uvs[0] = a.x, uvs[1] = a.y, uvs[2] = a.z, uvs[3] = a.w, uvs[4] = b.x, uvs[5] = b.y;
+                has_uv = b.z != 0.0f;
+            }
+            const TriConstants tc = triangle_constants(mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z), has_uv ? uvs : nullptr);
             c6 = make_float4(tc.n.x, tc.n.y, tc.n.z, 0.0f);
             c7 = make_float4(tc.ss.x, tc.ss.y, tc.ss.z, 0.0f);
         }

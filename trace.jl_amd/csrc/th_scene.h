@@ -8,6 +8,7 @@
 //                                  triangle: v0 v1 v2 (world space); v0.w = as_float(meta), meta = material | flags << 24
 //                                  sphere:   {as_float(sphere index), 0, 0, as_float(meta)}, unused, unused
 //   tri_nrm    float4[3*n_prims]   vertex normals of slot k (zeros when the mesh has none / slot is a sphere)
+//   tri_tan    float4[3*n_prims]   vertex tangents of slot k (only when some mesh has them; PRIM_HAS_TANGENTS)
 //   shade      float4[8*n_prims]   prims and tri_nrm of slot k side by side, 128-byte aligned: what rebuild_shading reads
 //   spheres    SphereRec[n_spheres]
 //   materials  MaterialRec[n_materials]: the ≤2 BxDF lobes each material adds, for allow_multiple_lobes = false / true
@@ -25,6 +26,7 @@ enum : uint32_t {
     PRIM_FAST = 1u << 28,         // triangle whose material (compute_scattering! with multiple lobes) is ONE LambertianReflection lobe: its
                                   // reflectance rides in the .w lanes of the three normal records (upload_scene), the shading kernel
                                   // classifies and shades it without touching the material table   // is_degenerate(triangle) (triangle_mesh.jl:65-68), evaluated once at scene commit
+    PRIM_HAS_TANGENTS = 1u << 29, // the mesh has vertex tangents: slot k's three are in DeviceScene::tri_tan (triangle_mesh.jl:172-176)
     PRIM_MATERIAL_MASK = 0x00ffffffu,
     PRIM_NO_MATERIAL = 0x00ffffffu
 };
@@ -73,6 +75,7 @@ struct DeviceScene {
     const float4* nodes;
     const float4* prims;
     const float4* tri_nrm;
+    const float4* tri_tan;  // float4[3*n_prims] vertex tangents of slot k, or null when no mesh of the scene has tangents
     const float4* shade;  // the shading kernels' view of slot k: {v0 | meta, v1, v2, n0 | r, n1 | g, n2 | b, geometric normal, unit dpdu (k_shade_constants)} in ONE 128-byte line (prims + tri_nrm
                           // interleaved): a path vertex gathers one line instead of ~2.75
     const SphereRec* spheres;

@@ -226,11 +226,55 @@ int upload_scene(trhip_scene* s) {
     if (int rc = upload(ctx, s->d_prims, prims.data(), prims.size() * sizeof(float4))) return rc;
     if (int rc = upload(ctx, s->d_nrm, nrm.data(), nrm.size() * sizeof(float4))) return rc;
     clk.tick("upload: 3 copies");
+    // the two optional mesh arrays (no scene of the reference sets them): tangents stay resident for the shading kernels, (u, v)s only feed k_shade_constants
+    bool any_tan = false, any_uv = false;
+    for (const HostPrim& p : s->prims) {
+        any_tan = any_tan || (p.kind == 0 && (p.meta & PRIM_HAS_TANGENTS));
+        any_uv = any_uv || (p.kind == 0 && p.has_uv);
+        if (any_tan && any_uv) break;
+    }
+    s->dev.tri_tan = nullptr;
+    if (any_tan) {
+        std::vector<float4> tan((size_t)n_prims * 3, make_float4(0, 0, 0, 0));
+        parallel_for(n_prims, [&](size_t k0, size_t k1) {
+            for (size_t k = k0; k < k1; ++k) {
+                const HostPrim& p = s->prims[s->bvh.order[k]];
+                if (p.kind == 0 && (p.meta & PRIM_HAS_TANGENTS))
+                    for (int j = 0; j < 3; ++j) tan[3 * k + j] = make_float4(p.tg[3 * j], p.tg[3 * j + 1], p.tg[3 * j + 2], 0.0f);
+            }
+        });
+        if (int rc = upload(ctx, s->d_tan, tan.data(), tan.size() * sizeof(float4))) return rc;
+        s->dev.tri_tan = (const float4*)s->d_tan.p;
+    } else {
+        release(s->d_tan);
+    }
+    DevBuf d_uv;
+    if (any_uv) {
+        std::vector<float4> uvs((size_t)n_prims * 2, make_float4(0, 0, 0, 0));
+        parallel_for(n_prims, [&](size_t k0, size_t k1) {
+            for (size_t k = k0; k < k1; ++k) {
+                const HostPrim& p = s->prims[s->bvh.order[k]];
+                if (p.kind == 0 && p.has_uv) {
+                    uvs[2 * k] = make_float4(p.uv[0], p.uv[1], p.uv[2], p.uv[3]);
+                    uvs[2 * k + 1] = make_float4(p.uv[4], p.uv[5], 1.0f, 0.0f);
+                }
+            }
+        });
+        if (int rc = upload(ctx, d_uv, uvs.data(), uvs.size() * sizeof(float4))) {
+            release(d_uv);
+            return rc;
+        }
+    }
     {  // the shading kernels' interleaved view (th_scene.h): one 128-byte line per slot, put together on the device from the two arrays just uploaded
-        if (int rc = ensure(ctx, s->d_shade, (size_t)n_prims * 8 * sizeof(float4))) return rc;
-        hipLaunchKernelGGL(k_shade_constants, dim3(std::max(1u, std::min((n_prims + kBlock - 1) / kBlock, 4096u))), dim3(kBlock), 0, ctx->stream, (float4*)s->d_shade.p, (const float4*)s->d_prims.p, (const float4*)s->d_nrm.p, n_prims);
-        HIP_TRY(ctx, hipGetLastError());
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (int rc = ensure(ctx, s->d_shade, (size_t)n_prims * 8 * sizeof(float4))) {
+            release(d_uv);
+            return rc;
+        }
+        hipLaunchKernelGGL(k_shade_constants, dim3(std::max(1u, std::min((n_prims + kBlock - 1) / kBlock, 4096u))), dim3(kBlock), 0, ctx->stream, (float4*)s->d_shade.p, (const float4*)s->d_prims.p, (const float4*)s->d_nrm.p, (const float4*)d_uv.p, n_prims);
+        const hipError_t e1 = hipGetLastError(), e2 = hipStreamSynchronize(ctx->stream);
+        release(d_uv);
+        HIP_TRY(ctx, e1);
+        HIP_TRY(ctx, e2);
     }
     clk.tick("upload: shade records");
     if (int rc = upload(ctx, s->d_spheres, s->spheres.data(), s->spheres.size() * sizeof(SphereRec))) return rc;
@@ -549,6 +593,7 @@ void trhip_scene_free(trhip_scene* s) {
     release(s->d_nodes);
     release(s->d_prims);
     release(s->d_nrm);
+    release(s->d_tan);
     release(s->d_shade);
     release(s->d_leaf_order);
     release(s->d_spheres);
@@ -573,6 +618,10 @@ int trhip_scene_add_material(trhip_scene* s, int kind, const float* params, int 
 }
 int trhip_scene_add_triangles(trhip_scene* s, const float* xyz, uint32_t n_verts, const uint32_t* idx, uint32_t n_tris, const float* normals, const uint32_t* mat, int flip,
                               uint32_t* first_out) {
+    return trhip_scene_add_triangles_ex(s, xyz, n_verts, idx, n_tris, normals, nullptr, nullptr, mat, flip, first_out);
+}
+int trhip_scene_add_triangles_ex(trhip_scene* s, const float* xyz, uint32_t n_verts, const uint32_t* idx, uint32_t n_tris, const float* normals, const float* tangents, const float* uv,
+                                 const uint32_t* mat, int flip, uint32_t* first_out) {
     if (!s || !xyz || !idx) return fail(s ? s->ctx : nullptr, TRHIP_ERR_INVALID, "null argument");
     const uint32_t first = (uint32_t)s->prims.size();
     // validate first (nothing is added when an index or a material is out of range), then fill the records on all cores
@@ -608,13 +657,18 @@ int trhip_scene_add_triangles(trhip_scene* s, const float* xyz, uint32_t n_verts
                 const uint32_t vi = idx[3 * k + j];
                 std::memcpy(&p.v[3 * j], &xyz[3 * (size_t)(vi - 1)], 3 * sizeof(float));
                 if (normals) std::memcpy(&p.n[3 * j], &normals[3 * (size_t)(vi - 1)], 3 * sizeof(float));
+                if (tangents) std::memcpy(&p.tg[3 * j], &tangents[3 * (size_t)(vi - 1)], 3 * sizeof(float));
+            }
+            if (uv) {  // mesh.uv[t.i + j]: by corner position, not through the indices (triangle_mesh.jl:82)
+                std::memcpy(p.uv, &uv[6 * k], 6 * sizeof(float));
+                p.has_uv = 1;
             }
             const uint32_t m = mat ? mat[k] : PRIM_NO_MATERIAL;
             // is_degenerate (triangle_mesh.jl:65-68) depends on the triangle alone: evaluated here, once, in the kernels' arithmetic
             const f3 tv0 = mk3(p.v[0], p.v[1], p.v[2]), tv1 = mk3(p.v[3], p.v[4], p.v[5]), tv2 = mk3(p.v[6], p.v[7], p.v[8]);
             const f3 tn = cross(tv2 - tv0, tv1 - tv0);
             const bool degenerate = dot(tn, tn) == 0.0f;
-            p.meta = (m & PRIM_MATERIAL_MASK) | (normals ? PRIM_HAS_NORMALS : 0u) | (flip ? PRIM_FLIP : 0u) | (degenerate ? PRIM_DEGENERATE : 0u);
+            p.meta = (m & PRIM_MATERIAL_MASK) | (normals ? PRIM_HAS_NORMALS : 0u) | (tangents ? PRIM_HAS_TANGENTS : 0u) | (flip ? PRIM_FLIP : 0u) | (degenerate ? PRIM_DEGENERATE : 0u);
             s->prims[(size_t)first + k] = p;
         }
     });
