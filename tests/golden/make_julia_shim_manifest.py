@@ -41,7 +41,8 @@ class DryReplay(jr.ShimReplay):
 def scenes(T):
     nested_inner = T.BVHAccel(T.scenes.cornell_primitives()[0][:6], 1)
     nested = T.Scene(T.scenes.cornell_lights(), T.BVHAccel([nested_inner] + T.scenes.cornell_primitives()[0][6:], 1))
-    return {"shadows": T.scenes.shadows_scene(), "caustic_glass_ply": T.scenes.caustic_scene(os.path.join(HERE, "caustic-glass.ply")), "nested_bvh_cornell": nested}
+    return {"shadows": T.scenes.shadows_scene(), "caustic_glass_ply": T.scenes.caustic_scene(os.path.join(HERE, "caustic-glass.ply")), "nested_bvh_cornell": nested,
+            "tangent_uv_mesh": jr.tangent_uv_scene(T)}
 
 
 if __name__ == "__main__":

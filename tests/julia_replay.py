@@ -241,17 +241,25 @@ class ShimReplay:
                 mesh = shape.mesh
                 core = mesh.core
                 flip = int(core.reverse_orientation != core.transform_swaps_handedness)
-                j, idx, mats = i, [], []
+                j, idx, mats, uvc = i, [], [], []
                 tri_idx = mesh.indices.reshape(-1, 3)
+                mesh_uv, mesh_tan = getattr(mesh, "uv", None), getattr(mesh, "tangents", None)
                 while j < len(prims) and isinstance(prims[j].shape, T.Triangle) and prims[j].shape.mesh is mesh:
                     idx.append(tri_idx[prims[j].shape.k])
                     mats.append(material_id(prims[j].material))
+                    if mesh_uv is not None:  # mesh.uv[t.i + c], by corner position
+                        uvc.append(mesh_uv[3 * prims[j].shape.k:3 * prims[j].shape.k + 3])
                     j += 1
                 idx = np.ascontiguousarray(np.array(idx, np.uint32).reshape(-1))
                 mats = np.array(mats, np.uint32)
                 verts = np.ascontiguousarray(mesh.vertices, np.float32).reshape(-1)
                 nrm = None if mesh.normals is None else np.ascontiguousarray(mesh.normals, np.float32).reshape(-1)
-                self.call("trhip_scene_add_triangles", s, verts, mesh.vertices.shape[0], idx, mats.size, nrm, mats, flip, None)
+                if mesh_uv is None and mesh_tan is None:
+                    self.call("trhip_scene_add_triangles", s, verts, mesh.vertices.shape[0], idx, mats.size, nrm, mats, flip, None)
+                else:
+                    tang = None if mesh_tan is None else np.ascontiguousarray(mesh_tan, np.float32).reshape(-1)
+                    uvs = None if mesh_uv is None else np.ascontiguousarray(np.array(uvc, np.float32).reshape(-1))
+                    self.call("trhip_scene_add_triangles_ex", s, verts, mesh.vertices.shape[0], idx, mats.size, nrm, tang, uvs, mats, flip, None)
                 i = j
             else:
                 raise RuntimeError(f"unsupported shape {type(shape).__name__}")
@@ -305,3 +313,17 @@ class ShimReplay:
             else:
                 out.append([rec[0], 1, rec[1:]])
         return out
+
+
+def tangent_uv_scene(T):
+    """The Cornell box with a small height field whose TriangleMesh carries tangents and (u, v)s (shapes/triangle_mesh.jl:11-14): what makes
+    TraceHIP.flatten take trhip_scene_add_triangles_ex.  One GeometricPrimitive per Triangle, as the reference holds them."""
+    prims, _ = T.scenes.cornell_primitives()
+    verts, idx, nrm = T.scenes.heightfield_mesh(6, 99)
+    rng = np.random.default_rng(5)
+    n_tris = idx.size // 3
+    tang = rng.normal(size=(verts.shape[0], 3)).astype(np.float32)
+    uv = rng.random((3 * n_tris, 2)).astype(np.float32)
+    plastic = T.PlasticMaterial(T.ConstantTexture(T.RGBSpectrum(0.5, 0.4, 0.3)), T.ConstantTexture(T.RGBSpectrum(0.4)), T.ConstantTexture(0.08), True)
+    tris = T.create_triangle_mesh(T.ShapeCore(T.translate([0, 0, 0]), False), n_tris, idx, verts.shape[0], verts, nrm, tang, uv)
+    return T.Scene(T.scenes.cornell_lights(), T.BVHAccel(prims + [T.GeometricPrimitive(t, plastic) for t in tris], 1))

@@ -29,12 +29,14 @@ def nested_cornell(T):
     return T.Scene(T.scenes.cornell_lights(), T.BVHAccel([T.BVHAccel(prims[:6], 1)] + prims[6:], 1))
 
 
-@pytest.mark.parametrize("name", ["shadows", "caustic_glass_ply", "nested_bvh_cornell"])
+@pytest.mark.parametrize("name", ["shadows", "caustic_glass_ply", "nested_bvh_cornell", "tangent_uv_mesh"])
 def test_replayed_shim_equals_python_host(T, ctx, manifest, name):
     if name == "shadows":
         scene, cam, entry, host = T.scenes.shadows_scene(), T.scenes.shadows_camera(64), "trhip_render_whitted", T.WhittedIntegrator
     elif name == "caustic_glass_ply":  # the reference's 88 064-triangle mesh: the case the old per-triangle marshalling could not carry
         scene, cam, entry, host = T.scenes.caustic_scene(os.path.join(GOLDEN, "caustic-glass.ply")), T.scenes.caustic_camera(64), "trhip_render_path", T.PathIntegrator
+    elif name == "tangent_uv_mesh":  # a mesh with tangents and (u, v)s: trhip_scene_add_triangles_ex
+        scene, cam, entry, host = jr.tangent_uv_scene(T), T.scenes.cornell_camera(64), "trhip_render_path", T.PathIntegrator
     else:  # a BVHAccel as a primitive of another (test/test_intersection.jl:137-138)
         scene, cam, entry, host = nested_cornell(T), T.scenes.cornell_camera(64), "trhip_render_path", T.PathIntegrator
     r = jr.ShimReplay(T, T._ffi.LIB_PATH, ctx._h)
@@ -45,6 +47,8 @@ def test_replayed_shim_equals_python_host(T, ctx, manifest, name):
     assert seq[flat_end - 1][0] == ("trhip_scene_commit" if name == "nested_bvh_cornell" else "trhip_scene_set_bvh")
     assert seq[:flat_end] == manifest["sequences"][name], "the call sequence differs from tests/golden/julia_shim_calls.json"
     assert [c[0] for c in seq[flat_end:]] == [entry, "trhip_scene_free"]
+    if name == "tangent_uv_mesh":
+        assert sum(c[0] == "trhip_scene_add_triangles_ex" for c in seq) >= 1  # one per run of the mesh's triangles in the order of Trace.jl's tree
     if name == "caustic_glass_ply":
         tri_calls = [c for c in seq if c[0] == "trhip_scene_add_triangles"]
         assert any(c[1] == 1 and "float32[132102]" in c[2] and "uint32[264192]" in c[2] for c in tri_calls)  # the whole mesh in ONE call

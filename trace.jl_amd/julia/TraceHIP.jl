@@ -141,24 +141,35 @@ function flatten(scene::Trace.Scene)
             # triangle_mesh.jl:45-58): the mesh's vertex / normal arrays cross the boundary once, with the run's index triples and
             # per-triangle materials — what trace.jl_amd/api.py does for the same object graph.
             mesh = shape.mesh
-            (mesh.uv === nothing && mesh.tangents === nothing) ||
-                error("TraceHIP: TriangleMesh.uv / .tangents are not carried across the C ABI (no scene of the reference sets them)")
             flip = shape.core.reverse_orientation ⊻ shape.core.transform_swaps_handedness
             j = i
             idx = UInt32[]
             mats = UInt32[]
+            uvc = Float32[]   # the run's corner (u, v)s: Trace.jl reads mesh.uv[t.i + j], by corner position (triangle_mesh.jl:82)
             while j <= length(prims) && prims[j].shape isa Trace.Triangle && prims[j].shape.mesh === mesh &&
                   (prims[j].shape.core.reverse_orientation ⊻ prims[j].shape.core.transform_swaps_handedness) == flip
                 t = prims[j].shape
                 append!(idx, (mesh.indices[t.i], mesh.indices[t.i+1], mesh.indices[t.i+2]))   # 1-based, as the ABI wants them
                 push!(mats, material_id(prims[j].material))
+                if mesh.uv !== nothing
+                    for c in 0:2
+                        append!(uvc, (mesh.uv[t.i+c][1], mesh.uv[t.i+c][2]))
+                    end
+                end
                 j += 1
             end
             verts = collect(reinterpret(Float32, mesh.vertices))          # already world space (triangle_mesh.jl:23)
             nrm = mesh.normals === nothing ? C_NULL : collect(reinterpret(Float32, mesh.normals))
-            check(ccall((:trhip_scene_add_triangles, LIB), Cint,
-                (Ptr{Cvoid}, Ptr{Float32}, UInt32, Ptr{UInt32}, UInt32, Ptr{Float32}, Ptr{UInt32}, Cint, Ptr{UInt32}),
-                s, verts, mesh.n_vertices, idx, length(mats), nrm, mats, flip, C_NULL))
+            if mesh.uv === nothing && mesh.tangents === nothing
+                check(ccall((:trhip_scene_add_triangles, LIB), Cint,
+                    (Ptr{Cvoid}, Ptr{Float32}, UInt32, Ptr{UInt32}, UInt32, Ptr{Float32}, Ptr{UInt32}, Cint, Ptr{UInt32}),
+                    s, verts, mesh.n_vertices, idx, length(mats), nrm, mats, flip, C_NULL))
+            else
+                tang = mesh.tangents === nothing ? C_NULL : collect(reinterpret(Float32, mesh.tangents))   # per vertex, untransformed (:27)
+                check(ccall((:trhip_scene_add_triangles_ex, LIB), Cint,
+                    (Ptr{Cvoid}, Ptr{Float32}, UInt32, Ptr{UInt32}, UInt32, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Ptr{UInt32}, Cint, Ptr{UInt32}),
+                    s, verts, mesh.n_vertices, idx, length(mats), nrm, tang, mesh.uv === nothing ? C_NULL : uvc, mats, flip, C_NULL))
+            end
             i = j
         else
             error("TraceHIP: unsupported shape $(typeof(shape))")
