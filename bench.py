@@ -96,7 +96,9 @@ def pmc_child_runs(args, kernel_prefix: str, want_any: bool, passes):
         try:
             res = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=900)
             if res.returncode != 0:
-                raise RuntimeError(f"rc {res.returncode}: " + res.stderr.decode(errors="replace")[-600:])
+                err = res.stderr.decode(errors="replace")
+                keep = [l for l in err.splitlines() if any(k in l for k in ("rror", "Traceback", "trhip", "HIP", "assert", "File \""))]
+                raise RuntimeError(f"rc {res.returncode}: " + " | ".join(keep[-12:])[-1500:])
             files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
             acc, n = {}, {}
             for r in csv.DictReader(open(files[0])):
@@ -523,17 +525,7 @@ def main():
             if sv.fallback_rays or int(sv.traversal) == 7:
                 roofline["fallback_rays_per_step"] = int(agg["fallback"] / steps)
                 roofline["fallback_fraction_of_closest_rays"] = round(agg["fallback"] / max(1, agg["closest"]), 5)
-            if world == 1 and not args.no_traffic:
-                traffic, valu = measure_counters(args, kprefix, False)
-                roofline["traffic_note"] = ("bytes per launch = fetch_factor x FETCH_SIZE + WRITE_SIZE (rocprofv3 --pmc, separate child runs of this command with --steps 1); fetch_factor: "
-                                            "MI355X_MICROARCH.md's gfx950 correction, re-measured for this kernel's access pattern by tools/calib/fetch_calib.hip")
-                if traffic:
-                    roofline["traffic"] = traffic["bytes"]
-                    roofline["traffic_detail"] = traffic
-                    roofline["achieved_counters"] = round(roofline["traffic"] / (dom_ms * 1e-3) / 1e9, 2)
-                    roofline["frac_counters"] = round(roofline["achieved_counters"] / HBM_PEAK_GBS, 5)
-                if valu:
-                    roofline["valu"] = valu
+            want_counters = world == 1 and not args.no_traffic  # measured last (below): the child runs need the HBM this process holds
             roofline["bound"] = classify_bound(roofline)
             roofline["bound_note"] = ("from counters: VALU busy >= 80 % -> valu-issue (lanes per VALU instruction in `valu`); else HBM-side bytes >= 60 % of peak -> hbm; else latency. "
                                       "`frac` stays SURVEY 8(d)'s algorithmic-bytes figure against the HBM peak")
@@ -565,6 +557,24 @@ def main():
                    "Msample_per_s": round(cst.camera_samples / dt / 1e6, 4)}
         if world == 1 and not args.no_micro:
             micro = micro_benchmark(args, T, ctx, flat, osc if not args.no_cpu_baseline else None)
+        rccl_ranks = ctx.comm_rank()[1]
+        if roofline and want_counters:
+            # the PMC child runs render the same workload in their own process: this one's wavefront buffers are sized to what was free (0.85 of HBM for a
+            # 4096^2 frame) and would leave them nothing — release the scene and the context first
+            flat.free()
+            scene._flat = None
+            ctx.close()
+            traffic, valu = measure_counters(args, kprefix, False)
+            roofline["traffic_note"] = ("bytes per launch = fetch_factor x FETCH_SIZE + WRITE_SIZE (rocprofv3 --pmc, separate child runs of this command with --steps 1); fetch_factor: "
+                                        "MI355X_MICROARCH.md's gfx950 correction, re-measured for this kernel's access pattern by tools/calib/fetch_calib.hip")
+            if traffic:
+                roofline["traffic"] = traffic["bytes"]
+                roofline["traffic_detail"] = traffic
+                roofline["achieved_counters"] = round(roofline["traffic"] / (dom_ms * 1e-3) / 1e9, 2)
+                roofline["frac_counters"] = round(roofline["achieved_counters"] / HBM_PEAK_GBS, 5)
+            if valu:
+                roofline["valu"] = valu
+            roofline["bound"] = classify_bound(roofline)
         spp_r = shard(args.scaling)[0]
         result = {
             "metric": "Mray/s (all bounces)", "value": round(total_rays / elapsed / 1e6, 2), "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -575,7 +585,7 @@ def main():
                        "rays_per_step": int(total_rays / args.steps), "samples_per_step": int(total_samples / args.steps), "bvh_build_upload_s": round(t_build, 3),
                        "traversal": int(sv.traversal),
                        "parallelism": f"sample-index sharding x{world} + film sum-reduce over RCCL (trhip_film_reduce)" if world > 1 else "single GPU",
-                       "rccl_ranks": ctx.comm_rank()[1], "film_reduce_ms_per_step": round(agg["film_reduce_ms_per_step"], 3) if world > 1 else 0.0},
+                       "rccl_ranks": rccl_ranks, "film_reduce_ms_per_step": round(agg["film_reduce_ms_per_step"], 3) if world > 1 else 0.0},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         if micro:

@@ -89,6 +89,7 @@ struct trhip_ctx {
     int traversal = 3;  // 1 = literal accel/bvh.jl loop, 2 = children-in-parent nodes + per-lane ray replacement, 3 = 2 with leaves postponed (while-while),
                         // 4 = 8-wide quantised nodes in the binary walk's order (th_trace8.h; scenes / rays it cannot take run 3), 6 = 3 with two rays per lane (th_trace4.h),
                         // 7 = closest-hit rays front to back with tie detection, flagged rays re-traced by 3 (th_trace7.h); any-hit rays as 3
+    bool trace3_spec = true;   // k_trace3 (closest-hit): lanes park the leaf they reach and go on descending (th_trace2.h, TH_TRACE3_SPEC); 0 = wait for the leaf phase
     bool trace7_cheap = true;  // k_trace7: conservative fma slab test on interior boxes, the reference's exact test once per leaf (th_trace7.h); 0 = exact test on every box
     // workspace (grown on demand, reused across calls)
     DevBuf q[2][3], sq[3], hits, Lbuf, pfilm, counters, sensor, table, film, scratch[4], overflow, wh_L, wh_parent, wh_coef, wh_pdf, wh_flags, occl, film_Lt, surv_list, surv_counts;

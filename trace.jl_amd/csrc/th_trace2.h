@@ -61,6 +61,9 @@ struct WideScene {            // device view of the v2 node array
     const uint32_t* leaf_order;  // one-leaf scenes: the order in which any-hit rays test the leaf's primitives (k_any_leaf); null = slot order
     uint32_t leaf_tight;      // every triangle leaf's box is exactly the union of its triangles' boxes (k_trace7's cheap interior test needs it)
     float sphere_lag;         // k_trace7: 64 ulp / (smallest world-space sphere radius), so that lag_s = sphere_lag x D^2 x max |1 / d|; 0 without spheres
+    // k_trace3's postponed leaves (TH_TRACE3_SPEC): only for rays whose t_max cannot go UP, i.e. whose origin lies outside every sphere's (grown) world bound (A.18)
+    uint32_t spec_spheres;    // number of boxes below; 0xffffffff: postponement off (option "trace3_spec" = 0, or more spheres than boxes)
+    float spec_box[8][6];
 };
 
 // The t_max-independent part of bounds.jl:186-206; returns false when the box is certainly missed, otherwise tx_min (to be
@@ -936,6 +939,18 @@ __global__ __launch_bounds__(kBlock, 5) void k_any_occluders(DeviceScene sc, Occ
 #ifndef TH_TRACE3_LEAF_PREFETCH
 #define TH_TRACE3_LEAF_PREFETCH 0
 #endif
+// Postponed leaves (closest-hit): a lane that reaches a leaf parks it (`pend`) and goes on descending instead of idling until the wave's next leaf
+// phase; the leaf phase tests the parked leaf first.  The lane's t_max is then STALE (too large) while it descends: it visits boxes the reference would
+// have culled — never fewer — and whatever leaf it finds there is tested against the clause `tx_min < t_max` again once the parked leaf has been
+// tested (a child's entry distance is never below its parent's, so a leaf under a box the reference culled fails that clause).  The primitives are
+// still tested in the reference's order with the reference's t_max, so the results are the same bit for bit.  Needs t_max to be non-increasing:
+// rays that start inside a sphere's bound (sphere.jl:137-138 returns t1 without looking at t_max, A.18) do not postpone.
+// Measured (round 3, S-mesh, 256 spp; profiles/r3/r3aa_postponed_leaves_ab.txt): exact (the 220 parity / scale / edge tests pass with it), 3 % more boxes per ray
+// (48.8 against 47.2) — and no gain: closest-hit 295.0 ms with the lanes parking, 295.0 ms with the same binary and the option off, 271.4 ms without the code
+// (its three extra live values turn 20 bytes of cold scratch into 100).  The wave's phase schedule already keeps the leaf phase short; compiled out.
+#ifndef TH_TRACE3_SPEC
+#define TH_TRACE3_SPEC 0
+#endif
 #ifdef TH_DIAG_PHASES
 // DIAGNOSTIC build (tools/phase_probe.py): wave cycles and active lanes per phase of k_trace3, summed over the waves of all launches
 static __device__ unsigned long long g_phase[16];
@@ -977,6 +992,10 @@ __global__ __launch_bounds__(kBlock, ANY ? TH_TRACE3_WAVES_ANY : (BIG ? TH_TRACE
     float t_max = 0.0f, slot_w = 0.0f, flag_w = 0.0f;
     bool found = false;
     uint32_t nn = 0, np = 0;
+    constexpr bool SPEC = !ANY && TH_TRACE3_SPEC != 0;
+    uint32_t pend = kRefNone;  // SPEC: the parked leaf (ref | count << 24)
+    float cur_tm = 0.0f;       // SPEC: entry distance of a leaf reached while another one is parked
+    bool spec_ok = false;
 #if TH_TRACE3_LEAF_PREFETCH
     uint32_t pf0 = 0, pf1 = 0;  // landing registers of the leaf prefetch, never read
 #endif
@@ -1034,6 +1053,14 @@ __global__ __launch_bounds__(kBlock, ANY ? TH_TRACE3_WAVES_ANY : (BIG ? TH_TRACE
                         sp = 0;
                         found = false;
                         active = true;
+                        if (SPEC) {
+                            pend = kRefNone;
+                            spec_ok = ws.spec_spheres != 0xffffffffu;
+                            for (uint32_t k = 0; k < 8u; ++k)
+                                if (k < ws.spec_spheres && o.x >= ws.spec_box[k][0] && o.y >= ws.spec_box[k][1] && o.z >= ws.spec_box[k][2] && o.x <= ws.spec_box[k][3] && o.y <= ws.spec_box[k][4] &&
+                                    o.z <= ws.spec_box[k][5])
+                                    spec_ok = false;
+                        }
                         float tmin;
 #ifdef TH_DIAG_RAY_VISITS
                         rn = 0;
@@ -1067,8 +1094,10 @@ __global__ __launch_bounds__(kBlock, ANY ? TH_TRACE3_WAVES_ANY : (BIG ? TH_TRACE
 #endif
             // lanes whose node is done pop their stack — together: the pop section runs only when TH_TRACE3_POP_MIN lanes wait for it (or
             // nobody can take an interior step), instead of in every round for the handful of lanes that happen to need it
-            const bool pop_now = (uint32_t)__popcll(__ballot(active && cur == kRefNone)) >= (uint32_t)TH_TRACE3_POP_MIN || __ballot(active && cur != kRefNone && cur_cnt == 0) == 0ull;
-            if (pop_now && active && cur == kRefNone) {  // pop the next entry whose tx_min is still below t_max (bvh.jl:247-250 with the deferred clause)
+            // SPEC: a lane whose stack is empty while a leaf is parked has nothing to pop: it waits for the leaf phase
+            const bool wants_pop = active && cur == kRefNone && !(SPEC && pend != kRefNone && sp == 0);
+            const bool pop_now = (uint32_t)__popcll(__ballot(wants_pop)) >= (uint32_t)TH_TRACE3_POP_MIN || __ballot(active && cur != kRefNone && cur_cnt == 0) == 0ull;
+            if (pop_now && wants_pop) {  // pop the next entry whose tx_min is still below t_max (bvh.jl:247-250 with the deferred clause)
                 finished = true;
                 while (sp > 0) {
                     sp--;
@@ -1087,9 +1116,16 @@ __global__ __launch_bounds__(kBlock, ANY ? TH_TRACE3_WAVES_ANY : (BIG ? TH_TRACE
                     if (tm < t_max) {
                         cur = enc & 0x00ffffffu;
                         cur_cnt = enc >> 24;
+                        if (SPEC) cur_tm = tm;
                         finished = false;
                         break;
                     }
+                }
+                if (SPEC && pend != kRefNone) finished = false;  // the parked leaf is still to be tested
+                if (SPEC && spec_ok && pend == kRefNone && cur != kRefNone && cur_cnt > 0) {  // a popped leaf: park it, the next pop round goes on
+                    pend = cur | (cur_cnt << 24);
+                    cur = kRefNone;
+                    cur_cnt = 0;
                 }
             }
             if (finished) {  // the ray is done: deliver (as k_trace2)
@@ -1187,15 +1223,22 @@ __global__ __launch_bounds__(kBlock, ANY ? TH_TRACE3_WAVES_ANY : (BIG ? TH_TRACE
                 const bool any_child = go_n | go_f;
                 cur = any_child ? (nxt & 0x00ffffffu) : kRefNone;
                 cur_cnt = any_child ? (nxt >> 24) : 0u;
+                if (SPEC) cur_tm = go_n ? tn : tf;
 #if TH_TRACE3_INLINE_POP
                 if (!any_child && sp > 0) {  // nothing was pushed in this step: the top read above is still the top
                     sp--;
                     if (top_tm < t_max && sp < kStack2Total) {
                         cur = top_enc & 0x00ffffffu;
                         cur_cnt = top_enc >> 24;
+                        if (SPEC) cur_tm = top_tm;
                     }
                 }
 #endif
+                if (SPEC && spec_ok && pend == kRefNone && cur != kRefNone && cur_cnt > 0) {  // reached a leaf: park it and go on (the pop section finds the next node)
+                    pend = cur | (cur_cnt << 24);
+                    cur = kRefNone;
+                    cur_cnt = 0;
+                }
 #if TH_TRACE3_LEAF_PREFETCH
                 // the lane now waits for phase B with a leaf in hand: touch its first primitive's record (48 bytes, possibly across two lines)
                 // so that phase B finds it in the cache.  The loaded words are never read; the asm hides the loads from the compiler, hence
@@ -1212,16 +1255,18 @@ __global__ __launch_bounds__(kBlock, ANY ? TH_TRACE3_WAVES_ANY : (BIG ? TH_TRACE
             ph_cnt[2] += 1ull;
 #endif
             // lanes that can go on without touching a leaf; when few are left, everybody's leaves are tested together
-            const uint32_t n_desc = (uint32_t)__popcll(__ballot(active && cur_cnt == 0));
+            const uint32_t n_desc = (uint32_t)__popcll(__ballot(active && cur_cnt == 0 && !(SPEC && pend != kRefNone && cur == kRefNone && sp == 0)));
             if (n_desc <= (uint32_t)TH_TRACE3_LEAF_WAIT) break;
         }
         // ---- phase B: leaves, primitives in slot order, later equal-t hit wins (bvh.jl:229-237, triangle_mesh.jl:211-214) ----------
 #ifdef TH_DIAG_PHASES
-        const unsigned long long ph_leaf_m = __ballot(active && cur != kRefNone && cur_cnt > 0);
+        const unsigned long long ph_leaf_m = __ballot(active && ((SPEC && pend != kRefNone) || (cur != kRefNone && cur_cnt > 0)));
         const unsigned long long ph_t_leaf = __builtin_readcyclecounter();
 #endif
-        if (active && cur != kRefNone && cur_cnt > 0) {
+        const bool has_pend = SPEC && pend != kRefNone;  // the parked leaf comes first: it was reached first
+        if (active && (has_pend || (cur != kRefNone && cur_cnt > 0))) {
             bool hit_any = false;
+            const uint32_t leaf_ref = has_pend ? (pend & 0x00ffffffu) : cur, leaf_cnt = has_pend ? (pend >> 24) : cur_cnt;
 #if TH_TRACE3_INLINE_POP
             // the stack top, read while the primitives are on their way: the leaf's lanes pop it at the end of this phase, together
             uint32_t top_enc = kRefNone;
@@ -1237,8 +1282,8 @@ __global__ __launch_bounds__(kBlock, ANY ? TH_TRACE3_WAVES_ANY : (BIG ? TH_TRACE
                 }
             }
 #endif
-            for (uint32_t k = 0; k < cur_cnt; ++k) {
-                const uint32_t slot = cur + k;
+            for (uint32_t k = 0; k < leaf_cnt; ++k) {
+                const uint32_t slot = leaf_ref + k;
                 const float4 p0 = sc.prims[3 * slot];
                 const float4 p1 = sc.prims[3 * slot + 1], p2 = sc.prims[3 * slot + 2];
 #if TH_TRACE3_LEAF_BURST
@@ -1284,18 +1329,37 @@ __global__ __launch_bounds__(kBlock, ANY ? TH_TRACE3_WAVES_ANY : (BIG ? TH_TRACE
                     }
                 }
             }
-            cur = kRefNone;
-            cur_cnt = 0;
+            bool keep_cur = false;
+            if (has_pend) {
+                pend = kRefNone;
+                if (cur != kRefNone && cur_cnt > 0) {
+                    // the lane also holds a leaf it reached while this one was parked, i.e. with a stale t_max: its clause again (bvh.jl:226), against the
+                    // t_max the reference has at this point; if it stands the leaf is parked in turn (first in line) and the lane goes on
+                    if (cur_tm < t_max) pend = cur | (cur_cnt << 24);
+                } else if (cur != kRefNone) {
+                    keep_cur = true;  // an interior node the lane was about to step into: it stays
+                }
+            }
+            if (!keep_cur) {
+                cur = kRefNone;
+                cur_cnt = 0;
+            }
             if (ANY && hit_any) {  // intersect_p returns at the first accepted primitive: drop the stack, the pop in phase A delivers
                 found = true;
                 sp = 0;
             }
 #if TH_TRACE3_INLINE_POP
-            else if (sp > 0) {  // the next stack entry, against the t_max the leaf left (bvh.jl:226 at pop time); a dead one is dropped, phase A goes on from there
+            else if (!keep_cur && sp > 0) {  // the next stack entry, against the t_max the leaf left (bvh.jl:226 at pop time); a dead one is dropped, phase A goes on from there
                 sp--;
                 if (top_tm < t_max && sp < kStack2Total) {
                     cur = top_enc & 0x00ffffffu;
                     cur_cnt = top_enc >> 24;
+                    if (SPEC) cur_tm = top_tm;
+                    if (SPEC && spec_ok && pend == kRefNone && cur_cnt > 0) {  // a leaf again: park it
+                        pend = cur | (cur_cnt << 24);
+                        cur = kRefNone;
+                        cur_cnt = 0;
+                    }
                 }
             }
 #endif

@@ -17,6 +17,20 @@ int ensure_overflow(trhip_ctx* ctx) {
 WideScene wide_view(const trhip_ctx* ctx, const trhip_scene* sc) {
     WideScene w = sc->wide;
     w.tight_scale = ctx->slab_margin_log2 > 0 ? std::ldexp(1.0f, -ctx->slab_margin_log2) : 0.0f;
+    // k_trace3's postponed leaves need a non-increasing t_max: the rays that can see it raised start inside (or on) a sphere (A.18) — inside its world bound
+    // grown by a thousandth of its size
+    w.spec_spheres = 0xffffffffu;
+    if (ctx->trace3_spec && sc->sphere_bounds.size() <= 8) {
+        w.spec_spheres = (uint32_t)sc->sphere_bounds.size();
+        for (size_t k = 0; k < sc->sphere_bounds.size(); ++k) {
+            const HostAABB& b = sc->sphere_bounds[k];
+            for (int a = 0; a < 3; ++a) {
+                const float grow = 1e-3f * (b.mx[a] - b.mn[a]) + 1e-6f * std::fmax(std::fabs(b.mn[a]), std::fabs(b.mx[a])) + 1e-30f;
+                w.spec_box[k][a] = b.mn[a] - grow;
+                w.spec_box[k][3 + a] = b.mx[a] + grow;
+            }
+        }
+    }
     return w;
 }
 
