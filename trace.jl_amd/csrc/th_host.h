@@ -10,6 +10,7 @@
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -131,6 +132,7 @@ struct trhip_scene {
     trhip_ctx* ctx = nullptr;
     std::vector<MaterialRec> materials;
     std::vector<HostPrim> prims;  // caller order
+    bool has_materialless_prim = false;  // set at commit: some GeometricPrimitive has no material (the integrators refuse such a scene; the trace entry points accept it)
     std::vector<SphereRec> spheres;
     std::vector<HostAABB> sphere_bounds;
     std::vector<LightRec> lights;
@@ -215,6 +217,17 @@ inline int grid_for(const trhip_ctx* ctx, uint64_t n, int blocks_per_cu) {
     return (int)std::max<uint64_t>(1, std::min(need, cap));
 }
 
+// TRHIP_FRAME_TIMING=1: host-side time between the stages of a render call, one line per stage on stderr
+struct HostClock {
+    bool on = std::getenv("TRHIP_FRAME_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void tick(const char* what) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[frame] %-32s %8.1f us\n", what, std::chrono::duration<double, std::micro>(now - t).count());
+        t = now;
+    }
+};
 struct Timer {
     trhip_ctx* ctx;
     bool on;

@@ -332,13 +332,13 @@ int render_stream_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sen
 // the range and whether the film gather starts from zero or adds onto the bands before (th_scene.h).
 int render_impl_band(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sensor* sensor, int integrator, uint32_t spp, int max_depth, uint64_t seed, uint32_t sample_offset, void* out,
                      bool out_is_device, trhip_stats* stats, const DeviceSensor* band) {
+    HostClock hclk;
     if (!ctx || !scene || !sensor || !out) return fail(ctx, TRHIP_ERR_INVALID, "null argument");
     if (!scene->committed) return fail(ctx, TRHIP_ERR_INVALID, "scene not committed");
     if (integrator != 0 && integrator != 1) return fail(ctx, TRHIP_ERR_INVALID, "unknown integrator %d", integrator);
     // A GeometricPrimitive without a material makes the reference re-spawn the ray behind the hit without counting a bounce
     // (sppm.jl:219-222; Whitted calls a method that does not exist, sampler.jl:77-80).  The wavefront does not model that.
-    for (const HostPrim& hp : scene->prims)
-        if ((hp.meta & PRIM_MATERIAL_MASK) == PRIM_NO_MATERIAL)
+    if (scene->has_materialless_prim)  // found once, at commit: walking a million host records here cost 2.8 ms of every frame
             return fail(ctx, TRHIP_ERR_UNSUPPORTED, "rendering a scene with a material-less primitive is not supported (the trace entry points accept it)");
     if (spp == 0 || max_depth < 1 || max_depth > kMaxDepth) return fail(ctx, TRHIP_ERR_INVALID, "spp must be >= 1 and max_depth in 1..%d", kMaxDepth);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -465,6 +465,7 @@ int render_impl_band(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
     const DeviceSensor* dsp = (const DeviceSensor*)ctx->sensor.p;
     float4* L = (float4*)ctx->Lbuf.p;
 
+    hclk.tick("setup (budget, buffers)");
     Timer tm(ctx, ctx->timing && stats);
     hipEvent_t e0, e1, ev_start;
     HIP_TRY(ctx, hipEventCreate(&e0));
@@ -540,7 +541,9 @@ int render_impl_band(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
     tm.end(4, st);
     HIP_TRY(ctx, hipEventRecord(e1, st));
     HIP_TRY(ctx, hipGetLastError());
+    hclk.tick("enqueue");
     HIP_TRY(ctx, hipStreamSynchronize(st));
+    hclk.tick("stream sync");
     ctx->last_L_count = total_slots;
     if (!out_is_device) HIP_TRY(ctx, hipMemcpy(out, d_film, film_bytes, hipMemcpyDeviceToHost));
     if (stats) {
@@ -570,6 +573,7 @@ int render_impl_band(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
         stats->max_depth_reached = (uint32_t)max_depth;
         traversal_info(ctx, scene, &stats->traversal, &stats->node_bytes);
     }
+    hclk.tick("counters + event times");
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     (void)hipEventDestroy(ev_start);

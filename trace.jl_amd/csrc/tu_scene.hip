@@ -228,10 +228,11 @@ int upload_scene(trhip_scene* s) {
     clk.tick("upload: 3 copies");
     // the two optional mesh arrays (no scene of the reference sets them): tangents stay resident for the shading kernels, (u, v)s only feed k_shade_constants
     bool any_tan = false, any_uv = false;
+    s->has_materialless_prim = false;
     for (const HostPrim& p : s->prims) {
         any_tan = any_tan || (p.kind == 0 && (p.meta & PRIM_HAS_TANGENTS));
         any_uv = any_uv || (p.kind == 0 && p.has_uv);
-        if (any_tan && any_uv) break;
+        s->has_materialless_prim = s->has_materialless_prim || (p.meta & PRIM_MATERIAL_MASK) == PRIM_NO_MATERIAL;
     }
     s->dev.tri_tan = nullptr;
     if (any_tan) {

@@ -17,8 +17,7 @@ int render_sppm_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
     if (ds.film_w <= 0 || ds.film_h <= 0) return fail(ctx, TRHIP_ERR_INVALID, "empty film");
     if (ds.crop_min[0] != 1.0f || ds.crop_min[1] != 1.0f)
         return fail(ctx, TRHIP_ERR_UNSUPPORTED, "SPPM needs a film whose crop starts at pixel (1, 1): sppm.jl:203 indexes pixels[y, x] with raster coordinates");
-    for (const HostPrim& hp : scene->prims)
-        if ((hp.meta & PRIM_MATERIAL_MASK) == PRIM_NO_MATERIAL) return fail(ctx, TRHIP_ERR_UNSUPPORTED, "SPPM: primitives without a material are not supported on the device");
+    if (scene->has_materialless_prim) return fail(ctx, TRHIP_ERR_UNSUPPORTED, "SPPM: primitives without a material are not supported on the device");
     const uint32_t W = (uint32_t)ds.film_w, H = (uint32_t)ds.film_h;
     const uint64_t n64 = (uint64_t)W * H;
     if (n64 >= (1ull << 26)) return fail(ctx, TRHIP_ERR_UNSUPPORTED, "SPPM: more than 2^26 film pixels");
