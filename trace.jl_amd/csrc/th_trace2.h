@@ -939,6 +939,9 @@ __global__ __launch_bounds__(kBlock, 5) void k_any_occluders(DeviceScene sc, Occ
 #ifndef TH_TRACE3_LEAF_PREFETCH
 #define TH_TRACE3_LEAF_PREFETCH 0
 #endif
+#ifndef TH_TRACE3_SMALL_CHUNKS
+#define TH_TRACE3_SMALL_CHUNKS 2  // quarter chunks once fewer than this many full chunks per wave of the segment's share are left; 0 = always full chunks
+#endif
 // Postponed leaves (closest-hit): a lane that reaches a leaf parks it (`pend`) and goes on descending instead of idling until the wave's next leaf
 // phase; the leaf phase tests the parked leaf first.  The lane's t_max is then STALE (too large) while it descends: it visits boxes the reference would
 // have culled — never fewer — and whatever leaf it finds there is tested against the clause `tx_min < t_max` again once the parked leaf has been
@@ -1018,13 +1021,23 @@ __global__ __launch_bounds__(kBlock, ANY ? TH_TRACE3_WAVES_ANY : (BIG ? TH_TRACE
                     // an empty segment, or one whose cursor already ran past its count, needs no atomic: the waves that arrive when the queue is
                     // drained (all of them, at the end of every launch) would otherwise queue 32 returning atomics each on the same 32 words
                     const uint32_t cnt = __builtin_amdgcn_readfirstlane(sv.count[wseg]);
-                    uint32_t base = cnt;
-                    if (lane == 0 && cnt != 0u && __hip_atomic_load(&work[wseg * kCtrStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < cnt)
-                        base = atomicAdd(&work[wseg * kCtrStride], (uint32_t)kChunk);
+                    uint32_t base = cnt, take = (uint32_t)kChunk;
+                    if (lane == 0 && cnt != 0u) {
+                        const uint32_t at = __hip_atomic_load(&work[wseg * kCtrStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (at < cnt) {
+                            // towards the end of a segment the waves take a quarter of a chunk: a wave that leaves with the last 256 rays works through four
+                            // generations of them alone while the others idle (≈ 0.4 ms per launch, a tenth of a 32-spp launch: profiles/r3/r3ad_*)
+#if TH_TRACE3_SMALL_CHUNKS
+                            if (cnt - at < (uint32_t)TH_TRACE3_SMALL_CHUNKS * (gthreads >> 6) / (uint32_t)kSeg * (uint32_t)kChunk) take = (uint32_t)kChunk / 4u;
+#endif
+                            base = atomicAdd(&work[wseg * kCtrStride], take);
+                        }
+                    }
                     base = __builtin_amdgcn_readfirstlane(base);
+                    take = __builtin_amdgcn_readfirstlane(take);
                     if (base < cnt) {
                         pool_next = base;
-                        pool_end = min(base + (uint32_t)kChunk, cnt);
+                        pool_end = min(base + take, cnt);
                         dry = 0;
                     } else {
                         pool_next = pool_end = 0;
