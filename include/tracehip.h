@@ -283,7 +283,7 @@ int trhip_film_allreduce(trhip_ctx* ctx, void* d_xyzw, uint64_t n_pixels);
  * "pipelines" (1..8): wavefront batches in flight at once (default 1).
  * "bvh_builder" (-1/0/1/2/3): how trhip_scene_commit builds the BVH: 0 = binned SAH on the host, 1 = linear BVH on the device
  *     (Morton keys, radix sort, Karras hierarchy; 25-35 % more node visits per ray), 3 = the host builder's binned SAH run on the
- *     device (the same tree, 34 ms per million primitives instead of ~170 ms; scenes it cannot take go to the host builder),
+ *     device (the same tree, 18 ms per million primitives instead of ~170 ms; scenes it cannot take go to the host builder),
  *     2 = the reference's own construction node for node (see trhip_scene_commit), -1 (default) = 3 from 64 Ki primitives on,
  *     0 below.  Every one of these trees is a valid BVHAccel: results differ only in exact-t ties.
  * "slab_margin_log2" (0..20, default 14): traversal 2 / 3 add to the reference's box test (bounds.jl:180-200) the two slab

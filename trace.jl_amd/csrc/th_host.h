@@ -64,7 +64,7 @@ struct trhip_ctx {
     int bvh_builder = -1;  // BVHAccel construction: 0 = binned SAH on the host (th_bvh.h), 1 = linear BVH on the device (th_lbvh.h), 3 = the host builder's
                            // binned SAH on the device (th_sahb.h: the same tree), 2 = the reference's own construction node for node (th_bvh_ref.h:
                            // the tree Trace.jl builds, hence its tie-breaks), -1 = automatic: builder 3 from 64 Ki primitives on, builder 0 below and
-                           // for the scenes builder 3 hands back.  Measured (r3): building the tree 34 ms (1 M triangles) / 186 ms (10 M) on the device
+                           // for the scenes builder 3 hands back.  Measured (r3): building the tree 18 ms (1 M triangles) / 53 ms (10 M) on the device
                            // against ~0.17 s / ~1.5 s on the host, commit 0.39 -> 0.26 s and 3.67 -> 2.37 s; the LBVH builds a 25-35 % costlier tree
     bool film_transpose = false;     // film pass on pixel-group-major copies of p_film / L (option "film_transpose"; launch_film)
     bool occluder_pretest = true;    // any-hit rays test the scene's largest triangles before the walk (option "occluder_pretest")

@@ -158,18 +158,40 @@ static __global__ __launch_bounds__(kBlock) void k_sah_bounds(SahBuild b) {
         }
         return;
     }
-    for (uint32_t i = first + threadIdx.x; i < last; i += kBlock) {
-        const uint32_t slot = b.pos_in[i];
-        if (slot == kSahNone) continue;
-        const uint32_t p = b.idx_in[i];
-        for (int a = 0; a < 3; ++a) {
-            const float lo = b.pb[6 * (size_t)p + a], hi = b.pb[6 * (size_t)p + 3 + a], c = b.cen[3 * (size_t)p + a];
-            if (lo == lo) atomicMin(&b.lvl_b[6 * (size_t)slot + a], enc_f32(lo));
-            if (hi == hi) atomicMax(&b.lvl_b[6 * (size_t)slot + 3 + a], enc_f32(hi));
-            if (c == c) {
-                atomicMin(&b.lvl_cb[6 * (size_t)slot + a], enc_f32(c));
-                atomicMax(&b.lvl_cb[6 * (size_t)slot + 3 + a], enc_f32(c));
+    // a block that spans several nodes: a wave's 64 consecutive positions still belong to one, two or three of them (a node of this phase holds more than
+    // kSahSmall = 64 primitives) — one reduction per node present in the wave, 12 atomics each, instead of 12 per primitive
+    for (uint32_t base = first + (threadIdx.x & ~63u); base < last; base += kBlock) {
+        const uint32_t i = base + (threadIdx.x & 63u);
+        const bool in = i < last;
+        const uint32_t slot = in ? b.pos_in[i] : kSahNone;
+        float lo[3] = {kInf, kInf, kInf}, hi[3] = {-kInf, -kInf, -kInf}, c[3] = {0.0f, 0.0f, 0.0f};
+        if (slot != kSahNone) {
+            const uint32_t p = b.idx_in[i];
+            for (int a = 0; a < 3; ++a) {
+                lo[a] = b.pb[6 * (size_t)p + a];
+                hi[a] = b.pb[6 * (size_t)p + 3 + a];
+                c[a] = b.cen[3 * (size_t)p + a];
             }
+        }
+        unsigned long long todo = __ballot(slot != kSahNone);
+        while (todo) {
+            const uint32_t s = (uint32_t)__shfl((int)slot, __ffsll((long long)todo) - 1);
+            const bool mine = slot == s;
+            float r[12];
+            for (int a = 0; a < 3; ++a) {
+                r[a] = wave_min(mine && lo[a] == lo[a] ? lo[a] : kInf);
+                r[3 + a] = wave_max(mine && hi[a] == hi[a] ? hi[a] : -kInf);
+                r[6 + a] = wave_min(mine && c[a] == c[a] ? c[a] : kInf);
+                r[9 + a] = wave_max(mine && c[a] == c[a] ? c[a] : -kInf);
+            }
+            if (lane_id() == 0)
+                for (int a = 0; a < 3; ++a) {
+                    atomicMin(&b.lvl_b[6 * (size_t)s + a], enc_f32(r[a]));
+                    atomicMax(&b.lvl_b[6 * (size_t)s + 3 + a], enc_f32(r[3 + a]));
+                    atomicMin(&b.lvl_cb[6 * (size_t)s + a], enc_f32(r[6 + a]));
+                    atomicMax(&b.lvl_cb[6 * (size_t)s + 3 + a], enc_f32(r[9 + a]));
+                }
+            todo &= ~__ballot(mine);
         }
     }
 }
@@ -218,17 +240,48 @@ static __global__ __launch_bounds__(kBlock) void k_sah_bin(SahBuild b) {
         }
         return;
     }
-    for (uint32_t i = first + threadIdx.x; i < last; i += kBlock) {
-        const uint32_t slot = b.pos_in[i];
-        if (slot == kSahNone) continue;
-        const uint32_t p = b.idx_in[i];
-        float box[6];
-        for (int a = 0; a < 6; ++a) box[a] = b.pb[6 * (size_t)p + a];
-        for (int a = 0; a < 3; ++a) {
-            const float c0 = dec_f32(b.lvl_cb[6 * (size_t)slot + a]), c1 = dec_f32(b.lvl_cb[6 * (size_t)slot + 3 + a]);
-            if (!(c1 > c0)) continue;
-            const float scale = (float)kSahBins / (c1 - c0);
-            sah_bin_add(&b.bins[(size_t)slot * kSahBinWords + (a * kSahBins + sah_bin(b.cen[3 * (size_t)p + a], c0, scale)) * 7], box);
+    // a block that spans several nodes: per wave, one pass per node present in it through the wave's own bins in LDS (see k_sah_bounds)
+    __shared__ uint32_t s_wbins[kBlock / 64][kSahBinWords];
+    uint32_t* wb = s_wbins[threadIdx.x >> 6];
+    const uint32_t lane = lane_id();
+    for (uint32_t base = first + (threadIdx.x & ~63u); base < last; base += kBlock) {
+        const uint32_t i = base + lane;
+        const bool in = i < last;
+        const uint32_t slot = in ? b.pos_in[i] : kSahNone;
+        uint32_t p = 0;
+        float box[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, cen[3] = {0.0f, 0.0f, 0.0f};
+        if (slot != kSahNone) {
+            p = b.idx_in[i];
+            for (int a = 0; a < 6; ++a) box[a] = b.pb[6 * (size_t)p + a];
+            for (int a = 0; a < 3; ++a) cen[a] = b.cen[3 * (size_t)p + a];
+        }
+        unsigned long long todo = __ballot(slot != kSahNone);
+        while (todo) {
+            const uint32_t s = (uint32_t)__shfl((int)slot, __ffsll((long long)todo) - 1);
+            const bool mine = slot == s;
+            for (int w = lane; w < kSahBinWords; w += 64) wb[w] = (w % 7) < 3 ? enc_f32(kInf) : ((w % 7) < 6 ? enc_f32(-kInf) : 0u);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (mine)
+                for (int a = 0; a < 3; ++a) {
+                    const float c0 = dec_f32(b.lvl_cb[6 * (size_t)s + a]), c1 = dec_f32(b.lvl_cb[6 * (size_t)s + 3 + a]);
+                    if (!(c1 > c0)) continue;
+                    const float scale = (float)kSahBins / (c1 - c0);
+                    sah_bin_add(&wb[(a * kSahBins + sah_bin(cen[a], c0, scale)) * 7], box);
+                }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            uint32_t* dst = b.bins + (size_t)s * kSahBinWords;
+            for (int w = lane; w < kSahBinWords; w += 64) {
+                const uint32_t v = wb[w];
+                if ((w % 7) < 3) {
+                    if (v != enc_f32(kInf)) atomicMin(&dst[w], v);
+                } else if ((w % 7) < 6) {
+                    if (v != enc_f32(-kInf)) atomicMax(&dst[w], v);
+                } else if (v) {
+                    atomicAdd(&dst[w], v);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            todo &= ~__ballot(mine);
         }
     }
 }
