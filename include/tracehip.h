@@ -281,6 +281,8 @@ int trhip_film_allreduce(trhip_ctx* ctx, void* d_xyzw, uint64_t n_pixels);
  *     "stream2_priority" (-1/0/1): that stream's priority: lowest (default: the closest-hit rays are the critical path), the
  *     default level, highest; read when the streams are created (first render of a context).
  * "pipelines" (1..8): wavefront batches in flight at once (default 1).
+ * "film_fused" (0/1, default 1): the path integrator's ray generation writes every sample's radiance record in the film pass's own layout, with its splat
+ *     descriptor, so that a frame needs no memset of the records and no pack / re-lay pass before the gather (film.jl:134-164 replaced; same film bit for bit).
  * "bvh_builder" (-1/0/1/2/3): how trhip_scene_commit builds the BVH: 0 = binned SAH on the host, 1 = linear BVH on the device
  *     (Morton keys, radix sort, Karras hierarchy; 25-35 % more node visits per ray), 3 = the host builder's binned SAH run on the
  *     device (the same tree, 18 ms per million primitives instead of ~170 ms; scenes it cannot take go to the host builder),

@@ -90,6 +90,8 @@ struct trhip_ctx {
     int traversal = 3;  // 1 = literal accel/bvh.jl loop, 2 = children-in-parent nodes + per-lane ray replacement, 3 = 2 with leaves postponed (while-while),
                         // 4 = 8-wide quantised nodes in the binary walk's order (th_trace8.h; scenes / rays it cannot take run 3), 6 = 3 with two rays per lane (th_trace4.h),
                         // 7 = closest-hit rays front to back with tie detection, flagged rays re-traced by 3 (th_trace7.h); any-hit rays as 3
+    bool film_fused = true;    // the path integrator's k_raygen writes the radiance records in the film pass's layout with their splat descriptors (no memset, no pack pass; option "film_fused")
+    uint32_t last_L_layout = 0, last_L_npix = 1, last_L_spp = 1;  // how Lbuf is laid out after the last render (trhip_last_sample_radiance)
     bool trace3_spec = true;   // k_trace3 (closest-hit): lanes park the leaf they reach and go on descending (th_trace2.h, TH_TRACE3_SPEC); 0 = wait for the leaf phase
     bool trace7_cheap = true;  // k_trace7: conservative fma slab test on interior boxes, the reference's exact test once per leaf (th_trace7.h); 0 = exact test on every box
     // workspace (grown on demand, reused across calls)
@@ -294,7 +296,7 @@ bool film_uses_desc(const trhip_ctx* ctx, const DeviceSensor& ds);
 bool film_uses_packed(const trhip_ctx* ctx, const DeviceSensor& ds);
 int ensure_film_samples(trhip_ctx* ctx, const DeviceSensor& ds, uint64_t total_slots);
 void launch_film(trhip_ctx* ctx, hipStream_t st, const DeviceSensor& ds, const DeviceSensor* dsp, const float4* L, uint64_t total_slots, uint32_t spp, uint64_t seed, uint32_t sample_offset,
-                 float4* d_film);
+                 float4* d_film, bool fused);
 // tu_whitted.hip
 int render_whitted_impl(trhip_ctx* ctx, const trhip_scene* scene, const DeviceSensor& ds, const trhip_sensor* sensor, uint32_t spp, int max_depth, uint64_t seed, uint32_t sample_offset,
                         void* d_film, trhip_stats* stats, double* ms_total);

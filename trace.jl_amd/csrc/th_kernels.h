@@ -141,6 +141,52 @@ TH_D SlotInfo slot_info(const DeviceSensor& se, uint32_t slot) {
     return r;
 }
 
+// ---- film: where a camera sample's radiance record lives, and its splat descriptor (used by k_raygen and the film pass below) -------
+TH_D size_t film_index(uint32_t layout, uint32_t npix, uint32_t spp, uint32_t s, uint32_t pix) {
+    return layout ? ((size_t)(pix >> 6) * spp + s) * 64u + (pix & 63u) : (size_t)s * npix + pix;
+}
+constexpr uint32_t kFilmPackSide = 0x80000000u;
+constexpr uint32_t kFilmPackOverflow = 0xffffffffu;
+constexpr uint32_t kFilmPackException = 0xffffffffu;  // what film_pack_desc returns for a descriptor that does not fit
+struct FilmSideTable {
+    uint4* desc;
+    uint32_t* count;
+    uint32_t cap;
+};
+TH_D uint32_t film_pack_word(const FilmSideTable& side, uint4 d, int px, int py);
+TH_D uint4 film_splat_desc(const DeviceSensor& se, int px, int py, uint64_t key) {  // the SplatDesc of one camera sample (k_film_descriptors' arithmetic)
+    const float rx = se.filter_radius[0], ry = se.filter_radius[1];
+    const float inv_rx = 1.0f / rx, inv_ry = 1.0f / ry;
+    const float pfx = (float)px + ts_uniform(key, TS_DIM_FILM_X), pfy = (float)py + ts_uniform(key, TS_DIM_FILM_Y);  // camera_sample.film
+    const float dpx = pfx - 0.5f, dpy = pfy - 0.5f;
+    const float p0x = __builtin_ceilf(dpx - rx), p0y = __builtin_ceilf(dpy - ry);
+    const float p1x = __builtin_floorf(dpx + rx) + 1.0f, p1y = __builtin_floorf(dpy + ry) + 1.0f;
+    const int nx = (int)(p1x - p0x) + 1, ny = (int)(p1y - p0y) + 1;
+    uint32_t oxw = 0, oyw = 0;
+    for (int c = 0; c < 8; ++c) {
+        const float X = p0x + (float)c, Y = p0y + (float)c;
+        oxw |= (uint32_t)((int)jclamp(__builtin_ceilf(fabs_((X - dpx) * inv_rx * 16.0f)), 1.0f, 16.0f) - 1) << (4 * c);   // ceil for x …
+        oyw |= (uint32_t)((int)jclamp(__builtin_floorf(fabs_((Y - dpy) * inv_ry * 16.0f)), 1.0f, 16.0f) - 1) << (4 * c);  // … floor for y (A.9)
+    }
+    return make_uint4(((uint32_t)(int)p0x & 0xffffu) | ((uint32_t)(int)p0y << 16), (uint32_t)nx | ((uint32_t)ny << 8), oxw, oyw);
+}
+// 32-bit form: bit 0 / 1 = px - p0x / py - p0y (0 or 1), bits 2-3 / 4-5 = nx - 1 / ny - 1 (0..2), bits 6-17 = table index of columns 0..2, bits 18-29 = rows 0..2
+TH_D uint32_t film_pack_desc(uint4 d, int px, int py) {
+    const int p0x = (int)(short)(d.x & 0xffffu), p0y = (int)(short)(d.x >> 16);
+    const uint32_t nx = d.y & 0xffu, ny = (d.y >> 8) & 0xffu;
+    const int ox = px - p0x, oy = py - p0y;
+    if (ox < 0 || ox > 1 || oy < 0 || oy > 1 || nx < 1u || nx > 3u || ny < 1u || ny > 3u) return kFilmPackException;
+    return (uint32_t)ox | ((uint32_t)oy << 1) | ((nx - 1u) << 2) | ((ny - 1u) << 4) | ((d.z & 0xfffu) << 6) | ((d.w & 0xfffu) << 18);
+}
+TH_D uint32_t film_pack_word(const FilmSideTable& side, uint4 d, int px, int py) {
+    const uint32_t w = film_pack_desc(d, px, py);
+    if (w != kFilmPackException) return w;
+    const uint32_t j = atomicAdd(side.count, 1u);
+    if (j >= side.cap || j >= 0x7fffffffu) return kFilmPackOverflow;
+    side.desc[j] = d;
+    return kFilmPackSide | j;
+}
+
 // ---- camera (camera/perspective.jl:85-114) ----------------------------------------------------------------------------------
 TH_D void generate_ray(const DeviceSensor& se, f2 film, f2 lens, float time_u, f3& o, f3& d, float& time) {
     const f3 p_camera = xf_point(se.raster_to_camera, mk3(film.x, film.y, 0.0f));
@@ -160,13 +206,20 @@ TH_D void generate_ray(const DeviceSensor& se, f2 film, f2 lens, float time_u, f
     d = normalize(d);
 }
 
+// Lf (optional, the path integrator's whole-frame launches): the sample's radiance record is initialised HERE, in the film pass's pixel-group-major layout
+// (film_index layout 1) with the packed splat descriptor in its .w lane, and the path carries that record's index as its slot — the frame then needs neither the
+// memset of L nor the pack / re-lay pass over it before the gather (2.9 ms of a 256-spp frame and a second copy of L)
 static __global__ __launch_bounds__(kBlock) void k_raygen(const DeviceSensor* __restrict__ sep, uint32_t slot0, uint32_t n, uint64_t seed, uint32_t sample_offset,
-                                                   PathQueue q, uint32_t cap, Counters* ctr) {
+                                                   PathQueue q, uint32_t cap, Counters* ctr, float4* __restrict__ Lf = nullptr, uint32_t spp_frame = 0, FilmSideTable side = FilmSideTable{nullptr, nullptr, 0}) {
     const DeviceSensor& se = *sep;
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-        const uint32_t slot = slot0 + i;
+        uint32_t slot = slot0 + i;
         const SlotInfo si = slot_info(se, slot);
         const uint64_t key = ts_stream_key(seed, si.px, si.py, sample_offset + si.sample);
+        if (Lf) {
+            slot = (uint32_t)film_index(1u, (uint32_t)(se.sb_w * se.band_rows), spp_frame, si.sample, si.pix);
+            Lf[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(film_pack_word(side, film_splat_desc(se, si.px, si.py, key), si.px, si.py)));
+        }
         const f2 film{(float)si.px + ts_uniform(key, TS_DIM_FILM_X), (float)si.py + ts_uniform(key, TS_DIM_FILM_Y)};
         const f2 lens{ts_uniform(key, TS_DIM_LENS_X), ts_uniform(key, TS_DIM_LENS_Y)};
         f3 o, d;
@@ -695,9 +748,7 @@ static __global__ __launch_bounds__(kBlock) void k_fill_u32(uint32_t* __restrict
 // stride of npix * 16 bytes (16 MB at 1024²) between consecutive loads — a new page for every one.  launch_film therefore
 // re-lays L (k_film_transpose) and writes p_film pixel-group-major: [group of 64 sample-pixels][s][lane]; consecutive samples
 // are then 1 KB apart and a wave's load is one contiguous chunk as before.  layout 0 = sample-major (option film_transpose 0).
-TH_D size_t film_index(uint32_t layout, uint32_t npix, uint32_t spp, uint32_t s, uint32_t pix) {
-    return layout ? ((size_t)(pix >> 6) * spp + s) * 64u + (pix & 63u) : (size_t)s * npix + pix;
-}
+// film_index: defined with the camera-sample helpers above (k_raygen writes in that layout too)
 static __global__ __launch_bounds__(kBlock) void k_film_transpose(const float4* __restrict__ L, uint32_t npix, uint32_t spp, float4* __restrict__ Lt) {
     const uint32_t groups = (npix + 63u) >> 6;
     const uint64_t chunks = (uint64_t)groups * spp;
@@ -1094,47 +1145,6 @@ __global__ __launch_bounds__(kBlock) void k_film_gather_desc(const DeviceSensor*
 // A sample whose range is 4 wide (or otherwise outside the encoding) keeps its full 16-byte descriptor in a side table: .w = kFilmPackSide | index.  The table
 // holds total / 16 + 65536 entries (the rate is ~2.4e-4 at 1024^2); should it ever run full the word is kFilmPackOverflow and the gather recomputes that
 // sample's descriptor from the sampler — in a cold copy of the loop, so that the hash and the descriptor arithmetic are not inlined into the unrolled hot one.
-constexpr uint32_t kFilmPackSide = 0x80000000u;
-constexpr uint32_t kFilmPackOverflow = 0xffffffffu;
-constexpr uint32_t kFilmPackException = 0xffffffffu;  // what film_pack_desc returns for a descriptor that does not fit
-struct FilmSideTable {
-    uint4* desc;
-    uint32_t* count;
-    uint32_t cap;
-};
-TH_D uint32_t film_pack_word(const FilmSideTable& side, uint4 d, int px, int py);
-TH_D uint4 film_splat_desc(const DeviceSensor& se, int px, int py, uint64_t key) {  // the SplatDesc of one camera sample (k_film_descriptors' arithmetic)
-    const float rx = se.filter_radius[0], ry = se.filter_radius[1];
-    const float inv_rx = 1.0f / rx, inv_ry = 1.0f / ry;
-    const float pfx = (float)px + ts_uniform(key, TS_DIM_FILM_X), pfy = (float)py + ts_uniform(key, TS_DIM_FILM_Y);  // camera_sample.film
-    const float dpx = pfx - 0.5f, dpy = pfy - 0.5f;
-    const float p0x = __builtin_ceilf(dpx - rx), p0y = __builtin_ceilf(dpy - ry);
-    const float p1x = __builtin_floorf(dpx + rx) + 1.0f, p1y = __builtin_floorf(dpy + ry) + 1.0f;
-    const int nx = (int)(p1x - p0x) + 1, ny = (int)(p1y - p0y) + 1;
-    uint32_t oxw = 0, oyw = 0;
-    for (int c = 0; c < 8; ++c) {
-        const float X = p0x + (float)c, Y = p0y + (float)c;
-        oxw |= (uint32_t)((int)jclamp(__builtin_ceilf(fabs_((X - dpx) * inv_rx * 16.0f)), 1.0f, 16.0f) - 1) << (4 * c);   // ceil for x …
-        oyw |= (uint32_t)((int)jclamp(__builtin_floorf(fabs_((Y - dpy) * inv_ry * 16.0f)), 1.0f, 16.0f) - 1) << (4 * c);  // … floor for y (A.9)
-    }
-    return make_uint4(((uint32_t)(int)p0x & 0xffffu) | ((uint32_t)(int)p0y << 16), (uint32_t)nx | ((uint32_t)ny << 8), oxw, oyw);
-}
-// 32-bit form: bit 0 / 1 = px - p0x / py - p0y (0 or 1), bits 2-3 / 4-5 = nx - 1 / ny - 1 (0..2), bits 6-17 = table index of columns 0..2, bits 18-29 = rows 0..2
-TH_D uint32_t film_pack_desc(uint4 d, int px, int py) {
-    const int p0x = (int)(short)(d.x & 0xffffu), p0y = (int)(short)(d.x >> 16);
-    const uint32_t nx = d.y & 0xffu, ny = (d.y >> 8) & 0xffu;
-    const int ox = px - p0x, oy = py - p0y;
-    if (ox < 0 || ox > 1 || oy < 0 || oy > 1 || nx < 1u || nx > 3u || ny < 1u || ny > 3u) return kFilmPackException;
-    return (uint32_t)ox | ((uint32_t)oy << 1) | ((nx - 1u) << 2) | ((ny - 1u) << 4) | ((d.z & 0xfffu) << 6) | ((d.w & 0xfffu) << 18);
-}
-TH_D uint32_t film_pack_word(const FilmSideTable& side, uint4 d, int px, int py) {
-    const uint32_t w = film_pack_desc(d, px, py);
-    if (w != kFilmPackException) return w;
-    const uint32_t j = atomicAdd(side.count, 1u);
-    if (j >= side.cap || j >= 0x7fffffffu) return kFilmPackOverflow;
-    side.desc[j] = d;
-    return kFilmPackSide | j;
-}
 // writes the descriptor into L[slot].w; the other lanes of the record are not touched (4-byte stores)
 static __global__ __launch_bounds__(kBlock) void k_film_pack_w(const DeviceSensor* __restrict__ sep, uint64_t n, uint64_t seed, uint32_t sample_offset, float4* __restrict__ L, FilmSideTable side) {
     const DeviceSensor& se = *sep;
@@ -1566,10 +1576,11 @@ static __global__ void k_bsdf_query(DeviceScene sc, uint32_t material, int multi
     }
 }
 // Per-sample radiance read-back: float4 L -> rgb with the NaN rule of integrators/sampler.jl:46
-static __global__ void k_export_L(const float4* __restrict__ L, uint64_t n, float* __restrict__ out) {
+// layout 1: L is pixel-group-major (film_index; k_raygen's Lf mode); the export is sample-major either way
+static __global__ void k_export_L(const float4* __restrict__ L, uint64_t n, float* __restrict__ out, uint32_t layout = 0, uint32_t npix = 1, uint32_t spp = 1) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float4 l = L[i];
+    const float4 l = L[layout ? film_index(1u, npix, spp, (uint32_t)(i / npix), (uint32_t)(i % npix)) : (size_t)i];
     f3 c = mk3(l.x, l.y, l.z);
     if (has_nan(c)) c = splat3(0.0f);
     out[3 * i] = c.x;

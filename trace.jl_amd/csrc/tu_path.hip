@@ -53,19 +53,36 @@ int ensure_film_samples(trhip_ctx* ctx, const DeviceSensor& ds, uint64_t total_s
     if (film_uses_desc(ctx, ds)) return ensure(ctx, ctx->fdesc, total_slots * sizeof(uint4));
     return ensure(ctx, ctx->pfilm, total_slots * sizeof(float2));
 }
+// can k_raygen write the radiance records in the film pass's layout, descriptors included (th_kernels.h, k_raygen's Lf)?  Whole sample passes of one band, 32-bit indices.
+bool film_fused(const trhip_ctx* ctx, const DeviceSensor& ds, uint32_t spp) {
+    const uint64_t npix_b = (uint64_t)ds.sb_w * ds.band_rows;
+    return ctx->film_fused && ctx->film_relayout && film_uses_packed(ctx, ds) && ((npix_b + 63u) / 64u) * 64u * spp < (1ull << 32);
+}
+FilmSideTable film_side_table(trhip_ctx* ctx, hipStream_t st, uint64_t total_slots, bool* ok) {
+    // side table for the descriptors that do not fit 30 bits (one sample in ~4000 at 1024^2): entry 0 of film_side is the counter, the descriptors follow
+    const uint32_t side_cap = (uint32_t)std::min<uint64_t>(total_slots / 16 + 65536, 0x7ffffff0ull);
+    *ok = ensure(ctx, ctx->film_side, ((size_t)side_cap + 1) * sizeof(uint4)) == 0;
+    if (!*ok) return FilmSideTable{nullptr, nullptr, 0};
+    (void)hipMemsetAsync(ctx->film_side.p, 0, sizeof(uint4), st);
+    return FilmSideTable{(uint4*)ctx->film_side.p + 1, (uint32_t*)ctx->film_side.p, side_cap};
+}
 void launch_film(trhip_ctx* ctx, hipStream_t st, const DeviceSensor& ds, const DeviceSensor* dsp, const float4* L, uint64_t total_slots, uint32_t spp, uint64_t seed, uint32_t sample_offset,
-                 float4* d_film) {
+                 float4* d_film, bool fused) {
     if (film_uses_packed(ctx, ds)) {
         // the descriptors go into the records' .w lanes — on the way into a pixel-group-major copy when there is room for one (option "film_relayout", default on)
         const uint32_t npix_b = (uint32_t)(ds.sb_w * ds.band_rows);
         const uint64_t padded = (uint64_t)((npix_b + 63u) / 64u) * 64u * spp;
         uint32_t layout = 0;
-        // side table for the descriptors that do not fit 30 bits (one sample in ~4000 at 1024^2): entry 0 of film_side is the counter, the descriptors follow
-        const uint32_t side_cap = (uint32_t)std::min<uint64_t>(total_slots / 16 + 65536, 0x7ffffff0ull);
-        if (ensure(ctx, ctx->film_side, ((size_t)side_cap + 1) * sizeof(uint4)) != 0) return;
-        (void)hipMemsetAsync(ctx->film_side.p, 0, sizeof(uint4), st);
-        const FilmSideTable side{(uint4*)ctx->film_side.p + 1, (uint32_t*)ctx->film_side.p, side_cap};
-        if (ctx->film_relayout && total_slots == (uint64_t)npix_b * spp && ensure(ctx, ctx->film_Lt, padded * sizeof(float4)) == 0) {
+        FilmSideTable side{ctx->film_side.p ? (uint4*)ctx->film_side.p + 1 : nullptr, (uint32_t*)ctx->film_side.p, 0};
+        if (fused) {
+            layout = 1;  // k_raygen wrote the records re-laid and with their descriptors (its side table is ctx->film_side, reset before the frame's first launch)
+        } else {
+            bool ok = false;
+            side = film_side_table(ctx, st, total_slots, &ok);
+            if (!ok) return;
+        }
+        if (fused) {
+        } else if (ctx->film_relayout && total_slots == (uint64_t)npix_b * spp && ensure(ctx, ctx->film_Lt, padded * sizeof(float4)) == 0) {
             layout = 1;
             hipLaunchKernelGGL(k_film_pack_transpose, dim3(grid_for(ctx, padded, 8)), dim3(kBlock), 0, st, dsp, npix_b, spp, seed, sample_offset, L, (float4*)ctx->film_Lt.p, side);
             L = (const float4*)ctx->film_Lt.p;
@@ -288,12 +305,13 @@ int render_stream_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sen
     tm.begin(4, st);
     // (no k_apply_poison here: the streaming shade kernel writes its terms — NaN included — straight into the per-depth slots and never notes
     //  poison; ctx->poison belongs to the classic path's two-stream mode alone)
-    launch_film(ctx, st, ds, dsp, L, total_slots, spp, seed, sample_offset, (float4*)d_film);
+    launch_film(ctx, st, ds, dsp, L, total_slots, spp, seed, sample_offset, (float4*)d_film, false);
     tm.end(4, st);
     HIP_TRY(ctx, hipEventRecord(e1, st));
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(st));
     ctx->last_L_count = total_slots;
+    ctx->last_L_layout = 0;
     if (!out_is_device) HIP_TRY(ctx, hipMemcpy(out, d_film, film_bytes, hipMemcpyDeviceToHost));
     uint32_t left[8];
     HIP_TRY(ctx, hipMemcpy(left, lc, sizeof left, hipMemcpyDeviceToHost));
@@ -367,6 +385,7 @@ int render_impl_band(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
         double ms = 0;
         if (int rc = render_whitted_impl(ctx, scene, ds, sensor, spp, max_depth, seed, sample_offset, df, stats, &ms)) return rc;
         ctx->last_L_count = total_slots;
+        ctx->last_L_layout = 0;
         if (!out_is_device) HIP_TRY(ctx, hipMemcpy(out, df, fb, hipMemcpyDeviceToHost));
         if (stats) {
             Counters h;
@@ -452,8 +471,11 @@ int render_impl_band(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
         for (int k = 0; k < 2; ++k)
             if (int rc = ensure(ctx, pp.overflow[k], slab_bytes)) return rc;
     }
-    if (int rc = ensure(ctx, ctx->poison, total_slots)) return rc;
-    if (int rc = ensure(ctx, ctx->Lbuf, total_slots * sizeof(float4))) return rc;
+    // the radiance records: sample-major, or — when k_raygen can initialise them for the film pass (film_fused) — pixel-group-major, padded to whole groups of 64 pixels
+    const bool fused = film_fused(ctx, ds, spp);
+    const uint64_t l_slots = fused ? ((npix + 63u) / 64u) * 64u * (uint64_t)spp : total_slots;
+    if (int rc = ensure(ctx, ctx->poison, l_slots)) return rc;
+    if (int rc = ensure(ctx, ctx->Lbuf, l_slots * sizeof(float4))) return rc;
     if (int rc = ensure_film_samples(ctx, ds, total_slots)) return rc;
     const size_t film_bytes = (size_t)ds.film_w * ds.film_h * sizeof(float4);
     void* d_film = out;
@@ -472,8 +494,15 @@ int render_impl_band(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
     HIP_TRY(ctx, hipEventCreate(&e1));
     HIP_TRY(ctx, hipEventCreateWithFlags(&ev_start, hipEventDisableTiming));
     HIP_TRY(ctx, hipEventRecord(e0, st));
-    HIP_TRY(ctx, hipMemsetAsync(L, 0, total_slots * sizeof(float4), st));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->poison.p, 0, total_slots, st));
+    FilmSideTable fside{nullptr, nullptr, 0};
+    if (fused) {
+        bool ok = false;
+        fside = film_side_table(ctx, st, total_slots, &ok);
+        if (!ok) return TRHIP_ERR_HIP;
+    } else {
+        HIP_TRY(ctx, hipMemsetAsync(L, 0, total_slots * sizeof(float4), st));
+    }
+    HIP_TRY(ctx, hipMemsetAsync(ctx->poison.p, 0, l_slots, st));
     HIP_TRY(ctx, hipEventRecord(ev_start, st));
     const int g_shade = ctx->num_cu * 8;
     const uint32_t bary_mode = (ctx->traversal >= 2 && scene->wide_ok) ? 1u : 0u;  // k_trace2 hands the barycentrics to the shading kernel
@@ -502,7 +531,7 @@ int render_impl_band(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
         float4* hits = (float4*)pp.hits.p;
         HIP_TRY(ctx, hipMemsetAsync(ctr, 0, offsetof(Counters, closest_total), ps));  // queue sizes + work cursors of this batch
         tm.begin(0, ps);
-        hipLaunchKernelGGL(k_raygen, dim3(grid_for(ctx, nb, 8)), dim3(kBlock), 0, ps, dsp, (uint32_t)(s0 * npix), (uint32_t)nb, seed, sample_offset, pq[0], cap, ctr);
+        hipLaunchKernelGGL(k_raygen, dim3(grid_for(ctx, nb, 8)), dim3(kBlock), 0, ps, dsp, (uint32_t)(s0 * npix), (uint32_t)nb, seed, sample_offset, pq[0], cap, ctr, fused ? L : nullptr, spp, fside);
         tm.end(0, ps);
         int cur = 0;
         for (int depth = 1; depth <= max_depth; ++depth) {
@@ -536,9 +565,12 @@ int render_impl_band(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
         HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->pipes[pi].ev_done, 0));
     }
     tm.begin(4, st);
-    if (ctx->overlap) hipLaunchKernelGGL(k_apply_poison, dim3(grid_for(ctx, total_slots, 8)), dim3(kBlock), 0, st, L, (const uint8_t*)ctx->poison.p, total_slots);
-    launch_film(ctx, st, ds, dsp, L, total_slots, spp, seed, sample_offset, (float4*)d_film);
+    if (ctx->overlap) hipLaunchKernelGGL(k_apply_poison, dim3(grid_for(ctx, l_slots, 8)), dim3(kBlock), 0, st, L, (const uint8_t*)ctx->poison.p, l_slots);
+    launch_film(ctx, st, ds, dsp, L, total_slots, spp, seed, sample_offset, (float4*)d_film, fused);
     tm.end(4, st);
+    ctx->last_L_layout = fused ? 1u : 0u;
+    ctx->last_L_npix = (uint32_t)npix;
+    ctx->last_L_spp = spp;
     HIP_TRY(ctx, hipEventRecord(e1, st));
     HIP_TRY(ctx, hipGetLastError());
     hclk.tick("enqueue");
@@ -655,6 +687,7 @@ int render_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sensor* se
         sum.node_bytes = st.node_bytes;
     }
     ctx->last_L_count = 0;  // trhip_last_sample_radiance describes whole frames only
+    ctx->last_L_layout = 0;
     if (!out_is_device) HIP_TRY(ctx, hipMemcpy(out, d_film, film_bytes, hipMemcpyDeviceToHost));
     if (stats) *stats = sum;
     return 0;
@@ -681,7 +714,7 @@ int trhip_last_sample_radiance(trhip_ctx* ctx, float* out, uint64_t n_floats) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (int rc = ensure(ctx, ctx->scratch[0], n_floats * sizeof(float))) return rc;
     const uint64_t n = ctx->last_L_count;
-    if (n) hipLaunchKernelGGL(k_export_L, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const float4*)ctx->Lbuf.p, n, (float*)ctx->scratch[0].p);
+    if (n) hipLaunchKernelGGL(k_export_L, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const float4*)ctx->Lbuf.p, n, (float*)ctx->scratch[0].p, ctx->last_L_layout, ctx->last_L_npix, ctx->last_L_spp);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemcpy(out, ctx->scratch[0].p, n_floats * sizeof(float), hipMemcpyDeviceToHost));
     return 0;
@@ -741,10 +774,11 @@ int trhip_film_accumulate(trhip_ctx* ctx, const trhip_sensor* sn, uint32_t spp, 
     if (int rc = ensure(ctx, ctx->film, film_bytes)) return rc;
     if (int rc = ensure_film_samples(ctx, ds, n)) return rc;
     if (n) hipLaunchKernelGGL(k_import_L, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const float*)ctx->scratch[0].p, n, (float4*)ctx->Lbuf.p);
-    launch_film(ctx, ctx->stream, ds, (const DeviceSensor*)ctx->sensor.p, (const float4*)ctx->Lbuf.p, n, spp, seed, sample_offset, (float4*)ctx->film.p);
+    launch_film(ctx, ctx->stream, ds, (const DeviceSensor*)ctx->sensor.p, (const float4*)ctx->Lbuf.p, n, spp, seed, sample_offset, (float4*)ctx->film.p, false);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->last_L_count = n;
+    ctx->last_L_layout = 0;
     HIP_TRY(ctx, hipMemcpy(out_xyzw, ctx->film.p, film_bytes, hipMemcpyDeviceToHost));
     return 0;
 }

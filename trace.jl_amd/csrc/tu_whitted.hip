@@ -96,7 +96,7 @@ int render_whitted_impl(trhip_ctx* ctx, const trhip_scene* scene, const DeviceSe
         tm.end(2, st);
     }
     tm.begin(4, st);
-    launch_film(ctx, st, ds, dsp, L, total_slots, spp, seed, sample_offset, (float4*)d_film);
+    launch_film(ctx, st, ds, dsp, L, total_slots, spp, seed, sample_offset, (float4*)d_film, false);
     tm.end(4, st);
     HIP_TRY(ctx, hipEventRecord(e1, st));
     HIP_TRY(ctx, hipGetLastError());
