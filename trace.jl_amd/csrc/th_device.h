@@ -243,9 +243,10 @@ TH_D TriConstants triangle_constants(f3 v0, f3 v1, f3 v2, const float* uv = null
     c.ss = normalize(dpdu);
     return c;
 }
-// tg: the three vertex tangents when the mesh has them (has_tangents), else unused
-TH_D Shading shade_triangle(f3 v0, f3 v1, f3 v2, bool has_normals, f3 n0, f3 n1, f3 n2, bool flip, f3 bary, f3 ray_d, const TriConstants* pre = nullptr, bool has_tangents = false,
-                            const f3* tg = nullptr) {
+// tan: the slot's three vertex tangents (float4 records) when the mesh has them, else null — fetched HERE, after the normals have been used up, so that a scene
+// without tangents (every scene of the reference) keeps the register budget it had
+TH_D Shading shade_triangle(f3 v0, f3 v1, f3 v2, bool has_normals, f3 n0, f3 n1, f3 n2, bool flip, f3 bary, f3 ray_d, const TriConstants* pre = nullptr, const float4* tan = nullptr) {
+    const bool has_tangents = tan != nullptr;
     Shading s;
     const TriConstants tc = pre ? *pre : triangle_constants(v0, v1, v2);
     s.p = bary.x * v0 + bary.y * v1 + bary.z * v2;  // sum_mul(barycentric, vs) :222
@@ -256,7 +257,11 @@ TH_D Shading shade_triangle(f3 v0, f3 v1, f3 v2, bool has_normals, f3 n0, f3 n1,
     f3 sh_dpdu = tc.ss;
     if (has_normals || has_tangents) {  // _init_triangle_shading_geometry! (:160-185)
         const f3 nsn = has_normals ? normalize(bary.x * n0 + bary.y * n1 + bary.z * n2) : n;
-        f3 ss = has_tangents ? normalize(bary.x * tg[0] + bary.y * tg[1] + bary.z * tg[2]) : tc.ss;
+        f3 ss = tc.ss;
+        if (has_tangents) {
+            const float4 ta = tan[0], tb = tan[1], tcn = tan[2];
+            ss = normalize(bary.x * mk3(ta.x, ta.y, ta.z) + bary.y * mk3(tb.x, tb.y, tb.z) + bary.z * mk3(tcn.x, tcn.y, tcn.z));
+        }
         f3 ts = cross(nsn, ss);
         if (dot(ts, ts) > 0.0f) {
             ts = normalize(ts);

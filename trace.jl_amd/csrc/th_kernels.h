@@ -445,7 +445,9 @@ __global__ __launch_bounds__(kBlock) void k_trace_any(DeviceScene sc, SegQueue q
 // t_max = Inf reproduces the accepted candidate's barycentrics / hit point bit-for-bit: they do not depend on t_max).
 // With `bary` (hits written with TraceOut::bary_mode: {b2, prim, b0, b1}) the triangle test is not repeated: the stored
 // barycentrics ARE the accepted candidate's.
-template <bool TRI_ONLY = false>
+// TAN = false: the scene has no mesh with vertex tangents (DeviceScene::tri_tan is null) — the hot shading kernels are instantiated both ways, because even the
+// never-taken branch costs the general code 5 % (S-mesh shading 59.7 -> 62.7 ms, measured)
+template <bool TRI_ONLY = false, bool TAN = true>
 TH_D bool rebuild_shading(const DeviceScene& sc, int prim, f3 o, f3 d, Shading& sh, uint32_t& material, const float4* bary = nullptr, f3* fast_r = nullptr) {
     // all six 16-byte loads are issued up front (independent of the sphere / normals flags) so that their latencies overlap.  (Fetching them
     // in k_shade_path while it classifies the entry — two dependent trips instead of three — was measured: 24 more live registers, 368
@@ -472,13 +474,9 @@ TH_D bool rebuild_shading(const DeviceScene& sc, int prim, f3 o, f3 d, Shading& 
         return false;
     const bool has_n = (meta & PRIM_HAS_NORMALS) != 0;
     const TriConstants tc{mk3(cn.x, cn.y, cn.z), mk3(cs.x, cs.y, cs.z)};
-    if (sc.tri_tan && (meta & PRIM_HAS_TANGENTS)) {  // a mesh with vertex tangents (no scene of the reference has one): its own call, so that the common one keeps its registers
-        const float4 ta = sc.tri_tan[3 * (size_t)prim], tb = sc.tri_tan[3 * (size_t)prim + 1], tcn = sc.tri_tan[3 * (size_t)prim + 2];
-        const f3 tg[3] = {mk3(ta.x, ta.y, ta.z), mk3(tb.x, tb.y, tb.z), mk3(tcn.x, tcn.y, tcn.z)};
-        sh = shade_triangle(v0, v1, v2, has_n, mk3(na.x, na.y, na.z), mk3(nb.x, nb.y, nb.z), mk3(nc.x, nc.y, nc.z), (meta & PRIM_FLIP) != 0, tt.bary, d, &tc, true, tg);
-        return true;
-    }
-    sh = shade_triangle(v0, v1, v2, has_n, mk3(na.x, na.y, na.z), mk3(nb.x, nb.y, nb.z), mk3(nc.x, nc.y, nc.z), (meta & PRIM_FLIP) != 0, tt.bary, d, &tc);
+    // a mesh with vertex tangents (no scene of the reference has one): the three records are fetched inside shade_triangle, where the normals are no longer live
+    const float4* tan = (TAN && sc.tri_tan && (meta & PRIM_HAS_TANGENTS)) ? sc.tri_tan + 3 * (size_t)prim : nullptr;
+    sh = shade_triangle(v0, v1, v2, has_n, mk3(na.x, na.y, na.z), mk3(nb.x, nb.y, nb.z), mk3(nc.x, nc.y, nc.z), (meta & PRIM_FLIP) != 0, tt.bary, d, &tc, tan);
     return true;
 }
 // Commit time: every slot's shading line (th_scene.h) from the two arrays the traversal kernels use — records 0-2 = prims, 3-5 = tri_nrm, 6 / 7 =
@@ -533,7 +531,7 @@ struct ShadeOut {  // what one vertex emits: a shadow ray and / or the continuat
 };
 // One PathIntegrator vertex for queue entry i (a real hit).  FAST: the caller has established that the hit is a triangle whose
 // material is a single LambertianReflection lobe; the sphere path and the general BSDF code are then not even compiled in.
-template <bool STREAM, bool FAST>
+template <bool STREAM, bool FAST, bool TAN = true>
 TH_D void shade_vertex(const DeviceScene& sc, const PathQueue& qin, const float4* __restrict__ hits, float4* __restrict__ L, uint32_t i, int depth_fixed, int max_depth,
                        uint32_t hits_have_bary, const ShadeStream& ss, ShadeOut& out) {
     const float4 h4 = hits[i];
@@ -547,7 +545,7 @@ TH_D void shade_vertex(const DeviceScene& sc, const PathQueue& qin, const float4
     Shading sh;
     uint32_t material;
     f3 fast_r;
-    if (!(rebuild_shading<FAST>(sc, prim, o, d, sh, material, hits_have_bary ? &h4 : nullptr, &fast_r) && material != PRIM_NO_MATERIAL)) return;
+    if (!(rebuild_shading<FAST, TAN>(sc, prim, o, d, sh, material, hits_have_bary ? &h4 : nullptr, &fast_r) && material != PRIM_NO_MATERIAL)) return;
     const LobeSet& bsdf = sc.materials[FAST ? 0u : material].set[1];  // compute_scattering!(si, ray, true); FAST never reads it
     const bool lambert = FAST || bsdf_is_single_lambert(bsdf);  // specialised evaluation of the same arithmetic (th_device.h)
     Lobe lam;  // the one lobe of a `lambert` vertex: FAST rebuilds it from the reflectance stored beside the normals
@@ -641,7 +639,7 @@ TH_D void shade_vertex(const DeviceScene& sc, const PathQueue& qin, const float4
 // (Two launches instead — the FAST entries, then the others from an index list in HBM, each with a register allocation of its
 // own — were measured: S-mesh frame 405 -> 415 ms, S-cornell 162 -> 173 ms; the list traffic and the second launch's tail cost
 // more than the 144 bytes of scratch the FAST code gets rid of.)
-template <bool STREAM>
+template <bool STREAM, bool TAN = true>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TH_SHADE_WAVES))) void k_shade_path(DeviceScene sc, const DeviceSensor* __restrict__ sep, PathQueue qin, PathQueue qout, ShadowQueue sq, uint32_t cap,
                                                        const float4* __restrict__ hits, float4* __restrict__ L, Counters* ctr, int row, int depth_fixed, int max_depth, uint32_t hits_have_bary,
                                                        ShadeStream ss) {
@@ -687,7 +685,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TH_SHADE
         ShadeOut e;
         e.want_shadow = e.want_next = false;
         e.next_depth = 0;
-        if (cls == 1) shade_vertex<STREAM, true>(sc, qin, hits, L, i, depth_fixed, max_depth, hits_have_bary, ss, e);
+        if (cls == 1) shade_vertex<STREAM, true, TAN>(sc, qin, hits, L, i, depth_fixed, max_depth, hits_have_bary, ss, e);
         emit(e);
         // park the others
         const unsigned long long m2 = __ballot(cls == 2);
@@ -700,7 +698,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TH_SHADE
                 ShadeOut g;
                 g.want_shadow = g.want_next = false;
                 g.next_depth = 0;
-                shade_vertex<STREAM, false>(sc, qin, hits, L, j, depth_fixed, max_depth, hits_have_bary, ss, g);
+                shade_vertex<STREAM, false, TAN>(sc, qin, hits, L, j, depth_fixed, max_depth, hits_have_bary, ss, g);
                 emit(g);
                 ring_head = (ring_head + 64u) & 127u;
                 ring_cnt -= 64u;
@@ -712,7 +710,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TH_SHADE
         ShadeOut g;
         g.want_shadow = g.want_next = false;
         g.next_depth = 0;
-        if (lane < ring_cnt) shade_vertex<STREAM, false>(sc, qin, hits, L, s_ring[wv][(ring_head + lane) & 127u], depth_fixed, max_depth, hits_have_bary, ss, g);
+        if (lane < ring_cnt) shade_vertex<STREAM, false, TAN>(sc, qin, hits, L, s_ring[wv][(ring_head + lane) & 127u], depth_fixed, max_depth, hits_have_bary, ss, g);
         emit(g);
     }
 }

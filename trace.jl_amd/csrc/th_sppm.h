@@ -179,6 +179,7 @@ TH_D void add_nan_where(float4* L, uint32_t slot, uint32_t poison) {  // L += β
 #ifndef TH_SHADE_SPPM_WAVES
 #define TH_SHADE_SPPM_WAVES 3  // 180 VGPRs unconstrained (2 waves per SIMD); capped at 3: C4 shading section 162.9 -> 159.3 ms, at 4 (spills) 162.2
 #endif
+template <bool TAN = true>
 static __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TH_SHADE_SPPM_WAVES))) void k_shade_sppm(DeviceScene sc, PathQueue qin, PathQueue qout, ShadowQueue sq, uint32_t cap, const float4* __restrict__ hits, VisiblePoints vp,
                                                        float4* __restrict__ Ld, Counters* ctr, int depth, int max_depth, uint64_t seed, uint32_t it0, uint32_t n_pix, uint32_t width) {
     __shared__ SegView sv;
@@ -210,7 +211,7 @@ static __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(T
                 const bool specular_bounce = __float_as_uint(d4.w) != 0u;
                 Shading sh;
                 uint32_t material;
-                if (rebuild_shading(sc, prim, o, d, sh, material) && material != PRIM_NO_MATERIAL) {
+                if (rebuild_shading<false, TAN>(sc, prim, o, d, sh, material) && material != PRIM_NO_MATERIAL) {
                     const LobeSet& bsdf = sc.materials[material].set[1];
                     const int py = 1 + (int)(pix / width), px = 1 + (int)(pix - (pix / width) * width);
                     const uint64_t key = ts_stream_key(seed, px, py, it0 + it_local - 1u);
@@ -578,6 +579,7 @@ constexpr int kPhotonRings = 4;
 #ifndef TH_SHADE_PHOTON_WAVES
 #define TH_SHADE_PHOTON_WAVES 4
 #endif
+template <bool TAN = true>
 static __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TH_SHADE_PHOTON_WAVES))) void k_shade_photon(DeviceScene sc, PathQueue qin, PathQueue qout, uint32_t cap, const float4* __restrict__ hits, PhotonRecords rec,
                                                          uint32_t n_batch_photons, Counters* ctr, int depth, int max_depth, uint64_t halton_base) {
     __shared__ SegView sv;
@@ -603,7 +605,7 @@ static __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(T
             const f3 beta = mk3(b4.x, b4.y, b4.z);
             Shading sh;
             uint32_t material;
-            if (rebuild_shading(sc, prim, o, d, sh, material) && material != PRIM_NO_MATERIAL) {
+            if (rebuild_shading<false, TAN>(sc, prim, o, d, sh, material) && material != PRIM_NO_MATERIAL) {
                 const f3 wi_photon = -d;
                 if (depth > 1) {
                     const size_t r = (size_t)(depth - 2) * n_batch_photons + photon;

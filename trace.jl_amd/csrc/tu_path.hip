@@ -277,7 +277,11 @@ int render_stream_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sen
         tm.end(1, ps);
         if (ps2 != ps && r > 0) HIP_TRY(ctx, hipStreamWaitEvent(ps, pp.ev_any, 0));  // shade(r) reuses the shadow queue
         tm.begin(2, ps);
-        hipLaunchKernelGGL(k_shade_path<true>, dim3(g_shade), dim3(kBlock), 0, ps, scene->dev, dsp, pq[cur], pq[cur ^ 1], sq, cap, hits, terms, ctr, r, 0, max_depth, 1u,
+        if (scene->dev.tri_tan)
+            hipLaunchKernelGGL(k_shade_path<true>, dim3(g_shade), dim3(kBlock), 0, ps, scene->dev, dsp, pq[cur], pq[cur ^ 1], sq, cap, hits, terms, ctr, r, 0, max_depth, 1u,
+                           ShadeStream{tags[cur], tags[cur ^ 1], (uint32_t)total_slots});
+        else
+            hipLaunchKernelGGL((k_shade_path<true, false>), dim3(g_shade), dim3(kBlock), 0, ps, scene->dev, dsp, pq[cur], pq[cur ^ 1], sq, cap, hits, terms, ctr, r, 0, max_depth, 1u,
                            ShadeStream{tags[cur], tags[cur ^ 1], (uint32_t)total_slots});
         tm.end(2, ps);
         if (ps2 != ps) {
@@ -542,7 +546,11 @@ int render_impl_band(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
             tm.end(1, ps);
             if (two && depth > 2) HIP_TRY(ctx, hipStreamWaitEvent(ps, ev_anys[depth & 1], 0));  // shade(d) refills the queue the shadow rays of depth d - 2 read
             tm.begin(2, ps);
-            hipLaunchKernelGGL(k_shade_path<false>, dim3(g_shade), dim3(kBlock), 0, ps, scene->dev, dsp, pq[cur], pq[cur ^ 1], sq, cap, hits, L, ctr, depth - 1, depth, max_depth, bary_mode,
+            if (scene->dev.tri_tan)
+                hipLaunchKernelGGL(k_shade_path<false>, dim3(g_shade), dim3(kBlock), 0, ps, scene->dev, dsp, pq[cur], pq[cur ^ 1], sq, cap, hits, L, ctr, depth - 1, depth, max_depth, bary_mode,
+                               ShadeStream{nullptr, nullptr, 0u, two ? (uint8_t*)ctx->poison.p : nullptr});
+            else
+                hipLaunchKernelGGL((k_shade_path<false, false>), dim3(g_shade), dim3(kBlock), 0, ps, scene->dev, dsp, pq[cur], pq[cur ^ 1], sq, cap, hits, L, ctr, depth - 1, depth, max_depth, bary_mode,
                                ShadeStream{nullptr, nullptr, 0u, two ? (uint8_t*)ctx->poison.p : nullptr});
             tm.end(2, ps);
             if (two) {

@@ -182,7 +182,10 @@ int render_sppm_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
                          pp.overflow[0].p);
             tm.end(1, st);
             tm.begin(2, st);
-            hipLaunchKernelGGL(k_shade_sppm, g_shade, blk, 0, st, scene->dev, pq[cur], pq[cur ^ 1], sq, cap, hits, vp_all, terms, ctr, depth, max_depth, seed, it0, n, W);
+            if (scene->dev.tri_tan)
+                hipLaunchKernelGGL(k_shade_sppm<true>, g_shade, blk, 0, st, scene->dev, pq[cur], pq[cur ^ 1], sq, cap, hits, vp_all, terms, ctr, depth, max_depth, seed, it0, n, W);
+            else
+                hipLaunchKernelGGL(k_shade_sppm<false>, g_shade, blk, 0, st, scene->dev, pq[cur], pq[cur ^ 1], sq, cap, hits, vp_all, terms, ctr, depth, max_depth, seed, it0, n, W);
             tm.end(2, st);
             tm.begin(3, st);
             launch_trace(ctx, st, scene, true, SegQueue{ctr->n_shadow[depth - 1], cap, 0u}, sq.o, sq.d, nullptr, TraceOut{nullptr, terms, sq.c, nullptr}, ctr->work_shadow[depth - 1], ctr,
@@ -210,7 +213,10 @@ int render_sppm_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
                              ctr, pp.overflow[0].p);
                 tm.end(1, st);
                 tm.begin(2, st);
-                hipLaunchKernelGGL(k_shade_photon, g_shade, blk, 0, st, scene->dev, pq[cur], pq[cur ^ 1], cap, hits, rec, NP, ctr, depth, max_depth, halton_base);
+                if (scene->dev.tri_tan)
+                    hipLaunchKernelGGL(k_shade_photon<true>, g_shade, blk, 0, st, scene->dev, pq[cur], pq[cur ^ 1], cap, hits, rec, NP, ctr, depth, max_depth, halton_base);
+                else
+                    hipLaunchKernelGGL(k_shade_photon<false>, g_shade, blk, 0, st, scene->dev, pq[cur], pq[cur ^ 1], cap, hits, rec, NP, ctr, depth, max_depth, halton_base);
                 tm.end(2, st);
                 cur ^= 1;
             }
