@@ -197,6 +197,19 @@ inline int upload(trhip_ctx* ctx, DevBuf& b, const void* src, size_t bytes) {
     if (bytes) HIP_TRY(ctx, hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
     return 0;
 }
+// a staging array that is NOT zero-filled on allocation (std::vector value-initialises: 1.5 GB of single-threaded memset for a 10 M-triangle scene's records, all of which the
+// fill loops overwrite)
+template <class T>
+struct RawArray {
+    std::unique_ptr<T[]> p;
+    size_t n = 0;
+    explicit RawArray(size_t count) : p(new T[count ? count : 1]), n(count) {}
+    T* data() { return p.get(); }
+    const T* data() const { return p.get(); }
+    size_t size() const { return n; }
+    T& operator[](size_t i) { return p[i]; }
+    const T& operator[](size_t i) const { return p[i]; }
+};
 // f(begin, end) over [0, n) on the host's cores (scene commit's loops over millions of nodes / primitives); ranges are disjoint and contiguous
 template <class F>
 inline void parallel_for(size_t n, F&& f, size_t grain = size_t(1) << 15) {

@@ -195,7 +195,7 @@ int upload_scene(trhip_scene* s) {
     trhip_ctx* ctx = s->ctx;
     CommitClock clk;
     const uint32_t n_nodes = (uint32_t)s->bvh.a.size(), n_prims = (uint32_t)s->bvh.order.size();
-    std::vector<float4> nodes((size_t)n_nodes * 2), prims((size_t)n_prims * 3), nrm((size_t)n_prims * 3);
+    RawArray<float4> nodes((size_t)n_nodes * 2), prims((size_t)n_prims * 3), nrm((size_t)n_prims * 3);  // every element is written below
     parallel_for(n_nodes, [&](size_t i0, size_t i1) {
         for (size_t i = i0; i < i1; ++i) {
             const float* b = &s->bvh.bounds[6 * i];
@@ -304,20 +304,71 @@ int upload_scene(trhip_scene* s) {
         for (uint32_t i = 0; i < n_nodes; ++i)
             if ((s->bvh.flags[i] & 3u) != 3u) widx[i] = n_int++;
         bool ok = n_int < (1u << 24);
-        std::vector<float4> wn((size_t)n_int * 4);
+        RawArray<float4> wn((size_t)n_int * 4);  // every interior node writes its four records below
         has_empty_leaf = false;
         // subtrees that hold a sphere keep the reference's loose slab test (th_trace2.h, slab_test2): the fp32 sphere quadratic
         // (sphere.jl:120-150) accepts rays that pass the sphere at a distance far beyond the tight test's margin
         std::vector<uint8_t> has_sphere(n_nodes, 0);
-        if (!s->spheres.empty())
-            for (uint32_t i = n_nodes; i-- > 0;) {
-                if ((s->bvh.flags[i] & 3u) == 3u) {
-                    const uint32_t first = s->bvh.a[i], cnt = s->bvh.flags[i] >> 2;
-                    for (uint32_t k = first; k < first + cnt && k < n_prims; ++k) has_sphere[i] |= s->prims[s->bvh.order[k]].kind == 1;
-                } else {
-                    has_sphere[i] = has_sphere[i + 1] | (s->bvh.a[i] < n_nodes ? has_sphere[s->bvh.a[i]] : 1);
+        if (!s->spheres.empty()) {
+            // the ordered slots that hold spheres (the .w lane of a slot's first record carries PRIM_SPHERE)
+            std::vector<uint32_t> sphere_slots;
+            std::mutex lock;
+            parallel_for(n_prims, [&](size_t k0, size_t k1) {
+                std::vector<uint32_t> mine;
+                for (size_t k = k0; k < k1; ++k)
+                    if (__builtin_bit_cast(uint32_t, prims[3 * k].w) & PRIM_SPHERE) mine.push_back((uint32_t)k);
+                if (!mine.empty()) {
+                    std::lock_guard<std::mutex> g(lock);
+                    sphere_slots.insert(sphere_slots.end(), mine.begin(), mine.end());
                 }
+            });
+            bool marked = false;
+            if (sphere_slots.size() <= 4096) {
+                // few spheres: mark the root path of each one's leaf.  In the depth-first layout a subtree's slots are contiguous and start at its leftmost leaf's first
+                // slot, so "which child holds slot k" is one comparison with the second child's leftmost slot.  (A tree that is not laid out that way — a caller's
+                // — fails the checks below and takes the bottom-up pass.)
+                auto leftmost = [&](uint32_t i, uint32_t& slot) {
+                    for (uint32_t guard = 0; guard < 4096u && i < n_nodes; ++guard) {
+                        if ((s->bvh.flags[i] & 3u) == 3u) {
+                            slot = s->bvh.a[i];
+                            return true;
+                        }
+                        ++i;
+                    }
+                    return false;
+                };
+                marked = true;
+                for (uint32_t k : sphere_slots) {
+                    uint32_t i = 0;
+                    bool found = false;
+                    for (uint32_t guard = 0; guard < 4096u && i < n_nodes; ++guard) {
+                        has_sphere[i] = 1;
+                        if ((s->bvh.flags[i] & 3u) == 3u) {
+                            found = k - s->bvh.a[i] < (s->bvh.flags[i] >> 2);
+                            break;
+                        }
+                        const uint32_t second = s->bvh.a[i];
+                        uint32_t lo2 = 0;
+                        if (second <= i + 1 || second >= n_nodes || !leftmost(second, lo2)) break;
+                        i = k >= lo2 ? second : i + 1;
+                    }
+                    if (!found) {
+                        marked = false;
+                        break;
+                    }
+                }
+                if (!marked) std::fill(has_sphere.begin(), has_sphere.end(), (uint8_t)0);
             }
+            if (!marked)  // many spheres, or a layout the shortcut does not understand: bottom-up over all nodes
+                for (uint32_t i = n_nodes; i-- > 0;) {
+                    if ((s->bvh.flags[i] & 3u) == 3u) {
+                        const uint32_t first = s->bvh.a[i], cnt = s->bvh.flags[i] >> 2;
+                        for (uint32_t k = first; k < first + cnt && k < n_prims; ++k) has_sphere[i] |= (__builtin_bit_cast(uint32_t, prims[3 * (size_t)k].w) & PRIM_SPHERE) != 0;
+                    } else {
+                        has_sphere[i] = has_sphere[i + 1] | (s->bvh.a[i] < n_nodes ? has_sphere[s->bvh.a[i]] : 1);
+                    }
+                }
+        }
         std::atomic<bool> bad{!ok}, empty_leaf{false};
         parallel_for(n_nodes, [&](size_t i0, size_t i1) {
             static const float kNanBox[6] = {NAN, NAN, NAN, NAN, NAN, NAN};
@@ -378,12 +429,15 @@ int upload_scene(trhip_scene* s) {
                 u.reset();
                 bool sphere = false;
                 for (uint32_t k = first; k < first + cnt && k < n_prims; ++k) {
-                    const HostPrim& p = s->prims[s->bvh.order[k]];
-                    if (p.kind == 1) {
+                    const float4* pr = &prims[3 * (size_t)k];  // the slot's records, in slot order (sequential here; the host primitives are in caller order)
+                    if (__builtin_bit_cast(uint32_t, pr[0].w) & PRIM_SPHERE) {
                         sphere = true;
                         break;
                     }
-                    for (int j = 0; j < 3; ++j) u.grow_point(&p.v[3 * j]);
+                    for (int j = 0; j < 3; ++j) {
+                        const float v[3] = {pr[j].x, pr[j].y, pr[j].z};
+                        u.grow_point(v);
+                    }
                 }
                 if (sphere) continue;  // sphere leaves are reached through exact tests anyway
                 const float* b = &s->bvh.bounds[6 * i];
