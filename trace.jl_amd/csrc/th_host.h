@@ -123,9 +123,6 @@ struct HostPrim {
     uint32_t kind;       // 0 triangle, 1 sphere
     float v[9];          // triangle vertices (world)
     float n[9];          // vertex normals
-    float tg[9];         // vertex tangents (PRIM_HAS_TANGENTS)
-    float uv[6];         // corner uvs (has_uv)
-    uint32_t has_uv;
     uint32_t meta;       // material | flags
     uint32_t sphere_id;  // for spheres
 };
@@ -134,6 +131,9 @@ struct trhip_scene {
     trhip_ctx* ctx = nullptr;
     std::vector<MaterialRec> materials;
     std::vector<HostPrim> prims;  // caller order
+    // the two optional mesh arrays (shapes/triangle_mesh.jl:11-14), beside the primitives and only when some mesh carries them (no scene of the reference does):
+    // prim_tan[9 i ..] = primitive i's vertex tangents (PRIM_HAS_TANGENTS), prim_uv[7 i ..] = its corner (u, v)s and a "has" flag; empty = none
+    std::vector<float> prim_tan, prim_uv;
     bool has_materialless_prim = false;  // set at commit: some GeometricPrimitive has no material (the integrators refuse such a scene; the trace entry points accept it)
     std::vector<SphereRec> spheres;
     std::vector<HostAABB> sphere_bounds;

@@ -227,21 +227,21 @@ int upload_scene(trhip_scene* s) {
     if (int rc = upload(ctx, s->d_nrm, nrm.data(), nrm.size() * sizeof(float4))) return rc;
     clk.tick("upload: 3 copies");
     // the two optional mesh arrays (no scene of the reference sets them): tangents stay resident for the shading kernels, (u, v)s only feed k_shade_constants
-    bool any_tan = false, any_uv = false;
+    const bool any_tan = !s->prim_tan.empty(), any_uv = !s->prim_uv.empty();
+    if (any_tan) s->prim_tan.resize(9 * s->prims.size(), 0.0f);  // primitives added after the last mesh with tangents / (u, v)s: zeros
+    if (any_uv) s->prim_uv.resize(7 * s->prims.size(), 0.0f);
     s->has_materialless_prim = false;
-    for (const HostPrim& p : s->prims) {
-        any_tan = any_tan || (p.kind == 0 && (p.meta & PRIM_HAS_TANGENTS));
-        any_uv = any_uv || (p.kind == 0 && p.has_uv);
-        s->has_materialless_prim = s->has_materialless_prim || (p.meta & PRIM_MATERIAL_MASK) == PRIM_NO_MATERIAL;
-    }
+    for (const HostPrim& p : s->prims) s->has_materialless_prim = s->has_materialless_prim || (p.meta & PRIM_MATERIAL_MASK) == PRIM_NO_MATERIAL;
     s->dev.tri_tan = nullptr;
     if (any_tan) {
         std::vector<float4> tan((size_t)n_prims * 3, make_float4(0, 0, 0, 0));
         parallel_for(n_prims, [&](size_t k0, size_t k1) {
             for (size_t k = k0; k < k1; ++k) {
-                const HostPrim& p = s->prims[s->bvh.order[k]];
+                const uint32_t id = s->bvh.order[k];
+                const HostPrim& p = s->prims[id];
+                const float* tg = &s->prim_tan[9 * (size_t)id];
                 if (p.kind == 0 && (p.meta & PRIM_HAS_TANGENTS))
-                    for (int j = 0; j < 3; ++j) tan[3 * k + j] = make_float4(p.tg[3 * j], p.tg[3 * j + 1], p.tg[3 * j + 2], 0.0f);
+                    for (int j = 0; j < 3; ++j) tan[3 * k + j] = make_float4(tg[3 * j], tg[3 * j + 1], tg[3 * j + 2], 0.0f);
             }
         });
         if (int rc = upload(ctx, s->d_tan, tan.data(), tan.size() * sizeof(float4))) return rc;
@@ -254,10 +254,11 @@ int upload_scene(trhip_scene* s) {
         std::vector<float4> uvs((size_t)n_prims * 2, make_float4(0, 0, 0, 0));
         parallel_for(n_prims, [&](size_t k0, size_t k1) {
             for (size_t k = k0; k < k1; ++k) {
-                const HostPrim& p = s->prims[s->bvh.order[k]];
-                if (p.kind == 0 && p.has_uv) {
-                    uvs[2 * k] = make_float4(p.uv[0], p.uv[1], p.uv[2], p.uv[3]);
-                    uvs[2 * k + 1] = make_float4(p.uv[4], p.uv[5], 1.0f, 0.0f);
+                const uint32_t id = s->bvh.order[k];
+                const float* uv = &s->prim_uv[7 * (size_t)id];
+                if (s->prims[id].kind == 0 && uv[6] != 0.0f) {
+                    uvs[2 * k] = make_float4(uv[0], uv[1], uv[2], uv[3]);
+                    uvs[2 * k + 1] = make_float4(uv[4], uv[5], 1.0f, 0.0f);
                 }
             }
         });
@@ -703,6 +704,9 @@ int trhip_scene_add_triangles_ex(trhip_scene* s, const float* xyz, uint32_t n_ve
         return fail(s->ctx, TRHIP_ERR_INVALID, "triangle %u: material %u not defined", k, mat[k]);
     }
     s->prims.resize((size_t)first + n_tris);
+    // the side arrays exist from the first mesh that brings tangents / (u, v)s on, one entry per primitive of the scene (zeros for the others)
+    if (tangents || !s->prim_tan.empty()) s->prim_tan.resize(9 * ((size_t)first + n_tris), 0.0f);
+    if (uv || !s->prim_uv.empty()) s->prim_uv.resize(7 * ((size_t)first + n_tris), 0.0f);
     parallel_for(n_tris, [&](size_t k0, size_t k1) {
         for (size_t k = k0; k < k1; ++k) {
             HostPrim p;
@@ -712,11 +716,12 @@ int trhip_scene_add_triangles_ex(trhip_scene* s, const float* xyz, uint32_t n_ve
                 const uint32_t vi = idx[3 * k + j];
                 std::memcpy(&p.v[3 * j], &xyz[3 * (size_t)(vi - 1)], 3 * sizeof(float));
                 if (normals) std::memcpy(&p.n[3 * j], &normals[3 * (size_t)(vi - 1)], 3 * sizeof(float));
-                if (tangents) std::memcpy(&p.tg[3 * j], &tangents[3 * (size_t)(vi - 1)], 3 * sizeof(float));
+                if (tangents) std::memcpy(&s->prim_tan[9 * ((size_t)first + k) + 3 * j], &tangents[3 * (size_t)(vi - 1)], 3 * sizeof(float));
             }
             if (uv) {  // mesh.uv[t.i + j]: by corner position, not through the indices (triangle_mesh.jl:82)
-                std::memcpy(p.uv, &uv[6 * k], 6 * sizeof(float));
-                p.has_uv = 1;
+                float* dst = &s->prim_uv[7 * ((size_t)first + k)];
+                std::memcpy(dst, &uv[6 * k], 6 * sizeof(float));
+                dst[6] = 1.0f;
             }
             const uint32_t m = mat ? mat[k] : PRIM_NO_MATERIAL;
             // is_degenerate (triangle_mesh.jl:65-68) depends on the triangle alone: evaluated here, once, in the kernels' arithmetic
