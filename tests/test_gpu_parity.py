@@ -498,3 +498,29 @@ def test_device_built_lbvh(T, ob, ctx):
     cam = T.scenes.cornell_camera(24)
     ref, _, _ = osc.render(cam, "path", 2, 5, seed=4)
     assert_bits_equal(T.PathIntegrator(cam, T.SeededSampler(2, seed=4), 5).render(scene, ctx), ref, "film (device-built BVH)")
+
+
+def test_film_records_written_by_raygen_equal_the_pack_pass(T, ob, ctx):
+    """Option film_fused (default on): k_raygen writes the radiance records in the gather's layout with their splat descriptors.  Film and per-sample
+    radiance must not depend on it — whole frames, banded frames (band_tile_rows), several sample passes per frame (batch_paths)."""
+    scene = T.scenes.cornell_scene()
+    cam = T.scenes.cornell_camera(40)
+    osc = ob.OracleScene.from_scene(scene, bvh=scene.flatten(ctx).bvh())
+    ref, ref_L, _ = osc.render(cam, "path", 5, 4, seed=123, want_samples=True)
+    try:
+        for opts in ({}, {"band_tile_rows": 1}, {"batch_paths": 42 * 42 * 2}):
+            for fused in (1, 0):
+                ctx.set_option("film_fused", fused)
+                for k, v in opts.items():
+                    ctx.set_option(k, v)
+                integ = T.PathIntegrator(cam, T.SeededSampler(5, seed=123), 4)
+                film = integ.render(scene, ctx)
+                assert_bits_equal(film, ref, f"film (film_fused {fused}, {opts})")
+                if "band_tile_rows" not in opts:  # per-sample radiance is kept for whole frames only
+                    assert_bits_equal(integ.sample_radiance(scene), ref_L, f"per-sample radiance (film_fused {fused}, {opts})")
+                for k in opts:
+                    ctx.set_option(k, 0)
+    finally:
+        ctx.set_option("film_fused", 1)
+        ctx.set_option("band_tile_rows", 0)
+        ctx.set_option("batch_paths", 0)
