@@ -524,3 +524,29 @@ def test_film_records_written_by_raygen_equal_the_pack_pass(T, ob, ctx):
         ctx.set_option("film_fused", 1)
         ctx.set_option("band_tile_rows", 0)
         ctx.set_option("batch_paths", 0)
+
+
+def test_one_leaf_scene_sorted_by_candidates(T, ob, ctx):
+    """Option leaf_sorted (th_leaf2.h; off by default — measured slower): a one-leaf scene's rays grouped by the primitives they can hit before the leaf is walked.
+    Hits, occlusion and a frame must equal the oracle's bit for bit."""
+    scene = T.scenes.cornell_scene()
+    flat = scene.flatten(ctx)
+    osc = ob.OracleScene.from_scene(scene, bvh=flat.bvh())
+    wb = osc.world_bound()
+    rays = np.concatenate([camera_rays(T, ob, T.scenes.cornell_camera(96)), T.scenes.incoherent_rays(60000, wb[:3] - 0.3, wb[3:] + 0.3, seed=17)])
+    rays[::97, 4] = 0.0  # some axis-parallel directions (every primitive is a candidate for those)
+    t_ref, prim_ref, _, _ = osc.trace_closest(rays)
+    occ_ref = osc.trace_any(rays)[0]
+    cam = T.scenes.cornell_camera(32)
+    ref, ref_L, _ = osc.render(cam, "path", 3, 6, seed=31, want_samples=True)
+    ctx.set_option("leaf_sorted", 1)
+    try:
+        got = flat.trace_closest(rays)
+        assert np.array_equal(got["prim"], prim_ref)
+        assert_bits_equal(got["t"], t_ref, "t (leaf_sorted)")
+        assert np.array_equal(flat.trace_any(rays), occ_ref)
+        integ = T.PathIntegrator(cam, T.SeededSampler(3, seed=31), 6)
+        assert_bits_equal(integ.render(scene, ctx), ref, "film (leaf_sorted)")
+        assert_bits_equal(integ.sample_radiance(scene), ref_L, "per-sample radiance (leaf_sorted)")
+    finally:
+        ctx.set_option("leaf_sorted", 0)

@@ -90,6 +90,8 @@ struct trhip_ctx {
     int traversal = 3;  // 1 = literal accel/bvh.jl loop, 2 = children-in-parent nodes + per-lane ray replacement, 3 = 2 with leaves postponed (while-while),
                         // 4 = 8-wide quantised nodes in the binary walk's order (th_trace8.h; scenes / rays it cannot take run 3), 6 = 3 with two rays per lane (th_trace4.h),
                         // 7 = closest-hit rays front to back with tie detection, flagged rays re-traced by 3 (th_trace7.h); any-hit rays as 3
+    bool leaf_sorted = false;  // one-leaf scenes: rays grouped by the primitives they can hit before the leaf is walked (th_leaf2.h, option "leaf_sorted"); exact, measured SLOWER
+                               // (S-cornell closest-hit 49.2 -> 60.2 ms, any-hit 15.9 -> 30.8: twelve candidate tests cost as much as the exact tests they save), off
     bool film_fused = true;    // the path integrator's k_raygen writes the radiance records in the film pass's layout with their splat descriptors (no memset, no pack pass; option "film_fused")
     uint32_t last_L_layout = 0, last_L_npix = 1, last_L_spp = 1;  // how Lbuf is laid out after the last render (trhip_last_sample_radiance)
     bool trace3_spec = true;   // k_trace3 (closest-hit): lanes park the leaf they reach and go on descending (th_trace2.h, TH_TRACE3_SPEC); 0 = wait for the leaf phase
@@ -140,6 +142,7 @@ struct trhip_scene {
     std::vector<LightRec> lights;
     FlatBVH bvh;
     bool committed = false;
+    DevBuf d_leaf_boxes;  // one-leaf scenes: the boxes of the leaf's triangles in slot order (th_leaf2.h)
     DevBuf d_nodes, d_prims, d_nrm, d_tan, d_shade, d_spheres, d_materials, d_lights, d_wnodes;
     DeviceScene dev{};
     WideScene wide{};

@@ -188,6 +188,8 @@ int trhip_set_option(trhip_ctx* ctx, const char* name, int64_t value) {
         ctx->occluder_pretest = value != 0;
     else if (!std::strcmp(name, "stream2_priority"))
         ctx->stream2_priority = (int)value;
+    else if (!std::strcmp(name, "leaf_sorted"))
+        ctx->leaf_sorted = value != 0;
     else if (!std::strcmp(name, "film_fused"))
         ctx->film_fused = value != 0;
     else if (!std::strcmp(name, "trace3_spec"))

@@ -512,6 +512,25 @@ int upload_scene(trhip_scene* s) {
         }
     }
     clk.tick("upload: 8-wide view");
+    // ---- one-leaf scenes: the boxes of the leaf's triangles, for the candidate masks of k_leaf_sorted (th_leaf2.h) ----
+    release(s->d_leaf_boxes);
+    if (s->wide_ok && s->wide.root_cnt > 0 && s->wide.root_cnt <= 30) {
+        const uint32_t first = s->wide.root_ref, cnt = s->wide.root_cnt;
+        std::vector<float> boxes(6 * (size_t)cnt, 0.0f);
+        for (uint32_t k = 0; k < cnt && first + k < n_prims; ++k) {
+            const float4* pr = &prims[3 * (size_t)(first + k)];
+            if (__builtin_bit_cast(uint32_t, pr[0].w) & PRIM_SPHERE) continue;
+            HostAABB u;
+            u.reset();
+            for (int j = 0; j < 3; ++j) {
+                const float v[3] = {pr[j].x, pr[j].y, pr[j].z};
+                u.grow_point(v);
+            }
+            std::memcpy(&boxes[6 * (size_t)k], u.mn, 3 * sizeof(float));
+            std::memcpy(&boxes[6 * (size_t)k + 3], u.mx, 3 * sizeof(float));
+        }
+        if (int rc = upload(ctx, s->d_leaf_boxes, boxes.data(), boxes.size() * sizeof(float))) return rc;
+    }
     // ---- one-leaf scenes: the order in which any-hit rays try the leaf's primitives (th_trace2.h, k_any_leaf) ----
     // A shadow ray runs from the surface THROUGH the light (t_max = Inf): what stops it at the latest is what the light sees, so the
     // primitives subtending the largest solid angle at the lights come first (triangles: Van Oosterom & Strackee; spheres: the cap of
@@ -649,6 +668,7 @@ void trhip_scene_free(trhip_scene* s) {
     release(s->d_nodes);
     release(s->d_prims);
     release(s->d_nrm);
+    release(s->d_leaf_boxes);
     release(s->d_tan);
     release(s->d_shade);
     release(s->d_leaf_order);

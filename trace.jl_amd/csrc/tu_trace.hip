@@ -1,6 +1,7 @@
 // tu_trace.hip — which traversal kernel walks a queue (launch_trace) and the kernel-level trace entry points.  The k_trace3 / k_trace4 / k_trace8
 // families are instantiated in tu_trace3.hip / tu_trace8.hip.
 #include "th_host.h"
+#include "th_leaf2.h"
 
 #ifndef TH_TRACE_BLOCKS_PER_CU
 #define TH_TRACE_BLOCKS_PER_CU 6
@@ -141,6 +142,20 @@ void launch_trace(trhip_ctx* ctx, hipStream_t st, const trhip_scene* sc, bool an
     if (v2) {
         if (sc->wide.root_cnt > 0 && ctx->debug_trace_budget == 0 && ctx->leaf_kernel) {  // one-leaf scene: the dedicated kernel (th_trace2.h, k_trace_leaf)
             const dim3 lgrid(ctx->num_cu * 8);
+            if (ctx->leaf_sorted && sc->d_leaf_boxes.p && sc->wide.root_cnt <= 30 && ctx->slab_margin_log2 > 0) {  // rays grouped by what they can hit (th_leaf2.h)
+                const float* lb = (const float*)sc->d_leaf_boxes.p;
+                const WideScene wsv = wide_view(ctx, sc);
+#define TH_LEAF2(A, C, F) hipLaunchKernelGGL((k_leaf_sorted<A, C, F>), lgrid, block, 0, st, sc->dev, wsv, q, ro, rd, tmax, out, ctr, lb)
+                if (any) {
+                    if (cnt) { if (full_only) TH_LEAF2(true, true, true); else TH_LEAF2(true, true, false); }
+                    else { if (full_only) TH_LEAF2(true, false, true); else TH_LEAF2(true, false, false); }
+                } else {
+                    if (cnt) { if (full_only) TH_LEAF2(false, true, true); else TH_LEAF2(false, true, false); }
+                    else { if (full_only) TH_LEAF2(false, false, true); else TH_LEAF2(false, false, false); }
+                }
+#undef TH_LEAF2
+                return;
+            }
             if (any) {
                 if (cnt)
                     { if (full_only) hipLaunchKernelGGL((k_any_leaf<true, true>), lgrid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, ctr); else hipLaunchKernelGGL((k_any_leaf<true, false>), lgrid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, ctr); }
