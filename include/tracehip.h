@@ -121,6 +121,19 @@ int trhip_scene_get_bvh(const trhip_scene* scene, float* node_bounds, uint32_t* 
 int trhip_scene_set_bvh(trhip_scene* scene, const float* node_bounds, const uint32_t* node_a, const uint32_t* node_flags, uint32_t n_nodes,
                         const uint32_t* prim_order, uint32_t n_prims);
 
+/* Hybrid mode (option "bvh_builder" = 4, and the default): the scene holds TWO trees over the same primitives.  The CANONICAL one — the reference's own construction
+ * (accel/bvh.jl:55-206, or the tree a host handed to trhip_scene_set_bvh) — defines the answers: slots, trhip_scene_get_bvh, shading records are its.  The library's
+ * binned-SAH tree rides along as the ACCELERATOR: closest-hit rays walk it and carry a certificate that every valid tree over the same leaves returns the same hit;
+ * rays without the certificate (a sphere entered from inside, sphere.jl:137-138; two acceptable primitives within 512 ulps of the ray's reach; a grazed leaf box;
+ * a zero direction component) are re-walked on the canonical tree in the reference's order (trhip_stats.fallback_rays).  Results equal a walk of the canonical tree
+ * alone bit for bit (option "hybrid" = 0 runs exactly that walk, for A/B).
+ * trhip_scene_bvh_mode: *mode = 0 the library's tree alone (bvh_builder 0 / 1 / 3), 1 the canonical tree alone (bvh_builder 2; or a scene whose accelerator could not be
+ *   certified: leaf boxes that differ between the trees), 2 both; *accel_nodes / *accel_depth describe the accelerator (0 without one).
+ * trhip_scene_get_accelerator: the accelerator in the layout of trhip_scene_get_bvh (prim_order[accelerator slot] = caller primitive index); size it with
+ *   trhip_scene_bvh_mode.  Any output pointer may be NULL. */
+int trhip_scene_bvh_mode(const trhip_scene* scene, int* mode, uint32_t* accel_nodes, uint32_t* accel_depth);
+int trhip_scene_get_accelerator(const trhip_scene* scene, float* node_bounds, uint32_t* node_a, uint32_t* node_flags, uint32_t* prim_order);
+
 /* ---- sensor: PerspectiveCamera + Film + filter (camera/perspective.jl:58-80, film.jl:34-61, filter.jl) ------------- */
 typedef struct {
     float raster_to_camera[16]; /* camera.core.raster_to_camera.m — composed by the host constructors, bugs included (A.3, A.4) */

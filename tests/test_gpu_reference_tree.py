@@ -86,9 +86,13 @@ def test_reference_tree_through_set_bvh_is_the_same_device_scene(T, ob, ctx):
     scene, cam = T.scenes.mesh_scene(40), T.scenes.cornell_camera(40)
     osc = ob.OracleScene.from_scene(scene)
     tree = osc.get_bvh()
+    ctx.set_option("bvh_builder", 0)
     flat = scene.flatten(ctx)  # the library's own tree first
     assert flat.bvh()[1].size != tree[1].size or not np.array_equal(flat.bvh()[3], tree[3]), "the SAH tree happens to equal the reference's: the test proves nothing"
+    ctx.set_option("bvh_builder", 2)  # … replaced by the host's tree, alone (the default would add the library's tree as an accelerator: tests/test_gpu_hybrid.py)
     flat.set_bvh(*tree)
+    ctx.set_option("bvh_builder", -1)
+    assert flat.bvh_mode()[0] == 1
     got = flat.bvh()
     for x, y in zip(got, tree):
         assert np.array_equal(np.ascontiguousarray(x).view(np.uint32), np.ascontiguousarray(y).view(np.uint32))

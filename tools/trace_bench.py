@@ -28,6 +28,10 @@ def main():
     ap.add_argument("--traversal", type=int, nargs="+", default=[1, 2, 3])
     ap.add_argument("--res", type=int, default=1024)
     ap.add_argument("--sorted-sets", action="store_true", help="also time the bounce / incoherent rays grouped by octant and origin cell")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="library option set before the scene is committed (e.g. bvh_builder=0: the library's tree alone)")
+    ap.add_argument("--post-opt", action="append", default=[], metavar="NAME=VALUE", help="library option set after the commit (e.g. hybrid=0: every ray on the canonical tree)")
+    ap.add_argument("--sets", nargs="+", default=None, help="ray sets to run (default: all)")
+    ap.add_argument("--kinds", nargs="+", default=["closest", "any"])
     args = ap.parse_args()
     import torch
     import __graft_entry__ as graft
@@ -36,9 +40,15 @@ def main():
     import bench
     ctx = T.Context(0)
     scene, cam, desc = bench.build_workload(T, args.workload, args.res)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        ctx.set_option(k, int(v))
     t0 = time.time()
     flat = scene.flatten(ctx)
-    print(json.dumps({"workload": args.workload, "desc": desc, "bvh_build_upload_s": round(time.time() - t0, 3), "nodes": int(flat.bvh()[1].size)}), flush=True)
+    for kv in args.post_opt:
+        k, v = kv.split("=")
+        ctx.set_option(k, int(v))
+    print(json.dumps({"workload": args.workload, "desc": desc, "bvh_build_upload_s": round(time.time() - t0, 3), "nodes": int(flat.bvh()[1].size), "bvh_mode": flat.bvh_mode()[0]}), flush=True)
     L = T.lib()
     n = args.rays
     # ---- ray sets ----
@@ -65,6 +75,8 @@ def main():
     bnd = flat.bvh()[0][0]
     incoherent = T.scenes.incoherent_rays(n, bnd[:3], bnd[3:])
     sets = {"primary": primary, "bounce": bounce, "incoherent": incoherent}
+    if args.sets:
+        sets = {k: v for k, v in sets.items() if k in args.sets}
     if args.sorted_sets:
         # what would ray reordering buy?  the same rays grouped by direction octant, and by octant + origin cell
         def octant(r):
@@ -92,7 +104,7 @@ def main():
         ref = None
         for trav in args.traversal:
             ctx.set_option("traversal", trav)
-            for kind in ("closest", "any"):
+            for kind in args.kinds:
                 fn = L.trhip_trace_closest_device if kind == "closest" else L.trhip_trace_any_device
                 outp = d_hits.data_ptr() if kind == "closest" else d_occ.data_ptr()
                 ctx.set_option("count_visits", 1)

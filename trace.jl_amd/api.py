@@ -617,6 +617,28 @@ class FlatScene:
         self.ctx.check(L.trhip_scene_get_bvh(self._h, _ffi.fptr(bounds), _ffi.u32ptr(a), _ffi.u32ptr(flags), _ffi.u32ptr(order)))
         return bounds, a, flags, order
 
+    def bvh_mode(self):
+        """(mode, accelerator nodes, accelerator depth): mode 0 = the library's tree alone, 1 = the canonical (reference / host) tree alone, 2 = hybrid: the canonical
+        tree defines the answers, the library's tree accelerates the rays that carry the order-independence certificate (csrc/th_trace3c.h)."""
+        mode, nn, dep = C.c_int(), C.c_uint32(), C.c_uint32()
+        self.ctx.check(_ffi.lib().trhip_scene_bvh_mode(self._h, C.byref(mode), C.byref(nn), C.byref(dep)))
+        return mode.value, nn.value, dep.value
+
+    def accelerator(self):
+        """The accelerator tree of a hybrid scene, in the layout of bvh() (order[accelerator slot] = caller primitive index)."""
+        mode, nn, _ = self.bvh_mode()
+        if mode != 2:
+            raise _ffi.TraceHipError("the scene has no accelerator tree")
+        L = _ffi.lib()
+        npr = C.c_uint32()
+        self.ctx.check(L.trhip_scene_bvh_size(self._h, None, C.byref(npr)))
+        bounds = np.empty((nn, 6), dtype=np.float32)
+        a = np.empty(nn, dtype=np.uint32)
+        flags = np.empty(nn, dtype=np.uint32)
+        order = np.empty(npr.value, dtype=np.uint32)
+        self.ctx.check(L.trhip_scene_get_accelerator(self._h, _ffi.fptr(bounds), _ffi.u32ptr(a), _ffi.u32ptr(flags), _ffi.u32ptr(order)))
+        return bounds, a, flags, order
+
     def set_bvh(self, bounds, a, flags, order):
         bounds, a, flags, order = _ffi.f32(bounds), np.ascontiguousarray(a, np.uint32), np.ascontiguousarray(flags, np.uint32), np.ascontiguousarray(order, np.uint32)
         self.ctx.check(_ffi.lib().trhip_scene_set_bvh(self._h, _ffi.fptr(bounds), _ffi.u32ptr(a), _ffi.u32ptr(flags), a.size, _ffi.u32ptr(order), order.size))

@@ -26,6 +26,7 @@
 #include "th_trace8.h"
 #include "th_trace4.h"
 #include "th_trace7.h"
+#include "th_trace3c.h"
 #include "th_comm.h"
 
 using namespace th;
@@ -95,6 +96,8 @@ struct trhip_ctx {
     bool film_fused = true;    // the path integrator's k_raygen writes the radiance records in the film pass's layout with their splat descriptors (no memset, no pack pass; option "film_fused")
     uint32_t last_L_layout = 0, last_L_npix = 1, last_L_spp = 1;  // how Lbuf is laid out after the last render (trhip_last_sample_radiance)
     bool trace3_spec = true;   // k_trace3 (closest-hit): lanes park the leaf they reach and go on descending (th_trace2.h, TH_TRACE3_SPEC); 0 = wait for the leaf phase
+    bool hybrid = true;        // scenes committed with both trees (bvh_builder 4 / -1): closest-hit rays walk the ACCELERATOR with the order-independence certificate of
+                               // th_trace3c.h and only the flagged ones the canonical tree (option "hybrid"; 0 = every ray walks the canonical tree: same answers, slower)
     bool trace7_cheap = true;  // k_trace7: conservative fma slab test on interior boxes, the reference's exact test once per leaf (th_trace7.h); 0 = exact test on every box
     // workspace (grown on demand, reused across calls)
     DevBuf q[2][3], sq[3], hits, Lbuf, pfilm, counters, sensor, table, film, scratch[4], overflow, wh_L, wh_parent, wh_coef, wh_pdf, wh_flags, occl, film_Lt, surv_list, surv_counts;
@@ -117,6 +120,7 @@ struct trhip_ctx {
     DevBuf film_side;  // packed film pass: counter + the full descriptors of the samples whose range does not fit 30 bits (th_kernels.h, FilmSideTable)
     DevBuf fdesc;   // film_block 3: one SplatDesc (16 B) per camera sample of the band (th_kernels.h, k_film_descriptors)
     DevBuf poison;  // one byte per camera sample of the band: ShadeStream::poison
+    DevBuf cert_cold;  // k_trace3c's CertCold (th_trace3c.h)
     DevBuf ov8[2], fb_list[2], fb_counts[2];  // k_trace8: global stack levels, fallback lists + their counters / work cursors ([closest | any])
     Comm comm;  // multi-GPU job this context belongs to (trhip_comm_init); n_ranks == 1 without one
 };
@@ -154,6 +158,15 @@ struct trhip_scene {
     bool wide_ok = false;
     bool w8_ok = false;            // the 8-wide view exists (th_trace8.h)
     bool literal_only = false;     // a caller-supplied BVH whose boxes do not nest (trhip_scene_set_bvh): literal kernels only
+    // ---- hybrid mode (th_trace3c.h): `bvh` above is the CANONICAL tree (the reference's construction, or the host's own tree) — slots, shading records, the inspection API
+    // and the answers are its; `acc` is the library's tree over the same primitives, which most rays walk instead
+    FlatBVH acc;                   // order[k] = caller primitive of accelerator slot k; empty without an accelerator
+    bool hybrid_ok = false;        // the accelerator exists and its leaves carry the canonical leaves' boxes bit for bit
+    int bvh_mode = 0;              // what trhip_scene_commit / trhip_scene_set_bvh built: 0 the library's tree alone, 1 the canonical (reference / host) tree alone, 2 both
+    DevBuf d_acc_wnodes, d_acc_prims, d_slot_boxes, d_sphere_boxes, d_sphere_slots, d_acc_leaf_order;
+    WideScene wide_acc{};
+    DeviceScene dev_acc{};         // dev with the accelerator's primitive records
+    CertScene cert{};
 };
 
 inline int fail(trhip_ctx* ctx, int code, const char* fmt, ...) {
@@ -229,6 +242,19 @@ inline void parallel_for(size_t n, F&& f, size_t grain = size_t(1) << 15) {
     f((size_t)0, std::min(n, step));
     for (auto& x : th) x.join();
 }
+// do camera rays start far outside the scene (more than 4 scene extents away)?  Then the hybrid walk's launch over them takes the per-axis form of its cull bound
+// (TraceOut::far_hint, th_trace3c.h): the scalar margin scales with the reach D of the rays' arithmetic, which is what such a distance inflates
+inline bool far_camera(const trhip_scene* sc, const trhip_sensor* sn) {
+    if (!sc->hybrid_ok || !sn) return false;
+    const float* rb = sc->wide_acc.root_box;
+    const float o[3] = {sn->camera_to_world[3], sn->camera_to_world[7], sn->camera_to_world[11]};
+    float reach = 0.0f, extent = 0.0f;
+    for (int a = 0; a < 3; ++a) {
+        reach = std::fmax(reach, std::fmax(std::fabs(rb[a] - o[a]), std::fabs(rb[3 + a] - o[a])));
+        extent = std::fmax(extent, rb[3 + a] - rb[a]);
+    }
+    return reach > 4.0f * extent;
+}
 inline int grid_for(const trhip_ctx* ctx, uint64_t n, int blocks_per_cu) {
     const uint64_t need = (n + kBlock - 1) / kBlock;
     const uint64_t cap = (uint64_t)ctx->num_cu * blocks_per_cu;
@@ -285,6 +311,7 @@ struct Timer {
 // ---- functions one unit calls in another ---------------------------------------------------------------------------------------------
 // tu_scene.hip
 int upload_scene(trhip_scene* s);
+int upload_accelerator(trhip_scene* s);
 // tu_lbvh.hip
 int build_bvh_device(trhip_ctx* ctx, const std::vector<HostAABB>& pb, FlatBVH& out);
 int build_bvh_device_sah(trhip_ctx* ctx, const std::vector<HostAABB>& pb, int max_node_prims, bool split_coincident, FlatBVH& out, double* ms_device);
@@ -302,6 +329,13 @@ void launch_trace3(trhip_ctx* ctx, hipStream_t st, const trhip_scene* sc, bool a
                    const TraceOut& out, uint32_t* work_cursors, uint2* ov, Counters* ctr);
 void launch_trace4(trhip_ctx* ctx, hipStream_t st, const trhip_scene* sc, bool any, bool cnt, bool full_only, const SegQueue& q, const float4* ro, const float4* rd, const float* tmax,
                    const TraceOut& out, uint32_t* work_cursors, uint2* ov, Counters* ctr);
+// tu_trace3c.hip: the hybrid mode's certified walks on the accelerator tree (th_trace3c.h)
+bool hybrid_active(const trhip_ctx* ctx, const trhip_scene* sc);
+WideScene wide_view_acc(const trhip_ctx* ctx, const trhip_scene* sc);
+void launch_trace3c(trhip_ctx* ctx, hipStream_t st, const trhip_scene* sc, bool cnt, bool full_only, bool big, const SegQueue& q, const float4* ro, const float4* rd, const float* tmax,
+                    const TraceOut& out, uint32_t* work_cursors, uint2* ov, Counters* ctr, const FallbackList& fb);
+void launch_leaf_c(trhip_ctx* ctx, hipStream_t st, const trhip_scene* sc, bool any, bool cnt, bool full_only, const SegQueue& q, const float4* ro, const float4* rd, const float* tmax,
+                   const TraceOut& out, Counters* ctr, const FallbackList& fb);
 void launch_trace7(trhip_ctx* ctx, hipStream_t st, const trhip_scene* sc, bool cnt, bool full_only, bool big, const SegQueue& q, const float4* ro, const float4* rd, const float* tmax,
                    const TraceOut& out, uint32_t* work_cursors, uint2* ov, Counters* ctr, const FallbackList& fb);
 void launch_trace8(trhip_ctx* ctx, hipStream_t st, const trhip_scene* sc, bool any, bool cnt, bool full_only, const Wide8Scene& w8, const SegQueue& q, const float4* ro, const float4* rd,

@@ -121,6 +121,7 @@ struct TraceOut {
     uint8_t* occluded;       // any-hit, plain mode
     uint32_t bary_mode;      // closest, 1: hits.x = third barycentric of a triangle hit instead of t (the shading kernels then
                              // skip re-running the triangle test); spheres keep t
+    uint32_t far_hint;       // closest, hybrid mode: 1 = the rays of this launch start far outside the scene (camera rays): k_trace3c's AXIS variant (th_trace3c.h)
 };
 
 // ---- streaming wavefront (DESIGN.md "Stragglers") ---------------------------------------------------------------------------

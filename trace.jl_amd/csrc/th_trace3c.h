@@ -1,0 +1,821 @@
+// th_trace3c.h — the HYBRID closest-hit walk: every ray is answered exactly as accel/bvh.jl:212-258 answers it on the CANONICAL tree (the reference's own
+// construction, th_bvh_ref.h, or the tree a host handed over), while the bulk of the rays never touch that tree.
+//
+// Why two trees.  intersect!(bvh, ray) keeps the LAST accepted primitive: a primitive is accepted iff its own test passes with the CURRENT t_max
+// (triangle_mesh.jl:211-214 rejects `t_scaled > t_max * det`, equality accepts; sphere.jl:137), a subtree is entered iff its box passes bounds.jl:186-200
+// with the current t_max — and a sphere entered from inside returns its far root WITHOUT looking at t_max (sphere.jl:137-138).  So the
+// answer depends on the visiting order, i.e. on the topology, for (a) rays that start inside a sphere, (b) rays with two acceptable primitives at (nearly)
+// the same t, (c) rays that graze a leaf's box so closely that `tx_min < t_max` is decided by rounding.  The reference's builder (12 buckets born as the
+// point 0, range-length weights: A.6) makes a tree that costs 2x the library's binned-SAH tree to walk.  This kernel walks the library's tree — the
+// ACCELERATOR — and returns, per ray, either an answer together with a certificate that EVERY valid tree gives it, or the ray itself on a fallback list
+// that k_trace3 (th_trace2.h) then walks on the canonical tree in the reference's order.
+//
+// The certificate.  Everything in the reference's tests except the comparisons with t_max is a function of (ray, primitive) or (ray, box) alone.  Call a
+// primitive p a CANDIDATE when the t_max-free clauses of bounds.jl:186-198 pass on the box of the canonical LEAF that holds it and the t_max-free part of
+// its own test passes; t_p (the t it would set) and tau_p (the smallest t_max that accepts it, within 4 ulps of t_p) do not depend on the walk.  Commit
+// verifies that every accelerator leaf has bit for bit the box of the canonical leaf of each of its primitives (otherwise there is no hybrid mode for the
+// scene), and for rays without a zero direction component a leaf box that passes the t_max-free clauses implies that every ancestor box — in any tree whose
+// boxes nest — passes them, and enters no later than the leaf (the slab products are monotonic in the box planes).  So the SET of candidates is the same in
+// both trees; only the t_max clauses see the order.  With D = the largest coordinate offset between the ray origin and the scene bound (the reach of the
+// ray's Float32 arithmetic) and kz the ray's dominant axis (every hit lies inside the scene, so t <= D |1 / d[kz]|),
+//     dt = 2^-18 D |1 / d[kz]|      (64 ulps of the largest possible t: all it has to cover is the rounding between t_p, tau_p and the slab products)
+// the walk keeps t_max = the t of the last accepted candidate w (or the ray's own t_max) and the GUARD g = max(t_w, entry of w's own leaf box), and
+//     * tests every primitive it reaches against the relaxed limit g + dt; a candidate p found that way is ACCEPTED iff max(t_p, entry of p's leaf box)
+//       <= t_max - dt, and otherwise the ray is FLAGGED: p lies within dt of the incumbent, or between the incumbent and the point where the incumbent's (or
+//       p's own) leaf box lets the reference in — the order decides (ties on shared edges, coincident surfaces, grazed boxes);
+//     * culls a child box c of node N only when a LOWER BOUND of the t of everything inside is >= g + dt.  Two bounds hold for every candidate p under c:
+//       (i) t_p >= (1 - 8 ulp) x [kz-slab entry of c]: t_p = sum(e_k z_k sz) / sum(e_k) is a convex combination of the vertices' own (v[kz] - o[kz]) / d[kz] — the very
+//       products the slab test forms for the box planes — and the box holds the vertices; (ii) the accepted hit point lies within 40 ulps of D of the triangle
+//       (translate, shear, edge functions: th_trace2.h), hence inside c grown by 2^-17 D per axis, hence its TRUE t is >= entry(c) - 2^-17 D max |1 / d|; and the
+//       computed t_p differs from the true one by no more than the triangle's extent along kz (both lie between the vertices' depths), which is <= mle(N) |1 / d[kz]|
+//       with mle(N) = the largest leaf-box extent in N's subtree (one float per node, set at commit).  The walk uses the larger of the two;
+//     * treats a full sphere entered from INSIDE (sphere.jl:137-138: the far root t1 is returned whatever t_max is — every ray reflected off or refracted into a
+//       sphere starts that way, its own surface at t1 ~ 1e-7 or the far side) as a candidate that the reference ALWAYS accepts when it tests it, overwriting what it
+//       held: it is accepted here under the same rule (the incumbent / the ray's own t_max lies beyond g + dt) and then STICKS — any further candidate below g + dt flags
+//       the ray, because a primitive nearer than t1 wins in the reference iff it happens to be tested after the sphere.  The sphere's leaf box holds the origin, so
+//       every tree reaches it (entry <= g, below every other candidate and the ray's own t_max);
+//     * flags a ray that meets a clipped sphere (sphere.jl:143-149 can return a root that ignores t_max), and a ray with a zero or non-finite direction component
+//       (0 x Inf = NaN breaks the monotonicity argument); boxes on the path to a sphere are never culled by t (the Float32 quadratic reports hits up to 1e-3 |o - c|
+//       outside the sphere's box, no margin derived from the boxes bounds where its candidates lie): every sphere whose leaf box passes the t_max-free clauses IS tested.
+// Claim: an unflagged ray's answer w is what the reference's walk returns on any tree over the same leaves.  With G = max(t_w, entry of w's leaf box):
+//   (1) every other candidate p has t_p, tau_p >= G + dt / 2: if it was tested it failed the relaxed limit of the moment (>= G + dt), or was accepted and later
+//       replaced (each acceptance lowers g by >= dt); if it never was, a box above it was culled with its lower bound >= g_then + dt >= G + dt;
+//   (2) on the other tree, before w is tested t_max is the ray's own (>= G + dt: the acceptance rule) or some t_p >= G + dt / 2; w's leaf box enters at <= G and
+//       every ancestor no later: w is reached, and accepted (tau_w <= t_w + 4 ulp);  (3) afterwards every other candidate is rejected (tau_p > t_w) and no sphere
+//       raises t_max: one entered from inside whose leaf passes the t_max-free clauses was tested here (its path is never culled) and IS w, or the ray was flagged.
+// The accelerator's own visiting order is irrelevant to the claim; it keeps k_trace3's (near child first by the split axis' sign) because that schedule is tuned.
+//
+// Primitive records of the accelerator are in ITS leaf order and carry the CANONICAL slot in the second record's .w lane: hits, shading records, the
+// inspection API and the oracle all speak canonical slots.
+#pragma once
+#include "th_trace2.h"
+#include "th_trace8.h"  // FallbackList
+
+namespace th {
+
+#ifndef TH_TRACE3C_WAVES
+#define TH_TRACE3C_WAVES 5
+#endif
+#ifndef TH_TRACE3C_LDS
+#define TH_TRACE3C_LDS 12
+#endif
+#ifndef TH_TRACE3C_LEAF_WAIT
+#define TH_TRACE3C_LEAF_WAIT 32
+#endif
+#ifndef TH_TRACE3C_POP_MIN
+#define TH_TRACE3C_POP_MIN 8
+#endif
+#ifndef TH_TRACE3C_MAX_A
+#define TH_TRACE3C_MAX_A 8
+#endif
+constexpr float kCertDt = 1.52587890625e-5f;     // 2^-16: dt = kCertDt D |1 / d[kz]| (256 ulps of the largest possible t)
+constexpr float kCertGrow = 9.5367431640625e-7f;  // 2^-20 (16 ulps): the sheared vertex coordinates x' = fl(fl(v_x - o_x) + fl(S_x fl(v_z - o_z))) carry <= 5 ulps of D each (one for each
+                                                  // subtraction, two for S_x, one for the product), so the point of the TRUE triangle with the computed barycentrics lies within 5 ulps of D per
+                                                  // lateral axis of the ray point at the computed t — which therefore lies inside the primitive's boxes grown by this x D per axis
+constexpr float kCertFlat = 3.814697265625e-6f;   // 2^-18 (64 ulps): … plus what the edge functions' own rounding (<= 3 ulps of each product) moves that point: for a FLAT primitive (in an
+                                                  // axis-aligned plane: its thin direction in the sheared frame IS a coordinate axis, the products are long x thin) at most 36 ulps of L^3 / 2A
+                                                  // whatever the viewing angle; for the others the kz-extent bound is used instead (mle_small)
+constexpr uint32_t kCertMaxSpheres = 8;          // (the order word of a primitive record holds 3 bits per sphere)
+constexpr float kCertCap = 4.0f;                  // a ray whose growth margin in t units exceeds this x (the kz extent margin) goes to the reference-order walk at once (near-axis-parallel
+                                                  // rays: |1 / d| ~ 1e3 and more): the accelerator walk would overshoot every hit by that much
+
+struct CertScene {               // what the certificate needs beside the accelerator's WideScene
+    const float* sphere_boxes;   // per sphere id: the box of the canonical leaf that holds it (6 floats)
+    const uint32_t* sphere_slots;  // per sphere id: its canonical slot
+    uint32_t n_spheres;          // spheres are tested when a ray is FETCHED (k_trace3c), all of them: never more than kCertMaxSpheres in a hybrid scene
+    const float* slot_boxes;     // one-leaf accelerator: per canonical slot, the box of the canonical leaf that holds it (6 floats)
+    float inv_tight;             // 1 / WideScene::tight_scale: D = em x inv_tight
+    float mle_small[3];          // per axis: the largest extent of a NON-FLAT leaf box along that axis — bounds |computed t - the depth of the ray's point on the (perturbed) triangle|
+                                 // of every primitive in such a leaf (both lie between the vertices' depths)
+    float sq_flat;               // FLAT leaves (zero extent in some axis: walls, floors — any size): the largest L^3 / (2 A) of their triangles (L longest edge, A area), which bounds
+                                 // how far the edge functions' rounding moves the ray point at the computed t off the triangle: 2^-19 x this / |d^[flat axis]|
+};
+
+// What k_trace3c reads only when a ray is fetched or handed to the fallback lists lives in HBM behind ONE pointer (scalar loads where it is used) instead of in the kernel's
+// argument list: the walk runs at the SGPR limit (lane masks, the queue, the scene), and every argument that stays live across the loop is spilled through v_writelane / v_readlane.
+struct CertCold {
+    const float* sphere_boxes;
+    const uint32_t* sphere_slots;
+    uint32_t* fb_list;
+    uint32_t* fb_counts;
+    uint32_t n_spheres, fb_cap;
+    float mle_small[3];
+    float sq_flat, inv_tight;
+    float pad;
+};
+struct CertHot {   // … and the three constants the walk itself needs
+    float kdt;     // kCertDt / tight_scale: dt = kdt x em x |1 / d[kz]|
+    float kgrow;   // kCertGrow / tight_scale
+    float gflat;   // kCertFlat x sq_flat: growth = kgrow x em + gflat
+};
+static __global__ void k_store_cert_cold(CertCold* dst, CertCold v) { *dst = v; }
+
+// bounds.jl:186-198 on one child box, as slab_test2 (its t_max-free clauses, plus the two tight clauses), returning the exact entry distance and, with AXIS, the entry distance
+// of the box GROWN by `grow` (a length) in every axis
+template <bool AXIS>
+TH_D bool slab_test3(float bx0, float by0, float bz0, float bx1, float by1, float bz1, f3 o, f3 inv_d, float em, float grow, bool tight, bool negx, bool negy, bool negz, float& tmin_out, float& tgrown_out) {
+    const float tx_min = ((negx ? bx1 : bx0) - o.x) * inv_d.x;
+    const float tx_max = ((negx ? bx0 : bx1) - o.x) * inv_d.x;
+    const float ty_min = ((negy ? by1 : by0) - o.y) * inv_d.y;
+    const float ty_max = ((negy ? by0 : by1) - o.y) * inv_d.y;
+    const float tz_min = ((negz ? bz1 : bz0) - o.z) * inv_d.z;
+    const float tz_max = ((negz ? bz0 : bz1) - o.z) * inv_d.z;
+    const bool miss_xy = (tx_min > ty_max) | (ty_min > tx_max);     // bounds.jl:188
+    const float a = ty_min > tx_min ? ty_min : tx_min;              // :189
+    const float b = ty_max > tx_max ? ty_max : tx_max;              // :190
+    const bool miss_z = (a > tz_max) | (tz_min > b);                // :194
+    const float t_in = tz_min > a ? tz_min : a;                     // :196
+    const float t_out = tz_max < b ? tz_max : b;                    // :197
+    const float exit_xy = fminf(__fmaf_rn(em, fabsf(inv_d.x), tx_max), __fmaf_rn(em, fabsf(inv_d.y), ty_max));
+    const bool miss_tight = tight & ((__fmaf_rn(-em, fabsf(inv_d.z), tz_min) > exit_xy) | (exit_xy < 0.0f));
+    tmin_out = t_in;
+    tgrown_out = AXIS ? fmaxf(fmaxf(__fmaf_rn(-grow, fabsf(inv_d.x), tx_min), __fmaf_rn(-grow, fabsf(inv_d.y), ty_min)), __fmaf_rn(-grow, fabsf(inv_d.z), tz_min)) : t_in;
+    return !(miss_xy | miss_z | miss_tight) & (t_out > 0.0f);
+}
+
+// sphere.jl:125-158 up to the roots: 0 = no candidate within t_lim, 1 = candidate at t (a full sphere seen from outside: accepted iff t0 <= t_max, sets t0),
+// 3 = a full sphere entered from INSIDE: the reference takes the far root t1 WHATEVER t_max is (sphere.jl:137-138) — a candidate that is always accepted (the caller's
+// "sticky" rule), 2 = a clipped sphere (:143-149 may return a root that ignores t_max after a clipped first one) or a NaN root: the ray goes to the reference-order walk
+template <bool FULL_ONLY>
+TH_D int sphere_candidate_c(const SphereRec& s, f3 o, f3 d, float t_lim, float& t) {
+    const f3 oo = xf_point(s.o2w_inv, o);
+    const f3 od = xf_vec(s.o2w_inv, d);
+    const float nd = norm(od);
+    const float a = nd * nd;
+    const float b = dot(2.0f * oo, od);
+    const float no = norm(oo);
+    const float c = no * no - s.radius * s.radius;
+    float t0, t1;
+    if (!solve_quadratic(a, b, c, t0, t1)) return 0;
+    if (!(t1 >= 0.0f)) return t1 < 0.0f ? 0 : 2;  // (a NaN root: let the reference-order walk decide)
+    if (!FULL_ONLY && !s.never_clipped) return 2;
+    if (!(t0 >= 0.0f)) {
+        if (!(t0 < 0.0f)) return 2;
+        t = t1;
+        return 3;
+    }
+    if (t0 > t_lim) return 0;
+    t = t0;
+    return 1;
+}
+
+// rays for the reference-order walk: appended to the fallback lists (kSeg lists, one counter each — a single counter word serialises at ~88 atomics per microsecond; a wave
+// starts at its own list and moves on while a list is full: together they hold as many entries as the queue has rays).  Whole wave; returns the number of rays appended.
+// Not inlined: its loop and the list's addresses then stay out of the walk's registers.
+TH_D uint32_t fallback_append(FallbackList fb, bool to_fb, uint32_t idx, uint32_t first_list) {
+    uint32_t fseg = first_list, n = 0;
+    for (int tries = 0; tries < kSeg && __ballot(to_fb) != 0ull; ++tries) {
+        const uint32_t j = wave_compact(to_fb, &fb.counts[fseg * kCtrStride]);
+        const bool put = to_fb && j < fb.cap;
+        if (put) {
+            fb.list[(size_t)fseg * fb.cap + j] = idx;
+            to_fb = false;
+        }
+        n += (uint32_t)__popcll(__ballot(put));
+        fseg = (fseg + 1) % kSeg;
+    }
+    return n;
+}
+
+// AXIS: the cull bound from the box grown per axis (two fma + max3 more per child) instead of the scalar margin — for launches whose rays start far outside the scene
+// (camera rays 50 scene sizes away: D, hence the scalar margin, is 50x larger, while their binding slab is almost always the dominant axis'); TraceOut::far_hint picks it.
+// Register budget: the node reference and its primitive count stay packed in ONE word (the child / stack word format), what is only read at a ray's fetch or at a hand-over lives
+// behind one pointer (CertCold), the spheres are tested at the fetch: the certificate costs the walk two live values (the per-ray margin and the current node's entry distance;
+// t_lim takes t_max's place).
+template <bool COUNT, bool FULL_ONLY, bool BIG = false, bool AXIS = false>
+__global__ __launch_bounds__(kBlock, BIG ? TH_TRACE3C_WAVES - 1 : TH_TRACE3C_WAVES) void k_trace3c(DeviceScene sc /* prims: the accelerator's order */, WideScene ws /* the accelerator */, CertHot ch,
+                                                                                               const CertCold* __restrict__ cold, SegQueue q, const float4* __restrict__ ro,
+                                                                                               const float4* __restrict__ rd, const float* __restrict__ tmax_or_null, TraceOut out,
+                                                                                               uint32_t* __restrict__ work, uint2* __restrict__ overflow, Counters* ctr) {
+    constexpr int kLds = TH_TRACE3C_LDS;
+    constexpr uint32_t kLeafBit = 1u << 24;  // a node word >= this (and != kRefNone) is a leaf: ref | count << 24
+    __shared__ uint32_t s_ref[kLds][kBlock];
+    __shared__ float s_tmin[kLds][kBlock];
+    __shared__ SegView sv;
+    seg_load(q, sv);
+    const uint32_t tid = threadIdx.x;
+    const uint32_t gthreads = gridDim.x * kBlock;
+    const uint32_t gtid = blockIdx.x * kBlock + tid;
+    const uint32_t lane = lane_id();
+
+    bool active = false, exhausted = false, to_fb = false;
+    uint32_t wseg = __builtin_amdgcn_readfirstlane((gtid >> 6) % kSeg), dry = 0, pool_next = 0, pool_end = 0;  // wave-uniform
+    uint32_t idx = 0, cur = kRefNone;  // cur: kRefNone, an interior node's index (< 2^24), or a leaf word
+    int sp = 0;
+    f3 o = splat3(0.0f), inv_d = splat3(0.0f);
+    float em = 0.0f;
+    RayShear shear{0, 0.0f, 0.0f, 0.0f};
+    bool negx = false, negy = false, negz = false;
+    float t_lim = 0.0f;   // t_max + 2 dt, t_max = the t of the last accepted candidate (or the ray's own t_max): what the primitive tests accept up to; a box is culled when the lower
+                          // bound of what it holds — its entry distance minus the margin — reaches it
+    float mb = 0.0f;      // per ray: the margin of the lower bound: non-flat primitives their kz extent, everything the growth in the entering axis (with AXIS the growth is applied per
+                          // axis to the box instead, and is not in here)
+    float cur_ex = 0.0f;  // entry distance of the node in `cur` (the reference's tx_min of its box)
+    uint32_t st = 0;      // 0: nothing accepted yet, 1: a candidate is; bits 8..: 1 + the sphere the ray started INSIDE of (header: what the reference tests before that sphere does not count)
+    uint32_t nn = 0, np = 0;
+    uint32_t n_fb = 0;    // wave-uniform
+    unsigned long long n_why[4] = {0ull, 0ull, 0ull, 0ull};  // COUNT: why rays went to the canonical tree — 0 direction / finiteness / cap, 1 a sphere (clipped, inside two), 2 near tie / guard
+    uint32_t why = 0;
+
+    auto margin_t = [&]() { return ch.kdt * em * fabsf(shear.sz); };       // dt, from what is live (D = em / tight_scale)
+    auto growth = [&]() { return __fmaf_rn(ch.kgrow, em, ch.gflat); };     // the length by which the ray point at a primitive's computed t can lie outside the primitive's boxes
+    auto inv_max = [&]() { return fmaxf(fmaxf(fabsf(inv_d.x), fabsf(inv_d.y)), fabsf(inv_d.z)); };
+
+    while (true) {
+        // ---- rays for the reference-order walk: appended to the fallback lists ----
+        if (__ballot(to_fb) != 0ull) {
+            const FallbackList fb{uniform_load(&cold->fb_list, 0), uniform_load(&cold->fb_counts, 0), uniform_load(&cold->fb_cap, 0)};
+            n_fb += fallback_append(fb, to_fb, idx, __builtin_amdgcn_readfirstlane((gtid >> 6) % kSeg));
+            to_fb = false;
+        }
+        // ---- refill idle lanes (as k_trace3) ----
+        const unsigned long long idle = __ballot(!active);
+        const uint32_t n_idle = (uint32_t)__popcll(idle);
+        if (n_idle == 64u || (!exhausted && n_idle >= (uint32_t)TH_TRACE_REFILL)) {
+            if (!exhausted) {
+                if (pool_next >= pool_end) {
+                    const uint32_t cnt = __builtin_amdgcn_readfirstlane(sv.count[wseg]);
+                    uint32_t base = cnt, take = (uint32_t)kChunk;
+                    if (lane == 0 && cnt != 0u) {
+                        const uint32_t at = __hip_atomic_load(&work[wseg * kCtrStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (at < cnt) {
+#if TH_TRACE3_SMALL_CHUNKS
+                            if (cnt - at < (uint32_t)TH_TRACE3_SMALL_CHUNKS * (gthreads >> 6) / (uint32_t)kSeg * (uint32_t)kChunk) take = (uint32_t)kChunk / 4u;
+#endif
+                            base = atomicAdd(&work[wseg * kCtrStride], take);
+                        }
+                    }
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    take = __builtin_amdgcn_readfirstlane(take);
+                    if (base < cnt) {
+                        pool_next = base;
+                        pool_end = min(base + take, cnt);
+                        dry = 0;
+                    } else {
+                        pool_next = pool_end = 0;
+                        wseg = (wseg + 1) % kSeg;
+                        if (++dry >= (uint32_t)kSeg) exhausted = true;
+                    }
+                }
+                const uint32_t avail = pool_end - pool_next;
+                if (avail && !active) {
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+                    if (rank < avail) {
+                        idx = seg_phys(q, wseg, pool_next + rank);
+                        if (q.indirect) idx = q.indirect[idx];
+                        const float4 o4 = ro[idx], d4 = rd[idx];
+                        o = mk3(o4.x, o4.y, o4.z);
+                        const f3 d = mk3(d4.x, d4.y, d4.z);
+                        inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                        em = slab_margin(ws.root_box, ws.tight_scale, o);
+                        shear = ray_shear(d);
+                        negx = d.x < 0.0f;
+                        negy = d.y < 0.0f;
+                        negz = d.z < 0.0f;
+                        const float t_own = tmax_or_null ? tmax_or_null[idx] : kInf;
+                        const float dt = margin_t();
+                        const float mkz = uniform_load(cold->mle_small, (uint32_t)shear.kz) * fabsf(shear.sz);
+                        mb = AXIS ? mkz : __fmaf_rn(growth(), inv_max(), mkz);
+                        t_lim = t_own + 2.0f * dt;
+                        sp = 0;
+                        st = 0u;
+                        active = true;
+                        if (COUNT) nn++;
+                        // what the certificate does not cover goes to the reference-order walk at once: a zero or non-finite direction component (0 x Inf = NaN in the slab
+                        // products), a non-finite origin or margin, a NaN t_max — and near-axis-parallel rays, whose scalar margin would make the walk overshoot every hit
+                        // (kCertCap; with AXIS the margin is per axis: no cap)
+                        const bool plain = d.x != 0.0f && d.y != 0.0f && d.z != 0.0f && mb < kInf && fabsf(o.x) < kInf && fabsf(o.y) < kInf && fabsf(o.z) < kInf && fabsf(inv_d.x) < kInf &&
+                                           fabsf(inv_d.y) < kInf && fabsf(inv_d.z) < kInf && t_own == t_own && (AXIS || mb - mkz <= kCertCap * mkz + dt);
+                        float tmin;
+                        if (!plain) {
+                            to_fb = true;
+                            active = false;
+                            if (COUNT) n_why[0]++;
+                        } else if (ws.root_ref != kRefNone && slab_test2(ws.root_box[0], ws.root_box[1], ws.root_box[2], ws.root_box[3], ws.root_box[4], ws.root_box[5], o, inv_d, em, false, negx, negy, negz, tmin)) {
+                            cur = ws.root_ref | (ws.root_cnt << 24);  // (the root is not culled by t: the reference's clause `tmin < t_max` holds whenever anything inside can be accepted)
+                            cur_ex = tmin;
+                            // ---- the scene's spheres, all of them, NOW (the ray's traversal state is not live yet: their transforms and quadratics cost the walk no register):
+                            //      a sphere is then never hidden from the certificate — whatever the boxes on its path do — and the walk skips sphere primitives.  Wave-uniform
+                            //      loop, scalar loads; a sphere counts only when the t_max-free clauses pass on ITS canonical leaf's box ----
+                            bool flagged = false;
+                            const uint32_t n_sph = uniform_load(&cold->n_spheres, 0);
+                            const float* sboxes = uniform_load(&cold->sphere_boxes, 0);
+#pragma unroll 1
+                            for (uint32_t k = 0; k < n_sph; ++k) {
+                                const float* sb = sboxes + 6 * (size_t)k;
+                                const float b0 = uniform_load(sb, 0), b1 = uniform_load(sb, 1), b2 = uniform_load(sb, 2), b3 = uniform_load(sb, 3), b4 = uniform_load(sb, 4), b5 = uniform_load(sb, 5);
+                                float ex;
+                                if (!flagged && slab_test2(b0, b1, b2, b3, b4, b5, o, inv_d, em, false, negx, negy, negz, ex)) {
+                                    if (COUNT) np++;
+                                    float t_c = 0.0f;
+                                    // a sphere the ray starts inside of is taken whatever the limit is (sphere.jl:137-138); one seen from outside up to the relaxed limit
+                                    const int r = sphere_candidate_c<FULL_ONLY>(sc.spheres[k], o, d, t_lim, t_c);
+                                    if (r == 2 || (r != 0 && (st >> 8) != 0u)) {
+                                        flagged = true;  // clipped; or the ray starts inside a sphere AND meets another one below that sphere's far root: left to the reference's order
+                                    } else if (r != 0) {
+                                        // accepted iff it lies 2 dt below the incumbent (t_lim - 4 dt; the ray's own t_max at first) and its leaf box lets the reference in by then.
+                                        // A sphere the ray starts INSIDE of (r == 3): the reference takes its far root whenever it tests it — and it always does: the box holds the
+                                        // origin (required: ex <= 0), so no t_max culls its path — and forgets what it held; the ray remembers the sphere (st), and of what the
+                                        // walk finds only what the reference tests AFTER that sphere counts (the order word of the primitive records, below)
+                                        if (!(t_c <= t_lim - 4.0f * dt) || !(ex <= (r == 3 ? 0.0f : t_c + dt))) {
+                                            flagged = true;
+                                        } else {
+                                            t_lim = t_c + 2.0f * dt;
+                                            st = 1u | (r == 3 ? (k + 1u) << 8 : 0u);
+                                            out.hits[idx] = make_float4(t_c, __uint_as_float(uniform_load(uniform_load(&cold->sphere_slots, 0), k)), 0.0f, 0.0f);
+                                        }
+                                    }
+                                }
+                            }
+                            if (flagged) {
+                                to_fb = true;
+                                active = false;
+                                if (COUNT) n_why[1]++;
+                            }
+                        } else {
+                            cur = kRefNone;
+                        }
+                    }
+                }
+                pool_next += min(n_idle, avail);
+            }
+            if (__ballot(active) == 0ull) {
+                if (__ballot(to_fb) != 0ull) continue;  // flush first
+                if (exhausted) break;
+                continue;
+            }
+        }
+        // ---- phase A: pops and interior steps; lanes holding a leaf wait (k_trace3's schedule) ----
+#pragma unroll 1
+        for (int it = 0; it < TH_TRACE3C_MAX_A; ++it) {
+            bool finished = false;
+            const bool wants_pop = active && cur == kRefNone;
+            const bool pop_now = (uint32_t)__popcll(__ballot(wants_pop)) >= (uint32_t)TH_TRACE3C_POP_MIN || __ballot(active && cur < kLeafBit) == 0ull;
+            if (pop_now && wants_pop) {
+                finished = true;
+                // a stack entry carries the node's EXACT entry distance (what the guard needs when it is a leaf): the pop-time check is the scalar form of the bound
+                const float t_pop = t_lim + (AXIS ? __fmaf_rn(growth(), inv_max(), mb) : mb);
+                while (sp > 0) {
+                    sp--;
+                    uint32_t enc;
+                    float tm;
+                    if (sp < kLds) {
+                        enc = s_ref[sp][tid];
+                        tm = s_tmin[sp][tid];
+                    } else if (sp < kStack2Total) {
+                        const uint2 e = overflow[(size_t)(sp - kLds) * gthreads + gtid];
+                        enc = e.x;
+                        tm = __uint_as_float(e.y);
+                    } else {
+                        continue;
+                    }
+                    if (tm < t_pop) {
+                        cur = enc;
+                        cur_ex = tm;
+                        finished = false;
+                        break;
+                    }
+                }
+            }
+            if (finished) {  // the walk is over: a certified hit (stored when it was accepted) or a certified miss
+                active = false;
+                if ((st & 1u) == 0u) out.hits[idx] = make_float4(kInf, __int_as_float(-1), 0.0f, 0.0f);
+            }
+            if (active && cur < kLeafBit) {  // interior: one 64-byte burst, both child boxes
+                const float4 a0 = ws.wnodes[4 * (size_t)cur], a1 = ws.wnodes[4 * (size_t)cur + 1], a2 = ws.wnodes[4 * (size_t)cur + 2], a3 = ws.wnodes[4 * (size_t)cur + 3];
+                uint32_t top_enc = kRefNone;
+                float top_tm = kInf;
+                if (sp > 0) {
+                    if (sp - 1 < kLds) {
+                        top_enc = s_ref[sp - 1][tid];
+                        top_tm = s_tmin[sp - 1][tid];
+                    } else if (sp - 1 < kStack2Total) {
+                        const uint2 e = overflow[(size_t)(sp - 1 - kLds) * gthreads + gtid];
+                        top_enc = e.x;
+                        top_tm = __uint_as_float(e.y);
+                    }
+                }
+                if (COUNT) nn += 2;
+                const uint32_t lenc = __float_as_uint(a3.x), renc = __float_as_uint(a3.y), meta = __float_as_uint(a3.z);
+                const float gr = AXIS ? growth() : 0.0f;
+                const float t_cull = t_lim + mb;
+                float tl, tr, gl, gr_;
+                const bool hl = slab_test3<AXIS>(a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, o, inv_d, em, gr, !(meta & 4u), negx, negy, negz, tl, gl);
+                const bool hr = slab_test3<AXIS>(a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, o, inv_d, em, gr, !(meta & 8u), negx, negy, negz, tr, gr_);
+                // per child: its exact entry distance travels with it; what is compared with t_cull is that distance (with AXIS: the entry of the grown box); a missed child: +Inf.
+                // (Boxes on a sphere's path keep the reference's clauses alone — bits 2 / 3 — but are culled like any other: the spheres themselves were tested at the fetch.)
+                const float bl = hl ? (AXIS ? gl : tl) : kInf, br = hr ? (AXIS ? gr_ : tr) : kInf;
+                const uint32_t axis = meta & 3u;
+                const bool neg = axis == 0 ? negx : (axis == 1 ? negy : negz);
+                const float bn = neg ? br : bl, bf = neg ? bl : br;
+                const float vn = neg ? tr : tl, vf = neg ? tl : tr;
+                const uint32_t nenc = neg ? renc : lenc, fenc = neg ? lenc : renc;
+                const bool go_n = bn < t_cull, go_f = bf < t_cull;
+                // t_max never goes up in THIS walk (a ray that could see it raised is flagged and leaves): an entry that fails now fails at pop time
+                if (go_n & go_f) {
+                    if (sp < kLds) {
+                        s_ref[sp][tid] = fenc;
+                        s_tmin[sp][tid] = vf;
+                    } else if (sp < kStack2Total) {
+                        overflow[(size_t)(sp - kLds) * gthreads + gtid] = make_uint2(fenc, __float_as_uint(vf));
+                    }
+                    sp++;
+                }
+                const bool any_child = go_n | go_f;
+                cur = any_child ? (go_n ? nenc : fenc) : kRefNone;
+                cur_ex = go_n ? vn : vf;
+                if (!any_child && sp > 0) {  // nothing was pushed in this step: the top read above is still the top
+                    sp--;
+                    const float t_pop = AXIS ? __fmaf_rn(gr, inv_max(), t_cull) : t_cull;
+                    if (top_tm < t_pop && sp < kStack2Total) {
+                        cur = top_enc;
+                        cur_ex = top_tm;
+                    }
+                }
+            }
+            const uint32_t n_desc = (uint32_t)__popcll(__ballot(active && (cur < kLeafBit || cur == kRefNone)));
+            if (n_desc <= (uint32_t)TH_TRACE3C_LEAF_WAIT) break;
+        }
+        // ---- phase B: leaves ----
+        if (active && cur >= kLeafBit && cur != kRefNone) {
+            bool flagged = false;
+            const uint32_t leaf_ref = cur & 0x00ffffffu, leaf_cnt = cur >> 24;
+            uint32_t top_enc = kRefNone;
+            float top_tm = kInf;
+            if (sp > 0) {
+                if (sp - 1 < kLds) {
+                    top_enc = s_ref[sp - 1][tid];
+                    top_tm = s_tmin[sp - 1][tid];
+                } else if (sp - 1 < kStack2Total) {
+                    const uint2 e = overflow[(size_t)(sp - 1 - kLds) * gthreads + gtid];
+                    top_enc = e.x;
+                    top_tm = __uint_as_float(e.y);
+                }
+            }
+            for (uint32_t k = 0; k < leaf_cnt; ++k) {
+                const uint32_t slot = leaf_ref + k;
+                const float4 p0 = sc.prims[3 * slot];
+                const float4 p1 = sc.prims[3 * slot + 1], p2 = sc.prims[3 * slot + 2];
+                asm volatile("" ::"v"(p1.x), "v"(p1.y), "v"(p1.z), "v"(p1.w), "v"(p2.x), "v"(p2.y), "v"(p2.z), "v"(p2.w));  // one burst (th_trace2.h "one fetch per leaf")
+                const uint32_t meta = __float_as_uint(p0.w);
+                if (COUNT) np++;
+                TriTest tt;
+                // (spheres were tested when the ray was fetched)
+                if (!(meta & (PRIM_SPHERE | PRIM_DEGENERATE)) && tri_intersect_sheared<true>(mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z), o, shear, t_lim, &tt)) {
+                    // a candidate below the relaxed limit.  A ray that started inside sphere s: only what the reference tests AFTER s counts — s overwrites the rest (header); the
+                    // primitive's order word (the third record's .w lane) holds, per sphere, the split axis of the canonical node where their paths part and the child it is in
+                    bool counts = true;
+                    if (st >> 8) {
+                        const uint32_t ow = __float_as_uint(p2.w) >> (3u * ((st >> 8) - 1u));
+                        const uint32_t ax = ow & 3u;
+                        const bool second = (ow & 4u) != 0u;  // the primitive sits in the second child there (axis 3: in the sphere's own leaf, behind it)
+                        counts = ax == 3u ? second : (second != (ax == 0u ? negx : (ax == 1u ? negy : negz)));  // bvh.jl:239-246: the second child is visited first iff d[axis] < 0
+                    }
+                    if (counts) {
+                        const float dt = margin_t();
+                        // accepted iff it lies 2 dt below the incumbent (t_lim - 4 dt; the ray's own t_max at first) AND its leaf box lets the reference in by t + dt (the guard); a NaN fails
+                        if (!(tt.t <= t_lim - 4.0f * dt) || !(cur_ex <= tt.t + dt)) {
+                            if (COUNT && !flagged) why = 2u;
+                            flagged = true;
+                        } else if (!flagged) {
+                            t_lim = tt.t + 2.0f * dt;
+                            st |= 1u;
+                            out.hits[idx] = make_float4(out.bary_mode ? tt.bary.z : tt.t, p1.w /* the canonical slot */, tt.bary.x, tt.bary.y);  // stored at once: a nearer candidate overwrites it
+                        }
+                    }
+                }
+            }
+            cur = kRefNone;
+            if (flagged) {  // the reference-order walk decides this ray
+                active = false;
+                to_fb = true;
+                sp = 0;
+                if (COUNT) n_why[why & 3u]++;
+            } else if (sp > 0) {  // the next stack entry against the limit the leaf left
+                sp--;
+                const float t_pop = t_lim + (AXIS ? __fmaf_rn(growth(), inv_max(), mb) : mb);
+                if (top_tm < t_pop && sp < kStack2Total) {
+                    cur = top_enc;
+                    cur_ex = top_tm;
+                }
+            }
+        }
+    }
+    if (ctr) {
+        if (blockIdx.x == 0 && threadIdx.x == 0 && !q.no_total) atomicAdd(&ctr->closest_total, (unsigned long long)seg_total(sv));
+        if (lane_id() == 0 && n_fb) atomicAdd(&ctr->fallback_total, (unsigned long long)n_fb);
+        if (COUNT) {
+            const unsigned long long sn = wave_sum(nn), spr = wave_sum(np);
+            if (lane_id() == 0) {
+                atomicAdd(&ctr->nodes_closest, sn);
+                atomicAdd(&ctr->prims_closest, spr);
+            }
+            for (int k = 0; k < 4; ++k) {
+                const unsigned long long w = wave_sum(n_why[k]);
+                if (lane_id() == 0 && w) atomicAdd(&ctr->fallback_why[k], w);
+            }
+        }
+    }
+}
+
+// ---- one-leaf accelerator (scenes of at most "tiny_scene_prims" primitives: S-cornell, the shadows scene) -------------------------------------------------
+// The accelerator is the list of all primitives in canonical slot order, walked with a wave-uniform index (k_trace_leaf's scheme: scalar loads, no stack).
+// Nothing is culled, so every candidate is seen; what remains of the certificate: a primitive counts only when the t_max-free clauses pass on the box of ITS
+// canonical leaf (cs.slot_boxes), and the acceptance / flag rule of the header (a candidate below g + dt is accepted iff max(t, entry of its leaf box) <= t_max - dt).  Flagged rays go to the fallback list, which k_trace3 walks on the canonical tree.
+template <bool COUNT, bool FULL_ONLY>
+__global__ __launch_bounds__(kBlock, FULL_ONLY ? TH_TRACE_LEAF_WAVES : 4) void k_trace_leaf_c(DeviceScene sc /* canonical records */, WideScene ws /* root box; root_ref / root_cnt = all slots */,
+                                                                              CertScene cs, SegQueue q, const float4* __restrict__ ro, const float4* __restrict__ rd,
+                                                                              const float* __restrict__ tmax_or_null, TraceOut out, Counters* ctr, FallbackList fb) {
+    __shared__ SegView sv;
+    seg_load(q, sv);
+    const uint32_t total = sv.prefix[kSeg];
+    const uint32_t first = ws.root_ref, cnt = ws.root_cnt;
+    const uint32_t gtid = blockIdx.x * kBlock + threadIdx.x;
+    uint32_t nn = 0, np = 0;
+    unsigned long long n_fb = 0;
+    for (uint32_t flat = gtid; flat < total; flat += gridDim.x * kBlock) {
+        uint32_t seg, lb;
+        seg_locate(sv, flat & ~63u, seg, lb);
+        const uint32_t local = lb + (flat & 63u);
+        const bool valid = local < sv.count[seg];
+        uint32_t idx = valid ? seg_phys(q, seg, local) : 0u;
+        if (valid && q.indirect) idx = q.indirect[idx];
+        float4 o4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), d4 = make_float4(0.0f, 0.0f, 1.0f, 0.0f);
+        if (valid) {
+            o4 = ro[idx];
+            d4 = rd[idx];
+        }
+        const f3 o = mk3(o4.x, o4.y, o4.z), d = mk3(d4.x, d4.y, d4.z);
+        const f3 inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+        const bool negx = d.x < 0.0f, negy = d.y < 0.0f, negz = d.z < 0.0f;
+        float t_max = (valid && tmax_or_null) ? tmax_or_null[idx] : kInf;
+        const RayShear shear = ray_shear(d);
+        const float D = slab_margin(ws.root_box, 1.0f, o);
+        const float dt = kCertDt * D * fabsf(shear.sz);
+        float t_lim = t_max + 2.0f * dt;  // t_max + 2 dt (header): the relaxed limit of the primitive tests
+        bool live = false, flagged = false;
+        if (valid) {
+            const bool plain = d.x != 0.0f && d.y != 0.0f && d.z != 0.0f && dt < kInf && fabsf(o.x) < kInf && fabsf(o.y) < kInf && fabsf(o.z) < kInf && fabsf(inv_d.x) < kInf && fabsf(inv_d.y) < kInf &&
+                               fabsf(inv_d.z) < kInf && t_max == t_max;
+            float tmin;
+            if (COUNT) nn++;
+            if (!plain)
+                flagged = true;
+            else  // the root box (bvh.jl:226): the same box in every tree
+                live = slab_test2(ws.root_box[0], ws.root_box[1], ws.root_box[2], ws.root_box[3], ws.root_box[4], ws.root_box[5], o, inv_d, 0.0f, false, negx, negy, negz, tmin) && tmin < t_lim;
+        }
+        bool found = false, sticky = false;
+        float4 rec = make_float4(kInf, __int_as_float(-1), 0.0f, 0.0f);
+#pragma unroll 1
+        for (uint32_t k = 0; k < cnt; ++k) {
+            if (__ballot(live) == 0ull) break;
+            const uint32_t slot = first + k;  // wave-uniform: scalar loads
+            const float4 p0 = uniform_load(sc.prims, 3 * slot);
+            const uint32_t meta = __float_as_uint(p0.w);
+            const float* bx = cs.slot_boxes + 6 * (size_t)slot;
+            const float b0 = uniform_load(bx, 0), b1 = uniform_load(bx, 1), b2 = uniform_load(bx, 2), b3 = uniform_load(bx, 3), b4 = uniform_load(bx, 4), b5 = uniform_load(bx, 5);
+            float t_c = 0.0f;
+            float4 r4 = make_float4(0.0f, __int_as_float((int)slot), 0.0f, 0.0f);
+            bool cand = false, inside = false;
+            if (meta & PRIM_SPHERE) {
+                const SphereRec sr = uniform_load(sc.spheres, __float_as_uint(p0.x));
+                if (live) {
+                    if (COUNT) np++;
+                    const int r = sphere_candidate_c<FULL_ONLY>(sr, o, d, t_lim, t_c);
+                    if (r == 1 || r == 3) {
+                        cand = true;
+                        inside = r == 3;
+                        r4.x = t_c;
+                    } else if (r == 2) {
+                        // clipped — but only a sphere the reference can reach at all (its leaf's t_max-free clauses) makes the order matter
+                        float ex;
+                        if (slab_test2(b0, b1, b2, b3, b4, b5, o, inv_d, 0.0f, false, negx, negy, negz, ex)) flagged = true;
+                    }
+                }
+            } else if (!(meta & PRIM_DEGENERATE)) {
+                const float4 p1 = uniform_load(sc.prims, 3 * slot + 1), p2 = uniform_load(sc.prims, 3 * slot + 2);
+                if (live) {
+                    if (COUNT) np++;
+                    TriTest tt;
+                    if (tri_intersect_sheared<true>(mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z), o, shear, t_lim, &tt)) {
+                        cand = true;
+                        t_c = tt.t;
+                        r4 = make_float4(out.bary_mode ? tt.bary.z : tt.t, __int_as_float((int)slot), tt.bary.x, tt.bary.y);
+                    }
+                }
+            } else if (COUNT && live) {
+                np++;
+            }
+            if (cand) {
+                float ex;
+                if (COUNT) nn++;
+                if (slab_test2(b0, b1, b2, b3, b4, b5, o, inv_d, 0.0f, false, negx, negy, negz, ex)) {  // the reference reaches this primitive's leaf at all
+                    if (sticky || !(t_c <= t_max - 2.0f * dt) || !(ex <= t_c + dt)) {
+                        flagged = true;
+                    } else {
+                        t_max = t_c;
+                        t_lim = t_c + 2.0f * dt;
+                        found = true;
+                        sticky = inside;
+                        rec = r4;
+                    }
+                }
+            }
+            if (flagged) live = false;
+        }
+        const bool to_fb = valid && flagged;
+        if (__ballot(to_fb) != 0ull) {
+            uint32_t fseg = __builtin_amdgcn_readfirstlane((gtid >> 6) % kSeg);
+            bool pending = to_fb;
+            for (int tries = 0; tries < kSeg && __ballot(pending) != 0ull; ++tries) {
+                const uint32_t j = wave_compact(pending, &fb.counts[fseg * kCtrStride]);
+                if (pending && j < fb.cap) {
+                    fb.list[(size_t)fseg * fb.cap + j] = idx;
+                    n_fb++;
+                    pending = false;
+                }
+                fseg = (fseg + 1) % kSeg;
+            }
+        }
+        if (valid && !flagged) out.hits[idx] = found ? rec : make_float4(kInf, __int_as_float(-1), 0.0f, 0.0f);
+    }
+    if (ctr) {
+        if (blockIdx.x == 0 && threadIdx.x == 0 && !q.no_total) atomicAdd(&ctr->closest_total, (unsigned long long)seg_total(sv));
+        const unsigned long long sfb = wave_sum(n_fb);
+        if (lane_id() == 0 && sfb) atomicAdd(&ctr->fallback_total, sfb);
+        if (COUNT) {
+            const unsigned long long sn = wave_sum(nn), spr = wave_sum(np);
+            if (lane_id() == 0) {
+                atomicAdd(&ctr->nodes_closest, sn);
+                atomicAdd(&ctr->prims_closest, spr);
+            }
+        }
+    }
+}
+
+// ---- any-hit rays of a one-leaf accelerator -----------------------------------------------------------------------------------------------------------
+// intersect_p(bvh, ray) is a boolean and the ray's t_max never changes during it (bvh.jl:260-299): a primitive stops the ray iff its canonical leaf's box
+// passes bounds.jl:186-200 with that t_max (its ancestors then pass too: monotonic) and its own test accepts — the same in every tree, in any order.  So the
+// leaf is walked in k_any_leaf's order (solid angle at the lights, two stages), a primitive that accepts the ray additionally has to pass its leaf's box, and
+// only rays with a zero direction component (NaN products) go to the canonical tree.
+template <bool COUNT, bool FULL_ONLY>
+__global__ __launch_bounds__(kBlock, FULL_ONLY ? TH_TRACE_LEAF_WAVES : 4) void k_any_leaf_c(DeviceScene sc, WideScene ws, CertScene cs, SegQueue q, const float4* __restrict__ ro,
+                                                                            const float4* __restrict__ rd, const float* __restrict__ tmax_or_null, TraceOut out, Counters* ctr,
+                                                                            FallbackList fb) {
+    __shared__ SegView sv;
+    __shared__ uint32_t s_ring[kBlock / 64][128];
+    seg_load(q, sv);
+    const uint32_t total = sv.prefix[kSeg];
+    const uint32_t first = ws.root_ref, cnt = ws.root_cnt;
+    const uint32_t lane = lane_id(), wv = threadIdx.x >> 6;
+    const uint32_t gtid = blockIdx.x * kBlock + threadIdx.x;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const uint32_t n_a = min(cnt, (uint32_t)TH_LEAF_STAGE_A);
+    uint32_t nn = 0, np = 0;
+    unsigned long long n_fb = 0;
+    uint32_t ring_head = 0, ring_cnt = 0;  // wave-uniform
+    auto run = [&](uint32_t idx, f3 o, f3 d, uint32_t k0, uint32_t k1, bool& live) {
+        const float t_max = (live && tmax_or_null) ? tmax_or_null[idx] : kInf;
+        const RayShear shear = ray_shear(d);
+        const f3 inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+        bool found = false;
+#pragma unroll 1
+        for (uint32_t k = k0; k < k1; ++k) {
+            if (__ballot(live) == 0ull) break;
+            const uint32_t slot = first + (ws.leaf_order ? uniform_load(ws.leaf_order, k) : k);  // wave-uniform: scalar loads
+            const float4 p0 = uniform_load(sc.prims, 3 * slot);
+            const uint32_t meta = __float_as_uint(p0.w);
+            const float* bx = cs.slot_boxes + 6 * (size_t)slot;
+            const float b0 = uniform_load(bx, 0), b1 = uniform_load(bx, 1), b2 = uniform_load(bx, 2), b3 = uniform_load(bx, 3), b4 = uniform_load(bx, 4), b5 = uniform_load(bx, 5);
+            if (COUNT && lane == 0) np++;
+            bool acc = false;
+            if (meta & PRIM_SPHERE) {
+                const SphereRec sr = uniform_load(sc.spheres, __float_as_uint(p0.x));
+                if (live) {
+                    SphereHit sh;
+                    acc = sphere_intersect<false, FULL_ONLY>(sr, o, d, t_max, sh);
+                }
+            } else if (!(meta & PRIM_DEGENERATE)) {
+                const float4 p1 = uniform_load(sc.prims, 3 * slot + 1), p2 = uniform_load(sc.prims, 3 * slot + 2);
+                if (live) {
+                    TriTest tt;
+                    acc = tri_intersect_sheared<false>(mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z), o, shear, t_max, &tt);
+                }
+            }
+            if (acc) {  // … and the reference reaches the primitive's leaf (bounds.jl:186-200 on its box, the ray's own t_max)
+                float tmin;
+                if (slab_test2(b0, b1, b2, b3, b4, b5, o, inv_d, 0.0f, false, d.x < 0.0f, d.y < 0.0f, d.z < 0.0f, tmin) && tmin < t_max) {
+                    found = true;
+                    live = false;
+                }
+            }
+        }
+        return found;
+    };
+    auto deliver = [&](bool on, uint32_t idx, float4 o4, float4 d4, bool found) {
+        if (!on) return;
+        if (out.L) {
+            const uint32_t slot = __float_as_uint(o4.w);
+            if (!found) {
+                const float4 c = out.contrib[idx];
+                float4 l = out.L[slot];
+                l.x += c.x;
+                l.y += c.y;
+                l.z += c.z;
+                out.L[slot] = l;
+            } else {
+                const uint32_t poison = __float_as_uint(d4.w);
+                if (poison) {
+                    float4 l = out.L[slot];
+                    const float nanv = __builtin_nanf("");
+                    if (poison & 1u) l.x += nanv;
+                    if (poison & 2u) l.y += nanv;
+                    if (poison & 4u) l.z += nanv;
+                    out.L[slot] = l;
+                }
+            }
+        } else {
+            out.occluded[idx] = found ? 1 : 0;
+        }
+    };
+    auto stage_b = [&](uint32_t n) {
+        const bool on = lane < n;
+        const uint32_t idx = on ? s_ring[wv][(ring_head + lane) & 127u] : 0u;
+        float4 o4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), d4 = make_float4(0.0f, 0.0f, 1.0f, 0.0f);
+        if (on) {
+            o4 = ro[idx];
+            d4 = rd[idx];
+        }
+        bool live = on;
+        const bool found = run(idx, mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z), n_a, cnt, live);
+        deliver(on, idx, o4, d4, found);
+    };
+    for (uint32_t flat = gtid; flat < total; flat += gridDim.x * kBlock) {
+        uint32_t seg, lb;
+        seg_locate(sv, flat & ~63u, seg, lb);
+        const uint32_t local = lb + (flat & 63u);
+        const bool valid = local < sv.count[seg];
+        uint32_t idx = valid ? seg_phys(q, seg, local) : 0u;
+        if (valid && q.indirect) idx = q.indirect[idx];
+        float4 o4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), d4 = make_float4(0.0f, 0.0f, 1.0f, 0.0f);
+        if (valid) {
+            o4 = ro[idx];
+            d4 = rd[idx];
+        }
+        const f3 o = mk3(o4.x, o4.y, o4.z), d = mk3(d4.x, d4.y, d4.z);
+        // a zero direction component: NaN products, the monotonicity argument fails — the canonical tree decides
+        const bool to_fb = valid && !(d.x != 0.0f && d.y != 0.0f && d.z != 0.0f);
+        if (__ballot(to_fb) != 0ull) {
+            uint32_t fseg = __builtin_amdgcn_readfirstlane((gtid >> 6) % kSeg);
+            bool pending = to_fb;
+            for (int tries = 0; tries < kSeg && __ballot(pending) != 0ull; ++tries) {
+                const uint32_t j = wave_compact(pending, &fb.counts[fseg * kCtrStride]);
+                if (pending && j < fb.cap) {
+                    fb.list[(size_t)fseg * fb.cap + j] = idx;
+                    n_fb++;
+                    pending = false;
+                }
+                fseg = (fseg + 1) % kSeg;
+            }
+        }
+        bool live = false;
+        if (valid && !to_fb) {
+            const float t_max = tmax_or_null ? tmax_or_null[idx] : kInf;
+            const f3 inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+            float tmin;
+            if (COUNT) nn++;
+            live = slab_test2(ws.root_box[0], ws.root_box[1], ws.root_box[2], ws.root_box[3], ws.root_box[4], ws.root_box[5], o, inv_d, 0.0f, false, d.x < 0.0f, d.y < 0.0f, d.z < 0.0f, tmin) &&
+                   tmin < t_max;
+        }
+        const bool found = run(idx, o, d, 0u, n_a, live);
+        const bool park = live && n_a < cnt;
+        deliver(valid && !to_fb && !park, idx, o4, d4, found);
+        const unsigned long long m = __ballot(park);
+        if (m) {
+            if (park) s_ring[wv][(ring_head + ring_cnt + (uint32_t)__popcll(m & lt_mask)) & 127u] = idx;
+            ring_cnt += (uint32_t)__popcll(m);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (ring_cnt >= 64u) {
+                stage_b(64u);
+                ring_head = (ring_head + 64u) & 127u;
+                ring_cnt -= 64u;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            }
+        }
+    }
+    if (ring_cnt) stage_b(ring_cnt);
+    if (ctr) {
+        // every ray of the queue is counted here, once: the launch that walks the fallback list is told not to (SegQueue::no_total)
+        if (COUNT) {
+            const unsigned long long sn = wave_sum(nn), spr = wave_sum(np);
+            if (lane_id() == 0) {
+                atomicAdd(&ctr->nodes_shadow, sn);
+                atomicAdd(&ctr->prims_shadow, spr);
+            }
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0 && !q.no_total) atomicAdd(&ctr->shadow_total, (unsigned long long)seg_total(sv));
+    }
+    (void)n_fb;
+}
+
+}  // namespace th

@@ -177,7 +177,9 @@ int trhip_set_option(trhip_ctx* ctx, const char* name, int64_t value) {
     else if (!std::strcmp(name, "sppm_batch"))
         ctx->sppm_batch = (uint64_t)std::max<int64_t>(0, value);
     else if (!std::strcmp(name, "bvh_builder"))
-        ctx->bvh_builder = value < 0 ? -1 : (value > 3 ? 3 : (int)value);
+        ctx->bvh_builder = value < 0 ? -1 : (value > 4 ? 4 : (int)value);
+    else if (!std::strcmp(name, "hybrid"))
+        ctx->hybrid = value != 0;
     else if (!std::strcmp(name, "film_transpose"))
         ctx->film_transpose = value != 0;
     else if (!std::strcmp(name, "band_tile_rows"))

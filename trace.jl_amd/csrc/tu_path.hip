@@ -541,8 +541,8 @@ int render_impl_band(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
         for (int depth = 1; depth <= max_depth; ++depth) {
             const ShadowQueue& sq = sqs[depth & 1];
             tm.begin(1, ps);
-            launch_trace(ctx, ps, scene, false, SegQueue{ctr->n_queue[depth - 1], cap, 0u}, pq[cur].o, pq[cur].d, nullptr, TraceOut{hits, nullptr, nullptr, nullptr, bary_mode}, ctr->work_closest[depth - 1], ctr,
-                         pp.overflow[0].p);
+            launch_trace(ctx, ps, scene, false, SegQueue{ctr->n_queue[depth - 1], cap, 0u}, pq[cur].o, pq[cur].d, nullptr,
+                         TraceOut{hits, nullptr, nullptr, nullptr, bary_mode, depth == 1 && far_camera(scene, sensor) ? 1u : 0u}, ctr->work_closest[depth - 1], ctr, pp.overflow[0].p);
             tm.end(1, ps);
             if (two && depth > 2) HIP_TRY(ctx, hipStreamWaitEvent(ps, ev_anys[depth & 1], 0));  // shade(d) refills the queue the shadow rays of depth d - 2 read
             tm.begin(2, ps);

@@ -653,6 +653,284 @@ int upload_scene(trhip_scene* s) {
     return 0;
 }
 
+// ---- the accelerator of the hybrid mode (th_trace3c.h) ------------------------------------------------------------------------------------------------
+// `s->bvh` (canonical: the reference's construction or the host's own tree) has been uploaded by upload_scene; `s->acc` is the library's tree over the same
+// primitives (acc.order[k] = caller primitive).  Derives: the accelerator's primitive records in ITS leaf order with the canonical slot in the second
+// record's .w lane, its children-in-parent nodes, the per-sphere / per-slot canonical leaf boxes the certificate reads — and verifies what the certificate
+// assumes: every accelerator leaf has, bit for bit, the box of the canonical leaf of each of its primitives.  Anything that does not fit leaves
+// hybrid_ok = false: every ray then walks the canonical tree (same answers).
+int upload_accelerator(trhip_scene* s) {
+    trhip_ctx* ctx = s->ctx;
+    CommitClock clk;
+    s->hybrid_ok = false;
+    std::memset(&s->wide_acc, 0, sizeof s->wide_acc);
+    s->wide_acc.root_ref = kRefNone;
+    s->cert = CertScene{};
+    s->dev_acc = s->dev;
+    const uint32_t n_prims = (uint32_t)s->bvh.order.size(), n_cnodes = (uint32_t)s->bvh.a.size(), n_anodes = (uint32_t)s->acc.a.size();
+    if (!s->wide_ok || s->literal_only || n_prims == 0 || n_anodes == 0 || s->acc.order.size() != n_prims || n_prims >= (1u << 24)) return 0;
+    if (s->wide.root_cnt > 0) return 0;  // the canonical tree is one leaf: nothing to accelerate
+    // canonical slot of every caller primitive, and the box of the canonical leaf that holds each canonical slot
+    std::vector<uint32_t> cslot(s->prims.size(), 0xffffffffu);
+    for (uint32_t k = 0; k < n_prims; ++k) cslot[s->bvh.order[k]] = k;
+    std::vector<float> slot_box((size_t)n_prims * 6, 0.0f);
+    std::vector<uint8_t> covered(n_prims, 0);
+    parallel_for(n_cnodes, [&](size_t i0, size_t i1) {
+        for (size_t i = i0; i < i1; ++i) {
+            if ((s->bvh.flags[i] & 3u) != 3u) continue;
+            const uint32_t first = s->bvh.a[i], cnt = s->bvh.flags[i] >> 2;
+            for (uint32_t k = first; k < first + cnt && k < n_prims; ++k) {
+                std::memcpy(&slot_box[6 * (size_t)k], &s->bvh.bounds[6 * i], 6 * sizeof(float));
+                covered[k] = 1;
+            }
+        }
+    });
+    for (uint32_t k = 0; k < n_prims; ++k)
+        if (!covered[k]) return 0;  // (a foreign tree that leaves a primitive out)
+    for (uint32_t k = 0; k < n_prims; ++k)
+        if (s->acc.order[k] >= s->prims.size() || cslot[s->acc.order[k]] == 0xffffffffu) return 0;
+    // per sphere: its canonical leaf's box
+    std::vector<float> sph_box(std::max<size_t>(1, s->spheres.size()) * 6, 0.0f);
+    for (uint32_t k = 0; k < n_prims; ++k) {
+        const HostPrim& p = s->prims[s->bvh.order[k]];
+        if (p.kind == 1 && p.sphere_id < s->spheres.size()) std::memcpy(&sph_box[6 * (size_t)p.sphere_id], &slot_box[6 * (size_t)k], 6 * sizeof(float));
+    }
+    std::vector<uint32_t> sph_slot(std::max<size_t>(1, s->spheres.size()), 0u);
+    for (uint32_t k = 0; k < n_prims; ++k) {
+        const HostPrim& p = s->prims[s->bvh.order[k]];
+        if (p.kind == 1 && p.sphere_id < s->spheres.size()) sph_slot[p.sphere_id] = k;
+    }
+    if (s->spheres.size() > kCertMaxSpheres) return 0;  // the certified walk tests EVERY sphere when it fetches a ray: a scene of many spheres keeps the canonical tree alone
+    if (int rc = upload(ctx, s->d_sphere_boxes, sph_box.data(), sph_box.size() * sizeof(float))) return rc;
+    if (int rc = upload(ctx, s->d_sphere_slots, sph_slot.data(), sph_slot.size() * sizeof(uint32_t))) return rc;
+    s->cert.sphere_boxes = (const float*)s->d_sphere_boxes.p;
+    s->cert.sphere_slots = (const uint32_t*)s->d_sphere_slots.p;
+    s->cert.n_spheres = (uint32_t)s->spheres.size();
+    std::memcpy(s->wide_acc.root_box, &s->bvh.bounds[0], 6 * sizeof(float));  // the union of all primitives: the same box in every tree (bvh.jl:226 tests it first)
+    const bool one_leaf = n_anodes == 1 && (s->acc.flags[0] & 3u) == 3u;
+    if (one_leaf) {
+        // every primitive in one leaf: walked over the CANONICAL records in canonical slot order (k_trace_leaf_c / k_any_leaf_c)
+        if (n_prims > 255) return 0;
+        if (int rc = upload(ctx, s->d_slot_boxes, slot_box.data(), slot_box.size() * sizeof(float))) return rc;
+        s->cert.slot_boxes = (const float*)s->d_slot_boxes.p;
+        s->wide_acc.root_ref = 0;
+        s->wide_acc.root_cnt = n_prims;
+        s->wide_acc.leaf_order = nullptr;
+        if (n_prims > 1 && !s->lights.empty()) {  // any-hit rays try what subtends the largest solid angle at the lights first (as k_any_leaf: any order gives the same boolean)
+            std::vector<std::pair<double, uint32_t>> ord;
+            for (uint32_t k = 0; k < n_prims; ++k) {
+                const HostPrim& p = s->prims[s->bvh.order[k]];
+                double w = 0.0;
+                for (const LightRec& l : s->lights) {
+                    const float* lp = l.position;
+                    if (p.kind == 1) {
+                        const HostAABB& b = s->sphere_bounds[p.sphere_id];
+                        double c[3], r = 0.0, d2 = 0.0;
+                        for (int a = 0; a < 3; ++a) {
+                            c[a] = 0.5 * ((double)b.mn[a] + b.mx[a]);
+                            r = std::max(r, 0.5 * ((double)b.mx[a] - b.mn[a]));
+                            d2 += (c[a] - lp[a]) * (c[a] - lp[a]);
+                        }
+                        w += d2 <= r * r ? 4.0 * 3.14159265358979 : 2.0 * 3.14159265358979 * (1.0 - std::sqrt(std::max(0.0, 1.0 - r * r / d2)));
+                    } else {
+                        double r[3][3], len[3];
+                        for (int v = 0; v < 3; ++v) {
+                            for (int c = 0; c < 3; ++c) r[v][c] = (double)p.v[3 * v + c] - lp[c];
+                            len[v] = std::sqrt(r[v][0] * r[v][0] + r[v][1] * r[v][1] + r[v][2] * r[v][2]);
+                        }
+                        const double det = r[0][0] * (r[1][1] * r[2][2] - r[1][2] * r[2][1]) - r[0][1] * (r[1][0] * r[2][2] - r[1][2] * r[2][0]) + r[0][2] * (r[1][0] * r[2][1] - r[1][1] * r[2][0]);
+                        auto dot3 = [&](int a, int b) { return r[a][0] * r[b][0] + r[a][1] * r[b][1] + r[a][2] * r[b][2]; };
+                        const double den = len[0] * len[1] * len[2] + dot3(0, 1) * len[2] + dot3(0, 2) * len[1] + dot3(1, 2) * len[0];
+                        w += 2.0 * std::fabs(std::atan2(det, den));
+                    }
+                }
+                ord.push_back({w, k});
+            }
+            std::stable_sort(ord.begin(), ord.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
+            std::vector<uint32_t> order(n_prims);
+            for (uint32_t k = 0; k < n_prims; ++k) order[k] = ord[k].second;
+            if (int rc = upload(ctx, s->d_acc_leaf_order, order.data(), order.size() * sizeof(uint32_t))) return rc;
+            s->wide_acc.leaf_order = (const uint32_t*)s->d_acc_leaf_order.p;
+        }
+        s->hybrid_ok = true;
+        clk.tick("accelerator: one leaf");
+        return 0;
+    }
+    // ---- a hierarchy: leaf boxes must be the canonical leaves' ----
+    std::atomic<bool> bad{false};
+    parallel_for(n_anodes, [&](size_t i0, size_t i1) {
+        for (size_t i = i0; i < i1 && !bad; ++i) {
+            if ((s->acc.flags[i] & 3u) != 3u) {
+                if (s->acc.a[i] <= i + 1 || s->acc.a[i] >= n_anodes) bad = true;
+                continue;
+            }
+            const uint32_t first = s->acc.a[i], cnt = s->acc.flags[i] >> 2;
+            if (cnt == 0 || cnt > 255 || (uint64_t)first + cnt > n_prims) {
+                bad = true;
+                continue;
+            }
+            for (uint32_t k = first; k < first + cnt; ++k)
+                if (std::memcmp(&s->acc.bounds[6 * i], &slot_box[6 * (size_t)cslot[s->acc.order[k]]], 6 * sizeof(float)) != 0) bad = true;
+        }
+    });
+    if (bad || (s->acc.flags[0] & 3u) == 3u) return 0;
+    if (std::memcmp(&s->acc.bounds[0], &s->bvh.bounds[0], 6 * sizeof(float)) != 0) return 0;
+    clk.tick("accelerator: leaf boxes");
+    // ---- per canonical slot, per sphere: where the reference's walk meets the primitive relative to the sphere (th_trace3c.h: a ray that starts inside a sphere only counts what
+    //      the reference tests AFTER that sphere).  3 bits per sphere: the split axis of the canonical node where the two root paths part (3: they share a leaf) and whether the
+    //      primitive is in that node's SECOND child (in a shared leaf: behind the sphere).  The depth-first layout makes a subtree's slots one contiguous range. ----
+    std::vector<uint32_t> order_word(n_prims, 0u);
+    {
+        auto leftmost = [&](uint32_t i, uint32_t& slot) {
+            for (uint32_t guard = 0; guard < 4096u && i < n_cnodes; ++guard) {
+                if ((s->bvh.flags[i] & 3u) == 3u) {
+                    slot = s->bvh.a[i];
+                    return true;
+                }
+                ++i;
+            }
+            return false;
+        };
+        for (uint32_t sid = 0; sid < (uint32_t)s->spheres.size(); ++sid) {
+            const uint32_t ks = sph_slot[sid], sh = 3u * sid;
+            uint32_t i = 0, lo = 0, hi = n_prims;
+            bool ok = false;
+            for (uint32_t guard = 0; guard < 4096u && i < n_cnodes; ++guard) {
+                if ((s->bvh.flags[i] & 3u) == 3u) {
+                    const uint32_t first = s->bvh.a[i], cnt = s->bvh.flags[i] >> 2;
+                    ok = ks - first < cnt && first == lo && first + cnt == hi;
+                    for (uint32_t k = first; ok && k < first + cnt; ++k)
+                        if (k != ks) order_word[k] |= (3u | (k > ks ? 4u : 0u)) << sh;
+                    break;
+                }
+                const uint32_t second = s->bvh.a[i], axis = s->bvh.flags[i] & 3u;
+                uint32_t lo2 = 0;
+                if (second <= i + 1 || second >= n_cnodes || !leftmost(second, lo2) || lo2 < lo || lo2 > hi) break;
+                if (ks >= lo2) {
+                    for (uint32_t k = lo; k < lo2; ++k) order_word[k] |= axis << sh;
+                    lo = lo2;
+                    i = second;
+                } else {
+                    for (uint32_t k = lo2; k < hi; ++k) order_word[k] |= (axis | 4u) << sh;
+                    hi = lo2;
+                    i = i + 1;
+                }
+            }
+            if (!ok) return 0;  // (a layout this walk does not understand: the canonical tree alone)
+        }
+    }
+    // primitive records in the accelerator's order; the canonical slot rides in the second record's .w lane, the order word in the third's
+    RawArray<float4> aprims((size_t)n_prims * 3);
+    std::vector<uint8_t> is_sphere(n_prims, 0);
+    parallel_for(n_prims, [&](size_t k0, size_t k1) {
+        for (size_t k = k0; k < k1; ++k) {
+            const HostPrim& p = s->prims[s->acc.order[k]];
+            const float cs = __builtin_bit_cast(float, cslot[s->acc.order[k]]);
+            if (p.kind == 1) {
+                aprims[3 * k] = make_float4(__builtin_bit_cast(float, p.sphere_id), 0, 0, __builtin_bit_cast(float, p.meta));
+                aprims[3 * k + 1] = make_float4(0, 0, 0, cs);
+                aprims[3 * k + 2] = make_float4(0, 0, 0, 0);
+                is_sphere[k] = 1;
+            } else {
+                aprims[3 * k] = make_float4(p.v[0], p.v[1], p.v[2], __builtin_bit_cast(float, p.meta));
+                aprims[3 * k + 1] = make_float4(p.v[3], p.v[4], p.v[5], cs);
+                aprims[3 * k + 2] = make_float4(p.v[6], p.v[7], p.v[8], __builtin_bit_cast(float, order_word[cslot[s->acc.order[k]]]));
+            }
+        }
+    });
+    if (int rc = upload(ctx, s->d_acc_prims, aprims.data(), aprims.size() * sizeof(float4))) return rc;
+    clk.tick("accelerator: primitive records");
+    // ---- what the certificate's lower bound needs of the TRIANGLES (th_trace3c.h; spheres are never hidden from the walk): per axis the largest extent of a NON-FLAT triangle
+    //      (the computed t of a primitive differs from the depth of the ray's point on it by at most the primitive's extent along the ray's dominant axis), and for FLAT ones
+    //      (zero extent in some axis: walls, floors — of any size) the largest L^3 / (2 A) (how far the edge functions' rounding can move that point) ----
+    {
+        std::mutex lock;
+        float mle[3] = {0.0f, 0.0f, 0.0f}, sq = 0.0f;
+        parallel_for(s->prims.size(), [&](size_t i0, size_t i1) {
+            float m[3] = {0.0f, 0.0f, 0.0f}, q = 0.0f;
+            for (size_t i = i0; i < i1; ++i) {
+                const HostPrim& p = s->prims[i];
+                if (p.kind != 0 || (p.meta & PRIM_DEGENERATE)) continue;
+                float e[3];
+                for (int c = 0; c < 3; ++c) e[c] = std::fmax(std::fmax(p.v[c], p.v[3 + c]), p.v[6 + c]) - std::fmin(std::fmin(p.v[c], p.v[3 + c]), p.v[6 + c]);
+                if (e[0] == 0.0f || e[1] == 0.0f || e[2] == 0.0f) {
+                    double ab[3], ac[3];
+                    for (int c = 0; c < 3; ++c) {
+                        ab[c] = (double)p.v[3 + c] - p.v[c];
+                        ac[c] = (double)p.v[6 + c] - p.v[c];
+                    }
+                    const double bc[3] = {ac[0] - ab[0], ac[1] - ab[1], ac[2] - ab[2]};
+                    const double l2 = std::max({ab[0] * ab[0] + ab[1] * ab[1] + ab[2] * ab[2], ac[0] * ac[0] + ac[1] * ac[1] + ac[2] * ac[2], bc[0] * bc[0] + bc[1] * bc[1] + bc[2] * bc[2]});
+                    const double cx = ab[1] * ac[2] - ab[2] * ac[1], cy = ab[2] * ac[0] - ab[0] * ac[2], cz = ab[0] * ac[1] - ab[1] * ac[0];
+                    const double area2 = std::sqrt(cx * cx + cy * cy + cz * cz);  // 2 A
+                    if (area2 > 0.0) q = std::fmax(q, (float)(l2 * std::sqrt(l2) / area2) * 1.0001f);
+                } else {
+                    for (int a = 0; a < 3; ++a)
+                        if (e[a] < INFINITY) m[a] = std::fmax(m[a], e[a]);
+                }
+            }
+            std::lock_guard<std::mutex> g(lock);
+            for (int a = 0; a < 3; ++a) mle[a] = std::fmax(mle[a], m[a]);
+            sq = std::fmax(sq, q);
+        });
+        for (int a = 0; a < 3; ++a) s->cert.mle_small[a] = mle[a];
+        s->cert.sq_flat = sq;
+        if (std::getenv("TRHIP_COMMIT_TIMING")) std::fprintf(stderr, "[commit] certificate: mle %g %g %g, sq_flat %g\n", mle[0], mle[1], mle[2], sq);
+    }
+    // children-in-parent nodes (as upload_scene's, th_trace2.h)
+    std::vector<uint32_t> widx(n_anodes, 0);
+    uint32_t n_int = 0;
+    for (uint32_t i = 0; i < n_anodes; ++i)
+        if ((s->acc.flags[i] & 3u) != 3u) widx[i] = n_int++;
+    if (n_int >= (1u << 24)) return 0;
+    std::vector<uint8_t> has_sphere(n_anodes, 0);
+    for (uint32_t i = n_anodes; i-- > 0;) {  // bottom-up (second children and first children both come later in the depth-first layout)
+        if ((s->acc.flags[i] & 3u) == 3u) {
+            const uint32_t first = s->acc.a[i], cnt = s->acc.flags[i] >> 2;
+            if (!s->spheres.empty())
+                for (uint32_t k = first; k < first + cnt; ++k) has_sphere[i] |= is_sphere[k];
+        } else {
+            has_sphere[i] = has_sphere[i + 1] | has_sphere[s->acc.a[i]];
+        }
+    }
+    RawArray<float4> wn((size_t)n_int * 4);
+    parallel_for(n_anodes, [&](size_t i0, size_t i1) {
+        for (size_t i = i0; i < i1; ++i) {
+            if ((s->acc.flags[i] & 3u) == 3u) continue;
+            const uint32_t c[2] = {(uint32_t)i + 1, s->acc.a[i]};
+            uint32_t ref[2], cnt[2];
+            for (int k = 0; k < 2; ++k) {
+                if ((s->acc.flags[c[k]] & 3u) == 3u) {
+                    ref[k] = s->acc.a[c[k]];
+                    cnt[k] = s->acc.flags[c[k]] >> 2;
+                } else {
+                    ref[k] = widx[c[k]];
+                    cnt[k] = 0;
+                }
+            }
+            const float* l = &s->acc.bounds[6 * (size_t)c[0]];
+            const float* r = &s->acc.bounds[6 * (size_t)c[1]];
+            float4* w = &wn[4 * (size_t)widx[i]];
+            w[0] = make_float4(l[0], l[1], l[2], l[3]);
+            w[1] = make_float4(l[4], l[5], r[0], r[1]);
+            w[2] = make_float4(r[2], r[3], r[4], r[5]);
+            // child word = ref | count << 24 (the stack entry format); meta = split axis | "subtree holds a sphere" bits 2 (first) / 3 (second)
+            w[3] = make_float4(__builtin_bit_cast(float, ref[0] | (cnt[0] << 24)), __builtin_bit_cast(float, ref[1] | (cnt[1] << 24)),
+                               __builtin_bit_cast(float, (s->acc.flags[i] & 3u) | ((uint32_t)has_sphere[c[0]] << 2) | ((uint32_t)has_sphere[c[1]] << 3)), 0.0f);
+        }
+    });
+    if (int rc = upload(ctx, s->d_acc_wnodes, wn.data(), wn.size() * sizeof(float4))) return rc;
+    s->wide_acc.wnodes = (const float4*)s->d_acc_wnodes.p;
+    s->wide_acc.n_wnodes = n_int;
+    s->wide_acc.root_ref = 0;
+    s->wide_acc.root_cnt = 0;
+    s->wide_acc.leaf_tight = s->wide.leaf_tight;
+    s->dev_acc.prims = (const float4*)s->d_acc_prims.p;
+    s->hybrid_ok = true;
+    clk.tick("accelerator: wnodes");
+    return 0;
+}
+
 extern "C" {
 
 int trhip_scene_new(trhip_ctx* ctx, trhip_scene** out) {
@@ -680,6 +958,12 @@ void trhip_scene_free(trhip_scene* s) {
     release(s->d_occ_boxes);
     release(s->d_w8nodes);
     release(s->d_w8tris);
+    release(s->d_acc_wnodes);
+    release(s->d_acc_prims);
+    release(s->d_slot_boxes);
+    release(s->d_sphere_boxes);
+    release(s->d_sphere_slots);
+    release(s->d_acc_leaf_order);
     delete s;
 }
 int trhip_scene_add_material(trhip_scene* s, int kind, const float* params, int n_params, uint32_t* id_out) {
@@ -834,78 +1118,128 @@ int trhip_scene_add_spot_light_fields(trhip_scene* s, const float* l2w, const fl
     return add_light(s, 1, l2w, l2w_inv, I, cos_total, cos_falloff, true);
 }
 
-int trhip_scene_commit(trhip_scene* s, int max_node_primitives) {
-    CommitClock clk;
-    if (!s) return fail(nullptr, TRHIP_ERR_INVALID, "null scene");
-    HIP_TRY(s->ctx, hipSetDevice(s->ctx->device));
-    std::vector<HostAABB> pb(s->prims.size());
+// world_bound of every primitive in caller order (triangle_mesh.jl:97, Shape.jl:17-19)
+static void primitive_bounds(const trhip_scene* s, std::vector<HostAABB>& pb) {
+    pb.resize(s->prims.size());
     parallel_for(s->prims.size(), [&](size_t i0, size_t i1) {
         for (size_t i = i0; i < i1; ++i) {
             const HostPrim& p = s->prims[i];
             if (p.kind == 1) {
                 pb[i] = s->sphere_bounds[p.sphere_id];
-            } else {  // world_bound(triangle) triangle_mesh.jl:97
+            } else {
                 pb[i].reset();
                 for (int j = 0; j < 3; ++j) pb[i].grow_point(&p.v[3 * j]);
             }
         }
     });
-    clk.tick("commit: primitive bounds");
-    // Scenes with a few spheres beside a mesh: a chain root -> {sphere 1, {sphere 2, ... {sphere k, the triangles' subtree}}}.  Any BVH2 is a valid
-    // BVHAccel (results depend on the topology only through exact-t ties, SURVEY.md A.6); this one keeps the spheres — whose fp32
-    // quadratic accepts rays far outside their box and can raise t_max (A.18) — out of the triangles' subtree, which the 8-wide
-    // kernel then walks with conservative interior boxes (th_wide8.h).  The leaf-size hint is a hint (bvh.jl:159-165 decides by cost).
-    std::vector<uint32_t> sph_ids, tri_ids;
-    for (size_t i = 0; i < s->prims.size(); ++i) (s->prims[i].kind == 1 ? sph_ids : tri_ids).push_back((uint32_t)i);
-    const bool want_chain = s->ctx->compose_spheres > 0 || (s->ctx->compose_spheres < 0 && s->ctx->traversal == 4);
-    const bool compose = s->ctx->bvh_builder != 2 && want_chain && !sph_ids.empty() && sph_ids.size() <= (size_t)kW8MaxSpheres && tri_ids.size() >= 2 && pb.size() > s->ctx->tiny_scene_prims;
-    std::vector<HostAABB> pb_sub;
-    if (compose) {
-        pb_sub.reserve(tri_ids.size());
-        for (uint32_t id : tri_ids) pb_sub.push_back(pb[id]);
-    }
-    const std::vector<HostAABB>& pb_build = compose ? pb_sub : pb;
+}
+
+// The LIBRARY's tree over primitive bounds `pb_build` (binned SAH on the device from 64 Ki primitives, on the host below and for what the device builder hands back;
+// mode 1: the linear BVH).  `mode` as option "bvh_builder" (2 / 4 are the caller's business).
+static int build_library_tree(trhip_ctx* ctx, const std::vector<HostAABB>& pb_build, int max_node_primitives, int mode, bool want_chain, FlatBVH& out) {
     bool built = false;
-    const int mode = s->ctx->bvh_builder;
-    s->ctx->bvh_device_ms = 0.0;
-    if (mode == 2) {
-        // the reference's own construction, node for node (th_bvh_ref.h): also for scenes the default would commit as one leaf, never composed
-        try {
-            RefBVHBuilder rb(pb, max_node_primitives);
-            s->bvh = rb.build();
-        } catch (const std::exception& e) {
-            return fail(s->ctx, TRHIP_ERR_UNSUPPORTED, "bvh_builder 2: %s", e.what());
-        }
-        if (s->bvh.max_depth > (uint32_t)(kStackLds + kStackSpill))
-            return fail(s->ctx, TRHIP_ERR_UNSUPPORTED, "BVH depth %u exceeds the 64-entry traversal stack (bvh.jl:222 throws a BoundsError there)", s->bvh.max_depth);
-        s->literal_only = false;
-        return upload_scene(s);
-    }
-    if ((mode == 3 || (mode < 0 && pb_build.size() >= (64u << 10))) && pb_build.size() > s->ctx->tiny_scene_prims) {
+    ctx->bvh_device_ms = 0.0;
+    if ((mode == 3 || ((mode < 0 || mode == 4) && pb_build.size() >= (64u << 10))) && pb_build.size() > ctx->tiny_scene_prims) {
         // the host builder's binned SAH, on the device (th_sahb.h); scenes it hands back (TRHIP_ERR_UNSUPPORTED) go to the host builder below
         FlatBVH dev;
-        const int rc = build_bvh_device_sah(s->ctx, pb_build, max_node_primitives, want_chain, dev, &s->ctx->bvh_device_ms);
+        const int rc = build_bvh_device_sah(ctx, pb_build, max_node_primitives, want_chain, dev, &ctx->bvh_device_ms);
         if (rc == 0) {
-            s->bvh = std::move(dev);
+            out = std::move(dev);
             built = true;
         } else if (rc != TRHIP_ERR_UNSUPPORTED) {
             return rc;
         }
     }
-    if (!built && mode == 1 && pb_build.size() > s->ctx->tiny_scene_prims) {
+    if (!built && mode == 1 && pb_build.size() > ctx->tiny_scene_prims) {
         FlatBVH dev;
-        const int rc = build_bvh_device(s->ctx, pb_build, dev);
+        const int rc = build_bvh_device(ctx, pb_build, dev);
         if (rc == 0) {
-            s->bvh = std::move(dev);
+            out = std::move(dev);
             built = true;
         } else if (rc != TRHIP_ERR_UNSUPPORTED) {
             return rc;
         }
     }
     if (!built) {
-        BVHBuilder builder(pb_build, max_node_primitives, s->ctx->tiny_scene_prims, want_chain);  // traversal 4 wants one primitive per leaf
-        s->bvh = builder.build();
+        BVHBuilder builder(pb_build, max_node_primitives, ctx->tiny_scene_prims, want_chain);  // traversal 4 wants one primitive per leaf
+        out = builder.build();
     }
+    return 0;
+}
+
+static void drop_accelerator(trhip_scene* s) {
+    s->acc = FlatBVH();
+    s->hybrid_ok = false;
+    std::memset(&s->wide_acc, 0, sizeof s->wide_acc);
+    s->wide_acc.root_ref = kRefNone;
+    release(s->d_acc_wnodes);
+    release(s->d_acc_prims);
+    release(s->d_slot_boxes);
+    release(s->d_acc_leaf_order);
+}
+
+int trhip_scene_commit(trhip_scene* s, int max_node_primitives) {
+    CommitClock clk;
+    if (!s) return fail(nullptr, TRHIP_ERR_INVALID, "null scene");
+    HIP_TRY(s->ctx, hipSetDevice(s->ctx->device));
+    std::vector<HostAABB> pb;
+    primitive_bounds(s, pb);
+    clk.tick("commit: primitive bounds");
+    drop_accelerator(s);
+    // Scenes with a few spheres beside a mesh: a chain root -> {sphere 1, {sphere 2, ... {sphere k, the triangles' subtree}}}.  Any BVH2 is a valid
+    // BVHAccel (results depend on the topology only through exact-t ties, SURVEY.md A.6); this one keeps the spheres — whose fp32
+    // quadratic accepts rays far outside their box and can raise t_max (A.18) — out of the triangles' subtree, which the 8-wide
+    // kernel then walks with conservative interior boxes (th_wide8.h).  The leaf-size hint is a hint (bvh.jl:159-165 decides by cost).
+    std::vector<uint32_t> sph_ids, tri_ids;
+    for (size_t i = 0; i < s->prims.size(); ++i) (s->prims[i].kind == 1 ? sph_ids : tri_ids).push_back((uint32_t)i);
+    const int mode = s->ctx->bvh_builder;
+    const bool want_chain = s->ctx->compose_spheres > 0 || (s->ctx->compose_spheres < 0 && s->ctx->traversal == 4);
+    const bool compose = mode != 2 && want_chain && !sph_ids.empty() && sph_ids.size() <= (size_t)kW8MaxSpheres && tri_ids.size() >= 2 && pb.size() > s->ctx->tiny_scene_prims;
+    // HYBRID (mode 4, and the default -1): the canonical tree is the reference's own construction — the answers are Trace.jl's, ray for ray — and the library's tree
+    // rides along as the accelerator most rays walk instead (th_trace3c.h).  Not with the sphere chain (a layout only traversal 4 asks for).
+    const bool want_hybrid = (mode == 4 || mode < 0) && !want_chain;
+    s->ctx->bvh_device_ms = 0.0;
+    if (mode == 2 || want_hybrid) {
+        // the reference's own construction, node for node (th_bvh_ref.h): also for scenes the library would commit as one leaf, never composed
+        bool ok = true;
+        std::string why;
+        try {
+            RefBVHBuilder rb(pb, max_node_primitives);
+            s->bvh = rb.build();
+        } catch (const std::exception& e) {
+            ok = false;
+            why = e.what();
+        }
+        if (ok && s->bvh.max_depth > (uint32_t)(kStackLds + kStackSpill)) {
+            ok = false;
+            why = "BVH depth " + std::to_string(s->bvh.max_depth) + " exceeds the 64-entry traversal stack (bvh.jl:222 throws a BoundsError there)";
+        }
+        clk.tick("commit: reference tree");
+        if (ok) {
+            s->literal_only = false;
+            s->bvh_mode = 1;
+            if (int rc = upload_scene(s)) return rc;
+            if (!want_hybrid) return 0;
+            if (int rc = build_library_tree(s->ctx, pb, max_node_primitives, mode, false, s->acc)) return rc;
+            clk.tick("commit: accelerator tree");
+            if (int rc = upload_accelerator(s)) return rc;
+            if (s->hybrid_ok)
+                s->bvh_mode = 2;
+            else
+                drop_accelerator(s);
+            return 0;
+        }
+        // Where the reference's own constructor fails (its recursion does not end, or its tree outgrows its 64-entry stack) there is no Trace.jl answer to reproduce:
+        // an explicit request is an error, the default falls back to the library's tree alone
+        if (mode == 2 || mode == 4) return fail(s->ctx, TRHIP_ERR_UNSUPPORTED, "bvh_builder %d: %s", mode, why.c_str());
+    }
+    std::vector<HostAABB> pb_sub;
+    if (compose) {
+        pb_sub.reserve(tri_ids.size());
+        for (uint32_t id : tri_ids) pb_sub.push_back(pb[id]);
+    }
+    const std::vector<HostAABB>& pb_build = compose ? pb_sub : pb;
+    if (int rc = build_library_tree(s->ctx, pb_build, max_node_primitives, mode, want_chain, s->bvh)) return rc;
     clk.tick("commit: tree");
     if (compose) {
         // flat layout (bvh.jl:187-206): chain node i at 2 i = interior {leaf of sphere i at 2 i + 1, rest at 2 i + 2}; the triangles' subtree at 2 n_sph
@@ -957,6 +1291,7 @@ int trhip_scene_commit(trhip_scene* s, int max_node_primitives) {
     if (s->bvh.max_depth > (uint32_t)(kStackLds + kStackSpill))
         return fail(s->ctx, TRHIP_ERR_UNSUPPORTED, "BVH depth %u exceeds the 64-entry traversal stack (bvh.jl:222)", s->bvh.max_depth);
     s->literal_only = false;
+    s->bvh_mode = 0;
     return upload_scene(s);
 }
 int trhip_build_bvh_host(int builder, const float* prim_bounds, uint32_t n_prims, int max_node_primitives, float* node_bounds, uint32_t* node_a, uint32_t* node_flags, uint32_t* n_nodes_inout,
@@ -1001,6 +1336,22 @@ int trhip_scene_get_bvh(const trhip_scene* s, float* bounds, uint32_t* a, uint32
     if (a) std::memcpy(a, s->bvh.a.data(), s->bvh.a.size() * sizeof(uint32_t));
     if (flags) std::memcpy(flags, s->bvh.flags.data(), s->bvh.flags.size() * sizeof(uint32_t));
     if (order) std::memcpy(order, s->bvh.order.data(), s->bvh.order.size() * sizeof(uint32_t));
+    return 0;
+}
+int trhip_scene_bvh_mode(const trhip_scene* s, int* mode, uint32_t* accel_nodes, uint32_t* accel_depth) {
+    if (!s) return TRHIP_ERR_INVALID;
+    if (mode) *mode = s->bvh_mode;
+    if (accel_nodes) *accel_nodes = s->hybrid_ok ? (uint32_t)s->acc.a.size() : 0u;
+    if (accel_depth) *accel_depth = s->hybrid_ok ? s->acc.max_depth : 0u;
+    return 0;
+}
+int trhip_scene_get_accelerator(const trhip_scene* s, float* bounds, uint32_t* a, uint32_t* flags, uint32_t* order) {
+    if (!s) return TRHIP_ERR_INVALID;
+    if (!s->hybrid_ok) return fail(s->ctx, TRHIP_ERR_INVALID, "the scene has no accelerator tree (trhip_scene_bvh_mode)");
+    if (bounds) std::memcpy(bounds, s->acc.bounds.data(), s->acc.bounds.size() * sizeof(float));
+    if (a) std::memcpy(a, s->acc.a.data(), s->acc.a.size() * sizeof(uint32_t));
+    if (flags) std::memcpy(flags, s->acc.flags.data(), s->acc.flags.size() * sizeof(uint32_t));
+    if (order) std::memcpy(order, s->acc.order.data(), s->acc.order.size() * sizeof(uint32_t));
     return 0;
 }
 int trhip_scene_set_bvh(trhip_scene* s, const float* bounds, const uint32_t* a, const uint32_t* flags, uint32_t n_nodes, const uint32_t* order, uint32_t n_prims) {
@@ -1063,7 +1414,32 @@ int trhip_scene_set_bvh(trhip_scene* s, const float* bounds, const uint32_t* a, 
     // only when boxes nest; a foreign tree that does not is walked by the literal kernels (the reference's loop, op for op).
     s->literal_only = !nested;
     HIP_TRY(s->ctx, hipSetDevice(s->ctx->device));
-    return upload_scene(s);
+    drop_accelerator(s);
+    s->bvh_mode = 1;
+    if (int rc = upload_scene(s)) return rc;
+    // The host's own tree is the canonical one (Trace.jl's BVHAccel through TraceHIP.jl): under the default / hybrid builder the library's tree over the same
+    // primitives rides along as the accelerator (th_trace3c.h) — same answers, most rays on the cheaper tree.  Needs every primitive in the tree exactly once.
+    const int mode = s->ctx->bvh_builder;
+    const bool want_chain = s->ctx->compose_spheres > 0 || (s->ctx->compose_spheres < 0 && s->ctx->traversal == 4);
+    if ((mode == 4 || mode < 0) && !want_chain && nested && n_prims == s->prims.size()) {
+        std::vector<uint8_t> seen(n_prims, 0);
+        bool perm = true;
+        for (uint32_t i = 0; i < n_prims && perm; ++i) {
+            perm = !seen[order[i]];
+            seen[order[i]] = 1;
+        }
+        if (perm) {
+            std::vector<HostAABB> pb;
+            primitive_bounds(s, pb);
+            if (int rc = build_library_tree(s->ctx, pb, 1, mode, false, s->acc)) return rc;
+            if (int rc = upload_accelerator(s)) return rc;
+            if (s->hybrid_ok)
+                s->bvh_mode = 2;
+            else
+                drop_accelerator(s);
+        }
+    }
+    return 0;
 }
 
 }  // extern "C"

@@ -178,8 +178,8 @@ int render_sppm_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
         int cur = 0;
         for (int depth = 1; depth <= max_depth; ++depth) {
             tm.begin(1, st);
-            launch_trace(ctx, st, scene, false, SegQueue{ctr->n_queue[depth - 1], cap, 0u}, pq[cur].o, pq[cur].d, nullptr, TraceOut{hits, nullptr, nullptr, nullptr}, ctr->work_closest[depth - 1], ctr,
-                         pp.overflow[0].p);
+            launch_trace(ctx, st, scene, false, SegQueue{ctr->n_queue[depth - 1], cap, 0u}, pq[cur].o, pq[cur].d, nullptr,
+                         TraceOut{hits, nullptr, nullptr, nullptr, 0u, depth == 1 && far_camera(scene, sensor) ? 1u : 0u}, ctr->work_closest[depth - 1], ctr, pp.overflow[0].p);
             tm.end(1, st);
             tm.begin(2, st);
             if (scene->dev.tri_tan)

@@ -45,6 +45,11 @@ static bool uses_trace7(const trhip_ctx* ctx, const trhip_scene* sc) { return ct
 // which kernel launch_trace picks for this scene, and the bytes one unit of the visit counters stands for (trhip_stats)
 void traversal_info(const trhip_ctx* ctx, const trhip_scene* sc, uint32_t* trav, uint32_t* node_bytes) {
     uint32_t t = 1, nb = 32;
+    if (hybrid_active(ctx, sc)) {
+        *trav = 9;  // the certified walk on the accelerator tree + the reference-order walk of the flagged rays on the canonical tree (th_trace3c.h)
+        *node_bytes = sc->wide_acc.root_cnt > 0 ? 0 : 32;
+        return;
+    }
     if (ctx->traversal >= 2 && sc->wide_ok) {
         if (sc->wide.root_cnt > 0 && ctx->leaf_kernel && ctx->debug_trace_budget == 0) {
             t = 5;
@@ -74,6 +79,32 @@ void launch_trace(trhip_ctx* ctx, hipStream_t st, const trhip_scene* sc, bool an
     const bool v2 = ctx->traversal >= 2 && sc->wide_ok;
     const bool cnt = ctx->count_visits;
     const bool full_only = !sc->partial_spheres;  // no clipped sphere in the scene: kernels without the Float64 atan2 path
+    // ---- hybrid mode (th_trace3c.h): the scene holds the canonical tree (the reference's construction / the host's own) AND the library's tree as an accelerator.
+    //      Closest-hit rays walk the accelerator with the order-independence certificate; the rays it flags come back on fallback lists that k_trace3 walks on the
+    //      canonical tree right after.  Any-hit rays of a one-leaf accelerator likewise (only rays with a zero direction component need the canonical tree); any-hit
+    //      rays of a hierarchy take the canonical path below (pre-pass on the largest triangles + k_trace3 on the canonical tree).
+    if (hybrid_active(ctx, sc) && !q.indirect && (!any || sc->wide_acc.root_cnt > 0)) {
+        const int w = any ? 1 : 0;
+        const uint32_t fcap = q.counts ? q.cap : (q.n_dense + kSeg - 1) / kSeg;
+        const size_t ctr_words = 2 * (size_t)kSeg * kCtrStride;  // counts, then the work cursors of the fallback launch
+        if (ensure(ctx, ctx->fb_list[w], (size_t)fcap * kSeg * sizeof(uint32_t)) == 0 && ensure(ctx, ctx->fb_counts[w], ctr_words * sizeof(uint32_t)) == 0) {
+            uint32_t* fcounts = (uint32_t*)ctx->fb_counts[w].p;
+            (void)hipMemsetAsync(fcounts, 0, ctr_words * sizeof(uint32_t), st);
+            const FallbackList fb{(uint32_t*)ctx->fb_list[w].p, fcounts, fcap};
+            uint2* ov = (uint2*)(overflow_slab ? overflow_slab : ctx->overflow.p);
+            const size_t canon_bytes = (size_t)sc->wide.n_wnodes * 64u + (size_t)sc->dev.n_prims * 48u;
+            if (sc->wide_acc.root_cnt > 0) {
+                launch_leaf_c(ctx, st, sc, any, cnt, full_only, q, ro, rd, tmax, out, ctr, fb);
+            } else {
+                const bool big = !cnt && (size_t)sc->wide_acc.n_wnodes * 64u + (size_t)sc->dev.n_prims * 48u > ((size_t)256 << 20);
+                launch_trace3c(ctx, st, sc, cnt, full_only, big, q, ro, rd, tmax, out, work_cursors, ov, ctr, fb);
+            }
+            // the flagged rays, in the reference's order on the canonical tree (already counted: no_total)
+            const SegQueue fq{fcounts, fcap, 0u, fb.list, 1u};
+            launch_trace3(ctx, st, sc, any, cnt, full_only, !any && !cnt && canon_bytes > ((size_t)256 << 20), fq, ro, rd, tmax, out, fcounts + (size_t)kSeg * kCtrStride, ov, ctr);
+            return;
+        }
+    }
     if (v2 && ctx->traversal >= 3 && sc->wide.root_cnt == 0) {  // k_trace8 / k_trace3; a single-leaf scene has nothing to postpone and runs k_trace_leaf / k_trace2
         uint2* ov = (uint2*)(overflow_slab ? overflow_slab : ctx->overflow.p);
         if (any && sc->n_occluders && ctx->occluder_pretest && ctx->pipelines <= 1 && !q.indirect) {

@@ -73,7 +73,8 @@ int render_whitted_impl(trhip_ctx* ctx, const trhip_scene* scene, const DeviceSe
         for (int depth = 1; depth <= max_depth; ++depth) {
             const uint32_t base_in = (uint32_t)((uint64_t)(depth - 1) * Pphys), base_out = (uint32_t)((uint64_t)depth * Pphys);
             tm.begin(1, st);
-            launch_trace(ctx, st, scene, false, SegQueue{ctr->n_queue[depth - 1], cap, 0u}, pq[cur].o, pq[cur].d, nullptr, TraceOut{hits, nullptr, nullptr, nullptr}, ctr->work_closest[depth - 1], ctr);
+            launch_trace(ctx, st, scene, false, SegQueue{ctr->n_queue[depth - 1], cap, 0u}, pq[cur].o, pq[cur].d, nullptr,
+                         TraceOut{hits, nullptr, nullptr, nullptr, 0u, depth == 1 && far_camera(scene, sensor) ? 1u : 0u}, ctr->work_closest[depth - 1], ctr);
             tm.end(1, st);
             tm.begin(2, st);
             hipLaunchKernelGGL(k_shade_whitted, dim3(g_shade), blk, 0, st, scene->dev, pq[cur], pq[cur ^ 1], sq, cap, cap_shadow, hits, pool, base_in, base_out, ctr, flags, depth, max_depth);
