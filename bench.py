@@ -28,7 +28,9 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 KERNEL_CLASSES = ("raygen", "trace_closest", "shade", "trace_any", "film")
-TRAVERSAL_KERNEL = {1: "k_trace_closest", 2: "k_trace2", 3: "k_trace3", 4: "k_trace8", 5: "k_trace_leaf", 6: "k_trace4", 7: "k_trace7"}
+TRAVERSAL_KERNEL = {1: "k_trace_closest", 2: "k_trace2", 3: "k_trace3", 4: "k_trace8", 5: "k_trace_leaf", 6: "k_trace4", 7: "k_trace7", 9: "k_trace3c"}
+BVH_MODE = {0: "library-sah", 1: "reference", 2: "hybrid"}  # trhip_scene_bvh_mode: which tree(s) the scene holds (include/tracehip.h)
+L2_PLUS_MALL_BYTES = (32 + 256) << 20  # 8 x 4 MiB L2 + 256 MiB Infinity Cache (MI355X_MICROARCH.md): a scene below this is served from cache, not HBM
 TRAVERSAL_KERNEL_ANY = {1: "k_trace_any", 2: "k_trace2", 3: "k_trace3", 4: "k_trace8", 5: "k_trace_leaf", 6: "k_trace4", 7: "k_trace3"}
 
 
@@ -64,9 +66,11 @@ def kernel_bytes(st, film_px: int):
         48 B next ray + 48 B shadow ray written = 288 B;
     raygen: 48 B (o, d, beta) written per camera sample; film: 24 B (radiance + film position) per camera sample + 16 B per film pixel."""
     nb = int(st.node_bytes)
-    leaf = int(st.traversal) == 5
+    leaf = int(st.traversal) == 5 or (int(st.traversal) == 9 and nb == 0)
     return {
         "trace_closest": st.closest_rays * 48 + (0 if leaf else st.nodes_visited * nb + st.prims_tested * 48),
+        # hybrid mode: the part of trace_closest that is the fallback walks' (k_trace3 on the canonical tree: its rays read again, its nodes are always 32 B per box)
+        "trace_fallback": st.fallback_rays * 48 + st.nodes_visited_fallback * 32 + st.prims_tested_fallback * 48,
         "trace_any": st.shadow_rays * 64 + (0 if leaf else st.nodes_visited_shadow * nb + st.prims_tested_shadow * 48),
         "shade": st.closest_rays * 288,
         "film": st.camera_samples * 24 + film_px * 16,
@@ -126,7 +130,7 @@ def pmc_child_runs(args, kernel_prefix: str, want_any: bool, passes):
 # (one 64-byte request each: FETCH_SIZE tallies REQUESTS at 64 B), 0.590 for 48-byte records (they straddle request boundaries).  The traversal kernels' reads are
 # 64-byte node gathers (1 510 of ~1 760 B per ray on S-mesh), 48-byte primitive records and a 32-byte ray stream: factor 1.0.  When the request-size counters
 # (TCC_EA0_RDREQ_{32B,64B,128B}) are available the bench uses their exact byte count instead of any factor.
-FETCH_FACTOR = {"default": 2.0, "k_trace3": 1.0, "k_trace2": 1.0, "k_trace7": 1.0, "k_trace4": 1.0, "k_trace_closest": 1.0, "k_sppm_gather": 1.0}
+FETCH_FACTOR = {"default": 2.0, "k_trace3": 1.0, "k_trace3c": 1.0, "k_trace2": 1.0, "k_trace7": 1.0, "k_trace4": 1.0, "k_trace_closest": 1.0, "k_sppm_gather": 1.0}
 
 
 def measure_counters(args, kernel_prefix: str, want_any: bool):
@@ -324,6 +328,7 @@ def run_sppm(args, T, ctx, graft, rank, world, comm_ok):
                                      f"SPPMIntegrator, {args.res}x{args.res}, {args.iterations} iterations, {info['photons_per_iteration']} photons per iteration, max depth {args.depth}, "
                                      f"radius {args.radius}, seed {args.seed:#x}",
                          "rays_per_step": int(rays / args.steps), "ms_per_iteration": round(elapsed / args.steps / args.iterations * 1e3, 3), "bvh_build_upload_s": round(t_build, 3),
+                         "bvh": BVH_MODE.get(flat.bvh_mode()[0], "?"), "fallback_fraction": round(sv.fallback_rays / max(1, sv.closest_rays), 5), "traversal": int(sv.traversal),
                          "parallelism": f"photon indices sharded x{world}, camera pass replicated (its rays counted once), one RCCL all-reduce of phi / M per iteration inside libtracehip" if world > 1 else "single GPU",
                          "rccl_ranks": ctx.comm_rank()[1]},
               "roofline": roofline, "cpu_baseline": cpu}
@@ -352,6 +357,7 @@ def main():
     ap.add_argument("--iterations", type=int, default=100, help="caustic_sppm: SPPM iterations per step")
     ap.add_argument("--radius", type=float, default=0.075, help="caustic_sppm: initial search radius")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="library option (trhip_set_option) set before the scene is committed; repeatable")
+    ap.add_argument("--no-modes", action="store_true", help="skip the two short comparison runs on the library's tree alone and on the reference's tree alone (`bvh_modes`)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -446,7 +452,7 @@ def main():
             step()
         sync()
         t_start = time.perf_counter()
-        agg = {"samples": 0, "ms": {k: 0.0 for k in KERNEL_CLASSES}, "launches": {}, "closest": 0, "shadow": 0, "fallback": 0}
+        agg = {"samples": 0, "ms": {k: 0.0 for k in KERNEL_CLASSES}, "launches": {}, "closest": 0, "shadow": 0, "fallback": 0, "ms_fallback": 0.0, "launches_fallback": 0}
         reduce_s[0] = 0.0
         for _ in range(steps):
             st = step()
@@ -454,6 +460,8 @@ def main():
             agg["shadow"] += st.shadow_rays
             agg["samples"] += st.camera_samples
             agg["fallback"] += st.fallback_rays
+            agg["ms_fallback"] += st.ms_fallback
+            agg["launches_fallback"] += st.launches_fallback
             for k in agg["ms"]:
                 agg["ms"][k] += getattr(st, "ms_" + k)
                 agg["launches"][k] = agg["launches"].get(k, 0) + getattr(st, "launches_" + k)
@@ -481,6 +489,11 @@ def main():
         steps = args.steps
         roofline = None
         sv = integ.stats
+        bvh_mode, n_acc_nodes, _ = flat.bvh_mode()
+        _bvh = flat.bvh()
+        n_canonical_nodes = int(_bvh[1].size)
+        n_scene_bytes = 32 * (n_acc_nodes if bvh_mode == 2 else n_canonical_nodes) + 48 * int(_bvh[3].size)  # what the dominant walk reads: its tree's boxes + the primitive records
+        modes = None
         if not args.no_visits:
             # ---- roofline of the dominant kernel (rank 0's launches): live HIP-event durations from the timed region, bytes from an
             #      untimed instrumented pass of the same frame (node / primitive visit counts) ----
@@ -489,20 +502,29 @@ def main():
             sv = integ.stats
             ctx.set_option("count_visits", 0)
             per_step = kernel_bytes(sv, h * w)
+            hybrid = int(sv.traversal) == 9
+            fb_bytes = per_step.pop("trace_fallback")
             # the shadow rays of depth d run on a second, low-priority stream beside the closest-hit rays of depth d+1: their HIP-event
             # time is wall time under contention, not the kernel's own — never the dominant kernel of these workloads; left out of the choice
             dominant = max((k for k in agg["ms"] if k != "trace_any"), key=lambda k: agg["ms"][k])
             dom_ms = agg["ms"][dominant] / max(1, agg["launches"][dominant])
             dom_bytes = per_step[dominant] * steps / max(1, agg["launches"][dominant])
-            achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
             kname = {"trace_closest": TRAVERSAL_KERNEL.get(int(sv.traversal), "k_trace"), "shade": "k_shade_path", "film": "k_film_gather", "raygen": "k_raygen"}[dominant]
+            if hybrid and dominant == "trace_closest":
+                # a hybrid closest-hit launch = the certified walk on the accelerator tree (k_trace3c, the dominant kernel) + the reference-order walk of the rays it hands back
+                # (k_trace3 on the canonical tree); the library times the hand-over inside every launch (trhip_stats.ms_fallback): the roofline is k_trace3c's alone
+                dom_ms = (agg["ms"]["trace_closest"] - agg["ms_fallback"]) / max(1, agg["launches"]["trace_closest"])
+                dom_bytes = (per_step["trace_closest"] - fb_bytes) * steps / max(1, agg["launches"]["trace_closest"])
+            achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
             kprefix = kname
             gbps = {k: round(per_step[k] / (agg["ms"][k] / steps * 1e-3) / 1e9, 1) if agg["ms"][k] > 0 else None for k in per_step}
             roofline = {"bound": "hbm", "kernel": kname + ("<closest>" if dominant == "trace_closest" else ""), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "avg_launch_ms": round(dom_ms, 4), "launches": agg["launches"][dominant],
                         "algorithmic_bytes_per_launch": int(dom_bytes),
-                        "frac_note": "frac = ALGORITHMIC bytes (what the kernel asks the memory system for: rays, hits, every node and primitive fetch — L2 and MALL serve part of it) "
-                                     "/ launch time / HBM peak; frac_counters = bytes that left L2 (2 x FETCH_SIZE + WRITE_SIZE) / launch time / HBM peak",
+                        "frac_requests": round(achieved / HBM_PEAK_GBS, 5),
+                        "frac_note": "frac_requests = ALGORITHMIC bytes (what the kernel asks the memory system for: rays, hits, every node and primitive fetch — SURVEY 8(d)) / launch time / HBM "
+                                     "peak: a request rate, L2 and the 256 MiB MALL serve part of it; frac_counters = bytes that left L2 (rocprofv3 --pmc) / launch time / HBM peak.  `frac` is the "
+                                     "counter figure whenever the scene's nodes + primitives fit L2 + MALL (then the request rate says nothing about HBM), else the request rate",
                         "visits_per_ray": {"closest_nodes": round(sv.nodes_visited / max(1, sv.closest_rays), 2), "closest_prims": round(sv.prims_tested / max(1, sv.closest_rays), 2),
                                            "shadow_nodes": round(sv.nodes_visited_shadow / max(1, sv.shadow_rays), 2), "shadow_prims": round(sv.prims_tested_shadow / max(1, sv.shadow_rays), 2),
                                            "node_bytes": int(sv.node_bytes), "traversal": int(sv.traversal)},
@@ -510,9 +532,15 @@ def main():
                         "kernel_ms_note": "HIP-event time per kernel class, one stream (option overlap = 0, the default)",
                         "kernel_GBps_note": "algorithmic bytes / class time; the traversal classes count REQUESTS (32 B per box tested, 48 B per primitive fetched): L2 and MALL serve part of them, so they may exceed the HBM peak — achieved_counters / frac_counters is what left L2",
                         "kernel_GBps": gbps}
+            if hybrid:
+                roofline["hybrid"] = {"certified_walk_ms_per_step": round((agg["ms"]["trace_closest"] - agg["ms_fallback"]) / steps, 3), "fallback_walk_ms_per_step": round(agg["ms_fallback"] / steps, 3),
+                                      "fallback_launches": agg["launches_fallback"], "fallback_nodes_per_fallback_ray": round(sv.nodes_visited_fallback / max(1, sv.fallback_rays), 1),
+                                      "fallback_why": dict(zip(("direction", "sphere", "near_tie_or_guard"), [int(x) for x in sv.count_sub[:3]])),
+                                      "note": "closest-hit launch = k_trace3c on the accelerator tree (the library's SAH tree, walked under the order-independence certificate) + k_trace3 on the "
+                                              "canonical tree (the reference's own) over the rays handed back; kernel_ms_per_step.trace_closest is both"}
             over = [k for k, v in gbps.items() if v is not None and v > HBM_PEAK_GBS and not k.startswith("trace")]
             # no line may carry a fraction above 1 without saying so: a request rate above the HBM peak means L2 / MALL serve part of the requests
-            roofline["byte_models_within_peak"] = not over and roofline["frac"] <= 1.0
+            roofline["byte_models_within_peak"] = not over and roofline["frac_requests"] <= 1.0
             if over:
                 sys.stderr.write(f"[bench] byte model exceeds the HBM peak for {over}: those bytes are not being moved\n")
             if dominant.startswith("trace"):
@@ -558,6 +586,33 @@ def main():
         if world == 1 and not args.no_micro:
             micro = micro_benchmark(args, T, ctx, flat, osc if not args.no_cpu_baseline else None)
         rccl_ranks = ctx.comm_rank()[1]
+        if world == 1 and bvh_mode == 2 and not args.no_modes:
+            # the same frame on either tree alone, a few steps each: what the hybrid default is measured against
+            modes = {}
+            m_steps = max(1, min(steps, 3))
+
+            def frame_ms(n):
+                it = T.PathIntegrator(cam, T.SeededSampler(args.spp, seed=args.seed), args.depth)
+                it.render(scene, ctx, device_out=film.data_ptr())
+                t1 = time.perf_counter()
+                rays = 0
+                for _ in range(n):
+                    it.render(scene, ctx, device_out=film.data_ptr())
+                    rays += it.stats.closest_rays + it.stats.shadow_rays
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t1
+                return {"ms_per_step": round(dt / n * 1e3, 3), "Mray_s": round(rays / dt / 1e6, 2), "closest_ms": round(it.stats.ms_trace_closest, 3), "steps": n}
+
+            ctx.set_option("hybrid", 0)  # every ray on the canonical (reference) tree: the same answers bit for bit
+            modes["reference_tree_alone"] = dict(frame_ms(m_steps), exact=True, note="option hybrid = 0: k_trace3 on the reference's own tree; same film as the hybrid default")
+            ctx.set_option("hybrid", 1)
+            ctx.set_option("bvh_builder", 0)
+            scene._flat = None
+            flat.free()
+            flat = scene.flatten(ctx)
+            modes["library_tree_alone"] = dict(frame_ms(m_steps), exact=False, note="option bvh_builder = 0: the library's SAH tree alone — fastest, but rays whose answer depends on the "
+                                                                                      "visiting order (ties, a sphere entered from inside) resolve in ITS order, not Trace.jl's")
+            ctx.set_option("bvh_builder", -1)
         if roofline and want_counters:
             # the PMC child runs render the same workload in their own process: this one's wavefront buffers are sized to what was free (0.85 of HBM for a
             # 4096^2 frame) and would leave them nothing — release the scene and the context first
@@ -575,6 +630,19 @@ def main():
             if valu:
                 roofline["valu"] = valu
             roofline["bound"] = classify_bound(roofline)
+        if roofline:
+            # which fraction the line leads with: a scene that fits L2 + MALL is not served from HBM, so its request rate is no HBM fraction — the counter figure is
+            scene_bytes = n_scene_bytes
+            roofline["scene_bytes"] = int(scene_bytes)
+            roofline["scene_fits_l2_plus_mall"] = bool(scene_bytes <= L2_PLUS_MALL_BYTES)
+            if roofline.get("frac_counters") is not None and (scene_bytes <= L2_PLUS_MALL_BYTES or roofline["frac_requests"] > 1.0):
+                roofline["frac"] = roofline["frac_counters"]
+                roofline["achieved"] = roofline["achieved_counters"]
+                roofline["frac_is"] = "counters (bytes that left L2)"
+            else:
+                roofline["frac_is"] = "requests (algorithmic bytes)"
+                if roofline["frac"] > 1.0:  # no counters in this run: a request rate above the peak is not a bandwidth
+                    roofline["frac"] = None
         spp_r = shard(args.scaling)[0]
         result = {
             "metric": "Mray/s (all bounces)", "value": round(total_rays / elapsed / 1e6, 2), "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -584,10 +652,19 @@ def main():
                                    + f", max depth {args.depth}, PathIntegrator, seed {args.seed:#x}",
                        "rays_per_step": int(total_rays / args.steps), "samples_per_step": int(total_samples / args.steps), "bvh_build_upload_s": round(t_build, 3),
                        "traversal": int(sv.traversal),
+                       "bvh": BVH_MODE.get(bvh_mode, str(bvh_mode)), "bvh_nodes": {"canonical": n_canonical_nodes, "accelerator": n_acc_nodes},
+                       "fallback_fraction": round(agg["fallback"] / max(1, agg["closest"]), 5),
                        "parallelism": f"sample-index sharding x{world} + film sum-reduce over RCCL (trhip_film_reduce)" if world > 1 else "single GPU",
                        "rccl_ranks": rccl_ranks, "film_reduce_ms_per_step": round(agg["film_reduce_ms_per_step"], 3) if world > 1 else 0.0},
             "roofline": roofline, "cpu_baseline": cpu,
+            "parity": {"vs": "the CPU oracle walking the reference's own tree (accel/bvh.jl:55-206, restated in oracle/orc_build.h)" if bvh_mode != 0 else
+                             "the CPU oracle walking the library's tree (NOT Trace.jl's tie-breaks: option bvh_builder selects it)",
+                       "bits": "equal", "tolerance": "0 ulp (bit-exact; SURVEY 8(d)'s 1e-3 radiance tolerance is not used)",
+                       "checked_in_this_run": (micro or {}).get("gpu_equals_cpu_on_subset"),
+                       "where": "tests/test_gpu_hybrid.py, tests/test_gpu_scale.py, tools/soak_hybrid.py (-m gpu); traversal_micro compares 2^21 rays in this run"},
         }
+        if modes:
+            result["bvh_modes"] = modes
         if micro:
             result["traversal_micro"] = micro
         if other:

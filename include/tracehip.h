@@ -41,7 +41,7 @@ void trhip_shutdown(trhip_ctx* ctx);
 /* ctx may be NULL to read the message of a failed trhip_init. */
 const char* trhip_last_error(const trhip_ctx* ctx);
 /* ABI version of this header: major*1000 + minor. */
-int trhip_version(void);  /* 3000 */
+int trhip_version(void);  /* 3001 */
 
 /* ---- scene flattening (replaces the Scene / BVHAccel / GeometricPrimitive object graph) --------------------------- */
 /* Scene(lights, aggregate)  Trace.jl:176-187 */
@@ -157,7 +157,8 @@ typedef struct {
     double ms_raygen, ms_trace_closest, ms_shade, ms_trace_any, ms_film;
     uint32_t launches_raygen, launches_trace_closest, launches_shade, launches_trace_any, launches_film;
     uint32_t n_batches, max_depth_reached;
-    uint32_t traversal;      /* traversal kernel that ran: 1 literal, 2, 3 binary children-in-parent walk, 4 8-wide nodes, 5 one-leaf scene */
+    uint32_t traversal;      /* traversal kernel that ran: 1 literal, 2, 3 binary children-in-parent walk, 4 8-wide nodes, 5 one-leaf scene, 9 hybrid: the certified
+                                walk on the accelerator tree + the reference-order walk of the rays it hands back (trhip_scene_bvh_mode) */
     uint32_t node_bytes;     /* bytes fetched per unit of nodes_visited: 32 (a node box of the binary kernels: 64-byte node = 2 boxes),
                                 96 (one 8-wide node: six 16-byte loads from one 128-byte line), 0 (one-leaf scene: scalar loads) */
     /* ---- since ABI 3000 ---- */
@@ -171,7 +172,14 @@ typedef struct {
     uint64_t count_sub[4];    /* trhip_render_sppm with "count_visits": [0] (pixel, photon) candidates distance-tested by the gather, [1] pairs accepted
                                  (BSDF evaluated), [2] photon hits binned, [3] visible points.  trhip_render_path with traversal 7 and "count_visits": why rays went to
                                  the reference-order walk — [0] zero / non-finite direction, [1] a sphere (origin inside, limb, clipped), [2] a candidate within the gap of
-                                 the ray's own t_max, [3] a second candidate within the gap of the nearest.  Otherwise zeros */
+                                 the ray's own t_max, [3] a second candidate within the gap of the nearest.  Hybrid mode (traversal 9) with "count_visits": why rays went to the
+                                 canonical tree — [0] a zero / non-finite direction component or a near-axis-parallel direction, [1] a sphere (clipped; inside two at once),
+                                 [2] a candidate within 2 dt of the incumbent or before its own leaf box's entry.  Otherwise zeros */
+    /* ---- since ABI 3001: hybrid mode (traversal 9).  Of ms_trace_closest / nodes_visited / prims_tested, the part of the FALLBACK walks (k_trace3 over the rays the
+       certified walk handed back, on the canonical tree); the certified walk on the accelerator tree (k_trace3c) is the difference ---- */
+    double ms_fallback;
+    uint32_t launches_fallback, reserved0;
+    uint64_t nodes_visited_fallback, prims_tested_fallback;
 } trhip_stats;
 
 /* ---- integrators (replace `integrator(scene)`, integrators/sampler.jl:12-56) ---------------------------------------

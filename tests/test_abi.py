@@ -18,7 +18,7 @@ def test_every_declared_symbol_is_exported(T):
     assert declared <= exported, f"declared but not exported: {sorted(declared - exported)}"
     assert declared == set(T._ffi.SIGNATURES), f"ctypes table out of sync: {sorted(declared ^ set(T._ffi.SIGNATURES))}"
     lib = T.lib()
-    assert lib.trhip_version() == 3000
+    assert lib.trhip_version() == 3001
 
 
 def test_no_cpu_fallback(T):

@@ -64,6 +64,10 @@ def test_cropped_film(T, ob, ctx):
             ctx.set_option("film_block", 5)
 
 
+def GP_sphere(T, centre, material, radius=0.03):
+    return T.GeometricPrimitive(T.Sphere(T.ShapeCore(T.translate(centre), False), radius, 360.0), material)
+
+
 def test_degenerate_triangles_and_single_leaf_threshold(T, ob, ctx):
     """Zero-area triangles are never hit (is_degenerate, triangle_mesh.jl:65-68; flagged at commit); 16 primitives make one
     leaf of the LIBRARY's tree (the accelerator of the default hybrid commit, th_trace3c.h), 17 a hierarchy; the canonical tree is the reference's either way."""
@@ -73,8 +77,11 @@ def test_degenerate_triangles_and_single_leaf_threshold(T, ob, ctx):
     idx = np.uint32([1, 2, 3, 1, 3, 4, 5, 6, 7, 7, 8, 9])  # two real triangles, a point triangle, a collinear one
     for extra in (12, 13):  # 4 + 12 = 16 primitives -> one leaf; 17 -> a tree
         prims = [T.GeometricPrimitive(t, white) for t in T.create_triangle_mesh(core, 4, idx, 9, verts)]
-        for k in range(extra):
-            prims.append(T.GeometricPrimitive(T.Sphere(T.ShapeCore(T.translate([0.1 + 0.07 * k, 0.5, -2.4]), False), 0.03, 360.0), white))
+        for k in range(6):  # (more than 8 spheres would leave the scene without an accelerator: th_trace3c.h kCertMaxSpheres)
+            prims.append(GP_sphere(T, [0.1 + 0.14 * k, 0.5, -2.4], white))
+        n_small = extra - 6
+        v2 = np.float32([[0.05 + 0.12 * k + dx, 0.2 + dy, -2.35] for k in range(n_small) for dx, dy in ((0, 0), (0.1, 0), (0, 0.1))])
+        prims += [T.GeometricPrimitive(t, white) for t in T.create_triangle_mesh(core, n_small, np.arange(1, 3 * n_small + 1, dtype=np.uint32), 3 * n_small, v2)]
         scene = T.Scene(T.scenes.cornell_lights(), T.BVHAccel(prims, 1))
         flat = scene.flatten(ctx)
         bounds, a, flags, order = flat.bvh()

@@ -215,3 +215,26 @@ def test_sppm_in_hybrid_mode(T, ob, hyb_ctx):
     assert_bits_equal(got["Ld"], ref["Ld"], "Ld")
     scene._flat = None
     flat.free()
+
+
+def test_more_than_eight_spheres_keep_the_canonical_tree_alone(T, ob, hyb_ctx):
+    """The certified walk tests every sphere for every ray (th_trace3c.h kCertMaxSpheres = 8): a scene with more commits without an accelerator (mode 1) and every ray
+    walks the reference's tree — same bits as the oracle."""
+    prims, _ = T.scenes.cornell_primitives(spheres=False)
+    white = T.MatteMaterial(T.ConstantTexture(T.RGBSpectrum(0.7)), T.ConstantTexture(0.0))
+    glass = T.GlassMaterial(T.ConstantTexture(T.RGBSpectrum(1.0)), T.ConstantTexture(T.RGBSpectrum(1.0)), T.ConstantTexture(0.0), T.ConstantTexture(0.0), T.ConstantTexture(1.5), True)
+    for k in range(9):
+        c = [0.1 + 0.1 * k, 0.1 + 0.25 * (k % 3), -2.8 + 0.2 * (k % 4)]
+        prims.append(T.GeometricPrimitive(T.Sphere(T.ShapeCore(T.translate(c), False), 0.09, 360.0), glass if k % 2 else white))
+    scene = T.Scene(T.scenes.cornell_lights(), T.BVHAccel(prims, 1))
+    flat = scene.flatten(hyb_ctx)
+    assert flat.bvh_mode()[0] == 1
+    osc = ob.OracleScene.from_scene(scene)
+    assert np.array_equal(flat.bvh()[1], osc.get_bvh()[1])
+    cam = T.scenes.cornell_camera(24)
+    ref, _, _ = osc.render(cam, "path", 2, 5, seed=3)
+    integ = T.PathIntegrator(cam, T.SeededSampler(2, seed=3), 5)
+    assert_bits_equal(integ.render(scene, hyb_ctx), ref, "film (9 spheres, canonical tree alone)")
+    assert integ.stats.fallback_rays == 0 and integ.stats.traversal == 3
+    scene._flat = None
+    flat.free()

@@ -17,9 +17,11 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--workload", default="mesh_1m")
 ap.add_argument("--spp", type=int, default=64)
 ap.add_argument("--no-spheres", action="store_true", help="mesh_* workloads: the Cornell box without its two spheres")
+ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="library option set before the commit (bvh_builder=0: the library's tree alone -> k_trace3)")
+ap.add_argument("--certified", action="store_true", help="read k_trace3c's counters (the hybrid mode's walk on the accelerator tree) instead of k_trace3's")
 a = ap.parse_args()
 L = T.lib()
-fn = L.trhip_debug_phases
+fn = L.trhip_debug_phases_c if a.certified else L.trhip_debug_phases
 fn.restype = C.c_int
 fn.argtypes = [C.POINTER(C.c_uint64), C.c_int]
 scene, cam, desc = bench.build_workload(T, a.workload, 1024)
@@ -30,6 +32,9 @@ if a.no_spheres:
     prims = prims + [T.create_mesh_primitives(T.ShapeCore(T.translate([0, 0, 0]), False), idx, verts, nrm, grey)]
     scene = T.Scene(T.scenes.cornell_lights(), T.BVHAccel(prims, 1))
 ctx = T.default_context()
+for kv in a.opt:
+    k_, v_ = kv.split("=")
+    ctx.set_option(k_, int(v_))
 out = np.zeros(13, np.uint64)
 integ = T.PathIntegrator(cam, T.SeededSampler(a.spp, seed=1), 8)
 integ.render(scene, ctx)

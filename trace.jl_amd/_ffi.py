@@ -65,6 +65,11 @@ class Stats(C.Structure):
         ("ms_sub", C.c_double * 4),
         ("launches_sub", C.c_uint32 * 4),
         ("count_sub", C.c_uint64 * 4),
+        ("ms_fallback", C.c_double),
+        ("launches_fallback", C.c_uint32),
+        ("reserved0", C.c_uint32),
+        ("nodes_visited_fallback", C.c_uint64),
+        ("prims_tested_fallback", C.c_uint64),
     ]
 
     def as_dict(self):

@@ -48,8 +48,10 @@ struct Pipe {
     DevBuf q[2][3], sq[3], sq2[3], hits, counters, overflow[2];  // sq / sq2: the shadow queues of odd / even depths (any(d) may still run while shade(d+1) fills the other)
 };
 
+struct Timer;
 struct trhip_ctx {
     int device = 0;
+    Timer* active_timer = nullptr;  // the Timer of the render call in progress (hybrid launches mark the hand-over between their two walks in it)
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;  // shadow rays of depth d overlap with the closest-hit rays of depth d+1
     std::string err;
@@ -163,7 +165,7 @@ struct trhip_scene {
     FlatBVH acc;                   // order[k] = caller primitive of accelerator slot k; empty without an accelerator
     bool hybrid_ok = false;        // the accelerator exists and its leaves carry the canonical leaves' boxes bit for bit
     int bvh_mode = 0;              // what trhip_scene_commit / trhip_scene_set_bvh built: 0 the library's tree alone, 1 the canonical (reference / host) tree alone, 2 both
-    DevBuf d_acc_wnodes, d_acc_prims, d_slot_boxes, d_sphere_boxes, d_sphere_slots, d_acc_leaf_order;
+    DevBuf d_acc_wnodes, d_acc_prims, d_slot_boxes, d_sphere_boxes, d_sphere_slots, d_sphere_cert, d_acc_leaf_order;
     WideScene wide_acc{};
     DeviceScene dev_acc{};         // dev with the accelerator's primitive records
     CertScene cert{};
@@ -276,13 +278,33 @@ struct Timer {
     trhip_ctx* ctx;
     bool on;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[8];  // 0 raygen, 1 closest, 2 shade, 3 any, 4 film; 5-7: sub-classes of an integrator (tu_sppm.hip)
-    explicit Timer(trhip_ctx* c, bool enable) : ctx(c), on(enable) {}
+    std::vector<std::pair<size_t, hipEvent_t>> marks;       // hybrid mode: (index into ev[1], event between the certified walk and the fallback walk of that closest-hit launch)
+    explicit Timer(trhip_ctx* c, bool enable) : ctx(c), on(enable) { c->active_timer = this; }
     ~Timer() {
+        if (ctx->active_timer == this) ctx->active_timer = nullptr;
         for (auto& v : ev)
             for (auto& p : v) {
                 (void)hipEventDestroy(p.first);
                 (void)hipEventDestroy(p.second);
             }
+        for (auto& m : marks) (void)hipEventDestroy(m.second);
+    }
+    void mark_fallback(hipStream_t st) {  // called by launch_trace between the two walks of a hybrid closest-hit launch (inside begin(1) .. end(1))
+        if (!on || ev[1].empty()) return;
+        hipEvent_t e;
+        (void)hipEventCreate(&e);
+        (void)hipEventRecord(e, st);
+        marks.push_back({ev[1].size() - 1, e});
+    }
+    double fallback_total(uint32_t* launches) {  // time from each mark to the end of its launch
+        double ms = 0;
+        for (auto& m : marks) {
+            float t = 0;
+            if (m.first < ev[1].size()) (void)hipEventElapsedTime(&t, m.second, ev[1][m.first].second);
+            ms += t;
+        }
+        *launches = (uint32_t)marks.size();
+        return ms;
     }
     void begin(int cls, hipStream_t st) {
         if (!on) return;

@@ -49,6 +49,8 @@ struct Counters {  // device-resident
     unsigned long long closest_total, shadow_total, nodes_closest, prims_closest, nodes_shadow, prims_shadow;
     unsigned long long fallback_total;  // closest-hit rays k_trace7 handed to the reference-order walk (th_trace7.h)
     unsigned long long fallback_why[4]; // … by reason, counted under "count_visits" (th_trace7.h)
+    // hybrid mode under "count_visits": the visit counters split between the certified walk and the fallback walks (k_hybrid_count_mark, th_trace3c.h)
+    unsigned long long nodes_seen, prims_seen, nodes_fallback, prims_fallback;
 };
 // How a kernel sees a queue: kSeg segments of `cap` physical entries with fill counts in HBM, or (counts == nullptr) one
 // dense array of n_dense entries (kernel-level API entry points).

@@ -17,33 +17,45 @@
 // scene), and for rays without a zero direction component a leaf box that passes the t_max-free clauses implies that every ancestor box — in any tree whose
 // boxes nest — passes them, and enters no later than the leaf (the slab products are monotonic in the box planes).  So the SET of candidates is the same in
 // both trees; only the t_max clauses see the order.  With D = the largest coordinate offset between the ray origin and the scene bound (the reach of the
-// ray's Float32 arithmetic) and kz the ray's dominant axis (every hit lies inside the scene, so t <= D |1 / d[kz]|),
-//     dt = 2^-18 D |1 / d[kz]|      (64 ulps of the largest possible t: all it has to cover is the rounding between t_p, tau_p and the slab products)
-// the walk keeps t_max = the t of the last accepted candidate w (or the ray's own t_max) and the GUARD g = max(t_w, entry of w's own leaf box), and
-//     * tests every primitive it reaches against the relaxed limit g + dt; a candidate p found that way is ACCEPTED iff max(t_p, entry of p's leaf box)
-//       <= t_max - dt, and otherwise the ray is FLAGGED: p lies within dt of the incumbent, or between the incumbent and the point where the incumbent's (or
-//       p's own) leaf box lets the reference in — the order decides (ties on shared edges, coincident surfaces, grazed boxes);
-//     * culls a child box c of node N only when a LOWER BOUND of the t of everything inside is >= g + dt.  Two bounds hold for every candidate p under c:
-//       (i) t_p >= (1 - 8 ulp) x [kz-slab entry of c]: t_p = sum(e_k z_k sz) / sum(e_k) is a convex combination of the vertices' own (v[kz] - o[kz]) / d[kz] — the very
-//       products the slab test forms for the box planes — and the box holds the vertices; (ii) the accepted hit point lies within 40 ulps of D of the triangle
-//       (translate, shear, edge functions: th_trace2.h), hence inside c grown by 2^-17 D per axis, hence its TRUE t is >= entry(c) - 2^-17 D max |1 / d|; and the
-//       computed t_p differs from the true one by no more than the triangle's extent along kz (both lie between the vertices' depths), which is <= mle(N) |1 / d[kz]|
-//       with mle(N) = the largest leaf-box extent in N's subtree (one float per node, set at commit).  The walk uses the larger of the two;
-//     * treats a full sphere entered from INSIDE (sphere.jl:137-138: the far root t1 is returned whatever t_max is — every ray reflected off or refracted into a
-//       sphere starts that way, its own surface at t1 ~ 1e-7 or the far side) as a candidate that the reference ALWAYS accepts when it tests it, overwriting what it
-//       held: it is accepted here under the same rule (the incumbent / the ray's own t_max lies beyond g + dt) and then STICKS — any further candidate below g + dt flags
-//       the ray, because a primitive nearer than t1 wins in the reference iff it happens to be tested after the sphere.  The sphere's leaf box holds the origin, so
-//       every tree reaches it (entry <= g, below every other candidate and the ray's own t_max);
-//     * flags a ray that meets a clipped sphere (sphere.jl:143-149 can return a root that ignores t_max), and a ray with a zero or non-finite direction component
-//       (0 x Inf = NaN breaks the monotonicity argument); boxes on the path to a sphere are never culled by t (the Float32 quadratic reports hits up to 1e-3 |o - c|
-//       outside the sphere's box, no margin derived from the boxes bounds where its candidates lie): every sphere whose leaf box passes the t_max-free clauses IS tested.
-// Claim: an unflagged ray's answer w is what the reference's walk returns on any tree over the same leaves.  With G = max(t_w, entry of w's leaf box):
-//   (1) every other candidate p has t_p, tau_p >= G + dt / 2: if it was tested it failed the relaxed limit of the moment (>= G + dt), or was accepted and later
-//       replaced (each acceptance lowers g by >= dt); if it never was, a box above it was culled with its lower bound >= g_then + dt >= G + dt;
-//   (2) on the other tree, before w is tested t_max is the ray's own (>= G + dt: the acceptance rule) or some t_p >= G + dt / 2; w's leaf box enters at <= G and
-//       every ancestor no later: w is reached, and accepted (tau_w <= t_w + 4 ulp);  (3) afterwards every other candidate is rejected (tau_p > t_w) and no sphere
-//       raises t_max: one entered from inside whose leaf passes the t_max-free clauses was tested here (its path is never culled) and IS w, or the ray was flagged.
+// ray's Float32 arithmetic; em / tight_scale) and kz the ray's dominant axis (every hit lies inside the scene, so t <= D |1 / d[kz]|),
+//     dt = 2^-16 D |1 / d[kz]|      (kCertDt: 256 ulps of the largest possible t — the rounding between t_p, tau_p and the slab products is a few ulps of it)
+// the walk keeps t_lim = T + 2 dt, T = the t of the last accepted candidate (the INCUMBENT) or the ray's own t_max, and
+//     * tests every primitive it reaches against the relaxed limit t_lim.  A candidate p found that way is ACCEPTED iff t_p <= T - 2 dt (= t_lim - 4 dt) and the EXACT
+//       entry distance of p's leaf box is <= t_p + dt (the reference, holding any t_max > t_p + dt, enters the leaf).  Otherwise the ray is FLAGGED: p lies within 2 dt of
+//       the incumbent or of the ray's own t_max, or its leaf box lets the reference in only beyond it — the order decides (shared edges, coincident surfaces, grazed boxes);
+//     * culls a box c only when entry(c) >= t_lim + mb, a bound below which no candidate inside c can have its t.  Two facts, for every triangle candidate p under c:
+//       (i) the ray point at the computed t_p lies within `growth` = 2^-20 D + 2^-18 sq_flat of p's boxes, per axis (kCertGrow: the sheared vertex coordinates carry <= 5
+//       ulps of D each; kCertFlat x sq_flat: what the edge functions' rounding moves the point for a FLAT triangle — zero extent along some axis, walls and floors of any
+//       size —, sq_flat = the scene's largest L^3 / 2A over such triangles), so t_p >= entry(c) - growth x max |1 / d|;  (ii) for the others, t_p = sum(e_k z_k sz) / sum(e_k)
+//       is a convex combination of the vertices' own depths along kz, all inside c's kz slab: t_p differs from the true depth of that point by at most the triangle's
+//       kz extent <= mle_small[kz] (the largest extent of a non-flat leaf box along kz, a scene constant) times |1 / d[kz]|.  mb = mle_small[kz] |1 / d[kz]| + growth max |1 / d|,
+//       one value per ray (AXIS: the growth term per axis instead, from the grown box: rays that start far outside the scene).  A ray whose growth term exceeds kCertCap
+//       times the extent term (near-axis-parallel: max |1 / d| ~ 1e3) would overshoot every hit by that much: it is flagged when it is fetched;
+//     * tests the scene's spheres (<= kCertMaxSpheres, else no hybrid mode) for every ray BEFORE its walk, all of them (the chunk pre-pass below): no box on a sphere's
+//       path is then ever culled — the Float32 quadratic reports hits up to 1e-3 |o - c| outside the sphere's box, no margin derived from the boxes bounds where they lie.
+//       A full sphere seen from outside is a candidate like any other (same acceptance rule, its own leaf box).  A full sphere entered from INSIDE (sphere.jl:137-138:
+//       the far root t1 is returned whatever t_max is — every ray reflected off or refracted into a sphere starts that way) is ALWAYS accepted by the reference when it
+//       tests it — and it always does: its leaf box holds the origin (required here: entry <= 0), no t_max culls its path — and OVERWRITES what the reference held.  So
+//       of the other candidates only those the reference tests AFTER that sphere count, and that is a function of the canonical tree and the direction signs alone:
+//       each accelerator primitive record carries, per sphere, the split axis of the canonical node where its root path parts from the sphere's and the child it is in
+//       (3 bits each, the ORDER WORD, set at commit; axis code 3 = the sphere's own leaf, before / behind it); bvh.jl:239-246 visits the second child first iff
+//       d[axis] < 0.  A candidate that does not count is skipped, one that does is held to the acceptance rule against T = t1.  A ray inside one sphere that meets a
+//       second sphere candidate is flagged;
+//     * flags a ray that meets a clipped sphere (sphere.jl:143-149 can return a root that ignores t_max), and a ray with a zero or non-finite direction component, a
+//       non-finite origin or a NaN t_max (0 x Inf = NaN breaks the monotonicity argument).
+// Claim: an unflagged ray's answer w (or "miss") is what the reference's walk returns on any tree over the same leaves.
+//   (1) every other candidate p that counts has t_p, tau_p > T_w + dt: if it was tested it failed the relaxed limit of the moment (>= T_w + 2 dt) — or was accepted and
+//       later replaced (each acceptance lowers T by >= 2 dt); if it never was, a box above it was culled with entry >= t_lim + mb, hence t_p >= t_lim >= T_w + 2 dt;
+//   (2) on the other tree, before w is tested t_max is the ray's own (>= t_w + 2 dt: the acceptance rule) or some t_p > t_w + dt; w's leaf box enters at <= t_w + dt and
+//       every ancestor no later: w is reached, and accepted (tau_w <= t_w + 4 ulp);  (3) afterwards every other candidate that counts is rejected (tau_p > t_w), and the
+//       ones that do not count were tested before the sphere that overwrote them.
 // The accelerator's own visiting order is irrelevant to the claim; it keeps k_trace3's (near child first by the split axis' sign) because that schedule is tuned.
+//
+// The chunk pre-pass.  A wave takes rays from the queue in chunks of kChunk; when it takes a chunk it runs ALL of the chunk's rays against ALL spheres, 64 rays at a
+// time with every lane (lanes in the middle of a walk included: their walk state just stays in its registers), and leaves {t, canonical slot, state} in the ray's hit
+// record: state = accepted-sphere bit, the id of the sphere the ray starts inside of, or "flagged".  A fetch reads the record back (past L1: same wave, other lane;
+// the stores are only waited for — an agent-scope fence here would write the XCD's L2 back, measured +70 % kernel time).  Testing the spheres at each fetch instead
+// (a dozen lanes at a time, the whole wave paying transforms and quadratics) cost 3x k_trace3's refill; in the leaf phase the sphere code sets the walk's registers.
 //
 // Primitive records of the accelerator are in ITS leaf order and carry the CANONICAL slot in the second record's .w lane: hits, shading records, the
 // inspection API and the oracle all speak canonical slots.
@@ -55,6 +67,9 @@ namespace th {
 
 #ifndef TH_TRACE3C_WAVES
 #define TH_TRACE3C_WAVES 5
+#endif
+#ifndef TH_TRACE3C_REFILL
+#define TH_TRACE3C_REFILL TH_TRACE_REFILL  // idle lanes of a wave that trigger a refill
 #endif
 #ifndef TH_TRACE3C_LDS
 #define TH_TRACE3C_LDS 12
@@ -82,7 +97,8 @@ constexpr float kCertCap = 4.0f;                  // a ray whose growth margin i
 struct CertScene {               // what the certificate needs beside the accelerator's WideScene
     const float* sphere_boxes;   // per sphere id: the box of the canonical leaf that holds it (6 floats)
     const uint32_t* sphere_slots;  // per sphere id: its canonical slot
-    uint32_t n_spheres;          // spheres are tested when a ray is FETCHED (k_trace3c), all of them: never more than kCertMaxSpheres in a hybrid scene
+    uint32_t n_spheres;          // every ray is tested against all of them before its walk (k_trace3c's chunk pre-pass): never more than kCertMaxSpheres in a hybrid scene
+    const void* sphere_cert;     // SphereCert[n_spheres]: what those tests read, one contiguous record per sphere
     const float* slot_boxes;     // one-leaf accelerator: per canonical slot, the box of the canonical leaf that holds it (6 floats)
     float inv_tight;             // 1 / WideScene::tight_scale: D = em x inv_tight
     float mle_small[3];          // per axis: the largest extent of a NON-FLAT leaf box along that axis — bounds |computed t - the depth of the ray's point on the (perturbed) triangle|
@@ -103,12 +119,27 @@ struct CertCold {
     float sq_flat, inv_tight;
     float pad;
 };
-struct CertHot {   // … and the three constants the walk itself needs
+struct SphereCert;
+struct CertHot {   // … and what the walk itself, or every fetch, needs
     float kdt;     // kCertDt / tight_scale: dt = kdt x em x |1 / d[kz]|
     float kgrow;   // kCertGrow / tight_scale
     float gflat;   // kCertFlat x sq_flat: growth = kgrow x em + gflat
+    uint32_t n_spheres;
+    const SphereCert* spheres;  // one contiguous record per sphere (a single burst of scalar loads each)
+    float mle[3];               // CertScene::mle_small
 };
 static __global__ void k_store_cert_cold(CertCold* dst, CertCold v) { *dst = v; }
+// "count_visits": one thread, between the certified walk and the fallback walk of a launch (phase 0) and after the fallback walk (phase 1): what the closest-hit visit
+// counters gained during the fallback walk goes to nodes_fallback / prims_fallback
+static __global__ void k_hybrid_count_mark(Counters* c, int phase) {
+    if (phase == 0) {
+        c->nodes_seen = c->nodes_closest;
+        c->prims_seen = c->prims_closest;
+    } else {
+        c->nodes_fallback += c->nodes_closest - c->nodes_seen;
+        c->prims_fallback += c->prims_closest - c->prims_seen;
+    }
+}
 
 // bounds.jl:186-198 on one child box, as slab_test2 (its t_max-free clauses, plus the two tight clauses), returning the exact entry distance and, with AXIS, the entry distance
 // of the box GROWN by `grow` (a length) in every axis
@@ -133,22 +164,38 @@ TH_D bool slab_test3(float bx0, float by0, float bz0, float bx1, float by1, floa
     return !(miss_xy | miss_z | miss_tight) & (t_out > 0.0f);
 }
 
+// One record per sphere for the sphere pre-pass of k_trace3c: everything a test reads, contiguous (one burst of scalar loads per sphere, no dependent second trip)
+struct SphereCert {
+    float box[6];       // the box of the canonical leaf that holds the sphere
+    float radius;
+    uint32_t slot;      // its canonical slot
+    float o2w_inv[16];  // SphereRec::o2w_inv (world_to_object.m)
+    uint32_t never_clipped, pad[3];
+};
+static_assert(sizeof(SphereCert) == 112, "SphereCert layout");
+
 // sphere.jl:125-158 up to the roots: 0 = no candidate within t_lim, 1 = candidate at t (a full sphere seen from outside: accepted iff t0 <= t_max, sets t0),
 // 3 = a full sphere entered from INSIDE: the reference takes the far root t1 WHATEVER t_max is (sphere.jl:137-138) — a candidate that is always accepted (the caller's
 // "sticky" rule), 2 = a clipped sphere (:143-149 may return a root that ignores t_max after a clipped first one) or a NaN root: the ray goes to the reference-order walk
 template <bool FULL_ONLY>
+TH_D int sphere_candidate_m(const float* o2w_inv, float radius, bool never_clipped, f3 o, f3 d, float t_lim, float& t);
+template <bool FULL_ONLY>
 TH_D int sphere_candidate_c(const SphereRec& s, f3 o, f3 d, float t_lim, float& t) {
-    const f3 oo = xf_point(s.o2w_inv, o);
-    const f3 od = xf_vec(s.o2w_inv, d);
+    return sphere_candidate_m<FULL_ONLY>(s.o2w_inv, s.radius, s.never_clipped != 0u, o, d, t_lim, t);
+}
+template <bool FULL_ONLY>
+TH_D int sphere_candidate_m(const float* o2w_inv, float radius, bool never_clipped, f3 o, f3 d, float t_lim, float& t) {
+    const f3 oo = xf_point(o2w_inv, o);
+    const f3 od = xf_vec(o2w_inv, d);
     const float nd = norm(od);
     const float a = nd * nd;
     const float b = dot(2.0f * oo, od);
     const float no = norm(oo);
-    const float c = no * no - s.radius * s.radius;
+    const float c = no * no - radius * radius;
     float t0, t1;
     if (!solve_quadratic(a, b, c, t0, t1)) return 0;
     if (!(t1 >= 0.0f)) return t1 < 0.0f ? 0 : 2;  // (a NaN root: let the reference-order walk decide)
-    if (!FULL_ONLY && !s.never_clipped) return 2;
+    if (!FULL_ONLY && !never_clipped) return 2;
     if (!(t0 >= 0.0f)) {
         if (!(t0 < 0.0f)) return 2;
         t = t1;
@@ -180,7 +227,7 @@ TH_D uint32_t fallback_append(FallbackList fb, bool to_fb, uint32_t idx, uint32_
 // AXIS: the cull bound from the box grown per axis (two fma + max3 more per child) instead of the scalar margin — for launches whose rays start far outside the scene
 // (camera rays 50 scene sizes away: D, hence the scalar margin, is 50x larger, while their binding slab is almost always the dominant axis'); TraceOut::far_hint picks it.
 // Register budget: the node reference and its primitive count stay packed in ONE word (the child / stack word format), what is only read at a ray's fetch or at a hand-over lives
-// behind one pointer (CertCold), the spheres are tested at the fetch: the certificate costs the walk two live values (the per-ray margin and the current node's entry distance;
+// behind one pointer (CertCold), the spheres are tested in the chunk pre-pass: the certificate costs the walk two live values (the per-ray margin and the current node's entry distance;
 // t_lim takes t_max's place).
 template <bool COUNT, bool FULL_ONLY, bool BIG = false, bool AXIS = false>
 __global__ __launch_bounds__(kBlock, BIG ? TH_TRACE3C_WAVES - 1 : TH_TRACE3C_WAVES) void k_trace3c(DeviceScene sc /* prims: the accelerator's order */, WideScene ws /* the accelerator */, CertHot ch,
@@ -191,6 +238,11 @@ __global__ __launch_bounds__(kBlock, BIG ? TH_TRACE3C_WAVES - 1 : TH_TRACE3C_WAV
     constexpr uint32_t kLeafBit = 1u << 24;  // a node word >= this (and != kRefNone) is a leaf: ref | count << 24
     __shared__ uint32_t s_ref[kLds][kBlock];
     __shared__ float s_tmin[kLds][kBlock];
+    // per-lane state that is only touched when a ray is fetched, accepted or finished lives in LDS, not in registers (the walk runs at the 80-VGPR line of six waves per
+    // SIMD; a scratch spill costs a trip to memory, an LDS word 64 cycles): the ray's queue index, its state word, the entry distance of the node in hand
+    __shared__ uint32_t s_idx[kBlock];
+    __shared__ uint32_t s_st[kBlock];
+    __shared__ float s_ex[kBlock];
     __shared__ SegView sv;
     seg_load(q, sv);
     const uint32_t tid = threadIdx.x;
@@ -200,7 +252,7 @@ __global__ __launch_bounds__(kBlock, BIG ? TH_TRACE3C_WAVES - 1 : TH_TRACE3C_WAV
 
     bool active = false, exhausted = false, to_fb = false;
     uint32_t wseg = __builtin_amdgcn_readfirstlane((gtid >> 6) % kSeg), dry = 0, pool_next = 0, pool_end = 0;  // wave-uniform
-    uint32_t idx = 0, cur = kRefNone;  // cur: kRefNone, an interior node's index (< 2^24), or a leaf word
+    uint32_t cur = kRefNone;  // kRefNone, an interior node's index (< 2^24), or a leaf word
     int sp = 0;
     f3 o = splat3(0.0f), inv_d = splat3(0.0f);
     float em = 0.0f;
@@ -210,13 +262,16 @@ __global__ __launch_bounds__(kBlock, BIG ? TH_TRACE3C_WAVES - 1 : TH_TRACE3C_WAV
                           // bound of what it holds — its entry distance minus the margin — reaches it
     float mb = 0.0f;      // per ray: the margin of the lower bound: non-flat primitives their kz extent, everything the growth in the entering axis (with AXIS the growth is applied per
                           // axis to the box instead, and is not in here)
-    float cur_ex = 0.0f;  // entry distance of the node in `cur` (the reference's tx_min of its box)
-    uint32_t st = 0;      // 0: nothing accepted yet, 1: a candidate is; bits 8..: 1 + the sphere the ray started INSIDE of (header: what the reference tests before that sphere does not count)
+    // s_ex[tid]: entry distance of the node in `cur` (the reference's tx_min of its box)
+    // s_st[tid]: 0: nothing accepted yet, 1: a candidate is; bits 8..: 1 + the sphere the ray started INSIDE of (header: what the reference tests before that sphere does not count)
     uint32_t nn = 0, np = 0;
     uint32_t n_fb = 0;    // wave-uniform
     unsigned long long n_why[4] = {0ull, 0ull, 0ull, 0ull};  // COUNT: why rays went to the canonical tree — 0 direction / finiteness / cap, 1 a sphere (clipped, inside two), 2 near tie / guard
     uint32_t why = 0;
 
+#ifdef TH_DIAG_PHASES
+    unsigned long long ph_cyc[4] = {0, 0, 0, 0}, ph_lan[4] = {0, 0, 0, 0}, ph_cnt[4] = {0, 0, 0, 0};  // refill (+ hand-over), pop, node, leaf (tools/phase_probe.py)
+#endif
     auto margin_t = [&]() { return ch.kdt * em * fabsf(shear.sz); };       // dt, from what is live (D = em / tight_scale)
     auto growth = [&]() { return __fmaf_rn(ch.kgrow, em, ch.gflat); };     // the length by which the ray point at a primitive's computed t can lie outside the primitive's boxes
     auto inv_max = [&]() { return fmaxf(fmaxf(fabsf(inv_d.x), fabsf(inv_d.y)), fabsf(inv_d.z)); };
@@ -225,13 +280,14 @@ __global__ __launch_bounds__(kBlock, BIG ? TH_TRACE3C_WAVES - 1 : TH_TRACE3C_WAV
         // ---- rays for the reference-order walk: appended to the fallback lists ----
         if (__ballot(to_fb) != 0ull) {
             const FallbackList fb{uniform_load(&cold->fb_list, 0), uniform_load(&cold->fb_counts, 0), uniform_load(&cold->fb_cap, 0)};
-            n_fb += fallback_append(fb, to_fb, idx, __builtin_amdgcn_readfirstlane((gtid >> 6) % kSeg));
+            n_fb += fallback_append(fb, to_fb, s_idx[tid], __builtin_amdgcn_readfirstlane((gtid >> 6) % kSeg));
             to_fb = false;
         }
         // ---- refill idle lanes (as k_trace3) ----
         const unsigned long long idle = __ballot(!active);
         const uint32_t n_idle = (uint32_t)__popcll(idle);
-        if (n_idle == 64u || (!exhausted && n_idle >= (uint32_t)TH_TRACE_REFILL)) {
+        if (n_idle == 64u || (!exhausted && n_idle >= (uint32_t)TH_TRACE3C_REFILL)) {
+            TH_PHASE_BEGIN();
             if (!exhausted) {
                 if (pool_next >= pool_end) {
                     const uint32_t cnt = __builtin_amdgcn_readfirstlane(sv.count[wseg]);
@@ -251,6 +307,64 @@ __global__ __launch_bounds__(kBlock, BIG ? TH_TRACE3C_WAVES - 1 : TH_TRACE3C_WAV
                         pool_next = base;
                         pool_end = min(base + take, cnt);
                         dry = 0;
+                        // ---- the chunk's SPHERE PRE-PASS: every ray of the chunk this wave now owns against every sphere of the scene, 64 rays at a time with ALL lanes (the lanes that
+                        //      are in the middle of a walk work too: their own state just stays where it is).  A sphere is then never hidden from the certificate — whatever the boxes on
+                        //      its path do — and the walk skips sphere primitives.  Done here rather than when a ray is fetched (a dozen lanes at a time, the whole wave paying the
+                        //      transforms, quadratics and their scalar loads: three times k_trace3's refill cost) or in the leaf phase (where the sphere code sets the walk's register
+                        //      count).  The outcome waits in the ray's hit record: {t, slot, state} ----
+                        if (ch.n_spheres != 0u) {
+                            const uint32_t n_chunk = pool_end - pool_next;
+#pragma unroll 1
+                            for (uint32_t i0 = 0; i0 < n_chunk; i0 += 64u) {
+                                const bool valid = i0 + lane < n_chunk;
+                                uint32_t pidx = valid ? seg_phys(q, wseg, pool_next + i0 + lane) : 0u;
+                                if (valid && q.indirect) pidx = q.indirect[pidx];
+                                float4 po4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), pd4 = make_float4(0.0f, 0.0f, 1.0f, 0.0f);
+                                if (valid) {
+                                    po4 = ro[pidx];
+                                    pd4 = rd[pidx];
+                                }
+                                const f3 po = mk3(po4.x, po4.y, po4.z), pd = mk3(pd4.x, pd4.y, pd4.z);
+                                const f3 pinv = mk3(1.0f / pd.x, 1.0f / pd.y, 1.0f / pd.z);
+                                const bool pnx = pd.x < 0.0f, pny = pd.y < 0.0f, pnz = pd.z < 0.0f;
+                                const float pem = slab_margin(ws.root_box, ws.tight_scale, po);
+                                const float pdt = ch.kdt * pem * fabsf(ray_shear(pd).sz);
+                                float p_lim = ((valid && tmax_or_null) ? tmax_or_null[pidx] : kInf) + 2.0f * pdt;
+                                uint32_t pst = 0u;
+                                float4 prec = make_float4(kInf, __int_as_float(-1), 0.0f, 0.0f);
+                                bool pflag = false;
+#pragma unroll 1
+                                for (uint32_t ks = 0; ks < ch.n_spheres; ++ks) {
+                                    const SphereCert sr = uniform_load(ch.spheres, ks);  // wave-uniform: scalar loads, one burst
+                                    float ex;
+                                    if (valid && !pflag && slab_test2(sr.box[0], sr.box[1], sr.box[2], sr.box[3], sr.box[4], sr.box[5], po, pinv, pem, false, pnx, pny, pnz, ex)) {
+                                        if (COUNT) np++;
+                                        float t_c = 0.0f;
+                                        // a sphere the ray starts inside of is taken whatever the limit is (sphere.jl:137-138); one seen from outside up to the relaxed limit
+                                        const int r = sphere_candidate_m<FULL_ONLY>(sr.o2w_inv, sr.radius, sr.never_clipped != 0u, po, pd, p_lim, t_c);
+                                        if (r == 2 || (r != 0 && (pst >> 8) != 0u)) {
+                                            pflag = true;  // clipped; or the ray starts inside a sphere AND meets another one below that sphere's far root: left to the reference's order
+                                        } else if (r != 0) {
+                                            // accepted iff it lies 2 dt below the incumbent (p_lim - 4 dt; the ray's own t_max at first) and its leaf box lets the reference in by then.
+                                            // A sphere the ray starts INSIDE of (r == 3): the reference takes its far root whenever it tests it — and it always does: the box holds the
+                                            // origin (required: ex <= 0), so no t_max culls its path — and forgets what it held; the ray remembers the sphere (state), and of what the
+                                            // walk finds only what the reference tests AFTER that sphere counts (the order word of the primitive records, below)
+                                            if (!(t_c <= p_lim - 4.0f * pdt) || !(ex <= (r == 3 ? 0.0f : t_c + pdt))) {
+                                                pflag = true;
+                                            } else {
+                                                p_lim = t_c + 2.0f * pdt;
+                                                pst = 1u | (r == 3 ? (ks + 1u) << 8 : 0u);
+                                                prec = make_float4(t_c, __uint_as_float(sr.slot), 0.0f, 0.0f);
+                                            }
+                                        }
+                                    }
+                                }
+                                prec.z = __uint_as_float(pflag ? 0x80000000u : pst);
+                                if (valid) out.hits[pidx] = prec;
+                            }
+                            __builtin_amdgcn_s_waitcnt(0);
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (the stores have reached L2: no cache is written back or invalidated — an agent-scope fence writes the XCD's whole L2 back.)  The records are read back past L1 when the rays are fetched
+                        }
                     } else {
                         pool_next = pool_end = 0;
                         wseg = (wseg + 1) % kSeg;
@@ -261,8 +375,10 @@ __global__ __launch_bounds__(kBlock, BIG ? TH_TRACE3C_WAVES - 1 : TH_TRACE3C_WAV
                 if (avail && !active) {
                     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
                     if (rank < avail) {
-                        idx = seg_phys(q, wseg, pool_next + rank);
+                        uint32_t idx = seg_phys(q, wseg, pool_next + rank);
                         if (q.indirect) idx = q.indirect[idx];
+                        s_idx[tid] = idx;
+                        uint32_t st = 0u;
                         const float4 o4 = ro[idx], d4 = rd[idx];
                         o = mk3(o4.x, o4.y, o4.z);
                         const f3 d = mk3(d4.x, d4.y, d4.z);
@@ -274,11 +390,10 @@ __global__ __launch_bounds__(kBlock, BIG ? TH_TRACE3C_WAVES - 1 : TH_TRACE3C_WAV
                         negz = d.z < 0.0f;
                         const float t_own = tmax_or_null ? tmax_or_null[idx] : kInf;
                         const float dt = margin_t();
-                        const float mkz = uniform_load(cold->mle_small, (uint32_t)shear.kz) * fabsf(shear.sz);
+                        const float mkz = (shear.kz == 0 ? ch.mle[0] : (shear.kz == 1 ? ch.mle[1] : ch.mle[2])) * fabsf(shear.sz);
                         mb = AXIS ? mkz : __fmaf_rn(growth(), inv_max(), mkz);
                         t_lim = t_own + 2.0f * dt;
                         sp = 0;
-                        st = 0u;
                         active = true;
                         if (COUNT) nn++;
                         // what the certificate does not cover goes to the reference-order walk at once: a zero or non-finite direction component (0 x Inf = NaN in the slab
@@ -293,40 +408,18 @@ __global__ __launch_bounds__(kBlock, BIG ? TH_TRACE3C_WAVES - 1 : TH_TRACE3C_WAV
                             if (COUNT) n_why[0]++;
                         } else if (ws.root_ref != kRefNone && slab_test2(ws.root_box[0], ws.root_box[1], ws.root_box[2], ws.root_box[3], ws.root_box[4], ws.root_box[5], o, inv_d, em, false, negx, negy, negz, tmin)) {
                             cur = ws.root_ref | (ws.root_cnt << 24);  // (the root is not culled by t: the reference's clause `tmin < t_max` holds whenever anything inside can be accepted)
-                            cur_ex = tmin;
-                            // ---- the scene's spheres, all of them, NOW (the ray's traversal state is not live yet: their transforms and quadratics cost the walk no register):
-                            //      a sphere is then never hidden from the certificate — whatever the boxes on its path do — and the walk skips sphere primitives.  Wave-uniform
-                            //      loop, scalar loads; a sphere counts only when the t_max-free clauses pass on ITS canonical leaf's box ----
+                            s_ex[tid] = tmin;
+                            // the sphere pre-pass of the chunk left this ray's state in its hit record: an accepted sphere (the incumbent), the sphere it starts inside of, or
+                            // "to the reference-order walk"
                             bool flagged = false;
-                            const uint32_t n_sph = uniform_load(&cold->n_spheres, 0);
-                            const float* sboxes = uniform_load(&cold->sphere_boxes, 0);
-#pragma unroll 1
-                            for (uint32_t k = 0; k < n_sph; ++k) {
-                                const float* sb = sboxes + 6 * (size_t)k;
-                                const float b0 = uniform_load(sb, 0), b1 = uniform_load(sb, 1), b2 = uniform_load(sb, 2), b3 = uniform_load(sb, 3), b4 = uniform_load(sb, 4), b5 = uniform_load(sb, 5);
-                                float ex;
-                                if (!flagged && slab_test2(b0, b1, b2, b3, b4, b5, o, inv_d, em, false, negx, negy, negz, ex)) {
-                                    if (COUNT) np++;
-                                    float t_c = 0.0f;
-                                    // a sphere the ray starts inside of is taken whatever the limit is (sphere.jl:137-138); one seen from outside up to the relaxed limit
-                                    const int r = sphere_candidate_c<FULL_ONLY>(sc.spheres[k], o, d, t_lim, t_c);
-                                    if (r == 2 || (r != 0 && (st >> 8) != 0u)) {
-                                        flagged = true;  // clipped; or the ray starts inside a sphere AND meets another one below that sphere's far root: left to the reference's order
-                                    } else if (r != 0) {
-                                        // accepted iff it lies 2 dt below the incumbent (t_lim - 4 dt; the ray's own t_max at first) and its leaf box lets the reference in by then.
-                                        // A sphere the ray starts INSIDE of (r == 3): the reference takes its far root whenever it tests it — and it always does: the box holds the
-                                        // origin (required: ex <= 0), so no t_max culls its path — and forgets what it held; the ray remembers the sphere (st), and of what the
-                                        // walk finds only what the reference tests AFTER that sphere counts (the order word of the primitive records, below)
-                                        if (!(t_c <= t_lim - 4.0f * dt) || !(ex <= (r == 3 ? 0.0f : t_c + dt))) {
-                                            flagged = true;
-                                        } else {
-                                            t_lim = t_c + 2.0f * dt;
-                                            st = 1u | (r == 3 ? (k + 1u) << 8 : 0u);
-                                            out.hits[idx] = make_float4(t_c, __uint_as_float(uniform_load(uniform_load(&cold->sphere_slots, 0), k)), 0.0f, 0.0f);
-                                        }
-                                    }
-                                }
+                            if (ch.n_spheres != 0u) {
+                                const float* recp = reinterpret_cast<const float*>(&out.hits[idx]);
+                                st = __float_as_uint(__hip_atomic_load(recp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                                flagged = (st >> 31) != 0u;
+                                st &= 0x7fffffffu;
+                                if (st & 1u) t_lim = __hip_atomic_load(recp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 2.0f * dt;
                             }
+                            s_st[tid] = st;
                             if (flagged) {
                                 to_fb = true;
                                 active = false;
@@ -334,11 +427,13 @@ __global__ __launch_bounds__(kBlock, BIG ? TH_TRACE3C_WAVES - 1 : TH_TRACE3C_WAV
                             }
                         } else {
                             cur = kRefNone;
+                            s_st[tid] = 0u;
                         }
                     }
                 }
                 pool_next += min(n_idle, avail);
             }
+            TH_PHASE_END(0, n_idle);
             if (__ballot(active) == 0ull) {
                 if (__ballot(to_fb) != 0ull) continue;  // flush first
                 if (exhausted) break;
@@ -349,6 +444,10 @@ __global__ __launch_bounds__(kBlock, BIG ? TH_TRACE3C_WAVES - 1 : TH_TRACE3C_WAV
 #pragma unroll 1
         for (int it = 0; it < TH_TRACE3C_MAX_A; ++it) {
             bool finished = false;
+#ifdef TH_DIAG_PHASES
+            const unsigned long long ph_pop_m = __ballot(active && cur == kRefNone);
+            const unsigned long long ph_t_pop = __builtin_readcyclecounter();
+#endif
             const bool wants_pop = active && cur == kRefNone;
             const bool pop_now = (uint32_t)__popcll(__ballot(wants_pop)) >= (uint32_t)TH_TRACE3C_POP_MIN || __ballot(active && cur < kLeafBit) == 0ull;
             if (pop_now && wants_pop) {
@@ -371,7 +470,7 @@ __global__ __launch_bounds__(kBlock, BIG ? TH_TRACE3C_WAVES - 1 : TH_TRACE3C_WAV
                     }
                     if (tm < t_pop) {
                         cur = enc;
-                        cur_ex = tm;
+                        s_ex[tid] = tm;
                         finished = false;
                         break;
                     }
@@ -379,8 +478,20 @@ __global__ __launch_bounds__(kBlock, BIG ? TH_TRACE3C_WAVES - 1 : TH_TRACE3C_WAV
             }
             if (finished) {  // the walk is over: a certified hit (stored when it was accepted) or a certified miss
                 active = false;
-                if ((st & 1u) == 0u) out.hits[idx] = make_float4(kInf, __int_as_float(-1), 0.0f, 0.0f);
+                const uint32_t fst = s_st[tid] & 3u;  // bit 0: a hit is held; bit 1: the walk stored it (else it is the pre-pass's sphere record, whose third lane holds the state)
+                if (fst == 0u) out.hits[s_idx[tid]] = make_float4(kInf, __int_as_float(-1), 0.0f, 0.0f);
+                else if (fst == 1u) reinterpret_cast<float*>(&out.hits[s_idx[tid]])[2] = 0.0f;
             }
+#ifdef TH_DIAG_PHASES
+            {
+                const unsigned long long now = __builtin_readcyclecounter();
+                ph_cyc[1] += now - ph_t_pop;
+                ph_lan[1] += (unsigned long long)__popcll(ph_pop_m);
+                ph_cnt[1] += 1ull;
+            }
+            const unsigned long long ph_node_m = __ballot(active && cur < kLeafBit);
+            const unsigned long long ph_t_node = __builtin_readcyclecounter();
+#endif
             if (active && cur < kLeafBit) {  // interior: one 64-byte burst, both child boxes
                 const float4 a0 = ws.wnodes[4 * (size_t)cur], a1 = ws.wnodes[4 * (size_t)cur + 1], a2 = ws.wnodes[4 * (size_t)cur + 2], a3 = ws.wnodes[4 * (size_t)cur + 3];
                 uint32_t top_enc = kRefNone;
@@ -423,20 +534,30 @@ __global__ __launch_bounds__(kBlock, BIG ? TH_TRACE3C_WAVES - 1 : TH_TRACE3C_WAV
                 }
                 const bool any_child = go_n | go_f;
                 cur = any_child ? (go_n ? nenc : fenc) : kRefNone;
-                cur_ex = go_n ? vn : vf;
+                float ex_new = go_n ? vn : vf;
                 if (!any_child && sp > 0) {  // nothing was pushed in this step: the top read above is still the top
                     sp--;
                     const float t_pop = AXIS ? __fmaf_rn(gr, inv_max(), t_cull) : t_cull;
                     if (top_tm < t_pop && sp < kStack2Total) {
                         cur = top_enc;
-                        cur_ex = top_tm;
+                        ex_new = top_tm;
                     }
                 }
+                s_ex[tid] = ex_new;
             }
+#ifdef TH_DIAG_PHASES
+            ph_cyc[2] += __builtin_readcyclecounter() - ph_t_node;
+            ph_lan[2] += (unsigned long long)__popcll(ph_node_m);
+            ph_cnt[2] += 1ull;
+#endif
             const uint32_t n_desc = (uint32_t)__popcll(__ballot(active && (cur < kLeafBit || cur == kRefNone)));
             if (n_desc <= (uint32_t)TH_TRACE3C_LEAF_WAIT) break;
         }
         // ---- phase B: leaves ----
+#ifdef TH_DIAG_PHASES
+        const unsigned long long ph_leaf_m = __ballot(active && cur >= kLeafBit && cur != kRefNone);
+        const unsigned long long ph_t_leaf = __builtin_readcyclecounter();
+#endif
         if (active && cur >= kLeafBit && cur != kRefNone) {
             bool flagged = false;
             const uint32_t leaf_ref = cur & 0x00ffffffu, leaf_cnt = cur >> 24;
@@ -465,6 +586,7 @@ __global__ __launch_bounds__(kBlock, BIG ? TH_TRACE3C_WAVES - 1 : TH_TRACE3C_WAV
                     // a candidate below the relaxed limit.  A ray that started inside sphere s: only what the reference tests AFTER s counts — s overwrites the rest (header); the
                     // primitive's order word (the third record's .w lane) holds, per sphere, the split axis of the canonical node where their paths part and the child it is in
                     bool counts = true;
+                    const uint32_t st = s_st[tid];
                     if (st >> 8) {
                         const uint32_t ow = __float_as_uint(p2.w) >> (3u * ((st >> 8) - 1u));
                         const uint32_t ax = ow & 3u;
@@ -474,13 +596,13 @@ __global__ __launch_bounds__(kBlock, BIG ? TH_TRACE3C_WAVES - 1 : TH_TRACE3C_WAV
                     if (counts) {
                         const float dt = margin_t();
                         // accepted iff it lies 2 dt below the incumbent (t_lim - 4 dt; the ray's own t_max at first) AND its leaf box lets the reference in by t + dt (the guard); a NaN fails
-                        if (!(tt.t <= t_lim - 4.0f * dt) || !(cur_ex <= tt.t + dt)) {
+                        if (!(tt.t <= t_lim - 4.0f * dt) || !(s_ex[tid] <= tt.t + dt)) {
                             if (COUNT && !flagged) why = 2u;
                             flagged = true;
                         } else if (!flagged) {
                             t_lim = tt.t + 2.0f * dt;
-                            st |= 1u;
-                            out.hits[idx] = make_float4(out.bary_mode ? tt.bary.z : tt.t, p1.w /* the canonical slot */, tt.bary.x, tt.bary.y);  // stored at once: a nearer candidate overwrites it
+                            s_st[tid] = st | 3u;
+                            out.hits[s_idx[tid]] = make_float4(out.bary_mode ? tt.bary.z : tt.t, p1.w /* the canonical slot */, tt.bary.x, tt.bary.y);  // stored at once: a nearer candidate overwrites it
                         }
                     }
                 }
@@ -496,11 +618,24 @@ __global__ __launch_bounds__(kBlock, BIG ? TH_TRACE3C_WAVES - 1 : TH_TRACE3C_WAV
                 const float t_pop = t_lim + (AXIS ? __fmaf_rn(growth(), inv_max(), mb) : mb);
                 if (top_tm < t_pop && sp < kStack2Total) {
                     cur = top_enc;
-                    cur_ex = top_tm;
+                    s_ex[tid] = top_tm;
                 }
             }
         }
+#ifdef TH_DIAG_PHASES
+        ph_cyc[3] += __builtin_readcyclecounter() - ph_t_leaf;
+        ph_lan[3] += (unsigned long long)__popcll(ph_leaf_m);
+        ph_cnt[3] += 1ull;
+#endif
     }
+#ifdef TH_DIAG_PHASES
+    if (lane == 0)
+        for (int k4 = 0; k4 < 4; ++k4) {
+            atomicAdd(&g_phase[3 * k4], ph_cyc[k4]);
+            atomicAdd(&g_phase[3 * k4 + 1], ph_lan[k4]);
+            atomicAdd(&g_phase[3 * k4 + 2], ph_cnt[k4]);
+        }
+#endif
     if (ctr) {
         if (blockIdx.x == 0 && threadIdx.x == 0 && !q.no_total) atomicAdd(&ctr->closest_total, (unsigned long long)seg_total(sv));
         if (lane_id() == 0 && n_fb) atomicAdd(&ctr->fallback_total, (unsigned long long)n_fb);

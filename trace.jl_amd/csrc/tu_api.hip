@@ -6,7 +6,7 @@ thread_local std::string g_init_error;
 
 extern "C" {
 
-int trhip_version(void) { return 3000; }
+int trhip_version(void) { return 3001; }
 
 int trhip_init(trhip_ctx** out, int device_id) {
     if (!out) return fail(nullptr, TRHIP_ERR_INVALID, "ctx out pointer is null");

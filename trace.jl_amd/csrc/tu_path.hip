@@ -331,11 +331,14 @@ int render_stream_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sen
         stats->nodes_visited_shadow = h.nodes_shadow;
         stats->prims_tested_shadow = h.prims_shadow;
         stats->fallback_rays = h.fallback_total;
+        stats->nodes_visited_fallback = h.nodes_fallback;
+        stats->prims_tested_fallback = h.prims_fallback;
         float ms = 0;
         (void)hipEventElapsedTime(&ms, e0, e1);
         stats->ms_total = ms;
         stats->ms_raygen = tm.total(0, &stats->launches_raygen);
         stats->ms_trace_closest = tm.total(1, &stats->launches_trace_closest);
+        stats->ms_fallback = tm.fallback_total(&stats->launches_fallback);
         stats->ms_shade = tm.total(2, &stats->launches_shade);
         stats->ms_trace_any = tm.total(3, &stats->launches_trace_any);
         stats->ms_film = tm.total(4, &stats->launches_film);
@@ -599,6 +602,8 @@ int render_impl_band(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
             stats->nodes_visited_shadow += h.nodes_shadow;
             stats->prims_tested_shadow += h.prims_shadow;
             stats->fallback_rays += h.fallback_total;
+            stats->nodes_visited_fallback += h.nodes_fallback;
+            stats->prims_tested_fallback += h.prims_fallback;
             for (int k = 0; k < 4; ++k) stats->count_sub[k] += h.fallback_why[k];
         }
         float ms = 0;
@@ -606,6 +611,7 @@ int render_impl_band(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
         stats->ms_total = ms;
         stats->ms_raygen = tm.total(0, &stats->launches_raygen);
         stats->ms_trace_closest = tm.total(1, &stats->launches_trace_closest);
+        stats->ms_fallback = tm.fallback_total(&stats->launches_fallback);
         stats->ms_shade = tm.total(2, &stats->launches_shade);
         stats->ms_trace_any = tm.total(3, &stats->launches_trace_any);
         stats->ms_film = tm.total(4, &stats->launches_film);
@@ -678,6 +684,11 @@ int render_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sensor* se
         sum.nodes_visited_shadow += st.nodes_visited_shadow;
         sum.prims_tested_shadow += st.prims_tested_shadow;
         sum.fallback_rays += st.fallback_rays;
+        sum.nodes_visited_fallback += st.nodes_visited_fallback;
+        sum.prims_tested_fallback += st.prims_tested_fallback;
+        sum.ms_fallback += st.ms_fallback;
+        sum.launches_fallback += st.launches_fallback;
+        for (int k = 0; k < 4; ++k) sum.count_sub[k] += st.count_sub[k];
         sum.ms_total += st.ms_total;
         sum.ms_raygen += st.ms_raygen;
         sum.ms_trace_closest += st.ms_trace_closest;

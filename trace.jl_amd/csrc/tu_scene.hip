@@ -706,6 +706,19 @@ int upload_accelerator(trhip_scene* s) {
     s->cert.sphere_boxes = (const float*)s->d_sphere_boxes.p;
     s->cert.sphere_slots = (const uint32_t*)s->d_sphere_slots.p;
     s->cert.n_spheres = (uint32_t)s->spheres.size();
+    {
+        std::vector<SphereCert> sc(std::max<size_t>(1, s->spheres.size()));
+        for (size_t k = 0; k < s->spheres.size(); ++k) {
+            std::memcpy(sc[k].box, &sph_box[6 * k], 6 * sizeof(float));
+            sc[k].radius = s->spheres[k].radius;
+            sc[k].slot = sph_slot[k];
+            std::memcpy(sc[k].o2w_inv, s->spheres[k].o2w_inv, 16 * sizeof(float));
+            sc[k].never_clipped = s->spheres[k].never_clipped;
+            sc[k].pad[0] = sc[k].pad[1] = sc[k].pad[2] = 0u;
+        }
+        if (int rc = upload(ctx, s->d_sphere_cert, sc.data(), sc.size() * sizeof(SphereCert))) return rc;
+        s->cert.sphere_cert = s->d_sphere_cert.p;
+    }
     std::memcpy(s->wide_acc.root_box, &s->bvh.bounds[0], 6 * sizeof(float));  // the union of all primitives: the same box in every tree (bvh.jl:226 tests it first)
     const bool one_leaf = n_anodes == 1 && (s->acc.flags[0] & 3u) == 3u;
     if (one_leaf) {
@@ -963,6 +976,7 @@ void trhip_scene_free(trhip_scene* s) {
     release(s->d_slot_boxes);
     release(s->d_sphere_boxes);
     release(s->d_sphere_slots);
+    release(s->d_sphere_cert);
     release(s->d_acc_leaf_order);
     delete s;
 }

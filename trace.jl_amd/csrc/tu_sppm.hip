@@ -286,11 +286,14 @@ int render_sppm_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
         stats->nodes_visited_shadow = h.nodes_shadow;
         stats->prims_tested_shadow = h.prims_shadow;
         stats->fallback_rays = h.fallback_total;
+        stats->nodes_visited_fallback = h.nodes_fallback;
+        stats->prims_tested_fallback = h.prims_fallback;
         float ms = 0;
         (void)hipEventElapsedTime(&ms, e0, e1);
         stats->ms_total = ms;
         stats->ms_raygen = tm.total(0, &stats->launches_raygen);
         stats->ms_trace_closest = tm.total(1, &stats->launches_trace_closest);
+        stats->ms_fallback = tm.fallback_total(&stats->launches_fallback);
         stats->ms_sub[0] = tm.total(5, &stats->launches_sub[0]);  // photon gather
         stats->ms_sub[1] = tm.total(2, &stats->launches_sub[1]);  // camera / photon shading
         stats->ms_sub[2] = tm.total(6, &stats->launches_sub[2]);  // grid bounds, hit binning, scans

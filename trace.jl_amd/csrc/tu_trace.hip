@@ -101,7 +101,10 @@ void launch_trace(trhip_ctx* ctx, hipStream_t st, const trhip_scene* sc, bool an
             }
             // the flagged rays, in the reference's order on the canonical tree (already counted: no_total)
             const SegQueue fq{fcounts, fcap, 0u, fb.list, 1u};
+            if (!any && ctx->active_timer) ctx->active_timer->mark_fallback(st);
+            if (!any && cnt && ctr) hipLaunchKernelGGL(k_hybrid_count_mark, dim3(1), dim3(1), 0, st, ctr, 0);
             launch_trace3(ctx, st, sc, any, cnt, full_only, !any && !cnt && canon_bytes > ((size_t)256 << 20), fq, ro, rd, tmax, out, fcounts + (size_t)kSeg * kCtrStride, ov, ctr);
+            if (!any && cnt && ctr) hipLaunchKernelGGL(k_hybrid_count_mark, dim3(1), dim3(1), 0, st, ctr, 1);
             return;
         }
     }

@@ -49,7 +49,7 @@ void launch_trace3c(trhip_ctx* ctx, hipStream_t st, const trhip_scene* sc, bool 
     cc.sq_flat = cv.sq_flat;
     cc.inv_tight = cv.inv_tight;
     hipLaunchKernelGGL(k_store_cert_cold, dim3(1), dim3(1), 0, st, cold, cc);
-    const CertHot hot{kCertDt * cv.inv_tight, kCertGrow * cv.inv_tight, kCertFlat * cv.sq_flat};
+    const CertHot hot{kCertDt * cv.inv_tight, kCertGrow * cv.inv_tight, kCertFlat * cv.sq_flat, cv.n_spheres, (const SphereCert*)cv.sphere_cert, {cv.mle_small[0], cv.mle_small[1], cv.mle_small[2]}};
     if (cnt) {
         if (full_only) TH_LAUNCH3C(true, true, false); else TH_LAUNCH3C(true, false, false);
     } else if (big) {
@@ -74,3 +74,16 @@ void launch_leaf_c(trhip_ctx* ctx, hipStream_t st, const trhip_scene* sc, bool a
     }
 #undef TH_LEAFC
 }
+
+#ifdef TH_DIAG_PHASES
+extern "C" __attribute__((visibility("default"))) int trhip_debug_phases_c(uint64_t* out12, int reset) {  // DIAGNOSTIC build only (tools/phase_probe.py): k_trace3c's phases
+    unsigned long long h[16];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase), sizeof h) != hipSuccess) return -1;
+    for (int i = 0; i < 13; ++i) out12[i] = h[i];
+    if (reset) {
+        std::memset(h, 0, sizeof h);
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase), h, sizeof h) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif

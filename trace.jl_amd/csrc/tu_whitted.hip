@@ -110,6 +110,7 @@ int render_whitted_impl(trhip_ctx* ctx, const trhip_scene* scene, const DeviceSe
     if (stats) {
         stats->ms_raygen = tm.total(0, &stats->launches_raygen);
         stats->ms_trace_closest = tm.total(1, &stats->launches_trace_closest);
+        stats->ms_fallback = tm.fallback_total(&stats->launches_fallback);
         stats->ms_shade = tm.total(2, &stats->launches_shade);
         stats->ms_trace_any = tm.total(3, &stats->launches_trace_any);
         stats->ms_film = tm.total(4, &stats->launches_film);

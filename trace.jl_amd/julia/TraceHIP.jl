@@ -54,7 +54,12 @@ mutable struct TrhipStats
     ms_sub::NTuple{4,Float64}
     launches_sub::NTuple{4,UInt32}
     count_sub::NTuple{4,UInt64}
-    TrhipStats() = new(0, 0, 0, 0, 0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, (0, 0, 0, 0, 0), 0, 0, 0, 0, 0, 0, (0.0, 0.0, 0.0, 0.0), (0, 0, 0, 0), (0, 0, 0, 0))
+    ms_fallback::Float64
+    launches_fallback::UInt32
+    reserved0::UInt32
+    nodes_visited_fallback::UInt64
+    prims_tested_fallback::UInt64
+    TrhipStats() = new(0, 0, 0, 0, 0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, (0, 0, 0, 0, 0), 0, 0, 0, 0, 0, 0, (0.0, 0.0, 0.0, 0.0), (0, 0, 0, 0), (0, 0, 0, 0), 0.0, 0, 0, 0, 0)
 end
 
 struct TraceHIPError <: Exception
