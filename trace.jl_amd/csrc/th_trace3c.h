@@ -257,7 +257,10 @@ __global__ __launch_bounds__(kBlock, BIG ? TH_TRACE3C_WAVES - 1 : TH_TRACE3C_WAV
     f3 o = splat3(0.0f), inv_d = splat3(0.0f);
     float em = 0.0f;
     RayShear shear{0, 0.0f, 0.0f, 0.0f};
-    bool negx = false, negy = false, negz = false;
+    // (the direction signs are read off inv_d where they are needed: a ray with a zero component, the one case where sign(1 / d) is not sign(d), never walks here)
+#define negx (inv_d.x < 0.0f)
+#define negy (inv_d.y < 0.0f)
+#define negz (inv_d.z < 0.0f)
     float t_lim = 0.0f;   // t_max + 2 dt, t_max = the t of the last accepted candidate (or the ray's own t_max): what the primitive tests accept up to; a box is culled when the lower
                           // bound of what it holds — its entry distance minus the margin — reaches it
     float mb = 0.0f;      // per ray: the margin of the lower bound: non-flat primitives their kz extent, everything the growth in the entering axis (with AXIS the growth is applied per
@@ -385,9 +388,6 @@ __global__ __launch_bounds__(kBlock, BIG ? TH_TRACE3C_WAVES - 1 : TH_TRACE3C_WAV
                         inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
                         em = slab_margin(ws.root_box, ws.tight_scale, o);
                         shear = ray_shear(d);
-                        negx = d.x < 0.0f;
-                        negy = d.y < 0.0f;
-                        negz = d.z < 0.0f;
                         const float t_own = tmax_or_null ? tmax_or_null[idx] : kInf;
                         const float dt = margin_t();
                         const float mkz = (shear.kz == 0 ? ch.mle[0] : (shear.kz == 1 ? ch.mle[1] : ch.mle[2])) * fabsf(shear.sz);
@@ -519,7 +519,7 @@ __global__ __launch_bounds__(kBlock, BIG ? TH_TRACE3C_WAVES - 1 : TH_TRACE3C_WAV
                 const uint32_t axis = meta & 3u;
                 const bool neg = axis == 0 ? negx : (axis == 1 ? negy : negz);
                 const float bn = neg ? br : bl, bf = neg ? bl : br;
-                const float vn = neg ? tr : tl, vf = neg ? tl : tr;
+                const float vn = AXIS ? (neg ? tr : tl) : bn, vf = AXIS ? (neg ? tl : tr) : bf;  // (only read for a child that is entered: there the two are the same number)
                 const uint32_t nenc = neg ? renc : lenc, fenc = neg ? lenc : renc;
                 const bool go_n = bn < t_cull, go_f = bf < t_cull;
                 // t_max never goes up in THIS walk (a ray that could see it raised is flagged and leaves): an entry that fails now fails at pop time
@@ -652,6 +652,9 @@ __global__ __launch_bounds__(kBlock, BIG ? TH_TRACE3C_WAVES - 1 : TH_TRACE3C_WAV
         }
     }
 }
+#undef negx
+#undef negy
+#undef negz
 
 // ---- one-leaf accelerator (scenes of at most "tiny_scene_prims" primitives: S-cornell, the shadows scene) -------------------------------------------------
 // The accelerator is the list of all primitives in canonical slot order, walked with a wave-uniform index (k_trace_leaf's scheme: scalar loads, no stack).
