@@ -660,8 +660,11 @@ __global__ __launch_bounds__(kBlock, BIG ? TH_TRACE3C_WAVES - 1 : TH_TRACE3C_WAV
 // The accelerator is the list of all primitives in canonical slot order, walked with a wave-uniform index (k_trace_leaf's scheme: scalar loads, no stack).
 // Nothing is culled, so every candidate is seen; what remains of the certificate: a primitive counts only when the t_max-free clauses pass on the box of ITS
 // canonical leaf (cs.slot_boxes), and the acceptance / flag rule of the header (a candidate below g + dt is accepted iff max(t, entry of its leaf box) <= t_max - dt).  Flagged rays go to the fallback list, which k_trace3 walks on the canonical tree.
+#ifndef TH_TRACE_LEAF_C_WAVES
+#define TH_TRACE_LEAF_C_WAVES TH_TRACE_LEAF_WAVES
+#endif
 template <bool COUNT, bool FULL_ONLY>
-__global__ __launch_bounds__(kBlock, FULL_ONLY ? TH_TRACE_LEAF_WAVES : 4) void k_trace_leaf_c(DeviceScene sc /* canonical records */, WideScene ws /* root box; root_ref / root_cnt = all slots */,
+__global__ __launch_bounds__(kBlock, FULL_ONLY ? TH_TRACE_LEAF_C_WAVES : 4) void k_trace_leaf_c(DeviceScene sc /* canonical records */, WideScene ws /* root box; root_ref / root_cnt = all slots */,
                                                                               CertScene cs, SegQueue q, const float4* __restrict__ ro, const float4* __restrict__ rd,
                                                                               const float* __restrict__ tmax_or_null, TraceOut out, Counters* ctr, FallbackList fb) {
     __shared__ SegView sv;
@@ -703,18 +706,15 @@ __global__ __launch_bounds__(kBlock, FULL_ONLY ? TH_TRACE_LEAF_WAVES : 4) void k
                 live = slab_test2(ws.root_box[0], ws.root_box[1], ws.root_box[2], ws.root_box[3], ws.root_box[4], ws.root_box[5], o, inv_d, 0.0f, false, negx, negy, negz, tmin) && tmin < t_lim;
         }
         bool found = false, sticky = false;
-        float4 rec = make_float4(kInf, __int_as_float(-1), 0.0f, 0.0f);
 #pragma unroll 1
         for (uint32_t k = 0; k < cnt; ++k) {
             if (__ballot(live) == 0ull) break;
             const uint32_t slot = first + k;  // wave-uniform: scalar loads
             const float4 p0 = uniform_load(sc.prims, 3 * slot);
             const uint32_t meta = __float_as_uint(p0.w);
-            const float* bx = cs.slot_boxes + 6 * (size_t)slot;
-            const float b0 = uniform_load(bx, 0), b1 = uniform_load(bx, 1), b2 = uniform_load(bx, 2), b3 = uniform_load(bx, 3), b4 = uniform_load(bx, 4), b5 = uniform_load(bx, 5);
             float t_c = 0.0f;
             float4 r4 = make_float4(0.0f, __int_as_float((int)slot), 0.0f, 0.0f);
-            bool cand = false, inside = false;
+            bool cand = false, inside = false, clipped = false;
             if (meta & PRIM_SPHERE) {
                 const SphereRec sr = uniform_load(sc.spheres, __float_as_uint(p0.x));
                 if (live) {
@@ -725,9 +725,7 @@ __global__ __launch_bounds__(kBlock, FULL_ONLY ? TH_TRACE_LEAF_WAVES : 4) void k
                         inside = r == 3;
                         r4.x = t_c;
                     } else if (r == 2) {
-                        // clipped — but only a sphere the reference can reach at all (its leaf's t_max-free clauses) makes the order matter
-                        float ex;
-                        if (slab_test2(b0, b1, b2, b3, b4, b5, o, inv_d, 0.0f, false, negx, negy, negz, ex)) flagged = true;
+                        clipped = true;  // — but only a sphere the reference can reach at all (its leaf's t_max-free clauses) makes the order matter
                     }
                 }
             } else if (!(meta & PRIM_DEGENERATE)) {
@@ -744,18 +742,20 @@ __global__ __launch_bounds__(kBlock, FULL_ONLY ? TH_TRACE_LEAF_WAVES : 4) void k
             } else if (COUNT && live) {
                 np++;
             }
-            if (cand) {
+            if (__ballot(cand | clipped) != 0ull) {  // (a few primitives per ray: the box of the primitive's canonical leaf is fetched only now — wave-uniform, scalar loads)
+                const float* bx = cs.slot_boxes + 6 * (size_t)slot;
+                const float b0 = uniform_load(bx, 0), b1 = uniform_load(bx, 1), b2 = uniform_load(bx, 2), b3 = uniform_load(bx, 3), b4 = uniform_load(bx, 4), b5 = uniform_load(bx, 5);
                 float ex;
-                if (COUNT) nn++;
-                if (slab_test2(b0, b1, b2, b3, b4, b5, o, inv_d, 0.0f, false, negx, negy, negz, ex)) {  // the reference reaches this primitive's leaf at all
-                    if (sticky || !(t_c <= t_max - 2.0f * dt) || !(ex <= t_c + dt)) {
+                if (COUNT && cand) nn++;
+                if ((cand | clipped) && slab_test2(b0, b1, b2, b3, b4, b5, o, inv_d, 0.0f, false, negx, negy, negz, ex)) {  // the reference reaches this primitive's leaf at all
+                    if (clipped || sticky || !(t_c <= t_max - 2.0f * dt) || !(ex <= t_c + dt)) {
                         flagged = true;
                     } else {
                         t_max = t_c;
                         t_lim = t_c + 2.0f * dt;
                         found = true;
                         sticky = inside;
-                        rec = r4;
+                        out.hits[idx] = r4;  // stored at once (a later accepted candidate overwrites it; a flagged ray's record is rewritten by the fallback walk)
                     }
                 }
             }
@@ -775,7 +775,7 @@ __global__ __launch_bounds__(kBlock, FULL_ONLY ? TH_TRACE_LEAF_WAVES : 4) void k
                 fseg = (fseg + 1) % kSeg;
             }
         }
-        if (valid && !flagged) out.hits[idx] = found ? rec : make_float4(kInf, __int_as_float(-1), 0.0f, 0.0f);
+        if (valid && !flagged && !found) out.hits[idx] = make_float4(kInf, __int_as_float(-1), 0.0f, 0.0f);
     }
     if (ctr) {
         if (blockIdx.x == 0 && threadIdx.x == 0 && !q.no_total) atomicAdd(&ctr->closest_total, (unsigned long long)seg_total(sv));
