@@ -50,7 +50,8 @@ function shadows_scene()   # docs/src/shadows.md:8-64
     prims = Trace.GeometricPrimitive[
         sphere((0.3, 0.11, -2.2), 0.1f0, glass), sphere((0.2, 0.11, -2.6), 0.1f0, material_blue), sphere((0.7, 0.31, -2.8), 0.3f0, mirror),
         sphere((0.7, 0.11, -2.3), 0.1f0, material_red)]
-    append!(prims, [Trace.GeometricPrimitive(t, material_white) for t in tris])
+    tri_materials = [mirror, mirror, material_white, material_white]   # docs/src/shadows.md:77-80: the two floor triangles are mirrors
+    append!(prims, [Trace.GeometricPrimitive(t, m) for (t, m) in zip(tris, tri_materials)])
     lights = [Trace.PointLight(Trace.translate(Vec3f(-1, 1, 0)), Trace.RGBSpectrum(25f0))]
     Trace.Scene(lights, Trace.BVHAccel(prims, 1))
 end

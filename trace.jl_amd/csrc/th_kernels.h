@@ -144,8 +144,25 @@ TH_D SlotInfo slot_info(const DeviceSensor& se, uint32_t slot) {
 }
 
 // ---- film: where a camera sample's radiance record lives, and its splat descriptor (used by k_raygen and the film pass below) -------
+// layout 0: sample-major (the integrators' order).  layout 1: pixel-group-major — [group of 64 consecutive sample pixels][sample][position], one 1 KB chunk per (group,
+// sample) — with the position inside a chunk PERMUTED: pixels p = 0, 4, 8, ... first, then 1, 5, 9, ..., 2, 6, ..., 3, 7, ...  The film gather's lanes own BX adjacent film
+// pixels each, so one of its load instructions wants every BX-th sample pixel: in pixel order that is 16 bytes out of every BX x 16 (half of every cache line fetched for
+// 2 x 4 blocks, a quarter for 4 x 4 — the counters of round 3 showed 10x the algorithmic bytes); permuted, the pixels of one residue class mod 4 are 256 contiguous bytes,
+// and BX = 1, 2 and 4 all read whole 128-byte lines.  Everything that touches the records goes through this function.
+#ifndef TH_FILM_PERM
+#define TH_FILM_PERM 4
+#endif
+TH_D uint32_t film_chunk_pos(uint32_t p) {  // p = pix & 63
+#if TH_FILM_PERM == 4
+    return ((p & 3u) << 4) | (p >> 2);
+#elif TH_FILM_PERM == 2
+    return ((p & 1u) << 5) | (p >> 1);
+#else
+    return p;
+#endif
+}
 TH_D size_t film_index(uint32_t layout, uint32_t npix, uint32_t spp, uint32_t s, uint32_t pix) {
-    return layout ? ((size_t)(pix >> 6) * spp + s) * 64u + (pix & 63u) : (size_t)s * npix + pix;
+    return layout ? ((size_t)(pix >> 6) * spp + s) * 64u + film_chunk_pos(pix & 63u) : (size_t)s * npix + pix;
 }
 constexpr uint32_t kFilmPackSide = 0x80000000u;
 constexpr uint32_t kFilmPackOverflow = 0xffffffffu;
