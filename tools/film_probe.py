@@ -10,7 +10,7 @@ ap.add_argument("--spp", type=int, default=64)
 a = ap.parse_args()
 scene, cam = T.scenes.cornell_scene(), T.scenes.cornell_camera(1024)
 ctx = T.default_context()
-ap2 = [(m, r) for r in (1, 0) for m in (4, 5, 6, 10, 12, 13)] + [(2, 0)]
+ap2 = [(m, 1) for m in (5, 7, 8, 4, 10, 6, 12, 13, 9, 11)] + [(5, 0), (2, 0)]
 for mode, relayout in ap2:
     ctx.set_option("film_block", mode)
     ctx.set_option("film_relayout", relayout)

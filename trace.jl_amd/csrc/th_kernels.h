@@ -1196,9 +1196,12 @@ static __global__ __launch_bounds__(kBlock) void k_film_pack_transpose(const Dev
 #ifndef TH_FILM_PACKED_UNROLL
 #define TH_FILM_PACKED_UNROLL 8
 #endif
+#ifndef TH_FILM_PACKED_PIPELINE
+#define TH_FILM_PACKED_PIPELINE 1
+#endif
 template <int BX, int BY>
 __global__ __launch_bounds__(kBlock) void k_film_gather_packed(const DeviceSensor* __restrict__ sep, const float* __restrict__ table, const float4* __restrict__ L, uint32_t spp, uint64_t seed,
-                                                               uint32_t sample_offset, uint32_t layout, const uint4* __restrict__ side, float4* __restrict__ out) {
+                                                               uint32_t sample_offset, uint32_t layout, const uint4* __restrict__ side, float4* __restrict__ out, uint32_t xcd_bands) {
     const DeviceSensor& se = *sep;
     __shared__ float s_table[256];
     for (uint32_t t = threadIdx.x; t < 256u; t += kBlock) s_table[t] = table[t];
@@ -1207,7 +1210,11 @@ __global__ __launch_bounds__(kBlock) void k_film_gather_packed(const DeviceSenso
     const size_t sstride = layout ? (size_t)64 : (size_t)npix;  // records between consecutive samples of one sample pixel (film_index)
     const float rx = se.filter_radius[0], ry = se.filter_radius[1];
     const uint32_t nbx = ((uint32_t)se.film_w + BX - 1) / BX, nby = ((uint32_t)se.film_h + BY - 1) / BY;
-    for (uint32_t bidx = blockIdx.x * kBlock + threadIdx.x; bidx < nbx * nby; bidx += gridDim.x * kBlock) {
+    // option "film_swizzle" (A/B, off): workgroup ids are dealt to the 8 XCDs round-robin; with it XCD x gets the x-th contiguous eighth of the grid, so that vertically
+    // adjacent strips share an L2.  Measured (profiles/r4): no fewer bytes leave L2 — a strip re-reads its neighbour's 3 halo rows ~4 row passes (hundreds of MB of
+    // streaming per XCD) after the neighbour did, far beyond what the 4 MB L2 holds.
+    const uint32_t vblock = (xcd_bands && gridDim.x % 8u == 0u) ? (blockIdx.x % 8u) * (gridDim.x / 8u) + blockIdx.x / 8u : blockIdx.x;
+    for (uint32_t bidx = vblock * kBlock + threadIdx.x; bidx < nbx * nby; bidx += gridDim.x * kBlock) {
         const int fy0 = (int)(bidx / nbx) * BY, fx0 = (int)(bidx - (bidx / nbx) * nbx) * BX;
         float X[BX], Y[BY];
         int Xi[BX], Yi[BY];
@@ -1219,9 +1226,13 @@ __global__ __launch_bounds__(kBlock) void k_film_gather_packed(const DeviceSenso
             Y[j] = se.crop_min[1] + (float)(fy0 + j);
             Yi[j] = (int)Y[j];
         }
-        // union of the pixels' reaches (k_film_gather: sx in (X - 1.5 - r, X + r + 0.5])
-        const int sx_lo = max((int)__builtin_floorf(X[0] - 1.5f - rx), se.sb_min[0]), sx_hi = min((int)__builtin_ceilf(X[BX - 1] + rx + 0.5f), se.sb_max[0]);
-        const int sy_lo = max((int)__builtin_floorf(Y[0] - 1.5f - ry), se.sb_min[1]), sy_hi = min((int)__builtin_ceilf(Y[BY - 1] + ry + 0.5f), se.sb_max[1]);
+        // union of the pixels' reaches.  A sample of sample pixel sx has p_film in [sx, sx + 1] (closed: px + u may round up), so with a radius <= 1 (this kernel's
+        // precondition) its range is p0 = ceil(p_film - 0.5 - r) >= sx - 1 and p1 = floor(p_film - 0.5 + r) + 1 <= sx + 2 (film.jl:145-148; both bounds are exact in
+        // Float32) — which is also all the 32-bit descriptor can say (origin sx - 1 or sx, at most 4 wide).  Film pixel X is reached from sx in [X - 2, X + 1]: a
+        // block of BX x BY pixels reads (BX + 3) x (BY + 3) sample pixels.  (Until round 4 the loop ran over floor(X - 1.5 - r) .. ceil(X + r + 0.5), one more on
+        // each side: 63 sample pixels instead of 35 for 2 x 4 blocks, every one of them 256 records that could not contribute.)
+        const int sx_lo = max(Xi[0] - 2, se.sb_min[0]), sx_hi = min(Xi[BX - 1] + 1, se.sb_max[0]);
+        const int sy_lo = max(Yi[0] - 2, se.sb_min[1]), sy_hi = min(Yi[BY - 1] + 1, se.sb_max[1]);
         f3 xyz[BY][BX];
         float wsum[BY][BX];
         for (int j = 0; j < BY; ++j)
@@ -1332,6 +1343,46 @@ __global__ __launch_bounds__(kBlock) void k_film_gather_packed(const DeviceSenso
                             constexpr uint32_t kU = TH_FILM_PACKED_UNROLL;
                             const float4* sp = L + film_index(layout, npix, spp, 0u, pix);  // sample 0 of this sample pixel; the next sample is `sstride` records on
                             uint32_t s = 0;
+#if TH_FILM_PACKED_PIPELINE
+                            // two batches of kU records in flight: the next batch's loads are issued before the current one is consumed (the frame has 2 waves per SIMD
+                            // here — 131 072 threads at 2 x 4 pixels each — so nothing else hides a load's latency, and registers are not what limits the occupancy)
+                            if (spp >= 2u * kU) {
+                                float4 la[kU], lb[kU];
+#pragma unroll
+                                for (uint32_t u = 0; u < kU; ++u) la[u] = sp[(size_t)u * sstride];
+                                bool stop = false;
+                                for (; s + 2u * kU <= spp && !stop; s += 2u * kU, sp += (size_t)(2u * kU) * sstride) {
+#pragma unroll
+                                    for (uint32_t u = 0; u < kU; ++u) lb[u] = sp[(size_t)(kU + u) * sstride];
+                                    bool overflow = false;
+#pragma unroll
+                                    for (uint32_t u = 0; u < kU; ++u) overflow = overflow || __float_as_uint(la[u].w) == kFilmPackOverflow;
+                                    if (__builtin_expect(overflow, 0)) break;  // never, unless the side table ran full: the cold loop below takes over at s
+#pragma unroll
+                                    for (uint32_t u = 0; u < kU; ++u) splat(la[u], s + u, std::false_type{});
+                                    const bool more = s + 3u * kU <= spp;
+                                    if (more) {
+#pragma unroll
+                                        for (uint32_t u = 0; u < kU; ++u) la[u] = sp[(size_t)(2u * kU + u) * sstride];
+                                    }
+#pragma unroll
+                                    for (uint32_t u = 0; u < kU; ++u) overflow = overflow || __float_as_uint(lb[u].w) == kFilmPackOverflow;
+                                    if (__builtin_expect(overflow, 0)) {  // the first half is done: the cold loop takes over at s + kU
+                                        s += kU;
+                                        sp += (size_t)kU * sstride;
+                                        break;
+                                    }
+#pragma unroll
+                                    for (uint32_t u = 0; u < kU; ++u) splat(lb[u], s + kU + u, std::false_type{});
+                                    if (!more) {  // what is left is less than a batch, or one batch that was not prefetched: the loops below
+                                        s += 2u * kU;
+                                        sp += (size_t)(2u * kU) * sstride;
+                                        stop = true;
+                                        break;
+                                    }
+                                }
+                            }
+#endif
                             for (; s + kU <= spp; s += kU, sp += (size_t)kU * sstride) {
                                 float4 lv[kU];
                                 bool overflow = false;

@@ -91,7 +91,7 @@ void launch_film(trhip_ctx* ctx, hipStream_t st, const DeviceSensor& ds, const D
         }
         const float* tb = (const float*)ctx->table.p;
         auto threads = [&](int bx, int by) { return (uint64_t)((ds.film_w + bx - 1) / bx) * (uint64_t)((ds.film_h + by - 1) / by); };
-#define TH_FILM_PACKED(BXV, BYV) hipLaunchKernelGGL((k_film_gather_packed<BXV, BYV>), dim3(grid_for(ctx, threads(BXV, BYV), 8)), dim3(kBlock), 0, st, dsp, tb, L, spp, seed, sample_offset, layout, (const uint4*)side.desc, d_film)
+#define TH_FILM_PACKED(BXV, BYV) hipLaunchKernelGGL((k_film_gather_packed<BXV, BYV>), dim3(grid_for(ctx, threads(BXV, BYV), 8)), dim3(kBlock), 0, st, dsp, tb, L, spp, seed, sample_offset, layout, (const uint4*)side.desc, d_film, ctx->film_swizzle ? 1u : 0u)
         switch (ctx->film_block) {
         case 4: TH_FILM_PACKED(1, 4); break;
         case 7: TH_FILM_PACKED(2, 2); break;
