@@ -84,10 +84,11 @@ def test_device_sah_tree_is_the_host_builders(T, ob, ctx, which):
 
 
 def test_device_sah_random_soups(T, ob, ctx):
-    """Random triangle soups of many sizes (around the small-phase threshold of 64 too) and leaf-size hints: valid layout, host topology."""
+    """Random triangle soups of many sizes (around the small-phase threshold of 64 too) and leaf-size hints: valid layout, host topology.  Hints above 64 (where the
+    host builder's leaf-cost test can keep a node the device's top phase would split) are handed to the host builder: same tree by construction."""
     rng = np.random.default_rng(5)
     try:
-        for n, leaf in [(17, 1), (64, 1), (65, 1), (66, 4), (129, 2), (1000, 1), (4097, 4), (20000, 1), (50000, 8)]:
+        for n, leaf in [(17, 1), (64, 1), (65, 1), (66, 4), (129, 2), (1000, 1), (4097, 4), (20000, 1), (50000, 8), (3000, 128), (20000, 255)]:
             c = rng.random((n, 1, 3), dtype=np.float32) * np.float32(4.0)
             v = (c + (rng.random((n, 3, 3), dtype=np.float32) - np.float32(0.5)) * np.float32(0.2)).astype(np.float32)
             pb = np.concatenate([v.min(axis=1), v.max(axis=1)], axis=1)

@@ -44,7 +44,7 @@ class RefBVHBuilder {
 
    private:
     static constexpr int kBuckets = 12;
-    static constexpr uint32_t kMaxRecursion = 4096;
+    static constexpr uint32_t kMaxRecursion = 128;  // (a tree deeper than the 64-entry traversal stack is refused by the commit anyway; each level holds the 12 buckets on the host stack)
 
     static float surface_area(const HostAABB& b) {
         const float dx = b.mx[0] - b.mn[0], dy = b.mx[1] - b.mn[1], dz = b.mx[2] - b.mn[2];
@@ -54,7 +54,11 @@ class RefBVHBuilder {
     int bucket_of(const HostAABB& cb, uint32_t prim, int dim) const {
         const float o = cen_[3 * (size_t)prim + dim] - cb.mn[dim];
         const float off = cb.mx[dim] > cb.mn[dim] ? o / (cb.mx[dim] - cb.mn[dim]) : o;
-        int b = (int)std::floor((float)kBuckets * off) + 1;
+        // a NaN / Inf centroid or extent (caller-supplied bounds, trhip_build_bvh_host): the reference's Int(floor(...)) throws InexactError, its bucket[b] a BoundsError —
+        // and (int) of such a float is undefined behaviour here.  Refused before the conversion.
+        const float fb = std::floor((float)kBuckets * off);
+        if (!(fb >= 0.0f && fb <= (float)kBuckets)) throw std::runtime_error("the reference's BVH construction fails on this input: a primitive's bounds are not finite (bvh.jl:135-138)");
+        int b = (int)fb + 1;
         if (b == kBuckets + 1) b -= 1;
         return b;
     }

@@ -70,10 +70,13 @@ int build_bvh_device(trhip_ctx* ctx, const std::vector<HostAABB>& pb, FlatBVH& o
 }
 
 // BVHAccel on the device with the host builder's binned SAH (th_sahb.h).  TRHIP_ERR_UNSUPPORTED: a scene this builder hands back to the host
-// (a large set of coincident centroids, a tree past depth 39 before the nodes get small).
+// (a large set of coincident centroids, a tree past depth 39 before the nodes get small, a leaf hint above kSahSmall).
 int build_bvh_device_sah(trhip_ctx* ctx, const std::vector<HostAABB>& pb, int max_node_prims, bool split_coincident, FlatBVH& out, double* ms_device) {
     const uint32_t n = (uint32_t)pb.size();
     if (n < 2 || n >= (1u << 30)) return TRHIP_ERR_UNSUPPORTED;
+    // th_bvh.h keeps a node of n <= max_node_prims primitives a leaf when splitting does not pay (its leaf-cost test); the top phase here splits every node of more
+    // than kSahSmall primitives without asking.  With a leaf hint of 65 .. 255 the two would differ: such scenes go to the host builder, whose tree this one promises.
+    if (std::min(255, max_node_prims) > (int)kSahSmall) return TRHIP_ERR_UNSUPPORTED;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     struct Buf {
         void* p = nullptr;

@@ -12,6 +12,7 @@ module TraceHIP
 using Trace
 using GeometryBasics
 using StaticArrays
+using Random
 
 const LIB = get(ENV, "TRACEHIP_LIB", joinpath(@__DIR__, "..", "libtracehip.so"))
 
@@ -254,33 +255,84 @@ end
 # the film accumulators onto rank 0, which alone writes the image; SPPM shards its photons inside trhip_render_sppm.
 const JOB = Ref{Tuple{Int,Int}}((0, 1))
 const JOB_ID_PATH = Ref{String}("")
-# what tells this job's id file from an earlier job's at the same path (an id of another job makes ncclCommInitRank hang)
-job_nonce() = get(ENV, "TRACEHIP_JOB_ID", haskey(ENV, "MASTER_PORT") ? string(get(ENV, "TORCHELASTIC_RUN_ID", "run"), "-", ENV["MASTER_PORT"]) : string("ppid", ccall(:getppid, Cint, ())))
+# Optional suffix of the id file's name (two jobs sharing TRACEHIP_ID_FILE): the same on every rank under any launcher — no pid, no ppid.  What makes a file a crashed
+# job left behind harmless is the token handshake below, not the name.
+function job_suffix()
+    for name in ("TRACEHIP_JOB_ID", "SLURM_JOB_ID", "PBS_JOBID", "LSB_JOBID")
+        haskey(ENV, name) && !isempty(ENV[name]) && return string(".", ENV[name])
+    end
+    ""
+end
+write_atomically(path, data) = (tmp = string(path, ".tmp", getpid()); write(tmp, data); mv(tmp, path; force = true))
+read_or_empty(path) = try read(path) catch; UInt8[] end
+random_token() = bytes2hex(rand(Random.RandomDevice(), UInt8, 16))
+# The RCCL id from rank 0 to the others through a shared directory — the protocol of trace.jl_amd/parallel.py file_rendezvous, byte for byte (a job may mix hosts):
+# reader r writes <path>.hello<r> = a fresh token, polls <path> for the line "r:<token>", answers with <path>.ack<r> = "<token>:<rank 0's token>"; rank 0 rewrites
+# <path> = id, "0:<its token>", one line per reader seen, until every ack matches.  Both sides give up after `timeout_s` (TRACEHIP_RENDEZVOUS_TIMEOUT, default 120).
+function file_rendezvous(path, rank, world; timeout_s = parse(Float64, get(ENV, "TRACEHIP_RENDEZVOUS_TIMEOUT", "120")))
+    t0 = time()
+    if rank == 0
+        id = Vector{UInt8}(undef, 128)
+        check(ccall((:trhip_comm_unique_id, LIB), Cint, (Ptr{UInt8},), id))
+        mine = random_token()
+        written = nothing
+        while true
+            tokens = Dict{Int,String}()
+            for r in 1:world-1
+                tok = strip(String(read_or_empty(string(path, ".hello", r))))
+                isempty(tok) || (tokens[r] = tok)
+            end
+            if tokens != written
+                io = IOBuffer()
+                write(io, id)
+                write(io, "0:", mine, "\n")
+                for r in sort(collect(keys(tokens)))
+                    write(io, string(r), ":", tokens[r], "\n")
+                end
+                write_atomically(path, take!(io))
+                written = copy(tokens)
+            end
+            if length(tokens) == world - 1 && all(strip(String(read_or_empty(string(path, ".ack", r)))) == string(tokens[r], ":", mine) for r in 1:world-1)
+                return id
+            end
+            time() - t0 > timeout_s && error("TraceHIP: RCCL id rendezvous at $path: not every rank showed up and acknowledged within $timeout_s s")
+            sleep(0.05)
+        end
+    end
+    token = random_token()
+    write_atomically(string(path, ".hello", rank), token)
+    want = string(rank, ":", token)
+    while true
+        data = read_or_empty(path)
+        if length(data) > 128
+            lines = split(String(data[129:end]), "\n")
+            if want in lines && startswith(lines[1], "0:")
+                write_atomically(string(path, ".ack", rank), string(token, ":", lines[1][3:end]))
+                return data[1:128]
+            end
+        end
+        time() - t0 > timeout_s && error("TraceHIP: no RCCL id for rank $rank at $path after $timeout_s s (is rank 0 running, and is the directory shared?)")
+        sleep(0.05)
+    end
+end
 function init_job!(; rank = parse(Int, get(ENV, "RANK", "0")), world = parse(Int, get(ENV, "WORLD_SIZE", "1")), id_file = get(ENV, "TRACEHIP_ID_FILE", ""))
     world <= 1 && return JOB[]
     isempty(id_file) && error("TraceHIP: set TRACEHIP_ID_FILE to a path all ranks can reach")
-    path = string(id_file, ".", job_nonce())
-    id = Vector{UInt8}(undef, 128)
-    if rank == 0
-        isfile(path) && rm(path)                      # a stale file of a crashed job with the same nonce
-        check(ccall((:trhip_comm_unique_id, LIB), Cint, (Ptr{UInt8},), id))
-        tmp = string(path, ".tmp", getpid())
-        write(tmp, id)
-        mv(tmp, path; force = true)
-        JOB_ID_PATH[] = path
-    else
-        while !(isfile(path) && filesize(path) == 128)
-            sleep(0.05)
-        end
-        id = read(path)
-    end
+    path = string(id_file, job_suffix())
+    id = file_rendezvous(path, rank, world)
+    rank == 0 && (JOB_ID_PATH[] = path)
     check(ccall((:trhip_comm_init, LIB), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Cint, Cint), context(), id, rank, world))
     JOB[] = (rank, world)
 end
 # end of the job: the communicator goes, rank 0 removes the id file (every rank has read it: trhip_comm_init returned everywhere)
 function close_job!()
     JOB[][2] > 1 && ccall((:trhip_comm_destroy, LIB), Cint, (Ptr{Cvoid},), context())
-    isempty(JOB_ID_PATH[]) || rm(JOB_ID_PATH[]; force = true)
+    if !isempty(JOB_ID_PATH[])
+        rm(JOB_ID_PATH[]; force = true)
+        for kind in ("hello", "ack"), r in 1:JOB[][2]-1
+            rm(string(JOB_ID_PATH[], ".", kind, r); force = true)
+        end
+    end
     JOB_ID_PATH[] = ""
     JOB[] = (0, 1)
 end

@@ -42,11 +42,77 @@ def reduce_film(film, dst: int = 0):
     return film
 
 
+def _write_atomically(path: str, data: bytes):
+    tmp = f"{path}.tmp{os.getpid()}"
+    with open(tmp, "wb") as f:
+        f.write(data)
+    os.replace(tmp, path)
+
+
+def _read(path: str) -> bytes:
+    try:
+        with open(path, "rb") as f:
+            return f.read()
+    except (FileNotFoundError, PermissionError):
+        return b""
+
+
+def file_rendezvous(path: str, rank: int, world: int, make_id, id_bytes: int, timeout_s: float = 120.0, poll_s: float = 0.05) -> bytes:
+    """The RCCL unique id from rank 0 to the others through a shared directory, safe against files a crashed job left behind (two ranks that call ncclCommInitRank
+    with different ids hang).  No file is trusted for being there: every reader proves to rank 0 that it is alive NOW, and accepts an id only from a rank 0 that has
+    seen that proof.
+
+        reader r:  writes  <path>.hello<r> = a fresh random token;  polls <path> until it holds the line "r:<its token>";  then writes <path>.ack<r> =
+                   "<its token>:<rank 0's token>" (the line "0:..." of the same file)
+        rank 0:    makes the id and a fresh random token once;  repeats { read the hello files that exist; (re)write <path> = id + "0:<token>" + one line "r:token"
+                   per reader seen; } until every reader's ack file holds "<the token of its current hello file>:<rank 0's token>".
+
+    A stale <path> does not carry the new tokens; a stale hello is echoed, ignored by the live reader, and replaced as soon as that reader writes its own; a stale
+    ack does not carry rank 0's new token.  Raises TraceHipError after `timeout_s` (both sides).  The same protocol, byte for byte, is in julia/TraceHIP.jl (init_job!)."""
+    import secrets
+    t0 = time.time()
+
+    def expired():
+        return time.time() - t0 > timeout_s
+
+    if rank == 0:
+        uid = bytes(make_id())
+        assert len(uid) == id_bytes
+        mine = secrets.token_hex(16).encode()
+        written = None
+        while True:
+            tokens = {}
+            for r in range(1, world):
+                tok = _read(f"{path}.hello{r}").strip()
+                if tok:
+                    tokens[r] = tok
+            if tokens != written:
+                _write_atomically(path, uid + b"0:%s\n" % mine + b"".join(b"%d:%s\n" % (r, tok) for r, tok in sorted(tokens.items())))
+                written = dict(tokens)
+            if len(tokens) == world - 1 and all(_read(f"{path}.ack{r}").strip() == tokens[r] + b":" + mine for r in range(1, world)):
+                return uid
+            if expired():
+                raise _ffi.TraceHipError(f"RCCL id rendezvous at {path}: {world - 1 - len(tokens)} rank(s) never showed up, or never acknowledged, within {timeout_s} s")
+            time.sleep(poll_s)
+    token = secrets.token_hex(16).encode()
+    _write_atomically(f"{path}.hello{rank}", token)
+    want = b"%d:%s" % (rank, token)
+    while True:
+        data = _read(path)
+        lines = data[id_bytes:].split(b"\n") if len(data) > id_bytes else []
+        if want in lines and lines[0].startswith(b"0:"):
+            _write_atomically(f"{path}.ack{rank}", token + b":" + lines[0][2:])
+            return data[:id_bytes]
+        if expired():
+            raise _ffi.TraceHipError(f"no RCCL id for rank {rank} at {path} after {timeout_s} s (is rank 0 running, and is the directory shared?)")
+        time.sleep(poll_s)
+
+
 class Job:
     """This process's membership in an N-GPU job: creates the library-side RCCL communicator on `ctx`.
 
-    rank / world default to RANK / WORLD_SIZE.  Rendezvous of the unique id: `id_file` (rank 0 writes it, the others poll for
-    it) or, when torch.distributed is initialised, a broadcast over that group."""
+    rank / world default to RANK / WORLD_SIZE.  Rendezvous of the unique id: `id_file` (a path in a directory all ranks share: file_rendezvous above) or, when
+    torch.distributed is initialised, a broadcast over that group."""
 
     def __init__(self, ctx: _ffi.Context, rank: int | None = None, world: int | None = None, id_file: str | None = None, timeout_s: float = 120.0):
         self.ctx = ctx
@@ -61,42 +127,20 @@ class Job:
         self.ok = True
 
     @staticmethod
-    def job_nonce() -> str:
-        """What tells this job's id file from an earlier job's at the same path: TRACEHIP_JOB_ID, else the launcher's rendezvous
-        (TORCHELASTIC_RUN_ID + MASTER_PORT), else the launcher's pid (the ranks of one node share their parent)."""
+    def job_suffix() -> str:
+        """Optional: TRACEHIP_JOB_ID (or the batch system's job id) keeps two jobs that share `id_file` apart in the file system.  It is NOT what makes a stale file
+        harmless — the token handshake of file_rendezvous is; without any of these variables every rank uses the bare path (all ranks compute the same name under any
+        launcher: srun, mpirun, wrapper shells)."""
         env = os.environ
-        if env.get("TRACEHIP_JOB_ID"):
-            return env["TRACEHIP_JOB_ID"]
-        if env.get("MASTER_PORT"):
-            return f"{env.get('TORCHELASTIC_RUN_ID', 'run')}-{env['MASTER_PORT']}"
-        return f"ppid{os.getppid()}"
+        for name in ("TRACEHIP_JOB_ID", "SLURM_JOB_ID", "PBS_JOBID", "LSB_JOBID"):
+            if env.get(name):
+                return "." + env[name]
+        return ""
 
     def _exchange_id(self, id_file, timeout_s) -> bytes:
         if id_file:
-            # the file is per job (nonce in its name), written atomically, and removed by rank 0 in close(): a second job at the same
-            # path never reads the first one's id (ncclCommInitRank with two different ids hangs)
-            path = self._id_path = f"{id_file}.{self.job_nonce()}"
-            if self.rank == 0:
-                if os.path.exists(path):
-                    os.unlink(path)  # a stale file of a crashed job with the same nonce
-                uid = _ffi.comm_unique_id()
-                tmp = path + f".tmp{os.getpid()}"
-                with open(tmp, "wb") as f:
-                    f.write(uid)
-                os.replace(tmp, path)
-                return uid
-            t0 = time.time()
-            while True:
-                try:
-                    with open(path, "rb") as f:
-                        uid = f.read()
-                    if len(uid) == _ffi.UNIQUE_ID_BYTES:
-                        return uid
-                except FileNotFoundError:
-                    pass
-                if time.time() - t0 > timeout_s:
-                    raise _ffi.TraceHipError(f"no RCCL id at {path} after {timeout_s} s")
-                time.sleep(0.05)
+            self._id_path = id_file + self.job_suffix()
+            return file_rendezvous(self._id_path, self.rank, self.world, _ffi.comm_unique_id, _ffi.UNIQUE_ID_BYTES, timeout_s)
         import torch
         import torch.distributed as dist
         if not (dist.is_available() and dist.is_initialized()):
@@ -121,6 +165,8 @@ class Job:
         if self.ok:
             self.ctx.comm_destroy()  # every rank has read the id by now (ncclCommInitRank returned everywhere)
             self.ok = False
-        if self.rank == 0 and self._id_path and os.path.exists(self._id_path):
-            os.unlink(self._id_path)
+        if self.rank == 0 and self._id_path:
+            for f in [self._id_path] + [f"{self._id_path}.{kind}{r}" for kind in ("hello", "ack") for r in range(1, self.world)]:
+                if os.path.exists(f):
+                    os.unlink(f)
             self._id_path = None
