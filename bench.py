@@ -336,6 +336,31 @@ def run_sppm(args, T, ctx, graft, rank, world, comm_ok):
     return result
 
 
+def require_communicator(T, ctx, rank, world, device):
+    """The job's communicator, inside the library (include/tracehip.h "multi-GPU"): rank 0 makes the RCCL id, torch.distributed carries it.  An N-rank bench line must
+    come from the library's own RCCL communicator with N ranks (trhip_comm_rank), or not at all: when it is not up on EVERY rank the ranks agree on that (one MIN
+    all-reduce over the launcher's group), say why on stderr and leave with exit code 3 — no torch.distributed stand-in, no line.  Returns True when world > 1 and
+    the communicator is up (tests/test_sharding_gloo.py drives this function with two CPU processes and a context whose communicator has one rank)."""
+    if world <= 1:
+        return False
+    import torch
+    import torch.distributed as dist
+    comm_ok, err = False, ""
+    try:
+        job = T.parallel.Job(ctx, rank, world)
+        comm_ok = job.ok and ctx.comm_rank()[1] == world
+    except Exception as e:  # noqa: BLE001
+        err = str(e)
+    flag = torch.tensor([1 if comm_ok else 0], device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if not bool(flag.item()):
+        sys.stderr.write(f"[bench] rank {rank}: the library's RCCL communicator is not up on every rank ({err or ('it has ' + str(ctx.comm_rank()[1]) + ' rank(s)' if not comm_ok else 'another rank failed')}); no bench line\n")
+        dist.barrier()
+        dist.destroy_process_group()
+        raise SystemExit(3)
+    return True
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -386,23 +411,7 @@ def main():
         name, _, value = kv.partition("=")
         ctx.set_option(name, int(value))
 
-    # ---- the job's communicator, inside the library (include/tracehip.h "multi-GPU"): rank 0 makes the RCCL id, torch.distributed carries it ----
-    comm_ok = False
-    if world > 1:
-        err = ""
-        try:
-            job = T.parallel.Job(ctx, rank, world)
-            comm_ok = job.ok and ctx.comm_rank()[1] == world
-        except Exception as e:
-            err = str(e)
-        flag = torch.tensor([1 if comm_ok else 0], device="cuda")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if not bool(flag.item()):
-            # no torch.distributed stand-in: an N-rank line must come from the library's own RCCL communicator with N ranks, or not at all
-            sys.stderr.write(f"[bench] rank {rank}: the library's RCCL communicator is not up on every rank ({err or 'another rank failed'}); no bench line\n")
-            dist.barrier()
-            dist.destroy_process_group()
-            raise SystemExit(3)
+    comm_ok = require_communicator(T, ctx, rank, world, "cuda")
 
     if args.workload == "caustic_sppm":
         r = run_sppm(args, T, ctx, graft, rank, world, comm_ok)

@@ -97,12 +97,19 @@ dist.destroy_process_group()
 '''
 
 
-def _run_two_ranks(tmp_path, body, out, port):
+def _run_ranks(tmp_path, body, out, port, n=2, check=True):
     script = tmp_path / "worker.py"
     script.write_text(body)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2")
-    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-                           str(script), ROOT, str(out)], env=env, timeout=600)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2" if n <= 2 else "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port), str(script), ROOT, str(out)]
+    if check:
+        subprocess.check_call(cmd, env=env, timeout=900)
+        return None
+    return subprocess.run(cmd, env=env, timeout=900, capture_output=True, text=True)
+
+
+def _run_two_ranks(tmp_path, body, out, port):
+    _run_ranks(tmp_path, body, out, port, 2)
 
 
 def test_two_rank_strong_scaling_frame(T, ob, tmp_path):
@@ -136,3 +143,87 @@ def test_two_rank_sppm_photon_sharding(T, ob, tmp_path):
     np.testing.assert_allclose(r0["phi"], ref["phi"], rtol=2e-5, atol=2e-5 * scale)
     np.testing.assert_allclose(r0["tau"], ref["tau"], rtol=5e-5, atol=5e-5 * np.abs(ref["tau"]).max())
     np.testing.assert_allclose(r0["image"], ref["image"], rtol=1e-4, atol=1e-4 * np.abs(ref["image"]).max())
+
+
+def test_c5_sample_sharding_arithmetic(T):
+    """BASELINE configs[4] (4096 x 4096, 1024 spp, 8 GPUs) is sharded by GLOBAL SAMPLE INDEX: rank r renders samples [offset_r, offset_r + spp_r) of every
+    pixel with the frame's seed, so that the union over the ranks is exactly the single-process frame's sample set — whatever the split."""
+    P = T.parallel
+    shards = [P.shard_samples(1024, r, 8) for r in range(8)]
+    assert shards == [(128, 128 * r) for r in range(8)]
+    for total, world in ((1000, 8), (1001, 8), (1023, 8), (7, 8), (1024, 3), (1, 2), (256, 1)):
+        shards = [P.shard_samples(total, r, world) for r in range(world)]
+        sizes = [n for n, _ in shards]
+        assert sum(sizes) == total and max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True), (total, world, sizes)
+        covered = []
+        for n, off in shards:
+            covered += list(range(off, off + n))
+        assert covered == list(range(total)), (total, world)  # contiguous, disjoint, in rank order
+    assert P.shard_samples(1000, 0, 8) == (125, 0) and P.shard_samples(1001, 0, 8) == (126, 0) and P.shard_samples(1001, 1, 8) == (125, 126)
+    # weak scaling (bench.py --scaling weak): every rank its own `spp` samples, offsets r * spp
+    assert [P.shard_sample_offset(r, 128) for r in range(8)] == [128 * r for r in range(8)]
+    # SPPM photons (trhip_render_sppm with a communicator): contiguous slices of every iteration's photon indices
+    for photons, world in ((1023 * 1023, 8), (9000, 2), (5, 8)):
+        sl = [P.photon_slice(photons, r, world) for r in range(world)]
+        assert sl[0][0] == 0 and sl[-1][1] == photons and all(sl[r][1] == sl[r + 1][0] for r in range(world - 1)) and all(b >= a for a, b in sl)
+
+
+EIGHT_WORKER = STRONG_WORKER.replace("total_spp = 7  # ONE frame of 7 samples per pixel split over the ranks (bench.py --scaling strong): 4 + 3", "total_spp = 11") \
+    .replace("assert (spp, off) == ((4, 0) if rank == 0 else (3, 4))", "assert world == 8 and spp == (2 if rank < 3 else 1)") \
+    .replace("T.scenes.shadows_camera(24)", "T.scenes.shadows_camera(16)")
+
+
+def test_eight_rank_strong_scaling_frame(T, ob, tmp_path):
+    """C5's decomposition at its rank count: ONE frame's 11 samples per pixel over 8 processes (2, 2, 2, 1, 1, 1, 1, 1), films sum-reduced onto rank 0: the
+    single-process frame of all 11 samples up to Float32 summation order."""
+    out = tmp_path / "film8.npy"
+    _run_ranks(tmp_path, EIGHT_WORKER, out, 29577, n=8)
+    reduced = np.load(out)
+    scene, cam = T.scenes.shadows_scene(), T.scenes.shadows_camera(16)
+    full, _, _ = ob.OracleScene.from_scene(scene).render(cam, "path", 11, 4, seed=11)
+    assert full[..., :3].max() > 0
+    np.testing.assert_allclose(reduced, full, rtol=5e-5, atol=2e-6)
+
+
+BENCH_GUARD_WORKER = r'''
+import os, sys
+import torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+import __graft_entry__ as graft
+import bench
+T = graft.load_package()
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group(backend="gloo")
+
+
+class OneRankContext:
+    """What bench.py sees when the library's communicator did not come up with the job's size: trhip_comm_init was called, trhip_comm_rank says (0, 1)."""
+    def __init__(self):
+        self.inits = []
+
+    def comm_init(self, uid, rank, world):
+        assert len(uid) == T._ffi.UNIQUE_ID_BYTES
+        self.inits.append((rank, world))
+
+    def comm_rank(self):
+        return (0, 1)
+
+
+ctx = OneRankContext()
+orig = T._ffi.comm_unique_id
+T._ffi.comm_unique_id = lambda: bytes(range(128))  # (the real one needs librccl and a GPU; the id's content is irrelevant here)
+try:
+    bench.require_communicator(T, ctx, rank, world, "cpu")
+finally:
+    T._ffi.comm_unique_id = orig
+print("UNREACHABLE: a bench line would follow")
+'''
+
+
+def test_bench_refuses_a_line_without_an_n_rank_library_communicator(T, tmp_path):
+    """bench.py --gpus N prints its line only when trhip_comm_rank reports N ranks on every rank; otherwise every rank leaves with exit code 3 (the driver then
+    records no SCALE entry instead of a number that came from a torch.distributed stand-in)."""
+    r = _run_ranks(tmp_path, BENCH_GUARD_WORKER, tmp_path / "unused", 29579, n=2, check=False)
+    assert r.returncode != 0, r.stdout + r.stderr
+    assert "UNREACHABLE" not in r.stdout and "no bench line" in r.stderr, r.stdout + r.stderr
+    assert "exitcode  : 3" in r.stderr or "exitcode: 3" in r.stderr or "exit code 3" in r.stderr.lower() or "(exitcode: 3)" in r.stderr, r.stderr[-2000:]

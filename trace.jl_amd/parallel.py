@@ -34,8 +34,8 @@ def photon_slice(photons_per_iteration: int, rank: int, world: int):
 
 
 def reduce_film(film, dst: int = 0):
-    """Sum-reduce (H, W, 4) film accumulators held in torch tensors over torch.distributed (gloo in the CPU tests; the fallback of
-    bench.py when the library's own communicator cannot be created)."""
+    """Sum-reduce (H, W, 4) film accumulators held in torch tensors over torch.distributed: what the CPU tests (gloo, tests/test_sharding_gloo.py) use to check
+    the sharding arithmetic with the oracle.  bench.py does NOT use it: an N-GPU line comes from the library's RCCL communicator (trhip_film_reduce) or not at all."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.reduce(film, dst=dst, op=dist.ReduceOp.SUM)
