@@ -174,7 +174,8 @@ typedef struct {
                                  the reference-order walk — [0] zero / non-finite direction, [1] a sphere (origin inside, limb, clipped), [2] a candidate within the gap of
                                  the ray's own t_max, [3] a second candidate within the gap of the nearest.  Hybrid mode (traversal 9) with "count_visits": why rays went to the
                                  canonical tree — [0] a zero / non-finite direction component or a near-axis-parallel direction, [1] a sphere (clipped; inside two at once),
-                                 [2] a candidate within 2 dt of the incumbent or before its own leaf box's entry.  Otherwise zeros */
+                                 [2] a candidate within 2 dt of the incumbent or before its own leaf box's entry; and, NOT a fallback, [3] rays that start inside a sphere and were
+                                 certified on the accelerator (sphere.jl:137-138 handled through the order word).  Otherwise zeros */
     /* ---- since ABI 3001: hybrid mode (traversal 9).  Of ms_trace_closest / nodes_visited / prims_tested, the part of the FALLBACK walks (k_trace3 over the rays the
        certified walk handed back, on the canonical tree); the certified walk on the accelerator tree (k_trace3c) is the difference ---- */
     double ms_fallback;

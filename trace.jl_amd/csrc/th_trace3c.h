@@ -269,7 +269,7 @@ __global__ __launch_bounds__(kBlock, BIG ? TH_TRACE3C_WAVES - 1 : TH_TRACE3C_WAV
     // s_st[tid]: 0: nothing accepted yet, 1: a candidate is; bits 8..: 1 + the sphere the ray started INSIDE of (header: what the reference tests before that sphere does not count)
     uint32_t nn = 0, np = 0;
     uint32_t n_fb = 0;    // wave-uniform
-    unsigned long long n_why[4] = {0ull, 0ull, 0ull, 0ull};  // COUNT: why rays went to the canonical tree — 0 direction / finiteness / cap, 1 a sphere (clipped, inside two), 2 near tie / guard
+    unsigned long long n_why[4] = {0ull, 0ull, 0ull, 0ull};  // COUNT: why rays went to the canonical tree — 0 direction / finiteness / cap, 1 a sphere (clipped, inside two), 2 near tie / guard; [3]: rays that start INSIDE a sphere and were certified (the order word)
     uint32_t why = 0;
 
 #ifdef TH_DIAG_PHASES
@@ -355,6 +355,7 @@ __global__ __launch_bounds__(kBlock, BIG ? TH_TRACE3C_WAVES - 1 : TH_TRACE3C_WAV
                                             if (!(t_c <= p_lim - 4.0f * pdt) || !(ex <= (r == 3 ? 0.0f : t_c + pdt))) {
                                                 pflag = true;
                                             } else {
+                                                if (COUNT && r == 3) n_why[3]++;  // (not a fallback: rays that start inside a sphere and stay on the accelerator)
                                                 p_lim = t_c + 2.0f * pdt;
                                                 pst = 1u | (r == 3 ? (ks + 1u) << 8 : 0u);
                                                 prec = make_float4(t_c, __uint_as_float(sr.slot), 0.0f, 0.0f);
