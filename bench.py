@@ -519,6 +519,8 @@ def main():
             dom_ms = agg["ms"][dominant] / max(1, agg["launches"][dominant])
             dom_bytes = per_step[dominant] * steps / max(1, agg["launches"][dominant])
             kname = {"trace_closest": TRAVERSAL_KERNEL.get(int(sv.traversal), "k_trace"), "shade": "k_shade_path", "film": "k_film_gather", "raygen": "k_raygen"}[dominant]
+            if hybrid and dominant == "trace_closest" and flat.bvh_mode()[1] == 1:
+                kname = "k_trace_leaf_c"  # a one-leaf accelerator (S-cornell, the shadows scene): the certified walk is the uniform loop over the canonical slots
             if hybrid and dominant == "trace_closest":
                 # a hybrid closest-hit launch = the certified walk on the accelerator tree (k_trace3c, the dominant kernel) + the reference-order walk of the rays it hands back
                 # (k_trace3 on the canonical tree); the library times the hand-over inside every launch (trhip_stats.ms_fallback): the roofline is k_trace3c's alone

@@ -1,6 +1,5 @@
 #!/bin/bash
-O=gpurun_out/r4z; mkdir -p $O
-timeout 600 python tools/tie_exposure.py --workload mesh_1m --res 1024 --spp 16 --depth 8 --time-spp 256 > $O/tie_mesh1m.json 2>$O/tie.err < /dev/null; cut -c1-2500 $O/tie_mesh1m.json
-timeout 600 python tools/tie_exposure.py --workload cornell --res 1024 --spp 16 --depth 8 --time-spp 256 > $O/tie_cornell.json 2>>$O/tie.err < /dev/null; cut -c1-1800 $O/tie_cornell.json
-timeout 600 python tools/tie_exposure.py --workload caustic --sppm --iterations 20 > $O/tie_caustic.json 2>>$O/tie.err < /dev/null; cut -c1-1500 $O/tie_caustic.json
-tail -3 $O/tie.err
+O=gpurun_out; mkdir -p $O
+timeout 1500 python -m pytest tests -q -m gpu > $O/r4a_pytest_gpu_full_suite.txt 2>&1 < /dev/null; tail -3 $O/r4a_pytest_gpu_full_suite.txt
+timeout 1500 python tools/soak_hybrid.py --scenes 60 --rays 400000 --frames 48 --seed 3 > $O/r4a_soak_hybrid.txt 2>$O/r4a_soak_hybrid.err < /dev/null; tail -1 $O/r4a_soak_hybrid.txt
+bash tools/final_runs.sh r4a < /dev/null

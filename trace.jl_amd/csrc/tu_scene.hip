@@ -3,6 +3,44 @@
 #include "th_host.h"
 #include "th_bvh_ref.h"
 
+// Where the children-in-parent node of interior node i of a depth-first FlatBVH lives (th_trace2.h wnodes): widx[i]; returns the number of 64-byte slots (>= the number of
+// interior nodes: layout 1 pads).  layout 0: interior nodes in depth-first order (a first child directly behind its parent).  layout 1 (option "node_layout"): the two
+// interior children of a node SIDE BY SIDE in one aligned 128-byte line — a node that misses L2 arrives as a 128-byte line either way (round 3's request-size counters on the
+// 10 M-triangle scene: 9.7e8 requests of 128 B, none of 32 / 64): with the siblings in it, the far child the walk comes back for is already on the chip.  Subtrees stay
+// contiguous (pairs are allocated when their parent is visited, depth first), the root stays slot 0.  Slots left empty by the alignment are zero-filled and never referenced.
+static uint32_t wide_node_order(const FlatBVH& t, int layout, std::vector<uint32_t>& widx) {
+    const uint32_t n = (uint32_t)t.a.size();
+    widx.assign(n, 0u);
+    auto interior = [&](uint32_t i) { return (t.flags[i] & 3u) != 3u; };
+    uint32_t next = 0;
+    if (layout != 1) {
+        for (uint32_t i = 0; i < n; ++i)
+            if (interior(i)) widx[i] = next++;
+        return next;
+    }
+    if (n == 0 || !interior(0)) return 0;
+    widx[0] = next++;
+    std::vector<uint32_t> stack{0u};
+    while (!stack.empty()) {
+        const uint32_t i = stack.back();
+        stack.pop_back();
+        const uint32_t c0 = i + 1, c1 = t.a[i];
+        const bool i0 = c0 < n && interior(c0), i1 = c1 < n && interior(c1);
+        if (i0 && i1) {
+            next = (next + 1u) & ~1u;  // the pair starts a 128-byte line
+            widx[c0] = next++;
+            widx[c1] = next++;
+        } else if (i0) {
+            widx[c0] = next++;
+        } else if (i1) {
+            widx[c1] = next++;
+        }
+        if (i1) stack.push_back(c1);  // the first child's subtree is laid out first
+        if (i0) stack.push_back(c0);
+    }
+    return next;
+}
+
 #include <atomic>
 #include <chrono>
 #include <cstdlib>
@@ -300,12 +338,11 @@ int upload_scene(trhip_scene* s) {
     std::memset(&s->wide, 0, sizeof s->wide);
     s->wide.root_ref = kRefNone;
     if (n_nodes > 0 && n_prims < (1u << 24) && !s->literal_only) {
-        std::vector<uint32_t> widx(n_nodes, 0);
-        uint32_t n_int = 0;
-        for (uint32_t i = 0; i < n_nodes; ++i)
-            if ((s->bvh.flags[i] & 3u) != 3u) widx[i] = n_int++;
+        std::vector<uint32_t> widx;
+        const uint32_t n_int = wide_node_order(s->bvh, ctx->node_layout, widx);
         bool ok = n_int < (1u << 24);
-        RawArray<float4> wn((size_t)n_int * 4);  // every interior node writes its four records below
+        RawArray<float4> wn((size_t)n_int * 4);  // every interior node writes its four records below (layout 1: the alignment gaps are zeroed first)
+        if (ctx->node_layout == 1 && ok) std::memset((void*)wn.data(), 0, (size_t)n_int * 4 * sizeof(float4));
         has_empty_leaf = false;
         // subtrees that hold a sphere keep the reference's loose slab test (th_trace2.h, slab_test2): the fp32 sphere quadratic
         // (sphere.jl:120-150) accepts rays that pass the sphere at a distance far beyond the tight test's margin
@@ -891,10 +928,8 @@ int upload_accelerator(trhip_scene* s) {
         if (std::getenv("TRHIP_COMMIT_TIMING")) std::fprintf(stderr, "[commit] certificate: mle %g %g %g, sq_flat %g\n", mle[0], mle[1], mle[2], sq);
     }
     // children-in-parent nodes (as upload_scene's, th_trace2.h)
-    std::vector<uint32_t> widx(n_anodes, 0);
-    uint32_t n_int = 0;
-    for (uint32_t i = 0; i < n_anodes; ++i)
-        if ((s->acc.flags[i] & 3u) != 3u) widx[i] = n_int++;
+    std::vector<uint32_t> widx;
+    const uint32_t n_int = wide_node_order(s->acc, ctx->node_layout, widx);
     if (n_int >= (1u << 24)) return 0;
     std::vector<uint8_t> has_sphere(n_anodes, 0);
     for (uint32_t i = n_anodes; i-- > 0;) {  // bottom-up (second children and first children both come later in the depth-first layout)
@@ -907,6 +942,7 @@ int upload_accelerator(trhip_scene* s) {
         }
     }
     RawArray<float4> wn((size_t)n_int * 4);
+    if (ctx->node_layout == 1) std::memset((void*)wn.data(), 0, (size_t)n_int * 4 * sizeof(float4));
     parallel_for(n_anodes, [&](size_t i0, size_t i1) {
         for (size_t i = i0; i < i1; ++i) {
             if ((s->acc.flags[i] & 3u) == 3u) continue;
