@@ -49,6 +49,8 @@ def cases(T):
     yield "shadows", T.scenes.shadows_scene(), T.scenes.shadows_camera(48), ([-1.2, -0.3, -3.2], [1.3, 1.2, 1.0])
     yield "cornell", T.scenes.cornell_scene(), T.scenes.cornell_camera(40), ([0, 0, -3], [1, 1, -2])
     yield "mesh64", T.scenes.mesh_scene(64), T.scenes.cornell_camera(48), ([0, 0, -3], [1, 1, -2])
+    # a closed object whose SAH leaves straddle the reference's leaves: the accelerator is regrouped by canonical leaf at commit (tu_scene.hip conform_accelerator)
+    yield "blob24", T.scenes.blob_scene(24), T.scenes.cornell_camera(48), ([0, 0, -3], [1, 1, -2])
     ply = os.path.join(GOLDEN, "caustic-glass.ply")
     if os.path.exists(ply):
         yield "caustic-glass.ply", T.scenes.caustic_scene(ply), T.scenes.caustic_camera(32), None

@@ -1,16 +1,7 @@
 #!/bin/bash
 O=gpurun_out/r4z; mkdir -p $O
-for nl in 0 1; do
-for b in 0 -1; do
-timeout 600 python bench.py --workload mesh_10m --steps 3 --warmup 1 --no-cpu-baseline --no-micro --no-modes --opt node_layout=$nl --opt bvh_builder=$b > $O/nl${nl}_b${b}.json 2>$O/nl.err < /dev/null
-python - $O/nl${nl}_b${b}.json $nl $b <<'PY'
-import json,sys
-for line in open(sys.argv[1]):
-    if line.startswith("{"):
-        d=json.loads(line); r=d["roofline"]
-        print("node_layout",sys.argv[2],"bvh_builder",sys.argv[3],"ms",d["ms_per_step"],"closest",d["roofline"]["kernel_ms_per_step"]["trace_closest"],"traffic",r.get("traffic"),"frac_counters",r.get("frac_counters"))
-PY
+timeout 600 python -m pytest tests/test_gpu_hybrid.py tests/test_gpu_edge_cases.py -x -q -m gpu 2>&1 | tail -3
+for v in libtracehip lib_a; do
+TRHIP_LIB=$PWD/trace.jl_amd/$v.so timeout 300 python tools/hybrid_probe.py --workload cornell --spp 64 --check-spp 2 --skip-library > $O/probe_c_$v.json 2>/dev/null < /dev/null; echo $v $(grep -E "closest_ms|fallback_fraction|differing" $O/probe_c_$v.json)
 done
-done
-timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-micro --no-modes --no-traffic --opt node_layout=1 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('mesh_1m node_layout 1', d['ms_per_step'], d['roofline']['kernel_ms_per_step'])"
-timeout 300 python -m pytest tests/test_gpu_hybrid.py -x -q -m gpu 2>&1 | tail -2
+timeout 600 python tools/hybrid_probe.py --workload blob_870k --spp 64 --check-spp 2 > $O/probe_blob.json 2>$O/probe_blob.err < /dev/null; grep -E "bvh_mode|frame_ms|closest_ms|fallback_fraction|differing|accelerator_nodes" $O/probe_blob.json

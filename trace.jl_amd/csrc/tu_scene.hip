@@ -696,7 +696,91 @@ int upload_scene(trhip_scene* s) {
 // record's .w lane, its children-in-parent nodes, the per-sphere / per-slot canonical leaf boxes the certificate reads — and verifies what the certificate
 // assumes: every accelerator leaf has, bit for bit, the box of the canonical leaf of each of its primitives.  Anything that does not fit leaves
 // hybrid_ok = false: every ray then walks the canonical tree (same answers).
-int upload_accelerator(trhip_scene* s) {
+static bool conform_accelerator(const FlatBVH& acc, const std::vector<uint32_t>& cslot, const std::vector<uint32_t>& leaf_of_slot, const std::vector<float>& slot_box, uint32_t n_prims,
+                                FlatBVH& out) {
+    const uint32_t n = (uint32_t)acc.a.size();
+    out.bounds.reserve((size_t)n * 6 + 64);
+    out.a.reserve(n + 16);
+    out.flags.reserve(n + 16);
+    out.order.reserve(n_prims);
+    out.max_depth = 0;
+    bool ok = true;
+    auto new_node = [&]() {
+        out.bounds.insert(out.bounds.end(), 6, 0.0f);
+        out.a.push_back(0u);
+        out.flags.push_back(0u);
+        return (uint32_t)out.a.size() - 1u;
+    };
+    auto unite = [&](uint32_t dst, uint32_t l, uint32_t r) {
+        for (int k = 0; k < 3; ++k) {
+            out.bounds[6 * (size_t)dst + k] = std::fmin(out.bounds[6 * (size_t)l + k], out.bounds[6 * (size_t)r + k]);
+            out.bounds[6 * (size_t)dst + 3 + k] = std::fmax(out.bounds[6 * (size_t)l + 3 + k], out.bounds[6 * (size_t)r + 3 + k]);
+        }
+    };
+    std::vector<std::pair<uint32_t, uint32_t>> items;  // (canonical leaf, caller primitive) of one accelerator leaf
+    // groups [g0, g1) of `items` (runs of one canonical leaf, bounded by `cuts`): one leaf each, a balanced subtree above them
+    std::vector<uint32_t> cuts;
+    std::function<uint32_t(uint32_t, uint32_t, uint32_t)> emit_groups = [&](uint32_t g0, uint32_t g1, uint32_t depth) -> uint32_t {
+        out.max_depth = std::max(out.max_depth, depth);
+        const uint32_t idx = new_node();
+        if (g1 - g0 == 1) {
+            const uint32_t b = cuts[g0], e = cuts[g0 + 1];
+            if (e - b > 255u) ok = false;
+            out.a[idx] = (uint32_t)out.order.size();
+            out.flags[idx] = ((e - b) << 2) | 3u;
+            for (uint32_t k = b; k < e; ++k) out.order.push_back(items[k].second);
+            std::memcpy(&out.bounds[6 * (size_t)idx], &slot_box[6 * (size_t)cslot[items[b].second]], 6 * sizeof(float));
+            return idx;
+        }
+        const uint32_t mid = g0 + (g1 - g0) / 2;
+        const uint32_t l = emit_groups(g0, mid, depth + 1);
+        const uint32_t r = emit_groups(mid, g1, depth + 1);
+        out.a[idx] = r;
+        out.flags[idx] = 0u;  // (any axis: the accelerator's visiting order does not matter)
+        unite(idx, l, r);
+        return idx;
+    };
+    std::function<uint32_t(uint32_t, uint32_t)> emit = [&](uint32_t i, uint32_t depth) -> uint32_t {
+        if (!ok || depth > 200u) {
+            ok = false;
+            return 0u;
+        }
+        if ((acc.flags[i] & 3u) == 3u) {
+            const uint32_t first = acc.a[i], cnt = acc.flags[i] >> 2;
+            if (cnt == 0 || (uint64_t)first + cnt > n_prims) {
+                ok = false;
+                return 0u;
+            }
+            items.clear();
+            for (uint32_t k = first; k < first + cnt; ++k) items.emplace_back(leaf_of_slot[cslot[acc.order[k]]], acc.order[k]);
+            std::stable_sort(items.begin(), items.end(), [](const std::pair<uint32_t, uint32_t>& x, const std::pair<uint32_t, uint32_t>& y) { return x.first < y.first; });
+            cuts.clear();
+            for (uint32_t k = 0; k < cnt; ++k)
+                if (k == 0 || items[k].first != items[k - 1].first) cuts.push_back(k);
+            const uint32_t n_groups = (uint32_t)cuts.size();
+            cuts.push_back(cnt);
+            return emit_groups(0, n_groups, depth);
+        }
+        const uint32_t idx = new_node();
+        if (acc.a[i] <= i + 1 || acc.a[i] >= n) {
+            ok = false;
+            return idx;
+        }
+        const uint32_t l = emit(i + 1, depth + 1);
+        const uint32_t r = emit(acc.a[i], depth + 1);
+        out.a[idx] = r;
+        out.flags[idx] = acc.flags[i] & 3u;
+        if (ok) unite(idx, l, r);
+        return idx;
+    };
+    emit(0, 1);
+    return ok && out.order.size() == n_prims && (out.flags[0] & 3u) != 3u;
+}
+
+static int upload_accelerator_impl(trhip_scene* s, bool conformed);
+int upload_accelerator(trhip_scene* s) { return upload_accelerator_impl(s, false); }
+static int upload_accelerator_conformed(trhip_scene* s) { return upload_accelerator_impl(s, true); }
+static int upload_accelerator_impl(trhip_scene* s, bool conformed) {
     trhip_ctx* ctx = s->ctx;
     CommitClock clk;
     s->hybrid_ok = false;
@@ -711,6 +795,7 @@ int upload_accelerator(trhip_scene* s) {
     std::vector<uint32_t> cslot(s->prims.size(), 0xffffffffu);
     for (uint32_t k = 0; k < n_prims; ++k) cslot[s->bvh.order[k]] = k;
     std::vector<float> slot_box((size_t)n_prims * 6, 0.0f);
+    std::vector<uint32_t> leaf_of_slot(n_prims, 0u);  // the canonical leaf (node index) that holds each canonical slot
     std::vector<uint8_t> covered(n_prims, 0);
     parallel_for(n_cnodes, [&](size_t i0, size_t i1) {
         for (size_t i = i0; i < i1; ++i) {
@@ -718,6 +803,7 @@ int upload_accelerator(trhip_scene* s) {
             const uint32_t first = s->bvh.a[i], cnt = s->bvh.flags[i] >> 2;
             for (uint32_t k = first; k < first + cnt && k < n_prims; ++k) {
                 std::memcpy(&slot_box[6 * (size_t)k], &s->bvh.bounds[6 * i], 6 * sizeof(float));
+                leaf_of_slot[k] = (uint32_t)i;
                 covered[k] = 1;
             }
         }
@@ -823,7 +909,18 @@ int upload_accelerator(trhip_scene* s) {
                 if (std::memcmp(&s->acc.bounds[6 * i], &slot_box[6 * (size_t)cslot[s->acc.order[k]]], 6 * sizeof(float)) != 0) bad = true;
         }
     });
-    if (bad || (s->acc.flags[0] & 3u) == 3u) return 0;
+    if ((s->acc.flags[0] & 3u) == 3u) return 0;
+    if (bad && conformed) return 0;  // (cannot happen: the conformed tree has the canonical leaf boxes by construction)
+    if (bad) {
+        // The library's builder draws its leaves where ITS cost function says (primitives with coincident centroids share one; a node that is not worth splitting stays
+        // whole), the reference's where its own does.  The certificate needs every accelerator leaf to be (part of) ONE canonical leaf, under that leaf's box: the
+        // accelerator is ours to change — its leaves are regrouped by canonical leaf (a leaf that straddles several becomes a small subtree), every leaf takes its canonical
+        // leaf's box, the interior boxes are re-derived bottom-up (so they still nest).  A looser leaf box costs the accelerator a few visits, never an answer.
+        FlatBVH out;
+        if (!conform_accelerator(s->acc, cslot, leaf_of_slot, slot_box, n_prims, out)) return 0;
+        s->acc = std::move(out);
+        return upload_accelerator_conformed(s);
+    }
     if (std::memcmp(&s->acc.bounds[0], &s->bvh.bounds[0], 6 * sizeof(float)) != 0) return 0;
     clk.tick("accelerator: leaf boxes");
     // ---- per canonical slot, per sphere: where the reference's walk meets the primitive relative to the sphere (th_trace3c.h: a ray that starts inside a sphere only counts what
