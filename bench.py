@@ -499,6 +499,7 @@ def main():
         roofline = None
         sv = integ.stats
         bvh_mode, n_acc_nodes, _ = flat.bvh_mode()
+        bvh_note = flat.bvh_note()
         _bvh = flat.bvh()
         n_canonical_nodes = int(_bvh[1].size)
         n_scene_bytes = 32 * (n_acc_nodes if bvh_mode == 2 else n_canonical_nodes) + 48 * int(_bvh[3].size)  # what the dominant walk reads: its tree's boxes + the primitive records
@@ -663,7 +664,7 @@ def main():
                                    + f", max depth {args.depth}, PathIntegrator, seed {args.seed:#x}",
                        "rays_per_step": int(total_rays / args.steps), "samples_per_step": int(total_samples / args.steps), "bvh_build_upload_s": round(t_build, 3),
                        "traversal": int(sv.traversal),
-                       "bvh": BVH_MODE.get(bvh_mode, str(bvh_mode)), "bvh_nodes": {"canonical": n_canonical_nodes, "accelerator": n_acc_nodes},
+                       "bvh": BVH_MODE.get(bvh_mode, str(bvh_mode)), "bvh_note": bvh_note or None, "bvh_nodes": {"canonical": n_canonical_nodes, "accelerator": n_acc_nodes},
                        "fallback_fraction": round(agg["fallback"] / max(1, agg["closest"]), 5),
                        "parallelism": f"sample-index sharding x{world} + film sum-reduce over RCCL (trhip_film_reduce)" if world > 1 else "single GPU",
                        "rccl_ranks": rccl_ranks, "film_reduce_ms_per_step": round(agg["film_reduce_ms_per_step"], 3) if world > 1 else 0.0},

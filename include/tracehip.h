@@ -132,6 +132,9 @@ int trhip_scene_set_bvh(trhip_scene* scene, const float* node_bounds, const uint
  * trhip_scene_get_accelerator: the accelerator in the layout of trhip_scene_get_bvh (prim_order[accelerator slot] = caller primitive index); size it with
  *   trhip_scene_bvh_mode.  Any output pointer may be NULL. */
 int trhip_scene_bvh_mode(const trhip_scene* scene, int* mode, uint32_t* accel_nodes, uint32_t* accel_depth);
+/* Why a scene committed with default options holds ONE tree (mode 0 or 1) instead of two: a NUL-terminated sentence copied into buf (at most n bytes; "" for mode 2 and for
+ * explicit builders).  E.g. "the reference's construction: BVH depth 71 exceeds the 64-entry traversal stack (bvh.jl:222 throws a BoundsError there)" -> the library's tree alone. */
+int trhip_scene_bvh_note(const trhip_scene* scene, char* buf, size_t n);
 int trhip_scene_get_accelerator(const trhip_scene* scene, float* node_bounds, uint32_t* node_a, uint32_t* node_flags, uint32_t* prim_order);
 
 /* ---- sensor: PerspectiveCamera + Film + filter (camera/perspective.jl:58-80, film.jl:34-61, filter.jl) ------------- */

@@ -24,7 +24,7 @@ HEADER = os.path.join(ROOT, "include", "tracehip.h")
 JL = {"Cint": "i32", "Int32": "i32", "UInt32": "u32", "UInt64": "u64", "Int64": "i64", "Float32": "f32", "Cfloat": "f32", "Cvoid": "void", "Cstring": "cstr", "Csize_t": "u64"}
 JL_PTR = {"Ptr{Cvoid}": "ptr:void", "Ptr{Ptr{Cvoid}}": "ptr:ptr", "Ptr{Float32}": "ptr:f32", "Ptr{UInt32}": "ptr:u32", "Ptr{UInt8}": "ptr:u8", "Ptr{TrhipSensor}": "ptr:sensor",
           "Ptr{TrhipStats}": "ptr:stats"}
-CT = {"int": "i32", "uint32_t": "u32", "uint64_t": "u64", "int64_t": "i64", "float": "f32", "double": "f64", "void": "void"}
+CT = {"int": "i32", "uint32_t": "u32", "uint64_t": "u64", "int64_t": "i64", "float": "f32", "double": "f64", "void": "void", "size_t": "u64"}
 
 
 def _split_top(s: str):

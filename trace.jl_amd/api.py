@@ -617,6 +617,12 @@ class FlatScene:
         self.ctx.check(L.trhip_scene_get_bvh(self._h, _ffi.fptr(bounds), _ffi.u32ptr(a), _ffi.u32ptr(flags), _ffi.u32ptr(order)))
         return bounds, a, flags, order
 
+    def bvh_note(self) -> str:
+        """Why a default commit holds one tree instead of two (trhip_scene_bvh_note); "" when it holds both."""
+        buf = C.create_string_buffer(512)
+        self.ctx.check(_ffi.lib().trhip_scene_bvh_note(self._h, buf, 512))
+        return buf.value.decode()
+
     def bvh_mode(self):
         """(mode, accelerator nodes, accelerator depth): mode 0 = the library's tree alone, 1 = the canonical (reference / host) tree alone, 2 = hybrid: the canonical
         tree defines the answers, the library's tree accelerates the rays that carry the order-independence certificate (csrc/th_trace3c.h)."""

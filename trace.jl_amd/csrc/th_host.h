@@ -166,6 +166,7 @@ struct trhip_scene {
     // and the answers are its; `acc` is the library's tree over the same primitives, which most rays walk instead
     FlatBVH acc;                   // order[k] = caller primitive of accelerator slot k; empty without an accelerator
     bool hybrid_ok = false;        // the accelerator exists and its leaves carry the canonical leaves' boxes bit for bit
+    std::string bvh_note;          // why a default commit ended with one tree (trhip_scene_bvh_note)
     int bvh_mode = 0;              // what trhip_scene_commit / trhip_scene_set_bvh built: 0 the library's tree alone, 1 the canonical (reference / host) tree alone, 2 both
     DevBuf d_acc_wnodes, d_acc_prims, d_slot_boxes, d_sphere_boxes, d_sphere_slots, d_sphere_cert, d_acc_leaf_order;
     WideScene wide_acc{};

@@ -1326,6 +1326,7 @@ static void drop_accelerator(trhip_scene* s) {
 }
 
 int trhip_scene_commit(trhip_scene* s, int max_node_primitives) {
+    if (s) s->bvh_note.clear();
     CommitClock clk;
     if (!s) return fail(nullptr, TRHIP_ERR_INVALID, "null scene");
     HIP_TRY(s->ctx, hipSetDevice(s->ctx->device));
@@ -1370,12 +1371,16 @@ int trhip_scene_commit(trhip_scene* s, int max_node_primitives) {
             if (int rc = build_library_tree(s->ctx, pb, max_node_primitives, mode, false, s->acc)) return rc;
             clk.tick("commit: accelerator tree");
             if (int rc = upload_accelerator(s)) return rc;
-            if (s->hybrid_ok)
+            if (s->hybrid_ok) {
                 s->bvh_mode = 2;
-            else
+            } else {
                 drop_accelerator(s);
+                s->bvh_note = s->spheres.size() > kCertMaxSpheres ? "more than 8 spheres: every ray walks the canonical tree (th_trace3c.h kCertMaxSpheres)"
+                                                                  : "no accelerator: the library's tree could not be conformed to the canonical leaves, or the canonical tree is a single leaf";
+            }
             return 0;
         }
+        s->bvh_note = "the reference's construction fails on this scene (" + why + "): there is no Trace.jl answer to reproduce, the library's tree alone";
         // Where the reference's own constructor fails (its recursion does not end, or its tree outgrows its 64-entry stack) there is no Trace.jl answer to reproduce:
         // an explicit request is an error, the default falls back to the library's tree alone
         if (mode == 2 || mode == 4) return fail(s->ctx, TRHIP_ERR_UNSUPPORTED, "bvh_builder %d: %s", mode, why.c_str());
@@ -1483,6 +1488,11 @@ int trhip_scene_get_bvh(const trhip_scene* s, float* bounds, uint32_t* a, uint32
     if (a) std::memcpy(a, s->bvh.a.data(), s->bvh.a.size() * sizeof(uint32_t));
     if (flags) std::memcpy(flags, s->bvh.flags.data(), s->bvh.flags.size() * sizeof(uint32_t));
     if (order) std::memcpy(order, s->bvh.order.data(), s->bvh.order.size() * sizeof(uint32_t));
+    return 0;
+}
+int trhip_scene_bvh_note(const trhip_scene* s, char* buf, size_t n) {
+    if (!s || !buf || n == 0) return TRHIP_ERR_INVALID;
+    std::snprintf(buf, n, "%s", s->bvh_note.c_str());
     return 0;
 }
 int trhip_scene_bvh_mode(const trhip_scene* s, int* mode, uint32_t* accel_nodes, uint32_t* accel_depth) {
