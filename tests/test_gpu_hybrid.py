@@ -197,6 +197,7 @@ def test_explicit_builders_keep_their_single_tree(T, ob, hyb_ctx):
         ctx.set_option("bvh_builder", builder)
         flat = scene.flatten(ctx)
         assert flat.bvh_mode()[0] == mode, f"bvh_builder {builder}: mode {flat.bvh_mode()[0]}"
+        assert flat.bvh_note() == ""
         scene._flat = None
         flat.free()
     ctx.set_option("bvh_builder", -1)
@@ -230,7 +231,7 @@ def test_more_than_eight_spheres_keep_the_canonical_tree_alone(T, ob, hyb_ctx):
         prims.append(T.GeometricPrimitive(T.Sphere(T.ShapeCore(T.translate(c), False), 0.09, 360.0), glass if k % 2 else white))
     scene = T.Scene(T.scenes.cornell_lights(), T.BVHAccel(prims, 1))
     flat = scene.flatten(hyb_ctx)
-    assert flat.bvh_mode()[0] == 1
+    assert flat.bvh_mode()[0] == 1 and "spheres" in flat.bvh_note()  # (trhip_scene_bvh_note says why there is one tree)
     osc = ob.OracleScene.from_scene(scene)
     assert np.array_equal(flat.bvh()[1], osc.get_bvh()[1])
     cam = T.scenes.cornell_camera(24)

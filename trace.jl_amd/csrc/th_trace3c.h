@@ -91,7 +91,10 @@ constexpr float kCertFlat = 3.814697265625e-6f;   // 2^-18 (64 ulps): … plus w
                                                   // axis-aligned plane: its thin direction in the sheared frame IS a coordinate axis, the products are long x thin) at most 36 ulps of L^3 / 2A
                                                   // whatever the viewing angle; for the others the kz-extent bound is used instead (mle_small)
 constexpr uint32_t kCertMaxSpheres = 8;          // (the order word of a primitive record holds 3 bits per sphere)
-constexpr float kCertCap = 4.0f;                  // a ray whose growth margin in t units exceeds this x (the kz extent margin) goes to the reference-order walk at once (near-axis-parallel
+#ifndef TH_CERT_CAP
+#define TH_CERT_CAP 64.0f
+#endif
+constexpr float kCertCap = TH_CERT_CAP;                  // a ray whose growth margin in t units exceeds this x (the kz extent margin) goes to the reference-order walk at once (near-axis-parallel
                                                   // rays: |1 / d| ~ 1e3 and more): the accelerator walk would overshoot every hit by that much
 
 struct CertScene {               // what the certificate needs beside the accelerator's WideScene
