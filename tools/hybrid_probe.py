@@ -31,10 +31,13 @@ def main():
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED0001)
     ap.add_argument("--count", action="store_true", help="also report boxes / primitives per closest-hit ray (an instrumented pass)")
     ap.add_argument("--skip-library", action="store_true")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="library option set once at the start (e.g. leaf_queue=1)")
     args = ap.parse_args()
     graft.build()
     T = graft.load_package()
     ctx = T.default_context()
+    for kv in args.opt:
+        ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     scene, cam, desc = bench.build_workload(T, args.workload, args.res)
     out = {"workload": f"{args.workload}: {desc}; {args.res}x{args.res}, depth {args.depth}", "modes": {}}
     films = {}

@@ -43,8 +43,11 @@ def main():
     ap.add_argument("--rays", type=int, default=400000)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--frames", type=int, default=0, help="also render each scene at this resolution (4 spp, depth 6) in the three modes and compare films and per-sample radiance")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="library option set once at the start (e.g. leaf_queue=1)")
     a = ap.parse_args()
     ctx = T.default_context()
+    for kv in a.opt:
+        ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     bad_total = rays_total = fb_total = closest_total = 0
     hybrid_scenes = 0
     for k in range(a.scenes):

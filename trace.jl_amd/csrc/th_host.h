@@ -84,6 +84,7 @@ struct trhip_ctx {
                          // sample's pixel range and table indices per thread; 3 = 1 x 4 from per-sample splat descriptors (k_film_descriptors): measured SLOWER
                          // (1024^2, 256 spp: 29.0 ms against 24.3 ms: the 16-byte descriptor doubles the gather's loads and the arithmetic it saves was hidden)
     bool film_relayout = true;  // packed film pass: gather from a pixel-group-major copy of the radiance records (k_film_pack_transpose) instead of the integrators' sample-major order
+    bool leaf_queue = false;  // hybrid mode: the certified walk queues the leaves it reaches and tests them 64 at a time with whichever lanes (th_trace3d.h, option "leaf_queue")
     int node_layout = 0;  // children-in-parent nodes: 0 depth-first, 1 the two interior children of a node in one aligned 128-byte line (option "node_layout", read at commit; tu_scene.hip)
     bool film_swizzle = false;  // packed film gather: XCD x owns the x-th contiguous eighth of the workgroups (option "film_swizzle"; measured: no effect, th_kernels.h)
     bool film_tiled = false;  // LDS-staged film gather (k_film_gather_tiled): bit-identical, measured 2.7x SLOWER than k_film_gather (11 % lane use), kept as an option

@@ -208,6 +208,8 @@ int trhip_set_option(trhip_ctx* ctx, const char* name, int64_t value) {
         ctx->film_block = (int)std::max<int64_t>(0, std::min<int64_t>(13, value));
     else if (!std::strcmp(name, "film_relayout"))
         ctx->film_relayout = value != 0;
+    else if (!std::strcmp(name, "leaf_queue"))
+        ctx->leaf_queue = value != 0;
     else if (!std::strcmp(name, "node_layout")) {
         if (value < 0 || value > 1) return fail(ctx, TRHIP_ERR_INVALID, "node_layout: 0 (depth-first) or 1 (sibling pairs per 128-byte line)");
         ctx->node_layout = (int)value;
