@@ -861,7 +861,10 @@ static __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(T
             }
             // kGatherAhead candidates of the lane's bucket per round, fetched together: the walk is a chain of dependent 16-byte loads (a round per candidate
             // kept the kernel waiting on memory: 54 M candidates per iteration took 0.6 ms for ~3 ms worth of arithmetic per 100 iterations)
-            constexpr uint32_t kGatherAhead = 4;
+#ifndef TH_SPPM_GATHER_AHEAD
+#define TH_SPPM_GATHER_AHEAD 4
+#endif
+            constexpr uint32_t kGatherAhead = TH_SPPM_GATHER_AHEAD;
             float4 hp[kGatherAhead];
             const uint32_t n_here = more ? min(kGatherAhead, e1 - e) : 0u;
 #pragma unroll

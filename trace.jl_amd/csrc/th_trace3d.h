@@ -82,7 +82,6 @@ __global__ __launch_bounds__(kBlock, TH_TRACE3D_WAVES) void k_trace3d(DeviceScen
     uint32_t nn = 0, np = 0;
     uint32_t n_fb = 0;    // wave-uniform
     unsigned long long n_why[4] = {0ull, 0ull, 0ull, 0ull};  // COUNT: why rays went to the canonical tree — 0 direction / finiteness / cap, 1 a sphere (clipped, inside two), 2 near tie / guard; [3]: rays that start INSIDE a sphere and were certified (the order word)
-    uint32_t why = 0;
 
 #ifdef TH_DIAG_PHASES
     unsigned long long ph_cyc[4] = {0, 0, 0, 0}, ph_lan[4] = {0, 0, 0, 0}, ph_cnt[4] = {0, 0, 0, 0};  // refill (+ hand-over), pop, node, leaf (tools/phase_probe.py)
