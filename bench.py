@@ -673,7 +673,10 @@ def main():
                              "the CPU oracle walking the library's tree (NOT Trace.jl's tie-breaks: option bvh_builder selects it)",
                        "bits": "equal", "tolerance": "0 ulp (bit-exact; SURVEY 8(d)'s 1e-3 radiance tolerance is not used)",
                        "checked_in_this_run": (micro or {}).get("gpu_equals_cpu_on_subset"),
-                       "where": "tests/test_gpu_hybrid.py, tests/test_gpu_scale.py, tools/soak_hybrid.py (-m gpu); traversal_micro compares 2^21 rays in this run"},
+                       "where": "tests/test_gpu_hybrid.py, tests/test_gpu_scale.py, tools/soak_hybrid.py (-m gpu); traversal_micro compares 2^21 rays in this run",
+                       "witness": "the oracle is a restatement pinned to the reference's unit-test vectors per callee (ray / shape / BSDF / film / BVH construction); the PathIntegrator composite "
+                                  "does not exist in the reference (SURVEY F2: defined here as the SPPM camera-pass loop) and has no reference-produced output to compare with — the only "
+                                  "end-to-end artefact of the reference, its SPPM golden PNG, is matched radiometrically (tests/test_gpu_golden_radiometry.py)"},
         }
         if modes:
             result["bvh_modes"] = modes
