@@ -13,8 +13,8 @@
 // The certificate.  Everything in the reference's tests except the comparisons with t_max is a function of (ray, primitive) or (ray, box) alone.  Call a
 // primitive p a CANDIDATE when the t_max-free clauses of bounds.jl:186-198 pass on the box of the canonical LEAF that holds it and the t_max-free part of
 // its own test passes; t_p (the t it would set) and tau_p (the smallest t_max that accepts it, within 4 ulps of t_p) do not depend on the walk.  Commit
-// verifies that every accelerator leaf has bit for bit the box of the canonical leaf of each of its primitives (otherwise there is no hybrid mode for the
-// scene), and for rays without a zero direction component a leaf box that passes the t_max-free clauses implies that every ancestor box — in any tree whose
+// makes every accelerator leaf (part of) one canonical leaf with bit for bit that leaf's box — regrouping the accelerator's leaves where the two builders drew
+// them differently (tu_scene.hip conform_accelerator) — and verifies it, and for rays without a zero direction component a leaf box that passes the t_max-free clauses implies that every ancestor box — in any tree whose
 // boxes nest — passes them, and enters no later than the leaf (the slab products are monotonic in the box planes).  So the SET of candidates is the same in
 // both trees; only the t_max clauses see the order.  With D = the largest coordinate offset between the ray origin and the scene bound (the reach of the
 // ray's Float32 arithmetic; em / tight_scale) and kz the ray's dominant axis (every hit lies inside the scene, so t <= D |1 / d[kz]|),
