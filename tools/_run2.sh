@@ -1,11 +1,5 @@
 #!/bin/bash
 O=gpurun_out/r4z; mkdir -p $O
-M=tests/golden/caustic-glass.ply
-for v in libtracehip lib_a lib_b lib_c; do
-TRHIP_LIB=$PWD/trace.jl_amd/$v.so timeout 300 python tools/sppm_bench.py --model $M > $O/sppm_$v.json 2>/dev/null < /dev/null; python - $O/sppm_$v.json $v <<'PY'
-import json,sys
-for line in open(sys.argv[1]):
-    if line.startswith("{"):
-        d=json.loads(line); print(sys.argv[2], {k:v for k,v in d.items() if 'ms' in k or 'gather' in k})
-PY
+for v in libtracehip lib_a lib_b lib_c lib_d; do
+TRHIP_LIB=$PWD/trace.jl_amd/$v.so timeout 300 python tools/hybrid_probe.py --workload mesh_1m --spp 64 --check-spp 1 --skip-library > $O/probe_$v.json 2>/dev/null < /dev/null; echo $v $(grep -E "closest_ms|differing" $O/probe_$v.json | head -1)
 done
