@@ -66,13 +66,16 @@
 namespace th {
 
 #ifndef TH_TRACE3C_WAVES
-#define TH_TRACE3C_WAVES 5
+#define TH_TRACE3C_WAVES 6
+#endif
+#ifndef TH_TRACE3C_AXIS_LESS
+#define TH_TRACE3C_AXIS_LESS 0  // 1: the per-axis form (camera rays far outside the scene) one wave per SIMD less
 #endif
 #ifndef TH_TRACE3C_REFILL
 #define TH_TRACE3C_REFILL TH_TRACE_REFILL  // idle lanes of a wave that trigger a refill
 #endif
 #ifndef TH_TRACE3C_LDS
-#define TH_TRACE3C_LDS 12
+#define TH_TRACE3C_LDS 11
 #endif
 #ifndef TH_TRACE3C_LEAF_WAIT
 #define TH_TRACE3C_LEAF_WAIT 32
@@ -233,7 +236,7 @@ TH_D uint32_t fallback_append(FallbackList fb, bool to_fb, uint32_t idx, uint32_
 // behind one pointer (CertCold), the spheres are tested in the chunk pre-pass: the certificate costs the walk two live values (the per-ray margin and the current node's entry distance;
 // t_lim takes t_max's place).
 template <bool COUNT, bool FULL_ONLY, bool BIG = false, bool AXIS = false>
-__global__ __launch_bounds__(kBlock, BIG ? TH_TRACE3C_WAVES - 1 : TH_TRACE3C_WAVES) void k_trace3c(DeviceScene sc /* prims: the accelerator's order */, WideScene ws /* the accelerator */, CertHot ch,
+__global__ __launch_bounds__(kBlock, (BIG || (AXIS && TH_TRACE3C_AXIS_LESS)) ? TH_TRACE3C_WAVES - 1 : TH_TRACE3C_WAVES) void k_trace3c(DeviceScene sc /* prims: the accelerator's order */, WideScene ws /* the accelerator */, CertHot ch,
                                                                                                const CertCold* __restrict__ cold, SegQueue q, const float4* __restrict__ ro,
                                                                                                const float4* __restrict__ rd, const float* __restrict__ tmax_or_null, TraceOut out,
                                                                                                uint32_t* __restrict__ work, uint2* __restrict__ overflow, Counters* ctr) {
