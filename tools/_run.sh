@@ -1,5 +1,5 @@
 #!/bin/bash
 O=gpurun_out; mkdir -p $O
-timeout 1500 python -m pytest tests -q -m gpu > $O/r4d_pytest_gpu_full_suite.txt 2>&1 < /dev/null; grep -E "passed|failed" $O/r4d_pytest_gpu_full_suite.txt | tail -1
-timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
-timeout 900 python bench.py > $O/r4d_bench_default.json 2>$O/r4d_bench_default.err < /dev/null; cut -c1-400 $O/r4d_bench_default.json
+timeout 1500 python -m pytest tests -q -m gpu > $O/r4e_pytest_gpu_full_suite.txt 2>&1 < /dev/null; grep -E "passed|failed" $O/r4e_pytest_gpu_full_suite.txt | tail -1
+timeout 1500 python tools/soak_hybrid.py --scenes 120 --rays 400000 --frames 48 --seed 31 > $O/r4e_soak_hybrid.txt 2>/dev/null < /dev/null; tail -1 $O/r4e_soak_hybrid.txt
+bash tools/final_runs.sh r4e < /dev/null
