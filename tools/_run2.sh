@@ -1,8 +1,5 @@
 #!/bin/bash
 O=gpurun_out/r4z; mkdir -p $O
-for rep in 1 2; do
-for v in libtracehip lib_a lib_b; do
-TRHIP_LIB=$PWD/trace.jl_amd/$v.so timeout 300 python tools/hybrid_probe.py --workload mesh_1m --spp 128 --check-spp 1 --skip-library > $O/probe_$v.json 2>/dev/null < /dev/null; echo $rep $v $(grep -E "closest_ms|frame_ms|differing" $O/probe_$v.json | head -2)
-done
-done
-timeout 300 python tools/hybrid_probe.py --workload cornell --spp 64 --check-spp 2 --skip-library 2>/dev/null | grep -E "closest_ms|differing"
+timeout 600 python -m pytest tests/test_gpu_hybrid.py tests/test_gpu_sppm.py tests/test_gpu_scale.py -x -q -m gpu 2>&1 | tail -2
+timeout 600 python tools/soak_sppm.py --scenes 30 2>&1 | tail -1
+timeout 600 python bench.py --workload caustic_sppm --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print(d['ms_per_step'], d['roofline']['kernel_ms_per_step'])"

@@ -84,6 +84,8 @@ struct trhip_ctx {
                          // sample's pixel range and table indices per thread; 3 = 1 x 4 from per-sample splat descriptors (k_film_descriptors): measured SLOWER
                          // (1024^2, 256 spp: 29.0 ms against 24.3 ms: the 16-byte descriptor doubles the gather's loads and the arithmetic it saves was hidden)
     bool film_relayout = true;  // packed film pass: gather from a pixel-group-major copy of the radiance records (k_film_pack_transpose) instead of the integrators' sample-major order
+    int any_on_accelerator = -1;  // hybrid mode: any-hit rays without a zero direction component walk the library's tree (TraceOut::zero_mode): 1 always, 0 never, -1 where the
+                                  // integrator asks for it (TraceOut::any_acc_hint: SPPM).  Option "any_on_accelerator"
     bool leaf_queue = false;  // hybrid mode: the certified walk queues the leaves it reaches and tests them 64 at a time with whichever lanes (th_trace3d.h, option "leaf_queue")
     int node_layout = 0;  // children-in-parent nodes: 0 depth-first, 1 the two interior children of a node in one aligned 128-byte line (option "node_layout", read at commit; tu_scene.hip)
     bool film_swizzle = false;  // packed film gather: XCD x owns the x-th contiguous eighth of the workgroups (option "film_swizzle"; measured: no effect, th_kernels.h)
@@ -352,7 +354,7 @@ void launch_trace2_stream(trhip_ctx* ctx, hipStream_t st, const trhip_scene* sc,
                           Counters* ctr, const StreamCtl& sx);
 // tu_trace3.hip / tu_trace8.hip: the kernel families launch_trace picks from
 void launch_trace3(trhip_ctx* ctx, hipStream_t st, const trhip_scene* sc, bool any, bool cnt, bool full_only, bool big, const SegQueue& q, const float4* ro, const float4* rd, const float* tmax,
-                   const TraceOut& out, uint32_t* work_cursors, uint2* ov, Counters* ctr);
+                   const TraceOut& out, uint32_t* work_cursors, uint2* ov, Counters* ctr, bool on_accelerator = false);
 void launch_trace4(trhip_ctx* ctx, hipStream_t st, const trhip_scene* sc, bool any, bool cnt, bool full_only, const SegQueue& q, const float4* ro, const float4* rd, const float* tmax,
                    const TraceOut& out, uint32_t* work_cursors, uint2* ov, Counters* ctr);
 // tu_trace3c.hip: the hybrid mode's certified walks on the accelerator tree (th_trace3c.h)

@@ -122,6 +122,14 @@ struct TraceOut {
     uint32_t bary_mode;      // closest, 1: hits.x = third barycentric of a triangle hit instead of t (the shading kernels then
                              // skip re-running the triangle test); spheres keep t
     uint32_t far_hint;       // closest, hybrid mode: 1 = the rays of this launch start far outside the scene (camera rays): k_trace3c's AXIS variant (th_trace3c.h)
+    // any-hit, hybrid mode (k_trace3 only): intersect_p is a boolean with a fixed t_max, so a ray WITHOUT a zero direction component gets the same answer on every tree
+    // whose leaves carry the canonical leaf boxes (monotonic slab products) — those rays walk the accelerator tree (zero_mode 1: rays with a zero component are skipped
+    // and *zero_flag is raised), the others (0 x Inf = NaN in the slab products: tree-dependent) the canonical tree in a second launch (zero_mode 2: only they; the
+    // launch returns at once when the flag is down)
+    uint32_t zero_mode;
+    uint32_t* zero_flag;
+    uint32_t any_acc_hint;   // any-hit, hybrid mode, option "any_on_accelerator" = -1 (default): 1 = this integrator's shadow rays are faster on the library's tree (SPPM's camera pass:
+                             // 16.0 -> 10.9 ms per 100 iterations of C4; the path tracer's on S-mesh / S-blob measure 6-12 % SLOWER there and keep the canonical tree)
 };
 
 // ---- streaming wavefront (DESIGN.md "Stragglers") ---------------------------------------------------------------------------
@@ -978,6 +986,7 @@ __global__ __launch_bounds__(kBlock, ANY ? TH_TRACE3_WAVES_ANY : (BIG ? TH_TRACE
     __shared__ uint32_t s_ref[kLds][kBlock];
     __shared__ float s_tmin[kLds][kBlock];
     __shared__ SegView sv;
+    if (ANY && out.zero_mode == 2u && *out.zero_flag == 0u) return;  // (uniform: no ray of this launch has a zero direction component)
     seg_load(q, sv);
     const uint32_t tid = threadIdx.x;
     const uint32_t gthreads = gridDim.x * kBlock;
@@ -1087,6 +1096,15 @@ __global__ __launch_bounds__(kBlock, ANY ? TH_TRACE3_WAVES_ANY : (BIG ? TH_TRACE
                         } else {
                             cur = kRefNone;
                             cur_cnt = 0;
+                        }
+                        if (ANY && out.zero_mode) {  // hybrid any-hit (TraceOut): mode 1 leaves the rays with a zero direction component to the second launch, mode 2 takes only those
+                            const bool z = d.x == 0.0f || d.y == 0.0f || d.z == 0.0f;
+                            if (z == (out.zero_mode == 1u)) {
+                                if (z) *out.zero_flag = 1u;
+                                active = false;  // not delivered here
+                                cur = kRefNone;
+                                cur_cnt = 0;
+                            }
                         }
                     }
                 }

@@ -208,6 +208,8 @@ int trhip_set_option(trhip_ctx* ctx, const char* name, int64_t value) {
         ctx->film_block = (int)std::max<int64_t>(0, std::min<int64_t>(13, value));
     else if (!std::strcmp(name, "film_relayout"))
         ctx->film_relayout = value != 0;
+    else if (!std::strcmp(name, "any_on_accelerator"))
+        ctx->any_on_accelerator = value < 0 ? -1 : (value != 0 ? 1 : 0);
     else if (!std::strcmp(name, "leaf_queue"))
         ctx->leaf_queue = value != 0;
     else if (!std::strcmp(name, "node_layout")) {

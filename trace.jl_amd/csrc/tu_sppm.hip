@@ -188,7 +188,7 @@ int render_sppm_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
                 hipLaunchKernelGGL(k_shade_sppm<false>, g_shade, blk, 0, st, scene->dev, pq[cur], pq[cur ^ 1], sq, cap, hits, vp_all, terms, ctr, depth, max_depth, seed, it0, n, W);
             tm.end(2, st);
             tm.begin(3, st);
-            launch_trace(ctx, st, scene, true, SegQueue{ctr->n_shadow[depth - 1], cap, 0u}, sq.o, sq.d, nullptr, TraceOut{nullptr, terms, sq.c, nullptr}, ctr->work_shadow[depth - 1], ctr,
+            launch_trace(ctx, st, scene, true, SegQueue{ctr->n_shadow[depth - 1], cap, 0u}, sq.o, sq.d, nullptr, TraceOut{nullptr, terms, sq.c, nullptr, 0u, 0u, 0u, nullptr, 1u}, ctr->work_shadow[depth - 1], ctr,
                          pp.overflow[0].p);
             tm.end(3, st);
             cur ^= 1;

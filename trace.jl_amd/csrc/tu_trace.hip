@@ -170,6 +170,23 @@ void launch_trace(trhip_ctx* ctx, hipStream_t st, const trhip_scene* sc, bool an
         }
         // scenes larger than the last-level cache (256 MB of MALL): one wave per SIMD fewer (k_trace3's BIG variant)
         const bool big = !any && !cnt && (size_t)sc->wide.n_wnodes * 64u + (size_t)sc->dev.n_prims * 48u > ((size_t)256 << 20);
+        if (any && hybrid_active(ctx, sc) && (ctx->any_on_accelerator > 0 || (ctx->any_on_accelerator < 0 && out.any_acc_hint)) && sc->wide_acc.root_cnt == 0) {
+            // any-hit rays of a two-tree scene (TraceOut::zero_mode): the library's tree for every ray without a zero direction component, the canonical tree for the rest
+            const size_t words = 16 + (size_t)kSeg * kCtrStride;  // the flag, then the second launch's work cursors
+            if (ensure(ctx, ctx->fb_counts[1], words * sizeof(uint32_t)) == 0) {
+                uint32_t* zf = (uint32_t*)ctx->fb_counts[1].p;
+                (void)hipMemsetAsync(zf, 0, words * sizeof(uint32_t), st);
+                TraceOut o1 = out, o2 = out;
+                o1.zero_mode = 1u;
+                o2.zero_mode = 2u;
+                o1.zero_flag = o2.zero_flag = zf;
+                launch_trace3(ctx, st, sc, true, cnt, full_only, false, q, ro, rd, tmax, o1, work_cursors, ov, ctr, true);
+                SegQueue q2 = q;
+                q2.no_total = 1u;  // (counted by the first launch)
+                launch_trace3(ctx, st, sc, true, cnt, full_only, false, q2, ro, rd, tmax, o2, zf + 16, ov, ctr, false);
+                return;
+            }
+        }
         launch_trace3(ctx, st, sc, any, cnt, full_only, big, q, ro, rd, tmax, out, work_cursors, ov, ctr);
         return;
     }

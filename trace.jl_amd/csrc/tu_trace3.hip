@@ -2,12 +2,13 @@
 // here and nowhere else; tu_trace.hip's launch_trace picks the variant.
 #include "th_host.h"
 
-#define TH_LAUNCH3(ANYV, CNTV, FULLV, BIGV) \
-    hipLaunchKernelGGL((k_trace3<ANYV, CNTV, FULLV, BIGV>), grid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, work_cursors, ov, ctr)
+#define TH_LAUNCH3(ANYV, CNTV, FULLV, BIGV)                                                                                                                                         \
+    hipLaunchKernelGGL((k_trace3<ANYV, CNTV, FULLV, BIGV>), grid, block, 0, st, on_accelerator ? sc->dev_acc : sc->dev, on_accelerator ? wide_view_acc(ctx, sc) : wide_view(ctx, sc), q, ro, rd, \
+                       tmax, out, work_cursors, ov, ctr)
 #define TH_LAUNCH4(ANYV, CNTV, FULLV) hipLaunchKernelGGL((k_trace4<ANYV, CNTV, FULLV>), grid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, work_cursors, ov, ctr)
 
 void launch_trace3(trhip_ctx* ctx, hipStream_t st, const trhip_scene* sc, bool any, bool cnt, bool full_only, bool big, const SegQueue& q, const float4* ro, const float4* rd, const float* tmax,
-                   const TraceOut& out, uint32_t* work_cursors, uint2* ov, Counters* ctr) {
+                   const TraceOut& out, uint32_t* work_cursors, uint2* ov, Counters* ctr, bool on_accelerator) {
     const dim3 grid(trace_grid(ctx)), block(kBlock);
     if (any) {
         if (cnt) {
