@@ -790,6 +790,7 @@ static int upload_accelerator_impl(trhip_scene* s, bool conformed) {
     s->dev_acc = s->dev;
     const uint32_t n_prims = (uint32_t)s->bvh.order.size(), n_cnodes = (uint32_t)s->bvh.a.size(), n_anodes = (uint32_t)s->acc.a.size();
     if (!s->wide_ok || s->literal_only || n_prims == 0 || n_anodes == 0 || s->acc.order.size() != n_prims || n_prims >= (1u << 24)) return 0;
+    if (s->acc.max_depth > (uint32_t)(kStackLds + kStackSpill)) return 0;  // the certified walk's stack holds 64 entries like every other kernel's (a regrouped leaf adds levels)
     if (s->wide.root_cnt > 0) return 0;  // the canonical tree is one leaf: nothing to accelerate
     // canonical slot of every caller primitive, and the box of the canonical leaf that holds each canonical slot
     std::vector<uint32_t> cslot(s->prims.size(), 0xffffffffu);
