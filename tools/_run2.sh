@@ -1,5 +1,11 @@
 #!/bin/bash
 O=gpurun_out/r4z; mkdir -p $O
-for t in 16 0; do
-timeout 300 python tools/hybrid_probe.py --workload cornell --spp 64 --check-spp 2 --opt tiny_scene_prims=$t > $O/probe_tiny$t.json 2>/dev/null < /dev/null; echo tiny $t $(grep -E "closest_ms|accelerator_nodes|differing" $O/probe_tiny$t.json)
+M=tests/golden/caustic-glass.ply
+for v in libtracehip lib_a lib_b lib_c; do
+TRHIP_LIB=$PWD/trace.jl_amd/$v.so timeout 300 python tools/sppm_bench.py --model $M > $O/sppm_$v.json 2>/dev/null < /dev/null; python - $O/sppm_$v.json $v <<'PY'
+import json,sys
+for line in open(sys.argv[1]):
+    if line.startswith("{"):
+        d=json.loads(line); print(sys.argv[2], d['ms_total'], d['kernel_ms'])
+PY
 done
