@@ -241,3 +241,29 @@ def test_more_than_eight_spheres_keep_the_canonical_tree_alone(T, ob, hyb_ctx):
     assert integ.stats.fallback_rays == 0 and integ.stats.traversal == 3
     scene._flat = None
     flat.free()
+
+
+@pytest.mark.parametrize("opts", [{"hybrid": 0}, {"leaf_queue": 1}, {"any_on_accelerator": 1}, {"any_on_accelerator": 0}, {"node_layout": 1}, {"overlap": 1}, {"pipelines": 2},
+                                  {"traversal": 7}, {"traversal": 1}, {"slab_margin_log2": 0}, {"count_visits": 1}, {"leaf_queue": 1, "overlap": 1}],
+                         ids=lambda o: ",".join(f"{k}={v}" for k, v in o.items()))
+def test_options_that_change_how_a_frame_is_computed_leave_the_frame_alone(T, opts):
+    """A two-tree scene under the switches of the hybrid mode and of the frame loop: film and per-sample radiance bit-equal to the default configuration's
+    (tools/option_exactness.py runs the long list on four scenes)."""
+    scene, cam = T.scenes.mesh_scene(48), T.scenes.cornell_camera(64)
+    out = []
+    for o in ({}, opts):
+        c = T.Context(0)
+        try:
+            for k, v in o.items():
+                c.set_option(k, v)
+            integ = T.PathIntegrator(cam, T.SeededSampler(3, seed=5), 6)
+            film = integ.render(scene, c).copy()
+            out.append((film, integ.sample_radiance(scene).copy(), scene._flat.bvh_mode()[0]))
+        finally:
+            if scene._flat is not None:
+                scene._flat.free()
+                scene._flat = None
+            c.close()
+    assert out[0][2] == 2 and out[1][2] == 2
+    assert_bits_equal(out[1][1], out[0][1], f"per-sample radiance under {opts}")
+    assert_bits_equal(out[1][0], out[0][0], f"film under {opts}")
