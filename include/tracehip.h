@@ -186,6 +186,11 @@ typedef struct {
     uint64_t nodes_visited_fallback, prims_tested_fallback;
 } trhip_stats;
 
+/* How trhip_render_path splits a frame whose per-sample buffers do not fit into `budget_bytes` (host arithmetic, no GPU): bands of whole rows of 16 x 16 sample tiles
+ * (integrators/sampler.jl:15-24: tiles in k order — bands are ranges of k, so the film is the sequential loop's bit for bit).  bytes_per_sample: 17 (radiance record + poison byte: the
+ * default film pass), 25 or 33 with the other film passes.  Writes up to `cap` bands: first sample row (film coordinates) and number of sample rows; *n_bands = how many there are. */
+int trhip_plan_bands(const trhip_sensor* sensor, uint32_t spp, uint64_t budget_bytes, uint32_t bytes_per_sample, uint32_t cap, uint32_t* n_bands, int32_t* first_row, int32_t* n_rows);
+
 /* ---- integrators (replace `integrator(scene)`, integrators/sampler.jl:12-56) ---------------------------------------
  * out_xyzw: (crop height) * (crop width) * 4 floats in film.pixels (y, x) order = Pixel.xyz sums + filter_weight_sum
  * (film.jl:7-11), i.e. exactly the state `save(film)` (film.jl:204-222) starts from.  NaN radiance samples are zeroed

@@ -227,3 +227,31 @@ def test_bench_refuses_a_line_without_an_n_rank_library_communicator(T, tmp_path
     assert r.returncode != 0, r.stdout + r.stderr
     assert "UNREACHABLE" not in r.stdout and "no bench line" in r.stderr, r.stdout + r.stderr
     assert "exitcode  : 3" in r.stderr or "exitcode: 3" in r.stderr or "exit code 3" in r.stderr.lower() or "(exitcode: 3)" in r.stderr, r.stderr[-2000:]
+
+
+def test_c5_band_boundaries(T):
+    """BASELINE configs[4] on one rank of eight: 4096 x 4096, 128 of the 1024 spp.  The per-sample buffers (17 B per camera sample with the default film pass) are larger than what
+    trhip_render_path gives them (half of the free HBM), so the frame renders in bands of whole 16-pixel tile rows (trhip_plan_bands: the library's own arithmetic, host only).
+    The bands must tile the sample rows exactly — contiguous, disjoint, tile-aligned, every row once — and each must fit 32-bit sample indices."""
+    import ctypes as C
+    cam = T.scenes.cornell_camera(4096)
+    sn = cam.sensor()
+    sb = cam.film.get_sample_bounds()
+    y_min, y_max = int(sb.p_min[1]), int(sb.p_max[1])
+    sb_w = int(sb.p_max[0]) - int(sb.p_min[0]) + 1
+    lib = T._ffi.lib()
+    for spp, budget in ((128, 120 << 30), (128, 40 << 30), (1024, 120 << 30), (128, 1 << 40), (8, 1 << 20)):
+        n = C.c_uint32(0)
+        first, rows = (C.c_int32 * 512)(), (C.c_int32 * 512)()
+        assert lib.trhip_plan_bands(C.byref(sn), spp, budget, 17, 512, C.byref(n), first, rows) == 0
+        nb = n.value
+        assert 1 <= nb <= 512
+        bands = [(first[k], rows[k]) for k in range(nb)]
+        assert bands[0][0] == y_min and bands[-1][0] + bands[-1][1] - 1 == y_max, (spp, budget, bands[:3])
+        for (y0, r0), (y1, _) in zip(bands, bands[1:]):
+            assert y1 == y0 + r0 and r0 % 16 == 0 and (y0 - y_min) % 16 == 0  # contiguous, whole tile rows
+        assert all(r > 0 and sb_w * r * spp < (1 << 32) for _, r in bands)
+        if budget >= (1 << 40):
+            assert nb == 1 or sb_w * (y_max - y_min + 1) * spp >= (1 << 32)   # everything fits: one band unless 32-bit indices forbid it
+        per_band_bytes = max(r for _, r in bands) * sb_w * spp * 17
+        assert nb == 1 or per_band_bytes <= budget or max(r for _, r in bands) == 16  # (a single tile row is the smallest band)

@@ -115,6 +115,7 @@ SIGNATURES = {
     "trhip_scene_bvh_size": (C.c_int, [_VP, _U32, _U32]),
     "trhip_scene_get_bvh": (C.c_int, [_VP, _F, _U32, _U32, _U32]),
     "trhip_scene_set_bvh": (C.c_int, [_VP, _F, _U32, _U32, C.c_uint32, _U32, C.c_uint32]),
+    "trhip_plan_bands": (C.c_int, [C.POINTER(Sensor), C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, _U32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "trhip_scene_bvh_mode": (C.c_int, [_VP, C.POINTER(C.c_int), _U32, _U32]),
     "trhip_scene_bvh_note": (C.c_int, [_VP, C.c_char_p, C.c_size_t]),
     "trhip_scene_get_accelerator": (C.c_int, [_VP, _F, _U32, _U32, _U32]),

@@ -626,6 +626,23 @@ int render_impl_band(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
     return 0;
 }
 
+// Bands of a frame whose per-sample buffers do not fit (render_impl below): whole rows of 16 x 16 sample tiles, as many per band as `budget` bytes hold at `bytes_per_sample`
+// (and fewer than 2^32 sample slots: 32-bit indices).  Host arithmetic only: trhip_plan_bands exposes it, tests/test_sharding_gloo.py checks C5's numbers on CPU.
+int plan_rows_per_band(const DeviceSensor& ds, uint32_t spp, double budget_bytes, double bytes_per_sample) {
+    const double row_bytes = (double)ds.sb_w * 16.0 * (double)spp * bytes_per_sample;
+    int rows = (int)std::max(1.0, std::min((double)ds.tiles_y, std::floor(budget_bytes / row_bytes)));
+    while (rows > 1 && (uint64_t)ds.sb_w * 16ull * (uint64_t)rows * spp >= (1ull << 32)) --rows;
+    return rows;
+}
+DeviceSensor band_of(const DeviceSensor& ds, int t0, int rows_per_band) {
+    DeviceSensor b = ds;
+    b.band_ty0 = t0;
+    b.band_ty1 = std::min(ds.tiles_y, t0 + rows_per_band) - 1;
+    b.band_y0 = ds.sb_min[1] + 16 * t0;
+    b.band_rows = std::min(ds.sb_max[1], ds.sb_min[1] + 16 * b.band_ty1 + 15) - b.band_y0 + 1;
+    b.accumulate = t0 > 0 ? 1 : 0;
+    return b;
+}
 // A frame: one band when its per-sample buffers (radiance 16 B + film position 8 B per camera sample) fit in HBM next to the queues — every
 // BASELINE configuration up to 1024^2 x 256 spp does — otherwise bands of whole tile rows, rendered one after the other into the same film.
 // The film is the sequential tile loop's bit for bit either way: a film pixel receives its tiles in k order (integrators/sampler.jl:24-52,
@@ -652,9 +669,7 @@ int render_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sensor* se
             }
             // half of what is free for the per-sample buffers, the rest for the wavefront queues (164 B per path in flight); 32-bit slot indices
             const double budget = std::min(0.5 * (double)(free_b + held), 4.0e9 * 24.0);
-            const double row_bytes = (double)ds.sb_w * 16.0 * (double)spp * (film_uses_packed(ctx, ds) ? 17.0 : film_uses_desc(ctx, ds) ? 33.0 : 25.0);  // radiance (+ descriptor / film position) + poison byte
-            rows_per_band = (int)std::max(1.0, std::min((double)ds.tiles_y, std::floor(budget / row_bytes)));
-            while (rows_per_band > 1 && (uint64_t)ds.sb_w * 16ull * (uint64_t)rows_per_band * spp >= (1ull << 32)) --rows_per_band;
+            rows_per_band = plan_rows_per_band(ds, spp, budget, film_uses_packed(ctx, ds) ? 17.0 : film_uses_desc(ctx, ds) ? 33.0 : 25.0);  // radiance (+ descriptor / film position) + poison byte
         }
     }
     if (rows_per_band >= ds.tiles_y) return render_impl_band(ctx, scene, sensor, integrator, spp, max_depth, seed, sample_offset, out, out_is_device, stats, nullptr);
@@ -668,12 +683,7 @@ int render_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sensor* se
     std::memset(&sum, 0, sizeof sum);
     uint32_t n_bands = 0;
     for (int t0 = 0; t0 < ds.tiles_y; t0 += rows_per_band, ++n_bands) {
-        DeviceSensor b = ds;
-        b.band_ty0 = t0;
-        b.band_ty1 = std::min(ds.tiles_y, t0 + rows_per_band) - 1;
-        b.band_y0 = ds.sb_min[1] + 16 * t0;
-        b.band_rows = std::min(ds.sb_max[1], ds.sb_min[1] + 16 * b.band_ty1 + 15) - b.band_y0 + 1;
-        b.accumulate = t0 > 0 ? 1 : 0;
+        const DeviceSensor b = band_of(ds, t0, rows_per_band);
         trhip_stats st;
         if (int rc = render_impl_band(ctx, scene, sensor, integrator, spp, max_depth, seed, sample_offset, d_film, true, &st, &b)) return rc;
         sum.camera_samples += st.camera_samples;
@@ -714,6 +724,25 @@ int render_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sensor* se
 }  // namespace
 
 extern "C" {
+
+int trhip_plan_bands(const trhip_sensor* sensor, uint32_t spp, uint64_t budget_bytes, uint32_t bytes_per_sample, uint32_t cap, uint32_t* n_bands, int32_t* first_row, int32_t* n_rows) {
+    if (!sensor || !n_bands || spp == 0 || bytes_per_sample == 0) return TRHIP_ERR_INVALID;
+    DeviceSensor ds;
+    derive_sensor(sensor, ds);
+    if (ds.sb_w <= 0 || ds.sb_h <= 0) return TRHIP_ERR_INVALID;
+    const int rows = plan_rows_per_band(ds, spp, (double)budget_bytes, (double)bytes_per_sample);
+    uint32_t n = 0;
+    for (int t0 = 0; t0 < ds.tiles_y; t0 += rows, ++n) {
+        const DeviceSensor b = band_of(ds, t0, rows);
+        if (n < cap) {
+            if (first_row) first_row[n] = b.band_y0;
+            if (n_rows) n_rows[n] = b.band_rows;
+        }
+    }
+    *n_bands = n;
+    return 0;
+}
+
 
 int trhip_render_path(trhip_ctx* ctx, const trhip_scene* sc, const trhip_sensor* sn, uint32_t spp, int max_depth, uint64_t seed, uint32_t off, float* out, trhip_stats* st) {
     return render_impl(ctx, sc, sn, 1, spp, max_depth, seed, off, out, false, st);
