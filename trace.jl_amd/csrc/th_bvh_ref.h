@@ -26,7 +26,13 @@ namespace th {
 
 class RefBVHBuilder {
    public:
-    RefBVHBuilder(const std::vector<HostAABB>& prim_bounds, int max_node_prims) : pb_(prim_bounds), max_leaf_(std::min(255, max_node_prims)) {}
+    // depth_limit > 0: give up (DepthExceeded) as soon as a node lies deeper — the commit's use: a tree deeper than the reference's 64-entry traversal stack is refused anyway
+    // (bvh.jl:222), and finishing it first cost 7 s on the 10 M-triangle scene
+    RefBVHBuilder(const std::vector<HostAABB>& prim_bounds, int max_node_prims, uint32_t depth_limit = 0) : pb_(prim_bounds), max_leaf_(std::min(255, max_node_prims)), depth_limit_(depth_limit) {}
+    struct DepthExceeded : std::runtime_error {
+        uint32_t depth;
+        explicit DepthExceeded(uint32_t d) : std::runtime_error("the reference's BVH is deeper than the limit"), depth(d) {}
+    };
 
     // throws std::runtime_error when the recursion does not end within kMaxRecursion levels (the reference would overflow its stack)
     FlatBVH build() {
@@ -77,6 +83,7 @@ class RefBVHBuilder {
     // _init over info_[from, to) (bvh.jl:87-185); returns the node's index in the flat arrays
     uint32_t node(uint32_t from, uint32_t to, uint32_t depth) {
         if (depth > kMaxRecursion) throw std::runtime_error("the reference's BVH construction does not terminate on this input (bvh.jl:166-185 recursion)");
+        if (depth_limit_ && depth > depth_limit_) throw DepthExceeded(depth);
         out_.max_depth = std::max(out_.max_depth, depth);
         const uint32_t n = to - from;
         HostAABB bounds;
@@ -143,6 +150,7 @@ class RefBVHBuilder {
 
     const std::vector<HostAABB>& pb_;
     int max_leaf_;
+    uint32_t depth_limit_;
     std::vector<uint32_t> info_;
     std::vector<float> cen_;
     FlatBVH out_;

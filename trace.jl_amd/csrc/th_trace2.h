@@ -979,7 +979,8 @@ static __device__ unsigned long long g_phase[16];
 #endif
 // BIG (closest-hit only): scenes whose nodes and primitives exceed the last-level cache (10.5 M triangles: 1.2 GB) run one wave per SIMD
 // fewer — there the sixth wave's extra streams cost more in misses than they hide (365 vs 374 ms; the 1 M-triangle scene: 282 vs 271 ms)
-template <bool ANY, bool COUNT, bool FULL_ONLY, bool BIG = false>
+// PAIRS: the node array is the hybrid mode's accelerator, whose nodes keep each axis' two planes side by side (tu_scene.hip build_accelerator; th_trace3c.h "The step")
+template <bool ANY, bool COUNT, bool FULL_ONLY, bool BIG = false, bool PAIRS = false>
 __global__ __launch_bounds__(kBlock, ANY ? TH_TRACE3_WAVES_ANY : (BIG ? TH_TRACE3_WAVES_CLOSEST - 1 : TH_TRACE3_WAVES_CLOSEST)) void k_trace3(DeviceScene sc, WideScene ws, SegQueue q, const float4* __restrict__ ro, const float4* __restrict__ rd, const float* __restrict__ tmax_or_null,
                                                    TraceOut out, uint32_t* __restrict__ work, uint2* __restrict__ overflow, Counters* ctr) {
     constexpr int kLds = ANY ? TH_TRACE3_LDS_ANY : TH_TRACE3_LDS_CLOSEST;
@@ -1228,8 +1229,10 @@ __global__ __launch_bounds__(kBlock, ANY ? TH_TRACE3_WAVES_ANY : (BIG ? TH_TRACE
 #endif
                 const uint32_t lenc = __float_as_uint(a3.x), renc = __float_as_uint(a3.y), meta = __float_as_uint(a3.z);
                 float tl, tr;
-                const bool hl = slab_test2(a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, o, inv_d, em, tight_on && !(meta & 4u), negx, negy, negz, tl);
-                const bool hr = slab_test2(a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, o, inv_d, em, tight_on && !(meta & 8u), negx, negy, negz, tr);
+                const bool hl = PAIRS ? slab_test2(a0.x, a0.z, a1.x, a0.y, a0.w, a1.y, o, inv_d, em, tight_on && !(meta & 4u), negx, negy, negz, tl)
+                                      : slab_test2(a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, o, inv_d, em, tight_on && !(meta & 4u), negx, negy, negz, tl);
+                const bool hr = PAIRS ? slab_test2(a1.z, a2.x, a2.z, a1.w, a2.y, a2.w, o, inv_d, em, tight_on && !(meta & 8u), negx, negy, negz, tr)
+                                      : slab_test2(a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, o, inv_d, em, tight_on && !(meta & 8u), negx, negy, negz, tr);
                 // a missed child gets tx_min = +Inf: it then fails `tx_min < t_max` like a hit one beyond t_max (a NaN tx_min fails it too, as in bounds.jl:198)
                 const float tlh = hl ? tl : kInf, trh = hr ? tr : kInf;
                 const uint32_t axis = meta & 3u;

@@ -86,6 +86,18 @@ namespace th {
 #ifndef TH_TRACE3C_MAX_A
 #define TH_TRACE3C_MAX_A 8
 #endif
+// The interior step of the scalar-margin form (round 5, header "The step"): 0 = slab_test3 on both children (the reference's clause structure, the two tight clauses, the
+// split axis' sign picks the near child); 1 = the six slab products once, near / far by min / max, one max3 / min3 pair for the exact entry / exit and one for the box grown by
+// the ray's margin, the nearer ENTRY first
+#ifndef TH_TRACE3C_FAST
+#define TH_TRACE3C_FAST 1
+#endif
+#ifndef TH_TRACE3C_LAT
+#define TH_TRACE3C_LAT 17
+#endif
+#ifndef TH_TRACE3C_ORDER
+#define TH_TRACE3C_ORDER 0  // FAST: 1 = the child with the smaller entry distance first (measured: 2 % more boxes, 1 % slower); 0 = the split axis' sign (k_trace3's order)
+#endif
 constexpr float kCertDt = 1.52587890625e-5f;     // 2^-16: dt = kCertDt D |1 / d[kz]| (256 ulps of the largest possible t)
 constexpr float kCertGrow = 9.5367431640625e-7f;  // 2^-20 (16 ulps): the sheared vertex coordinates x' = fl(fl(v_x - o_x) + fl(S_x fl(v_z - o_z))) carry <= 5 ulps of D each (one for each
                                                   // subtraction, two for S_x, one for the product), so the point of the TRUE triangle with the computed barycentrics lies within 5 ulps of D per
@@ -99,6 +111,35 @@ constexpr uint32_t kCertMaxSpheres = 8;          // (the order word of a primiti
 #endif
 constexpr float kCertCap = TH_CERT_CAP;                  // a ray whose growth margin in t units exceeds this x (the kz extent margin) goes to the reference-order walk at once (near-axis-parallel
                                                   // rays: |1 / d| ~ 1e3 and more): the accelerator walk would overshoot every hit by that much
+
+typedef float v2f __attribute__((ext_vector_type(2)));  // (two products per instruction: v_pk_add_f32 / v_pk_mul_f32)
+// {a.x - b[H], a.y - b[H]} and {a.x x b[H], a.y x b[H]}: the packed instructions with ONE half of the second operand feeding both lanes (op_sel), so that a ray's origin and
+// reciprocal direction live in three register pairs instead of six (the compiler's own selection duplicates each component into a pair of its own).  IEEE single operations, each
+// rounded once: the same numbers as the scalar forms.
+template <int H>
+TH_D v2f pk_sub_h(v2f a, v2f b) {
+    v2f r;
+    if (H == 0)
+        asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    else
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// min / max of values that came out of those instructions: written out, because the compiler cannot see that an asm result is no signalling NaN and would put a
+// canonicalising v_max_f32 x, x in front of every operand (IEEE mode).  No NaN reaches them (header: rays with a zero or non-finite component never walk here).
+TH_D float amin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+TH_D float amax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+TH_D float amin3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+TH_D float amax3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+template <int H>
+TH_D v2f pk_mul_h(v2f a, v2f b) {
+    v2f r;
+    if (H == 0)
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "v"(b));
+    else
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 
 struct CertScene {               // what the certificate needs beside the accelerator's WideScene
     const float* sphere_boxes;   // per sphere id: the box of the canonical leaf that holds it (6 floats)
@@ -133,6 +174,7 @@ struct CertHot {   // … and what the walk itself, or every fetch, needs
     uint32_t n_spheres;
     const SphereCert* spheres;  // one contiguous record per sphere (a single burst of scalar loads each)
     float mle[3];               // CertScene::mle_small
+    float klat;                 // TH_TRACE3C_FAST == 2: 2^-TH_TRACE3C_LAT / tight_scale: the scalar lateral margin ms = klat x em x max |1 / d|
 };
 static __global__ void k_store_cert_cold(CertCold* dst, CertCold v) { *dst = v; }
 // "count_visits": one thread, between the certified walk and the fallback walk of a launch (phase 0) and after the fallback walk (phase 1): what the closest-hit visit
@@ -242,8 +284,8 @@ __global__ __launch_bounds__(kBlock, (BIG || (AXIS && TH_TRACE3C_AXIS_LESS)) ? T
                                                                                                uint32_t* __restrict__ work, uint2* __restrict__ overflow, Counters* ctr) {
     constexpr int kLds = TH_TRACE3C_LDS;
     constexpr uint32_t kLeafBit = 1u << 24;  // a node word >= this (and != kRefNone) is a leaf: ref | count << 24
-    __shared__ uint32_t s_ref[kLds][kBlock];
-    __shared__ float s_tmin[kLds][kBlock];
+    constexpr bool FAST = TH_TRACE3C_FAST != 0 && !AXIS;  // header "The step"
+    __shared__ uint2 s_stk[kLds][kBlock];  // {child word, entry distance}: one 8-byte LDS access per push / pop
     // per-lane state that is only touched when a ray is fetched, accepted or finished lives in LDS, not in registers (the walk runs at the 80-VGPR line of six waves per
     // SIMD; a scratch spill costs a trip to memory, an LDS word 64 cycles): the ray's queue index, its state word, the entry distance of the node in hand
     __shared__ uint32_t s_idx[kBlock];
@@ -269,6 +311,9 @@ __global__ __launch_bounds__(kBlock, (BIG || (AXIS && TH_TRACE3C_AXIS_LESS)) ? T
 #define negz (inv_d.z < 0.0f)
     float t_lim = 0.0f;   // t_max + 2 dt, t_max = the t of the last accepted candidate (or the ray's own t_max): what the primitive tests accept up to; a box is culled when the lower
                           // bound of what it holds — its entry distance minus the margin — reaches it
+#if TH_TRACE3C_FAST == 2
+    float ms = 0.0f;      // per ray: the scalar lateral margin of the box tests (header "The step")
+#endif
     float mb = 0.0f;      // per ray: the margin of the lower bound: non-flat primitives their kz extent, everything the growth in the entering axis (with AXIS the growth is applied per
                           // axis to the box instead, and is not in here)
     // s_ex[tid]: entry distance of the node in `cur` (the reference's tx_min of its box)
@@ -399,6 +444,9 @@ __global__ __launch_bounds__(kBlock, (BIG || (AXIS && TH_TRACE3C_AXIS_LESS)) ? T
                         const float dt = margin_t();
                         const float mkz = (shear.kz == 0 ? ch.mle[0] : (shear.kz == 1 ? ch.mle[1] : ch.mle[2])) * fabsf(shear.sz);
                         mb = AXIS ? mkz : __fmaf_rn(growth(), inv_max(), mkz);
+#if TH_TRACE3C_FAST == 2
+                        ms = ch.klat * em * inv_max();
+#endif
                         t_lim = t_own + 2.0f * dt;
                         sp = 0;
                         active = true;
@@ -415,7 +463,7 @@ __global__ __launch_bounds__(kBlock, (BIG || (AXIS && TH_TRACE3C_AXIS_LESS)) ? T
                             if (COUNT) n_why[0]++;
                         } else if (ws.root_ref != kRefNone && slab_test2(ws.root_box[0], ws.root_box[1], ws.root_box[2], ws.root_box[3], ws.root_box[4], ws.root_box[5], o, inv_d, em, false, negx, negy, negz, tmin)) {
                             cur = ws.root_ref | (ws.root_cnt << 24);  // (the root is not culled by t: the reference's clause `tmin < t_max` holds whenever anything inside can be accepted)
-                            s_ex[tid] = tmin;
+                            s_ex[tid] = FAST ? __uint_as_float(__float_as_uint(tmin) & ~1u) : tmin;  // (FAST: bit 0 of an entry distance = "not strict"; the root passed the reference's own clauses)
                             // the sphere pre-pass of the chunk left this ray's state in its hit record: an accepted sphere (the incumbent), the sphere it starts inside of, or
                             // "to the reference-order walk"
                             bool flagged = false;
@@ -447,43 +495,16 @@ __global__ __launch_bounds__(kBlock, (BIG || (AXIS && TH_TRACE3C_AXIS_LESS)) ? T
                 continue;
             }
         }
-        // ---- phase A: pops and interior steps; lanes holding a leaf wait (k_trace3's schedule) ----
+        // ---- phase A: interior steps and pops; lanes holding a leaf wait (k_trace3's schedule).  A lane WITHOUT a node (both children failed and the stack top was dead, a leaf
+        //      that left a dead top) takes part in the step's tail instead of a pop section of its own: the tail reads the stack top anyway (k_trace3's in-step pop) — one entry per
+        //      round, dead ones dropped; what is left of the pop section is the delivery of the rays whose stack is empty ----
 #pragma unroll 1
         for (int it = 0; it < TH_TRACE3C_MAX_A; ++it) {
-            bool finished = false;
 #ifdef TH_DIAG_PHASES
-            const unsigned long long ph_pop_m = __ballot(active && cur == kRefNone);
+            const unsigned long long ph_pop_m = __ballot(active && cur == kRefNone && sp == 0);
             const unsigned long long ph_t_pop = __builtin_readcyclecounter();
 #endif
-            const bool wants_pop = active && cur == kRefNone;
-            const bool pop_now = (uint32_t)__popcll(__ballot(wants_pop)) >= (uint32_t)TH_TRACE3C_POP_MIN || __ballot(active && cur < kLeafBit) == 0ull;
-            if (pop_now && wants_pop) {
-                finished = true;
-                // a stack entry carries the node's EXACT entry distance (what the guard needs when it is a leaf): the pop-time check is the scalar form of the bound
-                const float t_pop = t_lim + (AXIS ? __fmaf_rn(growth(), inv_max(), mb) : mb);
-                while (sp > 0) {
-                    sp--;
-                    uint32_t enc;
-                    float tm;
-                    if (sp < kLds) {
-                        enc = s_ref[sp][tid];
-                        tm = s_tmin[sp][tid];
-                    } else if (sp < kStack2Total) {
-                        const uint2 e = overflow[(size_t)(sp - kLds) * gthreads + gtid];
-                        enc = e.x;
-                        tm = __uint_as_float(e.y);
-                    } else {
-                        continue;
-                    }
-                    if (tm < t_pop) {
-                        cur = enc;
-                        s_ex[tid] = tm;
-                        finished = false;
-                        break;
-                    }
-                }
-            }
-            if (finished) {  // the walk is over: a certified hit (stored when it was accepted) or a certified miss
+            if (active && cur == kRefNone && sp == 0) {  // the walk is over: a certified hit (stored when it was accepted) or a certified miss
                 active = false;
                 const uint32_t fst = s_st[tid] & 3u;  // bit 0: a hit is held; bit 1: the walk stored it (else it is the pre-pass's sphere record, whose third lane holds the state)
                 if (fst == 0u) out.hits[s_idx[tid]] = make_float4(kInf, __int_as_float(-1), 0.0f, 0.0f);
@@ -496,55 +517,108 @@ __global__ __launch_bounds__(kBlock, (BIG || (AXIS && TH_TRACE3C_AXIS_LESS)) ? T
                 ph_lan[1] += (unsigned long long)__popcll(ph_pop_m);
                 ph_cnt[1] += 1ull;
             }
-            const unsigned long long ph_node_m = __ballot(active && cur < kLeafBit);
+            const unsigned long long ph_node_m = __ballot(active && (cur < kLeafBit || cur == kRefNone));
             const unsigned long long ph_t_node = __builtin_readcyclecounter();
 #endif
-            if (active && cur < kLeafBit) {  // interior: one 64-byte burst, both child boxes
-                const float4 a0 = ws.wnodes[4 * (size_t)cur], a1 = ws.wnodes[4 * (size_t)cur + 1], a2 = ws.wnodes[4 * (size_t)cur + 2], a3 = ws.wnodes[4 * (size_t)cur + 3];
+            const bool stepping = active && cur < kLeafBit;
+            if (stepping || (active && cur == kRefNone)) {
+                float4 a0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), a1 = a0, a2 = a0, a3 = a0;
+                if (stepping) {  // interior: one 64-byte burst, both child boxes
+                    a0 = ws.wnodes[4 * (size_t)cur];
+                    a1 = ws.wnodes[4 * (size_t)cur + 1];
+                    a2 = ws.wnodes[4 * (size_t)cur + 2];
+                    a3 = ws.wnodes[4 * (size_t)cur + 3];
+                }
                 uint32_t top_enc = kRefNone;
                 float top_tm = kInf;
                 if (sp > 0) {
                     if (sp - 1 < kLds) {
-                        top_enc = s_ref[sp - 1][tid];
-                        top_tm = s_tmin[sp - 1][tid];
+                        const uint2 e = s_stk[sp - 1][tid];
+                        top_enc = e.x;
+                        top_tm = __uint_as_float(e.y);
                     } else if (sp - 1 < kStack2Total) {
                         const uint2 e = overflow[(size_t)(sp - 1 - kLds) * gthreads + gtid];
                         top_enc = e.x;
                         top_tm = __uint_as_float(e.y);
                     }
                 }
-                if (COUNT) nn += 2;
-                const uint32_t lenc = __float_as_uint(a3.x), renc = __float_as_uint(a3.y), meta = __float_as_uint(a3.z);
-                const float gr = AXIS ? growth() : 0.0f;
                 const float t_cull = t_lim + mb;
-                float tl, tr, gl, gr_;
-                const bool hl = slab_test3<AXIS>(a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, o, inv_d, em, gr, !(meta & 4u), negx, negy, negz, tl, gl);
-                const bool hr = slab_test3<AXIS>(a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, o, inv_d, em, gr, !(meta & 8u), negx, negy, negz, tr, gr_);
-                // per child: its exact entry distance travels with it; what is compared with t_cull is that distance (with AXIS: the entry of the grown box); a missed child: +Inf.
-                // (Boxes on a sphere's path keep the reference's clauses alone — bits 2 / 3 — but are culled like any other: the spheres themselves were tested at the fetch.)
-                const float bl = hl ? (AXIS ? gl : tl) : kInf, br = hr ? (AXIS ? gr_ : tr) : kInf;
-                const uint32_t axis = meta & 3u;
-                const bool neg = axis == 0 ? negx : (axis == 1 ? negy : negz);
-                const float bn = neg ? br : bl, bf = neg ? bl : br;
-                const float vn = AXIS ? (neg ? tr : tl) : bn, vf = AXIS ? (neg ? tl : tr) : bf;  // (only read for a child that is entered: there the two are the same number)
-                const uint32_t nenc = neg ? renc : lenc, fenc = neg ? lenc : renc;
-                const bool go_n = bn < t_cull, go_f = bf < t_cull;
-                // t_max never goes up in THIS walk (a ray that could see it raised is flagged and leaves): an entry that fails now fails at pop time
-                if (go_n & go_f) {
-                    if (sp < kLds) {
-                        s_ref[sp][tid] = fenc;
-                        s_tmin[sp][tid] = vf;
-                    } else if (sp < kStack2Total) {
-                        overflow[(size_t)(sp - kLds) * gthreads + gtid] = make_uint2(fenc, __float_as_uint(vf));
+                bool any_child = false;
+                float ex_new = 0.0f;
+                cur = kRefNone;
+                if (stepping) {
+                    if (COUNT) nn += 2;
+                    const uint32_t lenc = __float_as_uint(a3.x), renc = __float_as_uint(a3.y), meta = __float_as_uint(a3.z);
+                    float bl, br;    // per child: what is compared with t_cull — +Inf for a missed child
+                    float vl, vr;    // … and the entry distance that travels with it (only read for a child that is entered)
+                    bool neg;        // the second child first
+                    if constexpr (FAST) {
+                        // ---- header "The step": the slab products are the reference's (bounds.jl:183-193: (plane - o) x inv_d), two at a time (v_pk_add_f32 / v_pk_mul_f32: the
+                        //      accelerator's nodes keep each axis' two planes side by side); which plane is the near one is read off the products ----
+                        const v2f p_a = v2f{o.x, o.y}, p_b = v2f{o.z, inv_d.x}, p_c = v2f{inv_d.y, inv_d.z};
+                        const v2f Lx = pk_mul_h<1>(pk_sub_h<0>(v2f{a0.x, a0.y}, p_a), p_b), Ly = pk_mul_h<0>(pk_sub_h<1>(v2f{a0.z, a0.w}, p_a), p_c), Lz = pk_mul_h<1>(pk_sub_h<0>(v2f{a1.x, a1.y}, p_b), p_c);
+                        const v2f Rx = pk_mul_h<1>(pk_sub_h<0>(v2f{a1.z, a1.w}, p_a), p_b), Ry = pk_mul_h<0>(pk_sub_h<1>(v2f{a2.x, a2.y}, p_a), p_c), Rz = pk_mul_h<1>(pk_sub_h<0>(v2f{a2.z, a2.w}, p_b), p_c);
+                        const float lnx = amin(Lx.x, Lx.y), lfx = amax(Lx.x, Lx.y), lny = amin(Ly.x, Ly.y), lfy = amax(Ly.x, Ly.y), lnz = amin(Lz.x, Lz.y), lfz = amax(Lz.x, Lz.y);
+                        const float rnx = amin(Rx.x, Rx.y), rfx = amax(Rx.x, Rx.y), rny = amin(Ry.x, Ry.y), rfy = amax(Ry.x, Ry.y), rnz = amin(Rz.x, Rz.y), rfz = amax(Rz.x, Rz.y);
+                        const float l_in = amax3(lnx, lny, lnz), l_out = amin3(lfx, lfy, lfz);  // = bounds.jl:196's tx_min; <= :197's tx_max (the reference keeps the LARGER of the x and y exits)
+                        const float r_in = amax3(rnx, rny, rnz), r_out = amin3(rfx, rfy, rfz);
+#if TH_TRACE3C_FAST != 2
+                        // the box grown by em per axis (slab_test2's margin, now on every clause): a box that fails this holds no acceptable hit
+                        const float gx = em * fabsf(inv_d.x), gy = em * fabsf(inv_d.y), gz = em * fabsf(inv_d.z);
+                        const v2f Glx = v2f{lnx, lfx} + v2f{-gx, gx}, Gly = v2f{lny, lfy} + v2f{-gy, gy}, Glz = v2f{lnz, lfz} + v2f{-gz, gz};
+                        const v2f Grx = v2f{rnx, rfx} + v2f{-gx, gx}, Gry = v2f{rny, rfy} + v2f{-gy, gy}, Grz = v2f{rnz, rfz} + v2f{-gz, gz};
+                        const float l_ing = amax3(Glx.x, Gly.x, Glz.x), l_outg = amin3(Glx.y, Gly.y, Glz.y);
+                        const float r_ing = amax3(Grx.x, Gry.x, Grz.x), r_outg = amin3(Grx.y, Gry.y, Grz.y);
+                        const bool hl = (l_ing <= l_outg) && (l_outg >= 0.0f), hr = (r_ing <= r_outg) && (r_outg >= 0.0f);
+#else
+                        // … grown by the ray's scalar margin ms (t units: a length of 2^-TH_TRACE3C_LAT x D on the axis of the largest |1 / d|, more on the others)
+                        const bool hl = (l_in - l_out <= 2.0f * ms) && (l_out >= -ms), hr = (r_in - r_out <= 2.0f * ms) && (r_out >= -ms);
+#endif
+                        // STRICT: the un-grown interval is not empty and ends ahead of the origin: every clause of bounds.jl:186-198 but the t_max one then holds (its exits are no
+                        // smaller than l_out), and l_in is its tx_min bit for bit.  The entry distance travels with its lowest mantissa bit replaced by "not strict" (a leaf reached that
+                        // way: the reference may or may not enter it — a candidate found inside sends the ray to the reference-order walk)
+                        const bool sl = (l_in <= l_out) && (l_out > 0.0f), sr = (r_in <= r_out) && (r_out > 0.0f);
+                        vl = __uint_as_float((__float_as_uint(l_in) & ~1u) | (sl ? 0u : 1u));
+                        vr = __uint_as_float((__float_as_uint(r_in) & ~1u) | (sr ? 0u : 1u));
+                        bl = hl ? vl : kInf;
+                        br = hr ? vr : kInf;
+#if TH_TRACE3C_ORDER
+                        neg = br < bl;
+#else
+                        neg = ((meta & 3u) == 0u ? inv_d.x : ((meta & 3u) == 1u ? inv_d.y : inv_d.z)) < 0.0f;
+#endif
+                    } else {
+                        const float gr = AXIS ? growth() : 0.0f;
+                        float gl, gr_;
+                        const bool hl = slab_test3<AXIS>(a0.x, a0.z, a1.x, a0.y, a0.w, a1.y, o, inv_d, em, gr, !(meta & 4u), negx, negy, negz, vl, gl);  // (the accelerator's node layout: each axis' two planes side by side)
+                        const bool hr = slab_test3<AXIS>(a1.z, a2.x, a2.z, a1.w, a2.y, a2.w, o, inv_d, em, gr, !(meta & 8u), negx, negy, negz, vr, gr_);
+                        // per child: its exact entry distance travels with it; what is compared with t_cull is that distance (with AXIS: the entry of the grown box); a missed child: +Inf.
+                        // (Boxes on a sphere's path keep the reference's clauses alone — bits 2 / 3 — but are culled like any other: the spheres themselves were tested at the fetch.)
+                        bl = hl ? (AXIS ? gl : vl) : kInf;
+                        br = hr ? (AXIS ? gr_ : vr) : kInf;
+                        const uint32_t axis = meta & 3u;
+                        neg = axis == 0 ? negx : (axis == 1 ? negy : negz);
                     }
-                    sp++;
+                    const float bn = neg ? br : bl, bf = neg ? bl : br;
+                    const float vn = (AXIS && !FAST) ? (neg ? vr : vl) : bn, vf = (AXIS && !FAST) ? (neg ? vl : vr) : bf;  // (for a child that is entered the two are the same number unless AXIS)
+                    const uint32_t nenc = neg ? renc : lenc, fenc = neg ? lenc : renc;
+                    const bool go_n = bn < t_cull, go_f = bf < t_cull;
+                    // t_max never goes up in THIS walk (a ray that could see it raised is flagged and leaves): an entry that fails now fails at pop time
+                    if (go_n && go_f) {
+                        if (sp < kLds) {
+                            s_stk[sp][tid] = make_uint2(fenc, __float_as_uint(vf));
+                        } else if (sp < kStack2Total) {
+                            overflow[(size_t)(sp - kLds) * gthreads + gtid] = make_uint2(fenc, __float_as_uint(vf));
+                        }
+                        sp++;
+                    }
+                    any_child = go_n || go_f;
+                    cur = any_child ? (go_n ? nenc : fenc) : kRefNone;
+                    ex_new = go_n ? vn : vf;
                 }
-                const bool any_child = go_n | go_f;
-                cur = any_child ? (go_n ? nenc : fenc) : kRefNone;
-                float ex_new = go_n ? vn : vf;
                 if (!any_child && sp > 0) {  // nothing was pushed in this step: the top read above is still the top
                     sp--;
-                    const float t_pop = AXIS ? __fmaf_rn(gr, inv_max(), t_cull) : t_cull;
+                    const float t_pop = AXIS ? __fmaf_rn(growth(), inv_max(), t_cull) : t_cull;
                     if (top_tm < t_pop && sp < kStack2Total) {
                         cur = top_enc;
                         ex_new = top_tm;
@@ -572,8 +646,9 @@ __global__ __launch_bounds__(kBlock, (BIG || (AXIS && TH_TRACE3C_AXIS_LESS)) ? T
             float top_tm = kInf;
             if (sp > 0) {
                 if (sp - 1 < kLds) {
-                    top_enc = s_ref[sp - 1][tid];
-                    top_tm = s_tmin[sp - 1][tid];
+                    const uint2 e = s_stk[sp - 1][tid];
+                    top_enc = e.x;
+                    top_tm = __uint_as_float(e.y);
                 } else if (sp - 1 < kStack2Total) {
                     const uint2 e = overflow[(size_t)(sp - 1 - kLds) * gthreads + gtid];
                     top_enc = e.x;
@@ -603,7 +678,10 @@ __global__ __launch_bounds__(kBlock, (BIG || (AXIS && TH_TRACE3C_AXIS_LESS)) ? T
                     if (counts) {
                         const float dt = margin_t();
                         // accepted iff it lies 2 dt below the incumbent (t_lim - 4 dt; the ray's own t_max at first) AND its leaf box lets the reference in by t + dt (the guard); a NaN fails
-                        if (!(tt.t <= t_lim - 4.0f * dt) || !(s_ex[tid] <= tt.t + dt)) {
+                        // (FAST: the entry distance lost its lowest mantissa bit to the "not strict" flag: the guard reads the larger of the two numbers it can have been)
+                        const float ex = s_ex[tid];
+                        const float ex_hi = __uint_as_float(ex < 0.0f ? __float_as_uint(ex) & ~1u : __float_as_uint(ex) | 1u);
+                        if (!(tt.t <= t_lim - 4.0f * dt) || (FAST ? ((__float_as_uint(ex) & 1u) != 0u || !(ex_hi <= tt.t + dt)) : !(ex <= tt.t + dt))) {
                             if (COUNT && !flagged) why = 2u;
                             flagged = true;
                         } else if (!flagged) {

@@ -351,8 +351,8 @@ __global__ __launch_bounds__(kBlock, TH_TRACE3D_WAVES) void k_trace3d(DeviceScen
                 const float gr = AXIS ? growth() : 0.0f;
                 const float t_cull = t_lim + mb;
                 float tl, tr, gl, gr_;
-                const bool hl = slab_test3<AXIS>(a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, o, inv_d, em, gr, !(meta & 4u), negx, negy, negz, tl, gl);
-                const bool hr = slab_test3<AXIS>(a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, o, inv_d, em, gr, !(meta & 8u), negx, negy, negz, tr, gr_);
+                const bool hl = slab_test3<AXIS>(a0.x, a0.z, a1.x, a0.y, a0.w, a1.y, o, inv_d, em, gr, !(meta & 4u), negx, negy, negz, tl, gl);  // (the accelerator's node layout)
+                const bool hr = slab_test3<AXIS>(a1.z, a2.x, a2.z, a1.w, a2.y, a2.w, o, inv_d, em, gr, !(meta & 8u), negx, negy, negz, tr, gr_);
                 // per child: its exact entry distance travels with it; what is compared with t_cull is that distance (with AXIS: the entry of the grown box); a missed child: +Inf.
                 // (Boxes on a sphere's path keep the reference's clauses alone — bits 2 / 3 — but are culled like any other: the spheres themselves were tested at the fetch.)
                 const float bl = hl ? (AXIS ? gl : tl) : kInf, br = hr ? (AXIS ? gr_ : tr) : kInf;

@@ -1058,9 +1058,11 @@ static int upload_accelerator_impl(trhip_scene* s, bool conformed) {
             const float* l = &s->acc.bounds[6 * (size_t)c[0]];
             const float* r = &s->acc.bounds[6 * (size_t)c[1]];
             float4* w = &wn[4 * (size_t)widx[i]];
-            w[0] = make_float4(l[0], l[1], l[2], l[3]);
-            w[1] = make_float4(l[4], l[5], r[0], r[1]);
-            w[2] = make_float4(r[2], r[3], r[4], r[5]);
+            // the ACCELERATOR's layout: each axis' two planes side by side — {min x, max x, min y, max y}, {min z, max z | min x, max x}, {min y, max y, min z, max z} — so that
+            // k_trace3c's packed instructions take a pair as it was loaded (th_trace3c.h "The step"); the canonical tree's nodes keep {min xyz, max xyz} (upload_scene)
+            w[0] = make_float4(l[0], l[3], l[1], l[4]);
+            w[1] = make_float4(l[2], l[5], r[0], r[3]);
+            w[2] = make_float4(r[1], r[4], r[2], r[5]);
             // child word = ref | count << 24 (the stack entry format); meta = split axis | "subtree holds a sphere" bits 2 (first) / 3 (second)
             w[3] = make_float4(__builtin_bit_cast(float, ref[0] | (cnt[0] << 24)), __builtin_bit_cast(float, ref[1] | (cnt[1] << 24)),
                                __builtin_bit_cast(float, (s->acc.flags[i] & 3u) | ((uint32_t)has_sphere[c[0]] << 2) | ((uint32_t)has_sphere[c[1]] << 3)), 0.0f);
@@ -1352,25 +1354,32 @@ int trhip_scene_commit(trhip_scene* s, int max_node_primitives) {
         // the reference's own construction, node for node (th_bvh_ref.h): also for scenes the library would commit as one leaf, never composed
         bool ok = true;
         std::string why;
+        // the reference's builder is one host thread (0.6 s per million primitives); the library's tree — the accelerator of a hybrid commit, and the tree the default falls
+        // back on when the reference's construction fails — is built meanwhile (on the device from 64 Ki primitives: th_sahb.h)
+        auto ref_job = std::async(std::launch::async, [&pb, max_node_primitives]() {
+            RefBVHBuilder rb(pb, max_node_primitives, (uint32_t)(kStackLds + kStackSpill));  // (gives up at depth 65: bvh.jl:222 could not walk that tree)
+            return rb.build();
+        });
+        FlatBVH lib_tree;
+        int lib_rc = -1;  // -1: not built
+        if (want_hybrid) lib_rc = build_library_tree(s->ctx, pb, max_node_primitives, mode, false, lib_tree);
         try {
-            RefBVHBuilder rb(pb, max_node_primitives);
-            s->bvh = rb.build();
+            s->bvh = ref_job.get();
+        } catch (const RefBVHBuilder::DepthExceeded& e) {
+            ok = false;
+            why = "BVH depth exceeds the 64-entry traversal stack (a node at depth " + std::to_string(e.depth) + "; bvh.jl:222 throws a BoundsError there)";
         } catch (const std::exception& e) {
             ok = false;
             why = e.what();
         }
-        if (ok && s->bvh.max_depth > (uint32_t)(kStackLds + kStackSpill)) {
-            ok = false;
-            why = "BVH depth " + std::to_string(s->bvh.max_depth) + " exceeds the 64-entry traversal stack (bvh.jl:222 throws a BoundsError there)";
-        }
-        clk.tick("commit: reference tree");
+        clk.tick("commit: reference tree (+ library tree)");
         if (ok) {
             s->literal_only = false;
             s->bvh_mode = 1;
             if (int rc = upload_scene(s)) return rc;
             if (!want_hybrid) return 0;
-            if (int rc = build_library_tree(s->ctx, pb, max_node_primitives, mode, false, s->acc)) return rc;
-            clk.tick("commit: accelerator tree");
+            if (lib_rc) return lib_rc;
+            s->acc = std::move(lib_tree);
             if (int rc = upload_accelerator(s)) return rc;
             if (s->hybrid_ok) {
                 s->bvh_mode = 2;

@@ -3,8 +3,12 @@
 #include "th_host.h"
 
 #define TH_LAUNCH3(ANYV, CNTV, FULLV, BIGV)                                                                                                                                         \
-    hipLaunchKernelGGL((k_trace3<ANYV, CNTV, FULLV, BIGV>), grid, block, 0, st, on_accelerator ? sc->dev_acc : sc->dev, on_accelerator ? wide_view_acc(ctx, sc) : wide_view(ctx, sc), q, ro, rd, \
-                       tmax, out, work_cursors, ov, ctr)
+    do {                                                                                                                                                                            \
+        if (ANYV && on_accelerator) /* the accelerator's node layout (PAIRS); only any-hit rays walk it with this kernel */                                                        \
+            hipLaunchKernelGGL((k_trace3<ANYV, CNTV, FULLV, false, ANYV>), grid, block, 0, st, sc->dev_acc, wide_view_acc(ctx, sc), q, ro, rd, tmax, out, work_cursors, ov, ctr);    \
+        else                                                                                                                                                                        \
+            hipLaunchKernelGGL((k_trace3<ANYV, CNTV, FULLV, BIGV>), grid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, work_cursors, ov, ctr);                   \
+    } while (0)
 #define TH_LAUNCH4(ANYV, CNTV, FULLV) hipLaunchKernelGGL((k_trace4<ANYV, CNTV, FULLV>), grid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, work_cursors, ov, ctr)
 
 void launch_trace3(trhip_ctx* ctx, hipStream_t st, const trhip_scene* sc, bool any, bool cnt, bool full_only, bool big, const SegQueue& q, const float4* ro, const float4* rd, const float* tmax,
