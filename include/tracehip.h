@@ -248,6 +248,9 @@ int trhip_trace_any_device(trhip_ctx* ctx, const trhip_scene* scene, const void*
 
 /* Visit counters of the last *_device trace call when "count_visits" is on: nodes, prims (closest) then nodes, prims (any-hit). */
 int trhip_last_visit_counts(trhip_ctx* ctx, uint64_t* out4);
+/* Of the last closest-hit trace call (trhip_trace_closest, trhip_hit_geometry, *_device): rays traced, and how many of them the hybrid mode's certified walk handed to the
+ * reference-order walk on the canonical tree (0 when the scene holds one tree).  The frame entry points report the same through trhip_stats.fallback_rays. */
+int trhip_last_fallback_counts(trhip_ctx* ctx, uint64_t* out2);
 
 /* Device time (ms, HIP events: upload of the primitive bounds to the last flatten kernel) of the last BVHAccel built by the device
  * SAH builder ("bvh_builder" = 3, accel/bvh.jl:55-206 replaced); 0 when the last commit used another builder. */

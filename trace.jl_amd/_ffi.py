@@ -132,6 +132,7 @@ SIGNATURES = {
     "trhip_trace_closest_device": (C.c_int, [_VP, _VP, _VP, C.c_uint64, _VP, C.c_int, C.POINTER(C.c_double)]),
     "trhip_trace_any_device": (C.c_int, [_VP, _VP, _VP, C.c_uint64, _VP, C.c_int, C.POINTER(C.c_double)]),
     "trhip_last_visit_counts": (C.c_int, [_VP, C.POINTER(C.c_uint64)]),
+    "trhip_last_fallback_counts": (C.c_int, [_VP, C.POINTER(C.c_uint64)]),
     "trhip_last_bvh_build_ms": (C.c_int, [_VP, C.POINTER(C.c_double)]),
     "trhip_hit_geometry": (C.c_int, [_VP, _VP, _F, C.c_uint64, _F]),
     "trhip_generate_rays": (C.c_int, [_VP, C.POINTER(Sensor), _F, C.c_uint64, _F]),

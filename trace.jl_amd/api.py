@@ -655,6 +655,12 @@ class FlatScene:
         self.ctx.check(_ffi.lib().trhip_trace_closest(self.ctx._h, self._h, _ffi.fptr(rays), rays.shape[0], out.ctypes.data_as(C.c_void_p)))
         return out
 
+    def last_fallback(self):
+        """(rays, rays re-walked on the canonical tree) of the last closest-hit trace call (hybrid mode: th_trace3c.h)."""
+        out = np.zeros(2, np.uint64)
+        self.ctx.check(_ffi.lib().trhip_last_fallback_counts(self.ctx._h, out.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return int(out[0]), int(out[1])
+
     def trace_any(self, rays: np.ndarray) -> np.ndarray:
         rays = _ffi.f32(rays).reshape(-1, 8)
         out = np.empty(rays.shape[0], dtype=np.uint8)

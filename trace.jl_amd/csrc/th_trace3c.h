@@ -90,7 +90,7 @@ namespace th {
 // split axis' sign picks the near child); 1 = the six slab products once, near / far by min / max, one max3 / min3 pair for the exact entry / exit and one for the box grown by
 // the ray's margin, the nearer ENTRY first
 #ifndef TH_TRACE3C_FAST
-#define TH_TRACE3C_FAST 1
+#define TH_TRACE3C_FAST 0
 #endif
 #ifndef TH_TRACE3C_LAT
 #define TH_TRACE3C_LAT 17
@@ -748,6 +748,9 @@ __global__ __launch_bounds__(kBlock, (BIG || (AXIS && TH_TRACE3C_AXIS_LESS)) ? T
 #ifndef TH_TRACE_LEAF_C_WAVES
 #define TH_TRACE_LEAF_C_WAVES TH_TRACE_LEAF_WAVES
 #endif
+#ifndef TH_LEAF_C_DEFER
+#define TH_LEAF_C_DEFER 1  // 1: the canonical leaf boxes are tested once per ray, for the candidate it ends up holding; 0: for every candidate as it is found (round 4)
+#endif
 template <bool COUNT, bool FULL_ONLY>
 __global__ __launch_bounds__(kBlock, FULL_ONLY ? TH_TRACE_LEAF_C_WAVES : 4) void k_trace_leaf_c(DeviceScene sc /* canonical records */, WideScene ws /* root box; root_ref / root_cnt = all slots */,
                                                                               CertScene cs, SegQueue q, const float4* __restrict__ ro, const float4* __restrict__ rd,
@@ -791,6 +794,70 @@ __global__ __launch_bounds__(kBlock, FULL_ONLY ? TH_TRACE_LEAF_C_WAVES : 4) void
                 live = slab_test2(ws.root_box[0], ws.root_box[1], ws.root_box[2], ws.root_box[3], ws.root_box[4], ws.root_box[5], o, inv_d, 0.0f, false, negx, negy, negz, tmin) && tmin < t_lim;
         }
         bool found = false, sticky = false;
+#if TH_LEAF_C_DEFER
+        // The leaf boxes are looked at ONCE, for the candidate the ray ends up holding (header "one-leaf accelerator"): a candidate the reference cannot reach (its own test
+        // passes, the t_max-free clauses on its leaf's box do not) may ride as the incumbent for a while — whatever it displaced or hid lies farther than what finally holds the
+        // ray, or the final check sends the ray to the reference-order walk.
+        uint32_t best_slot = 0u;  // (the record itself is stored when the candidate is accepted — a nearer one overwrites it, the reference-order walk rewrites a flagged ray's)
+#pragma unroll 1
+        for (uint32_t k = 0; k < cnt; ++k) {
+            if (__ballot(live) == 0ull) break;
+            const uint32_t slot = first + k;  // wave-uniform: scalar loads
+            const float4 p0 = uniform_load(sc.prims, 3 * slot);
+            const uint32_t meta = __float_as_uint(p0.w);
+            float t_c = 0.0f;
+            float4 r4 = make_float4(0.0f, __int_as_float((int)slot), 0.0f, 0.0f);
+            bool cand = false, inside = false;
+            if (meta & PRIM_SPHERE) {
+                const SphereRec sr = uniform_load(sc.spheres, __float_as_uint(p0.x));
+                if (live) {
+                    if (COUNT) np++;
+                    const int r = sphere_candidate_c<FULL_ONLY>(sr, o, d, t_lim, t_c);
+                    if (r == 1 || r == 3) {
+                        cand = true;
+                        inside = r == 3;
+                        r4.x = t_c;
+                    } else if (r == 2) {
+                        flagged = true;  // a clipped sphere (or a NaN root) on the ray's line: the order decides
+                    }
+                }
+            } else if (!(meta & PRIM_DEGENERATE)) {
+                const float4 p1 = uniform_load(sc.prims, 3 * slot + 1), p2 = uniform_load(sc.prims, 3 * slot + 2);
+                if (live) {
+                    if (COUNT) np++;
+                    TriTest tt;
+                    if (tri_intersect_sheared<true>(mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z), o, shear, t_lim, &tt)) {
+                        cand = true;
+                        t_c = tt.t;
+                        r4 = make_float4(out.bary_mode ? tt.bary.z : tt.t, __int_as_float((int)slot), tt.bary.x, tt.bary.y);
+                    }
+                }
+            } else if (COUNT && live) {
+                np++;
+            }
+            if (cand) {
+                // accepted iff it lies 2 dt below the incumbent (the ray's own t_max at first) and no sphere the ray started inside of holds the ray (that one the reference
+                // takes whatever t_max is: what it tests afterwards is the order's business)
+                if (sticky || !(t_c <= t_max - 2.0f * dt)) {
+                    flagged = true;
+                } else {
+                    t_max = t_c;
+                    t_lim = t_c + 2.0f * dt;
+                    found = true;
+                    sticky = inside;
+                    best_slot = slot;
+                    out.hits[idx] = r4;
+                }
+            }
+            if (flagged) live = false;
+        }
+        if (valid && found && !flagged) {  // the reference reaches the holder's leaf (bounds.jl:186-198 on its box, t_max aside) and enters it by t + dt (the guard); a sphere entered from inside: its box holds the origin
+            const float* bx = cs.slot_boxes + 6 * (size_t)best_slot;
+            float ex;
+            if (COUNT) nn++;
+            if (!slab_test2(bx[0], bx[1], bx[2], bx[3], bx[4], bx[5], o, inv_d, 0.0f, false, negx, negy, negz, ex) || !(ex <= (sticky ? 0.0f : t_max + dt))) flagged = true;
+        }
+#else
 #pragma unroll 1
         for (uint32_t k = 0; k < cnt; ++k) {
             if (__ballot(live) == 0ull) break;
@@ -846,6 +913,7 @@ __global__ __launch_bounds__(kBlock, FULL_ONLY ? TH_TRACE_LEAF_C_WAVES : 4) void
             }
             if (flagged) live = false;
         }
+#endif
         const bool to_fb = valid && flagged;
         if (__ballot(to_fb) != 0ull) {
             uint32_t fseg = __builtin_amdgcn_readfirstlane((gtid >> 6) % kSeg);

@@ -343,6 +343,14 @@ int trhip_last_visit_counts(trhip_ctx* ctx, uint64_t* out4) {
     out4[3] = h.prims_shadow;
     return 0;
 }
+int trhip_last_fallback_counts(trhip_ctx* ctx, uint64_t* out2) {
+    if (!ctx || !out2 || !ctx->counters.p) return fail(ctx, TRHIP_ERR_INVALID, "no counters");
+    Counters h;
+    HIP_TRY(ctx, hipMemcpy(&h, ctx->counters.p, sizeof h, hipMemcpyDeviceToHost));
+    out2[0] = h.closest_total;
+    out2[1] = h.fallback_total;
+    return 0;
+}
 
 int trhip_hit_geometry(trhip_ctx* ctx, const trhip_scene* sc, const float* rays, uint64_t n, float* out15) {
     if (!ctx || !sc || !rays || !out15) return fail(ctx, TRHIP_ERR_INVALID, "null argument");
