@@ -135,6 +135,9 @@ int trhip_scene_bvh_mode(const trhip_scene* scene, int* mode, uint32_t* accel_no
 /* Why a scene committed with default options holds ONE tree (mode 0 or 1) instead of two: a NUL-terminated sentence copied into buf (at most n bytes; "" for mode 2 and for
  * explicit builders).  E.g. "the reference's construction: BVH depth 71 exceeds the 64-entry traversal stack (bvh.jl:222 throws a BoundsError there)" -> the library's tree alone. */
 int trhip_scene_bvh_note(const trhip_scene* scene, char* buf, size_t n);
+/* Why a scene that holds both trees is walked WITHOUT its accelerator under the context's current options ("" when it is used, or the scene holds one tree): such frames
+ * are exact but walk the reference's tree alone, at about twice the closest-hit time.  The first such frame of a context also says so on stderr. */
+int trhip_accelerator_note(const trhip_ctx* ctx, const trhip_scene* scene, char* buf, size_t n);
 int trhip_scene_get_accelerator(const trhip_scene* scene, float* node_bounds, uint32_t* node_a, uint32_t* node_flags, uint32_t* prim_order);
 
 /* ---- sensor: PerspectiveCamera + Film + filter (camera/perspective.jl:58-80, film.jl:34-61, filter.jl) ------------- */
@@ -222,6 +225,14 @@ int trhip_last_sample_radiance(trhip_ctx* ctx, float* out_rgb, uint64_t n_floats
  * bit for bit, τ (and the image) up to the summation order of ϕ. */
 int trhip_render_sppm(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sensor* sensor, float initial_search_radius, int max_depth, uint32_t n_iterations,
                       int64_t photons_per_iteration, uint64_t seed, float* out_xyzw, trhip_stats* stats);
+/* … with the reference's periodic image (integrators/sppm.jl:166-171: `iteration % write_frequency == 0 || iteration == n_iterations` -> _sppm_to_image,
+ * set_image!, save): after every iteration k < n_iterations that write_frequency divides, `write` receives the image of the first k iterations (in out_xyzw, which the
+ * call owns until it returns: film_h * film_w * 4) and returns 0 to go on; the last iteration's image is the call's result, as above.  The batches of iterations that
+ * share traversal launches end at those iterations, so write_frequency = 1 (the reference's default) runs one iteration per batch — about 3x the time of a call without
+ * a callback.  write == NULL or write_frequency == 0: trhip_render_sppm. */
+typedef int (*trhip_sppm_write_fn)(void* user, uint32_t iteration, const float* xyzw);
+int trhip_render_sppm_ex(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sensor* sensor, float initial_search_radius, int max_depth, uint32_t n_iterations,
+                         int64_t photons_per_iteration, uint64_t seed, float* out_xyzw, trhip_stats* stats, uint32_t write_frequency, trhip_sppm_write_fn write, void* user);
 /* SPPMPixel fields (sppm.jl:65-95) after the last trhip_render_sppm on this context, (film_h, film_w[, 3]) row-major; any
  * pointer may be NULL.  M, phi, vp_p, vp_beta: the last iteration's values before _update_pixels! cleared them.
  * info6 = grid resolution x y z, grid entries, photon hits inside the grid (all iterations), photons per iteration. */

@@ -82,6 +82,8 @@ def parse_header(path: str = HEADER):
             elif ptr == 1:
                 args.append("ptr:" + {"float": "f32", "uint32_t": "u32", "uint8_t": "u8", "double": "f64", "int64_t": "i64", "uint64_t": "u64", "int": "i32", "trhip_sensor": "sensor",
                                       "trhip_stats": "stats", "char": "u8"}.get(t, "void"))
+            elif t.endswith("_fn"):
+                args.append("ptr:void")  # a function pointer typedef (trhip_sppm_write_fn): the shim passes a @cfunction as Ptr{Cvoid}
             else:
                 args.append(CT[t])
         ret = {"int": "i32", "void": "void", "const char*": "cstr"}[m.group(1)]

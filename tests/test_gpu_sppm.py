@@ -108,3 +108,25 @@ def test_sppm_rejects_offset_crop(T, ctx):
     cam.film.crop_bounds = T.Bounds2(np.float32([2, 1]), cam.film.crop_bounds.p_max)
     with pytest.raises(T.TraceHipError):
         T.SPPMIntegrator(cam, 0.05, 3, 1).render(scene, ctx)
+
+
+def test_sppm_periodic_image_is_the_image_of_the_first_k_iterations(T, ctx):
+    """integrators/sppm.jl:166-171 through trhip_render_sppm_ex: the callback fires after every iteration below the last that write_frequency divides, with
+    _sppm_to_image(i, pixels, k) — which is what a k-iteration call returns (M, radius, N, Ld bit for bit; τ up to the order of the photon atomics).  The batches of
+    iterations end at those iterations, and the call's own result is unchanged by the callback."""
+    scene, cam = T.scenes.cornell_scene(), T.scenes.cornell_camera(48)
+    seen = {}
+    integ = T.SPPMIntegrator(cam, 0.06, 5, 5, 3000, write_frequency=2, seed=11)
+    final = integ.render(scene, ctx, on_write=lambda k, img: seen.__setitem__(k, img.copy())).copy()
+    assert sorted(seen) == [2, 4], sorted(seen)
+    plain = T.SPPMIntegrator(cam, 0.06, 5, 5, 3000, seed=11).render(scene, ctx)
+    assert np.allclose(final, plain, rtol=2e-4, atol=1e-7), "the callback changed the call's result"
+    for k, img in seen.items():
+        want = T.SPPMIntegrator(cam, 0.06, 5, k, 3000, seed=11).render(scene, ctx)
+        assert np.allclose(img, want, rtol=2e-4, atol=1e-7), f"image after {k} iterations: max difference {np.abs(img - want).max()}"
+        assert not np.allclose(img, final, rtol=1e-3, atol=1e-6), "an intermediate image equal to the final one proves nothing"
+    # a callback that fails stops the call with an error, nothing propagates through the C frames
+    def boom(k, img):
+        raise RuntimeError("disk full")
+    with pytest.raises(RuntimeError, match="disk full"):
+        T.SPPMIntegrator(cam, 0.06, 5, 5, 3000, write_frequency=2, seed=11).render(scene, ctx, on_write=boom)

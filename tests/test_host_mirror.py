@@ -70,3 +70,32 @@ def test_sensor_fields_match_the_restated_film_and_camera(T, ob, res, radius, cr
     assert np.array_equal(bits(np.float32(list(sn.filter_table))), bits(table.reshape(-1)))
     assert np.array_equal(bits(np.float32(list(sn.raster_to_camera))), bits(r2c.reshape(-1)))
     assert np.array_equal(bits(np.float32(list(sn.camera_to_world))), bits(cam.camera_to_world.m.reshape(-1)))
+
+
+def test_sppm_write_frequency_call_sequence(T, monkeypatch):
+    """integrators/sppm.jl:166-171: the film is stored and saved after every iteration that write_frequency divides and after the last.  The host side of that contract,
+    without a GPU: __call__ asks render() for the intermediate images exactly when there are any to write, stores each one in the film and saves it, and saves the
+    final image once more."""
+    import numpy as np
+    cam = T.scenes.shadows_camera(8, filename="/tmp/_sppm_wf_test.png")
+    integ = T.SPPMIntegrator(cam, 0.05, 3, 7, write_frequency=3)
+    saved, asked = [], {}
+
+    def fake_render(scene, ctx=None, on_write=None):
+        asked["on_write"] = on_write
+        h, w = cam.film.size
+        if on_write is not None:
+            for k in range(1, integ.n_iterations):
+                if k % integ.write_frequency == 0:  # what trhip_render_sppm_ex does (tests/test_gpu_sppm.py checks the library side)
+                    on_write(k, np.full((h, w, 4), float(k), np.float32))
+        cam.film.set_xyzw(np.full((h, w, 4), float(integ.n_iterations), np.float32))
+        return None
+    monkeypatch.setattr(integ, "render", fake_render)
+    monkeypatch.setattr(T.api, "save", lambda film: saved.append(float(film.xyz[0, 0, 0])) or "ok")
+    assert integ(None) == "ok"
+    assert saved == [3.0, 6.0, 7.0]  # iterations 3 and 6, then the final image
+    # write_frequency >= n_iterations (or 0): nothing to write before the end — the fast path, one save
+    saved.clear()
+    integ.write_frequency = 7
+    integ(None)
+    assert asked["on_write"] is None and saved == [7.0]

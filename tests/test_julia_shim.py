@@ -17,7 +17,7 @@ def test_every_ccall_binds_a_header_prototype():
             assert jr.compatible(sig, protos[fn]), f"{fn}: ccall {sig} does not match the C prototype {protos[fn]}"
     # the entry points a scene script needs are all bound
     for need in ("trhip_init", "trhip_scene_new", "trhip_scene_add_material", "trhip_scene_add_triangles", "trhip_scene_add_sphere_fields", "trhip_scene_add_point_light",
-                 "trhip_scene_add_spot_light_fields", "trhip_scene_commit", "trhip_scene_free", "trhip_render_path", "trhip_render_whitted", "trhip_render_sppm",
+                 "trhip_scene_add_spot_light_fields", "trhip_scene_commit", "trhip_scene_free", "trhip_render_path", "trhip_render_whitted", "trhip_render_sppm_ex",
                  "trhip_comm_unique_id", "trhip_comm_init", "trhip_film_reduce", "trhip_last_error"):
         assert need in calls, need
 

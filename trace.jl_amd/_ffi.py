@@ -93,6 +93,7 @@ HIT_DTYPE = np.dtype([("t", np.float32), ("prim", np.int32), ("b1", np.float32),
 _F = C.POINTER(C.c_float)
 _U32 = C.POINTER(C.c_uint32)
 _VP = C.c_void_p
+SPPM_WRITE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.POINTER(C.c_float))  # trhip_sppm_write_fn
 
 # name -> (restype, argtypes); every symbol include/tracehip.h declares
 SIGNATURES = {
@@ -125,12 +126,14 @@ SIGNATURES = {
     "trhip_render_whitted_device": (C.c_int, [_VP, _VP, C.POINTER(Sensor), C.c_uint32, C.c_int, C.c_uint64, C.c_uint32, _VP, C.POINTER(Stats)]),
     "trhip_last_sample_radiance": (C.c_int, [_VP, _F, C.c_uint64]),
     "trhip_render_sppm": (C.c_int, [_VP, _VP, C.POINTER(Sensor), C.c_float, C.c_int, C.c_uint32, C.c_int64, C.c_uint64, _F, C.POINTER(Stats)]),
+    "trhip_render_sppm_ex": (C.c_int, [_VP, _VP, C.POINTER(Sensor), C.c_float, C.c_int, C.c_uint32, C.c_int64, C.c_uint64, _F, C.POINTER(Stats), C.c_uint32, SPPM_WRITE_FN, _VP]),
     "trhip_sppm_state": (C.c_int, [_VP, _F, _F, _F, C.POINTER(C.c_double), C.POINTER(C.c_int64), _F, _F, _F, C.POINTER(C.c_int64)]),
     "trhip_film_to_rgb": (C.c_int, [_VP, _F, C.c_uint32, C.c_uint32, C.c_float, _F]),
     "trhip_trace_closest": (C.c_int, [_VP, _VP, _F, C.c_uint64, _VP]),
     "trhip_trace_any": (C.c_int, [_VP, _VP, _F, C.c_uint64, C.POINTER(C.c_uint8)]),
     "trhip_trace_closest_device": (C.c_int, [_VP, _VP, _VP, C.c_uint64, _VP, C.c_int, C.POINTER(C.c_double)]),
     "trhip_trace_any_device": (C.c_int, [_VP, _VP, _VP, C.c_uint64, _VP, C.c_int, C.POINTER(C.c_double)]),
+    "trhip_accelerator_note": (C.c_int, [_VP, _VP, C.c_char_p, C.c_size_t]),
     "trhip_last_visit_counts": (C.c_int, [_VP, C.POINTER(C.c_uint64)]),
     "trhip_last_fallback_counts": (C.c_int, [_VP, C.POINTER(C.c_uint64)]),
     "trhip_last_bvh_build_ms": (C.c_int, [_VP, C.POINTER(C.c_double)]),

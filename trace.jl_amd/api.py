@@ -655,6 +655,12 @@ class FlatScene:
         self.ctx.check(_ffi.lib().trhip_trace_closest(self.ctx._h, self._h, _ffi.fptr(rays), rays.shape[0], out.ctypes.data_as(C.c_void_p)))
         return out
 
+    def accelerator_note(self) -> str:
+        """Why this scene's accelerator is idle under the context's current options (trhip_accelerator_note); "" when it is used."""
+        buf = C.create_string_buffer(512)
+        self.ctx.check(_ffi.lib().trhip_accelerator_note(self.ctx._h, self._h, buf, 512))
+        return buf.value.decode()
+
     def last_fallback(self):
         """(rays, rays re-walked on the canonical tree) of the last closest-hit trace call (hybrid mode: th_trace3c.h)."""
         out = np.zeros(2, np.uint64)
@@ -753,9 +759,10 @@ class PathIntegrator(_SamplerIntegrator):
 class SPPMIntegrator:  # integrators/sppm.jl:108-130
     """SPPMIntegrator(camera, initial_search_radius, max_depth, n_iterations, photons_per_iteration = -1, write_frequency = 1).
 
-    ``seed`` selects the seeded sampler stream of the camera pass (the reference draws from the global RNG there);
-    ``write_frequency`` only matters to ``__call__``, which saves the film once at the end (the intermediate images of
-    sppm.jl:166-171 are not written)."""
+    ``seed`` selects the seeded sampler stream of the camera pass (the reference draws from the global RNG there).
+    ``write_frequency`` (sppm.jl:166-171): ``__call__`` stores and saves the film after every iteration it divides and after the
+    last one, as the reference does; ``render(on_write=...)`` hands those intermediate images to a callback instead.  Note the
+    reference's default of 1: an image per iteration (the library then runs one iteration per batch, about 3x slower)."""
 
     def __init__(self, camera: PerspectiveCamera, initial_search_radius, max_depth: int, n_iterations: int, photons_per_iteration: int = -1, write_frequency: int = 1,
                  seed: int = 0x5EED0001):
@@ -770,7 +777,9 @@ class SPPMIntegrator:  # integrators/sppm.jl:108-130
         self.stats: Optional[_ffi.Stats] = None
         self._ctx = None
 
-    def render(self, scene: Scene, ctx: Optional[_ffi.Context] = None) -> np.ndarray:
+    def render(self, scene: Scene, ctx: Optional[_ffi.Context] = None, on_write=None) -> np.ndarray:
+        """The film after ``n_iterations``.  ``on_write(iteration, xyzw)``: called with the image of the first ``iteration`` iterations after every iteration
+        below the last that ``write_frequency`` divides (sppm.jl:166-171); the array is only valid during the call."""
         flat = scene.flatten(ctx)
         ctx = flat.ctx
         sn = self.camera.sensor()
@@ -778,8 +787,25 @@ class SPPMIntegrator:  # integrators/sppm.jl:108-130
         film = self.camera.film
         h, w = film.size
         out = np.empty((h, w, 4), dtype=np.float32)
-        ctx.check(_ffi.lib().trhip_render_sppm(ctx._h, flat._h, C.byref(sn), float(self.initial_search_radius), self.max_depth, self.n_iterations, self.photons_per_iteration, self.seed,
-                                               _ffi.fptr(out), C.byref(st)))
+        if on_write is not None and self.write_frequency > 0:
+            failure = []
+
+            def _cb(_user, iteration, ptr):
+                try:
+                    on_write(int(iteration), np.ctypeslib.as_array(ptr, shape=(h, w, 4)))
+                    return 0
+                except Exception as e:  # nothing may propagate through the C frames
+                    failure.append(e)
+                    return 1
+            cb = _ffi.SPPM_WRITE_FN(_cb)
+            rc = _ffi.lib().trhip_render_sppm_ex(ctx._h, flat._h, C.byref(sn), float(self.initial_search_radius), self.max_depth, self.n_iterations, self.photons_per_iteration, self.seed,
+                                                 _ffi.fptr(out), C.byref(st), self.write_frequency, cb, None)
+            if failure:
+                raise failure[0]
+            ctx.check(rc)
+        else:
+            ctx.check(_ffi.lib().trhip_render_sppm(ctx._h, flat._h, C.byref(sn), float(self.initial_search_radius), self.max_depth, self.n_iterations, self.photons_per_iteration, self.seed,
+                                                   _ffi.fptr(out), C.byref(st)))
         self.stats = st
         self._ctx = ctx
         film.set_xyzw(out)  # set_image!(film, image) film.jl:195-202
@@ -800,9 +826,15 @@ class SPPMIntegrator:  # integrators/sppm.jl:108-130
         return out
 
     def __call__(self, scene: Scene):
-        self.render(scene)
-        if self.camera.film.filename:
-            return save(self.camera.film)
+        film = self.camera.film
+
+        def periodic(iteration, xyzw):  # sppm.jl:166-171: set_image!(film, image); save(film)
+            film.set_xyzw(xyzw.copy())
+            film.splat_xyz[...] = 0
+            save(film)
+        self.render(scene, on_write=periodic if film.filename and 0 < self.write_frequency < self.n_iterations else None)
+        if film.filename:
+            return save(film)
         return None
 
 

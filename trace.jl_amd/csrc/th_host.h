@@ -84,6 +84,7 @@ struct trhip_ctx {
                          // sample's pixel range and table indices per thread; 3 = 1 x 4 from per-sample splat descriptors (k_film_descriptors): measured SLOWER
                          // (1024^2, 256 spp: 29.0 ms against 24.3 ms: the 16-byte descriptor doubles the gather's loads and the arithmetic it saves was hidden)
     bool film_relayout = true;  // packed film pass: gather from a pixel-group-major copy of the radiance records (k_film_pack_transpose) instead of the integrators' sample-major order
+    bool warned_idle_accelerator = false;  // (tu_path.hip: the one-time stderr note)
     int any_on_accelerator = -1;  // hybrid mode: any-hit rays without a zero direction component walk the library's tree (TraceOut::zero_mode): 1 always, 0 never, -1 where the
                                   // integrator asks for it (TraceOut::any_acc_hint: SPPM).  Option "any_on_accelerator"
     bool leaf_queue = false;  // hybrid mode: the certified walk queues the leaves it reaches and tests them 64 at a time with whichever lanes (th_trace3d.h, option "leaf_queue")
@@ -359,6 +360,7 @@ void launch_trace4(trhip_ctx* ctx, hipStream_t st, const trhip_scene* sc, bool a
                    const TraceOut& out, uint32_t* work_cursors, uint2* ov, Counters* ctr);
 // tu_trace3c.hip: the hybrid mode's certified walks on the accelerator tree (th_trace3c.h)
 bool hybrid_active(const trhip_ctx* ctx, const trhip_scene* sc);
+const char* hybrid_idle_reason(const trhip_ctx* ctx, const trhip_scene* sc);
 WideScene wide_view_acc(const trhip_ctx* ctx, const trhip_scene* sc);
 void launch_trace3c(trhip_ctx* ctx, hipStream_t st, const trhip_scene* sc, bool cnt, bool full_only, bool big, const SegQueue& q, const float4* ro, const float4* rd, const float* tmax,
                     const TraceOut& out, uint32_t* work_cursors, uint2* ov, Counters* ctr, const FallbackList& fb);

@@ -366,6 +366,13 @@ int render_impl_band(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
     if (scene->has_materialless_prim)  // found once, at commit: walking a million host records here cost 2.8 ms of every frame
             return fail(ctx, TRHIP_ERR_UNSUPPORTED, "rendering a scene with a material-less primitive is not supported (the trace entry points accept it)");
     if (spp == 0 || max_depth < 1 || max_depth > kMaxDepth) return fail(ctx, TRHIP_ERR_INVALID, "spp must be >= 1 and max_depth in 1..%d", kMaxDepth);
+    if (!ctx->warned_idle_accelerator && ctx->hybrid) {  // a two-tree scene rendered with options that leave its accelerator idle: said once per context (trhip_accelerator_note has it too)
+        const char* why = hybrid_idle_reason(ctx, scene);
+        if (why[0]) {
+            ctx->warned_idle_accelerator = true;
+            std::fprintf(stderr, "[tracehip] this scene holds the reference's tree and an accelerator, but the accelerator is idle: %s\n", why);
+        }
+    }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     DeviceSensor ds;
     if (band)

@@ -6,7 +6,7 @@ namespace {
 // SPPMIntegrator (integrators/sppm.jl:132-173): n_iterations x {camera pass, grid, photon pass, pixel update}, then
 // _sppm_to_image + set_image!.  Everything runs on one stream; queue sizes stay in HBM, the host only enqueues.
 int render_sppm_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sensor* sensor, float initial_radius, int max_depth, uint32_t n_iterations, int64_t photons_per_iteration,
-                     uint64_t seed, float* out_xyzw, trhip_stats* stats) {
+                     uint64_t seed, float* out_xyzw, trhip_stats* stats, uint32_t write_frequency, trhip_sppm_write_fn write_cb, void* write_user) {
     if (!ctx || !scene || !sensor || !out_xyzw) return fail(ctx, TRHIP_ERR_INVALID, "null argument");
     if (!scene->committed) return fail(ctx, TRHIP_ERR_INVALID, "scene not committed");
     if (n_iterations == 0 || max_depth < 1 || max_depth > kMaxDepth) return fail(ctx, TRHIP_ERR_INVALID, "n_iterations must be >= 1 and max_depth in 1..%d", kMaxDepth);
@@ -162,11 +162,19 @@ int render_sppm_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
     const uint32_t p_lo = (uint32_t)((uint64_t)P * my_rank / n_ranks), p_hi = (uint32_t)((uint64_t)P * (my_rank + 1) / n_ranks);
     uint32_t n_batches = 0;
     // ray totals after every batch's camera pass and photon pass: what of closest_rays + shadow_rays every rank of a multi-GPU job repeats
-    const uint32_t max_batches = (uint32_t)((n_iterations + B - 1) / B);
+    const uint32_t max_batches = (uint32_t)((n_iterations + B - 1) / B) + (write_cb && write_frequency ? n_iterations / write_frequency + 1u : 0u);  // (a write iteration ends its batch)
     if (int rc = ensure(ctx, ctx->sp_raysnap, (size_t)max_batches * 4 * sizeof(unsigned long long))) return rc;
     unsigned long long* raysnap = (unsigned long long*)ctx->sp_raysnap.p;
-    for (uint32_t it0 = 1; it0 <= n_iterations; it0 += (uint32_t)B) {
-        const uint32_t nb = (uint32_t)std::min<uint64_t>(B, n_iterations - it0 + 1);
+    // sppm.jl:166-171 stores and saves the image whenever `iteration % write_frequency == 0`: with a write callback no batch runs past such an iteration (the image of
+    // iteration k is built from the pixels as they are after k iterations — Ld is folded per batch), and the host gets the image there
+    const bool periodic = write_cb != nullptr && write_frequency > 0;
+    uint32_t nb = 0;
+    for (uint32_t it0 = 1; it0 <= n_iterations; it0 += nb) {
+        nb = (uint32_t)std::min<uint64_t>(B, n_iterations - it0 + 1);
+        if (periodic) {
+            const uint32_t next_write = (uint32_t)std::min<uint64_t>(n_iterations, ((uint64_t)(it0 + write_frequency - 1) / write_frequency) * write_frequency);
+            nb = std::min(nb, next_write - it0 + 1);
+        }
         n_batches++;
         // ---- camera pass of iterations it0 .. it0 + nb - 1 (:175-270) ----
         for (auto& b : ctx->sp_vp) HIP_TRY(ctx, hipMemsetAsync(b.p, 0, (size_t)nb * n * sizeof(float4), st));  // vp.β = 0: no visible point
@@ -264,6 +272,15 @@ int render_sppm_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
             hipLaunchKernelGGL(k_sppm_update, g_pix, blk, 0, st, n, gamma, px, vp);
             tm.end(7, st);
         }
+        const uint32_t it_done = it0 + nb - 1;
+        if (periodic && it_done < n_iterations && it_done % write_frequency == 0) {  // (the last iteration's image is the call's result: the caller stores that one)
+            tm.begin(4, st);
+            hipLaunchKernelGGL(k_sppm_image, g_pix, blk, 0, st, n, it_done, (uint64_t)P, px, (float4*)ctx->film.p);  // _sppm_to_image(i, pixels, iteration)
+            tm.end(4, st);
+            HIP_TRY(ctx, hipStreamSynchronize(st));
+            HIP_TRY(ctx, hipMemcpy(out_xyzw, ctx->film.p, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost));
+            if (int rc = write_cb(write_user, it_done, out_xyzw)) return fail(ctx, TRHIP_ERR_INVALID, "the SPPM write callback returned %d at iteration %u", rc, it_done);
+        }
     }
     tm.begin(4, st);
     hipLaunchKernelGGL(k_sppm_image, g_pix, blk, 0, st, n, n_iterations, (uint64_t)P, px, (float4*)ctx->film.p);
@@ -329,9 +346,13 @@ int render_sppm_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
 
 extern "C" {
 
+int trhip_render_sppm_ex(trhip_ctx* ctx, const trhip_scene* sc, const trhip_sensor* sn, float initial_search_radius, int max_depth, uint32_t n_iterations, int64_t photons_per_iteration,
+                         uint64_t seed, float* out_xyzw, trhip_stats* st, uint32_t write_frequency, trhip_sppm_write_fn write_cb, void* user) {
+    return render_sppm_impl(ctx, sc, sn, initial_search_radius, max_depth, n_iterations, photons_per_iteration, seed, out_xyzw, st, write_frequency, write_cb, user);
+}
 int trhip_render_sppm(trhip_ctx* ctx, const trhip_scene* sc, const trhip_sensor* sn, float initial_search_radius, int max_depth, uint32_t n_iterations, int64_t photons_per_iteration,
                       uint64_t seed, float* out_xyzw, trhip_stats* st) {
-    return render_sppm_impl(ctx, sc, sn, initial_search_radius, max_depth, n_iterations, photons_per_iteration, seed, out_xyzw, st);
+    return render_sppm_impl(ctx, sc, sn, initial_search_radius, max_depth, n_iterations, photons_per_iteration, seed, out_xyzw, st, 0u, nullptr, nullptr);
 }
 int trhip_sppm_state(trhip_ctx* ctx, float* Ld3, float* tau3, float* radius, double* N, int64_t* M, float* phi3, float* vp_p3, float* vp_beta3, int64_t* info6) {
     if (!ctx) return TRHIP_ERR_INVALID;

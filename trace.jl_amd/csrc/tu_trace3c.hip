@@ -10,6 +10,23 @@ bool hybrid_active(const trhip_ctx* ctx, const trhip_scene* sc) {
     return sc->hybrid_ok && ctx->hybrid && ctx->traversal == 3 && ctx->slab_margin_log2 > 0 && ctx->pipelines <= 1 && ctx->debug_trace_budget == 0 && sc->wide_ok;
 }
 
+// Why a scene that holds both trees is NOT walked through its accelerator under the context's current options ("" when it is, or when the scene holds one tree): those
+// launches walk the reference's tree alone — exact, at about twice the closest-hit time.  trhip_accelerator_note; a frame says it once on stderr (tu_path.hip).
+const char* hybrid_idle_reason(const trhip_ctx* ctx, const trhip_scene* sc) {
+    if (!sc->hybrid_ok || !sc->wide_ok) return "";
+    if (!ctx->hybrid) return "option hybrid = 0: every ray walks the canonical tree";
+    if (ctx->traversal != 3) return "option traversal != 3: only the default traversal walks the accelerator, the A/B kernels walk the canonical tree (pair them with bvh_builder = 0 for the library's tree)";
+    if (ctx->slab_margin_log2 <= 0) return "option slab_margin_log2 = 0: the certificate's margins derive from the tight slab clauses";
+    if (ctx->pipelines > 1) return "option pipelines > 1: the certified walk runs with one pipeline";
+    if (ctx->debug_trace_budget != 0) return "option debug_trace_budget: diagnostic walks use the canonical tree";
+    return "";
+}
+extern "C" __attribute__((visibility("default"))) int trhip_accelerator_note(const trhip_ctx* ctx, const trhip_scene* sc, char* buf, size_t n) {
+    if (!ctx || !sc || !buf || !n) return TRHIP_ERR_INVALID;
+    std::snprintf(buf, n, "%s", hybrid_idle_reason(ctx, sc));
+    return 0;
+}
+
 WideScene wide_view_acc(const trhip_ctx* ctx, const trhip_scene* sc) {
     WideScene w = sc->wide_acc;
     w.tight_scale = std::ldexp(1.0f, -ctx->slab_margin_log2);

@@ -395,6 +395,20 @@ end
 
 # SPPMIntegrator (integrators/sppm.jl:132-173) on the device: trhip_render_sppm returns the film after set_image!
 # (film.jl:195-202).  `seed` selects the seeded stream of the camera pass (the reference draws from the global RNG there).
+# The reference's periodic image (sppm.jl:166-171: every iteration that write_frequency divides is stored in the film and saved): the library calls back with the
+# image of the first k iterations; the last iteration's image is the call's result.
+mutable struct SppmWriteCtx  # (mutable: pointer_from_objref needs an object with an address)
+    film::Trace.Film
+    h::Int
+    w::Int
+end
+function sppm_write_cb(user::Ptr{Cvoid}, iteration::UInt32, xyzw::Ptr{Float32})::Cint
+    c = unsafe_pointer_to_objref(user)::SppmWriteCtx
+    JOB[][1] == 0 || return Cint(0)
+    write_film!(c.film, unsafe_wrap(Array, xyzw, 4 * c.h * c.w), c.h, c.w; clear_splat = true)
+    Trace.save(c.film)
+    Cint(0)
+end
 function render_sppm!(i::Trace.SPPMIntegrator, scene::Trace.Scene; seed::Integer = 0x5EED0001)
     film = Trace.get_film(i.camera)
     s = flatten(scene)
@@ -402,9 +416,13 @@ function render_sppm!(i::Trace.SPPMIntegrator, scene::Trace.Scene; seed::Integer
     h, w = size(film.pixels)
     out = Vector{Float32}(undef, 4 * h * w)
     stats = TrhipStats()
-    rc = ccall((:trhip_render_sppm, LIB), Cint,
-        (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{TrhipSensor}, Cfloat, Cint, UInt32, Int64, UInt64, Ptr{Float32}, Ptr{TrhipStats}),
-        context(), s, sn, i.initial_search_radius, i.max_depth, i.n_iterations, i.photons_per_iteration, UInt64(seed), out, Ref(stats))
+    wf = UInt32(max(0, i.write_frequency))
+    user = SppmWriteCtx(film, Int(h), Int(w))
+    cb = @cfunction(sppm_write_cb, Cint, (Ptr{Cvoid}, UInt32, Ptr{Float32}))
+    rc = GC.@preserve user ccall((:trhip_render_sppm_ex, LIB), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{TrhipSensor}, Cfloat, Cint, UInt32, Int64, UInt64, Ptr{Float32}, Ptr{TrhipStats}, UInt32, Ptr{Cvoid}, Ptr{Cvoid}),
+        context(), s, sn, i.initial_search_radius, i.max_depth, i.n_iterations, i.photons_per_iteration, UInt64(seed), out, Ref(stats),
+        wf < i.n_iterations ? wf : UInt32(0), cb, pointer_from_objref(user))
     ccall((:trhip_scene_free, LIB), Cvoid, (Ptr{Cvoid},), s)
     check(rc)
     JOB[][1] == 0 || return nothing                 # with a communicator every rank holds the whole image; rank 0 writes it
