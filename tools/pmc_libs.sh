@@ -8,8 +8,8 @@ run() {
   if [ -n "$2" ]; then export TRHIP_LIB=$ROOT/$2; else unset TRHIP_LIB; fi
   D=$O/pmc_${TAG}_$1; mkdir -p $D
   rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d $D/pmc_sq -- python3 $ROOT/tools/option_sweep.py --workload $W --spp $S --repeat 1 > $D/log_sq.txt 2>&1
-  rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA --output-format csv -d $D/pmc_wait -- python3 $ROOT/tools/option_sweep.py --workload $W --spp $S --repeat 1 > $D/log_wait.txt 2>&1
-  echo "== $1"; python3 $ROOT/tools/summarize_pmc.py $D | grep -E "k_trace3c<false|k_trace3<false" | cut -c1-400
+  rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_ACTIVE_INST_ANY SQ_INSTS_FLAT SQ_ACTIVE_INST_SCA --output-format csv -d $D/pmc_wait -- python3 $ROOT/tools/option_sweep.py --workload $W --spp $S --repeat 1 > $D/log_wait.txt 2>&1
+  echo "== $1"; python3 $ROOT/tools/summarize_pmc.py $D | grep -E "${PMC_PAT:-k_trace3c<false|k_trace3<false}" | cut -c1-600
   rm -rf $D/pmc_sq $D/pmc_wait
 }
 run intree ""

@@ -91,6 +91,15 @@ TH_D void seg_locate(const SegView& v, uint32_t flat_base, uint32_t& seg, uint32
     seg = s;
     local_base = flat_base - v.prefix[s];
 }
+// … for a grid-stride loop, whose flat_base only grows: `seg` carries over from the iteration before (start it at 0), so the search is a step or two — and it is NOT unrolled:
+// unrolled, the compiler hoists all kSeg prefix sums out of the caller's loop into 32 VGPRs (k_shade_path's FAST part: 119 -> 84 registers without them).
+TH_D void seg_locate_from(const SegView& v, uint32_t flat_base, uint32_t& seg, uint32_t& local_base) {
+    uint32_t s = seg;
+#pragma unroll 1
+    while (s + 1 < (uint32_t)kSeg && flat_base >= v.prefix[s + 1]) ++s;
+    seg = s;
+    local_base = flat_base - v.prefix[s];
+}
 TH_D uint32_t seg_phys(const SegQueue& q, uint32_t seg, uint32_t local) { return q.counts ? seg * q.cap + local : local; }
 
 TH_D uint32_t lane_id() { return __lane_id(); }
@@ -378,9 +387,10 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest(DeviceScene sc, SegQue
     seg_load(q, sv);
     const uint32_t total = sv.prefix[kSeg];
     uint32_t nn = 0, np = 0;
+    uint32_t seg = 0;  // (carried over the iterations: seg_locate_from)
     for (uint32_t flat = blockIdx.x * kBlock + threadIdx.x; flat < total; flat += gridDim.x * kBlock) {
-        uint32_t seg, lb;
-        seg_locate(sv, flat & ~63u, seg, lb);
+        uint32_t lb;
+        seg_locate_from(sv, flat & ~63u, seg, lb);
         const uint32_t local = lb + (flat & 63u);
         if (local >= sv.count[seg]) continue;
         const uint32_t i = seg_phys(q, seg, local);
@@ -414,9 +424,10 @@ __global__ __launch_bounds__(kBlock) void k_trace_any(DeviceScene sc, SegQueue q
     seg_load(q, sv);
     const uint32_t total = sv.prefix[kSeg];
     uint32_t nn = 0, np = 0;
+    uint32_t seg = 0;  // (carried over the iterations: seg_locate_from)
     for (uint32_t flat = blockIdx.x * kBlock + threadIdx.x; flat < total; flat += gridDim.x * kBlock) {
-        uint32_t seg, lb;
-        seg_locate(sv, flat & ~63u, seg, lb);
+        uint32_t lb;
+        seg_locate_from(sv, flat & ~63u, seg, lb);
         const uint32_t local = lb + (flat & 63u);
         if (local >= sv.count[seg]) continue;
         const uint32_t i = seg_phys(q, seg, local);
@@ -658,6 +669,8 @@ TH_D void shade_vertex(const DeviceScene& sc, const PathQueue& qin, const float4
 // (Two launches instead — the FAST entries, then the others from an index list in HBM, each with a register allocation of its
 // own — were measured: S-mesh frame 405 -> 415 ms, S-cornell 162 -> 173 ms; the list traffic and the second launch's tail cost
 // more than the 144 bytes of scratch the FAST code gets rid of.)
+// (Round 5 built the two-launch form again — the matte entries alone, restructured to 88 VGPRs without scratch at 5 waves per SIMD, then the rest from index lists: 2 ms per
+// 64 spp SLOWER on S-mesh and S-cornell at 4, 5 and 6 waves alike; the matte path is bound neither by occupancy nor by scratch: profiles/r5/r5_shade_split_experiment.txt.)
 template <bool STREAM, bool TAN = true>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TH_SHADE_WAVES))) void k_shade_path(DeviceScene sc, const DeviceSensor* __restrict__ sep, PathQueue qin, PathQueue qout, ShadowQueue sq, uint32_t cap,
                                                        const float4* __restrict__ hits, float4* __restrict__ L, Counters* ctr, int row, int depth_fixed, int max_depth, uint32_t hits_have_bary,
@@ -689,9 +702,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TH_SHADE
             if (STREAM) ss.tags_out[ni] = e.next_depth;
         }
     };
+    uint32_t seg_in = 0;
     for (uint32_t flat = blockIdx.x * kBlock + threadIdx.x; flat < total; flat += gridDim.x * kBlock) {
-        uint32_t seg_in, lb;
-        seg_locate(sv, flat & ~63u, seg_in, lb);
+        uint32_t lb;
+        seg_locate_from(sv, flat & ~63u, seg_in, lb);
         const uint32_t local = lb + (flat & 63u);
         const uint32_t i = seg_in * cap + local;
         int cls = 0;  // 0: nothing to shade (padding, miss, suspended ray), 1: FAST, 2: general

@@ -186,9 +186,10 @@ static __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(T
     const SegQueue qv{ctr->n_queue[depth - 1], cap, 0u};
     seg_load(qv, sv);
     const uint32_t total = sv.prefix[kSeg];
+    uint32_t seg_in = 0;  // (carried over the iterations: seg_locate_from)
     for (uint32_t flat = blockIdx.x * kBlock + threadIdx.x; flat < total; flat += gridDim.x * kBlock) {
-        uint32_t seg_in, lb;
-        seg_locate(sv, flat & ~63u, seg_in, lb);
+        uint32_t lb;
+        seg_locate_from(sv, flat & ~63u, seg_in, lb);
         const uint32_t local = lb + (flat & 63u);
         const bool valid = local < sv.count[seg_in];
         const uint32_t i = seg_in * cap + local;
@@ -640,9 +641,10 @@ static __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(T
             qout.beta[ni] = nb4;
         }
     };
+    uint32_t seg_in = 0;  // (carried over the iterations: seg_locate_from)
     for (uint32_t flat = blockIdx.x * kBlock + threadIdx.x; flat < total; flat += gridDim.x * kBlock) {
-        uint32_t seg_in, lb;
-        seg_locate(sv, flat & ~63u, seg_in, lb);
+        uint32_t lb;
+        seg_locate_from(sv, flat & ~63u, seg_in, lb);
         const uint32_t local = lb + (flat & 63u);
         const uint32_t i = seg_in * cap + local;
         int cls = -1;  // -1: nothing to do (padding, miss)

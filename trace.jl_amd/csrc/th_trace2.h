@@ -523,9 +523,10 @@ __global__ __launch_bounds__(kBlock, FULL_ONLY ? TH_TRACE_LEAF_WAVES : 4) void k
     const uint32_t total = sv.prefix[kSeg];
     const uint32_t first = ws.root_ref, cnt = ws.root_cnt;
     uint32_t nn = 0, np = 0;
+    uint32_t seg = 0;  // (carried over the iterations: seg_locate_from)
     for (uint32_t flat = blockIdx.x * kBlock + threadIdx.x; flat < total; flat += gridDim.x * kBlock) {
-        uint32_t seg, lb;
-        seg_locate(sv, flat & ~63u, seg, lb);
+        uint32_t lb;
+        seg_locate_from(sv, flat & ~63u, seg, lb);
         const uint32_t local = lb + (flat & 63u);
         const bool valid = local < sv.count[seg];
         const uint32_t idx = valid ? seg_phys(q, seg, local) : 0u;
@@ -728,9 +729,10 @@ __global__ __launch_bounds__(kBlock, FULL_ONLY ? TH_TRACE_LEAF_WAVES : 4) void k
         const bool found = run(idx, mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z), n_a, cnt, live);
         deliver(on, idx, o4, d4, found);
     };
+    uint32_t seg = 0;  // (carried over the iterations: seg_locate_from)
     for (uint32_t flat = blockIdx.x * kBlock + threadIdx.x; flat < total; flat += gridDim.x * kBlock) {
-        uint32_t seg, lb;
-        seg_locate(sv, flat & ~63u, seg, lb);
+        uint32_t lb;
+        seg_locate_from(sv, flat & ~63u, seg, lb);
         const uint32_t local = lb + (flat & 63u);
         const bool valid = local < sv.count[seg];
         const uint32_t idx = valid ? seg_phys(q, seg, local) : 0u;
@@ -880,9 +882,10 @@ __global__ __launch_bounds__(kBlock, 5) void k_any_occluders(DeviceScene sc, Occ
         const bool found = run(on, idx, o4, d4, n_a, oc.n, live);
         survivors(on && !found, idx);
     };
+    uint32_t seg = 0;  // (carried over the iterations: seg_locate_from)
     for (uint32_t flat = blockIdx.x * kBlock + threadIdx.x; flat < total; flat += gridDim.x * kBlock) {
-        uint32_t seg, lb;
-        seg_locate(sv, flat & ~63u, seg, lb);
+        uint32_t lb;
+        seg_locate_from(sv, flat & ~63u, seg, lb);
         const uint32_t local = lb + (flat & 63u);
         const bool valid = local < sv.count[seg];
         const uint32_t idx = valid ? seg_phys(q, seg, local) : 0u;

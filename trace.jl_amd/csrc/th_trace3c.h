@@ -762,9 +762,10 @@ __global__ __launch_bounds__(kBlock, FULL_ONLY ? TH_TRACE_LEAF_C_WAVES : 4) void
     const uint32_t gtid = blockIdx.x * kBlock + threadIdx.x;
     uint32_t nn = 0, np = 0;
     unsigned long long n_fb = 0;
+    uint32_t seg = 0;  // (carried over the iterations: seg_locate_from)
     for (uint32_t flat = gtid; flat < total; flat += gridDim.x * kBlock) {
-        uint32_t seg, lb;
-        seg_locate(sv, flat & ~63u, seg, lb);
+        uint32_t lb;
+        seg_locate_from(sv, flat & ~63u, seg, lb);
         const uint32_t local = lb + (flat & 63u);
         const bool valid = local < sv.count[seg];
         uint32_t idx = valid ? seg_phys(q, seg, local) : 0u;
@@ -1041,9 +1042,10 @@ __global__ __launch_bounds__(kBlock, FULL_ONLY ? TH_TRACE_LEAF_WAVES : 4) void k
         const bool found = run(idx, mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z), n_a, cnt, live);
         deliver(on, idx, o4, d4, found);
     };
+    uint32_t seg = 0;  // (carried over the iterations: seg_locate_from)
     for (uint32_t flat = gtid; flat < total; flat += gridDim.x * kBlock) {
-        uint32_t seg, lb;
-        seg_locate(sv, flat & ~63u, seg, lb);
+        uint32_t lb;
+        seg_locate_from(sv, flat & ~63u, seg, lb);
         const uint32_t local = lb + (flat & 63u);
         const bool valid = local < sv.count[seg];
         uint32_t idx = valid ? seg_phys(q, seg, local) : 0u;

@@ -30,9 +30,10 @@ static __global__ __launch_bounds__(kBlock) void k_shade_whitted(DeviceScene sc,
     const SegQueue qv{ctr->n_queue[depth - 1], cap, 0u};
     seg_load(qv, sv);
     const uint32_t total = sv.prefix[kSeg];
+    uint32_t seg_in = 0;  // (carried over the iterations: seg_locate_from)
     for (uint32_t flat = blockIdx.x * kBlock + threadIdx.x; flat < total; flat += gridDim.x * kBlock) {
-        uint32_t seg_in, lb;
-        seg_locate(sv, flat & ~63u, seg_in, lb);
+        uint32_t lb;
+        seg_locate_from(sv, flat & ~63u, seg_in, lb);
         const uint32_t local = lb + (flat & 63u);
         const bool valid = local < sv.count[seg_in];
         const uint32_t i = seg_in * cap + local;
@@ -131,9 +132,10 @@ static __global__ __launch_bounds__(kBlock) void k_whitted_direct(SegQueue q, Sh
     __shared__ SegView sv;
     seg_load(q, sv);
     const uint32_t total = sv.prefix[kSeg];
+    uint32_t seg = 0;  // (carried over the iterations: seg_locate_from)
     for (uint32_t flat = blockIdx.x * kBlock + threadIdx.x; flat < total; flat += gridDim.x * kBlock) {
-        uint32_t seg, lb;
-        seg_locate(sv, flat & ~63u, seg, lb);
+        uint32_t lb;
+        seg_locate_from(sv, flat & ~63u, seg, lb);
         const uint32_t local = lb + (flat & 63u);
         if (local >= sv.count[seg]) continue;
         const uint32_t i = seg * q.cap + local;
@@ -152,9 +154,10 @@ static __global__ __launch_bounds__(kBlock) void k_whitted_resolve(SegQueue q, W
     __shared__ SegView sv;
     seg_load(q, sv);
     const uint32_t total = sv.prefix[kSeg];
+    uint32_t seg = 0;  // (carried over the iterations: seg_locate_from)
     for (uint32_t flat = blockIdx.x * kBlock + threadIdx.x; flat < total; flat += gridDim.x * kBlock) {
-        uint32_t seg, lb;
-        seg_locate(sv, flat & ~63u, seg, lb);
+        uint32_t lb;
+        seg_locate_from(sv, flat & ~63u, seg, lb);
         const uint32_t local = lb + (flat & 63u);
         if (local >= sv.count[seg]) continue;
         const uint32_t node = base + seg * q.cap + local;
@@ -175,9 +178,10 @@ static __global__ __launch_bounds__(kBlock) void k_whitted_finish(SegQueue q, co
     __shared__ SegView sv;
     seg_load(q, sv);
     const uint32_t total = sv.prefix[kSeg];
+    uint32_t seg = 0;  // (carried over the iterations: seg_locate_from)
     for (uint32_t flat = blockIdx.x * kBlock + threadIdx.x; flat < total; flat += gridDim.x * kBlock) {
-        uint32_t seg, lb;
-        seg_locate(sv, flat & ~63u, seg, lb);
+        uint32_t lb;
+        seg_locate_from(sv, flat & ~63u, seg, lb);
         const uint32_t local = lb + (flat & 63u);
         if (local >= sv.count[seg]) continue;
         const uint32_t i = seg * q.cap + local;

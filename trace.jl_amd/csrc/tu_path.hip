@@ -556,12 +556,12 @@ int render_impl_band(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
             tm.end(1, ps);
             if (two && depth > 2) HIP_TRY(ctx, hipStreamWaitEvent(ps, ev_anys[depth & 1], 0));  // shade(d) refills the queue the shadow rays of depth d - 2 read
             tm.begin(2, ps);
-            if (scene->dev.tri_tan)
-                hipLaunchKernelGGL(k_shade_path<false>, dim3(g_shade), dim3(kBlock), 0, ps, scene->dev, dsp, pq[cur], pq[cur ^ 1], sq, cap, hits, L, ctr, depth - 1, depth, max_depth, bary_mode,
-                               ShadeStream{nullptr, nullptr, 0u, two ? (uint8_t*)ctx->poison.p : nullptr});
-            else
-                hipLaunchKernelGGL((k_shade_path<false, false>), dim3(g_shade), dim3(kBlock), 0, ps, scene->dev, dsp, pq[cur], pq[cur ^ 1], sq, cap, hits, L, ctr, depth - 1, depth, max_depth, bary_mode,
-                               ShadeStream{nullptr, nullptr, 0u, two ? (uint8_t*)ctx->poison.p : nullptr});
+            const ShadeStream sst{nullptr, nullptr, 0u, two ? (uint8_t*)ctx->poison.p : nullptr};
+            if (scene->dev.tri_tan) {
+                hipLaunchKernelGGL(k_shade_path<false>, dim3(g_shade), dim3(kBlock), 0, ps, scene->dev, dsp, pq[cur], pq[cur ^ 1], sq, cap, hits, L, ctr, depth - 1, depth, max_depth, bary_mode, sst);
+            } else {
+                hipLaunchKernelGGL((k_shade_path<false, false>), dim3(g_shade), dim3(kBlock), 0, ps, scene->dev, dsp, pq[cur], pq[cur ^ 1], sq, cap, hits, L, ctr, depth - 1, depth, max_depth, bary_mode, sst);
+            }
             tm.end(2, ps);
             if (two) {
                 HIP_TRY(ctx, hipEventRecord(pp.ev_shade, ps));
