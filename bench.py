@@ -361,6 +361,31 @@ def require_communicator(T, ctx, rank, world, device):
     return True
 
 
+def hbm_resident_record(args):
+    """The roofline statement on the one workload where HBM is real: the 10.5 M-triangle scene — ~1.2 GB of nodes and primitives, far beyond L2 + the
+    256 MiB MALL — rendered by a CHILD run of this script (2 steps, its own PMC passes), after this process has released the GPU.  Returns the child's roofline figures
+    (request rate and counter rate against the HBM peak, lanes per VALU instruction, VALU busy) or {"error": ...}."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--workload", "mesh_10m", "--steps", "2", "--warmup", "1", "--res", str(args.res), "--spp", str(args.spp), "--depth", str(args.depth),
+           "--seed", str(args.seed), "--no-cpu-baseline", "--no-micro", "--no-modes", "--no-hbm-resident"] + [a for kv in args.opt for a in ("--opt", kv)]
+    t0 = time.perf_counter()
+    try:
+        res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+        line = [l for l in res.stdout.decode(errors="replace").splitlines() if l.startswith("{\"metric\"")]
+        if res.returncode != 0 or not line:
+            return {"error": f"child run rc {res.returncode}: " + res.stderr.decode(errors="replace")[-400:]}
+        d = json.loads(line[-1])
+        r = d.get("roofline") or {}
+        return {"workload": d["config"]["workload"], "why": "nodes + primitives exceed L2 + MALL: the request rate and the counter rate are both HBM figures here",
+                "value_Mray_s": d["value"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "bvh": d["config"].get("bvh"), "bvh_note": d["config"].get("bvh_note"),
+                "kernel": r.get("kernel"), "avg_launch_ms": r.get("avg_launch_ms"), "scene_bytes": r.get("scene_bytes"), "scene_fits_l2_plus_mall": r.get("scene_fits_l2_plus_mall"),
+                "frac_requests": r.get("frac_requests"), "frac_counters": r.get("frac_counters"), "achieved_requests_GBps": round((r.get("frac_requests") or 0.0) * HBM_PEAK_GBS, 1),
+                "achieved_counters_GBps": r.get("achieved_counters"), "valu": r.get("valu"), "valu_frac": r.get("valu_frac"), "bound": r.get("bound"),
+                "kernel_ms_per_step": r.get("kernel_ms_per_step"), "child_run_s": round(time.perf_counter() - t0, 1)}
+    except Exception as e:
+        return {"error": f"{type(e).__name__}: {str(e)[-300:]}"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -382,6 +407,7 @@ def main():
     ap.add_argument("--iterations", type=int, default=100, help="caustic_sppm: SPPM iterations per step")
     ap.add_argument("--radius", type=float, default=0.075, help="caustic_sppm: initial search radius")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="library option (trhip_set_option) set before the scene is committed; repeatable")
+    ap.add_argument("--no-hbm-resident", action="store_true", help="skip the short child run on the 10.5 M-triangle scene (`hbm_resident`: the one workload whose nodes + primitives exceed L2 + MALL)")
     ap.add_argument("--no-modes", action="store_true", help="skip the two short comparison runs on the library's tree alone and on the reference's tree alone (`bvh_modes`)")
     args = ap.parse_args()
 
@@ -641,6 +667,10 @@ def main():
                 roofline["frac_counters"] = round(roofline["achieved_counters"] / HBM_PEAK_GBS, 5)
             if valu:
                 roofline["valu"] = valu
+                if valu.get("valu_busy") is not None:
+                    # the share of the SIMDs' lane-cycles that did arithmetic: VALU busy x active lanes / 64 — what bounds a kernel whose HBM-side fraction says nothing
+                    # (a scene that lives in L2 + MALL): 1.0 = every lane of every SIMD issuing every cycle
+                    roofline["valu_frac"] = round(valu["valu_busy"] * valu["lanes_per_valu_inst"] / 64.0, 4)
             roofline["bound"] = classify_bound(roofline)
         if roofline:
             # which fraction the line leads with: a scene that fits L2 + MALL is not served from HBM, so its request rate is no HBM fraction — the counter figure is
@@ -684,6 +714,8 @@ def main():
             result["bvh_modes"] = modes
         if micro:
             result["traversal_micro"] = micro
+        if world == 1 and args.workload == "mesh_1m" and roofline and not args.no_hbm_resident and not args.no_traffic:
+            result["hbm_resident"] = hbm_resident_record(args)
         if other:
             result[other["scaling"] + "_scaling"] = other
         print(json.dumps(result), flush=True)

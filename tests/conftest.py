@@ -33,3 +33,31 @@ def ob(T):
 def ctx(T):
     """GPU context; fails loudly (no CPU fallback) when the extension cannot see an MI355X."""
     return T.default_context()
+
+
+EXPERIMENTS_NOTE = "needs the EXPERIMENTS build"
+
+
+def supported(ctx, name, values):
+    """The values of an option this build of the library honours (tests that sweep kernel variants sweep what exists).  Leaves the option at the last supported value."""
+    return [v for v in values if ctx.has_option(name, v)]
+
+
+@pytest.hookimpl(hookwrapper=True)
+def pytest_runtest_setup(item):
+    outcome = yield
+    _skip_if_experiments_only(outcome)
+
+
+@pytest.hookimpl(hookwrapper=True)
+def pytest_runtest_call(item):
+    outcome = yield
+    _skip_if_experiments_only(outcome)
+
+
+def _skip_if_experiments_only(outcome):
+    """A test (or fixture) that asks for a kernel family the default library does not carry is SKIPPED, not failed: run it against the EXPERIMENTS build
+    (TRHIP_LIB=trace.jl_amd/libtracehip_experiments.so python -m pytest tests -m gpu)."""
+    exc = outcome.excinfo
+    if exc is not None and EXPERIMENTS_NOTE in str(exc[1]):
+        outcome.force_exception(pytest.skip.Exception(str(exc[1])[-160:], _use_item_location=True))

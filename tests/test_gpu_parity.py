@@ -375,7 +375,8 @@ def test_partial_spheres_and_transforms(T, ob, ctx):
         osc2 = ob.OracleScene.from_scene(scene2, bvh=flat2.bvh())
         t2, prim2, _, _ = osc2.trace_closest(rays)
         occ2, _ = osc2.trace_any(rays)
-        for trav in (7, 6, 4, 3, 2, 1):
+        from conftest import supported
+        for trav in supported(ctx, "traversal", (7, 6, 4, 3, 2, 1)):
             ctx.set_option("traversal", trav)
             h2 = flat2.trace_closest(rays)
             assert np.array_equal(h2["prim"], prim2), trav

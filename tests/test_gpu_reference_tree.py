@@ -65,7 +65,8 @@ def test_commit_builds_the_reference_tree_and_every_kernel_agrees_with_the_oracl
         rays = np.concatenate([ob.generate_rays(cam, T.scenes.camera_sample_grid(cam, 1, seed=3)), T.scenes.incoherent_rays(30000, lo, hi, seed=17)])
         t_ref, prim_ref, bary_ref, _ = osc.trace_closest(rays)
         occ_ref, _ = osc.trace_any(rays)
-        for trav in (3, 7, 2, 6, 1):
+        from conftest import supported
+        for trav in supported(ctx, "traversal", (3, 7, 2, 6, 1)):
             ctx.set_option("traversal", trav)
             hits = flat.trace_closest(rays)
             assert np.array_equal(hits["prim"], prim_ref), f"{name}, traversal {trav}: primitives differ ({n_empty} empty leaves in the tree)"

@@ -20,7 +20,8 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 def traversals(T, ctx):
     """Traversal kernels of this build; the last entry (1) is the literal accel/bvh.jl loop, the first the library's default."""
-    return (3, 7, 6, 4, 2, 1)
+    from conftest import supported
+    return tuple(supported(ctx, "traversal", (3, 7, 6, 4, 2, 1)))  # (7, 6, 4: kernel families of the EXPERIMENTS build only)
 
 
 def bits(a):
@@ -136,7 +137,7 @@ def check_frame(T, ob, ctx, scene, osc, res=64, spp=32, depth=16, seed=0x5EED000
     films = {}
     travs = traversals(T, ctx)
     ran = {}
-    for trav in (3, 7, 6, 4, 1):
+    for trav in [t for t in (3, 7, 6, 4, 1) if t in travs]:
         ctx.set_option("traversal", trav)
         try:
             integ = T.PathIntegrator(cam, T.SeededSampler(spp, seed=seed), depth)
@@ -182,7 +183,7 @@ def test_mesh_10m_c5_geometry(T, ob, ctx):
     rays, sub = ray_set(T, ob, 1 << 19)
     sub = sub[::4]
     got = {}
-    for trav in (3, 7, 1):
+    for trav in [t for t in (3, 7, 1) if t in traversals(T, ctx)]:
         ctx.set_option("traversal", trav)
         try:
             got[trav] = (flat.trace_closest(rays), flat.trace_any(rays))
@@ -200,7 +201,7 @@ def test_mesh_10m_c5_geometry(T, ob, ctx):
     del osc
     cam = T.scenes.cornell_camera(4096)
     films = {}
-    for trav in (3, 7, 1):
+    for trav in [t for t in (3, 7, 1) if t in traversals(T, ctx)]:
         ctx.set_option("traversal", trav)
         try:
             films[trav] = T.PathIntegrator(cam, T.SeededSampler(1, seed=0x5EED0001), 16).render(scene, ctx).copy()

@@ -105,7 +105,8 @@ def compare_all(T, ob, ctx, scene, flat, sets, oracle_rays=6000):
         assert np.array_equal(ref_hits["prim"][sub], prim_ref), name
         assert_bits_equal(ref_hits["t"][sub], t_ref, f"{name}: literal kernel vs oracle")
         visits = {}
-        for trav in (7, 6, 4, 3, 2):  # 6: two rays per lane; 4: the 8-wide kernel (margin 0 hands its scenes to k_trace3)
+        from conftest import supported
+        for trav in supported(ctx, "traversal", (7, 6, 4, 3, 2)):  # 6: two rays per lane; 4: the 8-wide kernel (margin 0 hands its scenes to k_trace3); 7, 6, 4: EXPERIMENTS build
             ctx.set_option("traversal", trav)
             for margin in (0, 14, 16):
                 ctx.set_option("slab_margin_log2", margin)

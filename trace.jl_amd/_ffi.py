@@ -238,6 +238,12 @@ class Context:
     def set_option(self, name: str, value: int):
         self.check(lib().trhip_set_option(self._h, name.encode(), int(value)))
 
+    def has_option(self, name: str, value: int) -> bool:
+        """Whether this build of the library honours the option value (the kernel families that lost their measurements — traversals 4 / 6 / 7, leaf_queue, leaf_sorted,
+        the linear BVH builder — exist only in the EXPERIMENTS build: __graft_entry__.build_library(extra_flags=["-DTRHIP_EXPERIMENTS"], …)).  The option is left as it was
+        when the answer is no, and SET when it is yes."""
+        return lib().trhip_set_option(self._h, name.encode(), int(value)) != -3
+
     # ---- multi-GPU job (include/tracehip.h "multi-GPU"): one process per GPU, RCCL behind the C ABI -------------------
     def comm_init(self, unique_id: bytes, rank: int, n_ranks: int):
         buf = (C.c_uint8 * UNIQUE_ID_BYTES).from_buffer_copy(bytes(unique_id))

@@ -23,9 +23,11 @@
 #include "th_bvh.h"
 #include "th_kernels.h"
 #include "th_trace2.h"
-#include "th_trace8.h"
+#include "th_trace8.h"  // (FallbackList, the 8-wide view's types: the kernels themselves are only instantiated by an EXPERIMENTS build)
+#ifdef TRHIP_EXPERIMENTS
 #include "th_trace4.h"
 #include "th_trace7.h"
+#endif
 #include "th_trace3c.h"
 #include "th_comm.h"
 
@@ -87,6 +89,7 @@ struct trhip_ctx {
     bool warned_idle_accelerator = false;  // (tu_path.hip: the one-time stderr note)
     int any_on_accelerator = -1;  // hybrid mode: any-hit rays without a zero direction component walk the library's tree (TraceOut::zero_mode): 1 always, 0 never, -1 where the
                                   // integrator asks for it (TraceOut::any_acc_hint: SPPM).  Option "any_on_accelerator"
+    bool wide4 = true;  // hybrid mode: the accelerator is also laid out four children wide and the certified walk runs on that (th_trace3c4.h); option "wide4", read at commit and at launch
     bool leaf_queue = false;  // hybrid mode: the certified walk queues the leaves it reaches and tests them 64 at a time with whichever lanes (th_trace3d.h, option "leaf_queue")
     int node_layout = 0;  // children-in-parent nodes: 0 depth-first, 1 the two interior children of a node in one aligned 128-byte line (option "node_layout", read at commit; tu_scene.hip)
     bool film_swizzle = false;  // packed film gather: XCD x owns the x-th contiguous eighth of the workgroups (option "film_swizzle"; measured: no effect, th_kernels.h)
@@ -172,6 +175,7 @@ struct trhip_scene {
     bool hybrid_ok = false;        // the accelerator exists and its leaves carry the canonical leaves' boxes bit for bit
     std::string bvh_note;          // why a default commit ended with one tree (trhip_scene_bvh_note)
     int bvh_mode = 0;              // what trhip_scene_commit / trhip_scene_set_bvh built: 0 the library's tree alone, 1 the canonical (reference / host) tree alone, 2 both
+    DevBuf d_acc_w4nodes;  // the accelerator four children wide (th_trace3c4.h)
     DevBuf d_acc_wnodes, d_acc_prims, d_slot_boxes, d_sphere_boxes, d_sphere_slots, d_sphere_cert, d_acc_leaf_order;
     WideScene wide_acc{};
     DeviceScene dev_acc{};         // dev with the accelerator's primitive records

@@ -237,7 +237,7 @@ TH_D void generate_ray(const DeviceSensor& se, f2 film, f2 lens, float time_u, f
 // Lf (optional, the path integrator's whole-frame launches): the sample's radiance record is initialised HERE, in the film pass's pixel-group-major layout
 // (film_index layout 1) with the packed splat descriptor in its .w lane, and the path carries that record's index as its slot — the frame then needs neither the
 // memset of L nor the pack / re-lay pass over it before the gather (2.9 ms of a 256-spp frame and a second copy of L)
-static __global__ __launch_bounds__(kBlock) void k_raygen(const DeviceSensor* __restrict__ sep, uint32_t slot0, uint32_t n, uint64_t seed, uint32_t sample_offset,
+template <int TH_ONE_COPY = 0> __global__ __launch_bounds__(kBlock) void k_raygen(const DeviceSensor* __restrict__ sep, uint32_t slot0, uint32_t n, uint64_t seed, uint32_t sample_offset,
                                                    PathQueue q, uint32_t cap, Counters* ctr, float4* __restrict__ Lf = nullptr, uint32_t spp_frame = 0, FilmSideTable side = FilmSideTable{nullptr, nullptr, 0}) {
     const DeviceSensor& se = *sep;
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
@@ -270,7 +270,7 @@ static __global__ __launch_bounds__(kBlock) void k_raygen(const DeviceSensor* __
 }
 
 // L[slot] += NaN on the channels a shading vertex noted in `poison` (ShadeStream::poison): NaN + x = NaN, so when the note is applied is immaterial
-static __global__ __launch_bounds__(kBlock) void k_apply_poison(float4* __restrict__ L, const uint8_t* __restrict__ poison, uint64_t n) {
+template <int TH_ONE_COPY = 0> __global__ __launch_bounds__(kBlock) void k_apply_poison(float4* __restrict__ L, const uint8_t* __restrict__ poison, uint64_t n) {
     for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
         const uint32_t p = poison[i];
         if (p) {
@@ -512,7 +512,7 @@ TH_D bool rebuild_shading(const DeviceScene& sc, int prim, f3 o, f3 d, Shading& 
 // Commit time: every slot's shading line (th_scene.h) from the two arrays the traversal kernels use — records 0-2 = prims, 3-5 = tri_nrm, 6 / 7 =
 // triangle_constants of the vertices.
 // uv: 2 float4 per slot {u0, v0, u1, v1}, {u2, v2, has_uv, 0} for scenes where some mesh carries (u, v)s, else null
-static __global__ __launch_bounds__(kBlock) void k_shade_constants(float4* __restrict__ shade, const float4* __restrict__ prims, const float4* __restrict__ nrm, const float4* __restrict__ uv, uint32_t n_prims) {
+template <int TH_ONE_COPY = 0> __global__ __launch_bounds__(kBlock) void k_shade_constants(float4* __restrict__ shade, const float4* __restrict__ prims, const float4* __restrict__ nrm, const float4* __restrict__ uv, uint32_t n_prims) {
     for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < n_prims; k += gridDim.x * kBlock) {
         float4* rec = shade + 8 * (size_t)k;
         const float4 p0 = prims[3 * (size_t)k], p1 = prims[3 * (size_t)k + 1], p2 = prims[3 * (size_t)k + 2];
@@ -749,7 +749,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TH_SHADE
 }
 // STREAM: per-sample radiance = its per-depth terms added in depth order, which is the order the classic wavefront (and the
 // reference's loop) adds them in.  A depth that contributed nothing holds +0, and x + 0 == x for every x this sum can take.
-static __global__ __launch_bounds__(kBlock) void k_fold_terms(const float4* __restrict__ terms, uint64_t n_slots, uint32_t n_depths, float4* __restrict__ L) {
+template <int TH_ONE_COPY = 0> __global__ __launch_bounds__(kBlock) void k_fold_terms(const float4* __restrict__ terms, uint64_t n_slots, uint32_t n_depths, float4* __restrict__ L) {
     for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n_slots; i += (uint64_t)gridDim.x * kBlock) {
         float4 l = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         for (uint32_t dd = 0; dd < n_depths; ++dd) {
@@ -762,7 +762,7 @@ static __global__ __launch_bounds__(kBlock) void k_fold_terms(const float4* __re
     }
 }
 // depth tag 1 for every camera ray of a streaming batch
-static __global__ __launch_bounds__(kBlock) void k_fill_u32(uint32_t* __restrict__ p, uint64_t n, uint32_t v) {
+template <int TH_ONE_COPY = 0> __global__ __launch_bounds__(kBlock) void k_fill_u32(uint32_t* __restrict__ p, uint64_t n, uint32_t v) {
     for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) p[i] = v;
 }
 
@@ -780,7 +780,7 @@ static __global__ __launch_bounds__(kBlock) void k_fill_u32(uint32_t* __restrict
 // re-lays L (k_film_transpose) and writes p_film pixel-group-major: [group of 64 sample-pixels][s][lane]; consecutive samples
 // are then 1 KB apart and a wave's load is one contiguous chunk as before.  layout 0 = sample-major (option film_transpose 0).
 // film_index: defined with the camera-sample helpers above (k_raygen writes in that layout too)
-static __global__ __launch_bounds__(kBlock) void k_film_transpose(const float4* __restrict__ L, uint32_t npix, uint32_t spp, float4* __restrict__ Lt) {
+template <int TH_ONE_COPY = 0> __global__ __launch_bounds__(kBlock) void k_film_transpose(const float4* __restrict__ L, uint32_t npix, uint32_t spp, float4* __restrict__ Lt) {
     const uint32_t groups = (npix + 63u) >> 6;
     const uint64_t chunks = (uint64_t)groups * spp;
     const uint32_t lane = threadIdx.x & 63u;
@@ -790,7 +790,7 @@ static __global__ __launch_bounds__(kBlock) void k_film_transpose(const float4* 
         if (pix < npix) Lt[film_index(1u, npix, spp, s, pix)] = L[(size_t)s * npix + pix];
     }
 }
-static __global__ __launch_bounds__(kBlock) void k_film_positions(const DeviceSensor* __restrict__ sep, uint64_t n, uint64_t seed, uint32_t sample_offset, float2* __restrict__ pfilm, uint32_t layout,
+template <int TH_ONE_COPY = 0> __global__ __launch_bounds__(kBlock) void k_film_positions(const DeviceSensor* __restrict__ sep, uint64_t n, uint64_t seed, uint32_t sample_offset, float2* __restrict__ pfilm, uint32_t layout,
                                                            uint32_t spp) {
     const DeviceSensor& se = *sep;
     for (uint64_t slot = (uint64_t)blockIdx.x * kBlock + threadIdx.x; slot < n; slot += (uint64_t)gridDim.x * kBlock) {
@@ -799,7 +799,7 @@ static __global__ __launch_bounds__(kBlock) void k_film_positions(const DeviceSe
         pfilm[film_index(layout, (uint32_t)(se.sb_w * se.band_rows), spp, si.sample, si.pix)] = make_float2((float)si.px + ts_uniform(key, TS_DIM_FILM_X), (float)si.py + ts_uniform(key, TS_DIM_FILM_Y));
     }
 }
-static __global__ __launch_bounds__(kBlock) void k_film_gather(const DeviceSensor* __restrict__ sep, const float* __restrict__ table, const float4* __restrict__ L,
+template <int TH_ONE_COPY = 0> __global__ __launch_bounds__(kBlock) void k_film_gather(const DeviceSensor* __restrict__ sep, const float* __restrict__ table, const float4* __restrict__ L,
                                                         const float2* __restrict__ pfilm, uint32_t spp, uint32_t layout, float4* __restrict__ out) {
     const DeviceSensor& se = *sep;
     const uint32_t npx = (uint32_t)(se.film_w * se.film_h);
@@ -1028,7 +1028,7 @@ struct SplatDesc {   // uint4
     uint32_t ox;      // 4 bits per column: clamp(ceil(|x - dpx| / rx * 16), 1, 16) - 1
     uint32_t oy;      // 4 bits per row:    clamp(floor(|y - dpy| / ry * 16), 1, 16) - 1
 };
-static __global__ __launch_bounds__(kBlock) void k_film_descriptors(const DeviceSensor* __restrict__ sep, uint64_t n, uint64_t seed, uint32_t sample_offset, uint4* __restrict__ desc) {
+template <int TH_ONE_COPY = 0> __global__ __launch_bounds__(kBlock) void k_film_descriptors(const DeviceSensor* __restrict__ sep, uint64_t n, uint64_t seed, uint32_t sample_offset, uint4* __restrict__ desc) {
     const DeviceSensor& se = *sep;
     const float rx = se.filter_radius[0], ry = se.filter_radius[1];
     const float inv_rx = 1.0f / rx, inv_ry = 1.0f / ry;
@@ -1177,7 +1177,7 @@ __global__ __launch_bounds__(kBlock) void k_film_gather_desc(const DeviceSensor*
 // holds total / 16 + 65536 entries (the rate is ~2.4e-4 at 1024^2); should it ever run full the word is kFilmPackOverflow and the gather recomputes that
 // sample's descriptor from the sampler — in a cold copy of the loop, so that the hash and the descriptor arithmetic are not inlined into the unrolled hot one.
 // writes the descriptor into L[slot].w; the other lanes of the record are not touched (4-byte stores)
-static __global__ __launch_bounds__(kBlock) void k_film_pack_w(const DeviceSensor* __restrict__ sep, uint64_t n, uint64_t seed, uint32_t sample_offset, float4* __restrict__ L, FilmSideTable side) {
+template <int TH_ONE_COPY = 0> __global__ __launch_bounds__(kBlock) void k_film_pack_w(const DeviceSensor* __restrict__ sep, uint64_t n, uint64_t seed, uint32_t sample_offset, float4* __restrict__ L, FilmSideTable side) {
     const DeviceSensor& se = *sep;
     for (uint64_t slot = (uint64_t)blockIdx.x * kBlock + threadIdx.x; slot < n; slot += (uint64_t)gridDim.x * kBlock) {
         const SlotInfo si = slot_info(se, (uint32_t)slot);
@@ -1189,7 +1189,7 @@ static __global__ __launch_bounds__(kBlock) void k_film_pack_w(const DeviceSenso
 // sample pixel before the next pixel, which in the integrators' sample-major order is a 16 MB stride at 1024^2 — a new DRAM page and TLB entry for every 16-byte
 // load.  Re-laid, a wave's loads for consecutive samples are consecutive 1 KB chunks.  This pass reads and writes every record once (the in-place pass touches
 // every line too: same traffic), into a second buffer.
-static __global__ __launch_bounds__(kBlock) void k_film_pack_transpose(const DeviceSensor* __restrict__ sep, uint32_t npix, uint32_t spp, uint64_t seed, uint32_t sample_offset,
+template <int TH_ONE_COPY = 0> __global__ __launch_bounds__(kBlock) void k_film_pack_transpose(const DeviceSensor* __restrict__ sep, uint32_t npix, uint32_t spp, uint64_t seed, uint32_t sample_offset,
                                                                 const float4* __restrict__ L, float4* __restrict__ Lt, FilmSideTable side) {
     const DeviceSensor& se = *sep;
     const uint32_t groups = (npix + 63u) >> 6;
@@ -1435,7 +1435,7 @@ __global__ __launch_bounds__(kBlock) void k_film_gather_packed(const DeviceSenso
 // pixel is unchanged: one accumulator per sample tile (at most 2x2 reach a pixel), inside a tile rows ascending, columns
 // ascending, samples ascending; tiles merged in k order (film.jl:182-193).  LDS layout: five planes [s][col], so the lanes
 // of a wave (different columns, same s) read consecutive banks and equal columns broadcast.
-static __global__ __launch_bounds__(kBlock) void k_film_gather_tiled(const DeviceSensor* __restrict__ sep, const float* __restrict__ table, const float4* __restrict__ L,
+template <int TH_ONE_COPY = 0> __global__ __launch_bounds__(kBlock) void k_film_gather_tiled(const DeviceSensor* __restrict__ sep, const float* __restrict__ table, const float4* __restrict__ L,
                                                               const float2* __restrict__ pfilm, uint32_t spp, uint32_t layout, uint32_t cols, uint32_t ns_stage, float4* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float s_planes[];
     __shared__ float s_table[256];
@@ -1563,7 +1563,7 @@ static __global__ __launch_bounds__(kBlock) void k_film_gather_tiled(const Devic
 }
 
 // save(film) up to the encoder (film.jl:204-222)
-static __global__ void k_film_to_rgb(const float4* __restrict__ xyzw, uint32_t n, float scale, float* __restrict__ rgb) {
+template <int TH_ONE_COPY = 0> __global__ void k_film_to_rgb(const float4* __restrict__ xyzw, uint32_t n, float scale, float* __restrict__ rgb) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float4 p = xyzw[i];
@@ -1580,7 +1580,7 @@ static __global__ void k_film_to_rgb(const float4* __restrict__ xyzw, uint32_t n
 }
 
 // ---- test / inspection kernels -----------------------------------------------------------------------------------------------------
-static __global__ void k_hit_geometry(DeviceScene sc, const float4* __restrict__ ro, const float4* __restrict__ rd, const float4* __restrict__ hits, uint32_t n, float* __restrict__ out15) {
+template <int TH_ONE_COPY = 0> __global__ void k_hit_geometry(DeviceScene sc, const float4* __restrict__ ro, const float4* __restrict__ rd, const float4* __restrict__ hits, uint32_t n, float* __restrict__ out15) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float* g = out15 + 15 * (size_t)i;
@@ -1595,7 +1595,7 @@ static __global__ void k_hit_geometry(DeviceScene sc, const float4* __restrict__
     const float v[15] = {sh.p.x, sh.p.y, sh.p.z, sh.ng.x, sh.ng.y, sh.ng.z, sh.ns.x, sh.ns.y, sh.ns.z, sh.wo.x, sh.wo.y, sh.wo.z, sh.ss.x, sh.ss.y, sh.ss.z};
     for (int k = 0; k < 15; ++k) g[k] = v[k];
 }
-static __global__ void k_prepare_rays(const float* __restrict__ rays8, uint32_t n, float4* __restrict__ ro, float4* __restrict__ rd, float* __restrict__ tmax) {
+template <int TH_ONE_COPY = 0> __global__ void k_prepare_rays(const float* __restrict__ rays8, uint32_t n, float4* __restrict__ ro, float4* __restrict__ rd, float* __restrict__ tmax) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float* r = rays8 + 8 * (size_t)i;
@@ -1604,7 +1604,7 @@ static __global__ void k_prepare_rays(const float* __restrict__ rays8, uint32_t 
     rd[i] = make_float4(d.x, d.y, d.z, 0.0f);
     tmax[i] = r[3];
 }
-static __global__ void k_generate_rays(const DeviceSensor* __restrict__ sep, const float* __restrict__ samples5, uint32_t n, float* __restrict__ out8) {
+template <int TH_ONE_COPY = 0> __global__ void k_generate_rays(const DeviceSensor* __restrict__ sep, const float* __restrict__ samples5, uint32_t n, float* __restrict__ out8) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float* c = samples5 + 5 * (size_t)i;
@@ -1621,7 +1621,7 @@ static __global__ void k_generate_rays(const DeviceSensor* __restrict__ sep, con
     r[6] = d.z;
     r[7] = time;
 }
-static __global__ void k_bsdf_query(DeviceScene sc, uint32_t material, int multi, int mode, int flags, const float* __restrict__ frame9, const float* __restrict__ dirs6, uint32_t n,
+template <int TH_ONE_COPY = 0> __global__ void k_bsdf_query(DeviceScene sc, uint32_t material, int multi, int mode, int flags, const float* __restrict__ frame9, const float* __restrict__ dirs6, uint32_t n,
                              float* __restrict__ out8) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -1659,7 +1659,7 @@ static __global__ void k_bsdf_query(DeviceScene sc, uint32_t material, int multi
 }
 // Per-sample radiance read-back: float4 L -> rgb with the NaN rule of integrators/sampler.jl:46
 // layout 1: L is pixel-group-major (film_index; k_raygen's Lf mode); the export is sample-major either way
-static __global__ void k_export_L(const float4* __restrict__ L, uint64_t n, float* __restrict__ out, uint32_t layout = 0, uint32_t npix = 1, uint32_t spp = 1) {
+template <int TH_ONE_COPY = 0> __global__ void k_export_L(const float4* __restrict__ L, uint64_t n, float* __restrict__ out, uint32_t layout = 0, uint32_t npix = 1, uint32_t spp = 1) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float4 l = L[layout ? film_index(1u, npix, spp, (uint32_t)(i / npix), (uint32_t)(i % npix)) : (size_t)i];
@@ -1669,7 +1669,7 @@ static __global__ void k_export_L(const float4* __restrict__ L, uint64_t n, floa
     out[3 * i + 1] = c.y;
     out[3 * i + 2] = c.z;
 }
-static __global__ void k_import_L(const float* __restrict__ in, uint64_t n, float4* __restrict__ L) {
+template <int TH_ONE_COPY = 0> __global__ void k_import_L(const float* __restrict__ in, uint64_t n, float4* __restrict__ L) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     L[i] = make_float4(in[3 * i], in[3 * i + 1], in[3 * i + 2], 0.0f);

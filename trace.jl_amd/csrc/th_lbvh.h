@@ -34,7 +34,7 @@ struct LbvhBuild {  // device arrays, n primitives, n - 1 internal nodes
     uint32_t n;
 };
 
-static __global__ __launch_bounds__(kBlock) void k_lbvh_centroid_bounds(LbvhBuild b) {
+template <int TH_ONE_COPY = 0> __global__ __launch_bounds__(kBlock) void k_lbvh_centroid_bounds(LbvhBuild b) {
     float mn[3] = {kInf, kInf, kInf}, mx[3] = {-kInf, -kInf, -kInf};
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < b.n; i += gridDim.x * kBlock)
         for (int a = 0; a < 3; ++a) {
@@ -61,7 +61,7 @@ TH_D uint64_t spread21(uint64_t v) {  // 21 bits -> every third bit
     v = (v | v << 2) & 0x1249249249249249ull;
     return v;
 }
-static __global__ __launch_bounds__(kBlock) void k_lbvh_keys(LbvhBuild b) {
+template <int TH_ONE_COPY = 0> __global__ __launch_bounds__(kBlock) void k_lbvh_keys(LbvhBuild b) {
     float cmin[3], inv[3];
     for (int a = 0; a < 3; ++a) {
         cmin[a] = dec_f32(b.cbounds[a]);
@@ -86,7 +86,7 @@ TH_D int lbvh_delta(const uint64_t* __restrict__ keys, uint32_t n, int i, int j)
     if (a != c) return __clzll((long long)(a ^ c));
     return 64 + __clz((int)((uint32_t)i ^ (uint32_t)j));
 }
-static __global__ __launch_bounds__(kBlock) void k_lbvh_hierarchy(LbvhBuild b) {
+template <int TH_ONE_COPY = 0> __global__ __launch_bounds__(kBlock) void k_lbvh_hierarchy(LbvhBuild b) {
     const uint32_t n = b.n;
     for (uint32_t ii = blockIdx.x * kBlock + threadIdx.x; ii + 1 < n; ii += gridDim.x * kBlock) {
         const int i = (int)ii;
@@ -123,7 +123,7 @@ static __global__ __launch_bounds__(kBlock) void k_lbvh_hierarchy(LbvhBuild b) {
     }
 }
 // bounds bottom-up: the second thread to arrive at a node unions its children's boxes and goes on
-static __global__ __launch_bounds__(kBlock) void k_lbvh_refit(LbvhBuild b) {
+template <int TH_ONE_COPY = 0> __global__ __launch_bounds__(kBlock) void k_lbvh_refit(LbvhBuild b) {
     for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < b.n; k += gridDim.x * kBlock) {
         uint32_t p = b.parent_leaf[k];
         while (true) {
@@ -153,7 +153,7 @@ struct LbvhFlat {
     uint32_t* flags;   // leaf: 1 << 2 | 3; interior: split axis
     uint32_t* order;   // ordered slot -> primitive
 };
-static __global__ __launch_bounds__(kBlock) void k_lbvh_flatten(LbvhBuild b, LbvhFlat f) {
+template <int TH_ONE_COPY = 0> __global__ __launch_bounds__(kBlock) void k_lbvh_flatten(LbvhBuild b, LbvhFlat f) {
     const uint32_t n = b.n, total = 2 * n - 1;
     uint32_t deepest = 0;
     for (uint32_t t = blockIdx.x * kBlock + threadIdx.x; t < total; t += gridDim.x * kBlock) {

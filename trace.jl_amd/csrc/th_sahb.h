@@ -73,7 +73,7 @@ TH_D float sah_half_area(const float* mn, const float* mx) {
     return dx * dy + dx * dz + dy * dz;
 }
 
-static __global__ __launch_bounds__(kBlock) void k_sah_init(SahBuild b) {
+template <int TH_ONE_COPY = 0> __global__ __launch_bounds__(kBlock) void k_sah_init(SahBuild b) {
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < b.n; i += gridDim.x * kBlock) {
         b.idx_in[i] = i;
         b.pos_in[i] = b.n > kSahSmall ? 0u : kSahNone;
@@ -96,7 +96,7 @@ static __global__ __launch_bounds__(kBlock) void k_sah_init(SahBuild b) {
         b.small[0] = 0;
     }
 }
-static __global__ __launch_bounds__(kBlock) void k_sah_round_init(SahBuild b) {
+template <int TH_ONE_COPY = 0> __global__ __launch_bounds__(kBlock) void k_sah_round_init(SahBuild b) {
     const uint32_t emin = enc_f32(kInf), emax = enc_f32(-kInf);
     const size_t words = (size_t)b.n_active * kSahBinWords;
     for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < words; i += (size_t)gridDim.x * kBlock) {
@@ -116,7 +116,7 @@ TH_D uint32_t sah_block_slot(const SahBuild& b, uint32_t first, uint32_t last) {
     return s0 == s1 ? s0 : kSahNone;
 }
 // node bounds and centroid bounds of every active node
-static __global__ __launch_bounds__(kBlock) void k_sah_bounds(SahBuild b) {
+template <int TH_ONE_COPY = 0> __global__ __launch_bounds__(kBlock) void k_sah_bounds(SahBuild b) {
     __shared__ uint32_t s_acc[12];
     const uint32_t first = blockIdx.x * kSahChunk, last = min(b.n, first + kSahChunk);
     if (first >= last) return;
@@ -203,7 +203,7 @@ TH_D void sah_bin_add(uint32_t* bin, const float* box) {
     atomicAdd(&bin[6], 1u);
 }
 // every primitive into its bin on each axis
-static __global__ __launch_bounds__(kBlock) void k_sah_bin(SahBuild b) {
+template <int TH_ONE_COPY = 0> __global__ __launch_bounds__(kBlock) void k_sah_bin(SahBuild b) {
     __shared__ uint32_t s_bins[kSahBinWords];
     const uint32_t first = blockIdx.x * kSahChunk, last = min(b.n, first + kSahChunk);
     if (first >= last) return;
@@ -321,7 +321,7 @@ TH_D void sah_sweep(const float (*bb)[6], const uint32_t* cnt, int ax, float& be
     }
 }
 // one thread per active node: its bounds into the pool, the best split, two child ids
-static __global__ __launch_bounds__(kBlock) void k_sah_split(SahBuild b) {
+template <int TH_ONE_COPY = 0> __global__ __launch_bounds__(kBlock) void k_sah_split(SahBuild b) {
     const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
     if (slot >= b.n_active) return;
     const uint32_t node = b.act[slot];
@@ -357,7 +357,7 @@ static __global__ __launch_bounds__(kBlock) void k_sah_split(SahBuild b) {
     b.n_right[node] = base + 1;
     b.n_axis[node] = (uint32_t)best_axis;
 }
-static __global__ __launch_bounds__(kBlock) void k_sah_flag(SahBuild b) {
+template <int TH_ONE_COPY = 0> __global__ __launch_bounds__(kBlock) void k_sah_flag(SahBuild b) {
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i <= b.n; i += gridDim.x * kBlock) {
         uint32_t f = 0;
         if (i < b.n) {
@@ -376,7 +376,7 @@ static __global__ __launch_bounds__(kBlock) void k_sah_flag(SahBuild b) {
     }
 }
 // one thread per split node: the children's ranges, and where they go next (another round, or the small phase)
-static __global__ __launch_bounds__(kBlock) void k_sah_children(SahBuild b) {
+template <int TH_ONE_COPY = 0> __global__ __launch_bounds__(kBlock) void k_sah_children(SahBuild b) {
     const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
     if (slot >= b.n_active) return;
     b.cslot[2 * (size_t)slot] = kSahNone;
@@ -405,7 +405,7 @@ static __global__ __launch_bounds__(kBlock) void k_sah_children(SahBuild b) {
         }
     }
 }
-static __global__ __launch_bounds__(kBlock) void k_sah_scatter(SahBuild b) {
+template <int TH_ONE_COPY = 0> __global__ __launch_bounds__(kBlock) void k_sah_scatter(SahBuild b) {
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < b.n; i += gridDim.x * kBlock) {
         const uint32_t slot = b.pos_in[i], p = b.idx_in[i];
         if (slot == kSahNone || b.split[slot] == kSahNone) {
@@ -423,7 +423,7 @@ static __global__ __launch_bounds__(kBlock) void k_sah_scatter(SahBuild b) {
 }
 
 // ---- small phase: th_bvh.h's recursion, one thread per node of <= kSahSmall primitives ----
-static __global__ __launch_bounds__(64) void k_sah_small(SahBuild b, uint32_t n_small) {
+template <int TH_ONE_COPY = 0> __global__ __launch_bounds__(64) void k_sah_small(SahBuild b, uint32_t n_small) {
     const uint32_t t = blockIdx.x * 64 + threadIdx.x;
     if (t >= n_small) return;
     uint32_t stack[72];  // node ids; a subtree of <= 64 primitives is at most 63 interior nodes deep
@@ -541,7 +541,7 @@ static __global__ __launch_bounds__(64) void k_sah_small(SahBuild b, uint32_t n_
 }
 
 // ---- depth-first layout ----
-static __global__ __launch_bounds__(kBlock) void k_sah_mark_leaves(SahBuild b, uint32_t n_nodes) {
+template <int TH_ONE_COPY = 0> __global__ __launch_bounds__(kBlock) void k_sah_mark_leaves(SahBuild b, uint32_t n_nodes) {
     for (uint32_t node = blockIdx.x * kBlock + threadIdx.x; node < n_nodes; node += gridDim.x * kBlock)
         if (b.n_left[node] == kSahNone) b.flag[b.n_lo[node]] = 1u;
 }
@@ -550,7 +550,7 @@ struct SahFlat {
     uint32_t* a;
     uint32_t* flags;
 };
-static __global__ __launch_bounds__(kBlock) void k_sah_flatten(SahBuild b, uint32_t n_nodes, SahFlat f) {
+template <int TH_ONE_COPY = 0> __global__ __launch_bounds__(kBlock) void k_sah_flatten(SahBuild b, uint32_t n_nodes, SahFlat f) {
     for (uint32_t node = blockIdx.x * kBlock + threadIdx.x; node < n_nodes; node += gridDim.x * kBlock) {
         const uint32_t lo = b.n_lo[node];
         const uint32_t dfs = 2 * b.scan[lo] + b.n_lefts[node];

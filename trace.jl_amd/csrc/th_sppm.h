@@ -136,7 +136,7 @@ TH_D uint32_t grid_hash(uint32_t x, uint32_t y, uint32_t z, uint32_t hash_size) 
 // ---- camera pass ----------------------------------------------------------------------------------------------------------------
 // Camera rays of a BATCH of iterations: entry e = (iteration it0 + e / n_pix, pixel e % n_pix).  The camera paths of different
 // iterations do not depend on each other (only Ld accumulates, in order, see k_sppm_fold_ld), so they share the launches.
-static __global__ __launch_bounds__(kBlock) void k_sppm_raygen(const DeviceSensor* __restrict__ sep, uint32_t n, uint32_t n_pix, uint32_t width, uint64_t seed, uint32_t it0, PathQueue q,
+template <int TH_ONE_COPY = 0> __global__ __launch_bounds__(kBlock) void k_sppm_raygen(const DeviceSensor* __restrict__ sep, uint32_t n, uint32_t n_pix, uint32_t width, uint64_t seed, uint32_t it0, PathQueue q,
                                                         uint32_t cap, Counters* ctr) {
     const DeviceSensor& se = *sep;
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
@@ -180,7 +180,7 @@ TH_D void add_nan_where(float4* L, uint32_t slot, uint32_t poison) {  // L += β
 #define TH_SHADE_SPPM_WAVES 3  // 180 VGPRs unconstrained (2 waves per SIMD); capped at 3: C4 shading section 162.9 -> 159.3 ms, at 4 (spills) 162.2
 #endif
 template <bool TAN = true>
-static __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TH_SHADE_SPPM_WAVES))) void k_shade_sppm(DeviceScene sc, PathQueue qin, PathQueue qout, ShadowQueue sq, uint32_t cap, const float4* __restrict__ hits, VisiblePoints vp,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TH_SHADE_SPPM_WAVES))) void k_shade_sppm(DeviceScene sc, PathQueue qin, PathQueue qout, ShadowQueue sq, uint32_t cap, const float4* __restrict__ hits, VisiblePoints vp,
                                                        float4* __restrict__ Ld, Counters* ctr, int depth, int max_depth, uint64_t seed, uint32_t it0, uint32_t n_pix, uint32_t width) {
     __shared__ SegView sv;
     const SegQueue qv{ctr->n_queue[depth - 1], cap, 0u};
@@ -304,7 +304,7 @@ TH_D float wave_max(float v) {
     for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
     return v;
 }
-static __global__ __launch_bounds__(kBlock) void k_sppm_grid_reset(GridInfo* g) {
+template <int TH_ONE_COPY = 0> __global__ __launch_bounds__(kBlock) void k_sppm_grid_reset(GridInfo* g) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         for (int a = 0; a < 3; ++a) {
             g->enc_min[a] = enc_f32(kInf);
@@ -318,7 +318,7 @@ static __global__ __launch_bounds__(kBlock) void k_sppm_grid_reset(GridInfo* g) 
     }
 }
 // grid_bounds = ∪ expand(Bounds3(vp.p), radius), max_radius (:285-292)
-static __global__ __launch_bounds__(kBlock) void k_sppm_grid_bounds(VisiblePoints vp, const float* __restrict__ radius, uint32_t n, GridInfo* g) {
+template <int TH_ONE_COPY = 0> __global__ __launch_bounds__(kBlock) void k_sppm_grid_bounds(VisiblePoints vp, const float* __restrict__ radius, uint32_t n, GridInfo* g) {
     float mn[3] = {kInf, kInf, kInf}, mx[3] = {-kInf, -kInf, -kInf}, mr = 0.0f;
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
         const float4 b = vp.beta[i];
@@ -366,7 +366,7 @@ static __global__ __launch_bounds__(kBlock) void k_sppm_grid_bounds(VisiblePoint
     }
 }
 // grid resolution (:293-302)
-static __global__ void k_sppm_grid_setup(GridInfo* g) {
+template <int TH_ONE_COPY = 0> __global__ void k_sppm_grid_setup(GridInfo* g) {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     const float max_radius = dec_f32(g->enc_max_radius);
     if (!(max_radius > 0.0f)) {
@@ -397,7 +397,7 @@ static __global__ void k_sppm_grid_setup(GridInfo* g) {
 struct PhotonRecords;
 // pass = 0: count the in-bounds photon hits per bucket; pass = 1: fill (counts[h] counts down from the bucket size).
 // Record slots of one iteration: (d, first_photon + i), d < n_depths, i < n_photons.
-static __global__ __launch_bounds__(kBlock) void k_sppm_hit_bin(const float4* __restrict__ rec_p, const uint8_t* __restrict__ rec_valid, uint32_t n_batch_photons, uint32_t first_photon,
+template <int TH_ONE_COPY = 0> __global__ __launch_bounds__(kBlock) void k_sppm_hit_bin(const float4* __restrict__ rec_p, const uint8_t* __restrict__ rec_valid, uint32_t n_batch_photons, uint32_t first_photon,
                                                          uint32_t n_photons, uint32_t n_depths, uint32_t hash_size, GridInfo* gp, uint32_t* __restrict__ counts,
                                                          const uint32_t* __restrict__ starts, float4* __restrict__ hit_sorted, int pass) {
     const GridInfo& g = *gp;
@@ -423,7 +423,7 @@ static __global__ __launch_bounds__(kBlock) void k_sppm_hit_bin(const float4* __
 // Exclusive prefix sums of the bucket sizes in three launches: tiles of kScanTile counts (local prefix + tile total), the
 // tile totals (k_sppm_scan, one block), then the tile offsets added back.
 constexpr uint32_t kScanTile = 1024;
-static __global__ __launch_bounds__(kBlock) void k_sppm_scan_tiles(const uint32_t* __restrict__ counts, uint32_t* __restrict__ starts, uint32_t n, uint32_t* __restrict__ tile_sums) {
+template <int TH_ONE_COPY = 0> __global__ __launch_bounds__(kBlock) void k_sppm_scan_tiles(const uint32_t* __restrict__ counts, uint32_t* __restrict__ starts, uint32_t n, uint32_t* __restrict__ tile_sums) {
     __shared__ uint32_t wsum[kBlock / 64];
     const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * 4u;
     uint32_t v[4];
@@ -446,7 +446,7 @@ static __global__ __launch_bounds__(kBlock) void k_sppm_scan_tiles(const uint32_
     }
     if (threadIdx.x == kBlock - 1) tile_sums[blockIdx.x] = acc;
 }
-static __global__ __launch_bounds__(kBlock) void k_sppm_scan_add(uint32_t* __restrict__ starts, uint32_t n, const uint32_t* __restrict__ tile_offsets, uint32_t n_tiles) {
+template <int TH_ONE_COPY = 0> __global__ __launch_bounds__(kBlock) void k_sppm_scan_add(uint32_t* __restrict__ starts, uint32_t n, const uint32_t* __restrict__ tile_offsets, uint32_t n_tiles) {
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i <= n; i += gridDim.x * kBlock) {
         if (i == n)
             starts[n] = tile_offsets[n_tiles];
@@ -455,7 +455,7 @@ static __global__ __launch_bounds__(kBlock) void k_sppm_scan_add(uint32_t* __res
     }
 }
 // starts[0..n] = exclusive prefix sums of counts[0..n-1]; one block of 1024 threads.
-static __global__ __launch_bounds__(1024) void k_sppm_scan(const uint32_t* __restrict__ counts, uint32_t* __restrict__ starts, uint32_t n, GridInfo* g) {
+template <int TH_ONE_COPY = 0> __global__ __launch_bounds__(1024) void k_sppm_scan(const uint32_t* __restrict__ counts, uint32_t* __restrict__ starts, uint32_t n, GridInfo* g) {
     __shared__ uint32_t part[1024];
     const uint32_t t = threadIdx.x;
     const uint32_t chunk = (n + 1023u) / 1024u;
@@ -486,7 +486,7 @@ static __global__ __launch_bounds__(1024) void k_sppm_scan(const uint32_t* __res
 // Photon ray leaving the light: sample_discrete over light power, sample_le (point.jl:60-69, spot.jl:46-55), β.
 // per_iter / p_lo / p_hi: a multi-GPU job (trhip_comm_init) traces photon indices [p_lo, p_hi) of every iteration on this rank
 // (Threads.@threads over photon_index, sppm.jl:334, spread over processes); the index space and the records keep the full layout.
-static __global__ __launch_bounds__(kBlock) void k_photon_gen(DeviceScene sc, LightDistribution ld, uint32_t n_photons, uint64_t halton_base, PathQueue q, uint32_t cap, Counters* ctr,
+template <int TH_ONE_COPY = 0> __global__ __launch_bounds__(kBlock) void k_photon_gen(DeviceScene sc, LightDistribution ld, uint32_t n_photons, uint64_t halton_base, PathQueue q, uint32_t cap, Counters* ctr,
                                                        uint32_t per_iter, uint32_t p_lo, uint32_t p_hi) {
     const uint32_t total = (n_photons + 63u) & ~63u;
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < total; i += gridDim.x * kBlock) {
@@ -581,7 +581,7 @@ constexpr int kPhotonRings = 4;
 #define TH_SHADE_PHOTON_WAVES 4
 #endif
 template <bool TAN = true>
-static __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TH_SHADE_PHOTON_WAVES))) void k_shade_photon(DeviceScene sc, PathQueue qin, PathQueue qout, uint32_t cap, const float4* __restrict__ hits, PhotonRecords rec,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TH_SHADE_PHOTON_WAVES))) void k_shade_photon(DeviceScene sc, PathQueue qin, PathQueue qout, uint32_t cap, const float4* __restrict__ hits, PhotonRecords rec,
                                                          uint32_t n_batch_photons, Counters* ctr, int depth, int max_depth, uint64_t halton_base) {
     __shared__ SegView sv;
     __shared__ uint32_t s_ring[kBlock / 64][kPhotonRings][128];
@@ -736,7 +736,7 @@ TH_D GatherSum gather_pixel(const DeviceScene& sc, const PhotonRecords& rec, con
 #ifndef TH_SPPM_HOT_WAVES
 #define TH_SPPM_HOT_WAVES 4  // 144 VGPRs unconstrained (3 waves); capped at 4: C4 shading section 160.4 -> 156.4 ms
 #endif
-static __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TH_SPPM_GATHER_WAVES))) void k_sppm_gather(DeviceScene sc, PhotonRecords rec, VisiblePoints vp, PixelStats px, uint32_t n, GridInfo* gp, const uint32_t* __restrict__ starts,
+template <int TH_ONE_COPY = 0> __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TH_SPPM_GATHER_WAVES))) void k_sppm_gather(DeviceScene sc, PhotonRecords rec, VisiblePoints vp, PixelStats px, uint32_t n, GridInfo* gp, const uint32_t* __restrict__ starts,
                                                         const float4* __restrict__ hit_sorted, uint32_t hash_size, uint32_t* __restrict__ hot_list, uint32_t count_registrations, uint32_t count_stats) {
     // A wave takes 64 pixels.  Every lane walks the buckets of ITS pixel one candidate per round (a cursor over cells and entries);
     // the (pixel, photon) pairs that pass the distance test are parked in a per-wave ring and evaluated 64 at a time — frame and
@@ -922,7 +922,7 @@ static __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(T
         }
     }
 }
-static __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TH_SPPM_HOT_WAVES))) void k_sppm_gather_hot(DeviceScene sc, PhotonRecords rec, VisiblePoints vp, PixelStats px, GridInfo* gp, const uint32_t* __restrict__ starts,
+template <int TH_ONE_COPY = 0> __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TH_SPPM_HOT_WAVES))) void k_sppm_gather_hot(DeviceScene sc, PhotonRecords rec, VisiblePoints vp, PixelStats px, GridInfo* gp, const uint32_t* __restrict__ starts,
                                                             const float4* __restrict__ hit_sorted, uint32_t hash_size, const uint32_t* __restrict__ hot_list, uint32_t count_stats) {
     // One wave per hot pixel.  The distance test runs over a bucket with all 64 lanes; the photons that pass (about one in eight) are
     // not shaded where they are found — a handful of lanes would run the BSDF while the rest wait — but parked in a per-wave ring
@@ -1022,7 +1022,7 @@ static __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(T
 
 // pixel.Ld += every term of the batch in the reference's order: iterations ascending, inside an iteration by depth
 // (sppm.jl:211-232).  A depth nothing was added at holds +0, and x + 0 == x for every x this sum can take.
-static __global__ __launch_bounds__(kBlock) void k_sppm_fold_ld(uint32_t n_pix, uint32_t n_iter, uint32_t max_depth, const float4* __restrict__ terms, float4* __restrict__ Ld) {
+template <int TH_ONE_COPY = 0> __global__ __launch_bounds__(kBlock) void k_sppm_fold_ld(uint32_t n_pix, uint32_t n_iter, uint32_t max_depth, const float4* __restrict__ terms, float4* __restrict__ Ld) {
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n_pix; i += gridDim.x * kBlock) {
         float4 l = Ld[i];
         for (uint32_t k = 0; k < n_iter * max_depth; ++k) {
@@ -1036,7 +1036,7 @@ static __global__ __launch_bounds__(kBlock) void k_sppm_fold_ld(uint32_t n_pix, 
 }
 
 // ---- _update_pixels! (sppm.jl:438-459) and _sppm_to_image (:461-472) ------------------------------------------------------------------
-static __global__ __launch_bounds__(kBlock) void k_sppm_update(uint32_t n, float gamma, PixelStats px, VisiblePoints vp) {
+template <int TH_ONE_COPY = 0> __global__ __launch_bounds__(kBlock) void k_sppm_update(uint32_t n, float gamma, PixelStats px, VisiblePoints vp) {
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
         const uint32_t M = px.M[i];
         if (M > 0) {
@@ -1057,7 +1057,7 @@ static __global__ __launch_bounds__(kBlock) void k_sppm_update(uint32_t n, float
     }
 }
 // film pixel = set_image!(film, image): xyz = to_XYZ(image[i]), filter_weight_sum = 1 (film.jl:195-202)
-static __global__ __launch_bounds__(kBlock) void k_sppm_image(uint32_t n, uint32_t iteration, uint64_t photons_per_iteration, PixelStats px, float4* __restrict__ film) {
+template <int TH_ONE_COPY = 0> __global__ __launch_bounds__(kBlock) void k_sppm_image(uint32_t n, uint32_t iteration, uint64_t photons_per_iteration, PixelStats px, float4* __restrict__ film) {
     const double Np = (double)((uint64_t)iteration * photons_per_iteration) * 3.141592653589793;
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
         const float4 ld = px.Ld[i], t = px.tau[i];

@@ -46,6 +46,12 @@ constexpr int kStack2Total = 64;
 #endif
 constexpr int kStack3MinLds = TH_TRACE3_LDS_CLOSEST < TH_TRACE3_LDS_ANY ? TH_TRACE3_LDS_CLOSEST : TH_TRACE3_LDS_ANY;
 constexpr int kStackMinLds = kStack2Lds < kStack3MinLds ? kStack2Lds : kStack3MinLds;  // the global overflow slab holds the levels above this
+// levels per thread of the global overflow slab every traversal launch gets (the EXPERIMENTS build's two-rays-per-lane kernel, th_trace4.h with 8 LDS levels, needs 2 x 56)
+#ifdef TRHIP_EXPERIMENTS
+constexpr int kStackSlabLevels = (kStack2Total - kStackMinLds) > 112 ? (kStack2Total - kStackMinLds) : 112;
+#else
+constexpr int kStackSlabLevels = kStack2Total - kStackMinLds;
+#endif
 constexpr uint32_t kRefNone = 0xffffffffu;
 #ifndef TH_TRACE_REFILL
 #define TH_TRACE_REFILL 12  // idle lanes of a wave that trigger a refill from the queue
@@ -57,6 +63,8 @@ struct WideScene {            // device view of the v2 node array
     float root_box[6];        // bounds of flat node 0 (tested first, bvh.jl:226)
     uint32_t root_ref, root_cnt;  // root_cnt > 0: the root is a leaf with that many primitives starting at root_ref
     uint32_t n_wnodes;
+    const float4* w4nodes;    // hybrid accelerator only: the same tree four children wide, 8 float4 per node (th_trace3c4.h); null = none
+    uint32_t n_w4nodes;
     float tight_scale;        // slab_test2's margin as a fraction of the ray's reach (2^-14); 0: the reference's loose test alone
     const uint32_t* leaf_order;  // one-leaf scenes: the order in which any-hit rays test the leaf's primitives (k_any_leaf); null = slot order
     uint32_t leaf_tight;      // every triangle leaf's box is exactly the union of its triangles' boxes (k_trace7's cheap interior test needs it)

@@ -176,10 +176,10 @@ struct CertHot {   // … and what the walk itself, or every fetch, needs
     float mle[3];               // CertScene::mle_small
     float klat;                 // TH_TRACE3C_FAST == 2: 2^-TH_TRACE3C_LAT / tight_scale: the scalar lateral margin ms = klat x em x max |1 / d|
 };
-static __global__ void k_store_cert_cold(CertCold* dst, CertCold v) { *dst = v; }
+template <int TH_ONE_COPY = 0> __global__ void k_store_cert_cold(CertCold* dst, CertCold v) { *dst = v; }
 // "count_visits": one thread, between the certified walk and the fallback walk of a launch (phase 0) and after the fallback walk (phase 1): what the closest-hit visit
 // counters gained during the fallback walk goes to nodes_fallback / prims_fallback
-static __global__ void k_hybrid_count_mark(Counters* c, int phase) {
+template <int TH_ONE_COPY = 0> __global__ void k_hybrid_count_mark(Counters* c, int phase) {
     if (phase == 0) {
         c->nodes_seen = c->nodes_closest;
         c->prims_seen = c->prims_closest;

@@ -1,0 +1,512 @@
+// th_trace3c4.h — the hybrid mode's certified closest-hit walk on the accelerator laid out FOUR children wide (tu_scene.hip upload_accelerator: every other level of the library's
+// binary tree folded into its parent; 128 bytes per node).  Everything of th_trace3c.h's header holds — the certificate speaks of leaves (parts of canonical leaves with bit for
+// bit their boxes), of candidates and of lower bounds of what a culled box can hold; it is indifferent to the interior topology and to the visiting order — with these
+// differences:
+//   * one step = one 128-byte node = four boxes, tested in the packed min / max form of th_trace3c.h "The step": the slab products are the reference's own (bounds.jl:183-193),
+//     a child is ENTERED when the box grown by gm = max(em, growth) per axis is pierced ahead of the origin (em: slab_test2's margin, on every clause; growth: the
+//     certificate's bound on how far the ray point at a primitive's computed t lies outside the primitive's boxes, header (i)) and its grown entry distance lies below
+//     t_lim + mkz: by (i) and (ii) no candidate inside has its t below (grown entry - mkz).  This per-axis bound serves every launch (camera rays far outside the scene
+//     included: no AXIS variant) and needs no cap on near-axis-parallel rays (the scalar form's growth x max |1 / d| is gone from the push-time test);
+//   * an entry's EXACT entry distance travels with it (the guard reads it at a leaf), its lowest mantissa bit replaced by "not strict" — the un-grown interval was empty or
+//     ended behind the origin, i.e. the reference's own clauses (bounds.jl:186-198) may or may not let it into that box: a candidate found in such a leaf sends the ray to
+//     the reference-order walk.  Strict => every reference clause but the t_max one holds, and max3 of the near products IS the reference's tx_min;
+//   * a popped entry is held against the scalar form t_lim + mb (mb = mkz + growth x max |1 / d|) of the same bound, on its exact entry distance;
+//   * the four children are visited nearest first (a five-comparator network on the exact entry distances); up to three wait on the stack (64 entries: the commit lays a
+//     tree out four wide only when three times its depth fits).
+// Half the dependent node fetches per ray: the binary walk is bound by the latency of one node fetch per step as much as by its instructions (profiles/r5).
+#pragma once
+#include "th_trace3c.h"
+
+namespace th {
+
+#ifndef TH_TRACE3C4_WAVES
+#define TH_TRACE3C4_WAVES 6
+#endif
+#ifndef TH_TRACE3C4_LDS
+#define TH_TRACE3C4_LDS 11
+#endif
+
+template <bool COUNT, bool FULL_ONLY, bool BIG = false>
+__global__ __launch_bounds__(kBlock, BIG ? TH_TRACE3C4_WAVES - 1 : TH_TRACE3C4_WAVES) void k_trace3c4(DeviceScene sc /* prims: the accelerator's order */, WideScene ws /* the accelerator */, CertHot ch,
+                                                                                               const CertCold* __restrict__ cold, SegQueue q, const float4* __restrict__ ro,
+                                                                                               const float4* __restrict__ rd, const float* __restrict__ tmax_or_null, TraceOut out,
+                                                                                               uint32_t* __restrict__ work, uint2* __restrict__ overflow, Counters* ctr) {
+    constexpr int kLds = TH_TRACE3C4_LDS;
+    constexpr bool AXIS = false;  // (one form for every launch: the push-time bound is per axis, the pop-time bound scalar — header)
+    constexpr uint32_t kLeafBit = 1u << 24;  // a node word >= this (and != kRefNone) is a leaf: ref | count << 24
+    constexpr bool FAST = true;   // (entry distances carry the "not strict" bit: th_trace3c.h "The step")
+    __shared__ uint2 s_stk[kLds][kBlock];  // {child word, entry distance}: one 8-byte LDS access per push / pop
+    // per-lane state that is only touched when a ray is fetched, accepted or finished lives in LDS, not in registers (the walk runs at the 80-VGPR line of six waves per
+    // SIMD; a scratch spill costs a trip to memory, an LDS word 64 cycles): the ray's queue index, its state word, the entry distance of the node in hand
+    __shared__ uint32_t s_idx[kBlock];
+    __shared__ uint32_t s_st[kBlock];
+    __shared__ float s_ex[kBlock];
+    __shared__ SegView sv;
+    seg_load(q, sv);
+    const uint32_t tid = threadIdx.x;
+    const uint32_t gthreads = gridDim.x * kBlock;
+    const uint32_t gtid = blockIdx.x * kBlock + tid;
+    const uint32_t lane = lane_id();
+
+    bool active = false, exhausted = false, to_fb = false;
+    uint32_t wseg = __builtin_amdgcn_readfirstlane((gtid >> 6) % kSeg), dry = 0, pool_next = 0, pool_end = 0;  // wave-uniform
+    uint32_t cur = kRefNone;  // kRefNone, an interior node's index (< 2^24), or a leaf word
+    int sp = 0;
+    f3 o = splat3(0.0f), inv_d = splat3(0.0f);
+    float em = 0.0f;
+    RayShear shear{0, 0.0f, 0.0f, 0.0f};
+    // (the direction signs are read off inv_d where they are needed: a ray with a zero component, the one case where sign(1 / d) is not sign(d), never walks here)
+#define negx (inv_d.x < 0.0f)
+#define negy (inv_d.y < 0.0f)
+#define negz (inv_d.z < 0.0f)
+    float t_lim = 0.0f;   // t_max + 2 dt, t_max = the t of the last accepted candidate (or the ray's own t_max): what the primitive tests accept up to; a box is culled when the lower
+                          // bound of what it holds — its entry distance minus the margin — reaches it
+    float gm = 0.0f;      // per ray: the length every box is grown by per axis in the step: max(em, growth) — em for the entering test (slab_test2's margin), growth for the bound below
+    float mkz = 0.0f;     // per ray: the kz-extent part of mb alone: what the per-axis bound of the step adds to t_lim
+    float mb = 0.0f;      // per ray: the margin of the lower bound: non-flat primitives their kz extent, everything the growth in the entering axis (with AXIS the growth is applied per
+                          // axis to the box instead, and is not in here)
+    // s_ex[tid]: entry distance of the node in `cur` (the reference's tx_min of its box)
+    // s_st[tid]: 0: nothing accepted yet, 1: a candidate is; bits 8..: 1 + the sphere the ray started INSIDE of (header: what the reference tests before that sphere does not count)
+    uint32_t nn = 0, np = 0;
+    uint32_t n_fb = 0;    // wave-uniform
+    unsigned long long n_why[4] = {0ull, 0ull, 0ull, 0ull};  // COUNT: why rays went to the canonical tree — 0 direction / finiteness / cap, 1 a sphere (clipped, inside two), 2 near tie / guard; [3]: rays that start INSIDE a sphere and were certified (the order word)
+    uint32_t why = 0;
+
+#ifdef TH_DIAG_PHASES
+    unsigned long long ph_cyc[4] = {0, 0, 0, 0}, ph_lan[4] = {0, 0, 0, 0}, ph_cnt[4] = {0, 0, 0, 0};  // refill (+ hand-over), pop, node, leaf (tools/phase_probe.py)
+#endif
+    auto margin_t = [&]() { return ch.kdt * em * fabsf(shear.sz); };       // dt, from what is live (D = em / tight_scale)
+    auto growth = [&]() { return __fmaf_rn(ch.kgrow, em, ch.gflat); };     // the length by which the ray point at a primitive's computed t can lie outside the primitive's boxes
+    auto inv_max = [&]() { return fmaxf(fmaxf(fabsf(inv_d.x), fabsf(inv_d.y)), fabsf(inv_d.z)); };
+
+    while (true) {
+        // ---- rays for the reference-order walk: appended to the fallback lists ----
+        if (__ballot(to_fb) != 0ull) {
+            const FallbackList fb{uniform_load(&cold->fb_list, 0), uniform_load(&cold->fb_counts, 0), uniform_load(&cold->fb_cap, 0)};
+            n_fb += fallback_append(fb, to_fb, s_idx[tid], __builtin_amdgcn_readfirstlane((gtid >> 6) % kSeg));
+            to_fb = false;
+        }
+        // ---- refill idle lanes (as k_trace3) ----
+        const unsigned long long idle = __ballot(!active);
+        const uint32_t n_idle = (uint32_t)__popcll(idle);
+        if (n_idle == 64u || (!exhausted && n_idle >= (uint32_t)TH_TRACE3C_REFILL)) {
+            TH_PHASE_BEGIN();
+            if (!exhausted) {
+                if (pool_next >= pool_end) {
+                    const uint32_t cnt = __builtin_amdgcn_readfirstlane(sv.count[wseg]);
+                    uint32_t base = cnt, take = (uint32_t)kChunk;
+                    if (lane == 0 && cnt != 0u) {
+                        const uint32_t at = __hip_atomic_load(&work[wseg * kCtrStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (at < cnt) {
+#if TH_TRACE3_SMALL_CHUNKS
+                            if (cnt - at < (uint32_t)TH_TRACE3_SMALL_CHUNKS * (gthreads >> 6) / (uint32_t)kSeg * (uint32_t)kChunk) take = (uint32_t)kChunk / 4u;
+#endif
+                            base = atomicAdd(&work[wseg * kCtrStride], take);
+                        }
+                    }
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    take = __builtin_amdgcn_readfirstlane(take);
+                    if (base < cnt) {
+                        pool_next = base;
+                        pool_end = min(base + take, cnt);
+                        dry = 0;
+                        // ---- the chunk's SPHERE PRE-PASS: every ray of the chunk this wave now owns against every sphere of the scene, 64 rays at a time with ALL lanes (the lanes that
+                        //      are in the middle of a walk work too: their own state just stays where it is).  A sphere is then never hidden from the certificate — whatever the boxes on
+                        //      its path do — and the walk skips sphere primitives.  Done here rather than when a ray is fetched (a dozen lanes at a time, the whole wave paying the
+                        //      transforms, quadratics and their scalar loads: three times k_trace3's refill cost) or in the leaf phase (where the sphere code sets the walk's register
+                        //      count).  The outcome waits in the ray's hit record: {t, slot, state} ----
+                        if (ch.n_spheres != 0u) {
+                            const uint32_t n_chunk = pool_end - pool_next;
+#pragma unroll 1
+                            for (uint32_t i0 = 0; i0 < n_chunk; i0 += 64u) {
+                                const bool valid = i0 + lane < n_chunk;
+                                uint32_t pidx = valid ? seg_phys(q, wseg, pool_next + i0 + lane) : 0u;
+                                if (valid && q.indirect) pidx = q.indirect[pidx];
+                                float4 po4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), pd4 = make_float4(0.0f, 0.0f, 1.0f, 0.0f);
+                                if (valid) {
+                                    po4 = ro[pidx];
+                                    pd4 = rd[pidx];
+                                }
+                                const f3 po = mk3(po4.x, po4.y, po4.z), pd = mk3(pd4.x, pd4.y, pd4.z);
+                                const f3 pinv = mk3(1.0f / pd.x, 1.0f / pd.y, 1.0f / pd.z);
+                                const bool pnx = pd.x < 0.0f, pny = pd.y < 0.0f, pnz = pd.z < 0.0f;
+                                const float pem = slab_margin(ws.root_box, ws.tight_scale, po);
+                                const float pdt = ch.kdt * pem * fabsf(ray_shear(pd).sz);
+                                float p_lim = ((valid && tmax_or_null) ? tmax_or_null[pidx] : kInf) + 2.0f * pdt;
+                                uint32_t pst = 0u;
+                                float4 prec = make_float4(kInf, __int_as_float(-1), 0.0f, 0.0f);
+                                bool pflag = false;
+#pragma unroll 1
+                                for (uint32_t ks = 0; ks < ch.n_spheres; ++ks) {
+                                    const SphereCert sr = uniform_load(ch.spheres, ks);  // wave-uniform: scalar loads, one burst
+                                    float ex;
+                                    if (valid && !pflag && slab_test2(sr.box[0], sr.box[1], sr.box[2], sr.box[3], sr.box[4], sr.box[5], po, pinv, pem, false, pnx, pny, pnz, ex)) {
+                                        if (COUNT) np++;
+                                        float t_c = 0.0f;
+                                        // a sphere the ray starts inside of is taken whatever the limit is (sphere.jl:137-138); one seen from outside up to the relaxed limit
+                                        const int r = sphere_candidate_m<FULL_ONLY>(sr.o2w_inv, sr.radius, sr.never_clipped != 0u, po, pd, p_lim, t_c);
+                                        if (r == 2 || (r != 0 && (pst >> 8) != 0u)) {
+                                            pflag = true;  // clipped; or the ray starts inside a sphere AND meets another one below that sphere's far root: left to the reference's order
+                                        } else if (r != 0) {
+                                            // accepted iff it lies 2 dt below the incumbent (p_lim - 4 dt; the ray's own t_max at first) and its leaf box lets the reference in by then.
+                                            // A sphere the ray starts INSIDE of (r == 3): the reference takes its far root whenever it tests it — and it always does: the box holds the
+                                            // origin (required: ex <= 0), so no t_max culls its path — and forgets what it held; the ray remembers the sphere (state), and of what the
+                                            // walk finds only what the reference tests AFTER that sphere counts (the order word of the primitive records, below)
+                                            if (!(t_c <= p_lim - 4.0f * pdt) || !(ex <= (r == 3 ? 0.0f : t_c + pdt))) {
+                                                pflag = true;
+                                            } else {
+                                                if (COUNT && r == 3) n_why[3]++;  // (not a fallback: rays that start inside a sphere and stay on the accelerator)
+                                                p_lim = t_c + 2.0f * pdt;
+                                                pst = 1u | (r == 3 ? (ks + 1u) << 8 : 0u);
+                                                prec = make_float4(t_c, __uint_as_float(sr.slot), 0.0f, 0.0f);
+                                            }
+                                        }
+                                    }
+                                }
+                                prec.z = __uint_as_float(pflag ? 0x80000000u : pst);
+                                if (valid) out.hits[pidx] = prec;
+                            }
+                            __builtin_amdgcn_s_waitcnt(0);
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (the stores have reached L2: no cache is written back or invalidated — an agent-scope fence writes the XCD's whole L2 back.)  The records are read back past L1 when the rays are fetched
+                        }
+                    } else {
+                        pool_next = pool_end = 0;
+                        wseg = (wseg + 1) % kSeg;
+                        if (++dry >= (uint32_t)kSeg) exhausted = true;
+                    }
+                }
+                const uint32_t avail = pool_end - pool_next;
+                if (avail && !active) {
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+                    if (rank < avail) {
+                        uint32_t idx = seg_phys(q, wseg, pool_next + rank);
+                        if (q.indirect) idx = q.indirect[idx];
+                        s_idx[tid] = idx;
+                        uint32_t st = 0u;
+                        const float4 o4 = ro[idx], d4 = rd[idx];
+                        o = mk3(o4.x, o4.y, o4.z);
+                        const f3 d = mk3(d4.x, d4.y, d4.z);
+                        inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                        em = slab_margin(ws.root_box, ws.tight_scale, o);
+                        shear = ray_shear(d);
+                        const float t_own = tmax_or_null ? tmax_or_null[idx] : kInf;
+                        const float dt = margin_t();
+                        const float mkz_ = (shear.kz == 0 ? ch.mle[0] : (shear.kz == 1 ? ch.mle[1] : ch.mle[2])) * fabsf(shear.sz);
+                        mkz = mkz_;
+                        gm = fmaxf(em, growth());
+                        mb = __fmaf_rn(growth(), inv_max(), mkz_);  // the scalar form: what a popped entry's exact entry distance is held against
+                        t_lim = t_own + 2.0f * dt;
+                        sp = 0;
+                        active = true;
+                        if (COUNT) nn++;
+                        // what the certificate does not cover goes to the reference-order walk at once: a zero or non-finite direction component (0 x Inf = NaN in the slab
+                        // products), a non-finite origin or margin, a NaN t_max — and near-axis-parallel rays, whose scalar margin would make the walk overshoot every hit
+                        // (kCertCap; with AXIS the margin is per axis: no cap)
+                        const bool plain = d.x != 0.0f && d.y != 0.0f && d.z != 0.0f && mb < kInf && fabsf(o.x) < kInf && fabsf(o.y) < kInf && fabsf(o.z) < kInf && fabsf(inv_d.x) < kInf &&
+                                           fabsf(inv_d.y) < kInf && fabsf(inv_d.z) < kInf && t_own == t_own;  // (no cap on near-axis-parallel rays: the step's bound is per axis)
+                        float tmin;
+                        if (!plain) {
+                            to_fb = true;
+                            active = false;
+                            if (COUNT) n_why[0]++;
+                        } else if (ws.root_ref != kRefNone && slab_test2(ws.root_box[0], ws.root_box[1], ws.root_box[2], ws.root_box[3], ws.root_box[4], ws.root_box[5], o, inv_d, em, false, negx, negy, negz, tmin)) {
+                            cur = ws.root_ref | (ws.root_cnt << 24);  // (the root is not culled by t: the reference's clause `tmin < t_max` holds whenever anything inside can be accepted)
+                            s_ex[tid] = FAST ? __uint_as_float(__float_as_uint(tmin) & ~1u) : tmin;  // (FAST: bit 0 of an entry distance = "not strict"; the root passed the reference's own clauses)
+                            // the sphere pre-pass of the chunk left this ray's state in its hit record: an accepted sphere (the incumbent), the sphere it starts inside of, or
+                            // "to the reference-order walk"
+                            bool flagged = false;
+                            if (ch.n_spheres != 0u) {
+                                const float* recp = reinterpret_cast<const float*>(&out.hits[idx]);
+                                st = __float_as_uint(__hip_atomic_load(recp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                                flagged = (st >> 31) != 0u;
+                                st &= 0x7fffffffu;
+                                if (st & 1u) t_lim = __hip_atomic_load(recp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 2.0f * dt;
+                            }
+                            s_st[tid] = st;
+                            if (flagged) {
+                                to_fb = true;
+                                active = false;
+                                if (COUNT) n_why[1]++;
+                            }
+                        } else {
+                            cur = kRefNone;
+                            s_st[tid] = 0u;
+                        }
+                    }
+                }
+                pool_next += min(n_idle, avail);
+            }
+            TH_PHASE_END(0, n_idle);
+            if (__ballot(active) == 0ull) {
+                if (__ballot(to_fb) != 0ull) continue;  // flush first
+                if (exhausted) break;
+                continue;
+            }
+        }
+        // ---- phase A: interior steps and pops; lanes holding a leaf wait (k_trace3's schedule).  A lane WITHOUT a node (both children failed and the stack top was dead, a leaf
+        //      that left a dead top) takes part in the step's tail instead of a pop section of its own: the tail reads the stack top anyway (k_trace3's in-step pop) — one entry per
+        //      round, dead ones dropped; what is left of the pop section is the delivery of the rays whose stack is empty ----
+#pragma unroll 1
+        for (int it = 0; it < TH_TRACE3C_MAX_A; ++it) {
+#ifdef TH_DIAG_PHASES
+            const unsigned long long ph_pop_m = __ballot(active && cur == kRefNone && sp == 0);
+            const unsigned long long ph_t_pop = __builtin_readcyclecounter();
+#endif
+            if (active && cur == kRefNone && sp == 0) {  // the walk is over: a certified hit (stored when it was accepted) or a certified miss
+                active = false;
+                const uint32_t fst = s_st[tid] & 3u;  // bit 0: a hit is held; bit 1: the walk stored it (else it is the pre-pass's sphere record, whose third lane holds the state)
+                if (fst == 0u) out.hits[s_idx[tid]] = make_float4(kInf, __int_as_float(-1), 0.0f, 0.0f);
+                else if (fst == 1u) reinterpret_cast<float*>(&out.hits[s_idx[tid]])[2] = 0.0f;
+            }
+#ifdef TH_DIAG_PHASES
+            {
+                const unsigned long long now = __builtin_readcyclecounter();
+                ph_cyc[1] += now - ph_t_pop;
+                ph_lan[1] += (unsigned long long)__popcll(ph_pop_m);
+                ph_cnt[1] += 1ull;
+            }
+            const unsigned long long ph_node_m = __ballot(active && (cur < kLeafBit || cur == kRefNone));
+            const unsigned long long ph_t_node = __builtin_readcyclecounter();
+#endif
+            const bool stepping = active && cur < kLeafBit;
+            if (stepping || (active && cur == kRefNone)) {
+                float4 a0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), a1 = a0, a2 = a0, a3 = a0, a4 = a0, a5 = a0, a6 = a0;
+                if (stepping) {  // interior: one 128-byte line, four child boxes
+                    const float4* np = ws.w4nodes + 8 * (size_t)cur;
+                    a0 = np[0];
+                    a1 = np[1];
+                    a2 = np[2];
+                    a3 = np[3];
+                    a4 = np[4];
+                    a5 = np[5];
+                    a6 = np[6];
+                }
+                uint32_t top_enc = kRefNone;
+                float top_tm = kInf;
+                if (sp > 0) {
+                    if (sp - 1 < kLds) {
+                        const uint2 e = s_stk[sp - 1][tid];
+                        top_enc = e.x;
+                        top_tm = __uint_as_float(e.y);
+                    } else if (sp - 1 < kStack2Total) {
+                        const uint2 e = overflow[(size_t)(sp - 1 - kLds) * gthreads + gtid];
+                        top_enc = e.x;
+                        top_tm = __uint_as_float(e.y);
+                    }
+                }
+                const float t_pop = t_lim + mb;  // (scalar form, against an exact entry distance)
+                uint32_t n_go = 0;
+                float ex_new = 0.0f;
+                cur = kRefNone;
+                if (stepping) {
+                    if (COUNT) nn += 4;
+                    const float t_push = t_lim + mkz;  // (per-axis form, against the entry distance of the box grown by gm >= growth: header)
+                    const v2f p_a = v2f{o.x, o.y}, p_b = v2f{o.z, inv_d.x}, p_c = v2f{inv_d.y, inv_d.z};
+                    const float gx = gm * fabsf(inv_d.x), gy = gm * fabsf(inv_d.y), gz = gm * fabsf(inv_d.z);
+                    // one child: its three {min, max} pairs -> the sort key (its exact entry distance with the "not strict" bit, +Inf when it is not entered)
+                    auto child = [&](v2f X, v2f Y, v2f Z) {
+                        const v2f Tx = pk_mul_h<1>(pk_sub_h<0>(X, p_a), p_b), Ty = pk_mul_h<0>(pk_sub_h<1>(Y, p_a), p_c), Tz = pk_mul_h<1>(pk_sub_h<0>(Z, p_b), p_c);  // bounds.jl:183-193: (plane - o) x inv_d
+                        const float nx = amin(Tx.x, Tx.y), fx = amax(Tx.x, Tx.y), ny = amin(Ty.x, Ty.y), fy = amax(Ty.x, Ty.y), nz = amin(Tz.x, Tz.y), fz = amax(Tz.x, Tz.y);
+                        const float t_in = amax3(nx, ny, nz), t_out = amin3(fx, fy, fz);  // = bounds.jl:196's tx_min; <= :197's tx_max
+                        const float g_in = amax3(nx - gx, ny - gy, nz - gz), g_out = amin3(fx + gx, fy + gy, fz + gz);  // the box grown by gm per axis
+                        // two lower bounds of what the box can hold, either may cull: the scalar one on the exact entry distance (tight for rays that start inside the scene), the
+                        // per-axis one on the grown box (tight for camera rays far outside, whose max |1 / d| makes the scalar margin useless)
+#if defined(TH_W4_DIAG_STRICT)
+                        const bool enter = (t_in <= t_out) && (t_out > 0.0f) && (t_in < t_pop);  // DIAGNOSTIC (unsound): no margin at all
+#elif defined(TH_W4_DIAG_SCALAR)
+                        const bool enter = (g_in <= g_out) && (g_out >= 0.0f) && (t_in < t_pop);  // DIAGNOSTIC: the scalar bound alone
+#else
+                        const bool enter = (g_in <= g_out) && (g_out >= 0.0f) && (g_in < t_push) && (t_in < t_pop);
+#endif
+                        const bool strict = (t_in <= t_out) && (t_out > 0.0f);  // every clause of bounds.jl:186-198 but the t_max one then holds
+                        // what travels is max(entry, 0): boxes that hold the origin (every ray spawned on a surface starts inside its own leaf's box and that box's ancestors) tie at 0
+                        // instead of sorting the LARGEST box first; both readers stay right — the guard wants an upper bound of the entry distance, a popped entry below 0 passes anyway
+                        const float coded = __uint_as_float((__float_as_uint(fmaxf(t_in, 0.0f)) & ~1u) | (strict ? 0u : 1u));
+                        return enter ? coded : kInf;
+                    };
+                    float k0 = child(v2f{a0.x, a0.y}, v2f{a0.z, a0.w}, v2f{a1.x, a1.y});
+                    float k1 = child(v2f{a1.z, a1.w}, v2f{a2.x, a2.y}, v2f{a2.z, a2.w});
+                    float k2 = child(v2f{a3.x, a3.y}, v2f{a3.z, a3.w}, v2f{a4.x, a4.y});
+                    float k3 = child(v2f{a4.z, a4.w}, v2f{a5.x, a5.y}, v2f{a5.z, a5.w});
+                    uint32_t e0 = __float_as_uint(a6.x), e1 = __float_as_uint(a6.y), e2 = __float_as_uint(a6.z), e3 = __float_as_uint(a6.w);
+                    // nearest first (a five-comparator network on {key, child word}); a child that is not entered sorts last
+#define TH_CSWAP(ka, kb, ea, eb)              \
+    {                                         \
+        const bool sw = kb < ka;              \
+        const float tk = sw ? kb : ka;        \
+        const uint32_t te = sw ? eb : ea;     \
+        kb = sw ? ka : kb;                    \
+        eb = sw ? ea : eb;                    \
+        ka = tk;                              \
+        ea = te;                              \
+    }
+#ifndef TH_W4_DIAG_NOSORT
+                    TH_CSWAP(k0, k1, e0, e1);
+                    TH_CSWAP(k2, k3, e2, e3);
+                    TH_CSWAP(k0, k2, e0, e2);
+                    TH_CSWAP(k1, k3, e1, e3);
+                    TH_CSWAP(k1, k2, e1, e2);
+#else  // DIAGNOSTIC: slot order, the entered ones first
+                    {
+                        float kk[4] = {k0, k1, k2, k3};
+                        uint32_t ee[4] = {e0, e1, e2, e3};
+                        float ok[4] = {kInf, kInf, kInf, kInf};
+                        uint32_t oe[4] = {e0, e0, e0, e0};
+                        int w = 0;
+                        for (int j = 0; j < 4; ++j)
+                            if (kk[j] < kInf) {
+                                for (int m = 0; m < 4; ++m)
+                                    if (m == w) {
+                                        ok[m] = kk[j];
+                                        oe[m] = ee[j];
+                                    }
+                                w++;
+                            }
+                        k0 = ok[0], k1 = ok[1], k2 = ok[2], k3 = ok[3];
+                        e0 = oe[0], e1 = oe[1], e2 = oe[2], e3 = oe[3];
+                    }
+#endif
+#undef TH_CSWAP
+                    n_go = (k0 < kInf ? 1u : 0u) + (k1 < kInf ? 1u : 0u) + (k2 < kInf ? 1u : 0u) + (k3 < kInf ? 1u : 0u);
+                    // the far ones wait on the stack, the farthest deepest (an entry that fails now fails at pop time: t_lim never goes up in this walk)
+                    auto store = [&](int pos, uint32_t enc, float tm) {
+                        if (pos < kLds) {
+                            s_stk[pos][tid] = make_uint2(enc, __float_as_uint(tm));
+                        } else if (pos < kStack2Total) {
+                            overflow[(size_t)(pos - kLds) * gthreads + gtid] = make_uint2(enc, __float_as_uint(tm));
+                        }
+                    };
+                    if (n_go > 3u) store(sp + (int)n_go - 4, e3, k3);
+                    if (n_go > 2u) store(sp + (int)n_go - 3, e2, k2);
+                    if (n_go > 1u) store(sp + (int)n_go - 2, e1, k1);
+                    if (n_go > 1u) sp += (int)n_go - 1;
+                    if (n_go) {
+                        cur = e0;
+                        ex_new = k0;
+                    }
+                }
+                if (n_go == 0u && sp > 0) {  // nothing was pushed in this step: the top read above is still the top
+                    sp--;
+                    if (top_tm < t_pop && sp < kStack2Total) {
+                        cur = top_enc;
+                        ex_new = top_tm;
+                    }
+                }
+                s_ex[tid] = ex_new;
+            }
+#ifdef TH_DIAG_PHASES
+            ph_cyc[2] += __builtin_readcyclecounter() - ph_t_node;
+            ph_lan[2] += (unsigned long long)__popcll(ph_node_m);
+            ph_cnt[2] += 1ull;
+#endif
+            const uint32_t n_desc = (uint32_t)__popcll(__ballot(active && (cur < kLeafBit || cur == kRefNone)));
+            if (n_desc <= (uint32_t)TH_TRACE3C_LEAF_WAIT) break;
+        }
+        // ---- phase B: leaves ----
+#ifdef TH_DIAG_PHASES
+        const unsigned long long ph_leaf_m = __ballot(active && cur >= kLeafBit && cur != kRefNone);
+        const unsigned long long ph_t_leaf = __builtin_readcyclecounter();
+#endif
+        if (active && cur >= kLeafBit && cur != kRefNone) {
+            bool flagged = false;
+            const uint32_t leaf_ref = cur & 0x00ffffffu, leaf_cnt = cur >> 24;
+            uint32_t top_enc = kRefNone;
+            float top_tm = kInf;
+            if (sp > 0) {
+                if (sp - 1 < kLds) {
+                    const uint2 e = s_stk[sp - 1][tid];
+                    top_enc = e.x;
+                    top_tm = __uint_as_float(e.y);
+                } else if (sp - 1 < kStack2Total) {
+                    const uint2 e = overflow[(size_t)(sp - 1 - kLds) * gthreads + gtid];
+                    top_enc = e.x;
+                    top_tm = __uint_as_float(e.y);
+                }
+            }
+            for (uint32_t k = 0; k < leaf_cnt; ++k) {
+                const uint32_t slot = leaf_ref + k;
+                const float4 p0 = sc.prims[3 * slot];
+                const float4 p1 = sc.prims[3 * slot + 1], p2 = sc.prims[3 * slot + 2];
+                asm volatile("" ::"v"(p1.x), "v"(p1.y), "v"(p1.z), "v"(p1.w), "v"(p2.x), "v"(p2.y), "v"(p2.z), "v"(p2.w));  // one burst (th_trace2.h "one fetch per leaf")
+                const uint32_t meta = __float_as_uint(p0.w);
+                if (COUNT) np++;
+                TriTest tt;
+                // (spheres were tested when the ray was fetched)
+                if (!(meta & (PRIM_SPHERE | PRIM_DEGENERATE)) && tri_intersect_sheared<true>(mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z), o, shear, t_lim, &tt)) {
+                    // a candidate below the relaxed limit.  A ray that started inside sphere s: only what the reference tests AFTER s counts — s overwrites the rest (header); the
+                    // primitive's order word (the third record's .w lane) holds, per sphere, the split axis of the canonical node where their paths part and the child it is in
+                    bool counts = true;
+                    const uint32_t st = s_st[tid];
+                    if (st >> 8) {
+                        const uint32_t ow = __float_as_uint(p2.w) >> (3u * ((st >> 8) - 1u));
+                        const uint32_t ax = ow & 3u;
+                        const bool second = (ow & 4u) != 0u;  // the primitive sits in the second child there (axis 3: in the sphere's own leaf, behind it)
+                        counts = ax == 3u ? second : (second != (ax == 0u ? negx : (ax == 1u ? negy : negz)));  // bvh.jl:239-246: the second child is visited first iff d[axis] < 0
+                    }
+                    if (counts) {
+                        const float dt = margin_t();
+                        // accepted iff it lies 2 dt below the incumbent (t_lim - 4 dt; the ray's own t_max at first) AND its leaf box lets the reference in by t + dt (the guard); a NaN fails
+                        // (FAST: the entry distance lost its lowest mantissa bit to the "not strict" flag: the guard reads the larger of the two numbers it can have been)
+                        const float ex = s_ex[tid];
+                        const float ex_hi = __uint_as_float(ex < 0.0f ? __float_as_uint(ex) & ~1u : __float_as_uint(ex) | 1u);
+                        if (!(tt.t <= t_lim - 4.0f * dt) || (FAST ? ((__float_as_uint(ex) & 1u) != 0u || !(ex_hi <= tt.t + dt)) : !(ex <= tt.t + dt))) {
+                            if (COUNT && !flagged) why = 2u;
+                            flagged = true;
+                        } else if (!flagged) {
+                            t_lim = tt.t + 2.0f * dt;
+                            s_st[tid] = st | 3u;
+                            out.hits[s_idx[tid]] = make_float4(out.bary_mode ? tt.bary.z : tt.t, p1.w /* the canonical slot */, tt.bary.x, tt.bary.y);  // stored at once: a nearer candidate overwrites it
+                        }
+                    }
+                }
+            }
+            cur = kRefNone;
+            if (flagged) {  // the reference-order walk decides this ray
+                active = false;
+                to_fb = true;
+                sp = 0;
+                if (COUNT) n_why[why & 3u]++;
+            } else if (sp > 0) {  // the next stack entry against the limit the leaf left
+                sp--;
+                const float t_pop = t_lim + (AXIS ? __fmaf_rn(growth(), inv_max(), mb) : mb);
+                if (top_tm < t_pop && sp < kStack2Total) {
+                    cur = top_enc;
+                    s_ex[tid] = top_tm;
+                }
+            }
+        }
+#ifdef TH_DIAG_PHASES
+        ph_cyc[3] += __builtin_readcyclecounter() - ph_t_leaf;
+        ph_lan[3] += (unsigned long long)__popcll(ph_leaf_m);
+        ph_cnt[3] += 1ull;
+#endif
+    }
+#ifdef TH_DIAG_PHASES
+    if (lane == 0)
+        for (int k4 = 0; k4 < 4; ++k4) {
+            atomicAdd(&g_phase[3 * k4], ph_cyc[k4]);
+            atomicAdd(&g_phase[3 * k4 + 1], ph_lan[k4]);
+            atomicAdd(&g_phase[3 * k4 + 2], ph_cnt[k4]);
+        }
+#endif
+    if (ctr) {
+        if (blockIdx.x == 0 && threadIdx.x == 0 && !q.no_total) atomicAdd(&ctr->closest_total, (unsigned long long)seg_total(sv));
+        if (lane_id() == 0 && n_fb) atomicAdd(&ctr->fallback_total, (unsigned long long)n_fb);
+        if (COUNT) {
+            const unsigned long long sn = wave_sum(nn), spr = wave_sum(np);
+            if (lane_id() == 0) {
+                atomicAdd(&ctr->nodes_closest, sn);
+                atomicAdd(&ctr->prims_closest, spr);
+            }
+            for (int k = 0; k < 4; ++k) {
+                const unsigned long long w = wave_sum(n_why[k]);
+                if (lane_id() == 0 && w) atomicAdd(&ctr->fallback_why[k], w);
+            }
+        }
+    }
+}
+#undef negx
+#undef negy
+#undef negz
+
+}  // namespace th

@@ -37,7 +37,7 @@ namespace th {
 #endif
 
 // levels per resident thread of the global stack slab: what k_trace2 / k_trace3 need of it, or two rays' worth for k_trace4
-constexpr int kStackSlabLevels = (kStack2Total - kStackMinLds) > 2 * (kStack2Total - TH_TRACE4_LDS) ? (kStack2Total - kStackMinLds) : 2 * (kStack2Total - TH_TRACE4_LDS);
+static_assert(kStackSlabLevels >= 2 * (kStack2Total - TH_TRACE4_LDS), "the overflow slab (th_trace2.h kStackSlabLevels) holds two rays' levels per lane");
 
 struct Ray4 {  // one of a lane's two rays
     uint32_t idx, cur, cur_cnt;

@@ -24,7 +24,7 @@ struct WhittedFlags {
 };
 
 // One tree level: interaction, BSDF (allow_multiple_lobes = false), per-light shadow rays, ≤ 2 specular children.
-static __global__ __launch_bounds__(kBlock) void k_shade_whitted(DeviceScene sc, PathQueue qin, PathQueue qout, ShadowQueue sq, uint32_t cap, uint32_t cap_shadow, const float4* __restrict__ hits,
+template <int TH_ONE_COPY = 0> __global__ __launch_bounds__(kBlock) void k_shade_whitted(DeviceScene sc, PathQueue qin, PathQueue qout, ShadowQueue sq, uint32_t cap, uint32_t cap_shadow, const float4* __restrict__ hits,
                                                           WhittedPool pool, uint32_t base_in, uint32_t base_out, Counters* ctr, WhittedFlags* flags, int depth, int max_depth) {
     __shared__ SegView sv;
     const SegQueue qv{ctr->n_queue[depth - 1], cap, 0u};
@@ -128,7 +128,7 @@ static __global__ __launch_bounds__(kBlock) void k_shade_whitted(DeviceScene sc,
 }
 
 // `l += f * sampled_li * abs(wi ⋅ n) / pdf` for light `light`, for every unoccluded shadow ray of this level (:91-93).
-static __global__ __launch_bounds__(kBlock) void k_whitted_direct(SegQueue q, ShadowQueue sq, const uint8_t* __restrict__ occluded, uint32_t light, float4* __restrict__ node_L) {
+template <int TH_ONE_COPY = 0> __global__ __launch_bounds__(kBlock) void k_whitted_direct(SegQueue q, ShadowQueue sq, const uint8_t* __restrict__ occluded, uint32_t light, float4* __restrict__ node_L) {
     __shared__ SegView sv;
     seg_load(q, sv);
     const uint32_t total = sv.prefix[kSeg];
@@ -150,7 +150,7 @@ static __global__ __launch_bounds__(kBlock) void k_whitted_direct(SegQueue q, Sh
     }
 }
 // Fold one level into its parents: `l += f * li(child) * abs(wi ⋅ ns) / pdf` for the children of branch `branch`.
-static __global__ __launch_bounds__(kBlock) void k_whitted_resolve(SegQueue q, WhittedPool pool, uint32_t base, uint32_t branch) {
+template <int TH_ONE_COPY = 0> __global__ __launch_bounds__(kBlock) void k_whitted_resolve(SegQueue q, WhittedPool pool, uint32_t base, uint32_t branch) {
     __shared__ SegView sv;
     seg_load(q, sv);
     const uint32_t total = sv.prefix[kSeg];
@@ -174,7 +174,7 @@ static __global__ __launch_bounds__(kBlock) void k_whitted_resolve(SegQueue q, W
     }
 }
 // Level 1 (camera rays): node radiance -> per-sample radiance buffer indexed by slot.
-static __global__ __launch_bounds__(kBlock) void k_whitted_finish(SegQueue q, const uint32_t* __restrict__ root_slot, const float4* __restrict__ node_L, float4* __restrict__ L) {
+template <int TH_ONE_COPY = 0> __global__ __launch_bounds__(kBlock) void k_whitted_finish(SegQueue q, const uint32_t* __restrict__ root_slot, const float4* __restrict__ node_L, float4* __restrict__ L) {
     __shared__ SegView sv;
     seg_load(q, sv);
     const uint32_t total = sv.prefix[kSeg];

@@ -158,6 +158,14 @@ static int film_collective(trhip_ctx* ctx, void* d_xyzw, uint64_t n_pixels, int 
 int trhip_film_reduce(trhip_ctx* ctx, void* d_xyzw, uint64_t n_pixels, int root) { return film_collective(ctx, d_xyzw, n_pixels, root, false); }
 int trhip_film_allreduce(trhip_ctx* ctx, void* d_xyzw, uint64_t n_pixels) { return film_collective(ctx, d_xyzw, n_pixels, 0, true); }
 
+// Kernel families that lost their measurements (traversals 4 / 6 / 7, the leaf queue, the sorted one-leaf walk, the linear BVH builder) are compiled only with
+// -DTRHIP_EXPERIMENTS (__graft_entry__.build_library(extra_flags=["-DTRHIP_EXPERIMENTS"], out_name="libtracehip_experiments.so")); the default library refuses their options.
+#ifdef TRHIP_EXPERIMENTS
+static constexpr bool kExperiments = true;
+#else
+static constexpr bool kExperiments = false;
+#endif
+static const char* const kNeedsExperiments = "needs the EXPERIMENTS build of the library (-DTRHIP_EXPERIMENTS): not in the default binary";
 int trhip_set_option(trhip_ctx* ctx, const char* name, int64_t value) {
     if (!ctx || !name) return fail(ctx, TRHIP_ERR_INVALID, "null argument");
     if (!std::strcmp(name, "count_visits"))
@@ -176,8 +184,10 @@ int trhip_set_option(trhip_ctx* ctx, const char* name, int64_t value) {
         ctx->stream_budget_min = (uint32_t)std::max<int64_t>(1, value);
     else if (!std::strcmp(name, "sppm_batch"))
         ctx->sppm_batch = (uint64_t)std::max<int64_t>(0, value);
-    else if (!std::strcmp(name, "bvh_builder"))
+    else if (!std::strcmp(name, "bvh_builder")) {
+        if (value == 1 && !kExperiments) return fail(ctx, TRHIP_ERR_UNSUPPORTED, "bvh_builder = 1 (the linear BVH) %s", kNeedsExperiments);
         ctx->bvh_builder = value < 0 ? -1 : (value > 4 ? 4 : (int)value);
+    }
     else if (!std::strcmp(name, "hybrid"))
         ctx->hybrid = value != 0;
     else if (!std::strcmp(name, "film_transpose"))
@@ -190,8 +200,10 @@ int trhip_set_option(trhip_ctx* ctx, const char* name, int64_t value) {
         ctx->occluder_pretest = value != 0;
     else if (!std::strcmp(name, "stream2_priority"))
         ctx->stream2_priority = (int)value;
-    else if (!std::strcmp(name, "leaf_sorted"))
+    else if (!std::strcmp(name, "leaf_sorted")) {
+        if (value != 0 && !kExperiments) return fail(ctx, TRHIP_ERR_UNSUPPORTED, "leaf_sorted %s", kNeedsExperiments);
         ctx->leaf_sorted = value != 0;
+    }
     else if (!std::strcmp(name, "film_fused"))
         ctx->film_fused = value != 0;
     else if (!std::strcmp(name, "trace3_spec"))
@@ -210,8 +222,12 @@ int trhip_set_option(trhip_ctx* ctx, const char* name, int64_t value) {
         ctx->film_relayout = value != 0;
     else if (!std::strcmp(name, "any_on_accelerator"))
         ctx->any_on_accelerator = value < 0 ? -1 : (value != 0 ? 1 : 0);
-    else if (!std::strcmp(name, "leaf_queue"))
+    else if (!std::strcmp(name, "leaf_queue")) {
+        if (value != 0 && !kExperiments) return fail(ctx, TRHIP_ERR_UNSUPPORTED, "leaf_queue %s", kNeedsExperiments);
         ctx->leaf_queue = value != 0;
+    }
+    else if (!std::strcmp(name, "wide4"))
+        ctx->wide4 = value != 0;
     else if (!std::strcmp(name, "node_layout")) {
         if (value < 0 || value > 1) return fail(ctx, TRHIP_ERR_INVALID, "node_layout: 0 (depth-first) or 1 (sibling pairs per 128-byte line)");
         ctx->node_layout = (int)value;
@@ -226,6 +242,7 @@ int trhip_set_option(trhip_ctx* ctx, const char* name, int64_t value) {
         ctx->overlap = value != 0;
     else if (!std::strcmp(name, "traversal")) {
         if (value < 1 || value > 7 || value == 5) return fail(ctx, TRHIP_ERR_INVALID, "traversal must be 1, 2, 3, 4, 6 or 7");
+        if ((value == 4 || value == 6 || value == 7) && !kExperiments) return fail(ctx, TRHIP_ERR_UNSUPPORTED, "traversal %d %s", (int)value, kNeedsExperiments);
         ctx->traversal = (int)value;
     } else if (!std::strcmp(name, "batch_paths")) {
         if (value < 0) return fail(ctx, TRHIP_ERR_INVALID, "batch_paths must be >= 0 (0 = auto)");

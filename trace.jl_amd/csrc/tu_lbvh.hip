@@ -1,11 +1,14 @@
 // tu_lbvh.hip — BVHAccel construction on the device (th_lbvh.h).
 #include "th_host.h"
 #include "th_sppm.h"
+#ifdef TRHIP_EXPERIMENTS
 #include "th_lbvh.h"
+#endif
 #include "th_sahb.h"
 
 // BVHAccel on the device (th_lbvh.h): returns TRHIP_ERR_UNSUPPORTED when the tree is deeper than the traversal stack allows
 // (the caller then falls back to the host builder).
+#ifdef TRHIP_EXPERIMENTS
 int build_bvh_device(trhip_ctx* ctx, const std::vector<HostAABB>& pb, FlatBVH& out) {
     const uint32_t n = (uint32_t)pb.size();
     if (n < 2 || n >= (1u << 30)) return TRHIP_ERR_UNSUPPORTED;
@@ -68,6 +71,9 @@ int build_bvh_device(trhip_ctx* ctx, const std::vector<HostAABB>& pb, FlatBVH& o
     out.max_depth = misc[6];
     return 0;
 }
+#else  // the linear BVH (option bvh_builder = 1: +25-35 % node visits against the SAH builders) is an EXPERIMENTS-build kernel set
+int build_bvh_device(trhip_ctx*, const std::vector<HostAABB>&, FlatBVH&) { return TRHIP_ERR_UNSUPPORTED; }
+#endif
 
 // BVHAccel on the device with the host builder's binned SAH (th_sahb.h).  TRHIP_ERR_UNSUPPORTED: a scene this builder hands back to the host
 // (a large set of coincident centroids, a tree past depth 39 before the nodes get small, a leaf hint above kSahSmall).

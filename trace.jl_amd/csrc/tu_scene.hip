@@ -509,6 +509,7 @@ int upload_scene(trhip_scene* s) {
     // ---- 8-wide nodes over the triangles' subtree for k_trace8 (th_wide8.h) ----
     s->w8_ok = false;
     std::memset(&s->w8, 0, sizeof s->w8);
+#ifdef TRHIP_EXPERIMENTS  // (traversal 4 is a kernel family of the EXPERIMENTS build: the default commit does not build its view)
     if (s->wide_ok && s->wide.root_cnt == 0 && n_nodes >= 3 && !has_empty_leaf) {
         // root of the triangles' subtree: the whole tree when the scene has no sphere; with spheres the commit composed
         // root -> {leaf of all spheres (flat node 1), triangles (flat node 2)} (compose_bvh)
@@ -548,6 +549,7 @@ int upload_scene(trhip_scene* s) {
             }
         }
     }
+#endif
     clk.tick("upload: 8-wide view");
     // ---- one-leaf scenes: the boxes of the leaf's triangles, for the candidate masks of k_leaf_sorted (th_leaf2.h) ----
     release(s->d_leaf_boxes);
@@ -1071,6 +1073,87 @@ static int upload_accelerator_impl(trhip_scene* s, bool conformed) {
     if (int rc = upload(ctx, s->d_acc_wnodes, wn.data(), wn.size() * sizeof(float4))) return rc;
     s->wide_acc.wnodes = (const float4*)s->d_acc_wnodes.p;
     s->wide_acc.n_wnodes = n_int;
+    // ---- the same tree FOUR children wide (th_trace3c4.h): every other level of the binary tree folded into its parent, the widest child first (by surface area) while fewer
+    //      than four slots are taken.  128 bytes per node = one L2 line: {min, max} pairs per axis of child 0 … 3 (six float4), the four child words (leaf: first primitive |
+    //      count << 24 — the accelerator's leaves, i.e. parts of canonical leaves with exactly their boxes, untouched; interior: index of the 4-wide node), one spare float4.
+    //      An empty slot holds NaN planes (every comparison false: never entered).  The certified walk is free in its order and in its topology (th_trace3c.h header): half
+    //      the dependent node fetches per ray.
+    s->wide_acc.w4nodes = nullptr;
+    s->wide_acc.n_w4nodes = 0;
+    if (ctx->wide4) {
+        struct Frame { uint32_t node, out; };
+        std::vector<float4> w4;
+        w4.reserve((size_t)n_int / 2 * 8 + 64);
+        std::vector<Frame> todo;
+        todo.push_back({0u, 0u});
+        w4.resize(8);
+        uint32_t max_depth4 = 0;
+        std::vector<uint32_t> depth4{1u};  // per 4-wide node
+        bool ok4 = (s->acc.flags[0] & 3u) != 3u;
+        auto area = [&](uint32_t n) {
+            const float* b = &s->acc.bounds[6 * (size_t)n];
+            const float dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2];
+            return dx * dy + dx * dz + dy * dz;
+        };
+        while (ok4 && !todo.empty()) {
+            const Frame f = todo.back();
+            todo.pop_back();
+            uint32_t kids[4];
+            int nk = 2;
+            kids[0] = f.node + 1;
+            kids[1] = s->acc.a[f.node];
+            while (nk < 4) {
+                int best = -1;
+                float best_a = -1.0f;
+                for (int k = 0; k < nk; ++k)
+                    if ((s->acc.flags[kids[k]] & 3u) != 3u && area(kids[k]) > best_a) {
+                        best_a = area(kids[k]);
+                        best = k;
+                    }
+                if (best < 0) break;
+                const uint32_t c = kids[best];
+                kids[best] = c + 1;
+                kids[nk++] = s->acc.a[c];
+            }
+            float4 rec[8];
+            const float qn = std::nanf("");
+            float planes[24];
+            uint32_t enc[4] = {1u << 24, 1u << 24, 1u << 24, 1u << 24};
+            for (int k = 0; k < 24; ++k) planes[k] = qn;
+            for (int k = 0; k < nk; ++k) {
+                const uint32_t c = kids[k];
+                const float* b = &s->acc.bounds[6 * (size_t)c];
+                for (int a = 0; a < 3; ++a) {
+                    planes[6 * k + 2 * a] = b[a];
+                    planes[6 * k + 2 * a + 1] = b[3 + a];
+                }
+                if ((s->acc.flags[c] & 3u) == 3u) {
+                    const uint32_t cnt = s->acc.flags[c] >> 2;
+                    if (cnt == 0 || cnt > 255) ok4 = false;
+                    enc[k] = s->acc.a[c] | (cnt << 24);
+                } else {
+                    const uint32_t idx = (uint32_t)(w4.size() / 8);
+                    if (idx >= (1u << 24)) ok4 = false;
+                    enc[k] = idx;
+                    w4.resize(w4.size() + 8);
+                    depth4.push_back(depth4[f.out] + 1);
+                    max_depth4 = std::max(max_depth4, depth4.back());
+                    todo.push_back({c, idx});
+                }
+            }
+            for (int j = 0; j < 6; ++j) rec[j] = make_float4(planes[4 * j], planes[4 * j + 1], planes[4 * j + 2], planes[4 * j + 3]);
+            rec[6] = make_float4(__builtin_bit_cast(float, enc[0]), __builtin_bit_cast(float, enc[1]), __builtin_bit_cast(float, enc[2]), __builtin_bit_cast(float, enc[3]));
+            rec[7] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            std::memcpy(&w4[8 * (size_t)f.out], rec, sizeof rec);
+        }
+        // the walk pushes up to three entries per level: its 64-entry stack holds a tree of at most 21 four-wide levels (a deeper one keeps the binary walk)
+        if (ok4 && 3 * (max_depth4 + 1) <= (uint32_t)kStack2Total) {
+            if (int rc = upload(ctx, s->d_acc_w4nodes, w4.data(), w4.size() * sizeof(float4))) return rc;
+            s->wide_acc.w4nodes = (const float4*)s->d_acc_w4nodes.p;
+            s->wide_acc.n_w4nodes = (uint32_t)(w4.size() / 8);
+        }
+        clk.tick("accelerator: 4-wide nodes");
+    }
     s->wide_acc.root_ref = 0;
     s->wide_acc.root_cnt = 0;
     s->wide_acc.leaf_tight = s->wide.leaf_tight;
@@ -1108,6 +1191,7 @@ void trhip_scene_free(trhip_scene* s) {
     release(s->d_w8nodes);
     release(s->d_w8tris);
     release(s->d_acc_wnodes);
+    release(s->d_acc_w4nodes);
     release(s->d_acc_prims);
     release(s->d_slot_boxes);
     release(s->d_sphere_boxes);
@@ -1323,6 +1407,7 @@ static void drop_accelerator(trhip_scene* s) {
     std::memset(&s->wide_acc, 0, sizeof s->wide_acc);
     s->wide_acc.root_ref = kRefNone;
     release(s->d_acc_wnodes);
+    release(s->d_acc_w4nodes);
     release(s->d_acc_prims);
     release(s->d_slot_boxes);
     release(s->d_acc_leaf_order);

@@ -1,7 +1,9 @@
 // tu_trace.hip — which traversal kernel walks a queue (launch_trace) and the kernel-level trace entry points.  The k_trace3 / k_trace4 / k_trace8
 // families are instantiated in tu_trace3.hip / tu_trace8.hip.
 #include "th_host.h"
+#ifdef TRHIP_EXPERIMENTS
 #include "th_leaf2.h"
+#endif
 
 #ifndef TH_TRACE_BLOCKS_PER_CU
 #define TH_TRACE_BLOCKS_PER_CU 6
@@ -37,10 +39,18 @@ WideScene wide_view(const trhip_ctx* ctx, const trhip_scene* sc) {
 
 // k_trace8 takes the launch (traversal 4) only with the tight slab clauses on and a single pipeline; otherwise k_trace3 walks the 32-byte boxes.
 // One place for the rule: launch_trace and the byte model of trhip_stats (traversal_info) must agree.
+#ifdef TRHIP_EXPERIMENTS
 static bool uses_trace8(const trhip_ctx* ctx, const trhip_scene* sc) { return ctx->traversal == 4 && sc->w8_ok && ctx->slab_margin_log2 > 0 && ctx->pipelines <= 1; }
+#else  // traversals 4, 6, 7, leaf_sorted, leaf_queue: kernels of the EXPERIMENTS build (trhip_set_option refuses them here)
+static bool uses_trace8(const trhip_ctx*, const trhip_scene*) { return false; }
+#endif
 
 // k_trace7 (traversal 7) takes the closest-hit launches of scenes with a hierarchy when the tight slab clauses are on (its margins derive from them)
+#ifdef TRHIP_EXPERIMENTS
 static bool uses_trace7(const trhip_ctx* ctx, const trhip_scene* sc) { return ctx->traversal == 7 && sc->wide_ok && sc->wide.root_cnt == 0 && ctx->slab_margin_log2 > 0 && ctx->pipelines <= 1; }
+#else
+static bool uses_trace7(const trhip_ctx*, const trhip_scene*) { return false; }
+#endif
 
 // which kernel launch_trace picks for this scene, and the bytes one unit of the visit counters stands for (trhip_stats)
 void traversal_info(const trhip_ctx* ctx, const trhip_scene* sc, uint32_t* trav, uint32_t* node_bytes) {
@@ -129,6 +139,7 @@ void launch_trace(trhip_ctx* ctx, hipStream_t st, const trhip_scene* sc, bool an
                 q = SegQueue{scn, scap, 0u, sl, 1u};
             }
         }
+#ifdef TRHIP_EXPERIMENTS
         // ---- traversal 4: 8-wide nodes (th_trace8.h); the rays it does not take come back on a fallback list that k_trace3 walks below ----
         if (uses_trace8(ctx, sc)) {
             const int w = any ? 1 : 0;
@@ -168,6 +179,7 @@ void launch_trace(trhip_ctx* ctx, hipStream_t st, const trhip_scene* sc, bool an
             launch_trace4(ctx, st, sc, any, cnt, full_only, q, ro, rd, tmax, out, work_cursors, ov, ctr);
             return;
         }
+#endif
         // scenes larger than the last-level cache (256 MB of MALL): one wave per SIMD fewer (k_trace3's BIG variant)
         const bool big = !any && !cnt && (size_t)sc->wide.n_wnodes * 64u + (size_t)sc->dev.n_prims * 48u > ((size_t)256 << 20);
         if (any && hybrid_active(ctx, sc) && (ctx->any_on_accelerator > 0 || (ctx->any_on_accelerator < 0 && out.any_acc_hint)) && sc->wide_acc.root_cnt == 0) {
@@ -193,6 +205,7 @@ void launch_trace(trhip_ctx* ctx, hipStream_t st, const trhip_scene* sc, bool an
     if (v2) {
         if (sc->wide.root_cnt > 0 && ctx->debug_trace_budget == 0 && ctx->leaf_kernel) {  // one-leaf scene: the dedicated kernel (th_trace2.h, k_trace_leaf)
             const dim3 lgrid(ctx->num_cu * 8);
+#ifdef TRHIP_EXPERIMENTS
             if (ctx->leaf_sorted && sc->d_leaf_boxes.p && sc->wide.root_cnt <= 30 && ctx->slab_margin_log2 > 0) {  // rays grouped by what they can hit (th_leaf2.h)
                 const float* lb = (const float*)sc->d_leaf_boxes.p;
                 const WideScene wsv = wide_view(ctx, sc);
@@ -207,6 +220,7 @@ void launch_trace(trhip_ctx* ctx, hipStream_t st, const trhip_scene* sc, bool an
 #undef TH_LEAF2
                 return;
             }
+#endif
             if (any) {
                 if (cnt)
                     { if (full_only) hipLaunchKernelGGL((k_any_leaf<true, true>), lgrid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, ctr); else hipLaunchKernelGGL((k_any_leaf<true, false>), lgrid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, ctr); }

@@ -9,7 +9,9 @@
         else                                                                                                                                                                        \
             hipLaunchKernelGGL((k_trace3<ANYV, CNTV, FULLV, BIGV>), grid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, work_cursors, ov, ctr);                   \
     } while (0)
+#ifdef TRHIP_EXPERIMENTS
 #define TH_LAUNCH4(ANYV, CNTV, FULLV) hipLaunchKernelGGL((k_trace4<ANYV, CNTV, FULLV>), grid, block, 0, st, sc->dev, wide_view(ctx, sc), q, ro, rd, tmax, out, work_cursors, ov, ctr)
+#endif
 
 void launch_trace3(trhip_ctx* ctx, hipStream_t st, const trhip_scene* sc, bool any, bool cnt, bool full_only, bool big, const SegQueue& q, const float4* ro, const float4* rd, const float* tmax,
                    const TraceOut& out, uint32_t* work_cursors, uint2* ov, Counters* ctr, bool on_accelerator) {
@@ -29,6 +31,7 @@ void launch_trace3(trhip_ctx* ctx, hipStream_t st, const trhip_scene* sc, bool a
     }
 }
 
+#ifdef TRHIP_EXPERIMENTS
 void launch_trace4(trhip_ctx* ctx, hipStream_t st, const trhip_scene* sc, bool any, bool cnt, bool full_only, const SegQueue& q, const float4* ro, const float4* rd, const float* tmax,
                    const TraceOut& out, uint32_t* work_cursors, uint2* ov, Counters* ctr) {
     const dim3 grid(trace_grid(ctx)), block(kBlock);
@@ -46,6 +49,7 @@ void launch_trace4(trhip_ctx* ctx, hipStream_t st, const trhip_scene* sc, bool a
         }
     }
 }
+#endif
 
 #ifdef TH_DIAG_PHASES
 extern "C" __attribute__((visibility("default"))) int trhip_debug_phases(uint64_t* out12, int reset) {  // DIAGNOSTIC build only (tools/phase_probe.py)

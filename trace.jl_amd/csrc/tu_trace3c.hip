@@ -2,7 +2,10 @@
 // walks (k_trace_leaf_c, k_any_leaf_c), instantiated here and nowhere else; tu_trace.hip's launch_trace decides when they run and sends their fallback lists
 // through k_trace3 on the canonical tree.
 #include "th_host.h"
+#ifdef TRHIP_EXPERIMENTS
 #include "th_trace3d.h"
+#endif
+#include "th_trace3c4.h"
 
 // Every ray of a scene committed with both trees walks the accelerator when: the option is on, the default traversal is selected (the others are the A/B kernels
 // and walk the canonical tree), the tight slab clauses are on (the certificate's margins derive from the same reach D), one pipeline, no diagnostic budget.
@@ -40,6 +43,7 @@ static CertScene cert_view(const trhip_ctx* ctx, const trhip_scene* sc) {
     return c;
 }
 
+#ifdef TRHIP_EXPERIMENTS
 #define TH_LAUNCH3D(CNTV, FULLV)                                                                                                                                       \
     do {                                                                                                                                                           \
         if (out.far_hint)                                                                                                                                          \
@@ -47,6 +51,7 @@ static CertScene cert_view(const trhip_ctx* ctx, const trhip_scene* sc) {
         else                                                                                                                                                       \
             hipLaunchKernelGGL((k_trace3d<CNTV, FULLV, false>), grid, block, 0, st, sc->dev_acc, wide_view_acc(ctx, sc), hot, cold, q, ro, rd, tmax, out, work_cursors, ov, ctr); \
     } while (0)
+#endif
 #define TH_LAUNCH3C(CNTV, FULLV, BIGV)                                                                                                                                 \
     do {                                                                                                                                                           \
         if (out.far_hint)                                                                                                                                          \
@@ -75,12 +80,27 @@ void launch_trace3c(trhip_ctx* ctx, hipStream_t st, const trhip_scene* sc, bool 
     cc.inv_tight = cv.inv_tight;
     hipLaunchKernelGGL(k_store_cert_cold, dim3(1), dim3(1), 0, st, cold, cc);
     const CertHot hot{kCertDt * cv.inv_tight, kCertGrow * cv.inv_tight, kCertFlat * cv.sq_flat, cv.n_spheres, (const SphereCert*)cv.sphere_cert, {cv.mle_small[0], cv.mle_small[1], cv.mle_small[2]}, std::ldexp(cv.inv_tight, -TH_TRACE3C_LAT)};
+#ifdef TRHIP_EXPERIMENTS
     if (ctx->leaf_queue && !big) {  // option "leaf_queue": the same walk with queued leaves (th_trace3d.h)
         if (cnt) {
             if (full_only) TH_LAUNCH3D(true, true); else TH_LAUNCH3D(true, false);
         } else {
             if (full_only) TH_LAUNCH3D(false, true); else TH_LAUNCH3D(false, false);
         }
+        return;
+    }
+#endif
+    const WideScene wv4 = wide_view_acc(ctx, sc);
+    if (ctx->wide4 && wv4.w4nodes) {  // the accelerator four children wide (th_trace3c4.h): one form for every launch
+#define TH_LAUNCH3C4(CNTV, FULLV, BIGV) hipLaunchKernelGGL((k_trace3c4<CNTV, FULLV, BIGV>), grid, block, 0, st, sc->dev_acc, wv4, hot, cold, q, ro, rd, tmax, out, work_cursors, ov, ctr)
+        if (cnt) {
+            if (full_only) TH_LAUNCH3C4(true, true, false); else TH_LAUNCH3C4(true, false, false);
+        } else if (big) {
+            if (full_only) TH_LAUNCH3C4(false, true, true); else TH_LAUNCH3C4(false, false, true);
+        } else {
+            if (full_only) TH_LAUNCH3C4(false, true, false); else TH_LAUNCH3C4(false, false, false);
+        }
+#undef TH_LAUNCH3C4
         return;
     }
     if (cnt) {

@@ -1,5 +1,6 @@
 // tu_trace7.hip — the k_trace7 kernel family (closest-hit rays front to back with tie detection, th_trace7.h; option "traversal" = 7).
 #include "th_host.h"
+#ifdef TRHIP_EXPERIMENTS  // (the default build does not carry this kernel family: __graft_entry__.build_library(extra_flags=["-DTRHIP_EXPERIMENTS"], …))
 
 #define TH_LAUNCH7(CNTV, FULLV, BIGV)                                                                                                                                       \
     do {                                                                                                                                                                \
@@ -22,3 +23,4 @@ void launch_trace7(trhip_ctx* ctx, hipStream_t st, const trhip_scene* sc, bool c
         if (full_only) TH_LAUNCH7(false, true, false); else TH_LAUNCH7(false, false, false);
     }
 }
+#endif

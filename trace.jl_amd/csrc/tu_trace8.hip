@@ -1,5 +1,6 @@
 // tu_trace8.hip — the k_trace8 kernel family (8-wide quantised nodes in the binary walk's order, th_trace8.h; option "traversal" = 4).
 #include "th_host.h"
+#ifdef TRHIP_EXPERIMENTS  // (the default build does not carry this kernel family: __graft_entry__.build_library(extra_flags=["-DTRHIP_EXPERIMENTS"], …))
 
 #define TH_LAUNCH8(ANYV, CNTV, FULLV) hipLaunchKernelGGL((k_trace8<ANYV, CNTV, FULLV>), grid, block, 0, st, sc->dev, w8, q, ro, rd, tmax, out, work_cursors, ov8, ctr, fb)
 
@@ -20,3 +21,4 @@ void launch_trace8(trhip_ctx* ctx, hipStream_t st, const trhip_scene* sc, bool a
         }
     }
 }
+#endif
