@@ -2,17 +2,14 @@
 // binary tree folded into its parent; 128 bytes per node).  Everything of th_trace3c.h's header holds — the certificate speaks of leaves (parts of canonical leaves with bit for
 // bit their boxes), of candidates and of lower bounds of what a culled box can hold; it is indifferent to the interior topology and to the visiting order — with these
 // differences:
-//   * one step = one 128-byte node = four boxes, tested in the packed min / max form of th_trace3c.h "The step": the slab products are the reference's own (bounds.jl:183-193),
-//     a child is ENTERED when the box grown by gm = max(em, growth) per axis is pierced ahead of the origin (em: slab_test2's margin, on every clause; growth: the
-//     certificate's bound on how far the ray point at a primitive's computed t lies outside the primitive's boxes, header (i)) and its grown entry distance lies below
-//     t_lim + mkz: by (i) and (ii) no candidate inside has its t below (grown entry - mkz).  This per-axis bound serves every launch (camera rays far outside the scene
-//     included: no AXIS variant) and needs no cap on near-axis-parallel rays (the scalar form's growth x max |1 / d| is gone from the push-time test);
-//   * an entry's EXACT entry distance travels with it (the guard reads it at a leaf), its lowest mantissa bit replaced by "not strict" — the un-grown interval was empty or
-//     ended behind the origin, i.e. the reference's own clauses (bounds.jl:186-198) may or may not let it into that box: a candidate found in such a leaf sends the ray to
-//     the reference-order walk.  Strict => every reference clause but the t_max one holds, and max3 of the near products IS the reference's tx_min;
-//   * a popped entry is held against the scalar form t_lim + mb (mb = mkz + growth x max |1 / d|) of the same bound, on its exact entry distance;
-//   * the four children are visited nearest first (a five-comparator network on the exact entry distances); up to three wait on the stack (64 entries: the commit lays a
-//     tree out four wide only when three times its depth fits).
+//   * one step = one 128-byte node = four boxes, each tested with slab_test3's clauses (the reference's own, bounds.jl:186-198 as written, plus the two it lost on the
+//     box grown by em) evaluated on the reference's slab products in the packed min / max form of th_trace3c.h "The step": a child's entry distance IS the reference's
+//     tx_min, a leaf child is entered iff the reference's clauses pass on its (canonical) box — exactly the binary walk's rule, so the certificate's argument carries
+//     over unchanged.  (A first version grew every clause by em instead: + 50 % primitive tests — rays that pass a leaf box laterally within em — and 84 ms against the
+//     binary walk's 76; with no margin at all, unsound, 66 ms: profiles/r5.)
+//   * the four children are visited nearest first (a five-comparator network on the entry distances; unsorted: 129 ms); up to three wait on the stack (64 entries: the
+//     commit lays a tree out four wide only when three times its depth fits);
+//   * AXIS (launches whose rays start far outside the scene) adds the per-axis form of the lower bound as in k_trace3c.
 // Half the dependent node fetches per ray: the binary walk is bound by the latency of one node fetch per step as much as by its instructions (profiles/r5).
 #pragma once
 #include "th_trace3c.h"
@@ -26,15 +23,15 @@ namespace th {
 #define TH_TRACE3C4_LDS 11
 #endif
 
-template <bool COUNT, bool FULL_ONLY, bool BIG = false>
+template <bool COUNT, bool FULL_ONLY, bool BIG = false, bool AXIS = false>
 __global__ __launch_bounds__(kBlock, BIG ? TH_TRACE3C4_WAVES - 1 : TH_TRACE3C4_WAVES) void k_trace3c4(DeviceScene sc /* prims: the accelerator's order */, WideScene ws /* the accelerator */, CertHot ch,
                                                                                                const CertCold* __restrict__ cold, SegQueue q, const float4* __restrict__ ro,
                                                                                                const float4* __restrict__ rd, const float* __restrict__ tmax_or_null, TraceOut out,
                                                                                                uint32_t* __restrict__ work, uint2* __restrict__ overflow, Counters* ctr) {
     constexpr int kLds = TH_TRACE3C4_LDS;
-    constexpr bool AXIS = false;  // (one form for every launch: the push-time bound is per axis, the pop-time bound scalar — header)
+
     constexpr uint32_t kLeafBit = 1u << 24;  // a node word >= this (and != kRefNone) is a leaf: ref | count << 24
-    constexpr bool FAST = true;   // (entry distances carry the "not strict" bit: th_trace3c.h "The step")
+    constexpr bool FAST = false;  // (entry distances are the reference's own tx_min, no flag bit)
     __shared__ uint2 s_stk[kLds][kBlock];  // {child word, entry distance}: one 8-byte LDS access per push / pop
     // per-lane state that is only touched when a ray is fetched, accepted or finished lives in LDS, not in registers (the walk runs at the 80-VGPR line of six waves per
     // SIMD; a scratch spill costs a trip to memory, an LDS word 64 cycles): the ray's queue index, its state word, the entry distance of the node in hand
@@ -61,7 +58,6 @@ __global__ __launch_bounds__(kBlock, BIG ? TH_TRACE3C4_WAVES - 1 : TH_TRACE3C4_W
 #define negz (inv_d.z < 0.0f)
     float t_lim = 0.0f;   // t_max + 2 dt, t_max = the t of the last accepted candidate (or the ray's own t_max): what the primitive tests accept up to; a box is culled when the lower
                           // bound of what it holds — its entry distance minus the margin — reaches it
-    float gm = 0.0f;      // per ray: the length every box is grown by per axis in the step: max(em, growth) — em for the entering test (slab_test2's margin), growth for the bound below
     float mkz = 0.0f;     // per ray: the kz-extent part of mb alone: what the per-axis bound of the step adds to t_lim
     float mb = 0.0f;      // per ray: the margin of the lower bound: non-flat primitives their kz extent, everything the growth in the entering axis (with AXIS the growth is applied per
                           // axis to the box instead, and is not in here)
@@ -193,7 +189,6 @@ __global__ __launch_bounds__(kBlock, BIG ? TH_TRACE3C4_WAVES - 1 : TH_TRACE3C4_W
                         const float dt = margin_t();
                         const float mkz_ = (shear.kz == 0 ? ch.mle[0] : (shear.kz == 1 ? ch.mle[1] : ch.mle[2])) * fabsf(shear.sz);
                         mkz = mkz_;
-                        gm = fmaxf(em, growth());
                         mb = __fmaf_rn(growth(), inv_max(), mkz_);  // the scalar form: what a popped entry's exact entry distance is held against
                         t_lim = t_own + 2.0f * dt;
                         sp = 0;
@@ -203,7 +198,7 @@ __global__ __launch_bounds__(kBlock, BIG ? TH_TRACE3C4_WAVES - 1 : TH_TRACE3C4_W
                         // products), a non-finite origin or margin, a NaN t_max — and near-axis-parallel rays, whose scalar margin would make the walk overshoot every hit
                         // (kCertCap; with AXIS the margin is per axis: no cap)
                         const bool plain = d.x != 0.0f && d.y != 0.0f && d.z != 0.0f && mb < kInf && fabsf(o.x) < kInf && fabsf(o.y) < kInf && fabsf(o.z) < kInf && fabsf(inv_d.x) < kInf &&
-                                           fabsf(inv_d.y) < kInf && fabsf(inv_d.z) < kInf && t_own == t_own;  // (no cap on near-axis-parallel rays: the step's bound is per axis)
+                                           fabsf(inv_d.y) < kInf && fabsf(inv_d.z) < kInf && t_own == t_own && (AXIS || mb - mkz_ <= kCertCap * mkz_ + dt);
                         float tmin;
                         if (!plain) {
                             to_fb = true;
@@ -300,29 +295,26 @@ __global__ __launch_bounds__(kBlock, BIG ? TH_TRACE3C4_WAVES - 1 : TH_TRACE3C4_W
                 cur = kRefNone;
                 if (stepping) {
                     if (COUNT) nn += 4;
-                    const float t_push = t_lim + mkz;  // (per-axis form, against the entry distance of the box grown by gm >= growth: header)
+                    const float t_push = t_lim + mkz;  // (AXIS: the per-axis form of the bound, against the entry distance of the box grown by growth — launches whose rays start far outside the scene)
                     const v2f p_a = v2f{o.x, o.y}, p_b = v2f{o.z, inv_d.x}, p_c = v2f{inv_d.y, inv_d.z};
-                    const float gx = gm * fabsf(inv_d.x), gy = gm * fabsf(inv_d.y), gz = gm * fabsf(inv_d.z);
-                    // one child: its three {min, max} pairs -> the sort key (its exact entry distance with the "not strict" bit, +Inf when it is not entered)
+                    const float gx = em * fabsf(inv_d.x), gy = em * fabsf(inv_d.y), gz = em * fabsf(inv_d.z);
+                    const float grow = AXIS ? growth() : 0.0f;
+                    const float ax_x = grow * fabsf(inv_d.x), ax_y = grow * fabsf(inv_d.y), ax_z = grow * fabsf(inv_d.z);
+                    // one child: its three {min, max} pairs -> the sort key = its entry distance (the reference's tx_min, bit for bit), +Inf when it is not entered.  The clauses are
+                    // slab_test3's — bounds.jl:186-198 as written (the LARGER of the x and y exits, :190), t_max aside, and the two clauses that lost on the box grown by em — on the
+                    // reference's own slab products, two per instruction (th_trace3c.h "The step").  Every clause of the reference's is monotonic in the box: a box that fails one holds
+                    // no leaf box that passes it, i.e. no candidate — no margin is needed on them, for leaves or interior boxes (header: the set of candidates is the same in every tree)
                     auto child = [&](v2f X, v2f Y, v2f Z) {
                         const v2f Tx = pk_mul_h<1>(pk_sub_h<0>(X, p_a), p_b), Ty = pk_mul_h<0>(pk_sub_h<1>(Y, p_a), p_c), Tz = pk_mul_h<1>(pk_sub_h<0>(Z, p_b), p_c);  // bounds.jl:183-193: (plane - o) x inv_d
                         const float nx = amin(Tx.x, Tx.y), fx = amax(Tx.x, Tx.y), ny = amin(Ty.x, Ty.y), fy = amax(Ty.x, Ty.y), nz = amin(Tz.x, Tz.y), fz = amax(Tz.x, Tz.y);
-                        const float t_in = amax3(nx, ny, nz), t_out = amin3(fx, fy, fz);  // = bounds.jl:196's tx_min; <= :197's tx_max
-                        const float g_in = amax3(nx - gx, ny - gy, nz - gz), g_out = amin3(fx + gx, fy + gy, fz + gz);  // the box grown by gm per axis
-                        // two lower bounds of what the box can hold, either may cull: the scalar one on the exact entry distance (tight for rays that start inside the scene), the
-                        // per-axis one on the grown box (tight for camera rays far outside, whose max |1 / d| makes the scalar margin useless)
-#if defined(TH_W4_DIAG_STRICT)
-                        const bool enter = (t_in <= t_out) && (t_out > 0.0f) && (t_in < t_pop);  // DIAGNOSTIC (unsound): no margin at all
-#elif defined(TH_W4_DIAG_SCALAR)
-                        const bool enter = (g_in <= g_out) && (g_out >= 0.0f) && (t_in < t_pop);  // DIAGNOSTIC: the scalar bound alone
-#else
-                        const bool enter = (g_in <= g_out) && (g_out >= 0.0f) && (g_in < t_push) && (t_in < t_pop);
-#endif
-                        const bool strict = (t_in <= t_out) && (t_out > 0.0f);  // every clause of bounds.jl:186-198 but the t_max one then holds
-                        // what travels is max(entry, 0): boxes that hold the origin (every ray spawned on a surface starts inside its own leaf's box and that box's ancestors) tie at 0
-                        // instead of sorting the LARGEST box first; both readers stay right — the guard wants an upper bound of the entry distance, a popped entry below 0 passes anyway
-                        const float coded = __uint_as_float((__float_as_uint(fmaxf(t_in, 0.0f)) & ~1u) | (strict ? 0u : 1u));
-                        return enter ? coded : kInf;
+                        const float a = amax(nx, ny), b = amax(fx, fy);        // :189-190
+                        const float t_in = amax(a, nz), t_out = amin(fz, b);   // :196-197
+                        const bool ref = !(nx > fy) && !(ny > fx) && !(a > fz) && !(nz > b) && (t_out > 0.0f);  // :188, :194, :198
+                        const float exit_xy = amin(fx + gx, fy + gy);
+                        const bool tight = !(nz - gz > exit_xy) && !(exit_xy < 0.0f);
+                        bool enter = ref && tight && (t_in < t_pop);
+                        if constexpr (AXIS) enter = enter && (amax3(nx - ax_x, ny - ax_y, nz - ax_z) < t_push);
+                        return enter ? t_in : kInf;
                     };
                     float k0 = child(v2f{a0.x, a0.y}, v2f{a0.z, a0.w}, v2f{a1.x, a1.y});
                     float k1 = child(v2f{a1.z, a1.w}, v2f{a2.x, a2.y}, v2f{a2.z, a2.w});
@@ -340,32 +332,11 @@ __global__ __launch_bounds__(kBlock, BIG ? TH_TRACE3C4_WAVES - 1 : TH_TRACE3C4_W
         ka = tk;                              \
         ea = te;                              \
     }
-#ifndef TH_W4_DIAG_NOSORT
                     TH_CSWAP(k0, k1, e0, e1);
                     TH_CSWAP(k2, k3, e2, e3);
                     TH_CSWAP(k0, k2, e0, e2);
                     TH_CSWAP(k1, k3, e1, e3);
                     TH_CSWAP(k1, k2, e1, e2);
-#else  // DIAGNOSTIC: slot order, the entered ones first
-                    {
-                        float kk[4] = {k0, k1, k2, k3};
-                        uint32_t ee[4] = {e0, e1, e2, e3};
-                        float ok[4] = {kInf, kInf, kInf, kInf};
-                        uint32_t oe[4] = {e0, e0, e0, e0};
-                        int w = 0;
-                        for (int j = 0; j < 4; ++j)
-                            if (kk[j] < kInf) {
-                                for (int m = 0; m < 4; ++m)
-                                    if (m == w) {
-                                        ok[m] = kk[j];
-                                        oe[m] = ee[j];
-                                    }
-                                w++;
-                            }
-                        k0 = ok[0], k1 = ok[1], k2 = ok[2], k3 = ok[3];
-                        e0 = oe[0], e1 = oe[1], e2 = oe[2], e3 = oe[3];
-                    }
-#endif
 #undef TH_CSWAP
                     n_go = (k0 < kInf ? 1u : 0u) + (k1 < kInf ? 1u : 0u) + (k2 < kInf ? 1u : 0u) + (k3 < kInf ? 1u : 0u);
                     // the far ones wait on the stack, the farthest deepest (an entry that fails now fails at pop time: t_lim never goes up in this walk)

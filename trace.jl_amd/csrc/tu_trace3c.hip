@@ -92,7 +92,13 @@ void launch_trace3c(trhip_ctx* ctx, hipStream_t st, const trhip_scene* sc, bool 
 #endif
     const WideScene wv4 = wide_view_acc(ctx, sc);
     if (ctx->wide4 && wv4.w4nodes) {  // the accelerator four children wide (th_trace3c4.h): one form for every launch
-#define TH_LAUNCH3C4(CNTV, FULLV, BIGV) hipLaunchKernelGGL((k_trace3c4<CNTV, FULLV, BIGV>), grid, block, 0, st, sc->dev_acc, wv4, hot, cold, q, ro, rd, tmax, out, work_cursors, ov, ctr)
+#define TH_LAUNCH3C4(CNTV, FULLV, BIGV)                                                                                                                                     \
+    do {                                                                                                                                                                \
+        if (out.far_hint)                                                                                                                                               \
+            hipLaunchKernelGGL((k_trace3c4<CNTV, FULLV, BIGV, true>), grid, block, 0, st, sc->dev_acc, wv4, hot, cold, q, ro, rd, tmax, out, work_cursors, ov, ctr);    \
+        else                                                                                                                                                            \
+            hipLaunchKernelGGL((k_trace3c4<CNTV, FULLV, BIGV, false>), grid, block, 0, st, sc->dev_acc, wv4, hot, cold, q, ro, rd, tmax, out, work_cursors, ov, ctr);   \
+    } while (0)
         if (cnt) {
             if (full_only) TH_LAUNCH3C4(true, true, false); else TH_LAUNCH3C4(true, false, false);
         } else if (big) {
