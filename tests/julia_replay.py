@@ -300,8 +300,10 @@ class ShimReplay:
         out = np.empty(4 * h * w, np.float32)
         st = self.T._ffi.Stats()
         try:
-            self.call("trhip_render_sppm", self.ctx, s, C.byref(sn), float(integ.initial_search_radius), integ.max_depth, integ.n_iterations, integ.photons_per_iteration,
-                      integ.seed, out, C.byref(st))
+            # render_sppm! (TraceHIP.jl): trhip_render_sppm_ex with the periodic-image callback; write_frequency >= n_iterations passes 0 (nothing to write before the end)
+            wf = int(getattr(integ, "write_frequency", 0))
+            self.call("trhip_render_sppm_ex", self.ctx, s, C.byref(sn), float(integ.initial_search_radius), integ.max_depth, integ.n_iterations, integ.photons_per_iteration,
+                      integ.seed, out, C.byref(st), wf if 0 < wf < integ.n_iterations else 0, None, None)
         finally:
             self.call("trhip_scene_free", s)
         return out.reshape(h, w, 4), st

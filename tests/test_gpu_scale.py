@@ -159,7 +159,7 @@ def test_mesh_1m_all_traversals_and_oracle(T, ob, ctx, chain):
     scene = T.scenes.mesh_scene(T.scenes.MESH_N["mesh_1m"])
     _, osc = check_traversals(T, ob, ctx, scene, 1 << 21, 2 * 724 * 724 + 12, chain)
     ran = check_frame(T, ob, ctx, scene, osc)
-    assert ran[4] == (4 if chain else 3)  # trhip_stats.traversal: k_trace8 needs the chain when the scene has spheres
+    assert 4 not in ran or ran[4] == (4 if chain else 3)  # trhip_stats.traversal: k_trace8 (EXPERIMENTS build) needs the chain when the scene has spheres
 
 
 def test_blob_870k_all_traversals_and_oracle(T, ob, ctx):
@@ -167,7 +167,7 @@ def test_blob_870k_all_traversals_and_oracle(T, ob, ctx):
     scene = T.scenes.blob_scene(270)
     _, osc = check_traversals(T, ob, ctx, scene, 1 << 21, 12 * 270 * 270 + 10, True)  # commit for traversal 4: one primitive per leaf
     ran = check_frame(T, ob, ctx, scene, osc)
-    assert ran[4] == 4 and ran[3] == 3
+    assert (4 not in ran or ran[4] == 4) and ran[3] == 3
 
 
 def test_mesh_10m_c5_geometry(T, ob, ctx):
