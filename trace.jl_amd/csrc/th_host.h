@@ -115,7 +115,6 @@ struct trhip_ctx {
     uint64_t last_L_count = 0;  // float4 entries valid in Lbuf
     // SPPM state (th_sppm.h): per film pixel, kept after trhip_render_sppm for trhip_sppm_state
     DevBuf sp_vp[7], sp_Ld, sp_tau, sp_radius, sp_N, sp_phi, sp_M, sp_counts, sp_starts, sp_entries, sp_grid, sp_ldist, sp_snap_M, sp_snap_phi, sp_snap_p, sp_snap_beta;
-    DevBuf sp_order, sp_class_counts;  // k_sppm_classify -> k_sppm_gather<ORDERED>: pixel lists by candidate count (th_sppm.h)
     DevBuf sp_terms, sp_rec[3], sp_rec_valid, sp_raysnap;  // sp_raysnap: {closest_total, shadow_total} after every batch's camera pass and photon pass
     // streaming wavefront (render_stream_impl)
     DevBuf st_terms, st_tags[2], st_frozen, st_counts, st_list[2][2][7];  // [closest|any][ping-pong][o, d, b, trav, st, depth, stack]
@@ -126,7 +125,6 @@ struct trhip_ctx {
     uint32_t stream_budget_shift = 12;  // budget = max(stream_budget_min, fresh rays of the round >> shift)
     uint32_t stream_list_cap = 0;       // suspended-ray list capacity (0 = max(65536, paths / 128)); tests shrink it
     uint32_t stream_budget_min = 2048;  // interior fetches before a ray may be suspended (tests lower it to force suspensions)
-    bool sppm_order = true;   // SPPM gather: pixels taken in the order of their candidate counts (th_sppm.h k_sppm_classify; option "sppm_order")
     uint64_t sppm_batch = 0;  // SPPM iterations per wavefront batch (0 = from free HBM, at most 128)
     uint32_t sp_pixels = 0;
     int64_t sp_photons = 0;

@@ -729,73 +729,6 @@ TH_D GatherSum gather_pixel(const DeviceScene& sc, const PhotonRecords& rec, con
             }
     return s;
 }
-// ---- pixels in the order of their work (round 5) ------------------------------------------------------------------------------------
-// k_sppm_gather's walk is bound by its slowest lane: a wave stays until the pixel with the most candidates is done.  k_sppm_classify counts every pixel's
-// candidates (the summed occupancy of the cells its visible point registers in — what the gather used to count itself), sends the hot ones to k_sppm_gather_hot as before and
-// appends the others to one of kGatherClasses lists by ceil(log2(candidates)); the gather then takes its 64 pixels from ONE list (longest walks first): the lanes of a wave
-// finish together.  Every pixel still walks its own buckets in the same order: per pixel nothing changes.
-constexpr int kGatherClasses = 9;  // 1, 2, 3-4, 5-8, …, 129-256 candidates (the hot threshold cuts the last one short)
-TH_D uint32_t gather_class(uint32_t candidates) { return candidates <= 1u ? 0u : 32u - (uint32_t)__builtin_clz(candidates - 1u); }
-template <int TH_ONE_COPY = 0> __global__ __launch_bounds__(kBlock) void k_sppm_classify(VisiblePoints vp, PixelStats px, uint32_t n, GridInfo* gp, const uint32_t* __restrict__ starts, uint32_t hash_size,
-                                                                            uint32_t* __restrict__ hot_list, uint32_t* __restrict__ order /* [kGatherClasses][n] */,
-                                                                            uint32_t* __restrict__ class_counts /* [kGatherClasses] x kCtrStride */, uint32_t count_registrations, uint32_t count_stats) {
-    const GridInfo& g = *gp;
-    if (!g.valid) return;
-    const uint32_t lane = lane_id();
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    unsigned long long n_reg = 0, n_cand = 0, n_vp = 0;
-    const uint32_t total = (n + 63u) & ~63u;
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < total; i += gridDim.x * kBlock) {
-        bool hot = false;
-        uint32_t cls = 0xffffffffu;
-        if (i < n) {
-            const float4 b = vp.beta[i];
-            if (!(b.x == 0.0f && b.y == 0.0f && b.z == 0.0f)) {
-                n_vp++;
-                const float4 p4 = vp.p_mat[i];
-                const float rad = px.radius[i];
-                uint32_t lo[3], hi[3];
-                to_grid(g, mk3(p4.x - rad, p4.y - rad, p4.z - rad), lo);
-                to_grid(g, mk3(p4.x + rad, p4.y + rad, p4.z + rad), hi);
-                uint32_t candidates = 0;
-                for (uint32_t z = lo[2]; z <= hi[2]; ++z)
-                    for (uint32_t y = lo[1]; y <= hi[1]; ++y)
-                        for (uint32_t x = lo[0]; x <= hi[0]; ++x) {
-                            n_reg++;
-                            const uint32_t h = grid_hash(x, y, z, hash_size);
-                            candidates += starts[h + 1] - starts[h];
-                        }
-                hot = candidates > kHotCandidates;
-                if (!hot && candidates > 0) cls = min(gather_class(candidates), (uint32_t)kGatherClasses - 1u);
-                n_cand += candidates;  // hot pixels too: k_sppm_gather_hot tests every one of them
-            }
-        }
-        const uint32_t k = wave_compact(hot, &gp->n_hot);
-        if (hot) hot_list[k] = i;
-#pragma unroll 1
-        for (uint32_t c = 0; c < (uint32_t)kGatherClasses; ++c) {
-            const unsigned long long m = __ballot(cls == c);
-            if (m == 0ull) continue;
-            uint32_t base = 0;
-            const int leader = __ffsll((long long)m) - 1;
-            if ((int)lane == leader) base = atomicAdd(&class_counts[c * kCtrStride], (uint32_t)__popcll(m));
-            base = __shfl(base, leader);
-            if (cls == c) order[(size_t)c * n + base + (uint32_t)__popcll(m & lt_mask)] = i;
-        }
-    }
-    if (count_registrations) {  // trhip_sppm_state reports the last iteration's
-        n_reg = wave_sum(n_reg);
-        if (lane_id() == 0 && n_reg) atomicAdd(&gp->registrations, n_reg);
-    }
-    if (count_stats) {
-        n_cand = wave_sum(n_cand);
-        n_vp = wave_sum(n_vp);
-        if (lane_id() == 0) {
-            if (n_cand) atomicAdd(&gp->stat_candidates, n_cand);
-            if (n_vp) atomicAdd(&gp->stat_visible_points, n_vp);
-        }
-    }
-}
 // One thread per pixel; also counts the registrations (the reference's list nodes) for trhip_sppm_state.
 #ifndef TH_SPPM_GATHER_WAVES
 #define TH_SPPM_GATHER_WAVES 4
@@ -803,10 +736,8 @@ template <int TH_ONE_COPY = 0> __global__ __launch_bounds__(kBlock) void k_sppm_
 #ifndef TH_SPPM_HOT_WAVES
 #define TH_SPPM_HOT_WAVES 4  // 144 VGPRs unconstrained (3 waves); capped at 4: C4 shading section 160.4 -> 156.4 ms
 #endif
-// ORDERED: the pixels come from k_sppm_classify's lists (order / class_counts), classes of long walks first, instead of in image order
-template <bool ORDERED = false> __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TH_SPPM_GATHER_WAVES))) void k_sppm_gather(DeviceScene sc, PhotonRecords rec, VisiblePoints vp, PixelStats px, uint32_t n, GridInfo* gp, const uint32_t* __restrict__ starts,
-                                                        const float4* __restrict__ hit_sorted, uint32_t hash_size, uint32_t* __restrict__ hot_list, uint32_t count_registrations, uint32_t count_stats, const uint32_t* __restrict__ order = nullptr,
-                                                        const uint32_t* __restrict__ class_counts = nullptr) {
+template <int TH_ONE_COPY = 0> __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TH_SPPM_GATHER_WAVES))) void k_sppm_gather(DeviceScene sc, PhotonRecords rec, VisiblePoints vp, PixelStats px, uint32_t n, GridInfo* gp, const uint32_t* __restrict__ starts,
+                                                        const float4* __restrict__ hit_sorted, uint32_t hash_size, uint32_t* __restrict__ hot_list, uint32_t count_registrations, uint32_t count_stats) {
     // A wave takes 64 pixels.  Every lane walks the buckets of ITS pixel one candidate per round (a cursor over cells and entries);
     // the (pixel, photon) pairs that pass the distance test are parked in a per-wave ring and evaluated 64 at a time — frame and
     // material of the pair's pixel are fetched by whichever lane gets the pair — and summed per pixel in LDS.  (One thread per pixel
@@ -825,44 +756,13 @@ template <bool ORDERED = false> __global__ __launch_bounds__(kBlock) __attribute
     const uint32_t lane = lane_id(), wv = threadIdx.x >> 6;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     unsigned long long n_reg = 0, n_cand = 0, n_acc = 0, n_vp = 0;
-    // ORDERED: the flat work space = the classes from the longest walks down, each padded to whole waves
-    __shared__ uint32_t s_cls[kGatherClasses + 1];
-    if (ORDERED) {
-        if (threadIdx.x == 0) {
-            uint32_t acc = 0;
-            for (int c = kGatherClasses - 1; c >= 0; --c) {
-                s_cls[kGatherClasses - 1 - c] = acc;
-                acc += (min(class_counts[c * kCtrStride], n) + 63u) & ~63u;
-            }
-            s_cls[kGatherClasses] = acc;
-        }
-        __syncthreads();
-    }
-    const uint32_t total = ORDERED ? s_cls[kGatherClasses] : ((n + 63u) & ~63u);
-    uint32_t kcls = 0;  // ORDERED: position in s_cls of the class the wave is in (carried over the iterations)
-    for (uint32_t flat = blockIdx.x * kBlock + threadIdx.x; flat < total; flat += gridDim.x * kBlock) {
-        uint32_t i = flat;
-        bool listed = true;
-        if (ORDERED) {
-#pragma unroll 1
-            while (kcls + 1 < (uint32_t)kGatherClasses && (flat & ~63u) >= s_cls[kcls + 1]) ++kcls;
-            const uint32_t c = (uint32_t)kGatherClasses - 1u - kcls, k = flat - s_cls[kcls];
-            listed = k < min(class_counts[c * kCtrStride], n);
-            i = listed ? order[(size_t)c * n + k] : n;
-        }
+    const uint32_t total = (n + 63u) & ~63u;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < total; i += gridDim.x * kBlock) {
         bool hot = false, walk = false;
         float4 p4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         float rad = 0.0f;
         uint32_t lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
-        if (ORDERED) {
-            if (listed) {  // (a listed pixel has a visible point and between 1 and kHotCandidates candidates)
-                p4 = vp.p_mat[i];
-                rad = px.radius[i];
-                to_grid(g, mk3(p4.x - rad, p4.y - rad, p4.z - rad), lo);
-                to_grid(g, mk3(p4.x + rad, p4.y + rad, p4.z + rad), hi);
-                walk = true;
-            }
-        } else if (i < n) {
+        if (i < n) {
             const float4 b = vp.beta[i];
             if (!(b.x == 0.0f && b.y == 0.0f && b.z == 0.0f)) {
                 n_vp++;
@@ -883,10 +783,8 @@ template <bool ORDERED = false> __global__ __launch_bounds__(kBlock) __attribute
                 n_cand += candidates;  // hot pixels too: k_sppm_gather_hot tests every one of them
             }
         }
-        if (!ORDERED) {
-            const uint32_t k = wave_compact(hot, &gp->n_hot);
-            if (hot) hot_list[k] = i;
-        }
+        const uint32_t k = wave_compact(hot, &gp->n_hot);
+        if (hot) hot_list[k] = i;
         if (__ballot(walk) == 0ull) continue;
         s_phi[wv][lane][0] = s_phi[wv][lane][1] = s_phi[wv][lane][2] = 0.0f;
         s_m[wv][lane] = 0u;
@@ -1009,11 +907,11 @@ template <bool ORDERED = false> __global__ __launch_bounds__(kBlock) __attribute
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
-    if (count_registrations && !ORDERED) {  // trhip_sppm_state reports the last iteration's: only that launch pays for 8 192 atomics on one word (90 µs); ORDERED: k_sppm_classify did
+    if (count_registrations) {  // trhip_sppm_state reports the last iteration's: only that launch pays for 8 192 atomics on one word (90 µs)
         n_reg = wave_sum(n_reg);
         if (lane_id() == 0 && n_reg) atomicAdd(&gp->registrations, n_reg);
     }
-    if (count_stats) {  // option "count_visits": the instrumented pass of bench.py (ORDERED: candidates and visible points were counted by k_sppm_classify: zero here)
+    if (count_stats) {  // option "count_visits": the instrumented pass of bench.py
         n_cand = wave_sum(n_cand);
         n_acc = wave_sum(n_acc);
         n_vp = wave_sum(n_vp);

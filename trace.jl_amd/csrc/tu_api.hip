@@ -88,7 +88,7 @@ void trhip_shutdown(trhip_ctx* ctx) {
             for (auto& c : b) release(c);
     for (DevBuf* b : {&ctx->sp_Ld, &ctx->sp_tau, &ctx->sp_radius, &ctx->sp_N, &ctx->sp_phi, &ctx->sp_M, &ctx->sp_counts, &ctx->sp_starts, &ctx->sp_entries, &ctx->sp_grid, &ctx->sp_ldist,
                       &ctx->sp_snap_M, &ctx->sp_snap_phi, &ctx->sp_snap_p, &ctx->sp_snap_beta, &ctx->sp_terms, &ctx->sp_rec[0], &ctx->sp_rec[1], &ctx->sp_rec[2],
-                      &ctx->sp_rec_valid, &ctx->sp_raysnap, &ctx->sp_order, &ctx->sp_class_counts})
+                      &ctx->sp_rec_valid, &ctx->sp_raysnap})
         release(*b);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
@@ -182,8 +182,6 @@ int trhip_set_option(trhip_ctx* ctx, const char* name, int64_t value) {
         ctx->stream_list_cap = (uint32_t)std::max<int64_t>(0, value);
     else if (!std::strcmp(name, "stream_budget_min"))
         ctx->stream_budget_min = (uint32_t)std::max<int64_t>(1, value);
-    else if (!std::strcmp(name, "sppm_order"))
-        ctx->sppm_order = value != 0;
     else if (!std::strcmp(name, "sppm_batch"))
         ctx->sppm_batch = (uint64_t)std::max<int64_t>(0, value);
     else if (!std::strcmp(name, "bvh_builder")) {

@@ -100,10 +100,6 @@ int render_sppm_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
     if (int rc = ensure(ctx, ctx->sp_starts, ((size_t)n + 1) * sizeof(uint32_t))) return rc;
     if (int rc = ensure(ctx, ctx->sp_entries, (size_t)entry_cap * sizeof(float4))) return rc;
     if (int rc = ensure(ctx, ctx->sp_grid, sizeof(GridInfo))) return rc;
-    if (ctx->sppm_order) {
-        if (int rc = ensure(ctx, ctx->sp_order, (size_t)kGatherClasses * n * sizeof(uint32_t))) return rc;
-        if (int rc = ensure(ctx, ctx->sp_class_counts, (size_t)kGatherClasses * kCtrStride * sizeof(uint32_t))) return rc;
-    }
     if (int rc = ensure(ctx, ctx->sp_snap_M, (size_t)n * sizeof(uint32_t))) return rc;
     if (int rc = ensure(ctx, ctx->sp_snap_phi, (size_t)n * 3 * sizeof(float))) return rc;
     if (int rc = ensure(ctx, ctx->sp_snap_p, (size_t)n * sizeof(float4))) return rc;
@@ -254,17 +250,7 @@ int render_sppm_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
                                    (const uint32_t*)starts, entries, 1);
             tm.end(6, st);
             tm.begin(5, st);
-            if (ctx->sppm_order) {  // pixels in the order of their work (th_sppm.h k_sppm_classify): a wave's 64 pixels walk about the same number of candidates
-                uint32_t* order = (uint32_t*)ctx->sp_order.p;
-                uint32_t* class_counts = (uint32_t*)ctx->sp_class_counts.p;
-                HIP_TRY(ctx, hipMemsetAsync(class_counts, 0, (size_t)kGatherClasses * kCtrStride * sizeof(uint32_t), st));
-                hipLaunchKernelGGL(k_sppm_classify, g_pix, blk, 0, st, vp, px, n, grid, (const uint32_t*)starts, n, hot_list, order, class_counts, it0 + j == n_iterations ? 1u : 0u, ctx->count_visits ? 1u : 0u);
-                hipLaunchKernelGGL((k_sppm_gather<true>), g_pix, blk, 0, st, scene->dev, rec, vp, px, n, grid, (const uint32_t*)starts, (const float4*)entries, n, hot_list, 0u, ctx->count_visits ? 1u : 0u,
-                                   (const uint32_t*)order, (const uint32_t*)class_counts);
-            } else {
-                hipLaunchKernelGGL((k_sppm_gather<false>), g_pix, blk, 0, st, scene->dev, rec, vp, px, n, grid, (const uint32_t*)starts, (const float4*)entries, n, hot_list, it0 + j == n_iterations ? 1u : 0u,
-                                   ctx->count_visits ? 1u : 0u);
-            }
+            hipLaunchKernelGGL(k_sppm_gather, g_pix, blk, 0, st, scene->dev, rec, vp, px, n, grid, (const uint32_t*)starts, (const float4*)entries, n, hot_list, it0 + j == n_iterations ? 1u : 0u, ctx->count_visits ? 1u : 0u);
             hipLaunchKernelGGL(k_sppm_gather_hot, g_shade, blk, 0, st, scene->dev, rec, vp, px, grid, (const uint32_t*)starts, (const float4*)entries, n, (const uint32_t*)hot_list, ctx->count_visits ? 1u : 0u);
             tm.end(5, st);
             if (ctx->comm.comm && ctx->comm.n_ranks > 1) {
