@@ -19,6 +19,9 @@ namespace th {
 #ifndef TH_TRACE3C4_WAVES
 #define TH_TRACE3C4_WAVES 6
 #endif
+#ifndef TH_TRACE3C4_FETCH_BURST
+#define TH_TRACE3C4_FETCH_BURST 1
+#endif
 #ifndef TH_TRACE3C4_LDS
 #define TH_TRACE3C4_LDS 11
 #endif
@@ -179,13 +182,25 @@ __global__ __launch_bounds__(kBlock, BIG ? TH_TRACE3C4_WAVES - 1 : TH_TRACE3C4_W
                         if (q.indirect) idx = q.indirect[idx];
                         s_idx[tid] = idx;
                         uint32_t st = 0u;
+                        // everything the fetch reads, in ONE round trip: origin, direction, the ray's own t_max and what the chunk's sphere pre-pass left in the hit record (read past
+                        // L1: same wave, other lane) — left to itself the compiler sinks the last two behind the root box test: a second dependent trip per refill (2 000 of its 8 000 cycles)
                         const float4 o4 = ro[idx], d4 = rd[idx];
+                        const float t_own = tmax_or_null ? tmax_or_null[idx] : kInf;
+                        uint32_t st_rec = 0u;
+                        float t_rec = 0.0f;
+                        if (ch.n_spheres != 0u) {  // (wave-uniform)
+                            const float* recp = reinterpret_cast<const float*>(&out.hits[idx]);
+                            st_rec = __float_as_uint(__hip_atomic_load(recp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                            t_rec = __hip_atomic_load(recp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+#if TH_TRACE3C4_FETCH_BURST
+                        asm volatile("" ::"v"(o4.x), "v"(d4.x), "v"(t_own), "v"(st_rec), "v"(t_rec));
+#endif
                         o = mk3(o4.x, o4.y, o4.z);
                         const f3 d = mk3(d4.x, d4.y, d4.z);
                         inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
                         em = slab_margin(ws.root_box, ws.tight_scale, o);
                         shear = ray_shear(d);
-                        const float t_own = tmax_or_null ? tmax_or_null[idx] : kInf;
                         const float dt = margin_t();
                         const float mkz_ = (shear.kz == 0 ? ch.mle[0] : (shear.kz == 1 ? ch.mle[1] : ch.mle[2])) * fabsf(shear.sz);
                         mkz = mkz_;
@@ -211,11 +226,10 @@ __global__ __launch_bounds__(kBlock, BIG ? TH_TRACE3C4_WAVES - 1 : TH_TRACE3C4_W
                             // "to the reference-order walk"
                             bool flagged = false;
                             if (ch.n_spheres != 0u) {
-                                const float* recp = reinterpret_cast<const float*>(&out.hits[idx]);
-                                st = __float_as_uint(__hip_atomic_load(recp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                                st = st_rec;
                                 flagged = (st >> 31) != 0u;
                                 st &= 0x7fffffffu;
-                                if (st & 1u) t_lim = __hip_atomic_load(recp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 2.0f * dt;
+                                if (st & 1u) t_lim = t_rec + 2.0f * dt;
                             }
                             s_st[tid] = st;
                             if (flagged) {
