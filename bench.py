@@ -29,7 +29,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 KERNEL_CLASSES = ("raygen", "trace_closest", "shade", "trace_any", "film")
 TRAVERSAL_KERNEL = {1: "k_trace_closest", 2: "k_trace2", 3: "k_trace3", 4: "k_trace8", 5: "k_trace_leaf", 6: "k_trace4", 7: "k_trace7", 9: "k_trace3c"}
-BVH_MODE = {0: "library-sah", 1: "reference", 2: "hybrid"}  # trhip_scene_bvh_mode: which tree(s) the scene holds (include/tracehip.h)
+BVH_MODE = {0: "library-sah", 1: "reference", 2: "hybrid", 3: "library-sah + itself four-wide as accelerator"}  # trhip_scene_bvh_mode: which tree(s) the scene holds (include/tracehip.h)
 L2_PLUS_MALL_BYTES = (32 + 256) << 20  # 8 x 4 MiB L2 + 256 MiB Infinity Cache (MI355X_MICROARCH.md): a scene below this is served from cache, not HBM
 TRAVERSAL_KERNEL_ANY = {1: "k_trace_any", 2: "k_trace2", 3: "k_trace3", 4: "k_trace8", 5: "k_trace_leaf", 6: "k_trace4", 7: "k_trace3"}
 
@@ -528,7 +528,7 @@ def main():
         bvh_note = flat.bvh_note()
         _bvh = flat.bvh()
         n_canonical_nodes = int(_bvh[1].size)
-        n_scene_bytes = 32 * (n_acc_nodes if bvh_mode == 2 else n_canonical_nodes) + 48 * int(_bvh[3].size)  # what the dominant walk reads: its tree's boxes + the primitive records
+        n_scene_bytes = 32 * (n_acc_nodes if bvh_mode in (2, 3) else n_canonical_nodes) + 48 * int(_bvh[3].size)  # what the dominant walk reads: its tree's boxes + the primitive records
         modes = None
         if not args.no_visits:
             # ---- roofline of the dominant kernel (rank 0's launches): live HIP-event durations from the timed region, bytes from an
@@ -699,7 +699,7 @@ def main():
                        "parallelism": f"sample-index sharding x{world} + film sum-reduce over RCCL (trhip_film_reduce)" if world > 1 else "single GPU",
                        "rccl_ranks": rccl_ranks, "film_reduce_ms_per_step": round(agg["film_reduce_ms_per_step"], 3) if world > 1 else 0.0},
             "roofline": roofline, "cpu_baseline": cpu,
-            "parity": {"vs": "the CPU oracle walking the reference's own tree (accel/bvh.jl:55-206, restated in oracle/orc_build.h)" if bvh_mode != 0 else
+            "parity": {"vs": "the CPU oracle walking the reference's own tree (accel/bvh.jl:55-206, restated in oracle/orc_build.h)" if bvh_mode in (1, 2) else
                              "the CPU oracle walking the library's tree (NOT Trace.jl's tie-breaks: option bvh_builder selects it)",
                        # measured, not asserted: what traversal_micro found in THIS run (None: --no-micro or more than one rank: nothing was compared)
                        "bits": {True: "equal", False: "differ", None: "not checked in this run"}[(micro or {}).get("gpu_equals_cpu_on_subset")],

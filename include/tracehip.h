@@ -128,7 +128,8 @@ int trhip_scene_set_bvh(trhip_scene* scene, const float* node_bounds, const uint
  * a zero direction component) are re-walked on the canonical tree in the reference's order (trhip_stats.fallback_rays).  Results equal a walk of the canonical tree
  * alone bit for bit (option "hybrid" = 0 runs exactly that walk, for A/B).
  * trhip_scene_bvh_mode: *mode = 0 the library's tree alone (bvh_builder 0 / 1 / 3), 1 the canonical tree alone (bvh_builder 2; or a scene whose accelerator could not be
- *   certified: leaf boxes that differ between the trees), 2 both; *accel_nodes / *accel_depth describe the accelerator (0 without one).
+ *   certified: leaf boxes that differ between the trees), 2 both, 3 the library's tree as the canonical tree AND, four children wide, as its own accelerator (a default
+ *   commit on a scene where the reference's construction fails: trhip_scene_bvh_note says why); *accel_nodes / *accel_depth describe the accelerator (0 without one).
  * trhip_scene_get_accelerator: the accelerator in the layout of trhip_scene_get_bvh (prim_order[accelerator slot] = caller primitive index); size it with
  *   trhip_scene_bvh_mode.  Any output pointer may be NULL. */
 int trhip_scene_bvh_mode(const trhip_scene* scene, int* mode, uint32_t* accel_nodes, uint32_t* accel_depth);

@@ -86,18 +86,6 @@ namespace th {
 #ifndef TH_TRACE3C_MAX_A
 #define TH_TRACE3C_MAX_A 8
 #endif
-// The interior step of the scalar-margin form (round 5, header "The step"): 0 = slab_test3 on both children (the reference's clause structure, the two tight clauses, the
-// split axis' sign picks the near child); 1 = the six slab products once, near / far by min / max, one max3 / min3 pair for the exact entry / exit and one for the box grown by
-// the ray's margin, the nearer ENTRY first
-#ifndef TH_TRACE3C_FAST
-#define TH_TRACE3C_FAST 0
-#endif
-#ifndef TH_TRACE3C_LAT
-#define TH_TRACE3C_LAT 17
-#endif
-#ifndef TH_TRACE3C_ORDER
-#define TH_TRACE3C_ORDER 0  // FAST: 1 = the child with the smaller entry distance first (measured: 2 % more boxes, 1 % slower); 0 = the split axis' sign (k_trace3's order)
-#endif
 constexpr float kCertDt = 1.52587890625e-5f;     // 2^-16: dt = kCertDt D |1 / d[kz]| (256 ulps of the largest possible t)
 constexpr float kCertGrow = 9.5367431640625e-7f;  // 2^-20 (16 ulps): the sheared vertex coordinates x' = fl(fl(v_x - o_x) + fl(S_x fl(v_z - o_z))) carry <= 5 ulps of D each (one for each
                                                   // subtraction, two for S_x, one for the product), so the point of the TRUE triangle with the computed barycentrics lies within 5 ulps of D per
@@ -117,7 +105,7 @@ typedef float v2f __attribute__((ext_vector_type(2)));  // (two products per ins
 // reciprocal direction live in three register pairs instead of six (the compiler's own selection duplicates each component into a pair of its own).  IEEE single operations, each
 // rounded once: the same numbers as the scalar forms.
 template <int H>
-TH_D v2f pk_sub_h(v2f a, v2f b) {
+TH_D v2f pk_sub_h(v2f a, v2f b) {  // (used by the four-wide step: th_trace3c4.h)
     v2f r;
     if (H == 0)
         asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
@@ -174,7 +162,6 @@ struct CertHot {   // … and what the walk itself, or every fetch, needs
     uint32_t n_spheres;
     const SphereCert* spheres;  // one contiguous record per sphere (a single burst of scalar loads each)
     float mle[3];               // CertScene::mle_small
-    float klat;                 // TH_TRACE3C_FAST == 2: 2^-TH_TRACE3C_LAT / tight_scale: the scalar lateral margin ms = klat x em x max |1 / d|
 };
 template <int TH_ONE_COPY = 0> __global__ void k_store_cert_cold(CertCold* dst, CertCold v) { *dst = v; }
 // "count_visits": one thread, between the certified walk and the fallback walk of a launch (phase 0) and after the fallback walk (phase 1): what the closest-hit visit
@@ -284,7 +271,6 @@ __global__ __launch_bounds__(kBlock, (BIG || (AXIS && TH_TRACE3C_AXIS_LESS)) ? T
                                                                                                uint32_t* __restrict__ work, uint2* __restrict__ overflow, Counters* ctr) {
     constexpr int kLds = TH_TRACE3C_LDS;
     constexpr uint32_t kLeafBit = 1u << 24;  // a node word >= this (and != kRefNone) is a leaf: ref | count << 24
-    constexpr bool FAST = TH_TRACE3C_FAST != 0 && !AXIS;  // header "The step"
     __shared__ uint2 s_stk[kLds][kBlock];  // {child word, entry distance}: one 8-byte LDS access per push / pop
     // per-lane state that is only touched when a ray is fetched, accepted or finished lives in LDS, not in registers (the walk runs at the 80-VGPR line of six waves per
     // SIMD; a scratch spill costs a trip to memory, an LDS word 64 cycles): the ray's queue index, its state word, the entry distance of the node in hand
@@ -311,9 +297,6 @@ __global__ __launch_bounds__(kBlock, (BIG || (AXIS && TH_TRACE3C_AXIS_LESS)) ? T
 #define negz (inv_d.z < 0.0f)
     float t_lim = 0.0f;   // t_max + 2 dt, t_max = the t of the last accepted candidate (or the ray's own t_max): what the primitive tests accept up to; a box is culled when the lower
                           // bound of what it holds — its entry distance minus the margin — reaches it
-#if TH_TRACE3C_FAST == 2
-    float ms = 0.0f;      // per ray: the scalar lateral margin of the box tests (header "The step")
-#endif
     float mb = 0.0f;      // per ray: the margin of the lower bound: non-flat primitives their kz extent, everything the growth in the entering axis (with AXIS the growth is applied per
                           // axis to the box instead, and is not in here)
     // s_ex[tid]: entry distance of the node in `cur` (the reference's tx_min of its box)
@@ -444,9 +427,6 @@ __global__ __launch_bounds__(kBlock, (BIG || (AXIS && TH_TRACE3C_AXIS_LESS)) ? T
                         const float dt = margin_t();
                         const float mkz = (shear.kz == 0 ? ch.mle[0] : (shear.kz == 1 ? ch.mle[1] : ch.mle[2])) * fabsf(shear.sz);
                         mb = AXIS ? mkz : __fmaf_rn(growth(), inv_max(), mkz);
-#if TH_TRACE3C_FAST == 2
-                        ms = ch.klat * em * inv_max();
-#endif
                         t_lim = t_own + 2.0f * dt;
                         sp = 0;
                         active = true;
@@ -463,7 +443,7 @@ __global__ __launch_bounds__(kBlock, (BIG || (AXIS && TH_TRACE3C_AXIS_LESS)) ? T
                             if (COUNT) n_why[0]++;
                         } else if (ws.root_ref != kRefNone && slab_test2(ws.root_box[0], ws.root_box[1], ws.root_box[2], ws.root_box[3], ws.root_box[4], ws.root_box[5], o, inv_d, em, false, negx, negy, negz, tmin)) {
                             cur = ws.root_ref | (ws.root_cnt << 24);  // (the root is not culled by t: the reference's clause `tmin < t_max` holds whenever anything inside can be accepted)
-                            s_ex[tid] = FAST ? __uint_as_float(__float_as_uint(tmin) & ~1u) : tmin;  // (FAST: bit 0 of an entry distance = "not strict"; the root passed the reference's own clauses)
+                            s_ex[tid] = tmin;
                             // the sphere pre-pass of the chunk left this ray's state in its hit record: an accepted sphere (the incumbent), the sphere it starts inside of, or
                             // "to the reference-order walk"
                             bool flagged = false;
@@ -552,55 +532,18 @@ __global__ __launch_bounds__(kBlock, (BIG || (AXIS && TH_TRACE3C_AXIS_LESS)) ? T
                     float bl, br;    // per child: what is compared with t_cull — +Inf for a missed child
                     float vl, vr;    // … and the entry distance that travels with it (only read for a child that is entered)
                     bool neg;        // the second child first
-                    if constexpr (FAST) {
-                        // ---- header "The step": the slab products are the reference's (bounds.jl:183-193: (plane - o) x inv_d), two at a time (v_pk_add_f32 / v_pk_mul_f32: the
-                        //      accelerator's nodes keep each axis' two planes side by side); which plane is the near one is read off the products ----
-                        const v2f p_a = v2f{o.x, o.y}, p_b = v2f{o.z, inv_d.x}, p_c = v2f{inv_d.y, inv_d.z};
-                        const v2f Lx = pk_mul_h<1>(pk_sub_h<0>(v2f{a0.x, a0.y}, p_a), p_b), Ly = pk_mul_h<0>(pk_sub_h<1>(v2f{a0.z, a0.w}, p_a), p_c), Lz = pk_mul_h<1>(pk_sub_h<0>(v2f{a1.x, a1.y}, p_b), p_c);
-                        const v2f Rx = pk_mul_h<1>(pk_sub_h<0>(v2f{a1.z, a1.w}, p_a), p_b), Ry = pk_mul_h<0>(pk_sub_h<1>(v2f{a2.x, a2.y}, p_a), p_c), Rz = pk_mul_h<1>(pk_sub_h<0>(v2f{a2.z, a2.w}, p_b), p_c);
-                        const float lnx = amin(Lx.x, Lx.y), lfx = amax(Lx.x, Lx.y), lny = amin(Ly.x, Ly.y), lfy = amax(Ly.x, Ly.y), lnz = amin(Lz.x, Lz.y), lfz = amax(Lz.x, Lz.y);
-                        const float rnx = amin(Rx.x, Rx.y), rfx = amax(Rx.x, Rx.y), rny = amin(Ry.x, Ry.y), rfy = amax(Ry.x, Ry.y), rnz = amin(Rz.x, Rz.y), rfz = amax(Rz.x, Rz.y);
-                        const float l_in = amax3(lnx, lny, lnz), l_out = amin3(lfx, lfy, lfz);  // = bounds.jl:196's tx_min; <= :197's tx_max (the reference keeps the LARGER of the x and y exits)
-                        const float r_in = amax3(rnx, rny, rnz), r_out = amin3(rfx, rfy, rfz);
-#if TH_TRACE3C_FAST != 2
-                        // the box grown by em per axis (slab_test2's margin, now on every clause): a box that fails this holds no acceptable hit
-                        const float gx = em * fabsf(inv_d.x), gy = em * fabsf(inv_d.y), gz = em * fabsf(inv_d.z);
-                        const v2f Glx = v2f{lnx, lfx} + v2f{-gx, gx}, Gly = v2f{lny, lfy} + v2f{-gy, gy}, Glz = v2f{lnz, lfz} + v2f{-gz, gz};
-                        const v2f Grx = v2f{rnx, rfx} + v2f{-gx, gx}, Gry = v2f{rny, rfy} + v2f{-gy, gy}, Grz = v2f{rnz, rfz} + v2f{-gz, gz};
-                        const float l_ing = amax3(Glx.x, Gly.x, Glz.x), l_outg = amin3(Glx.y, Gly.y, Glz.y);
-                        const float r_ing = amax3(Grx.x, Gry.x, Grz.x), r_outg = amin3(Grx.y, Gry.y, Grz.y);
-                        const bool hl = (l_ing <= l_outg) && (l_outg >= 0.0f), hr = (r_ing <= r_outg) && (r_outg >= 0.0f);
-#else
-                        // … grown by the ray's scalar margin ms (t units: a length of 2^-TH_TRACE3C_LAT x D on the axis of the largest |1 / d|, more on the others)
-                        const bool hl = (l_in - l_out <= 2.0f * ms) && (l_out >= -ms), hr = (r_in - r_out <= 2.0f * ms) && (r_out >= -ms);
-#endif
-                        // STRICT: the un-grown interval is not empty and ends ahead of the origin: every clause of bounds.jl:186-198 but the t_max one then holds (its exits are no
-                        // smaller than l_out), and l_in is its tx_min bit for bit.  The entry distance travels with its lowest mantissa bit replaced by "not strict" (a leaf reached that
-                        // way: the reference may or may not enter it — a candidate found inside sends the ray to the reference-order walk)
-                        const bool sl = (l_in <= l_out) && (l_out > 0.0f), sr = (r_in <= r_out) && (r_out > 0.0f);
-                        vl = __uint_as_float((__float_as_uint(l_in) & ~1u) | (sl ? 0u : 1u));
-                        vr = __uint_as_float((__float_as_uint(r_in) & ~1u) | (sr ? 0u : 1u));
-                        bl = hl ? vl : kInf;
-                        br = hr ? vr : kInf;
-#if TH_TRACE3C_ORDER
-                        neg = br < bl;
-#else
-                        neg = ((meta & 3u) == 0u ? inv_d.x : ((meta & 3u) == 1u ? inv_d.y : inv_d.z)) < 0.0f;
-#endif
-                    } else {
-                        const float gr = AXIS ? growth() : 0.0f;
-                        float gl, gr_;
-                        const bool hl = slab_test3<AXIS>(a0.x, a0.z, a1.x, a0.y, a0.w, a1.y, o, inv_d, em, gr, !(meta & 4u), negx, negy, negz, vl, gl);  // (the accelerator's node layout: each axis' two planes side by side)
-                        const bool hr = slab_test3<AXIS>(a1.z, a2.x, a2.z, a1.w, a2.y, a2.w, o, inv_d, em, gr, !(meta & 8u), negx, negy, negz, vr, gr_);
-                        // per child: its exact entry distance travels with it; what is compared with t_cull is that distance (with AXIS: the entry of the grown box); a missed child: +Inf.
-                        // (Boxes on a sphere's path keep the reference's clauses alone — bits 2 / 3 — but are culled like any other: the spheres themselves were tested at the fetch.)
-                        bl = hl ? (AXIS ? gl : vl) : kInf;
-                        br = hr ? (AXIS ? gr_ : vr) : kInf;
-                        const uint32_t axis = meta & 3u;
-                        neg = axis == 0 ? negx : (axis == 1 ? negy : negz);
-                    }
+                    const float gr = AXIS ? growth() : 0.0f;
+                    float gl, gr_;
+                    const bool hl = slab_test3<AXIS>(a0.x, a0.z, a1.x, a0.y, a0.w, a1.y, o, inv_d, em, gr, !(meta & 4u), negx, negy, negz, vl, gl);  // (the accelerator's node layout: each axis' two planes side by side)
+                    const bool hr = slab_test3<AXIS>(a1.z, a2.x, a2.z, a1.w, a2.y, a2.w, o, inv_d, em, gr, !(meta & 8u), negx, negy, negz, vr, gr_);
+                    // per child: its exact entry distance travels with it; what is compared with t_cull is that distance (with AXIS: the entry of the grown box); a missed child: +Inf.
+                    // (Boxes on a sphere's path keep the reference's clauses alone — bits 2 / 3 — but are culled like any other: the spheres themselves were tested at the fetch.)
+                    bl = hl ? (AXIS ? gl : vl) : kInf;
+                    br = hr ? (AXIS ? gr_ : vr) : kInf;
+                    const uint32_t axis = meta & 3u;
+                    neg = axis == 0 ? negx : (axis == 1 ? negy : negz);
                     const float bn = neg ? br : bl, bf = neg ? bl : br;
-                    const float vn = (AXIS && !FAST) ? (neg ? vr : vl) : bn, vf = (AXIS && !FAST) ? (neg ? vl : vr) : bf;  // (for a child that is entered the two are the same number unless AXIS)
+                    const float vn = AXIS ? (neg ? vr : vl) : bn, vf = AXIS ? (neg ? vl : vr) : bf;  // (for a child that is entered the two are the same number unless AXIS)
                     const uint32_t nenc = neg ? renc : lenc, fenc = neg ? lenc : renc;
                     const bool go_n = bn < t_cull, go_f = bf < t_cull;
                     // t_max never goes up in THIS walk (a ray that could see it raised is flagged and leaves): an entry that fails now fails at pop time
@@ -678,10 +621,7 @@ __global__ __launch_bounds__(kBlock, (BIG || (AXIS && TH_TRACE3C_AXIS_LESS)) ? T
                     if (counts) {
                         const float dt = margin_t();
                         // accepted iff it lies 2 dt below the incumbent (t_lim - 4 dt; the ray's own t_max at first) AND its leaf box lets the reference in by t + dt (the guard); a NaN fails
-                        // (FAST: the entry distance lost its lowest mantissa bit to the "not strict" flag: the guard reads the larger of the two numbers it can have been)
-                        const float ex = s_ex[tid];
-                        const float ex_hi = __uint_as_float(ex < 0.0f ? __float_as_uint(ex) & ~1u : __float_as_uint(ex) | 1u);
-                        if (!(tt.t <= t_lim - 4.0f * dt) || (FAST ? ((__float_as_uint(ex) & 1u) != 0u || !(ex_hi <= tt.t + dt)) : !(ex <= tt.t + dt))) {
+                        if (!(tt.t <= t_lim - 4.0f * dt) || !(s_ex[tid] <= tt.t + dt)) {
                             if (COUNT && !flagged) why = 2u;
                             flagged = true;
                         } else if (!flagged) {

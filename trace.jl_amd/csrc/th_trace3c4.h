@@ -16,25 +16,26 @@
 
 namespace th {
 
+// five waves per SIMD at 87 VGPRs without a spill and 13 stack levels in LDS: 66.9 / 67.4 ms against 67.8 / 68.1 at six waves (80 VGPRs, 13 spilled, 11 levels); 14 levels: 75 (a block
+// fewer per CU)
 #ifndef TH_TRACE3C4_WAVES
-#define TH_TRACE3C4_WAVES 6
+#define TH_TRACE3C4_WAVES 5
 #endif
 #ifndef TH_TRACE3C4_FETCH_BURST
 #define TH_TRACE3C4_FETCH_BURST 1
 #endif
 #ifndef TH_TRACE3C4_LDS
-#define TH_TRACE3C4_LDS 11
+#define TH_TRACE3C4_LDS 13
 #endif
 
 template <bool COUNT, bool FULL_ONLY, bool BIG = false, bool AXIS = false>
-__global__ __launch_bounds__(kBlock, BIG ? TH_TRACE3C4_WAVES - 1 : TH_TRACE3C4_WAVES) void k_trace3c4(DeviceScene sc /* prims: the accelerator's order */, WideScene ws /* the accelerator */, CertHot ch,
+__global__ __launch_bounds__(kBlock, TH_TRACE3C4_WAVES) void k_trace3c4(DeviceScene sc /* prims: the accelerator's order */, WideScene ws /* the accelerator */, CertHot ch,
                                                                                                const CertCold* __restrict__ cold, SegQueue q, const float4* __restrict__ ro,
                                                                                                const float4* __restrict__ rd, const float* __restrict__ tmax_or_null, TraceOut out,
                                                                                                uint32_t* __restrict__ work, uint2* __restrict__ overflow, Counters* ctr) {
     constexpr int kLds = TH_TRACE3C4_LDS;
 
     constexpr uint32_t kLeafBit = 1u << 24;  // a node word >= this (and != kRefNone) is a leaf: ref | count << 24
-    constexpr bool FAST = false;  // (entry distances are the reference's own tx_min, no flag bit)
     __shared__ uint2 s_stk[kLds][kBlock];  // {child word, entry distance}: one 8-byte LDS access per push / pop
     // per-lane state that is only touched when a ray is fetched, accepted or finished lives in LDS, not in registers (the walk runs at the 80-VGPR line of six waves per
     // SIMD; a scratch spill costs a trip to memory, an LDS word 64 cycles): the ray's queue index, its state word, the entry distance of the node in hand
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(kBlock, BIG ? TH_TRACE3C4_WAVES - 1 : TH_TRACE3C4_W
                             if (COUNT) n_why[0]++;
                         } else if (ws.root_ref != kRefNone && slab_test2(ws.root_box[0], ws.root_box[1], ws.root_box[2], ws.root_box[3], ws.root_box[4], ws.root_box[5], o, inv_d, em, false, negx, negy, negz, tmin)) {
                             cur = ws.root_ref | (ws.root_cnt << 24);  // (the root is not culled by t: the reference's clause `tmin < t_max` holds whenever anything inside can be accepted)
-                            s_ex[tid] = FAST ? __uint_as_float(__float_as_uint(tmin) & ~1u) : tmin;  // (FAST: bit 0 of an entry distance = "not strict"; the root passed the reference's own clauses)
+                            s_ex[tid] = tmin;
                             // the sphere pre-pass of the chunk left this ray's state in its hit record: an accepted sphere (the incumbent), the sphere it starts inside of, or
                             // "to the reference-order walk"
                             bool flagged = false;
@@ -431,10 +432,7 @@ __global__ __launch_bounds__(kBlock, BIG ? TH_TRACE3C4_WAVES - 1 : TH_TRACE3C4_W
                     if (counts) {
                         const float dt = margin_t();
                         // accepted iff it lies 2 dt below the incumbent (t_lim - 4 dt; the ray's own t_max at first) AND its leaf box lets the reference in by t + dt (the guard); a NaN fails
-                        // (FAST: the entry distance lost its lowest mantissa bit to the "not strict" flag: the guard reads the larger of the two numbers it can have been)
-                        const float ex = s_ex[tid];
-                        const float ex_hi = __uint_as_float(ex < 0.0f ? __float_as_uint(ex) & ~1u : __float_as_uint(ex) | 1u);
-                        if (!(tt.t <= t_lim - 4.0f * dt) || (FAST ? ((__float_as_uint(ex) & 1u) != 0u || !(ex_hi <= tt.t + dt)) : !(ex <= tt.t + dt))) {
+                        if (!(tt.t <= t_lim - 4.0f * dt) || !(s_ex[tid] <= tt.t + dt)) {
                             if (COUNT && !flagged) why = 2u;
                             flagged = true;
                         } else if (!flagged) {

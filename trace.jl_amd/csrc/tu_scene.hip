@@ -1539,7 +1539,19 @@ int trhip_scene_commit(trhip_scene* s, int max_node_primitives) {
         return fail(s->ctx, TRHIP_ERR_UNSUPPORTED, "BVH depth %u exceeds the 64-entry traversal stack (bvh.jl:222)", s->bvh.max_depth);
     s->literal_only = false;
     s->bvh_mode = 0;
-    return upload_scene(s);
+    if (int rc = upload_scene(s)) return rc;
+    // A DEFAULT commit that ended with the library's tree as its one (canonical) tree — the reference's construction failed on the scene: 10 M triangles — still gets the
+    // four-wide certified walk: the same tree rides along as its own accelerator (mode 3).  The answers are the canonical tree's own walk's, as always; explicit requests
+    // (bvh_builder 0 / 3) keep the single tree.
+    if (mode < 0 && s->ctx->wide4 && !want_chain && !compose && s->wide_ok && s->wide.root_cnt == 0) {
+        s->acc = s->bvh;
+        if (int rc = upload_accelerator(s)) return rc;
+        if (s->hybrid_ok && s->wide_acc.w4nodes)
+            s->bvh_mode = 3;
+        else
+            drop_accelerator(s);
+    }
+    return 0;
 }
 int trhip_build_bvh_host(int builder, const float* prim_bounds, uint32_t n_prims, int max_node_primitives, float* node_bounds, uint32_t* node_a, uint32_t* node_flags, uint32_t* n_nodes_inout,
                          uint32_t* prim_order, uint32_t* max_depth_out) {

@@ -79,7 +79,7 @@ void launch_trace3c(trhip_ctx* ctx, hipStream_t st, const trhip_scene* sc, bool 
     cc.sq_flat = cv.sq_flat;
     cc.inv_tight = cv.inv_tight;
     hipLaunchKernelGGL(k_store_cert_cold, dim3(1), dim3(1), 0, st, cold, cc);
-    const CertHot hot{kCertDt * cv.inv_tight, kCertGrow * cv.inv_tight, kCertFlat * cv.sq_flat, cv.n_spheres, (const SphereCert*)cv.sphere_cert, {cv.mle_small[0], cv.mle_small[1], cv.mle_small[2]}, std::ldexp(cv.inv_tight, -TH_TRACE3C_LAT)};
+    const CertHot hot{kCertDt * cv.inv_tight, kCertGrow * cv.inv_tight, kCertFlat * cv.sq_flat, cv.n_spheres, (const SphereCert*)cv.sphere_cert, {cv.mle_small[0], cv.mle_small[1], cv.mle_small[2]}};
 #ifdef TRHIP_EXPERIMENTS
     if (ctx->leaf_queue && !big) {  // option "leaf_queue": the same walk with queued leaves (th_trace3d.h)
         if (cnt) {
