@@ -31,6 +31,13 @@ KERNEL_CLASSES = ("raygen", "trace_closest", "shade", "trace_any", "film")
 TRAVERSAL_KERNEL = {1: "k_trace_closest", 2: "k_trace2", 3: "k_trace3", 4: "k_trace8", 5: "k_trace_leaf", 6: "k_trace4", 7: "k_trace7", 9: "k_trace3c"}
 BVH_MODE = {0: "library-sah", 1: "reference", 2: "hybrid", 3: "library-sah + itself four-wide as accelerator"}  # trhip_scene_bvh_mode: which tree(s) the scene holds (include/tracehip.h)
 L2_PLUS_MALL_BYTES = (32 + 256) << 20  # 8 x 4 MiB L2 + 256 MiB Infinity Cache (MI355X_MICROARCH.md): a scene below this is served from cache, not HBM
+def closest_kernel(traversal, opts):
+    """The closest-hit walk a launch runs: hybrid mode (traversal 9) walks the accelerator four-wide (k_trace3c4, th_trace3c4.h) unless option wide4 = 0 (k_trace3c, the binary walk)."""
+    if int(traversal) == 9 and not any(kv.replace(" ", "") == "wide4=0" for kv in opts):
+        return "k_trace3c4"
+    return TRAVERSAL_KERNEL.get(int(traversal), "k_trace")
+
+
 TRAVERSAL_KERNEL_ANY = {1: "k_trace_any", 2: "k_trace2", 3: "k_trace3", 4: "k_trace8", 5: "k_trace_leaf", 6: "k_trace4", 7: "k_trace3"}
 
 
@@ -130,7 +137,7 @@ def pmc_child_runs(args, kernel_prefix: str, want_any: bool, passes):
 # (one 64-byte request each: FETCH_SIZE tallies REQUESTS at 64 B), 0.590 for 48-byte records (they straddle request boundaries).  The traversal kernels' reads are
 # 64-byte node gathers (1 510 of ~1 760 B per ray on S-mesh), 48-byte primitive records and a 32-byte ray stream: factor 1.0.  When the request-size counters
 # (TCC_EA0_RDREQ_{32B,64B,128B}) are available the bench uses their exact byte count instead of any factor.
-FETCH_FACTOR = {"default": 2.0, "k_trace3": 1.0, "k_trace3c": 1.0, "k_trace2": 1.0, "k_trace7": 1.0, "k_trace4": 1.0, "k_trace_closest": 1.0, "k_sppm_gather": 1.0}
+FETCH_FACTOR = {"default": 2.0, "k_trace3": 1.0, "k_trace3c": 1.0, "k_trace3c4": 1.0, "k_trace2": 1.0, "k_trace7": 1.0, "k_trace4": 1.0, "k_trace_closest": 1.0, "k_sppm_gather": 1.0}
 
 
 def measure_counters(args, kernel_prefix: str, want_any: bool):
@@ -286,7 +293,7 @@ def run_sppm(args, T, ctx, graft, rank, world, comm_ok):
         dom_bytes = kb["trace_closest"] * (args.steps if world == 1 else 0) / max(1, launches["trace_closest"])
         dom_ms = ms["trace_closest"] / max(1, launches["trace_closest"])
         dom_launches = launches["trace_closest"]
-        kprefix = TRAVERSAL_KERNEL.get(int(sv.traversal), "k_trace")
+        kprefix = closest_kernel(sv.traversal, args.opt)
         kname = kprefix + "<closest>"
         extra = {}
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
@@ -545,11 +552,11 @@ def main():
             dominant = max((k for k in agg["ms"] if k != "trace_any"), key=lambda k: agg["ms"][k])
             dom_ms = agg["ms"][dominant] / max(1, agg["launches"][dominant])
             dom_bytes = per_step[dominant] * steps / max(1, agg["launches"][dominant])
-            kname = {"trace_closest": TRAVERSAL_KERNEL.get(int(sv.traversal), "k_trace"), "shade": "k_shade_path", "film": "k_film_gather", "raygen": "k_raygen"}[dominant]
+            kname = {"trace_closest": closest_kernel(sv.traversal, args.opt), "shade": "k_shade_path", "film": "k_film_gather", "raygen": "k_raygen"}[dominant]
             if hybrid and dominant == "trace_closest" and flat.bvh_mode()[1] == 1:
                 kname = "k_trace_leaf_c"  # a one-leaf accelerator (S-cornell, the shadows scene): the certified walk is the uniform loop over the canonical slots
             if hybrid and dominant == "trace_closest":
-                # a hybrid closest-hit launch = the certified walk on the accelerator tree (k_trace3c, the dominant kernel) + the reference-order walk of the rays it hands back
+                # a hybrid closest-hit launch = the certified walk on the accelerator tree (k_trace3c4 or k_trace3c, the dominant kernel) + the reference-order walk of the rays it hands back
                 # (k_trace3 on the canonical tree); the library times the hand-over inside every launch (trhip_stats.ms_fallback): the roofline is k_trace3c's alone
                 dom_ms = (agg["ms"]["trace_closest"] - agg["ms_fallback"]) / max(1, agg["launches"]["trace_closest"])
                 dom_bytes = (per_step["trace_closest"] - fb_bytes) * steps / max(1, agg["launches"]["trace_closest"])
@@ -574,7 +581,7 @@ def main():
                 roofline["hybrid"] = {"certified_walk_ms_per_step": round((agg["ms"]["trace_closest"] - agg["ms_fallback"]) / steps, 3), "fallback_walk_ms_per_step": round(agg["ms_fallback"] / steps, 3),
                                       "fallback_launches": agg["launches_fallback"], "fallback_nodes_per_fallback_ray": round(sv.nodes_visited_fallback / max(1, sv.fallback_rays), 1),
                                       "fallback_why": dict(zip(("direction", "sphere", "near_tie_or_guard"), [int(x) for x in sv.count_sub[:3]])),
-                                      "note": "closest-hit launch = k_trace3c on the accelerator tree (the library's SAH tree, walked under the order-independence certificate) + k_trace3 on the "
+                                      "note": "closest-hit launch = the certified walk (k_trace3c4, four-wide; k_trace3c under wide4 = 0) on the accelerator tree (the library's SAH tree, walked under the order-independence certificate) + k_trace3 on the "
                                               "canonical tree (the reference's own) over the rays handed back; kernel_ms_per_step.trace_closest is both"}
             over = [k for k, v in gbps.items() if v is not None and v > HBM_PEAK_GBS and not k.startswith("trace")]
             # no line may carry a fraction above 1 without saying so: a request rate above the HBM peak means L2 / MALL serve part of the requests

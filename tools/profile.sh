@@ -7,7 +7,7 @@ TAG=$1; shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="$GRAFT_REPO_ROOT/bench.py --no-traffic --no-cpu-baseline --no-micro --no-hbm-resident"
+B="$GRAFT_REPO_ROOT/bench.py --no-traffic --no-cpu-baseline --no-micro --no-hbm-resident --no-modes"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $B "$@" > $OUT/bench_stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $B "$@" > $OUT/bench_pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $B "$@" > $OUT/bench_pmc_write.log 2>&1

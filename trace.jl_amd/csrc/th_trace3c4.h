@@ -24,6 +24,9 @@ namespace th {
 #ifndef TH_TRACE3C4_FETCH_BURST
 #define TH_TRACE3C4_FETCH_BURST 1
 #endif
+#ifndef TH_TRACE3C4_LEAF_PIPE
+#define TH_TRACE3C4_LEAF_PIPE 0
+#endif
 #ifndef TH_TRACE3C4_LDS
 #define TH_TRACE3C4_LDS 13
 #endif
@@ -409,11 +412,26 @@ __global__ __launch_bounds__(kBlock, TH_TRACE3C4_WAVES) void k_trace3c4(DeviceSc
                     top_tm = __uint_as_float(e.y);
                 }
             }
+#if TH_TRACE3C4_LEAF_PIPE
+            // the records of primitive k + 1 are requested before primitive k is tested: a leaf of n primitives costs one round trip + n tests, not n round trips
+            float4 q0 = sc.prims[3 * leaf_ref], q1 = sc.prims[3 * leaf_ref + 1], q2 = sc.prims[3 * leaf_ref + 2];
+#pragma unroll 1
+            for (uint32_t k = 0; k < leaf_cnt; ++k) {
+                const float4 p0 = q0, p1 = q1, p2 = q2;
+                asm volatile("" ::"v"(p0.x), "v"(p0.w), "v"(p1.x), "v"(p1.y), "v"(p1.z), "v"(p1.w), "v"(p2.x), "v"(p2.y), "v"(p2.z), "v"(p2.w));
+                if (k + 1 < leaf_cnt) {
+                    const float4* nx = sc.prims + 3 * (size_t)(leaf_ref + k + 1);
+                    q0 = nx[0];
+                    q1 = nx[1];
+                    q2 = nx[2];
+                }
+#else
             for (uint32_t k = 0; k < leaf_cnt; ++k) {
                 const uint32_t slot = leaf_ref + k;
                 const float4 p0 = sc.prims[3 * slot];
                 const float4 p1 = sc.prims[3 * slot + 1], p2 = sc.prims[3 * slot + 2];
                 asm volatile("" ::"v"(p1.x), "v"(p1.y), "v"(p1.z), "v"(p1.w), "v"(p2.x), "v"(p2.y), "v"(p2.z), "v"(p2.w));  // one burst (th_trace2.h "one fetch per leaf")
+#endif
                 const uint32_t meta = __float_as_uint(p0.w);
                 if (COUNT) np++;
                 TriTest tt;
