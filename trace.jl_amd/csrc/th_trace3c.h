@@ -688,12 +688,6 @@ __global__ __launch_bounds__(kBlock, (BIG || (AXIS && TH_TRACE3C_AXIS_LESS)) ? T
 #ifndef TH_TRACE_LEAF_C_WAVES
 #define TH_TRACE_LEAF_C_WAVES TH_TRACE_LEAF_WAVES
 #endif
-#ifndef TH_LEAF_C_CULL
-#define TH_LEAF_C_CULL 0
-#endif
-#ifndef TH_LEAF_C_STORE_END
-#define TH_LEAF_C_STORE_END 0
-#endif
 #ifndef TH_LEAF_C_DEFER
 #define TH_LEAF_C_DEFER 1  // 1: the canonical leaf boxes are tested once per ray, for the candidate it ends up holding; 0: for every candidate as it is found (round 4)
 #endif
@@ -746,32 +740,13 @@ __global__ __launch_bounds__(kBlock, FULL_ONLY ? TH_TRACE_LEAF_C_WAVES : 4) void
         // passes, the t_max-free clauses on its leaf's box do not) may ride as the incumbent for a while — whatever it displaced or hid lies farther than what finally holds the
         // ray, or the final check sends the ray to the reference-order walk.
         uint32_t best_slot = 0u;
-#if TH_LEAF_C_CULL
-        float best_ex = 0.0f;
-#endif
-#if TH_LEAF_C_STORE_END
-        float4 best_r4 = make_float4(kInf, __int_as_float(-1), 0.0f, 0.0f);
-#endif  // (the record itself is stored when the candidate is accepted — a nearer one overwrites it, the reference-order walk rewrites a flagged ray's)
+        float4 best_r4 = make_float4(kInf, __int_as_float(-1), 0.0f, 0.0f);  // the record the ray holds, stored once at the end (stored at every acceptance: 17.9 against 17.4 ms per 64 spp
+                                                                             // on S-cornell).  Measured and dropped (profiles/r5/r5_trace3c4_experiments.txt): the leaf-box clauses in front
+                                                                             // of every primitive (11.9 -> 4.7 tests per ray, 19.1 ms), the next slot's scalar loads issued a slot ahead (18.9 ms)
 #pragma unroll 1
         for (uint32_t k = 0; k < cnt; ++k) {
             if (__ballot(live) == 0ull) break;
             const uint32_t slot = first + k;  // wave-uniform: scalar loads
-#if TH_LEAF_C_CULL
-            // the reference tests a primitive only in a leaf whose box passes bounds.jl:186-198 (t_max aside: monotonic in the box, so the leaf's ancestors pass with it):
-            // the same clauses on the slot's canonical leaf box, no margin — a wave none of whose rays reaches the leaf skips the primitive's records altogether
-            const bool live_all = live;
-            float ex_k = 0.0f;
-            {
-                const float* bx = cs.slot_boxes + 6 * (size_t)slot;
-                const float b0 = uniform_load(bx, 0), b1 = uniform_load(bx, 1), b2 = uniform_load(bx, 2), b3 = uniform_load(bx, 3), b4 = uniform_load(bx, 4), b5 = uniform_load(bx, 5);
-                if (COUNT && live) nn++;
-                live = live && slab_test2(b0, b1, b2, b3, b4, b5, o, inv_d, 0.0f, false, negx, negy, negz, ex_k);
-            }
-            if (__ballot(live) == 0ull) {
-                live = live_all;
-                continue;
-            }
-#endif
             const float4 p0 = uniform_load(sc.prims, 3 * slot);
             const uint32_t meta = __float_as_uint(p0.w);
             float t_c = 0.0f;
@@ -815,35 +790,18 @@ __global__ __launch_bounds__(kBlock, FULL_ONLY ? TH_TRACE_LEAF_C_WAVES : 4) void
                     found = true;
                     sticky = inside;
                     best_slot = slot;
-#if TH_LEAF_C_CULL
-                    best_ex = ex_k;
-#endif
-#if TH_LEAF_C_STORE_END
                     best_r4 = r4;
-#else
-                    out.hits[idx] = r4;
-#endif
                 }
             }
-#if TH_LEAF_C_CULL
-            live = live_all;
-#endif
             if (flagged) live = false;
         }
-#if TH_LEAF_C_CULL
-        (void)best_slot;
-        if (valid && found && !flagged && !(best_ex <= (sticky ? 0.0f : t_max + dt))) flagged = true;  // the guard: the reference enters the holder's leaf by t + dt
-#else
         if (valid && found && !flagged) {  // the reference reaches the holder's leaf (bounds.jl:186-198 on its box, t_max aside) and enters it by t + dt (the guard); a sphere entered from inside: its box holds the origin
             const float* bx = cs.slot_boxes + 6 * (size_t)best_slot;
             float ex;
             if (COUNT) nn++;
             if (!slab_test2(bx[0], bx[1], bx[2], bx[3], bx[4], bx[5], o, inv_d, 0.0f, false, negx, negy, negz, ex) || !(ex <= (sticky ? 0.0f : t_max + dt))) flagged = true;
         }
-#endif
-#if TH_LEAF_C_STORE_END
         if (valid && found && !flagged) out.hits[idx] = best_r4;
-#endif
 #else
 #pragma unroll 1
         for (uint32_t k = 0; k < cnt; ++k) {

@@ -24,8 +24,8 @@ namespace th {
 #ifndef TH_TRACE3C4_FETCH_BURST
 #define TH_TRACE3C4_FETCH_BURST 1
 #endif
-#ifndef TH_TRACE3C4_LEAF_PIPE
-#define TH_TRACE3C4_LEAF_PIPE 0
+#ifndef TH_TRACE3C4_LEAN
+#define TH_TRACE3C4_LEAN 0
 #endif
 #ifndef TH_TRACE3C4_LDS
 #define TH_TRACE3C4_LDS 13
@@ -325,12 +325,24 @@ __global__ __launch_bounds__(kBlock, TH_TRACE3C4_WAVES) void k_trace3c4(DeviceSc
                     auto child = [&](v2f X, v2f Y, v2f Z) {
                         const v2f Tx = pk_mul_h<1>(pk_sub_h<0>(X, p_a), p_b), Ty = pk_mul_h<0>(pk_sub_h<1>(Y, p_a), p_c), Tz = pk_mul_h<1>(pk_sub_h<0>(Z, p_b), p_c);  // bounds.jl:183-193: (plane - o) x inv_d
                         const float nx = amin(Tx.x, Tx.y), fx = amax(Tx.x, Tx.y), ny = amin(Ty.x, Ty.y), fy = amax(Ty.x, Ty.y), nz = amin(Tz.x, Tz.y), fz = amax(Tz.x, Tz.y);
+#if TH_TRACE3C4_LEAN
+                        // the same clauses with the implied ones folded (every product is a number: the ray is `plain`, an empty slot's planes are NaN and fail `t_in < t_pop`):
+                        //   :188 + half of :194   nx <= fy && ny <= fx && a <= fz   <=>   a <= min3(fx, fy, fz)      (nx <= fx and ny <= fy always)
+                        //   the other half of :194 (nz <= max(fx, fy), the reference's LOOSE clause) is left to its grown tight form below, which all but implies it — a box let in
+                        //   by the difference holds no candidate the reference reaches either way (a superset of the visits is sound);  :198's t_out > 0 as fz >= 0 next to the grown
+                        //   exit >= 0 (weaker at fz == 0 only)
+                        const float a = amax(nx, ny);
+                        const float t_in = amax(a, nz);
+                        const float exit_xy = amin(fx + gx, fy + gy);
+                        bool enter = (int)!(a > amin3(fx, fy, fz)) & (int)!(nz - gz > exit_xy) & (int)!(amin(exit_xy, fz) < 0.0f) & (int)(t_in < t_pop);  // (`&`: no short-circuit branches)
+#else
                         const float a = amax(nx, ny), b = amax(fx, fy);        // :189-190
                         const float t_in = amax(a, nz), t_out = amin(fz, b);   // :196-197
                         const bool ref = !(nx > fy) && !(ny > fx) && !(a > fz) && !(nz > b) && (t_out > 0.0f);  // :188, :194, :198
                         const float exit_xy = amin(fx + gx, fy + gy);
                         const bool tight = !(nz - gz > exit_xy) && !(exit_xy < 0.0f);
                         bool enter = ref && tight && (t_in < t_pop);
+#endif
                         if constexpr (AXIS) enter = enter && (amax3(nx - ax_x, ny - ax_y, nz - ax_z) < t_push);
                         return enter ? t_in : kInf;
                     };
@@ -412,26 +424,13 @@ __global__ __launch_bounds__(kBlock, TH_TRACE3C4_WAVES) void k_trace3c4(DeviceSc
                     top_tm = __uint_as_float(e.y);
                 }
             }
-#if TH_TRACE3C4_LEAF_PIPE
-            // the records of primitive k + 1 are requested before primitive k is tested: a leaf of n primitives costs one round trip + n tests, not n round trips
-            float4 q0 = sc.prims[3 * leaf_ref], q1 = sc.prims[3 * leaf_ref + 1], q2 = sc.prims[3 * leaf_ref + 2];
-#pragma unroll 1
-            for (uint32_t k = 0; k < leaf_cnt; ++k) {
-                const float4 p0 = q0, p1 = q1, p2 = q2;
-                asm volatile("" ::"v"(p0.x), "v"(p0.w), "v"(p1.x), "v"(p1.y), "v"(p1.z), "v"(p1.w), "v"(p2.x), "v"(p2.y), "v"(p2.z), "v"(p2.w));
-                if (k + 1 < leaf_cnt) {
-                    const float4* nx = sc.prims + 3 * (size_t)(leaf_ref + k + 1);
-                    q0 = nx[0];
-                    q1 = nx[1];
-                    q2 = nx[2];
-                }
-#else
+            // (requesting primitive k + 1's records before primitive k is tested — one round trip per leaf instead of one per primitive — costs 12 live registers and measured 74.7 against
+            // 67.8 ms: the kernel is VALU-bound at 97 % busy, the latency was already hidden)
             for (uint32_t k = 0; k < leaf_cnt; ++k) {
                 const uint32_t slot = leaf_ref + k;
                 const float4 p0 = sc.prims[3 * slot];
                 const float4 p1 = sc.prims[3 * slot + 1], p2 = sc.prims[3 * slot + 2];
                 asm volatile("" ::"v"(p1.x), "v"(p1.y), "v"(p1.z), "v"(p1.w), "v"(p2.x), "v"(p2.y), "v"(p2.z), "v"(p2.w));  // one burst (th_trace2.h "one fetch per leaf")
-#endif
                 const uint32_t meta = __float_as_uint(p0.w);
                 if (COUNT) np++;
                 TriTest tt;
