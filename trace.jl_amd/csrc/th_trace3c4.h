@@ -24,8 +24,8 @@ namespace th {
 #ifndef TH_TRACE3C4_FETCH_BURST
 #define TH_TRACE3C4_FETCH_BURST 1
 #endif
-#ifndef TH_TRACE3C4_LEAN
-#define TH_TRACE3C4_LEAN 0
+#ifndef TH_TRACE3C4_LEAF_ONE
+#define TH_TRACE3C4_LEAF_ONE 0
 #endif
 #ifndef TH_TRACE3C4_LDS
 #define TH_TRACE3C4_LDS 13
@@ -259,8 +259,14 @@ __global__ __launch_bounds__(kBlock, TH_TRACE3C4_WAVES) void k_trace3c4(DeviceSc
         // ---- phase A: interior steps and pops; lanes holding a leaf wait (k_trace3's schedule).  A lane WITHOUT a node (both children failed and the stack top was dead, a leaf
         //      that left a dead top) takes part in the step's tail instead of a pop section of its own: the tail reads the stack top anyway (k_trace3's in-step pop) — one entry per
         //      round, dead ones dropped; what is left of the pop section is the delivery of the rays whose stack is empty ----
+#if TH_TRACE3C4_LEAF_ONE
+        // (phase B tests ONE primitive per lane and round: a round goes to the side most lanes wait on)
+        const bool run_a = (uint32_t)__popcll(__ballot(active && (cur < kLeafBit || cur == kRefNone))) > (uint32_t)TH_TRACE3C_LEAF_WAIT || __ballot(active && cur >= kLeafBit && cur != kRefNone) == 0ull;
+#else
+        const bool run_a = true;
+#endif
 #pragma unroll 1
-        for (int it = 0; it < TH_TRACE3C_MAX_A; ++it) {
+        for (int it = 0; run_a && it < TH_TRACE3C_MAX_A; ++it) {
 #ifdef TH_DIAG_PHASES
             const unsigned long long ph_pop_m = __ballot(active && cur == kRefNone && sp == 0);
             const unsigned long long ph_t_pop = __builtin_readcyclecounter();
@@ -325,24 +331,15 @@ __global__ __launch_bounds__(kBlock, TH_TRACE3C4_WAVES) void k_trace3c4(DeviceSc
                     auto child = [&](v2f X, v2f Y, v2f Z) {
                         const v2f Tx = pk_mul_h<1>(pk_sub_h<0>(X, p_a), p_b), Ty = pk_mul_h<0>(pk_sub_h<1>(Y, p_a), p_c), Tz = pk_mul_h<1>(pk_sub_h<0>(Z, p_b), p_c);  // bounds.jl:183-193: (plane - o) x inv_d
                         const float nx = amin(Tx.x, Tx.y), fx = amax(Tx.x, Tx.y), ny = amin(Ty.x, Ty.y), fy = amax(Ty.x, Ty.y), nz = amin(Tz.x, Tz.y), fz = amax(Tz.x, Tz.y);
-#if TH_TRACE3C4_LEAN
-                        // the same clauses with the implied ones folded (every product is a number: the ray is `plain`, an empty slot's planes are NaN and fail `t_in < t_pop`):
-                        //   :188 + half of :194   nx <= fy && ny <= fx && a <= fz   <=>   a <= min3(fx, fy, fz)      (nx <= fx and ny <= fy always)
-                        //   the other half of :194 (nz <= max(fx, fy), the reference's LOOSE clause) is left to its grown tight form below, which all but implies it — a box let in
-                        //   by the difference holds no candidate the reference reaches either way (a superset of the visits is sound);  :198's t_out > 0 as fz >= 0 next to the grown
-                        //   exit >= 0 (weaker at fz == 0 only)
-                        const float a = amax(nx, ny);
-                        const float t_in = amax(a, nz);
-                        const float exit_xy = amin(fx + gx, fy + gy);
-                        bool enter = (int)!(a > amin3(fx, fy, fz)) & (int)!(nz - gz > exit_xy) & (int)!(amin(exit_xy, fz) < 0.0f) & (int)(t_in < t_pop);  // (`&`: no short-circuit branches)
-#else
                         const float a = amax(nx, ny), b = amax(fx, fy);        // :189-190
                         const float t_in = amax(a, nz), t_out = amin(fz, b);   // :196-197
                         const bool ref = !(nx > fy) && !(ny > fx) && !(a > fz) && !(nz > b) && (t_out > 0.0f);  // :188, :194, :198
                         const float exit_xy = amin(fx + gx, fy + gy);
                         const bool tight = !(nz - gz > exit_xy) && !(exit_xy < 0.0f);
                         bool enter = ref && tight && (t_in < t_pop);
-#endif
+                        // (the clauses are the reference's EXACTLY for a leaf child: what it lets in is what the reference tests.  A folded form — a <= min3(fx, fy, fz), :194's loose
+                        // half and t_out > 0 left to the grown clauses — is 18 VALU instructions shorter per step, 2 % faster and WRONG: 152 559 film values differ, a leaf let in by the
+                        // difference holds candidates the reference never tests)
                         if constexpr (AXIS) enter = enter && (amax3(nx - ax_x, ny - ax_y, nz - ax_z) < t_push);
                         return enter ? t_in : kInf;
                     };
@@ -413,7 +410,7 @@ __global__ __launch_bounds__(kBlock, TH_TRACE3C4_WAVES) void k_trace3c4(DeviceSc
             const uint32_t leaf_ref = cur & 0x00ffffffu, leaf_cnt = cur >> 24;
             uint32_t top_enc = kRefNone;
             float top_tm = kInf;
-            if (sp > 0) {
+            if (sp > 0 && (!TH_TRACE3C4_LEAF_ONE || leaf_cnt == 1u)) {
                 if (sp - 1 < kLds) {
                     const uint2 e = s_stk[sp - 1][tid];
                     top_enc = e.x;
@@ -426,7 +423,7 @@ __global__ __launch_bounds__(kBlock, TH_TRACE3C4_WAVES) void k_trace3c4(DeviceSc
             }
             // (requesting primitive k + 1's records before primitive k is tested — one round trip per leaf instead of one per primitive — costs 12 live registers and measured 74.7 against
             // 67.8 ms: the kernel is VALU-bound at 97 % busy, the latency was already hidden)
-            for (uint32_t k = 0; k < leaf_cnt; ++k) {
+            for (uint32_t k = 0; k < (TH_TRACE3C4_LEAF_ONE ? 1u : leaf_cnt); ++k) {
                 const uint32_t slot = leaf_ref + k;
                 const float4 p0 = sc.prims[3 * slot];
                 const float4 p1 = sc.prims[3 * slot + 1], p2 = sc.prims[3 * slot + 2];
@@ -460,8 +457,9 @@ __global__ __launch_bounds__(kBlock, TH_TRACE3C4_WAVES) void k_trace3c4(DeviceSc
                     }
                 }
             }
-            cur = kRefNone;
-            if (flagged) {  // the reference-order walk decides this ray
+            cur = (TH_TRACE3C4_LEAF_ONE && !flagged && leaf_cnt > 1u) ? ((leaf_ref + 1u) | ((leaf_cnt - 1u) << 24)) : kRefNone;  // LEAF_ONE: the rest of the leaf in the next rounds
+            if (cur != kRefNone) {
+            } else if (flagged) {  // the reference-order walk decides this ray
                 active = false;
                 to_fb = true;
                 sp = 0;
