@@ -24,6 +24,9 @@ namespace th {
 #ifndef TH_TRACE3C4_FETCH_BURST
 #define TH_TRACE3C4_FETCH_BURST 1
 #endif
+#ifndef TH_TRACE3C4_LEAF_MAJ
+#define TH_TRACE3C4_LEAF_MAJ 0
+#endif
 #ifndef TH_TRACE3C4_LEAF_ONE
 #define TH_TRACE3C4_LEAF_ONE 0
 #endif
@@ -261,7 +264,12 @@ __global__ __launch_bounds__(kBlock, TH_TRACE3C4_WAVES) void k_trace3c4(DeviceSc
         //      round, dead ones dropped; what is left of the pop section is the delivery of the rays whose stack is empty ----
 #if TH_TRACE3C4_LEAF_ONE
         // (phase B tests ONE primitive per lane and round: a round goes to the side most lanes wait on)
+#if TH_TRACE3C4_LEAF_MAJ
+        const uint32_t n_want_a = (uint32_t)__popcll(__ballot(active && (cur < kLeafBit || cur == kRefNone))), n_want_b = (uint32_t)__popcll(__ballot(active && cur >= kLeafBit && cur != kRefNone));
+        const bool run_a = n_want_a >= n_want_b;
+#else
         const bool run_a = (uint32_t)__popcll(__ballot(active && (cur < kLeafBit || cur == kRefNone))) > (uint32_t)TH_TRACE3C_LEAF_WAIT || __ballot(active && cur >= kLeafBit && cur != kRefNone) == 0ull;
+#endif
 #else
         const bool run_a = true;
 #endif
