@@ -24,11 +24,10 @@ namespace th {
 #ifndef TH_TRACE3C4_FETCH_BURST
 #define TH_TRACE3C4_FETCH_BURST 1
 #endif
-#ifndef TH_TRACE3C4_LEAF_MAJ
-#define TH_TRACE3C4_LEAF_MAJ 0
-#endif
+// 1: phase B tests ONE primitive per lane and round (a leaf of n primitives takes n rounds; the lanes of a short leaf go back to the node steps instead of idling through the longest
+// leaf of the wave): 66.2 against 67.8 ms on S-mesh, 49.5 against 50.2 on S-blob; thresholds 24 / 40, 4 / 16 node steps per round, majority vote: 68.6 / 67.4, 66.6 / 66.2, 66.1
 #ifndef TH_TRACE3C4_LEAF_ONE
-#define TH_TRACE3C4_LEAF_ONE 0
+#define TH_TRACE3C4_LEAF_ONE 1
 #endif
 #ifndef TH_TRACE3C4_LDS
 #define TH_TRACE3C4_LDS 13
@@ -264,12 +263,7 @@ __global__ __launch_bounds__(kBlock, TH_TRACE3C4_WAVES) void k_trace3c4(DeviceSc
         //      round, dead ones dropped; what is left of the pop section is the delivery of the rays whose stack is empty ----
 #if TH_TRACE3C4_LEAF_ONE
         // (phase B tests ONE primitive per lane and round: a round goes to the side most lanes wait on)
-#if TH_TRACE3C4_LEAF_MAJ
-        const uint32_t n_want_a = (uint32_t)__popcll(__ballot(active && (cur < kLeafBit || cur == kRefNone))), n_want_b = (uint32_t)__popcll(__ballot(active && cur >= kLeafBit && cur != kRefNone));
-        const bool run_a = n_want_a >= n_want_b;
-#else
         const bool run_a = (uint32_t)__popcll(__ballot(active && (cur < kLeafBit || cur == kRefNone))) > (uint32_t)TH_TRACE3C_LEAF_WAIT || __ballot(active && cur >= kLeafBit && cur != kRefNone) == 0ull;
-#endif
 #else
         const bool run_a = true;
 #endif
