@@ -15,8 +15,10 @@
 // (bounds.jl:137-145), bucket = floor(12 x offset) + 1 clamped to 12, surface area = 2 ((dx dy + dx dz) + dy dz) (bounds.jl:93-96),
 // cost = 1 + (s1 + s2) / area.  argmin is Julia's: the first minimum, a NaN counts as the smallest.
 #pragma once
+#include <atomic>
 #include <cmath>
 #include <cstdint>
+#include <future>
 #include <stdexcept>
 #include <vector>
 
@@ -43,9 +45,10 @@ class RefBVHBuilder {
             info_[i] = i;
             for (int a = 0; a < 3; ++a) cen_[3 * (size_t)i + a] = 0.5f * pb_[i].mn[a] + 0.5f * pb_[i].mx[a];
         }
-        out_.order.reserve(n);
-        if (n) node(0, n, 1);
-        return std::move(out_);
+        FlatBVH out;
+        reserve(out, n);
+        if (n) node(out, 0, n, 1);
+        return out;
     }
 
    private:
@@ -68,28 +71,38 @@ class RefBVHBuilder {
         if (b == kBuckets + 1) b -= 1;
         return b;
     }
-    uint32_t emit(const HostAABB& b, uint32_t a, uint32_t flags) {
-        const uint32_t at = (uint32_t)out_.a.size();
-        out_.bounds.insert(out_.bounds.end(), {b.mn[0], b.mn[1], b.mn[2], b.mx[0], b.mx[1], b.mx[2]});
-        out_.a.push_back(a);
-        out_.flags.push_back(flags);
+    static void reserve(FlatBVH& out, uint32_t n_prims) {  // (a hint: one primitive per leaf gives 2 n - 1 nodes, the empty leaves of partition! a few more)
+        out.order.reserve(n_prims);
+        out.a.reserve(2 * (size_t)n_prims);
+        out.flags.reserve(2 * (size_t)n_prims);
+        out.bounds.reserve(12 * (size_t)n_prims);
+    }
+    static uint32_t emit(FlatBVH& out, const HostAABB& b, uint32_t a, uint32_t flags) {
+        const uint32_t at = (uint32_t)out.a.size();
+        out.bounds.insert(out.bounds.end(), {b.mn[0], b.mn[1], b.mn[2], b.mx[0], b.mx[1], b.mx[2]});
+        out.a.push_back(a);
+        out.flags.push_back(flags);
         return at;
     }
-    uint32_t leaf(uint32_t from, uint32_t to, const HostAABB& bounds) {  // _create_leaf bvh.jl:97-106
-        const uint32_t first = (uint32_t)out_.order.size();
-        for (uint32_t i = from; i < to; ++i) out_.order.push_back(info_[i]);
-        return emit(bounds, first, ((to - from) << 2) | 3u);
+    uint32_t leaf(FlatBVH& out, uint32_t from, uint32_t to, const HostAABB& bounds) {  // _create_leaf bvh.jl:97-106
+        const uint32_t first = (uint32_t)out.order.size();
+        for (uint32_t i = from; i < to; ++i) out.order.push_back(info_[i]);
+        return emit(out, bounds, first, ((to - from) << 2) | 3u);
     }
     // _init over info_[from, to) (bvh.jl:87-185); returns the node's index in the flat arrays
-    uint32_t node(uint32_t from, uint32_t to, uint32_t depth) {
+    // `out` holds the subtree's nodes in the reference's order (a node, its first child's subtree, its second child's) with indices LOCAL to it: the subtrees of a large node work on
+    // disjoint ranges of info_ and are built concurrently, the second one into arrays of its own that are appended (indices shifted) behind the first — the same flat arrays as the
+    // serial recursion, node for node
+    uint32_t node(FlatBVH& out, uint32_t from, uint32_t to, uint32_t depth) {
+        if (abort_.load(std::memory_order_relaxed)) throw Aborted();
         if (depth > kMaxRecursion) throw std::runtime_error("the reference's BVH construction does not terminate on this input (bvh.jl:166-185 recursion)");
         if (depth_limit_ && depth > depth_limit_) throw DepthExceeded(depth);
-        out_.max_depth = std::max(out_.max_depth, depth);
+        out.max_depth = std::max(out.max_depth, depth);
         const uint32_t n = to - from;
         HostAABB bounds;
         bounds.reset();
         for (uint32_t i = from; i < to; ++i) bounds.grow(pb_[info_[i]]);
-        if (n == 1) return leaf(from, to, bounds);
+        if (n == 1) return leaf(out, from, to, bounds);
         HostAABB cb;
         cb.reset();
         for (uint32_t i = from; i < to; ++i) cb.grow_point(&cen_[3 * (size_t)info_[i]]);
@@ -97,7 +110,7 @@ class RefBVHBuilder {
         const int dim = (dx > dy && dx > dz) ? 0 : (dy > dz ? 1 : 2);  // maximum_extent bounds.jl:118-126
         bool valid = true;                                             // is_valid bounds.jl:30-32 (an empty range: the 0-primitive leaf)
         for (int a = 0; a < 3; ++a) valid = valid && cb.mn[a] != INFINITY && cb.mx[a] != -INFINITY;
-        if (!valid || cb.mn[dim] == cb.mx[dim]) return leaf(from, to, bounds);
+        if (!valid || cb.mn[dim] == cb.mx[dim]) return leaf(out, from, to, bounds);
         uint32_t mid;  // LAST index of the left child (the reference's `mid`, 0-based here)
         if (n <= 2) {
             mid = (from + to - 1) / 2;
@@ -131,7 +144,7 @@ class RefBVHBuilder {
                 }
                 if (costs[i - 1] < costs[best - 1]) best = i;
             }
-            if (!((int)n > max_leaf_ || costs[best - 1] < (float)n)) return leaf(from, to, bounds);
+            if (!((int)n > max_leaf_ || costs[best - 1] < (float)n)) return leaf(out, from, to, bounds);
             // partition! Trace.jl:128-137
             uint32_t left = from;
             for (uint32_t i = from; i < to; ++i)
@@ -141,19 +154,64 @@ class RefBVHBuilder {
                 }
             mid = left;
         }
-        const uint32_t self = emit(bounds, 0u, (uint32_t)dim);  // bounds = left ∪ right = the union over the range (min / max are exact)
-        node(from, mid + 1, depth + 1);
-        const uint32_t second = node(mid + 1, to, depth + 1);
-        out_.a[self] = second;
+        const uint32_t self = emit(out, bounds, 0u, (uint32_t)dim);  // bounds = left ∪ right = the union over the range (min / max are exact)
+        uint32_t second;
+        if (n >= kParallelMin && depth <= kParallelDepth) {
+            std::future<FlatBVH> right = std::async(std::launch::async, [this, mid, to, depth] {
+                FlatBVH r;
+                reserve(r, to - (mid + 1));
+                try {
+                    node(r, mid + 1, to, depth + 1);
+                } catch (...) {
+                    abort_.store(true, std::memory_order_relaxed);  // the other subtrees stop at their next node
+                    throw;
+                }
+                return r;
+            });
+            try {
+                node(out, from, mid + 1, depth + 1);
+            } catch (const Aborted&) {
+                right.get();  // the second subtree's own failure, when that is what stopped this one
+                throw;
+            } catch (...) {
+                abort_.store(true, std::memory_order_relaxed);
+                right.wait();
+                throw;
+            }
+            const FlatBVH r = right.get();  // (rethrows what the second subtree threw)
+            second = (uint32_t)out.a.size();
+            const uint32_t order_base = (uint32_t)out.order.size();
+            out.bounds.insert(out.bounds.end(), r.bounds.begin(), r.bounds.end());
+            out.flags.insert(out.flags.end(), r.flags.begin(), r.flags.end());
+            out.order.insert(out.order.end(), r.order.begin(), r.order.end());
+            out.a.reserve(out.a.size() + r.a.size());
+            for (size_t i = 0; i < r.a.size(); ++i) out.a.push_back(r.a[i] + ((r.flags[i] & 3u) == 3u ? order_base : second));
+            out.max_depth = std::max(out.max_depth, r.max_depth);
+        } else {
+            node(out, from, mid + 1, depth + 1);
+            second = node(out, mid + 1, to, depth + 1);
+        }
+        out.a[self] = second;
         return self;
     }
+    struct Aborted : std::runtime_error {
+        Aborted() : std::runtime_error("the reference's BVH construction was abandoned (another subtree failed)") {}
+    };
+#ifndef TH_REF_PARALLEL_MIN
+#define TH_REF_PARALLEL_MIN (1u << 15)
+#endif
+    static constexpr uint32_t kParallelMin = TH_REF_PARALLEL_MIN;  // primitives in a node whose two subtrees are worth a thread
+#ifndef TH_REF_PARALLEL_DEPTH
+#define TH_REF_PARALLEL_DEPTH 8
+#endif
+    static constexpr uint32_t kParallelDepth = TH_REF_PARALLEL_DEPTH;       // (at most 2^8 concurrent subtrees)
 
     const std::vector<HostAABB>& pb_;
     int max_leaf_;
     uint32_t depth_limit_;
     std::vector<uint32_t> info_;
     std::vector<float> cen_;
-    FlatBVH out_;
+    std::atomic<bool> abort_{false};
 };
 
 }  // namespace th
