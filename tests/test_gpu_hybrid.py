@@ -267,3 +267,46 @@ def test_options_that_change_how_a_frame_is_computed_leave_the_frame_alone(T, op
     assert out[0][2] == 2 and out[1][2] == 2
     assert_bits_equal(out[1][1], out[0][1], f"per-sample radiance under {opts}")
     assert_bits_equal(out[1][0], out[0][0], f"film under {opts}")
+
+
+def test_a_scene_whose_reference_construction_fails_keeps_the_library_tree(T, hyb_ctx):
+    """220 triangles whose sizes and positions grow geometrically (x 1.45 each): accel/bvh.jl:87-185 peels them off a few per level and ends 69 levels deep — deeper than the
+    64-entry stack bvh.jl:222 walks with, so Trace.jl itself cannot trace this scene.  The default commit says so (trhip_scene_bvh_note), keeps the library's tree as the canonical
+    one (mode 0) or, when three times its four-wide depth fits the stack, ALSO as its own four-wide accelerator (mode 3: what the 10.5 M-triangle scene of test_gpu_scale.py gets);
+    either way the default kernels return what the literal accel/bvh.jl loop returns on that tree, bit for bit."""
+    import attack_scenes as A
+    n, base = 220, 1.45
+    rng = np.random.default_rng(7)
+    tris = np.empty((n, 3, 3), np.float64)
+    for i in range(n):
+        c = np.array([base ** i, 0.37 * base ** i, -0.2 * base ** i])
+        tris[i] = c + 0.05 * base ** i * rng.uniform(-1.0, 1.0, (3, 3))
+    pb = np.concatenate([tris.min(axis=1), tris.max(axis=1)], axis=1).astype(np.float32)
+    assert T._ffi.build_bvh_host(pb, 1, builder=2)[4] > 64  # (the host-only entry builds it to the end)
+    scene, tri32, _, _ = A.build_scene(T, tris.reshape(-1, 3), [], 1.0, (0.0, 0.0, 0.0))
+    flat = scene.flatten(hyb_ctx)
+    mode = flat.bvh_mode()[0]
+    assert mode in (0, 3) and "depth" in flat.bvh_note(), (mode, flat.bvh_note())
+    # rays from a point off the chain towards points on the first 120 triangles (coordinates up to 1e19: every product stays finite) and into empty space
+    k = rng.integers(0, 120, 4000)
+    w = rng.dirichlet([1.0, 1.0, 1.0], 4000)
+    target = np.einsum("nk,nkc->nc", w, tri32[k].astype(np.float64))
+    origin = np.array([-3.0, 2.0, 5.0]) + rng.uniform(-1.0, 1.0, (4000, 3))
+    d = target - origin
+    d[3000:] = rng.normal(size=(1000, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = A.rays8(origin.astype(np.float32), d.astype(np.float32))
+    got = {}
+    for trav in (3, 1):
+        hyb_ctx.set_option("traversal", trav)
+        try:
+            got[trav] = (flat.trace_closest(rays), flat.trace_any(rays))
+        finally:
+            hyb_ctx.set_option("traversal", 3)
+    assert (got[1][0]["prim"] >= 0).sum() > 1000
+    assert np.array_equal(got[3][0]["prim"], got[1][0]["prim"])
+    for f in ("t", "b1", "b2"):
+        assert_bits_equal(got[3][0][f], got[1][0][f], f"closest-hit {f} on a scene the reference cannot build")
+    assert np.array_equal(got[3][1], got[1][1])
+    scene._flat = None
+    flat.free()

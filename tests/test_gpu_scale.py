@@ -180,6 +180,7 @@ def test_mesh_10m_c5_geometry(T, ob, ctx):
     flat = scene.flatten(ctx)
     bvh = flat.bvh()
     assert bvh[3].size == 2 * n * n + 12
+    assert flat.bvh_mode()[0] == 3 and "depth" in flat.bvh_note()  # the reference's construction ends 65 levels deep here: the library's tree, canonical and (four-wide) its own accelerator
     rays, sub = ray_set(T, ob, 1 << 19)
     sub = sub[::4]
     got = {}

@@ -625,7 +625,8 @@ class FlatScene:
 
     def bvh_mode(self):
         """(mode, accelerator nodes, accelerator depth): mode 0 = the library's tree alone, 1 = the canonical (reference / host) tree alone, 2 = hybrid: the canonical
-        tree defines the answers, the library's tree accelerates the rays that carry the order-independence certificate (csrc/th_trace3c.h)."""
+        tree defines the answers, the library's tree accelerates the rays that carry the order-independence certificate (csrc/th_trace3c.h); 3 = the library's tree is the
+        canonical one (the reference's construction fails on this scene) and, four children wide, its own accelerator."""
         mode, nn, dep = C.c_int(), C.c_uint32(), C.c_uint32()
         self.ctx.check(_ffi.lib().trhip_scene_bvh_mode(self._h, C.byref(mode), C.byref(nn), C.byref(dep)))
         return mode.value, nn.value, dep.value
@@ -633,7 +634,7 @@ class FlatScene:
     def accelerator(self):
         """The accelerator tree of a hybrid scene, in the layout of bvh() (order[accelerator slot] = caller primitive index)."""
         mode, nn, _ = self.bvh_mode()
-        if mode != 2:
+        if mode not in (2, 3):
             raise _ffi.TraceHipError("the scene has no accelerator tree")
         L = _ffi.lib()
         npr = C.c_uint32()
