@@ -270,25 +270,25 @@ def test_options_that_change_how_a_frame_is_computed_leave_the_frame_alone(T, op
 
 
 def test_a_scene_whose_reference_construction_fails_keeps_the_library_tree(T, hyb_ctx):
-    """220 triangles whose sizes and positions grow geometrically (x 1.45 each): accel/bvh.jl:87-185 peels them off a few per level and ends 69 levels deep — deeper than the
+    """240 triangles whose sizes and positions grow geometrically (x 1.45 each, from 1e-8): accel/bvh.jl:87-185 peels them off a few per level and ends more than 64 levels deep — deeper than the
     64-entry stack bvh.jl:222 walks with, so Trace.jl itself cannot trace this scene.  The default commit says so (trhip_scene_bvh_note), keeps the library's tree as the canonical
     one (mode 0) or, when three times its four-wide depth fits the stack, ALSO as its own four-wide accelerator (mode 3: what the 10.5 M-triangle scene of test_gpu_scale.py gets);
     either way the default kernels return what the literal accel/bvh.jl loop returns on that tree, bit for bit."""
     import attack_scenes as A
-    n, base = 220, 1.45
+    n, base, s0 = 240, 1.45, 1e-8
     rng = np.random.default_rng(7)
     tris = np.empty((n, 3, 3), np.float64)
     for i in range(n):
-        c = np.array([base ** i, 0.37 * base ** i, -0.2 * base ** i])
-        tris[i] = c + 0.05 * base ** i * rng.uniform(-1.0, 1.0, (3, 3))
+        sc = s0 * base ** i
+        tris[i] = np.array([sc, 0.37 * sc, -0.2 * sc]) + 0.05 * sc * rng.uniform(-1.0, 1.0, (3, 3))
     pb = np.concatenate([tris.min(axis=1), tris.max(axis=1)], axis=1).astype(np.float32)
     assert T._ffi.build_bvh_host(pb, 1, builder=2)[4] > 64  # (the host-only entry builds it to the end)
     scene, tri32, _, _ = A.build_scene(T, tris.reshape(-1, 3), [], 1.0, (0.0, 0.0, 0.0))
     flat = scene.flatten(hyb_ctx)
     mode = flat.bvh_mode()[0]
     assert mode in (0, 3) and "depth" in flat.bvh_note(), (mode, flat.bvh_note())
-    # rays from a point off the chain towards points on the first 120 triangles (coordinates up to 1e19: every product stays finite) and into empty space
-    k = rng.integers(0, 120, 4000)
+    # rays from a point off the chain towards points on triangles 40 … 120 (coordinates 3e-2 … 2e11) and into empty space
+    k = rng.integers(40, 120, 4000)
     w = rng.dirichlet([1.0, 1.0, 1.0], 4000)
     target = np.einsum("nk,nkc->nc", w, tri32[k].astype(np.float64))
     origin = np.array([-3.0, 2.0, 5.0]) + rng.uniform(-1.0, 1.0, (4000, 3))
