@@ -719,7 +719,7 @@ __global__ __launch_bounds__(kBlock, FULL_ONLY ? TH_TRACE_LEAF_C_WAVES : 4) void
         const f3 inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
         const bool negx = d.x < 0.0f, negy = d.y < 0.0f, negz = d.z < 0.0f;
         float t_max = (valid && tmax_or_null) ? tmax_or_null[idx] : kInf;
-        const RayShear shear = ray_shear(d);
+        const RayShear shear = ray_shear(d, inv_d);
         const float D = slab_margin(ws.root_box, 1.0f, o);
         const float dt = kCertDt * D * fabsf(shear.sz);
         float t_lim = t_max + 2.0f * dt;  // t_max + 2 dt (header): the relaxed limit of the primitive tests

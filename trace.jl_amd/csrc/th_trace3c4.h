@@ -26,6 +26,10 @@ namespace th {
 #endif
 // 1: phase B tests ONE primitive per lane and round (a leaf of n primitives takes n rounds; the lanes of a short leaf go back to the node steps instead of idling through the longest
 // leaf of the wave): 66.2 against 67.8 ms on S-mesh, 49.5 against 50.2 on S-blob; thresholds 24 / 40, 4 / 16 node steps per round, majority vote: 68.6 / 67.4, 66.6 / 66.2, 66.1
+// 1: a refill skips the root box test and takes 1 / d[kz] from the reciprocal direction it already holds (-35 VALU instructions per refill: 67.0 -> 65.6 ms, bit-equal)
+#ifndef TH_TRACE3C4_REFILL_LEAN
+#define TH_TRACE3C4_REFILL_LEAN 1
+#endif
 #ifndef TH_TRACE3C4_LEAF_ONE
 #define TH_TRACE3C4_LEAF_ONE 1
 #endif
@@ -206,7 +210,7 @@ __global__ __launch_bounds__(kBlock, TH_TRACE3C4_WAVES) void k_trace3c4(DeviceSc
                         const f3 d = mk3(d4.x, d4.y, d4.z);
                         inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
                         em = slab_margin(ws.root_box, ws.tight_scale, o);
-                        shear = ray_shear(d);
+                        shear = TH_TRACE3C4_REFILL_LEAN ? ray_shear(d, inv_d) : ray_shear(d);
                         const float dt = margin_t();
                         const float mkz_ = (shear.kz == 0 ? ch.mle[0] : (shear.kz == 1 ? ch.mle[1] : ch.mle[2])) * fabsf(shear.sz);
                         mkz = mkz_;
@@ -220,12 +224,14 @@ __global__ __launch_bounds__(kBlock, TH_TRACE3C4_WAVES) void k_trace3c4(DeviceSc
                         // (kCertCap; with AXIS the margin is per axis: no cap)
                         const bool plain = d.x != 0.0f && d.y != 0.0f && d.z != 0.0f && mb < kInf && fabsf(o.x) < kInf && fabsf(o.y) < kInf && fabsf(o.z) < kInf && fabsf(inv_d.x) < kInf &&
                                            fabsf(inv_d.y) < kInf && fabsf(inv_d.z) < kInf && t_own == t_own && (AXIS || mb - mkz_ <= kCertCap * mkz_ + dt);
-                        float tmin;
+                        float tmin = 0.0f;
                         if (!plain) {
                             to_fb = true;
                             active = false;
                             if (COUNT) n_why[0]++;
-                        } else if (ws.root_ref != kRefNone && slab_test2(ws.root_box[0], ws.root_box[1], ws.root_box[2], ws.root_box[3], ws.root_box[4], ws.root_box[5], o, inv_d, em, false, negx, negy, negz, tmin)) {
+                        } else if (ws.root_ref != kRefNone && (TH_TRACE3C4_REFILL_LEAN || slab_test2(ws.root_box[0], ws.root_box[1], ws.root_box[2], ws.root_box[3], ws.root_box[4], ws.root_box[5], o, inv_d, em, false, negx, negy, negz, tmin))) {
+                            // (REFILL_LEAN: the root box (bvh.jl:226) is not tested — the root of a four-wide tree is interior, each of its children's boxes lies inside it and every clause is
+                            // monotonic in the box: a ray that fails the root fails all four children in its first step)
                             cur = ws.root_ref | (ws.root_cnt << 24);  // (the root is not culled by t: the reference's clause `tmin < t_max` holds whenever anything inside can be accepted)
                             s_ex[tid] = tmin;
                             // the sphere pre-pass of the chunk left this ray's state in its hit record: an accepted sphere (the incumbent), the sphere it starts inside of, or
