@@ -502,13 +502,9 @@ __global__ __launch_bounds__(kBlock, (BIG || (AXIS && TH_TRACE3C_AXIS_LESS)) ? T
 #endif
             const bool stepping = active && cur < kLeafBit;
             if (stepping || (active && cur == kRefNone)) {
-                float4 a0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), a1 = a0, a2 = a0, a3 = a0;
-                if (stepping) {  // interior: one 64-byte burst, both child boxes
-                    a0 = ws.wnodes[4 * (size_t)cur];
-                    a1 = ws.wnodes[4 * (size_t)cur + 1];
-                    a2 = ws.wnodes[4 * (size_t)cur + 2];
-                    a3 = ws.wnodes[4 * (size_t)cur + 3];
-                }
+                // interior: one 64-byte burst, both child boxes (every lane of the section loads, a lane that only pops the root's node: no zero-initialised registers, th_trace3c4.h)
+                const float4* np = ws.wnodes + 4 * (size_t)(stepping ? cur : 0u);
+                const float4 a0 = np[0], a1 = np[1], a2 = np[2], a3 = np[3];
                 uint32_t top_enc = kRefNone;
                 float top_tm = kInf;
                 if (sp > 0) {
