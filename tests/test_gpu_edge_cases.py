@@ -77,7 +77,7 @@ def test_degenerate_triangles_and_single_leaf_threshold(T, ob, ctx):
     idx = np.uint32([1, 2, 3, 1, 3, 4, 5, 6, 7, 7, 8, 9])  # two real triangles, a point triangle, a collinear one
     for extra in (12, 13):  # 4 + 12 = 16 primitives -> one leaf; 17 -> a tree
         prims = [T.GeometricPrimitive(t, white) for t in T.create_triangle_mesh(core, 4, idx, 9, verts)]
-        for k in range(6):  # (more than 8 spheres would leave the scene without an accelerator: th_trace3c.h kCertMaxSpheres)
+        for k in range(6):  # (more than 32 spheres would leave the scene without an accelerator: th_trace3c.h kCertMaxSpheres)
             prims.append(GP_sphere(T, [0.1 + 0.14 * k, 0.5, -2.4], white))
         n_small = extra - 6
         v2 = np.float32([[0.05 + 0.12 * k + dx, 0.2 + dy, -2.35] for k in range(n_small) for dx, dy in ((0, 0), (0.1, 0), (0, 0.1))])

@@ -220,16 +220,40 @@ def test_sppm_in_hybrid_mode(T, ob, hyb_ctx):
     flat.free()
 
 
-def test_more_than_eight_spheres_keep_the_canonical_tree_alone(T, ob, hyb_ctx):
-    """The certified walk tests every sphere for every ray (th_trace3c.h kCertMaxSpheres = 8): a scene with more commits without an accelerator (mode 1) and every ray
-    walks the reference's tree — same bits as the oracle."""
+def _sphere_scene(T, n_spheres):
     prims, _ = T.scenes.cornell_primitives(spheres=False)
     white = T.MatteMaterial(T.ConstantTexture(T.RGBSpectrum(0.7)), T.ConstantTexture(0.0))
     glass = T.GlassMaterial(T.ConstantTexture(T.RGBSpectrum(1.0)), T.ConstantTexture(T.RGBSpectrum(1.0)), T.ConstantTexture(0.0), T.ConstantTexture(0.0), T.ConstantTexture(1.5), True)
-    for k in range(9):
-        c = [0.1 + 0.1 * k, 0.1 + 0.25 * (k % 3), -2.8 + 0.2 * (k % 4)]
-        prims.append(T.GeometricPrimitive(T.Sphere(T.ShapeCore(T.translate(c), False), 0.09, 360.0), glass if k % 2 else white))
-    scene = T.Scene(T.scenes.cornell_lights(), T.BVHAccel(prims, 1))
+    for k in range(n_spheres):
+        c = [0.1 + 0.1 * (k % 9) + 0.02 * (k // 9), 0.1 + 0.25 * (k % 3) + 0.05 * (k // 9), -2.8 + 0.2 * (k % 4) + 0.04 * (k // 12)]
+        prims.append(T.GeometricPrimitive(T.Sphere(T.ShapeCore(T.translate(c), False), 0.09 if k < 9 else 0.04, 360.0), glass if k % 2 else white))
+    return T.Scene(T.scenes.cornell_lights(), T.BVHAccel(prims, 1))
+
+
+@pytest.mark.parametrize("n_spheres", [9, 14])
+def test_more_than_ten_spheres_stay_on_the_accelerator(T, ob, hyb_ctx, n_spheres):
+    """The order word of a primitive record has bits for the scene's first ten spheres (th_trace3c.h kCertOrderSpheres); a scene of up to 32 spheres (kCertMaxSpheres) still commits
+    with both trees: every ray is tested against every sphere before its walk, and a ray that starts INSIDE one of the later spheres (glass: every refracted ray does) is handed to
+    the reference-order walk.  Film and per-sample radiance: the oracle's on the reference's tree, bit for bit."""
+    scene = _sphere_scene(T, n_spheres)
+    flat = scene.flatten(hyb_ctx)
+    assert flat.bvh_mode()[0] == 2 and flat.bvh_note() == "", flat.bvh_note()
+    osc = ob.OracleScene.from_scene(scene)
+    assert np.array_equal(flat.bvh()[1], osc.get_bvh()[1])
+    cam = T.scenes.cornell_camera(32)
+    ref, ref_L, _ = osc.render(cam, "path", 2, 6, seed=3, want_samples=True)
+    integ = T.PathIntegrator(cam, T.SeededSampler(2, seed=3), 6)
+    assert_bits_equal(integ.render(scene, hyb_ctx), ref, f"film ({n_spheres} spheres, hybrid)")
+    assert_bits_equal(integ.sample_radiance(scene), ref_L, f"per-sample radiance ({n_spheres} spheres, hybrid)")
+    assert integ.stats.traversal == 9 and 0 < integ.stats.fallback_rays < integ.stats.closest_rays
+    scene._flat = None
+    flat.free()
+
+
+def test_more_than_32_spheres_keep_the_canonical_tree_alone(T, ob, hyb_ctx):
+    """The certified walk tests every sphere for every ray (th_trace3c.h kCertMaxSpheres = 32): a scene with more commits without an accelerator (mode 1) and every ray
+    walks the reference's tree — same bits as the oracle."""
+    scene = _sphere_scene(T, 36)
     flat = scene.flatten(hyb_ctx)
     assert flat.bvh_mode()[0] == 1 and "spheres" in flat.bvh_note()  # (trhip_scene_bvh_note says why there is one tree)
     osc = ob.OracleScene.from_scene(scene)
@@ -237,7 +261,7 @@ def test_more_than_eight_spheres_keep_the_canonical_tree_alone(T, ob, hyb_ctx):
     cam = T.scenes.cornell_camera(24)
     ref, _, _ = osc.render(cam, "path", 2, 5, seed=3)
     integ = T.PathIntegrator(cam, T.SeededSampler(2, seed=3), 5)
-    assert_bits_equal(integ.render(scene, hyb_ctx), ref, "film (9 spheres, canonical tree alone)")
+    assert_bits_equal(integ.render(scene, hyb_ctx), ref, "film (36 spheres, canonical tree alone)")
     assert integ.stats.fallback_rays == 0 and integ.stats.traversal == 3
     scene._flat = None
     flat.free()

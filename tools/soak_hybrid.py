@@ -7,7 +7,7 @@ occlusion must agree bit for bit; so must small frames (PathIntegrator, every bo
     python tools/soak_hybrid.py --scenes 24 --rays 400000 --frames 48
 
 Scenes (tools/soak_parity.py's generator): a closed or open box of large triangles around 2-40 k random small triangles (needles, axis-aligned ones), full and clipped
-spheres (0-8: more than 8 leave the scene without an accelerator, which is reported), optionally a height field; rays: uniform in the bound, towards the light, from
+spheres (0-39: more than 32 leave the scene without an accelerator, which is reported), optionally a height field; rays: uniform in the bound, towards the light, from
 far away, skimming / axis-parallel, through vertices, from inside the spheres, a third with a finite t_max.  Exit code 1 on any mismatch."""
 import argparse
 import os
@@ -28,7 +28,7 @@ def sphere_rays(rng, scene_prims, n):
     """Rays that start inside / on the scene's spheres."""
     out = []
     spheres = [p.shape for p in scene_prims if isinstance(getattr(p, "shape", None), T.Sphere)]
-    for s in spheres[:8]:
+    for s in spheres[:16]:  # (the first ten have order bits in the primitive records: inside rays of the others go to the reference-order walk)
         c = s.core.object_to_world.point([0, 0, 0])
         u = rng.normal(size=(n, 3))
         u /= np.linalg.norm(u, axis=1, keepdims=True)

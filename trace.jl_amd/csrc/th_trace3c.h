@@ -93,7 +93,8 @@ constexpr float kCertGrow = 9.5367431640625e-7f;  // 2^-20 (16 ulps): the sheare
 constexpr float kCertFlat = 3.814697265625e-6f;   // 2^-18 (64 ulps): … plus what the edge functions' own rounding (<= 3 ulps of each product) moves that point: for a FLAT primitive (in an
                                                   // axis-aligned plane: its thin direction in the sheared frame IS a coordinate axis, the products are long x thin) at most 36 ulps of L^3 / 2A
                                                   // whatever the viewing angle; for the others the kz-extent bound is used instead (mle_small)
-constexpr uint32_t kCertMaxSpheres = 8;          // (the order word of a primitive record holds 3 bits per sphere)
+constexpr uint32_t kCertOrderSpheres = 10;       // the order word of a primitive record holds 3 bits per sphere: the first ten spheres of a scene have them; a ray that starts INSIDE a later one goes to the reference-order walk
+constexpr uint32_t kCertMaxSpheres = 32;         // every ray is tested against every sphere before its walk (a box test each, all lanes): beyond this the canonical tree alone
 #ifndef TH_CERT_CAP
 #define TH_CERT_CAP 64.0f
 #endif
@@ -132,7 +133,7 @@ TH_D v2f pk_mul_h(v2f a, v2f b) {
 struct CertScene {               // what the certificate needs beside the accelerator's WideScene
     const float* sphere_boxes;   // per sphere id: the box of the canonical leaf that holds it (6 floats)
     const uint32_t* sphere_slots;  // per sphere id: its canonical slot
-    uint32_t n_spheres;          // every ray is tested against all of them before its walk (k_trace3c's chunk pre-pass): never more than kCertMaxSpheres in a hybrid scene
+    uint32_t n_spheres;          // every ray is tested against all of them before its walk (k_trace3c's chunk pre-pass): never more than kCertMaxSpheres (32) in a hybrid scene
     const void* sphere_cert;     // SphereCert[n_spheres]: what those tests read, one contiguous record per sphere
     const float* slot_boxes;     // one-leaf accelerator: per canonical slot, the box of the canonical leaf that holds it (6 floats)
     float inv_tight;             // 1 / WideScene::tight_scale: D = em x inv_tight
@@ -386,7 +387,7 @@ __global__ __launch_bounds__(kBlock, (BIG || (AXIS && TH_TRACE3C_AXIS_LESS)) ? T
                                             // A sphere the ray starts INSIDE of (r == 3): the reference takes its far root whenever it tests it — and it always does: the box holds the
                                             // origin (required: ex <= 0), so no t_max culls its path — and forgets what it held; the ray remembers the sphere (state), and of what the
                                             // walk finds only what the reference tests AFTER that sphere counts (the order word of the primitive records, below)
-                                            if (!(t_c <= p_lim - 4.0f * pdt) || !(ex <= (r == 3 ? 0.0f : t_c + pdt))) {
+                                            if (!(t_c <= p_lim - 4.0f * pdt) || !(ex <= (r == 3 ? 0.0f : t_c + pdt)) || (r == 3 && ks >= kCertOrderSpheres)) {  // (a sphere without order bits: inside rays to the reference's order)
                                                 pflag = true;
                                             } else {
                                                 if (COUNT && r == 3) n_why[3]++;  // (not a fallback: rays that start inside a sphere and stay on the accelerator)

@@ -941,7 +941,7 @@ static int upload_accelerator_impl(trhip_scene* s, bool conformed) {
             }
             return false;
         };
-        for (uint32_t sid = 0; sid < (uint32_t)s->spheres.size(); ++sid) {
+        for (uint32_t sid = 0; sid < std::min<uint32_t>((uint32_t)s->spheres.size(), kCertOrderSpheres); ++sid) {  // (30 of the word's 32 bits; later spheres have no order bits: th_trace3c.h)
             const uint32_t ks = sph_slot[sid], sh = 3u * sid;
             uint32_t i = 0, lo = 0, hi = n_prims;
             bool ok = false;
@@ -1470,7 +1470,7 @@ int trhip_scene_commit(trhip_scene* s, int max_node_primitives) {
                 s->bvh_mode = 2;
             } else {
                 drop_accelerator(s);
-                s->bvh_note = s->spheres.size() > kCertMaxSpheres ? "more than 8 spheres: every ray walks the canonical tree (th_trace3c.h kCertMaxSpheres)"
+                s->bvh_note = s->spheres.size() > kCertMaxSpheres ? "more than 32 spheres: every ray walks the canonical tree (th_trace3c.h kCertMaxSpheres)"
                                                                   : "no accelerator: the library's tree could not be conformed to the canonical leaves, or the canonical tree is a single leaf";
             }
             return 0;
