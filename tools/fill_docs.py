@@ -2,7 +2,7 @@
 """DESIGN.md and README.md from docs/templates/*.in.md: every R5_* name is replaced by a figure read from the round's committed bench lines (profiles/r5/<tag>_bench_*.json), so the
 prose never quotes a number no file under profiles/ holds.
 
-    python tools/fill_docs.py [--tag r5d] [--so-mb 4.99] [--gpu-suite-s 148]
+    python tools/fill_docs.py [--tag r5f] [--so-mb 4.99] [--gpu-suite-s 140]
 """
 import argparse
 import json
@@ -18,9 +18,9 @@ def line(tag, name):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--tag", default="r5d")
+    ap.add_argument("--tag", default="r5f")
     ap.add_argument("--so-mb", type=float, default=os.path.getsize(os.path.join(ROOT, "trace.jl_amd", "libtracehip.so")) / 1e6)
-    ap.add_argument("--gpu-suite-s", type=float, default=148.0)
+    ap.add_argument("--gpu-suite-s", type=float, default=140.0)
     a = ap.parse_args()
     m, c, b, m10, s, c5 = (line(a.tag, n) for n in ("mesh1m", "cornell", "blob_870k", "mesh_10m", "caustic_sppm", "c5_share"))
     r = m["roofline"]
