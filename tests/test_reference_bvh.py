@@ -22,6 +22,7 @@ def scenes(T):
     yield "mesh24", T.scenes.mesh_scene(24)
     yield "mesh64", T.scenes.mesh_scene(64)
     yield "blob10", T.scenes.blob_scene(10)
+    yield "mesh400", T.scenes.mesh_scene(400)  # 320 012 primitives: four nested levels of concurrently built subtrees
     yield "mesh160", T.scenes.mesh_scene(160)  # 51 200 triangles: above th_bvh_ref.h's kParallelMin, the subtrees are built concurrently and appended
     ply = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "caustic-glass.ply")
     yield "caustic", T.scenes.caustic_scene(ply if os.path.exists(ply) else "")
