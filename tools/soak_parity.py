@@ -107,7 +107,7 @@ def main():
     for k in range(a.scenes):
         rng = np.random.default_rng(a.seed * 1000 + k)
         scene, tri = rand_scene(rng, k)
-        ctx.set_option("bvh_builder", 1 if k % 5 == 4 else (3 if k % 5 == 3 else 0))  # host SAH, the same on the device, LBVH
+        ctx.set_option("bvh_builder", (1 if ctx.has_option("bvh_builder", 1) else 0) if k % 5 == 4 else (3 if k % 5 == 3 else 0))  # host SAH, the same on the device, LBVH
         ctx.set_option("compose_spheres", 1 if a.wide else -1)
         flat = scene.flatten(ctx)
         bnd = flat.bvh()[0][0]
@@ -116,7 +116,8 @@ def main():
         h1, o1 = flat.trace_closest(rays), flat.trace_any(rays)
         bad = 0
         for trav in ((3, 7, 2, 6, 4) if a.wide else (3, 7, 2, 6)):
-            ctx.set_option("traversal", trav)
+            if not ctx.has_option("traversal", trav):  # (4 / 6 / 7: only in the EXPERIMENTS build of the library)
+                continue
             h, o = flat.trace_closest(rays), flat.trace_any(rays)
             bad += int((h["prim"] != h1["prim"]).sum())
             for f in ("t", "b1", "b2"):
@@ -127,7 +128,8 @@ def main():
             cam = T.scenes.cornell_camera(a.frames)
             films = []
             for trav in ((1, 3, 7, 6, 4) if a.wide else (1, 3, 7, 6)):
-                ctx.set_option("traversal", trav)
+                if not ctx.has_option("traversal", trav):
+                    continue
                 films.append(T.PathIntegrator(cam, T.SeededSampler(4, seed=100 + k), 6).render(scene, ctx).copy())
             for other in films[1:]:
                 fa, fb = films[0].view(np.uint32), other.view(np.uint32)
