@@ -592,7 +592,7 @@ def main():
                                            "shadow_nodes": round(sv.nodes_visited_shadow / max(1, sv.shadow_rays), 2), "shadow_prims": round(sv.prims_tested_shadow / max(1, sv.shadow_rays), 2),
                                            "node_bytes": int(sv.node_bytes), "traversal": int(sv.traversal)},
                         "kernel_ms_per_step": {k: round(v / steps, 3) for k, v in agg["ms"].items()},
-                        "kernel_ms_note": "HIP-event time per kernel class, one stream (option overlap = 0, the default)",
+                        "kernel_ms_note": "HIP-event time per kernel class on its own stream; option overlap (default 1) puts the shadow rays of depth d on a second stream beside the closest-hit rays of depth d + 1: class times are wall times under that contention and add up to more than the frame",
                         "kernel_GBps_note": "algorithmic bytes / class time; the traversal classes count REQUESTS (32 B per box tested, 48 B per primitive fetched): L2 and MALL serve part of them, so they may exceed the HBM peak — achieved_counters / frac_counters is what left L2",
                         "kernel_GBps": gbps}
             if hybrid:

@@ -143,7 +143,7 @@ def test_bench_size_properties(T, ctx):
         try:
             return T.PathIntegrator(cam, T.SeededSampler(spp, seed=0x5EED0001, sample_offset=offset), 8).render(scene, ctx).copy()
         finally:
-            for k, v in {"traversal": 3, "film_block": 5, "batch_paths": 0, "overlap": 0}.items():
+            for k, v in {"traversal": 3, "film_block": 5, "batch_paths": 0, "overlap": 1}.items():
                 ctx.set_option(k, v)
 
     a = render()

@@ -227,12 +227,12 @@ def test_render_batches_and_sample_offset(T, ob, ctx, shadows):
     finally:
         ctx.set_option("batch_paths", 0)
     assert_bits_equal(a, b, "batched film")
-    for overlap in (0, 1):  # single-stream schedule / shadow rays on a second stream (the default is the single stream)
+    for overlap in (0, 1):  # single-stream schedule / shadow rays on a second stream (the default is the second stream since round 5)
         ctx.set_option("overlap", overlap)
         try:
             c = T.PathIntegrator(cam, T.SeededSampler(4, seed=9), 4).render(scene).copy()
         finally:
-            ctx.set_option("overlap", 0)
+            ctx.set_option("overlap", 1)
         assert_bits_equal(a, c, f"film with overlap = {overlap}")
     ctx.set_option("pipelines", 4)  # four batches in flight on separate stream pairs
     ctx.set_option("batch_paths", 4 * 34 * 34)
@@ -411,7 +411,7 @@ def test_streaming_wavefront_matches_classic_and_oracle(T, ob, ctx, traversal):
             ctx.set_option("streaming", 0)
             ctx.set_option("stream_budget_min", 2048)
             ctx.set_option("stream_list_cap", 0)
-            ctx.set_option("overlap", 0)
+            ctx.set_option("overlap", 1)
 
     classic, classic_L, st0 = render(streaming=0)
     assert_bits_equal(classic, ref, "classic film")

@@ -17,10 +17,10 @@ ap.add_argument("--res", type=int, default=96)
 a = ap.parse_args()
 scene = {"mesh64": lambda: T.scenes.mesh_scene(64), "blob24": lambda: T.scenes.blob_scene(24), "cornell": T.scenes.cornell_scene, "shadows": T.scenes.shadows_scene}[a.workload]()
 cam = T.scenes.shadows_camera(a.res) if a.workload == "shadows" else T.scenes.cornell_camera(a.res)
-SETS = [{}, {"hybrid": 0}, {"wide4": 0}, {"wide4": 0, "overlap": 1}, {"leaf_queue": 1}, {"any_on_accelerator": 1}, {"any_on_accelerator": 0}, {"node_layout": 1}, {"overlap": 1}, {"pipelines": 2}, {"band_tile_rows": 2},
+SETS = [{}, {"hybrid": 0}, {"wide4": 0}, {"wide4": 0, "overlap": 0}, {"leaf_queue": 1}, {"any_on_accelerator": 1}, {"any_on_accelerator": 0}, {"node_layout": 1}, {"overlap": 0}, {"pipelines": 2}, {"band_tile_rows": 2},
         {"traversal": 2}, {"traversal": 6}, {"traversal": 7}, {"traversal": 1}, {"traversal": 4}, {"slab_margin_log2": 0}, {"count_visits": 1}, {"bvh_builder": 2}, {"bvh_builder": 4},
         {"film_block": 6}, {"film_block": 2}, {"film_fused": 0}, {"film_swizzle": 1}, {"occluder_pretest": 0}, {"leaf_kernel": 0}, {"batch_paths": 20000}, {"tiny_scene_prims": 0, "bvh_builder": 2},
-        {"leaf_queue": 1, "count_visits": 1}, {"hybrid": 0, "traversal": 7}, {"overlap": 1, "leaf_queue": 1}]
+        {"leaf_queue": 1, "count_visits": 1}, {"hybrid": 0, "traversal": 7}, {"overlap": 0, "leaf_queue": 1}]
 ref = None
 bad = 0
 for opts in SETS:

@@ -94,9 +94,9 @@ struct trhip_ctx {
     int node_layout = 0;  // children-in-parent nodes: 0 depth-first, 1 the two interior children of a node in one aligned 128-byte line (option "node_layout", read at commit; tu_scene.hip)
     bool film_swizzle = false;  // packed film gather: XCD x owns the x-th contiguous eighth of the workgroups (option "film_swizzle"; measured: no effect, th_kernels.h)
     bool film_tiled = false;  // LDS-staged film gather (k_film_gather_tiled): bit-identical, measured 2.7x SLOWER than k_film_gather (11 % lane use), kept as an option
-    bool overlap = false;  // shadow rays of depth d on a second stream beside the closest-hit rays of depth d+1 (option "overlap").  Off since the two-stage
-                           // any-hit kernels (k_any_occluders, k_any_leaf) halved the shadow rays' cost: 256 spp, on / off: S-cornell 158.2 / 157.9 ms, S-mesh 399 / 393,
-                           // 10 M triangles 485 / 480 (it was worth 5 ms of S-cornell's 172 before)
+    bool overlap = true;   // shadow rays of depth d on a second stream beside the closest-hit rays of depth d+1 (option "overlap").  On again since round 5: with the four-wide
+                           // certified walk no longer saturating VALU issue the shadow kernels fill its gaps and tails — 256 spp, off / on: S-mesh 325.5 / 314.5 ms, S-blob 234.8 / 222.3,
+                           // S-cornell 160.4 / 157.1, 10.5 M triangles 376.4 / 367.7.  (Rounds 2-4 measured it neutral — S-cornell 158.2 / 157.9, S-mesh 399 / 393 — and kept it off.)
     int compose_spheres = -1;  // commit: spheres as a chain of leaves above the triangles' subtree, what k_trace8 needs of a scene with spheres
                                // (option "compose_spheres": 1 / 0 = one SAH tree over everything / -1 = when "traversal" is 4 at commit time)
     int traversal = 3;  // 1 = literal accel/bvh.jl loop, 2 = children-in-parent nodes + per-lane ray replacement, 3 = 2 with leaves postponed (while-while),
