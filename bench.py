@@ -31,13 +31,6 @@ KERNEL_CLASSES = ("raygen", "trace_closest", "shade", "trace_any", "film")
 TRAVERSAL_KERNEL = {1: "k_trace_closest", 2: "k_trace2", 3: "k_trace3", 4: "k_trace8", 5: "k_trace_leaf", 6: "k_trace4", 7: "k_trace7", 9: "k_trace3c"}
 BVH_MODE = {0: "library-sah", 1: "reference", 2: "hybrid", 3: "library-sah + itself four-wide as accelerator"}  # trhip_scene_bvh_mode: which tree(s) the scene holds (include/tracehip.h)
 L2_PLUS_MALL_BYTES = (32 + 256) << 20  # 8 x 4 MiB L2 + 256 MiB Infinity Cache (MI355X_MICROARCH.md): a scene below this is served from cache, not HBM
-def closest_kernel(traversal, opts):
-    """The closest-hit walk a launch runs: hybrid mode (traversal 9) walks the accelerator four-wide (k_trace3c4, th_trace3c4.h) unless option wide4 = 0 (k_trace3c, the binary walk)."""
-    if int(traversal) == 9 and not any(kv.replace(" ", "") == "wide4=0" for kv in opts):
-        return "k_trace3c4"
-    return TRAVERSAL_KERNEL.get(int(traversal), "k_trace")
-
-
 TRAVERSAL_KERNEL_ANY = {1: "k_trace_any", 2: "k_trace2", 3: "k_trace3", 4: "k_trace8", 5: "k_trace_leaf", 6: "k_trace4", 7: "k_trace3"}
 
 
@@ -309,7 +302,7 @@ def run_sppm(args, T, ctx, graft, rank, world, comm_ok):
         dom_bytes = kb["trace_closest"] * (args.steps if world == 1 else 0) / max(1, launches["trace_closest"])
         dom_ms = ms["trace_closest"] / max(1, launches["trace_closest"])
         dom_launches = launches["trace_closest"]
-        kprefix = closest_kernel(sv.traversal, args.opt)
+        kprefix = flat.closest_kernel_name()  # (the library's own launch decision for this scene: a one-leaf accelerator runs k_trace_leaf_c, wide4 = 0 k_trace3c)
         kname = kprefix + "<closest>"
         extra = {}
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
@@ -570,9 +563,8 @@ def main():
             dominant = max((k for k in agg["ms"] if k != "trace_any"), key=lambda k: agg["ms"][k])
             dom_ms = agg["ms"][dominant] / max(1, agg["launches"][dominant])
             dom_bytes = per_step[dominant] * steps / max(1, agg["launches"][dominant])
-            kname = {"trace_closest": closest_kernel(sv.traversal, args.opt), "shade": "k_shade_path", "film": "k_film_gather", "raygen": "k_raygen"}[dominant]
-            if hybrid and dominant == "trace_closest" and flat.bvh_mode()[1] == 1:
-                kname = "k_trace_leaf_c"  # a one-leaf accelerator (S-cornell, the shadows scene): the certified walk is the uniform loop over the canonical slots
+            # (the closest-hit kernel's name comes from the library — launch_trace's own decision for this scene under the current options —, not from the option string)
+            kname = {"trace_closest": flat.closest_kernel_name(), "shade": "k_shade_path", "film": "k_film_gather", "raygen": "k_raygen"}[dominant]
             if hybrid and dominant == "trace_closest":
                 # a hybrid closest-hit launch = the certified walk on the accelerator tree (k_trace3c4 or k_trace3c, the dominant kernel) + the reference-order walk of the rays it hands back
                 # (k_trace3 on the canonical tree); the library times the hand-over inside every launch (trhip_stats.ms_fallback): the roofline is k_trace3c's alone
@@ -649,6 +641,7 @@ def main():
         if world == 1 and not args.no_micro:
             micro = micro_benchmark(args, T, ctx, flat, osc if not args.no_cpu_baseline else None)
         rccl_ranks = ctx.comm_rank()[1]
+        full_frame_equal = None
         if world == 1 and bvh_mode == 2 and not args.no_modes:
             # the same frame on either tree alone, a few steps each: what the hybrid default is measured against
             modes = {}
@@ -666,15 +659,35 @@ def main():
                 dt = time.perf_counter() - t1
                 return {"ms_per_step": round(dt / n * 1e3, 3), "Mray_s": round(rays / dt / 1e6, 2), "closest_ms": round(it.stats.ms_trace_closest, 3), "steps": n}
 
-            ctx.set_option("hybrid", 0)  # every ray on the canonical (reference) tree: the same answers bit for bit
-            modes["reference_tree_alone"] = dict(frame_ms(m_steps), exact=True, note="option hybrid = 0: k_trace3 on the reference's own tree; same film as the hybrid default")
+            def film_witness(reference_film):
+                """The film now on the device against `reference_film`, bit for bit, at the frame's FULL size: (equal, values that differ, 64-bit checksum of the bit patterns)."""
+                a, b = film.view(torch.int32), reference_film.view(torch.int32)
+                differ = int((a != b).sum().item())
+                return differ == 0, differ, int(a.to(torch.int64).sum().item()) & 0xFFFFFFFFFFFFFFFF
+
+            # the hybrid default's own frame (same sampler, same seed: what the timed region rendered), kept on the device as the thing the other two are held against
+            frame_ms(1)
+            hybrid_film = film.clone()
+            hybrid_sum = film_witness(hybrid_film)[2]
+            ctx.set_option("hybrid", 0)  # every ray on the canonical (reference) tree, in the reference's order (accel/bvh.jl:212-258): the frame the default claims to reproduce
+            m = frame_ms(m_steps)
+            eq, differ, csum = film_witness(hybrid_film)
+            modes["reference_tree_alone"] = dict(m, exact=eq, film_values_that_differ_from_hybrid=differ, film_checksum=f"{csum:#018x}",
+                                                 note="option hybrid = 0: k_trace3 on the reference's own tree; `exact` is MEASURED in this run: its film against the hybrid default's, "
+                                                      f"all {h}x{w}x4 Float32 bit patterns on the device")
+            full_frame_equal = eq
             ctx.set_option("hybrid", 1)
             ctx.set_option("bvh_builder", 0)
             scene._flat = None
             flat.free()
             flat = scene.flatten(ctx)
-            modes["library_tree_alone"] = dict(frame_ms(m_steps), exact=False, note="option bvh_builder = 0: the library's SAH tree alone — fastest, but rays whose answer depends on the "
-                                                                                      "visiting order (ties, a sphere entered from inside) resolve in ITS order, not Trace.jl's")
+            m = frame_ms(m_steps)
+            eq, differ, csum = film_witness(hybrid_film)
+            modes["library_tree_alone"] = dict(m, exact=eq, film_values_that_differ_from_hybrid=differ, film_checksum=f"{csum:#018x}",
+                                               note="option bvh_builder = 0: the library's SAH tree alone — rays whose answer depends on the visiting order (ties, a sphere entered "
+                                                    "from inside) resolve in ITS order, not Trace.jl's; `exact` is measured the same way")
+            modes["hybrid_film_checksum"] = f"{hybrid_sum:#018x}"
+            del hybrid_film
             ctx.set_option("bvh_builder", -1)
         if roofline and want_counters:
             # the PMC child runs render the same workload in their own process: this one's wavefront buffers are sized to what was free (0.85 of HBM for a
@@ -730,6 +743,9 @@ def main():
                        "bits": {True: "equal", False: "differ", None: "not checked in this run"}[(micro or {}).get("gpu_equals_cpu_on_subset")],
                        "tolerance": "0 ulp (the tests demand bit equality; SURVEY 8(d)'s 1e-3 radiance tolerance is not used)",
                        "checked_in_this_run": (micro or {}).get("gpu_equals_cpu_on_subset"),
+                       # the headline frame at its own size: the hybrid default's film == the film of every ray walking the reference's tree in the reference's order (bvh_modes;
+                       # None: not compared in this run — more than one rank, --no-modes, or a scene without two trees)
+                       "full_frame_equal": full_frame_equal,
                        "where": "tests/test_gpu_hybrid.py, tests/test_gpu_scale.py, tools/soak_hybrid.py (-m gpu); traversal_micro compares 2^21 rays in this run",
                        "witness": "the oracle is a restatement pinned to the reference's unit-test vectors per callee (ray / shape / BSDF / film / BVH construction); the PathIntegrator composite "
                                   "does not exist in the reference (SURVEY F2: defined here as the SPPM camera-pass loop) and has no reference-produced output to compare with — the only "

@@ -133,6 +133,10 @@ int trhip_scene_set_bvh(trhip_scene* scene, const float* node_bounds, const uint
  * trhip_scene_get_accelerator: the accelerator in the layout of trhip_scene_get_bvh (prim_order[accelerator slot] = caller primitive index); size it with
  *   trhip_scene_bvh_mode.  Any output pointer may be NULL. */
 int trhip_scene_bvh_mode(const trhip_scene* scene, int* mode, uint32_t* accel_nodes, uint32_t* accel_depth);
+/* The name of the kernel a closest-hit launch on this scene runs under the context's current options ("k_trace3c4": the certified walk on the accelerator four children wide,
+ * "k_trace3c": the same on the binary accelerator — wide4 = 0, or an accelerator whose four-wide form does not fit the stack —, "k_trace_leaf_c": a one-leaf accelerator, "k_trace3",
+ * "k_trace_leaf", …): for profile filters and rooflines, which must name the kernel that ran. */
+int trhip_closest_kernel_name(const trhip_ctx* ctx, const trhip_scene* scene, char* buf, size_t n);
 /* Why a scene committed with default options holds ONE tree (mode 0 or 1) instead of two: a NUL-terminated sentence copied into buf (at most n bytes; "" for mode 2 and for
  * explicit builders).  E.g. "the reference's construction: BVH depth 71 exceeds the 64-entry traversal stack (bvh.jl:222 throws a BoundsError there)" -> the library's tree alone. */
 int trhip_scene_bvh_note(const trhip_scene* scene, char* buf, size_t n);
@@ -230,7 +234,8 @@ int trhip_render_sppm(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sens
  * set_image!, save): after every iteration k < n_iterations that write_frequency divides, `write` receives the image of the first k iterations (in out_xyzw, which the
  * call owns until it returns: film_h * film_w * 4) and returns 0 to go on; the last iteration's image is the call's result, as above.  The batches of iterations that
  * share traversal launches end at those iterations, so write_frequency = 1 (the reference's default) runs one iteration per batch — about 3x the time of a call without
- * a callback.  write == NULL or write_frequency == 0: trhip_render_sppm. */
+ * a callback.  write == NULL or write_frequency == 0: trhip_render_sppm.  In a multi-GPU job every rank's callback runs (each holds the whole image after the iteration's
+ * all-reduce; hosts let rank 0 write) and the return codes are max-reduced over the ranks before anyone acts on them: a failure on one rank ends the call on all. */
 typedef int (*trhip_sppm_write_fn)(void* user, uint32_t iteration, const float* xyzw);
 int trhip_render_sppm_ex(trhip_ctx* ctx, const trhip_scene* scene, const trhip_sensor* sensor, float initial_search_radius, int max_depth, uint32_t n_iterations,
                          int64_t photons_per_iteration, uint64_t seed, float* out_xyzw, trhip_stats* stats, uint32_t write_frequency, trhip_sppm_write_fn write, void* user);
@@ -260,7 +265,8 @@ int trhip_trace_any_device(trhip_ctx* ctx, const trhip_scene* scene, const void*
 
 /* Visit counters of the last *_device trace call when "count_visits" is on: nodes, prims (closest) then nodes, prims (any-hit). */
 int trhip_last_visit_counts(trhip_ctx* ctx, uint64_t* out4);
-/* Of the last closest-hit trace call (trhip_trace_closest, trhip_hit_geometry, *_device): rays traced, and how many of them the hybrid mode's certified walk handed to the
+/* Of the last trace call of the kernel-level entry points — closest-hit OR any-hit: every one of them zeroes the counters first, an any-hit call leaves 0 handed back —
+ * (trhip_trace_closest, trhip_trace_any, trhip_hit_geometry, *_device): rays traced, and how many of them the hybrid mode's certified walk handed to the
  * reference-order walk on the canonical tree (0 when the scene holds one tree).  The frame entry points report the same through trhip_stats.fallback_rays. */
 int trhip_last_fallback_counts(trhip_ctx* ctx, uint64_t* out2);
 
@@ -359,6 +365,10 @@ int trhip_film_allreduce(trhip_ctx* ctx, void* d_xyzw, uint64_t n_pixels);
  *     way); this option forces bands of N tile rows (tests; 0 = automatic).  trhip_last_sample_radiance needs a one-band frame.
  * "debug_trace_budget": DIAGNOSTIC ONLY, traversal abandons rays after this many node fetches (results wrong). */
 int trhip_set_option(trhip_ctx* ctx, const char* name, int64_t value);
+/* Whether this BUILD of the library carries the kernel families behind `name = value` (traversal 4 / 6 / 7, leaf_queue, leaf_sorted,
+ * bvh_builder 1 exist only in the EXPERIMENTS build, -DTRHIP_EXPERIMENTS): 1 yes, 0 no (trhip_set_option would return
+ * TRHIP_ERR_UNSUPPORTED).  A property of the binary: needs no context and no GPU — test suites decide at COLLECTION which variants exist. */
+int trhip_option_in_build(const char* name, int64_t value);
 
 /* The deterministic elementary functions of trace_detmath.h for hosts that cannot include a C header
  * (fn: 0 sin, 1 cos, 2 tan, 3 atan2(y, x), 4 acos, 5 log, 6 / 7 the sin / cos part of tm_sincosf); y may be NULL unless

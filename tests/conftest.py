@@ -12,6 +12,33 @@ import __graft_entry__ as graft  # noqa: E402
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "experiments(option, value): the test (or this parameter of it) drives a kernel family that only the EXPERIMENTS build of the library "
+                            "carries (traversal 4 / 6 / 7, leaf_queue, leaf_sorted, bvh_builder 1); DESELECTED at collection when the loaded binary lacks it")
+
+
+def option_in_build(name, value) -> bool:
+    """trhip_option_in_build: a property of the loaded binary (no context, no GPU)."""
+    graft.build_library()
+    return bool(graft.load_package().lib().trhip_option_in_build(name.encode(), int(value)))
+
+
+def experiments(name, value):
+    """Mark for a test or a pytest.param: exists only in a build that carries `name = value`."""
+    return pytest.mark.experiments(name, value)
+
+
+def pytest_collection_modifyitems(config, items):
+    """Variants the loaded library does not carry are not in the run at all (deselected, reported as such) — decided from the BINARY at collection, not from the text of an
+    exception at run time: a test of the default path that fails with whatever message FAILS.  Run them against the EXPERIMENTS build with
+    TRHIP_LIB=trace.jl_amd/libtracehip_experiments.so python -m pytest tests -m gpu."""
+    keep, drop = [], []
+    for item in items:
+        missing = [m.args for m in item.iter_markers("experiments") if not option_in_build(*m.args)]
+        (drop if missing else keep).append(item)
+    if drop:
+        config.hook.pytest_deselected(items=drop)
+        items[:] = keep
+
 
 
 @pytest.fixture(scope="session")
@@ -35,29 +62,6 @@ def ctx(T):
     return T.default_context()
 
 
-EXPERIMENTS_NOTE = "needs the EXPERIMENTS build"
-
-
 def supported(ctx, name, values):
-    """The values of an option this build of the library honours (tests that sweep kernel variants sweep what exists).  Leaves the option at the last supported value."""
-    return [v for v in values if ctx.has_option(name, v)]
-
-
-@pytest.hookimpl(hookwrapper=True)
-def pytest_runtest_setup(item):
-    outcome = yield
-    _skip_if_experiments_only(outcome)
-
-
-@pytest.hookimpl(hookwrapper=True)
-def pytest_runtest_call(item):
-    outcome = yield
-    _skip_if_experiments_only(outcome)
-
-
-def _skip_if_experiments_only(outcome):
-    """A test (or fixture) that asks for a kernel family the default library does not carry is SKIPPED, not failed: run it against the EXPERIMENTS build
-    (TRHIP_LIB=trace.jl_amd/libtracehip_experiments.so python -m pytest tests -m gpu)."""
-    exc = outcome.excinfo
-    if exc is not None and EXPERIMENTS_NOTE in str(exc[1]):
-        outcome.force_exception(pytest.skip.Exception(str(exc[1])[-160:], _use_item_location=True))
+    """The values of an option this build of the library honours (tests that sweep kernel variants inside one test sweep what exists).  Leaves the options alone."""
+    return [v for v in values if option_in_build(name, v)]

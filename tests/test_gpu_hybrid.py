@@ -14,6 +14,7 @@ import os
 
 import numpy as np
 import pytest
+from conftest import experiments
 
 pytestmark = pytest.mark.gpu
 
@@ -267,8 +268,9 @@ def test_more_than_32_spheres_keep_the_canonical_tree_alone(T, ob, hyb_ctx):
     flat.free()
 
 
-@pytest.mark.parametrize("opts", [{"hybrid": 0}, {"leaf_queue": 1}, {"any_on_accelerator": 1}, {"any_on_accelerator": 0}, {"node_layout": 1}, {"overlap": 0}, {"pipelines": 2},
-                                  {"traversal": 7}, {"traversal": 1}, {"slab_margin_log2": 0}, {"count_visits": 1}, {"leaf_queue": 1, "overlap": 0}],
+@pytest.mark.parametrize("opts", [{"hybrid": 0}, pytest.param({"leaf_queue": 1}, marks=experiments("leaf_queue", 1)), {"any_on_accelerator": 1}, {"any_on_accelerator": 0}, {"node_layout": 1}, {"overlap": 0},
+                                  {"pipelines": 2}, pytest.param({"traversal": 7}, marks=experiments("traversal", 7)), {"traversal": 1}, {"slab_margin_log2": 0}, {"count_visits": 1},
+                                  pytest.param({"leaf_queue": 1, "overlap": 0}, marks=experiments("leaf_queue", 1))],
                          ids=lambda o: ",".join(f"{k}={v}" for k, v in o.items()))
 def test_options_that_change_how_a_frame_is_computed_leave_the_frame_alone(T, opts):
     """A two-tree scene under the switches of the hybrid mode and of the frame loop: film and per-sample radiance bit-equal to the default configuration's

@@ -4,11 +4,13 @@ order, the deterministic elementary functions and the counter-based sampler, and
 """
 import numpy as np
 import pytest
+from conftest import experiments
 
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=[4, 6, 7, 2, 3, 1], ids=["trace8", "trace4x2", "trace7", "trace2", "trace3", "trace1"])
+@pytest.fixture(autouse=True, params=[pytest.param(4, marks=experiments("traversal", 4)), pytest.param(6, marks=experiments("traversal", 6)), pytest.param(7, marks=experiments("traversal", 7)), 2, 3, 1],
+                ids=["trace8", "trace4x2", "trace7", "trace2", "trace3", "trace1"])
 def traversal(request, ctx):
     """Every parity test runs with all traversal kernels: 4 = k_trace8 (8-wide quantised nodes in the binary walk's order; the
     default), 2 = k_trace2 (children-in-parent nodes, per-lane ray replacement), 3 = k_trace3 (the same with leaves postponed
@@ -463,6 +465,7 @@ def test_render_closed_mesh_scene(T, ob, ctx):
     assert_bits_equal(film, ref, "film (S-blob)")
 
 
+@experiments("bvh_builder", 1)
 def test_device_built_lbvh(T, ob, ctx):
     """BVHAccel built on the device (th_lbvh.h, option bvh_builder = 1): a valid BVH2 in the reference's flat layout — every
     primitive in exactly one leaf, first child = i + 1, child boxes inside their parent's, leaf boxes = primitive bounds — and
@@ -527,6 +530,7 @@ def test_film_records_written_by_raygen_equal_the_pack_pass(T, ob, ctx):
         ctx.set_option("batch_paths", 0)
 
 
+@experiments("leaf_sorted", 1)
 def test_one_leaf_scene_sorted_by_candidates(T, ob, ctx):
     """Option leaf_sorted (th_leaf2.h; off by default — measured slower): a one-leaf scene's rays grouped by the primitives they can hit before the leaf is walked.
     Hits, occlusion and a frame must equal the oracle's bit for bit."""

@@ -142,6 +142,8 @@ SIGNATURES = {
     "trhip_bsdf_query": (C.c_int, [_VP, _VP, C.c_uint32, C.c_int, C.c_int, C.c_int, _F, _F, C.c_uint64, _F]),
     "trhip_film_accumulate": (C.c_int, [_VP, C.POINTER(Sensor), C.c_uint32, C.c_uint64, C.c_uint32, _F, _F]),
     "trhip_set_option": (C.c_int, [_VP, C.c_char_p, C.c_int64]),
+    "trhip_option_in_build": (C.c_int, [C.c_char_p, C.c_int64]),
+    "trhip_closest_kernel_name": (C.c_int, [_VP, _VP, C.c_char_p, C.c_size_t]),
     "trhip_comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
     "trhip_comm_init": (C.c_int, [_VP, C.POINTER(C.c_uint8), C.c_int, C.c_int]),
     "trhip_comm_destroy": (C.c_int, [_VP]),

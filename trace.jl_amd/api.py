@@ -623,6 +623,12 @@ class FlatScene:
         self.ctx.check(_ffi.lib().trhip_scene_bvh_note(self._h, buf, 512))
         return buf.value.decode()
 
+    def closest_kernel_name(self) -> str:
+        """The kernel a closest-hit launch on this scene runs under the context's current options (trhip_closest_kernel_name)."""
+        buf = C.create_string_buffer(64)
+        self.ctx.check(_ffi.lib().trhip_closest_kernel_name(self.ctx._h, self._h, buf, 64))
+        return buf.value.decode()
+
     def bvh_mode(self):
         """(mode, accelerator nodes, accelerator depth): mode 0 = the library's tree alone, 1 = the canonical (reference / host) tree alone, 2 = hybrid: the canonical
         tree defines the answers, the library's tree accelerates the rays that carry the order-independence certificate (csrc/th_trace3c.h); 3 = the library's tree is the
@@ -830,13 +836,20 @@ class SPPMIntegrator:  # integrators/sppm.jl:108-130
         film = self.camera.film
 
         def periodic(iteration, xyzw):  # sppm.jl:166-171: set_image!(film, image); save(film)
+            if self._job_rank() != 0:  # in a multi-GPU job every rank holds the whole image after the iteration's all-reduce: rank 0 writes it (as julia/TraceHIP.jl does)
+                return
             film.set_xyzw(xyzw.copy())
             film.splat_xyz[...] = 0
             save(film)
         self.render(scene, on_write=periodic if film.filename and 0 < self.write_frequency < self.n_iterations else None)
-        if film.filename:
+        if film.filename and self._job_rank() == 0:
             return save(film)
         return None
+
+    def _job_rank(self) -> int:
+        """This process's rank in the library's multi-GPU job (0 without a communicator)."""
+        ctx = self._ctx or _ffi.default_context()
+        return ctx.comm_rank()[0]
 
 
 # ---- model_loader.jl:1-11 without Assimp: a minimal PLY reader ---------------------------------------------------------------------

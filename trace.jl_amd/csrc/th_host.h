@@ -132,6 +132,7 @@ struct trhip_ctx {
     DevBuf fdesc;   // film_block 3: one SplatDesc (16 B) per camera sample of the band (th_kernels.h, k_film_descriptors)
     DevBuf poison;  // one byte per camera sample of the band: ShadeStream::poison
     DevBuf cert_cold;  // k_trace3c's CertCold (th_trace3c.h)
+    DevBuf cb_rc;      // one word: a host callback's return code, max-reduced over the ranks of a job (tu_sppm.hip)
     DevBuf ov8[2], fb_list[2], fb_counts[2];  // k_trace8: global stack levels, fallback lists + their counters / work cursors ([closest | any])
     Comm comm;  // multi-GPU job this context belongs to (trhip_comm_init); n_ranks == 1 without one
 };

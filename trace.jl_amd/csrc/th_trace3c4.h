@@ -467,7 +467,7 @@ __global__ __launch_bounds__(kBlock, TH_TRACE3C4_WAVES) void k_trace3c4(DeviceSc
                 if (COUNT) n_why[why & 3u]++;
             } else if (sp > 0) {  // the next stack entry against the limit the leaf left
                 sp--;
-                const float t_pop = t_lim + (AXIS ? __fmaf_rn(growth(), inv_max(), mb) : mb);
+                const float t_pop = t_lim + mb;  // (mb holds the growth term in either form: the step's own t_pop)
                 if (top_tm < t_pop && sp < kStack2Total) {
                     cur = top_enc;
                     s_ex[tid] = top_tm;

@@ -46,6 +46,8 @@ void trhip_shutdown(trhip_ctx* ctx) {
     release(ctx->pfilm);
     release(ctx->fdesc);
     release(ctx->film_side);
+    release(ctx->cert_cold);
+    release(ctx->cb_rc);
     for (auto& pp : ctx->pipes) {
         for (auto& a : pp.q)
             for (auto& b : a) release(b);
@@ -166,6 +168,13 @@ static constexpr bool kExperiments = true;
 static constexpr bool kExperiments = false;
 #endif
 static const char* const kNeedsExperiments = "needs the EXPERIMENTS build of the library (-DTRHIP_EXPERIMENTS): not in the default binary";
+static bool experiments_only(const char* name, int64_t value) {
+    if (!std::strcmp(name, "traversal")) return value == 4 || value == 6 || value == 7;
+    if (!std::strcmp(name, "bvh_builder")) return value == 1;
+    if (!std::strcmp(name, "leaf_sorted") || !std::strcmp(name, "leaf_queue")) return value != 0;
+    return false;
+}
+int trhip_option_in_build(const char* name, int64_t value) { return (name && (kExperiments || !experiments_only(name, value))) ? 1 : 0; }
 int trhip_set_option(trhip_ctx* ctx, const char* name, int64_t value) {
     if (!ctx || !name) return fail(ctx, TRHIP_ERR_INVALID, "null argument");
     if (!std::strcmp(name, "count_visits"))

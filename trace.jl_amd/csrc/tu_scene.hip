@@ -1435,6 +1435,8 @@ int trhip_scene_commit(trhip_scene* s, int max_node_primitives) {
     // rides along as the accelerator most rays walk instead (th_trace3c.h).  Not with the sphere chain (a layout only traversal 4 asks for).
     const bool want_hybrid = (mode == 4 || mode < 0) && !want_chain;
     s->ctx->bvh_device_ms = 0.0;
+    FlatBVH lib_tree;  // a hybrid commit's library tree: the accelerator — or, when the reference's construction fails, the tree the default falls back on (built ONCE)
+    int lib_rc = -1;   // -1: not built
     if (mode == 2 || want_hybrid) {
         // the reference's own construction, node for node (th_bvh_ref.h): also for scenes the library would commit as one leaf, never composed
         bool ok = true;
@@ -1445,8 +1447,6 @@ int trhip_scene_commit(trhip_scene* s, int max_node_primitives) {
             RefBVHBuilder rb(pb, max_node_primitives, (uint32_t)(kStackLds + kStackSpill));  // (gives up at depth 65: bvh.jl:222 could not walk that tree)
             return rb.build();
         });
-        FlatBVH lib_tree;
-        int lib_rc = -1;  // -1: not built
         if (want_hybrid) lib_rc = build_library_tree(s->ctx, pb, max_node_primitives, mode, false, lib_tree);
         try {
             s->bvh = ref_job.get();
@@ -1486,7 +1486,11 @@ int trhip_scene_commit(trhip_scene* s, int max_node_primitives) {
         for (uint32_t id : tri_ids) pb_sub.push_back(pb[id]);
     }
     const std::vector<HostAABB>& pb_build = compose ? pb_sub : pb;
-    if (int rc = build_library_tree(s->ctx, pb_build, max_node_primitives, mode, want_chain, s->bvh)) return rc;
+    if (lib_rc == 0 && !compose && !want_chain) {
+        s->bvh = std::move(lib_tree);  // (the reference's construction failed: the tree built beside it, same arguments, is the one to keep)
+    } else if (int rc = build_library_tree(s->ctx, pb_build, max_node_primitives, mode, want_chain, s->bvh)) {
+        return rc;
+    }
     clk.tick("commit: tree");
     if (compose) {
         // flat layout (bvh.jl:187-206): chain node i at 2 i = interior {leaf of sphere i at 2 i + 1, rest at 2 i + 2}; the triangles' subtree at 2 n_sph

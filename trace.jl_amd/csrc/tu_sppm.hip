@@ -279,7 +279,19 @@ int render_sppm_impl(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
             tm.end(4, st);
             HIP_TRY(ctx, hipStreamSynchronize(st));
             HIP_TRY(ctx, hipMemcpy(out_xyzw, ctx->film.p, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost));
-            if (int rc = write_cb(write_user, it_done, out_xyzw)) return fail(ctx, TRHIP_ERR_INVALID, "the SPPM write callback returned %d at iteration %u", rc, it_done);
+            int rc_cb = write_cb(write_user, it_done, out_xyzw);
+            if (ctx->comm.comm && ctx->comm.n_ranks > 1) {
+                // every rank leaves the loop together, or none does: a rank that returned here alone would leave the others inside the next iteration's all-reduce
+                if (int rc = ensure(ctx, ctx->cb_rc, sizeof(int32_t))) return rc;
+                const int32_t mine = rc_cb != 0 ? 1 : 0;
+                int32_t all = 0;
+                HIP_TRY(ctx, hipMemcpyAsync(ctx->cb_rc.p, &mine, sizeof mine, hipMemcpyHostToDevice, st));
+                NCCL_TRY(ctx, rccl_api()->AllReduce(ctx->cb_rc.p, ctx->cb_rc.p, 1, ncclInt32, ncclMax, ctx->comm.comm, st));
+                HIP_TRY(ctx, hipMemcpyAsync(&all, ctx->cb_rc.p, sizeof all, hipMemcpyDeviceToHost, st));
+                HIP_TRY(ctx, hipStreamSynchronize(st));
+                if (all && !rc_cb) rc_cb = -1;  // (another rank's callback failed)
+            }
+            if (rc_cb) return fail(ctx, TRHIP_ERR_INVALID, "the SPPM write callback returned %d at iteration %u%s", rc_cb, it_done, rc_cb == -1 ? " (on another rank of the job)" : "");
         }
     }
     tm.begin(4, st);

@@ -52,6 +52,11 @@ static bool uses_trace7(const trhip_ctx* ctx, const trhip_scene* sc) { return ct
 static bool uses_trace7(const trhip_ctx*, const trhip_scene*) { return false; }
 #endif
 
+#ifdef TRHIP_EXPERIMENTS
+static constexpr bool kExperimentsBuild = true;
+#else
+static constexpr bool kExperimentsBuild = false;
+#endif
 // which kernel launch_trace picks for this scene, and the bytes one unit of the visit counters stands for (trhip_stats)
 void traversal_info(const trhip_ctx* ctx, const trhip_scene* sc, uint32_t* trav, uint32_t* node_bytes) {
     uint32_t t = 1, nb = 32;
@@ -79,6 +84,23 @@ void traversal_info(const trhip_ctx* ctx, const trhip_scene* sc, uint32_t* trav,
     }
     *trav = t;
     *node_bytes = nb;
+}
+
+// The name of the kernel a closest-hit launch on this scene runs under the context's CURRENT options (launch_trace's own decisions, restated in one place for the
+// measurement side: a profile filter or a roofline must name the kernel that ran, not the one the option string suggests).
+extern "C" __attribute__((visibility("default"))) int trhip_closest_kernel_name(const trhip_ctx* ctx, const trhip_scene* sc, char* buf, size_t n) {
+    if (!ctx || !sc || !buf || !n) return TRHIP_ERR_INVALID;
+    const char* name = "k_trace_closest";
+    if (hybrid_active(ctx, sc)) {
+        name = sc->wide_acc.root_cnt > 0 ? "k_trace_leaf_c" : ((ctx->wide4 && sc->wide_acc.w4nodes && !(kExperimentsBuild && ctx->leaf_queue)) ? "k_trace3c4" : (kExperimentsBuild && ctx->leaf_queue ? "k_trace3d" : "k_trace3c"));
+    } else {
+        uint32_t t = 1, nb = 0;
+        traversal_info(ctx, sc, &t, &nb);
+        static const char* const kNames[] = {"k_trace_closest", "k_trace_closest", "k_trace2", "k_trace3", "k_trace8", "k_trace_leaf", "k_trace4", "k_trace7"};
+        name = kNames[t < 8 ? t : 0];
+    }
+    std::snprintf(buf, n, "%s", name);
+    return 0;
 }
 
 // One traversal launch over a queue (count in HBM at count_ptr, or n_max when count_ptr is null).

@@ -409,14 +409,22 @@ function sppm_write_cb(user::Ptr{Cvoid}, iteration::UInt32, xyzw::Ptr{Float32}):
     Trace.save(c.film)
     Cint(0)
 end
-function render_sppm!(i::Trace.SPPMIntegrator, scene::Trace.Scene; seed::Integer = 0x5EED0001)
+# periodic_images: the reference stores and saves the image after every iteration `write_frequency` divides (sppm.jl:166-171; its default, 1, is EVERY iteration) — faithful, and
+# about 3x the time of a call without them (one iteration per batch of traversal launches + an image copy and a PNG per iteration).  `periodic_images = false` renders the
+# last image only; a default-constructed integrator with periodic images on gets a one-time note.
+const SPPM_NOTED = Ref(false)
+function render_sppm!(i::Trace.SPPMIntegrator, scene::Trace.Scene; seed::Integer = 0x5EED0001, periodic_images::Bool = true)
     film = Trace.get_film(i.camera)
     s = flatten(scene)
     sn = Ref(sensor(i.camera))
     h, w = size(film.pixels)
     out = Vector{Float32}(undef, 4 * h * w)
     stats = TrhipStats()
-    wf = UInt32(max(0, i.write_frequency))
+    wf = periodic_images ? UInt32(clamp(i.write_frequency, 0, typemax(UInt32))) : UInt32(0)
+    if wf == 1 && i.n_iterations > 1 && !SPPM_NOTED[]
+        SPPM_NOTED[] = true
+        @info "TraceHIP: write_frequency = 1 (Trace.jl's default) saves the image after every SPPM iteration: about 3x the time of render_sppm!(…; periodic_images = false)"
+    end
     user = SppmWriteCtx(film, Int(h), Int(w))
     cb = @cfunction(sppm_write_cb, Cint, (Ptr{Cvoid}, UInt32, Ptr{Float32}))
     rc = GC.@preserve user ccall((:trhip_render_sppm_ex, LIB), Cint,
