@@ -12,5 +12,7 @@ name = sys.argv[1]
 out = graft.build_library(extra_flags=sys.argv[2:], out_name=f"libvariant_{name}.so")
 os.makedirs(os.path.join(ROOT, "_diag"), exist_ok=True)
 shutil.move(out, os.path.join(ROOT, "_diag", f"lib_{name}.so"))
+if os.path.exists(out + ".flags"):
+    os.remove(out + ".flags")
 print(os.path.join("_diag", f"lib_{name}.so"))
 shutil.rmtree(os.path.join(ROOT, "trace.jl_amd", "csrc", f"obj_libvariant_{name}_so"), ignore_errors=True)  # (11 MB of objects per variant, and gpurun ships the tree)

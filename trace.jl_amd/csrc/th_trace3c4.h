@@ -34,8 +34,47 @@ namespace th {
 #define TH_TRACE3C4_LEAF_ONE 1
 #endif
 #ifndef TH_TRACE3C4_LDS
-#define TH_TRACE3C4_LDS 13
+#define TH_TRACE3C4_LDS 12  // (13 until the top of the tree moved into LDS, TH_TRACE3C4_TOP below: 36 nodes beside 12 levels beat 18 beside 13)
 #endif
+// 1: the CHEAP step (round 6).  The certificate needs the reference's exact clauses only where a LEAF is decided (th_trace3c.h header: candidates are defined by their canonical
+// leaf's box); which interior boxes a walk passes through, and in which order, is free as long as (a) every box that holds a candidate's leaf is entered and (b) a box is culled
+// only on a lower bound of what it holds.  So the step tests all four children — leaf or interior — with ONE conservative slab test, and the exact clauses move to the moment a
+// primitive test reports a hit (a ray has one or two of those; it has ~49 box tests):
+//   * per ray and axis, c_lo = -(o + em') x (1 / d) and c_hi = -(o - em') x (1 / d): one v_pk_fma_f32 per plane pair gives the slab distances of the box GROWN by em' per axis,
+//     em' = em + 2^-19 (max |o| + D) — em is the margin of the reference-side tight clauses (2^-14 D), the rest covers what the fused form's rounding differs from the
+//     reference's fl(fl(plane - o) x (1 / d)) by (<= 2^-24 (2 |o| + 3 D + 3 em') |1 / d|: a tenth of it);
+//   * enter iff max3(near) <= min3(far), min3(far) >= 0 and max3(near) < t_lim + mb.  Every clause of slab_test3 (bounds.jl:186-198 + the two tight ones) implies these on the
+//     grown box, for the box itself and — the slab distances are monotonic in the planes — for every box inside it; max3(near) is a lower bound of the exact entry distance of
+//     every box inside: (a) and (b) hold;
+//   * a primitive test that reports a hit below the relaxed limit is a CANDIDATE only if slab_test3's clauses pass on its leaf's canonical box: verified on the triangle's OWN
+//     box (from the vertices at hand; the clauses are monotonic in the box in float arithmetic, the leaf box holds the triangle's), whose exact entry distance — an upper
+//     bound of the leaf's — is what the guard (entry <= t + dt) reads; a hit whose own box fails sends the ray to the reference-order walk.  The t-cull of the leaf itself is
+//     left to the guard: a hit below t_lim inside a box whose exact entry is >= t_lim + mb cannot be accepted, it flags the ray.
+// Per step 4 x 15 VALU instructions instead of 4 x 35; 8 % more nodes and 37 % more primitive tests per ray (the em-grown version of round 5 measured those visits).
+#ifndef TH_TRACE3C4_CHEAP
+#define TH_TRACE3C4_CHEAP 0
+#endif
+// The TOP of the tree in LDS (round 6).  What a step pays for its node is not the bytes but the L1's address rate: each lane reads seven 16-byte pieces of its OWN 128-byte
+// line, one tag lookup per lane and instruction — an eighth load from the same line (no new L2 traffic) costs 4.3 % of the kernel (profiles/r6: 64.9 -> 67.7 ms, the step
+// 3 756 -> 3 916 cycles, the leaf rounds 3 460 -> 3 634 as well: they share the L1).  The first TH_TRACE3C4_TOP nodes of the array — the commit numbers the tree breadth-first
+// down to there: the root, its children, their children — are copied into LDS by every block when it starts; a lane whose node is one of them, and a lane that only pops,
+// reads LDS instead (same values, same arithmetic: nothing of the certificate is touched).  LDS is allocated in units of 1 280 bytes: five blocks per CU have 32 000 bytes each
+// (32 308 — 21 nodes beside 13 stack levels — ran four blocks per CU: every phase 10 % faster, the kernel 8 % slower).
+// S-mesh closest-hit per 64 spp (frames without the second stream): none 66.1, 18 nodes + 13 stack levels 64.2, 36 + 12: 63.4, 54 + 11: 63.7, 72 + 10: 63.5 ms; S-blob 47.9 / 47.3 / 47.5 / 46.9 / 47.1.
+#ifndef TH_TRACE3C4_TOP
+#define TH_TRACE3C4_TOP 36
+#endif
+
+// a x b[H] + c, two per instruction (v_pk_fma_f32; IEEE, one rounding each)
+template <int H>
+TH_D v2f pk_fma_h(v2f a, v2f b, v2f c) {
+    v2f r;
+    if (H == 0)
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    else
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 
 template <bool COUNT, bool FULL_ONLY, bool BIG = false, bool AXIS = false>
 __global__ __launch_bounds__(kBlock, TH_TRACE3C4_WAVES) void k_trace3c4(DeviceScene sc /* prims: the accelerator's order */, WideScene ws /* the accelerator */, CertHot ch,
@@ -52,6 +91,11 @@ __global__ __launch_bounds__(kBlock, TH_TRACE3C4_WAVES) void k_trace3c4(DeviceSc
     __shared__ uint32_t s_st[kBlock];
     __shared__ float s_ex[kBlock];
     __shared__ SegView sv;
+#if TH_TRACE3C4_TOP
+    __shared__ float4 s_top[TH_TRACE3C4_TOP * 7];
+    const uint32_t n_top = min((uint32_t)TH_TRACE3C4_TOP, ws.n_w4nodes);
+    for (uint32_t i = threadIdx.x; i < n_top * 7u; i += kBlock) s_top[i] = ws.w4nodes[8u * (i / 7u) + i % 7u];  // (seg_load's barrier publishes it)
+#endif
     seg_load(q, sv);
     const uint32_t tid = threadIdx.x;
     const uint32_t gthreads = gridDim.x * kBlock;
@@ -65,6 +109,12 @@ __global__ __launch_bounds__(kBlock, TH_TRACE3C4_WAVES) void k_trace3c4(DeviceSc
     f3 o = splat3(0.0f), inv_d = splat3(0.0f);
     float em = 0.0f;
     RayShear shear{0, 0.0f, 0.0f, 0.0f};
+#if TH_TRACE3C4_CHEAP
+    v2f cx = v2f{0.0f, 0.0f}, cy = v2f{0.0f, 0.0f}, cz = v2f{0.0f, 0.0f};  // per axis {-(o + em') / d, -(o - em') / d}: the CHEAP step's addends
+#if TH_TRACE3C4_CHEAP == 2
+    float gxz = 0.0f, gyz = 0.0f;  // em x (|1 / d.x| + |1 / d.z|), em x (|1 / d.y| + |1 / d.z|): the tight clause's growth, both sides at once
+#endif
+#endif
     // (the direction signs are read off inv_d where they are needed: a ray with a zero component, the one case where sign(1 / d) is not sign(d), never walks here)
 #define negx (inv_d.x < 0.0f)
 #define negy (inv_d.y < 0.0f)
@@ -222,7 +272,25 @@ __global__ __launch_bounds__(kBlock, TH_TRACE3C4_WAVES) void k_trace3c4(DeviceSc
                         // what the certificate does not cover goes to the reference-order walk at once: a zero or non-finite direction component (0 x Inf = NaN in the slab
                         // products), a non-finite origin or margin, a NaN t_max — and near-axis-parallel rays, whose scalar margin would make the walk overshoot every hit
                         // (kCertCap; with AXIS the margin is per axis: no cap)
-                        const bool plain = d.x != 0.0f && d.y != 0.0f && d.z != 0.0f && mb < kInf && fabsf(o.x) < kInf && fabsf(o.y) < kInf && fabsf(o.z) < kInf && fabsf(inv_d.x) < kInf &&
+#if TH_TRACE3C4_CHEAP
+                        // the CHEAP step's per-ray addends (header); reach = what a plane x (1 / d) product can be: kept far from overflow (Inf - Inf = NaN would close every box)
+                        const float o_max = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z));
+                        const float reach = o_max + em * uniform_load(&cold->inv_tight, 0);
+#if TH_TRACE3C4_CHEAP == 2
+                        const float emc = 1.9073486328125e-6f * reach;  // (the fused form's rounding slack alone: the tight clause's own growth is applied where that clause is)
+                        gxz = em * fabsf(inv_d.x) + em * fabsf(inv_d.z);
+                        gyz = em * fabsf(inv_d.y) + em * fabsf(inv_d.z);
+#else
+                        const float emc = __fmaf_rn(1.9073486328125e-6f, reach, em);
+#endif
+                        cx = v2f{-(o.x + emc) * inv_d.x, -(o.x - emc) * inv_d.x};
+                        cy = v2f{-(o.y + emc) * inv_d.y, -(o.y - emc) * inv_d.y};
+                        cz = v2f{-(o.z + emc) * inv_d.z, -(o.z - emc) * inv_d.z};
+                        const bool cheap_ok = reach * inv_max() < 1e36f;
+#else
+                        const bool cheap_ok = true;
+#endif
+                        const bool plain = cheap_ok && d.x != 0.0f && d.y != 0.0f && d.z != 0.0f && mb < kInf && fabsf(o.x) < kInf && fabsf(o.y) < kInf && fabsf(o.z) < kInf && fabsf(inv_d.x) < kInf &&
                                            fabsf(inv_d.y) < kInf && fabsf(inv_d.z) < kInf && t_own == t_own && (AXIS || mb - mkz_ <= kCertCap * mkz_ + dt);
                         float tmin = 0.0f;
                         if (!plain) {
@@ -299,8 +367,27 @@ __global__ __launch_bounds__(kBlock, TH_TRACE3C4_WAVES) void k_trace3c4(DeviceSc
             if (stepping || (active && cur == kRefNone)) {
                 // interior: one 128-byte line, four child boxes.  Every lane of the section loads — a lane that only pops reads the root's line (always cached) and ignores it: loads under
                 // `if (stepping)` into zero-initialised registers cost 28 v_mov per step (the compiler keeps the zeros alive across the stack-top read between the loads and their use)
+#if TH_TRACE3C4_TOP
+                // a node of the top of the tree, and the placeholder of a lane that only pops, from LDS (header "TOP"); both sides of the branch define all seven values
+                float4 a0, a1, a2, a3, a4, a5, a6;
+                const uint32_t ncur = stepping ? cur : 0u;
+                if (ncur < n_top) {
+                    const float4* tp = s_top + 7u * ncur;
+                    a0 = tp[0], a1 = tp[1], a2 = tp[2], a3 = tp[3], a4 = tp[4], a5 = tp[5], a6 = tp[6];
+                } else {
+                    const float4* np = ws.w4nodes + 8 * (size_t)ncur;
+                    a0 = np[0], a1 = np[1], a2 = np[2], a3 = np[3], a4 = np[4], a5 = np[5], a6 = np[6];
+                }
+#else
                 const float4* np = ws.w4nodes + 8 * (size_t)(stepping ? cur : 0u);
                 const float4 a0 = np[0], a1 = np[1], a2 = np[2], a3 = np[3], a4 = np[4], a5 = np[5], a6 = np[6];
+#endif
+#ifdef TH_TRACE3C4_DUMMY_LOAD  // DIAGNOSTIC: an eighth 16-byte load from the same line (no new L2 traffic): does the step pay for the L1's address rate?
+                {
+                    const float4 a7 = np[7];
+                    asm volatile("" ::"v"(a7.x), "v"(a7.y), "v"(a7.z), "v"(a7.w));
+                }
+#endif
                 uint32_t top_enc = kRefNone;
                 float top_tm = kInf;
                 if (sp > 0) {
@@ -321,6 +408,31 @@ __global__ __launch_bounds__(kBlock, TH_TRACE3C4_WAVES) void k_trace3c4(DeviceSc
                 if (stepping) {
                     if (COUNT) nn += 4;
                     const float t_push = t_lim + mkz;  // (AXIS: the per-axis form of the bound, against the entry distance of the box grown by growth — launches whose rays start far outside the scene)
+#if TH_TRACE3C4_CHEAP
+                    const float grow = AXIS ? growth() : 0.0f;
+                    const float ax_x = grow * fabsf(inv_d.x), ax_y = grow * fabsf(inv_d.y), ax_z = grow * fabsf(inv_d.z);
+                    const v2f i_xy = v2f{inv_d.x, inv_d.y}, i_z = v2f{inv_d.z, inv_d.z};
+                    // one child, leaf or interior: the slab distances of its box grown by em' (one fused instruction per plane pair), the standard overlap test; the sort key is a lower
+                    // bound of the exact entry distance of everything inside (header "CHEAP").  An empty slot's NaN planes fail every comparison.
+                    auto child = [&](v2f X, v2f Y, v2f Z) {
+                        const v2f Tx = pk_fma_h<0>(X, i_xy, cx), Ty = pk_fma_h<1>(Y, i_xy, cy), Tz = pk_fma_h<0>(Z, i_z, cz);
+                        const float nx = amin(Tx.x, Tx.y), fx = amax(Tx.x, Tx.y), ny = amin(Ty.x, Ty.y), fy = amax(Ty.x, Ty.y), nz = amin(Tz.x, Tz.y), fz = amax(Tz.x, Tz.y);
+#if TH_TRACE3C4_CHEAP == 2
+                        // the reference's clauses FOLDED (x-y entry <= every exit: bounds.jl:188 and the first half of :194) on the box grown by the rounding slack, the tight
+                        // clause (z entry <= the earlier x-y exit, grown by em on both sides) in place of :194's loose half, z exit > 0 and the grown x-y exit >= 0 in place of :198:
+                        // each is implied by slab_test3 passing on the box or on any box inside it; visits as the exact clauses' (the lateral growth of CHEAP = 1 cost + 12 % boxes and
+                        // + 58 % primitive tests on S-mesh, + 41 % / + 183 % on S-blob: profiles/r6)
+                        const float A = amax(nx, ny), t_out = amin3(fx, fy, fz), t_in = amax(A, nz);
+                        const float Bp = amin(fx + gxz, fy + gyz);
+                        bool enter = (A <= t_out) && (nz <= Bp) && (fz > 0.0f) && (Bp >= 0.0f) && (t_in < t_pop);
+#else
+                        const float t_in = amax3(nx, ny, nz), t_out = amin3(fx, fy, fz);
+                        bool enter = (t_in <= t_out) && (t_out >= 0.0f) && (t_in < t_pop);
+#endif
+                        if constexpr (AXIS) enter = enter && (amax3(nx - ax_x, ny - ax_y, nz - ax_z) < t_push);
+                        return enter ? t_in : kInf;
+                    };
+#else
                     const v2f p_a = v2f{o.x, o.y}, p_b = v2f{o.z, inv_d.x}, p_c = v2f{inv_d.y, inv_d.z};
                     const float gx = em * fabsf(inv_d.x), gy = em * fabsf(inv_d.y), gz = em * fabsf(inv_d.z);
                     const float grow = AXIS ? growth() : 0.0f;
@@ -344,6 +456,7 @@ __global__ __launch_bounds__(kBlock, TH_TRACE3C4_WAVES) void k_trace3c4(DeviceSc
                         if constexpr (AXIS) enter = enter && (amax3(nx - ax_x, ny - ax_y, nz - ax_z) < t_push);
                         return enter ? t_in : kInf;
                     };
+#endif
                     float k0 = child(v2f{a0.x, a0.y}, v2f{a0.z, a0.w}, v2f{a1.x, a1.y});
                     float k1 = child(v2f{a1.z, a1.w}, v2f{a2.x, a2.y}, v2f{a2.z, a2.w});
                     float k2 = child(v2f{a3.x, a3.y}, v2f{a3.z, a3.w}, v2f{a4.x, a4.y});
@@ -391,7 +504,11 @@ __global__ __launch_bounds__(kBlock, TH_TRACE3C4_WAVES) void k_trace3c4(DeviceSc
                         ex_new = top_tm;
                     }
                 }
+#if !TH_TRACE3C4_CHEAP
                 s_ex[tid] = ex_new;
+#else
+                (void)ex_new;
+#endif
             }
 #ifdef TH_DIAG_PHASES
             ph_cyc[2] += __builtin_readcyclecounter() - ph_t_node;
@@ -444,10 +561,34 @@ __global__ __launch_bounds__(kBlock, TH_TRACE3C4_WAVES) void k_trace3c4(DeviceSc
                         const bool second = (ow & 4u) != 0u;  // the primitive sits in the second child there (axis 3: in the sphere's own leaf, behind it)
                         counts = ax == 3u ? second : (second != (ax == 0u ? negx : (ax == 1u ? negy : negz)));  // bvh.jl:239-246: the second child is visited first iff d[axis] < 0
                     }
+#if TH_TRACE3C4_CHEAP
+                    // the step let this leaf in on the conservative test: the hit is a candidate only if the reference's clauses pass on its leaf's canonical box (header
+                    // "CHEAP").  They are evaluated on the TRIANGLE's own box, from the vertices at hand — no load: the leaf box holds it, and every clause of slab_test3 is
+                    // monotonic in the box IN FLOAT ARITHMETIC (fl(fl(plane - o) x (1 / d)) is a monotonic function of the plane; so are fl(far + g) and fl(near - g)): passing
+                    // on the triangle's box implies passing on the leaf's, and the leaf's exact entry distance is <= the triangle box's, which the guard reads.  A hit whose own
+                    // box fails (the ray grazes it within rounding) says nothing about the leaf box: the ray goes to the reference-order walk.
+                    float ex_leaf = 0.0f;
+                    bool unverified = false;
+                    if (counts) {
+                        const v2f bx = v2f{amin3(p0.x, p1.x, p2.x), amax3(p0.x, p1.x, p2.x)}, by = v2f{amin3(p0.y, p1.y, p2.y), amax3(p0.y, p1.y, p2.y)}, bz = v2f{amin3(p0.z, p1.z, p2.z), amax3(p0.z, p1.z, p2.z)};
+                        const v2f p_a = v2f{o.x, o.y}, p_b = v2f{o.z, inv_d.x}, p_c = v2f{inv_d.y, inv_d.z};
+                        const v2f Tx = pk_mul_h<1>(pk_sub_h<0>(bx, p_a), p_b), Ty = pk_mul_h<0>(pk_sub_h<1>(by, p_a), p_c), Tz = pk_mul_h<1>(pk_sub_h<0>(bz, p_b), p_c);
+                        const float nx = amin(Tx.x, Tx.y), fx = amax(Tx.x, Tx.y), ny = amin(Ty.x, Ty.y), fy = amax(Ty.x, Ty.y), nz = amin(Tz.x, Tz.y), fz = amax(Tz.x, Tz.y);
+                        const float a = amax(nx, ny), b = amax(fx, fy);        // bounds.jl:189-190
+                        ex_leaf = amax(a, nz);                                 // :196
+                        const float t_out = amin(fz, b);                       // :197
+                        const bool ref = !(nx > fy) && !(ny > fx) && !(a > fz) && !(nz > b) && (t_out > 0.0f);  // :188, :194, :198
+                        const float exit_xy = amin(fx + em * fabsf(inv_d.x), fy + em * fabsf(inv_d.y));
+                        unverified = !(ref && !(nz - em * fabsf(inv_d.z) > exit_xy) && !(exit_xy < 0.0f));
+                    }
+#else
+                    const float ex_leaf = s_ex[tid];
+                    const bool unverified = false;
+#endif
                     if (counts) {
                         const float dt = margin_t();
                         // accepted iff it lies 2 dt below the incumbent (t_lim - 4 dt; the ray's own t_max at first) AND its leaf box lets the reference in by t + dt (the guard); a NaN fails
-                        if (!(tt.t <= t_lim - 4.0f * dt) || !(s_ex[tid] <= tt.t + dt)) {
+                        if (unverified || !(tt.t <= t_lim - 4.0f * dt) || !(ex_leaf <= tt.t + dt)) {
                             if (COUNT && !flagged) why = 2u;
                             flagged = true;
                         } else if (!flagged) {
@@ -470,7 +611,9 @@ __global__ __launch_bounds__(kBlock, TH_TRACE3C4_WAVES) void k_trace3c4(DeviceSc
                 const float t_pop = t_lim + mb;  // (mb holds the growth term in either form: the step's own t_pop)
                 if (top_tm < t_pop && sp < kStack2Total) {
                     cur = top_enc;
+#if !TH_TRACE3C4_CHEAP
                     s_ex[tid] = top_tm;
+#endif
                 }
             }
         }

@@ -1095,9 +1095,17 @@ static int upload_accelerator_impl(trhip_scene* s, bool conformed) {
             const float dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2];
             return dx * dy + dx * dz + dy * dz;
         };
-        while (ok4 && !todo.empty()) {
-            const Frame f = todo.back();
-            todo.pop_back();
+        // the first nodes breadth-first — the root, its children, theirs: the first 85 indices, of which k_trace3c4 keeps as many as fit in LDS (TH_TRACE3C4_TOP) —, the rest depth-first
+        // (a subtree's nodes near each other)
+        size_t bfs_head = 0;
+        while (ok4 && bfs_head < todo.size()) {
+            Frame f;
+            if (w4.size() / 8 < 85u) {
+                f = todo[bfs_head++];  // (first in, first out while the top is being numbered)
+            } else {
+                f = todo.back();
+                todo.pop_back();
+            }
             uint32_t kids[4];
             int nk = 2;
             kids[0] = f.node + 1;
