@@ -67,3 +67,53 @@ def test_sppm_with_communicator_equals_sppm_without(T, ctx, comm_ctx):
     np.testing.assert_allclose(st_b["phi"], st_a["phi"], rtol=2e-5, atol=2e-5 * np.abs(st_a["phi"]).max())
     np.testing.assert_allclose(st_b["tau"], st_a["tau"], rtol=5e-5, atol=5e-5 * np.abs(st_a["tau"]).max())
     np.testing.assert_allclose(img_b, img_a, rtol=1e-4, atol=1e-4 * np.abs(img_a).max())
+
+
+def test_torch_nccl_group_and_library_communicator_coexist(T):
+    """What `bench.py --gpus N` does in every rank, on the one GPU there is: torch.distributed holds an `nccl` process group (torch's own copy of RCCL) while the library
+    dlopens librccl.so.1 for its communicator (th_comm.h) — two RCCL instances in one process.  The frame is rendered with the second (low-priority) stream live
+    (option overlap = 1: shadow rays beside the next depth's closest-hit rays), then summed by trhip_film_reduce inside the library, then all-reduced by torch's group:
+    neither may disturb the other, the film must come through bit for bit."""
+    import os
+    import subprocess
+    import sys
+    import textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import os, sys
+        import numpy as np
+        sys.path.insert(0, %r)
+        import torch
+        import torch.distributed as dist
+        import __graft_entry__ as g
+        T = g.load_package()
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29731", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1)
+        warm = torch.ones(1024, device="cuda")
+        dist.all_reduce(warm)                      # torch's RCCL instance is up and has built its communicator
+        torch.cuda.synchronize()
+        ctx = T.Context(0)
+        ctx.comm_init(T._ffi.comm_unique_id(), 0, 1)  # the library's communicator (its own dlopen'ed RCCL), made exactly as an N-rank job makes it
+        assert ctx.comm_rank() == (0, 1)
+        ctx.set_option("overlap", 1)
+        scene, cam = T.scenes.mesh_scene(96), T.scenes.cornell_camera(128)
+        h, w = cam.film.size
+        film = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+        integ = T.PathIntegrator(cam, T.SeededSampler(8, seed=21), 6)
+        ref = integ.render(scene, ctx).copy()       # host copy of the same frame
+        for _ in range(3):
+            integ.render(scene, ctx, device_out=film.data_ptr())
+            ctx.film_reduce(film.data_ptr(), h * w, 0)      # ncclReduce inside the library, on the library's stream
+            dist.all_reduce(film)                           # … and torch's group right behind it
+            torch.cuda.synchronize()
+            assert np.array_equal(film.cpu().numpy().view(np.uint32), ref.view(np.uint32)), "film changed under the two collectives"
+        assert integ.stats.shadow_rays > 0 and int(integ.stats.traversal) == 9
+        ctx.comm_destroy()
+        dist.barrier()
+        dist.destroy_process_group()
+        print("COEXIST OK", integ.stats.closest_rays, integ.stats.shadow_rays)
+    """) % root
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert res.returncode == 0 and "COEXIST OK" in res.stdout, (res.stdout[-1500:], res.stderr[-3000:])
