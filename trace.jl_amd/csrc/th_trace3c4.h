@@ -258,8 +258,13 @@ __global__ __launch_bounds__(kBlock, TH_TRACE3C4_WAVES) void k_trace3c4(DeviceSc
 #endif
                         o = mk3(o4.x, o4.y, o4.z);
                         const f3 d = mk3(d4.x, d4.y, d4.z);
+#ifdef TH_DIAG_FAST_REFILL  // DIAGNOSTIC (results NOT exact): what a refill without its arithmetic would cost — approximate reciprocals, the margin from the origin's first coordinate alone
+                        inv_d = mk3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+                        em = (fabsf(ws.root_box[3] - o.x) + fabsf(ws.root_box[0] - o.x)) * ws.tight_scale;
+#else
                         inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
                         em = slab_margin(ws.root_box, ws.tight_scale, o);
+#endif
                         shear = TH_TRACE3C4_REFILL_LEAN ? ray_shear(d, inv_d) : ray_shear(d);
                         const float dt = margin_t();
                         const float mkz_ = (shear.kz == 0 ? ch.mle[0] : (shear.kz == 1 ? ch.mle[1] : ch.mle[2])) * fabsf(shear.sz);
