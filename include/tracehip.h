@@ -141,7 +141,9 @@ int trhip_closest_kernel_name(const trhip_ctx* ctx, const trhip_scene* scene, ch
  * explicit builders).  E.g. "the reference's construction: BVH depth 71 exceeds the 64-entry traversal stack (bvh.jl:222 throws a BoundsError there)" -> the library's tree alone. */
 int trhip_scene_bvh_note(const trhip_scene* scene, char* buf, size_t n);
 /* Why a scene that holds both trees is walked WITHOUT its accelerator under the context's current options ("" when it is used, or the scene holds one tree): such frames
- * are exact but walk the reference's tree alone, at about twice the closest-hit time.  The first such frame of a context also says so on stderr. */
+ * are exact but walk the reference's tree alone, at about twice the closest-hit time.  The first such frame of a context also says so on stderr.  Also non-empty when the
+ * accelerator IS used but the last frame that reported statistics handed more than a fifth of its closest-hit rays back to the reference-order walk (trhip_stats.fallback_rays /
+ * closest_rays: scenes of near-ties — tiny coplanar triangles, rays in a primitive's plane): exact, at little gain; that frame says so once on stderr as well. */
 int trhip_accelerator_note(const trhip_ctx* ctx, const trhip_scene* scene, char* buf, size_t n);
 int trhip_scene_get_accelerator(const trhip_scene* scene, float* node_bounds, uint32_t* node_a, uint32_t* node_flags, uint32_t* prim_order);
 

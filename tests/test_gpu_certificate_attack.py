@@ -73,6 +73,10 @@ def test_certified_walk_equals_the_reference_order_walk(family, T, ob, hyb_ctx):
     L = integ.sample_radiance(scene).copy()
     st = integ.stats
     assert int(st.traversal) == 9, f"{family}: the frame did not run the hybrid walk"
+    # the cliff is SAID: a frame that hands more than a fifth of its rays back leaves a note for the caller (trhip_accelerator_note), an ordinary one leaves none
+    share = st.fallback_rays / max(1, st.closest_rays)
+    note = flat.accelerator_note()
+    assert ("reference-order walk" in note) == (share > 0.2), (family, share, note)
     ctx.set_option("hybrid", 0)
     integ0 = T.PathIntegrator(cam, T.SeededSampler(4, seed=21), 8)
     film0 = integ0.render(scene, ctx)

@@ -87,6 +87,8 @@ struct trhip_ctx {
                          // (1024^2, 256 spp: 29.0 ms against 24.3 ms: the 16-byte descriptor doubles the gather's loads and the arithmetic it saves was hidden)
     bool film_relayout = true;  // packed film pass: gather from a pixel-group-major copy of the radiance records (k_film_pack_transpose) instead of the integrators' sample-major order
     bool warned_idle_accelerator = false;  // (tu_path.hip: the one-time stderr note)
+    bool warned_fallback_cliff = false;    // … and the one about a frame whose certified walk handed back more than a fifth of its rays
+    double last_fallback_share = 0.0;      // fallback rays / closest-hit rays of the last frame that reported statistics (trhip_accelerator_note)
     int any_on_accelerator = -1;  // hybrid mode: any-hit rays without a zero direction component walk the library's tree (TraceOut::zero_mode): 1 always, 0 never, -1 where the
                                   // integrator asks for it (TraceOut::any_acc_hint: SPPM).  Option "any_on_accelerator"
     bool wide4 = true;  // hybrid mode: the accelerator is also laid out four children wide and the certified walk runs on that (th_trace3c4.h); option "wide4", read at commit and at launch

@@ -686,7 +686,8 @@ __global__ __launch_bounds__(kBlock, (BIG || (AXIS && TH_TRACE3C_AXIS_LESS)) ? T
 #define TH_TRACE_LEAF_C_WAVES TH_TRACE_LEAF_WAVES
 #endif
 #ifndef TH_LEAF_C_DEFER
-#define TH_LEAF_C_DEFER 1  // 1: the canonical leaf boxes are tested once per ray, for the candidate it ends up holding; 0: for every candidate as it is found (round 4)
+#define TH_LEAF_C_DEFER 2  // 1: the canonical leaf boxes are tested once per ray, for the candidate it ends up holding; 0: for every candidate as it is found (round 4); 2: 1 with the spheres in
+                           // a loop of their own and a branch-free triangle loop (round 6: S-cornell closest-hit 18.9 -> 17.65 ms per 64 spp, 17.5 -> 15.9 without the second stream; 60 VGPRs)
 #endif
 template <bool COUNT, bool FULL_ONLY>
 __global__ __launch_bounds__(kBlock, FULL_ONLY ? TH_TRACE_LEAF_C_WAVES : 4) void k_trace_leaf_c(DeviceScene sc /* canonical records */, WideScene ws /* root box; root_ref / root_cnt = all slots */,
@@ -732,7 +733,76 @@ __global__ __launch_bounds__(kBlock, FULL_ONLY ? TH_TRACE_LEAF_C_WAVES : 4) void
                 live = slab_test2(ws.root_box[0], ws.root_box[1], ws.root_box[2], ws.root_box[3], ws.root_box[4], ws.root_box[5], o, inv_d, 0.0f, false, negx, negy, negz, tmin) && tmin < t_lim;
         }
         bool found = false, sticky = false;
-#if TH_LEAF_C_DEFER
+#if TH_LEAF_C_DEFER == 2
+        // LEAN (round 6): the spheres first, in a loop of their own (the scene's sphere list), then the triangles in a loop whose body is the test and five selects — the generic
+        // candidate record (one path for sphere and triangle candidates) and its lane masks cost 1.44 x k_trace_leaf's instructions per primitive (profiles/r6).  The order in
+        // which candidates are met is free (header: the acceptance rule flags what the order could decide).
+        uint32_t best_slot = 0u;
+        float4 best_r4 = make_float4(kInf, __int_as_float(-1), 0.0f, 0.0f);
+#pragma unroll 1
+        for (uint32_t ks = 0; ks < cs.n_spheres; ++ks) {
+            if (__ballot(live) == 0ull) break;
+            const uint32_t slot = uniform_load(cs.sphere_slots, ks);
+            const float4 p0 = uniform_load(sc.prims, 3 * slot);
+            const SphereRec sr = uniform_load(sc.spheres, __float_as_uint(p0.x));
+            if (live) {
+                if (COUNT) np++;
+                float t_c = 0.0f;
+                const int r = sphere_candidate_c<FULL_ONLY>(sr, o, d, t_lim, t_c);
+                if (r == 2) {
+                    flagged = true;  // a clipped sphere (or a NaN root) on the ray's line: the order decides
+                } else if (r != 0) {
+                    if (sticky || !(t_c <= t_max - 2.0f * dt)) {
+                        flagged = true;
+                    } else {
+                        t_max = t_c;
+                        t_lim = t_c + 2.0f * dt;
+                        found = true;
+                        sticky = r == 3;
+                        best_slot = slot;
+                        best_r4 = make_float4(t_c, __int_as_float((int)slot), 0.0f, 0.0f);
+                    }
+                }
+                if (flagged) live = false;
+            }
+        }
+#pragma unroll 1
+        for (uint32_t k = 0; k < cnt; ++k) {
+            if (__ballot(live) == 0ull) break;
+            const uint32_t slot = first + k;  // wave-uniform: scalar loads
+            const float4 p0 = uniform_load(sc.prims, 3 * slot);
+            const uint32_t meta = __float_as_uint(p0.w);
+            if (meta & (PRIM_SPHERE | PRIM_DEGENERATE)) {  // (uniform)
+                if (COUNT && live && (meta & PRIM_DEGENERATE)) np++;
+                continue;
+            }
+            const float4 p1 = uniform_load(sc.prims, 3 * slot + 1), p2 = uniform_load(sc.prims, 3 * slot + 2);
+            if (COUNT && live) np++;
+            TriTest tt;
+            tt.t = 0.0f;
+            tt.bary = mk3(0.0f, 0.0f, 0.0f);
+            const bool hit = live && tri_intersect_sheared<true>(mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z), o, shear, t_lim, &tt);
+            // accepted iff it lies 2 dt below the incumbent and no sphere the ray started inside of holds the ray; a candidate that is not accepted flags the ray
+            const bool acc = hit && !sticky && (tt.t <= t_max - 2.0f * dt);
+            flagged = flagged || (hit && !acc);
+            live = live && !(hit && !acc);
+            found = found || acc;
+            t_max = acc ? tt.t : t_max;
+            t_lim = acc ? tt.t + 2.0f * dt : t_lim;
+            best_slot = acc ? slot : best_slot;
+            best_r4.x = acc ? (out.bary_mode ? tt.bary.z : tt.t) : best_r4.x;
+            best_r4.y = acc ? __int_as_float((int)slot) : best_r4.y;
+            best_r4.z = acc ? tt.bary.x : best_r4.z;
+            best_r4.w = acc ? tt.bary.y : best_r4.w;
+        }
+        if (valid && found && !flagged) {  // the reference reaches the holder's leaf (bounds.jl:186-198 on its box, t_max aside) and enters it by t + dt (the guard); a sphere entered from inside: its box holds the origin
+            const float* bx = cs.slot_boxes + 6 * (size_t)best_slot;
+            float ex;
+            if (COUNT) nn++;
+            if (!slab_test2(bx[0], bx[1], bx[2], bx[3], bx[4], bx[5], o, inv_d, 0.0f, false, negx, negy, negz, ex) || !(ex <= (sticky ? 0.0f : t_max + dt))) flagged = true;
+        }
+        if (valid && found && !flagged) out.hits[idx] = best_r4;
+#elif TH_LEAF_C_DEFER
         // The leaf boxes are looked at ONCE, for the candidate the ray ends up holding (header "one-leaf accelerator"): a candidate the reference cannot reach (its own test
         // passes, the t_max-free clauses on its leaf's box do not) may ride as the incumbent for a while — whatever it displaced or hid lies farther than what finally holds the
         // ray, or the final check sends the ray to the reference-order walk.

@@ -625,6 +625,14 @@ int render_impl_band(trhip_ctx* ctx, const trhip_scene* scene, const trhip_senso
         stats->n_batches = n_batches;
         stats->max_depth_reached = (uint32_t)max_depth;
         traversal_info(ctx, scene, &stats->traversal, &stats->node_bytes);
+        // The certified walk's cliff: scenes made of near-ties (tiny coplanar triangles, rays in a wall's plane — tests/attack_scenes.py) send up to half of their rays to the
+        // reference-order walk: exact, at about twice the closest-hit time.  Said once per context, and kept for trhip_accelerator_note.
+        ctx->last_fallback_share = stats->closest_rays ? (double)stats->fallback_rays / (double)stats->closest_rays : 0.0;
+        if (stats->traversal == 9 && ctx->last_fallback_share > 0.2 && !ctx->warned_fallback_cliff) {
+            ctx->warned_fallback_cliff = true;
+            std::fprintf(stderr, "[tracehip] the certified walk handed %.0f %% of this frame's closest-hit rays back to the reference-order walk (near-ties, grazed leaf boxes, rays in a "
+                                 "primitive's plane): the frame is exact but the accelerator saves little on this scene\n", 100.0 * ctx->last_fallback_share);
+        }
     }
     hclk.tick("counters + event times");
     (void)hipEventDestroy(e0);

@@ -26,7 +26,11 @@ const char* hybrid_idle_reason(const trhip_ctx* ctx, const trhip_scene* sc) {
 }
 extern "C" __attribute__((visibility("default"))) int trhip_accelerator_note(const trhip_ctx* ctx, const trhip_scene* sc, char* buf, size_t n) {
     if (!ctx || !sc || !buf || !n) return TRHIP_ERR_INVALID;
-    std::snprintf(buf, n, "%s", hybrid_idle_reason(ctx, sc));
+    const char* why = hybrid_idle_reason(ctx, sc);
+    if (!why[0] && hybrid_active(ctx, sc) && ctx->last_fallback_share > 0.2)
+        std::snprintf(buf, n, "the certified walk handed %.0f %% of the last frame's closest-hit rays back to the reference-order walk (near-ties, grazed leaf boxes): exact, but the accelerator saves little", 100.0 * ctx->last_fallback_share);
+    else
+        std::snprintf(buf, n, "%s", why);
     return 0;
 }
 
