@@ -36,21 +36,23 @@ namespace th {
 #ifndef TH_TRACE3C4_LDS
 #define TH_TRACE3C4_LDS 12  // (13 until the top of the tree moved into LDS, TH_TRACE3C4_TOP below: 36 nodes beside 12 levels beat 18 beside 13)
 #endif
-// 1: the CHEAP step (round 6).  The certificate needs the reference's exact clauses only where a LEAF is decided (th_trace3c.h header: candidates are defined by their canonical
-// leaf's box); which interior boxes a walk passes through, and in which order, is free as long as (a) every box that holds a candidate's leaf is entered and (b) a box is culled
-// only on a lower bound of what it holds.  So the step tests all four children — leaf or interior — with ONE conservative slab test, and the exact clauses move to the moment a
-// primitive test reports a hit (a ray has one or two of those; it has ~49 box tests):
-//   * per ray and axis, c_lo = -(o + em') x (1 / d) and c_hi = -(o - em') x (1 / d): one v_pk_fma_f32 per plane pair gives the slab distances of the box GROWN by em' per axis,
-//     em' = em + 2^-19 (max |o| + D) — em is the margin of the reference-side tight clauses (2^-14 D), the rest covers what the fused form's rounding differs from the
-//     reference's fl(fl(plane - o) x (1 / d)) by (<= 2^-24 (2 |o| + 3 D + 3 em') |1 / d|: a tenth of it);
-//   * enter iff max3(near) <= min3(far), min3(far) >= 0 and max3(near) < t_lim + mb.  Every clause of slab_test3 (bounds.jl:186-198 + the two tight ones) implies these on the
-//     grown box, for the box itself and — the slab distances are monotonic in the planes — for every box inside it; max3(near) is a lower bound of the exact entry distance of
-//     every box inside: (a) and (b) hold;
+// CONSERVATIVE steps (round 6; built, exact, SLOWER: compiled out — profiles/r6/r6_trace3c4_experiments.txt).  The certificate needs the reference's exact clauses only where a
+// LEAF is decided (th_trace3c.h header: candidates are defined by their canonical leaf's box); which boxes a walk passes through, and in which order, is free as long as (a) every
+// box that holds a candidate's leaf is entered and (b) a box is culled only on a lower bound of what it holds.  TH_TRACE3C4_CHEAP = 2 tests all four children — leaf or interior —
+// with ONE conservative slab test and moves the exact clauses to the moment a primitive test reports a hit (a ray has one or two of those; it has ~49 box tests):
+//   * per ray and axis, c_lo = -(o + em') x (1 / d) and c_hi = -(o - em') x (1 / d): one v_pk_fma_f32 per plane pair gives the slab distances of the box grown by em' per axis,
+//     em' = 2^-19 (max |o| + D): what the fused form's rounding differs from the reference's fl(fl(plane - o) x (1 / d)) by (<= 2^-24 (2 |o| + 3 D + 3 em') |1 / d|: a tenth of it);
+//   * enter iff the reference's clauses FOLDED pass (x-y entry <= every exit; the tight clause — z entry <= the earlier x-y exit, grown by em on both sides — in place of
+//     bounds.jl:194's loose half; z exit > 0 and the grown x-y exit >= 0 in place of :198) and the entry lies below t_lim + mb.  Every clause of slab_test3 implies these, for the
+//     box itself and — the slab distances are monotonic in the planes — for every box inside it; the entry distance is a lower bound of the exact one of every box inside;
 //   * a primitive test that reports a hit below the relaxed limit is a CANDIDATE only if slab_test3's clauses pass on its leaf's canonical box: verified on the triangle's OWN
 //     box (from the vertices at hand; the clauses are monotonic in the box in float arithmetic, the leaf box holds the triangle's), whose exact entry distance — an upper
 //     bound of the leaf's — is what the guard (entry <= t + dt) reads; a hit whose own box fails sends the ray to the reference-order walk.  The t-cull of the leaf itself is
 //     left to the guard: a hit below t_lim inside a box whose exact entry is >= t_lim + mb cannot be accepted, it flags the ray.
-// Per step 4 x 15 VALU instructions instead of 4 x 35; 8 % more nodes and 37 % more primitive tests per ray (the em-grown version of round 5 measured those visits).
+// TH_TRACE3C4_CHEAP = 3: the same on 64-byte QUANTISED nodes (four loads instead of seven; tu_scene.hip writes them when the library is compiled this way): plane = lo + q x scale,
+// one byte per plane rounded outwards, a power-of-two scale per axis and node; one v_perm_b32 per plane dword orders each byte pair {near, far} for the ray's signs.
+// Measured: 0 film values differ in either form; S-mesh closest-hit + 0.8 % (2) / + 11 % (3), S-blob + 5 % / + 14 %: the step trades VALU issue, L1 requests and primitive tests
+// against each other one for one.  0: the exact clauses per child, shipped.
 #ifndef TH_TRACE3C4_CHEAP
 #define TH_TRACE3C4_CHEAP 0
 #endif
@@ -91,7 +93,11 @@ __global__ __launch_bounds__(kBlock, TH_TRACE3C4_WAVES) void k_trace3c4(DeviceSc
     __shared__ uint32_t s_st[kBlock];
     __shared__ float s_ex[kBlock];
     __shared__ SegView sv;
-#if TH_TRACE3C4_TOP
+#if TH_TRACE3C4_TOP && TH_TRACE3C4_CHEAP == 3
+    __shared__ float4 s_top[TH_TRACE3C4_TOP * 4];  // (64-byte quantised records: four 16-byte pieces each)
+    const uint32_t n_top = min((uint32_t)TH_TRACE3C4_TOP, ws.n_w4nodes);
+    for (uint32_t i = threadIdx.x; i < n_top * 4u; i += kBlock) s_top[i] = ws.w4nodes[i];
+#elif TH_TRACE3C4_TOP
     __shared__ float4 s_top[TH_TRACE3C4_TOP * 7];
     const uint32_t n_top = min((uint32_t)TH_TRACE3C4_TOP, ws.n_w4nodes);
     for (uint32_t i = threadIdx.x; i < n_top * 7u; i += kBlock) s_top[i] = ws.w4nodes[8u * (i / 7u) + i % 7u];  // (seg_load's barrier publishes it)
@@ -111,8 +117,11 @@ __global__ __launch_bounds__(kBlock, TH_TRACE3C4_WAVES) void k_trace3c4(DeviceSc
     RayShear shear{0, 0.0f, 0.0f, 0.0f};
 #if TH_TRACE3C4_CHEAP
     v2f cx = v2f{0.0f, 0.0f}, cy = v2f{0.0f, 0.0f}, cz = v2f{0.0f, 0.0f};  // per axis {-(o + em') / d, -(o - em') / d}: the CHEAP step's addends
-#if TH_TRACE3C4_CHEAP == 2
+#if TH_TRACE3C4_CHEAP >= 2
     float gxz = 0.0f, gyz = 0.0f;  // em x (|1 / d.x| + |1 / d.z|), em x (|1 / d.y| + |1 / d.z|): the tight clause's growth, both sides at once
+#endif
+#if TH_TRACE3C4_CHEAP == 3
+    uint32_t sel_xy = 0x03020100u, sel_zx = 0x03020100u, sel_yz = 0x03020100u;  // v_perm_b32 selectors: a dword's two {low plane, high plane} byte pairs in {near, far} order for this ray's signs
 #endif
 #endif
     // (the direction signs are read off inv_d where they are needed: a ray with a zero component, the one case where sign(1 / d) is not sign(d), never walks here)
@@ -281,16 +290,25 @@ __global__ __launch_bounds__(kBlock, TH_TRACE3C4_WAVES) void k_trace3c4(DeviceSc
                         // the CHEAP step's per-ray addends (header); reach = what a plane x (1 / d) product can be: kept far from overflow (Inf - Inf = NaN would close every box)
                         const float o_max = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z));
                         const float reach = o_max + em * uniform_load(&cold->inv_tight, 0);
-#if TH_TRACE3C4_CHEAP == 2
+#if TH_TRACE3C4_CHEAP >= 2
                         const float emc = 1.9073486328125e-6f * reach;  // (the fused form's rounding slack alone: the tight clause's own growth is applied where that clause is)
                         gxz = em * fabsf(inv_d.x) + em * fabsf(inv_d.z);
                         gyz = em * fabsf(inv_d.y) + em * fabsf(inv_d.z);
 #else
-                        const float emc = __fmaf_rn(1.9073486328125e-6f, reach, em);
+#error "TH_TRACE3C4_CHEAP: 0 (the exact step, shipped), 2 (folded clauses + fused products) or 3 (2 on 64-byte quantised nodes)"
 #endif
                         cx = v2f{-(o.x + emc) * inv_d.x, -(o.x - emc) * inv_d.x};
                         cy = v2f{-(o.y + emc) * inv_d.y, -(o.y - emc) * inv_d.y};
                         cz = v2f{-(o.z + emc) * inv_d.z, -(o.z - emc) * inv_d.z};
+#if TH_TRACE3C4_CHEAP == 3
+                        // QUANTISED nodes: the addends in {near plane, far plane} order (the step brings the plane bytes into that order with one v_perm_b32 per dword: no min / max)
+                        if (negx) cx = v2f{cx.y, cx.x};
+                        if (negy) cy = v2f{cy.y, cy.x};
+                        if (negz) cz = v2f{cz.y, cz.x};
+                        sel_xy = (negx ? 0x0001u : 0x0100u) | (negy ? 0x02030000u : 0x03020000u);
+                        sel_zx = (negz ? 0x0001u : 0x0100u) | (negx ? 0x02030000u : 0x03020000u);
+                        sel_yz = (negy ? 0x0001u : 0x0100u) | (negz ? 0x02030000u : 0x03020000u);
+#endif
                         const bool cheap_ok = reach * inv_max() < 1e36f;
 #else
                         const bool cheap_ok = true;
@@ -372,7 +390,21 @@ __global__ __launch_bounds__(kBlock, TH_TRACE3C4_WAVES) void k_trace3c4(DeviceSc
             if (stepping || (active && cur == kRefNone)) {
                 // interior: one 128-byte line, four child boxes.  Every lane of the section loads — a lane that only pops reads the root's line (always cached) and ignores it: loads under
                 // `if (stepping)` into zero-initialised registers cost 28 v_mov per step (the compiler keeps the zeros alive across the stack-top read between the loads and their use)
+#if TH_TRACE3C4_CHEAP == 3
+                // QUANTISED node: 64 bytes = four loads {lo.xyz, scale.x | 16 plane bytes | 8 plane bytes, scale.yz | four child words} (tu_scene.hip upload_accelerator)
+                float4 a0, a1, a2, a6;
+                const uint32_t ncur = stepping ? cur : 0u;
 #if TH_TRACE3C4_TOP
+                if (ncur < n_top) {
+                    const float4* tp = s_top + 4u * ncur;
+                    a0 = tp[0], a1 = tp[1], a2 = tp[2], a6 = tp[3];
+                } else
+#endif
+                {
+                    const float4* np = ws.w4nodes + 4 * (size_t)ncur;
+                    a0 = np[0], a1 = np[1], a2 = np[2], a6 = np[3];
+                }
+#elif TH_TRACE3C4_TOP
                 // a node of the top of the tree, and the placeholder of a lane that only pops, from LDS (header "TOP"); both sides of the branch define all seven values
                 float4 a0, a1, a2, a3, a4, a5, a6;
                 const uint32_t ncur = stepping ? cur : 0u;
@@ -387,7 +419,7 @@ __global__ __launch_bounds__(kBlock, TH_TRACE3C4_WAVES) void k_trace3c4(DeviceSc
                 const float4* np = ws.w4nodes + 8 * (size_t)(stepping ? cur : 0u);
                 const float4 a0 = np[0], a1 = np[1], a2 = np[2], a3 = np[3], a4 = np[4], a5 = np[5], a6 = np[6];
 #endif
-#ifdef TH_TRACE3C4_DUMMY_LOAD  // DIAGNOSTIC: an eighth 16-byte load from the same line (no new L2 traffic): does the step pay for the L1's address rate?
+#if defined(TH_TRACE3C4_DUMMY_LOAD) && !TH_TRACE3C4_TOP  // DIAGNOSTIC: an eighth 16-byte load from the same line (no new L2 traffic): does the step pay for the L1's address rate?
                 {
                     const float4 a7 = np[7];
                     asm volatile("" ::"v"(a7.x), "v"(a7.y), "v"(a7.z), "v"(a7.w));
@@ -413,6 +445,35 @@ __global__ __launch_bounds__(kBlock, TH_TRACE3C4_WAVES) void k_trace3c4(DeviceSc
                 if (stepping) {
                     if (COUNT) nn += 4;
                     const float t_push = t_lim + mkz;  // (AXIS: the per-axis form of the bound, against the entry distance of the box grown by growth — launches whose rays start far outside the scene)
+#if TH_TRACE3C4_CHEAP == 3
+                    const float grow = AXIS ? growth() : 0.0f;
+                    const float ax_x = grow * fabsf(inv_d.x), ax_y = grow * fabsf(inv_d.y), ax_z = grow * fabsf(inv_d.z);
+                    // plane = lo + q x scale (q: one byte, rounded outwards at commit), so its slab distance is q x (scale / d) + ((lo - o -+ em') / d): per node three products and three
+                    // fused pairs, per plane pair two byte conversions and one fused pair — after one v_perm_b32 per dword has put each byte pair into {near, far} order for this ray
+                    const v2f i_xy = v2f{inv_d.x, inv_d.y}, i_z = v2f{inv_d.z, inv_d.z};
+                    const v2f S_xy = v2f{a0.w * inv_d.x, a2.z * inv_d.y}, S_z = v2f{a2.w * inv_d.z, 0.0f};
+                    const v2f Cx = pk_fma_h<0>(v2f{a0.x, a0.x}, i_xy, cx), Cy = pk_fma_h<1>(v2f{a0.y, a0.y}, i_xy, cy), Cz = pk_fma_h<0>(v2f{a0.z, a0.z}, i_z, cz);
+                    const uint32_t d0 = __builtin_amdgcn_perm(__float_as_uint(a1.x), __float_as_uint(a1.x), sel_xy), d1 = __builtin_amdgcn_perm(__float_as_uint(a1.y), __float_as_uint(a1.y), sel_zx),
+                                   d2 = __builtin_amdgcn_perm(__float_as_uint(a1.z), __float_as_uint(a1.z), sel_yz), d3 = __builtin_amdgcn_perm(__float_as_uint(a1.w), __float_as_uint(a1.w), sel_xy),
+                                   d4 = __builtin_amdgcn_perm(__float_as_uint(a2.x), __float_as_uint(a2.x), sel_zx), d5 = __builtin_amdgcn_perm(__float_as_uint(a2.y), __float_as_uint(a2.y), sel_yz);
+                    auto lo_pair = [](uint32_t dw) { return v2f{(float)(dw & 0xffu), (float)((dw >> 8) & 0xffu)}; };       // v_cvt_f32_ubyte0 / 1
+                    auto hi_pair = [](uint32_t dw) { return v2f{(float)((dw >> 16) & 0xffu), (float)(dw >> 24)}; };          // v_cvt_f32_ubyte2 / 3
+                    // one child, leaf or interior: {near, far} slab distances per axis, the folded clauses of CHEAP = 2 (header); an empty slot (child word kRefNone) is never entered
+                    auto child = [&](v2f qx, v2f qy, v2f qz, uint32_t word) {
+                        const v2f Tx = pk_fma_h<0>(qx, S_xy, Cx), Ty = pk_fma_h<1>(qy, S_xy, Cy), Tz = pk_fma_h<0>(qz, S_z, Cz);
+                        const float nx = Tx.x, fx = Tx.y, ny = Ty.x, fy = Ty.y, nz = Tz.x, fz = Tz.y;
+                        const float A = amax(nx, ny), t_out = amin3(fx, fy, fz), t_in = amax(A, nz);
+                        const float Bp = amin(fx + gxz, fy + gyz);
+                        bool enter = (A <= t_out) && (nz <= Bp) && (fz > 0.0f) && (Bp >= 0.0f) && (t_in < t_pop) && (word != kRefNone);
+                        if constexpr (AXIS) enter = enter && (amax3(nx - ax_x, ny - ax_y, nz - ax_z) < t_push);
+                        return enter ? t_in : kInf;
+                    };
+                    uint32_t e0 = __float_as_uint(a6.x), e1 = __float_as_uint(a6.y), e2 = __float_as_uint(a6.z), e3 = __float_as_uint(a6.w);
+                    float k0 = child(lo_pair(d0), hi_pair(d0), lo_pair(d1), e0);
+                    float k1 = child(hi_pair(d1), lo_pair(d2), hi_pair(d2), e1);
+                    float k2 = child(lo_pair(d3), hi_pair(d3), lo_pair(d4), e2);
+                    float k3 = child(hi_pair(d4), lo_pair(d5), hi_pair(d5), e3);
+#else
 #if TH_TRACE3C4_CHEAP
                     const float grow = AXIS ? growth() : 0.0f;
                     const float ax_x = grow * fabsf(inv_d.x), ax_y = grow * fabsf(inv_d.y), ax_z = grow * fabsf(inv_d.z);
@@ -422,7 +483,7 @@ __global__ __launch_bounds__(kBlock, TH_TRACE3C4_WAVES) void k_trace3c4(DeviceSc
                     auto child = [&](v2f X, v2f Y, v2f Z) {
                         const v2f Tx = pk_fma_h<0>(X, i_xy, cx), Ty = pk_fma_h<1>(Y, i_xy, cy), Tz = pk_fma_h<0>(Z, i_z, cz);
                         const float nx = amin(Tx.x, Tx.y), fx = amax(Tx.x, Tx.y), ny = amin(Ty.x, Ty.y), fy = amax(Ty.x, Ty.y), nz = amin(Tz.x, Tz.y), fz = amax(Tz.x, Tz.y);
-#if TH_TRACE3C4_CHEAP == 2
+#if TH_TRACE3C4_CHEAP >= 2
                         // the reference's clauses FOLDED (x-y entry <= every exit: bounds.jl:188 and the first half of :194) on the box grown by the rounding slack, the tight
                         // clause (z entry <= the earlier x-y exit, grown by em on both sides) in place of :194's loose half, z exit > 0 and the grown x-y exit >= 0 in place of :198:
                         // each is implied by slab_test3 passing on the box or on any box inside it; visits as the exact clauses' (the lateral growth of CHEAP = 1 cost + 12 % boxes and
@@ -430,9 +491,6 @@ __global__ __launch_bounds__(kBlock, TH_TRACE3C4_WAVES) void k_trace3c4(DeviceSc
                         const float A = amax(nx, ny), t_out = amin3(fx, fy, fz), t_in = amax(A, nz);
                         const float Bp = amin(fx + gxz, fy + gyz);
                         bool enter = (A <= t_out) && (nz <= Bp) && (fz > 0.0f) && (Bp >= 0.0f) && (t_in < t_pop);
-#else
-                        const float t_in = amax3(nx, ny, nz), t_out = amin3(fx, fy, fz);
-                        bool enter = (t_in <= t_out) && (t_out >= 0.0f) && (t_in < t_pop);
 #endif
                         if constexpr (AXIS) enter = enter && (amax3(nx - ax_x, ny - ax_y, nz - ax_z) < t_push);
                         return enter ? t_in : kInf;
@@ -467,6 +525,7 @@ __global__ __launch_bounds__(kBlock, TH_TRACE3C4_WAVES) void k_trace3c4(DeviceSc
                     float k2 = child(v2f{a3.x, a3.y}, v2f{a3.z, a3.w}, v2f{a4.x, a4.y});
                     float k3 = child(v2f{a4.z, a4.w}, v2f{a5.x, a5.y}, v2f{a5.z, a5.w});
                     uint32_t e0 = __float_as_uint(a6.x), e1 = __float_as_uint(a6.y), e2 = __float_as_uint(a6.z), e3 = __float_as_uint(a6.w);
+#endif  // TH_TRACE3C4_CHEAP == 3
                     // nearest first (a five-comparator network on {key, child word}); a child that is not entered sorts last
 #define TH_CSWAP(ka, kb, ea, eb)              \
     {                                         \

@@ -1155,11 +1155,76 @@ static int upload_accelerator_impl(trhip_scene* s, bool conformed) {
             std::memcpy(&w4[8 * (size_t)f.out], rec, sizeof rec);
         }
         // the walk pushes up to three entries per level: its 64-entry stack holds a tree of at most 21 four-wide levels (a deeper one keeps the binary walk)
+#if defined(TH_TRACE3C4_CHEAP) && TH_TRACE3C4_CHEAP == 3
+        // EXPERIMENT (th_trace3c4.h CHEAP = 3): the same nodes in 64 bytes — {lo.xyz, scale.x}, 24 plane bytes (child k, axis a: byte 6 k + 2 a the low plane, + 1 the high one) +
+        // {scale.y, scale.z}, four child words (an empty slot: kRefNone) —, plane = lo + q x scale with a power-of-two scale per axis, low planes rounded down, high planes up
+        if (ok4 && 3 * (max_depth4 + 1) <= (uint32_t)kStack2Total) {
+            const size_t nn4 = w4.size() / 8;
+            std::vector<float4> q4(nn4 * 4);
+            for (size_t n = 0; n < nn4 && ok4; ++n) {
+                const float* pl = reinterpret_cast<const float*>(&w4[8 * n]);        // 24 planes: child k at 6 k: x0 x1 y0 y1 z0 z1 (NaN: empty)
+                const uint32_t* wd = reinterpret_cast<const uint32_t*>(&w4[8 * n + 6]);
+                float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+                bool present[4];
+                for (int k = 0; k < 4; ++k) {
+                    present[k] = !(pl[6 * k] != pl[6 * k]);
+                    if (!present[k]) continue;
+                    for (int a = 0; a < 3; ++a) {
+                        lo[a] = std::fmin(lo[a], pl[6 * k + 2 * a]);
+                        hi[a] = std::fmax(hi[a], pl[6 * k + 2 * a + 1]);
+                    }
+                }
+                float scale[3];
+                uint8_t qb[24];
+                std::memset(qb, 0, sizeof qb);
+                for (int a = 0; a < 3; ++a) {
+                    const double ext = (double)hi[a] - (double)lo[a];
+                    int e = ext > 0.0 ? (int)std::ceil(std::log2(ext / 255.0)) : -120;
+                    e = std::max(-120, std::min(120, e));
+                    for (int tries = 0; tries < 4; ++tries) {
+                        const double sc = std::ldexp(1.0, e);
+                        bool fits = true;
+                        for (int k = 0; k < 4 && fits; ++k) {
+                            if (!present[k]) continue;
+                            double ql = std::floor(((double)pl[6 * k + 2 * a] - (double)lo[a]) / sc), qh = std::ceil(((double)pl[6 * k + 2 * a + 1] - (double)lo[a]) / sc);
+                            while (ql > 0.0 && (double)lo[a] + ql * sc > (double)pl[6 * k + 2 * a]) ql -= 1.0;
+                            while ((double)lo[a] + qh * sc < (double)pl[6 * k + 2 * a + 1]) qh += 1.0;
+                            if (ql < 0.0) ql = 0.0;
+                            if (qh > 255.0) {
+                                fits = false;
+                                break;
+                            }
+                            qb[6 * k + 2 * a] = (uint8_t)ql;
+                            qb[6 * k + 2 * a + 1] = (uint8_t)qh;
+                        }
+                        if (fits) break;
+                        ++e;
+                        if (tries == 3) ok4 = false;
+                    }
+                    scale[a] = (float)std::ldexp(1.0, e);
+                }
+                uint32_t dw[6];
+                std::memcpy(dw, qb, sizeof dw);
+                uint32_t words[4];
+                for (int k = 0; k < 4; ++k) words[k] = present[k] ? wd[k] : kRefNone;
+                q4[4 * n] = make_float4(lo[0], lo[1], lo[2], scale[0]);
+                q4[4 * n + 1] = make_float4(__builtin_bit_cast(float, dw[0]), __builtin_bit_cast(float, dw[1]), __builtin_bit_cast(float, dw[2]), __builtin_bit_cast(float, dw[3]));
+                q4[4 * n + 2] = make_float4(__builtin_bit_cast(float, dw[4]), __builtin_bit_cast(float, dw[5]), scale[1], scale[2]);
+                q4[4 * n + 3] = make_float4(__builtin_bit_cast(float, words[0]), __builtin_bit_cast(float, words[1]), __builtin_bit_cast(float, words[2]), __builtin_bit_cast(float, words[3]));
+            }
+            if (ok4) {
+                if (int rc = upload(ctx, s->d_acc_w4nodes, q4.data(), q4.size() * sizeof(float4))) return rc;
+                s->wide_acc.w4nodes = (const float4*)s->d_acc_w4nodes.p;
+                s->wide_acc.n_w4nodes = (uint32_t)nn4;
+            }
+        }
+#else
         if (ok4 && 3 * (max_depth4 + 1) <= (uint32_t)kStack2Total) {
             if (int rc = upload(ctx, s->d_acc_w4nodes, w4.data(), w4.size() * sizeof(float4))) return rc;
             s->wide_acc.w4nodes = (const float4*)s->d_acc_w4nodes.p;
             s->wide_acc.n_w4nodes = (uint32_t)(w4.size() / 8);
         }
+#endif
         clk.tick("accelerator: 4-wide nodes");
     }
     s->wide_acc.root_ref = 0;
