@@ -789,6 +789,7 @@ class SPPMIntegrator:  # integrators/sppm.jl:108-130
         below the last that ``write_frequency`` divides (sppm.jl:166-171); the array is only valid during the call."""
         flat = scene.flatten(ctx)
         ctx = flat.ctx
+        self._ctx = ctx  # (before the call: the periodic-image callback asks it for this process's rank in the job)
         sn = self.camera.sensor()
         st = _ffi.Stats()
         film = self.camera.film
@@ -848,8 +849,7 @@ class SPPMIntegrator:  # integrators/sppm.jl:108-130
 
     def _job_rank(self) -> int:
         """This process's rank in the library's multi-GPU job (0 without a communicator)."""
-        ctx = self._ctx or _ffi.default_context()
-        return ctx.comm_rank()[0]
+        return self._ctx.comm_rank()[0] if self._ctx is not None else 0  # (no render yet on a context: nothing to ask)
 
 
 # ---- model_loader.jl:1-11 without Assimp: a minimal PLY reader ---------------------------------------------------------------------
