@@ -38,3 +38,15 @@ def test_product_does_not_reference_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp", ".jl")):
                 src = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "liboracle" not in src and "oracle_bridge" not in src and "/oracle/" not in src, f"{f} references the oracle"
+
+
+def test_option_in_build_is_a_property_of_the_binary(T):
+    """trhip_option_in_build needs no context and no GPU: what tests/conftest.py decides the collection on.  Options of the default path exist in every build; the kernel
+    families behind traversal 4 / 6 / 7, leaf_queue, leaf_sorted and bvh_builder 1 exist together or not at all (-DTRHIP_EXPERIMENTS)."""
+    lib = T.lib()
+    for name, value in (("traversal", 1), ("traversal", 2), ("traversal", 3), ("leaf_queue", 0), ("leaf_sorted", 0), ("bvh_builder", 0), ("bvh_builder", 2), ("bvh_builder", -1),
+                        ("overlap", 1), ("no_such_option", 5)):
+        assert lib.trhip_option_in_build(name.encode(), value) == 1, (name, value)
+    experiments = [lib.trhip_option_in_build(n.encode(), v) for n, v in (("traversal", 4), ("traversal", 6), ("traversal", 7), ("leaf_queue", 1), ("leaf_sorted", 1), ("bvh_builder", 1))]
+    assert experiments in ([0] * 6, [1] * 6), experiments
+    assert lib.trhip_option_in_build(None, 0) == 0

@@ -336,3 +336,31 @@ def test_a_scene_whose_reference_construction_fails_keeps_the_library_tree(T, hy
     assert np.array_equal(got[3][1], got[1][1])
     scene._flat = None
     flat.free()
+
+
+def test_the_library_names_the_closest_hit_kernel_it_launches(T):
+    """trhip_closest_kernel_name: launch_trace's own decision for the scene under the context's current options — what bench.py's roofline and its PMC filter name.  The
+    frame's statistics (trhip_stats.traversal) must agree with the name."""
+    cases = [({}, T.scenes.mesh_scene(48), "k_trace3c4", 9), ({"wide4": 0}, T.scenes.mesh_scene(48), "k_trace3c", 9), ({}, T.scenes.cornell_scene(), "k_trace_leaf_c", 9),
+             ({"bvh_builder": 0}, T.scenes.mesh_scene(48), "k_trace3", 3), ({"bvh_builder": 0}, T.scenes.cornell_scene(), "k_trace_leaf", 5)]
+    for opts, scene, name, trav in cases:
+        c = T.Context(0)
+        try:
+            for k, v in opts.items():
+                c.set_option(k, v)
+            flat = scene.flatten(c)
+            assert flat.closest_kernel_name() == name, (opts, flat.closest_kernel_name())
+            integ = T.PathIntegrator(T.scenes.cornell_camera(32), T.SeededSampler(2, seed=3), 4)
+            integ.render(scene, c)
+            assert int(integ.stats.traversal) == trav, (opts, integ.stats.traversal)
+            if name.startswith("k_trace3c"):
+                c.set_option("hybrid", 0)  # the same scene, every ray on the canonical tree
+                assert flat.closest_kernel_name() == "k_trace3"
+                c.set_option("hybrid", 1)
+                c.set_option("traversal", 1)  # the literal loop walks the canonical tree
+                assert flat.closest_kernel_name() == "k_trace_closest"
+        finally:
+            if scene._flat is not None:
+                scene._flat.free()
+                scene._flat = None
+            c.close()
