@@ -96,7 +96,7 @@ def pmc_child_runs(args, kernel_prefix: str, want_any: bool, passes):
         cmd = [exe, "--pmc"] + list(counters) + ["--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "1", "--warmup", "0",
                "--workload", args.workload, "--res", str(args.res), "--spp", str(args.spp), "--depth", str(args.depth), "--seed", str(args.seed), "--traversal", str(args.traversal),
                "--iterations", str(args.iterations), "--radius", str(args.radius),
-               "--no-cpu-baseline", "--no-traffic", "--no-micro", "--no-visits"] + [a for kv in args.opt for a in ("--opt", kv)]
+               "--no-cpu-baseline", "--no-traffic", "--no-micro", "--no-visits", "--no-modes"] + [a for kv in args.opt for a in ("--opt", kv)]
         try:
             res = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=900)
             if res.returncode != 0:
@@ -337,6 +337,27 @@ def run_sppm(args, T, ctx, graft, rank, world, comm_ok):
         cpu = {"value": round((r["stats"].closest_rays + r["stats"].shadow_rays) / dt / 1e6, 3), "unit": "Mray/s", "cores": threads, "kind": "port",
                "sample": f"{n_it} of {args.iterations} iterations of the same configuration ({dt:.1f} s)"}
     info = integ.state()["info"]
+    # ---- full-size witness (C4 at its literal size): the same run with every ray on the canonical tree in the reference's order (option hybrid = 0) against the default's.
+    #      M, N, radius, Ld and the visible points are integers / Float32 values that do not depend on the order of the photon atomics: they must be EQUAL; phi / tau / the image
+    #      are Float32 sums of the same terms in an order that differs from run to run (the reference's own are unordered atomics, sppm.jl:398-399): largest relative difference ----
+    witness = None
+    if world == 1 and not args.no_modes and flat.bvh_mode()[0] == 2:
+        import numpy as np
+        img_h = integ.render(scene, ctx).copy()
+        st_h = {k: v.copy() for k, v in integ.state().items() if k != "info"}
+        ctx.set_option("hybrid", 0)
+        try:
+            ref_i = T.SPPMIntegrator(cam, args.radius, args.depth, args.iterations, -1, seed=args.seed)
+            img_r = ref_i.render(scene, ctx)
+            st_r = ref_i.state()
+        finally:
+            ctx.set_option("hybrid", 1)
+        exact = {k: bool(np.array_equal(st_h[k].view(np.uint8), st_r[k].view(np.uint8))) for k in ("M", "N", "radius", "Ld", "vp_p", "vp_beta")}
+        rel = lambda a, b: float(np.max(np.abs(a - b)) / max(1e-30, float(np.max(np.abs(b)))))
+        witness = {"vs": "the same run with option hybrid = 0 (every ray on the reference's tree in the reference's order), at this line's full size",
+                   "equal_bit_for_bit": exact, "all_equal": all(exact.values()),
+                   "largest_relative_difference": {"phi": rel(st_h["phi"], st_r["phi"]), "tau": rel(st_h["tau"], st_r["tau"]), "image": rel(img_h, img_r)},
+                   "tolerance_of_the_tests": {"phi": 2e-5, "tau": 5e-5, "image": 1e-4}}
     result = {"metric": "Mray/s (all bounces)", "value": round(rays / elapsed / 1e6, 2), "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
               "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
               "dtype": "f32 (f64 pixel update)", "data": "synthetic",
@@ -347,7 +368,9 @@ def run_sppm(args, T, ctx, graft, rank, world, comm_ok):
                          "bvh": BVH_MODE.get(flat.bvh_mode()[0], "?"), "fallback_fraction": round(sv.fallback_rays / max(1, sv.closest_rays), 5), "traversal": int(sv.traversal),
                          "parallelism": f"photon indices sharded x{world}, camera pass replicated (its rays counted once), one RCCL all-reduce of phi / M per iteration inside libtracehip" if world > 1 else "single GPU",
                          "rccl_ranks": ctx.comm_rank()[1]},
-              "roofline": roofline, "cpu_baseline": cpu}
+              "roofline": roofline, "cpu_baseline": cpu,
+              "parity": {"full_size_witness": witness,
+                         "where": "tests/test_gpu_sppm.py, tests/test_gpu_baseline_configs.py (C4 at its literal size by properties), tools/soak_sppm.py; the oracle is too slow for 100 iterations at 1024^2"}}
     if untimed:
         result["without_class_timers"] = untimed
     print(json.dumps(result), flush=True)
