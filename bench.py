@@ -665,7 +665,7 @@ def main():
             micro = micro_benchmark(args, T, ctx, flat, osc if not args.no_cpu_baseline else None)
         rccl_ranks = ctx.comm_rank()[1]
         full_frame_equal = None
-        if world == 1 and bvh_mode == 2 and not args.no_modes:
+        if world == 1 and bvh_mode in (2, 3) and not args.no_modes:
             # the same frame on either tree alone, a few steps each: what the hybrid default is measured against
             modes = {}
             m_steps = max(1, min(steps, 3))
@@ -700,15 +700,18 @@ def main():
                                                       f"all {h}x{w}x4 Float32 bit patterns on the device")
             full_frame_equal = eq
             ctx.set_option("hybrid", 1)
-            ctx.set_option("bvh_builder", 0)
-            scene._flat = None
-            flat.free()
-            flat = scene.flatten(ctx)
-            m = frame_ms(m_steps)
-            eq, differ, csum = film_witness(hybrid_film)
-            modes["library_tree_alone"] = dict(m, exact=eq, film_values_that_differ_from_hybrid=differ, film_checksum=f"{csum:#018x}",
-                                               note="option bvh_builder = 0: the library's SAH tree alone — rays whose answer depends on the visiting order (ties, a sphere entered "
-                                                    "from inside) resolve in ITS order, not Trace.jl's; `exact` is measured the same way")
+            if bvh_mode == 2:
+                ctx.set_option("bvh_builder", 0)
+                scene._flat = None
+                flat.free()
+                flat = scene.flatten(ctx)
+                m = frame_ms(m_steps)
+                eq, differ, csum = film_witness(hybrid_film)
+                modes["library_tree_alone"] = dict(m, exact=eq, film_values_that_differ_from_hybrid=differ, film_checksum=f"{csum:#018x}",
+                                                   note="option bvh_builder = 0: the library's SAH tree alone — rays whose answer depends on the visiting order (ties, a sphere entered "
+                                                        "from inside) resolve in ITS order, not Trace.jl's; `exact` is measured the same way")
+            else:  # mode 3: the canonical tree IS the library's (the reference's construction fails on this scene): "reference_tree_alone" above is that tree walked in the reference's order
+                modes["reference_tree_alone"]["note"] += " — on this scene the canonical tree is the library's own (trhip_scene_bvh_note): the comparison is the four-wide certified walk against the reference-ORDER walk of the same tree"
             modes["hybrid_film_checksum"] = f"{hybrid_sum:#018x}"
             del hybrid_film
             ctx.set_option("bvh_builder", -1)
